@@ -1,0 +1,34 @@
+// Common definitions for the inverse-audio-synthesis MI355X (gfx950) kernels.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define IAS_HD __host__ __device__ __forceinline__
+#else
+// Host-only build of the per-sample arithmetic (used by tests/ to check the
+// device math against the oracle without a GPU; never part of the product path).
+#define IAS_HD inline
+#endif
+
+// Error codes returned by every C-ABI entry point.
+#define IAS_OK 0
+#define IAS_ERR_ARG (-1)        // bad pointer / dimension
+#define IAS_ERR_UNSUPPORTED (-2)
+#define IAS_ERR_LAUNCH (-3)     // HIP launch failure (hipGetLastError != success)
+#define IAS_ERR_WORKSPACE (-4)  // workspace too small
+
+#define IAS_NPARAMS 78
+#define IAS_NCTRL 5             // mod-matrix outputs: vco1 pitch, vco1 amp, vco2 pitch, vco2 amp, noise amp
+
+// Per-voice scalars produced by the control-rate kernel, consumed at audio rate.
+struct IasVoiceConst {
+  float f0_1, depth_1, phi_1;   // vco_1: fl(midi_f0 + tuning), mod_depth, initial_phase
+  float f0_2, depth_2, phi_2;   // vco_2
+  float kpart;                  // fl(pi_f32 * partials_constant)
+  float shape;                  // vco_2 shape
+  float shape_gain;             // fl(1 - shape/2)
+  float lvl0, lvl1, lvl2;       // mixer levels: vco_1, vco_2, noise
+  float pad[4];
+};

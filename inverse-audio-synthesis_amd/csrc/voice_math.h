@@ -1,0 +1,191 @@
+// Per-sample arithmetic of the Voice render, shared by the HIP kernels (device)
+// and by a host-only test build (tests/ compile this header with g++ to check
+// the arithmetic against oracle/synth_oracle.py without a GPU).
+//
+// Semantics: the restatement of torchsynth's Voice.output() documented in
+// oracle/synth_oracle.py, math mode "cr": every fp32 elementary operation is
+// correctly rounded (transcendentals are evaluated in fp64 and rounded once),
+// reductions follow the order torch's CPU kernels use (bmm = fma chain in k,
+// 5-element sum = (((a0+a4)+a1)+a2)+a3, linear upsample = fma(w0,a,w1*b)).
+// Reference call sites: /root/reference/vicreg_audio_params.py:86-94,114,
+// /root/reference/audio_to_params.py:215,240-257.
+#pragma once
+#include "ias_common.h"
+
+#define IAS_PI_D 3.141592653589793
+#define IAS_TWO_PI_D 6.283185307179586
+
+// ---- exactly-rounded fp32 primitives (no contraction, no reassociation) ----
+#if defined(__HIP_DEVICE_COMPILE__)
+IAS_HD float ias_mul(float a, float b) { return __fmul_rn(a, b); }
+IAS_HD float ias_add(float a, float b) { return __fadd_rn(a, b); }
+IAS_HD float ias_sub(float a, float b) { return __fsub_rn(a, b); }
+IAS_HD float ias_div(float a, float b) { return __fdiv_rn(a, b); }
+IAS_HD float ias_fma(float a, float b, float c) { return __fmaf_rn(a, b, c); }
+#else
+// host build is compiled with -ffp-contract=off, so plain ops are exact.
+IAS_HD float ias_mul(float a, float b) { return a * b; }
+IAS_HD float ias_add(float a, float b) { return a + b; }
+IAS_HD float ias_sub(float a, float b) { return a - b; }
+IAS_HD float ias_div(float a, float b) { return a / b; }
+IAS_HD float ias_fma(float a, float b, float c) { return fmaf(a, b, c); }
+#endif
+
+// ---- correctly rounded fp32 transcendentals (fp64 evaluate, round once) ----
+IAS_HD float ias_pow_cr(float x, float a) { return (float)pow((double)x, (double)a); }
+IAS_HD float ias_log2_cr(float x) { return (float)log2((double)x); }
+IAS_HD float ias_log10_cr(float x) { return (float)log10((double)x); }
+IAS_HD float ias_cos_cr(float x) { return (float)cos((double)x); }
+IAS_HD float ias_exp2_slow_cr(float x) { return (float)exp2((double)x); }
+
+// 2^t for the audio-rate pitch path.  n = rint(t), f = t - n is exact in fp32;
+// 2^f by a degree-13 Taylor polynomial in fp64 (|f| <= 0.5: truncation < 2e-17
+// relative), scaled by 2^n, rounded once to fp32.
+IAS_HD float ias_exp2_cr(float t) {
+  if (!(t > -160.0f)) return (t != t) ? t : 0.0f;
+  if (t > 130.0f) return INFINITY;
+  const float n = rintf(t);
+  const double z = (double)(t - n) * 0.6931471805599453;
+  double p = 1.6059043836821613e-10;           // 1/13!
+  p = fma(p, z, 2.08767569878681e-09);         // 1/12!
+  p = fma(p, z, 2.505210838544172e-08);        // 1/11!
+  p = fma(p, z, 2.755731922398589e-07);        // 1/10!
+  p = fma(p, z, 2.7557319223985893e-06);       // 1/9!
+  p = fma(p, z, 2.48015873015873e-05);         // 1/8!
+  p = fma(p, z, 0.0001984126984126984);        // 1/7!
+  p = fma(p, z, 0.001388888888888889);         // 1/6!
+  p = fma(p, z, 0.008333333333333333);         // 1/5!
+  p = fma(p, z, 0.041666666666666664);         // 1/4!
+  p = fma(p, z, 0.16666666666666666);          // 1/3!
+  p = fma(p, z, 0.5);
+  p = fma(p, z, 1.0);
+  p = fma(p, z, 1.0);
+  return (float)ldexp(p, (int)n);
+}
+
+// ---- parameter range mapping (torchsynth ModuleParameterRange.from_0to1) ----
+// lo = fl32(minimum); span = fl32(maximum - minimum) (non-symmetric) or
+// fl32((maximum - minimum) / 2) (symmetric), both rounded from the double table.
+IAS_HD float ias_map_param(float u, float lo, float span, float curve, int symmetric) {
+  if (!symmetric) {
+    if (curve != 1.0f) u = ias_exp2_slow_cr(ias_div(ias_log2_cr(u), curve));
+    return ias_add(lo, ias_mul(span, u));
+  }
+  const float dist = ias_sub(ias_mul(2.0f, u), 1.0f);
+  float v = dist;
+  if (curve != 1.0f && dist != 0.0f) {
+    const float mag = ias_exp2_slow_cr(ias_div(ias_log2_cr(fabsf(dist)), curve));
+    v = dist < 0.0f ? -mag : mag;
+  }
+  return ias_add(lo, ias_mul(span, ias_add(v, 1.0f)));
+}
+
+// ---- ADSR (control rate) ----
+// ramp(t) of torchsynth ADSR.ramp: t = control-sample index, durations in seconds.
+IAS_HD float ias_ramp(int t, float duration, float start, int has_start, int inverse,
+                      float alpha, float control_rate, float eps) {
+  const float dur = ias_mul(duration, control_rate);
+  float r = (float)t;
+  if (has_start) r = ias_sub(r, ias_mul(start, control_rate));
+  r = fmaxf(r, 0.0f);
+  r = ias_add(ias_div(ias_add(r, eps), dur), eps);
+  r = fminf(r, 1.0f);
+  if (inverse && dur > 0.0f) r = ias_sub(1.0f, r);
+  return ias_pow_cr(r, alpha);
+}
+
+struct IasAdsr { float attack, decay, sustain, release, alpha; };
+
+IAS_HD float ias_adsr(int t, const IasAdsr& e, float note_on, float control_rate, float eps) {
+  const float new_attack = fminf(e.attack, note_on);
+  const float new_decay = fminf(fmaxf(ias_sub(note_on, e.attack), 0.0f), e.decay);
+  const float a = ias_ramp(t, new_attack, 0.0f, 0, 0, e.alpha, control_rate, eps);
+  const float dr = ias_ramp(t, new_decay, new_attack, 1, 1, e.alpha, control_rate, eps);
+  const float d = ias_add(ias_mul(ias_sub(1.0f, e.sustain), dr), e.sustain);
+  const float r = ias_ramp(t, e.release, note_on, 1, 1, e.alpha, control_rate, eps);
+  return ias_mul(ias_mul(a, d), r);
+}
+
+// ---- LFO (control rate) ----
+IAS_HD float ias_lfo_inc(float freq, float depth, float rate_env, float control_rate) {
+  const float fr = fmaxf(ias_add(freq, ias_mul(depth, rate_env)), 0.0f);
+  return ias_div(ias_mul((float)IAS_TWO_PI_D, fr), control_rate);
+}
+
+// torch.remainder(a, b) for b > 0
+IAS_HD float ias_remainder(float a, float b) {
+  float m = fmodf(a, b);
+  if (m != 0.0f && m < 0.0f) m = ias_add(m, b);
+  return m;
+}
+
+// arg = fl(fl32(cumsum_double(inc)) + phi0); mode[5] already normalised.
+IAS_HD float ias_lfo_shape_mix(float arg, const float* mode) {
+  const float two_pi = (float)IAS_TWO_PI_D;
+  float c = ias_cos_cr(ias_add(arg, (float)IAS_PI_D));
+  float sq = (c > 0.0f) ? 1.0f : ((c < 0.0f) ? -1.0f : 0.0f);
+  c = ias_div(ias_add(c, 1.0f), 2.0f);
+  sq = ias_div(ias_add(sq, 1.0f), 2.0f);
+  const float saw = ias_div(ias_remainder(arg, two_pi), two_pi);
+  const float rsaw = ias_sub(1.0f, saw);
+  float tri = ias_mul(2.0f, saw);
+  if (tri > 1.0f) tri = ias_sub(2.0f, tri);
+  float o = ias_mul(mode[0], c);
+  o = ias_fma(mode[1], tri, o);
+  o = ias_fma(mode[2], saw, o);
+  o = ias_fma(mode[3], rsaw, o);
+  o = ias_fma(mode[4], sq, o);
+  return o;
+}
+
+IAS_HD void ias_lfo_mode(const float* p5, float* mode) {
+  float m[5];
+  for (int k = 0; k < 5; ++k) m[k] = ias_mul(p5[k], p5[k]);  // pow(x, 2) correctly rounded
+  const float s = ias_add(ias_add(ias_add(ias_add(m[0], m[4]), m[1]), m[2]), m[3]);
+  for (int k = 0; k < 5; ++k) mode[k] = ias_div(m[k], s);
+}
+
+// ---- audio rate ----
+// linear upsample with align_corners=True (torch CPU kernel arithmetic)
+IAS_HD void ias_interp_pos(int j, float scale, int Tc, int& i0, int& i1, float& w0, float& w1) {
+  const float real = ias_mul(scale, (float)j);
+  int k = (int)floorf(real);
+  if (k > Tc - 1) k = Tc - 1;
+  i0 = k;
+  i1 = k + (k < Tc - 1 ? 1 : 0);
+  w1 = fminf(fmaxf(ias_sub(real, (float)k), 0.0f), 1.0f);
+  w0 = ias_sub(1.0f, w1);
+}
+IAS_HD float ias_lerp(float a, float b, float w0, float w1) { return ias_fma(w0, a, ias_mul(w1, b)); }
+
+IAS_HD float ias_midi_to_hz(float midi) {
+  return ias_mul(440.0f, ias_exp2_cr(ias_div(ias_sub(midi, 69.0f), 12.0f)));
+}
+
+// phase increment of one VCO sample: fl(fl(2pi*hz)/sr)
+IAS_HD float ias_vco_inc(float f0, float depth, float pitch_mod, float sample_rate) {
+  float c = ias_add(f0, ias_mul(depth, pitch_mod));
+  c = fminf(fmaxf(c, 0.0f), 127.0f);
+  return ias_div(ias_mul((float)IAS_TWO_PI_D, ias_midi_to_hz(c)), sample_rate);
+}
+
+IAS_HD float ias_partials_k(float midi_f0, float depth_2) {
+  const float max_pitch = ias_add(midi_f0, fmaxf(depth_2, 0.0f));
+  const float max_f0 = ias_midi_to_hz(max_pitch);
+  const float partials = ias_div(12000.0f, ias_mul(max_f0, ias_log10_cr(max_f0)));
+  return ias_mul((float)IAS_PI_D, partials);
+}
+
+// unnormalised mixer output for one sample, given both phases (fp32, phi added).
+IAS_HD float ias_mix_sample(float arg1, float arg2, float amp1, float amp2, float ampn,
+                            float noise, const IasVoiceConst& vc) {
+  const float v1 = ias_mul(cosf(arg1), amp1);
+  const float sq = tanhf(ias_mul(ias_mul(vc.kpart, sinf(arg2)), 0.5f));
+  const float v2 = ias_mul(ias_mul(ias_mul(vc.shape_gain, sq),
+                                   ias_add(1.0f, ias_mul(vc.shape, cosf(arg2)))), amp2);
+  const float nz = ias_mul(noise, ampn);
+  float o = ias_mul(vc.lvl0, v1);
+  o = ias_fma(vc.lvl1, v2, o);
+  o = ias_fma(vc.lvl2, nz, o);
+  return o;
+}

@@ -1,0 +1,275 @@
+"""CPU oracle for the Voice render (TEST INFRASTRUCTURE -- never imported by the product).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import this module, and only as the checker / the timed CPU baseline.
+
+What it restates: ``torchsynth.synth.Voice.output()`` as the reference drives it
+(/root/reference/vicreg_audio_params.py:86-94,114; audio_to_params.py:215,240-257;
+pretrain.py:75).  torchsynth itself is NOT on this machine
+(/root/reference/requirements.txt:1, unpinned, un-vendored) and the reference holds
+no test or golden vector at that boundary, so this is a restatement of
+torchsynth 1.0.x's published algorithm written from its documentation:
+**PARITY UNPINNED** for this file.
+
+Numerics.  Every step below is issued as the torch CPU op torchsynth would issue
+(fp32 tensors, ``torch.cumsum`` accumulating in double on CPU, ``nn.Upsample``
+linear/align_corners).  Two math modes:
+
+* ``math="torch"``  transcendental ops (pow/exp2/log2/cos at control rate, exp2 at
+  audio rate) are the fp32 torch CPU ops (SLEEF, <=1 ulp, CPU-ISA dependent).
+* ``math="cr"``     the same ops evaluated in float64 and rounded once to fp32
+  ("correctly rounded" fp32 op).  This is the bit-reproducible definition the HIP
+  kernels implement; the difference between the two modes is the irreducible
+  libm-to-libm spread of the reference itself (quantified in tests and DESIGN.md).
+"""
+import math
+
+import torch
+
+from . import synth_spec as S
+
+TWO_PI = 2 * math.pi
+
+
+class VoiceConfig:
+    def __init__(self, batch_size=128, sample_rate=44100, buffer_size_seconds=4.0,
+                 control_rate=S.CONTROL_RATE, reproducible=False):
+        self.batch_size = int(batch_size)
+        self.sample_rate = int(sample_rate)
+        self.buffer_size_seconds = float(buffer_size_seconds)
+        self.control_rate = int(control_rate)
+        self.reproducible = bool(reproducible)
+        self.buffer_size = int(self.buffer_size_seconds * self.sample_rate)
+        self.control_buffer_size = int(self.buffer_size_seconds * self.control_rate)
+
+
+# --------------------------------------------------------------------------- math
+
+
+class _Math:
+    def __init__(self, mode):
+        assert mode in ("torch", "cr")
+        self.cr = mode == "cr"
+
+    def _u(self, fn, *xs):
+        if self.cr:
+            return fn(*[x.double() for x in xs]).float()
+        return fn(*xs)
+
+    def pow(self, x, a):
+        return self._u(torch.pow, x, a)
+
+    def exp2(self, x):
+        return self._u(torch.exp2, x)
+
+    def log2(self, x):
+        return self._u(torch.log2, x)
+
+    def log10(self, x):
+        return self._u(torch.log10, x)
+
+    def cos(self, x):
+        return self._u(torch.cos, x)
+
+
+# --------------------------------------------------------------------- parameters
+
+
+def from_0to1(u, lo, hi, curve, symmetric, m):
+    """torchsynth ModuleParameterRange.from_0to1 (skewed [0,1] -> [lo,hi])."""
+    if not symmetric:
+        if curve != 1.0:
+            u = m.exp2(m.log2(u) / curve)
+        return lo + (hi - lo) * u
+    dist = 2.0 * u - 1.0
+    if curve != 1.0:
+        u = torch.where(dist == 0.0, dist, m.exp2(m.log2(torch.abs(dist)) / curve) * torch.sign(dist))
+    else:
+        u = dist
+    return lo + (hi - lo) / 2.0 * (u + 1.0)
+
+
+def sample_params01(cfg, batch_idx):
+    """Voice.randomize(seed=batch_idx): [B,78] uniforms in registration order.
+
+    torchsynth draws the values in sub-batches of 32 voices (seed = global
+    sub-batch number) and assigns them to the parameters in *sorted name* order.
+    A batch that is not a multiple of 32 (only possible with reproducible=False)
+    is drawn as one block seeded with batch_idx.
+    """
+    names = [f"{m}.{n}" for (m, n, *_r) in S.PARAMS]
+    order = sorted(range(S.NPARAMS), key=lambda i: names[i])
+    B = cfg.batch_size
+    g = torch.Generator(device="cpu")
+    sub = S.REPRODUCIBLE_SUBBATCH
+    if B % sub == 0:
+        blocks = []
+        for i in range(B // sub):
+            g.manual_seed(int(batch_idx) * (B // sub) + i)
+            blocks.append(torch.rand((sub, S.NPARAMS), generator=g))
+        drawn = torch.cat(blocks, 0)
+    else:
+        g.manual_seed(int(batch_idx))
+        drawn = torch.rand((B, S.NPARAMS), generator=g)
+    out = torch.empty(B, S.NPARAMS)
+    for col, i in enumerate(order):
+        out[:, i] = drawn[:, col]
+    return out
+
+
+def is_train(cfg, batch_idx):
+    B = cfg.batch_size
+    idx = torch.arange(B * int(batch_idx), B * (int(batch_idx) + 1))
+    return (idx // S.REPRODUCIBLE_SUBBATCH) % 10 != 9
+
+
+def make_noise(cfg):
+    """Noise(seed=13): a fixed [B,T] uniform(-1,1) buffer from a CPU MT19937 stream."""
+    g = torch.Generator(device="cpu").manual_seed(S.NOISE_SEED)
+    return torch.rand((cfg.batch_size, cfg.buffer_size), generator=g) * 2.0 - 1.0
+
+
+# ------------------------------------------------------------------ control rate
+
+
+class _P:
+    """Range-mapped parameter lookup p(module, name) -> [B] fp32."""
+
+    def __init__(self, params01, m):
+        self.v = {}
+        for i, (mod, name, lo, hi, curve, sym) in enumerate(S.PARAMS):
+            self.v[(mod, name)] = from_0to1(params01[:, i].float(), lo, hi, curve, sym, m)
+
+    def __call__(self, mod, name):
+        return self.v[(mod, name)]
+
+
+def _ramp(cfg, m, duration, alpha, start=None, inverse=False):
+    dur = (duration * cfg.control_rate).unsqueeze(1)
+    rng = torch.arange(cfg.control_buffer_size, dtype=torch.float32)
+    ramp = rng.expand(duration.shape[0], -1)
+    if start is not None:
+        ramp = ramp - (start * cfg.control_rate).unsqueeze(1)
+    ramp = torch.maximum(ramp, torch.tensor(0.0))
+    ramp = (ramp + S.EPS) / dur + S.EPS
+    ramp = torch.minimum(ramp, torch.tensor(1.0))
+    if inverse:
+        ramp = torch.where(dur > 0.0, 1.0 - ramp, ramp)
+    return m.pow(ramp, alpha)
+
+
+def adsr(cfg, m, p, mod, note_on):
+    attack, decay, sustain = p(mod, "attack"), p(mod, "decay"), p(mod, "sustain")
+    release, alpha = p(mod, "release"), p(mod, "alpha").unsqueeze(1)
+    new_attack = torch.minimum(attack, note_on)
+    new_decay = torch.maximum(note_on - attack, torch.tensor(0.0))
+    new_decay = torch.minimum(new_decay, decay)
+    a = _ramp(cfg, m, new_attack, alpha)
+    sus = sustain.unsqueeze(1)
+    d = (1.0 - sus) * _ramp(cfg, m, new_decay, alpha, start=new_attack, inverse=True) + sus
+    r = _ramp(cfg, m, release, alpha, start=note_on, inverse=True)
+    return a * d * r
+
+
+def lfo(cfg, m, p, mod, rate_env):
+    freq = p(mod, "frequency").unsqueeze(1)
+    freq = torch.maximum(freq + p(mod, "mod_depth").unsqueeze(1) * rate_env, torch.tensor(0.0))
+    arg = torch.cumsum(TWO_PI * freq / cfg.control_rate, dim=1)
+    arg = arg + p(mod, "initial_phase").unsqueeze(1)
+    cos = m.cos(arg + math.pi)
+    square = torch.sign(cos)
+    cos = (cos + 1.0) / 2.0
+    square = (square + 1.0) / 2.0
+    saw = torch.remainder(arg, TWO_PI) / TWO_PI
+    revsaw = 1.0 - saw
+    tri = 2 * saw
+    tri = torch.where(tri > 1.0, 2.0 - tri, tri)
+    shapes = torch.stack([cos, tri, saw, revsaw, square], dim=1)
+    mode = torch.stack([p(mod, s) for s in S.LFO_SHAPES], dim=1)
+    mode = m.pow(mode, torch.tensor(S.LFO_EXPONENT))
+    mode = mode / torch.sum(mode, dim=1, keepdim=True)
+    return torch.matmul(mode.unsqueeze(1), shapes).squeeze(1)
+
+
+def control_signals(cfg, params01, math_mode="torch"):
+    """-> (ctrl [B,5,Tc] fp32 mod-matrix outputs, p) ; order = S.MOD_OUTPUTS."""
+    m = _Math(math_mode)
+    p = _P(params01, m)
+    note_on = p("keyboard", "duration")
+    lfo_1_rate = adsr(cfg, m, p, "lfo_1_rate_adsr", note_on)
+    lfo_2_rate = adsr(cfg, m, p, "lfo_2_rate_adsr", note_on)
+    lfo_1_amp = adsr(cfg, m, p, "lfo_1_amp_adsr", note_on)
+    lfo_2_amp = adsr(cfg, m, p, "lfo_2_amp_adsr", note_on)
+    lfo_1 = lfo(cfg, m, p, "lfo_1", lfo_1_rate) * lfo_1_amp
+    lfo_2 = lfo(cfg, m, p, "lfo_2", lfo_2_rate) * lfo_2_amp
+    adsr_1 = adsr(cfg, m, p, "adsr_1", note_on)
+    adsr_2 = adsr(cfg, m, p, "adsr_2", note_on)
+    w = torch.stack([p("mod_matrix", f"{i}->{o}") for i in S.MOD_INPUTS for o in S.MOD_OUTPUTS], dim=1)
+    w = w.reshape(-1, len(S.MOD_INPUTS), len(S.MOD_OUTPUTS)).swapaxes(1, 2)
+    mod = torch.stack([adsr_1, adsr_2, lfo_1, lfo_2], dim=1)
+    return torch.matmul(w, mod), p
+
+
+# -------------------------------------------------------------------- audio rate
+
+
+def midi_to_hz(midi, m):
+    return 440.0 * m.exp2((midi - 69.0) / 12.0)
+
+
+def vco_phase(cfg, m, p, mod, midi_f0, pitch_mod):
+    f0 = (midi_f0 + p(mod, "tuning")).unsqueeze(1)
+    control = torch.clamp(f0 + p(mod, "mod_depth").unsqueeze(1) * pitch_mod, 0.0, 127.0)
+    hz = midi_to_hz(control, m)
+    arg = torch.cumsum(TWO_PI * hz / cfg.sample_rate, dim=1)
+    return arg + p(mod, "initial_phase").unsqueeze(1)
+
+
+def render_from_params01(cfg, params01, noise, math_mode="torch", return_parts=False):
+    """Voice.output() for explicit normalised parameters -> audio [B,T] fp32."""
+    ctrl, p = control_signals(cfg, params01, math_mode)
+    m = _Math(math_mode)
+    up = torch.nn.Upsample(size=cfg.buffer_size, mode="linear", align_corners=True)
+    upc = up(ctrl)  # [B,5,T]
+    midi_f0 = p("keyboard", "midi_f0")
+
+    arg1 = vco_phase(cfg, m, p, "vco_1", midi_f0, upc[:, 0])
+    vco_1 = torch.cos(arg1) * upc[:, 1]
+
+    arg2 = vco_phase(cfg, m, p, "vco_2", midi_f0, upc[:, 2])
+    max_pitch = midi_f0 + torch.maximum(p("vco_2", "mod_depth"), torch.tensor(0.0))
+    max_f0 = midi_to_hz(max_pitch, m)
+    partials = (12000.0 / (max_f0 * m.log10(max_f0))).unsqueeze(1)
+    square = torch.tanh(math.pi * partials * torch.sin(arg2) / 2)
+    shape = p("vco_2", "shape").unsqueeze(1)
+    vco_2 = ((1 - shape / 2) * square * (1 + shape * torch.cos(arg2))) * upc[:, 3]
+
+    noise_out = noise * upc[:, 4]
+
+    lv = torch.stack([p("mixer", "vco_1"), p("mixer", "vco_2"), p("mixer", "noise")], dim=1)
+    sig = torch.stack([vco_1, vco_2, noise_out], dim=1)
+    mixed = torch.matmul(lv.unsqueeze(1), sig).squeeze(1)
+    peak = torch.max(torch.abs(mixed), dim=1, keepdim=True)[0]
+    audio = torch.where(peak > 1.0, mixed / peak, mixed)
+    if return_parts:
+        return audio, dict(ctrl=ctrl, arg1=arg1, arg2=arg2, mixed=mixed, peak=peak)
+    return audio
+
+
+class OracleVoice:
+    """Minimal look-alike of ``Voice(synthconfig)``: voice(batch_idx) -> (audio, params, is_train)."""
+
+    def __init__(self, cfg, math_mode="torch"):
+        self.cfg = cfg
+        self.math_mode = math_mode
+        self.noise = make_noise(cfg)
+        self.params01 = torch.full((cfg.batch_size, S.NPARAMS), 0.5)
+
+    def __call__(self, batch_idx=None):
+        if batch_idx is not None:
+            self.params01 = sample_params01(self.cfg, batch_idx)
+            train = is_train(self.cfg, batch_idx)
+        else:
+            train = torch.ones(self.cfg.batch_size, dtype=torch.bool)
+        audio = render_from_params01(self.cfg, self.params01, self.noise, self.math_mode)
+        return audio, self.params01.clone(), train

@@ -1,0 +1,86 @@
+// Host-only emulation of the Voice kernels' arithmetic (TEST AID, not product):
+// compiles csrc/voice_math.h with g++ and runs the same per-sample functions in
+// plain sequential loops, so `-m "not gpu"` tests can check the device math
+// against oracle/synth_oracle.py (math mode "cr") without a GPU.
+// Build: g++ -O2 -ffp-contract=off -shared -fPIC (see tests/test_voice_math_cpu.py).
+#include <vector>
+#include <cstring>
+#include "voice_math.h"
+#include "voice_table.h"
+
+static void adsr_from(const float* p, int base, IasAdsr& e) {
+  e.attack = p[base + 0]; e.decay = p[base + 1]; e.sustain = p[base + 2];
+  e.release = p[base + 3]; e.alpha = p[base + 4];
+}
+
+extern "C" int emul_voice_render(const float* params01, const float* noise, float* audio,
+                                 float* ctrl_out /* [B,5,Tc] or null */,
+                                 float* mixed_out /* [B,T] or null */,
+                                 int B, int T, int Tc, int sample_rate, int control_rate) {
+  const float cr = (float)control_rate, sr = (float)sample_rate, eps = (float)IAS_EPS;
+  const float scale = (T > 1) ? (float)(Tc - 1) / (float)(T - 1) : 0.0f;
+  std::vector<float> env(6 * Tc), lfo(2 * Tc), ctrl(5 * Tc), mixed(T);
+  for (int b = 0; b < B; ++b) {
+    float p[IAS_NPARAMS];
+    for (int i = 0; i < IAS_NPARAMS; ++i) {
+      const IasParamRange& r = IAS_PARAM_TABLE[i];
+      p[i] = ias_map_param(params01[b * IAS_NPARAMS + i], (float)r.lo, (float)r.span, (float)r.curve, r.symmetric);
+    }
+    const float midi_f0 = p[IAS_P_KEYBOARD_MIDI_F0], note_on = p[IAS_P_KEYBOARD_DURATION];
+    // env order: adsr_1, adsr_2, lfo_1_amp, lfo_2_amp, lfo_1_rate, lfo_2_rate
+    const int bases[6] = {IAS_P_ADSR_1_ATTACK, IAS_P_ADSR_2_ATTACK, IAS_P_LFO_1_AMP_ADSR_ATTACK,
+                          IAS_P_LFO_2_AMP_ADSR_ATTACK, IAS_P_LFO_1_RATE_ADSR_ATTACK, IAS_P_LFO_2_RATE_ADSR_ATTACK};
+    for (int a = 0; a < 6; ++a) {
+      IasAdsr e; adsr_from(p, bases[a], e);
+      for (int t = 0; t < Tc; ++t) env[a * Tc + t] = ias_adsr(t, e, note_on, cr, eps);
+    }
+    const int lbase[2] = {IAS_P_LFO_1_FREQUENCY, IAS_P_LFO_2_FREQUENCY};
+    for (int l = 0; l < 2; ++l) {
+      const float* q = p + lbase[l];
+      float mode[5]; ias_lfo_mode(q + 3, mode);
+      double acc = 0.0;
+      for (int t = 0; t < Tc; ++t) {
+        acc += (double)ias_lfo_inc(q[0], q[1], env[(4 + l) * Tc + t], cr);
+        const float arg = ias_add((float)acc, q[2]);
+        lfo[l * Tc + t] = ias_mul(ias_lfo_shape_mix(arg, mode), env[(2 + l) * Tc + t]);
+      }
+    }
+    const float* w = p + IAS_P_MOD_MATRIX_ADSR_1_TO_VCO_1_PITCH;  // [input k][output j]
+    for (int j = 0; j < 5; ++j)
+      for (int t = 0; t < Tc; ++t) {
+        float o = ias_mul(w[0 * 5 + j], env[0 * Tc + t]);
+        o = ias_fma(w[1 * 5 + j], env[1 * Tc + t], o);
+        o = ias_fma(w[2 * 5 + j], lfo[0 * Tc + t], o);
+        o = ias_fma(w[3 * 5 + j], lfo[1 * Tc + t], o);
+        ctrl[j * Tc + t] = o;
+      }
+    if (ctrl_out) memcpy(ctrl_out + (size_t)b * 5 * Tc, ctrl.data(), sizeof(float) * 5 * Tc);
+
+    IasVoiceConst vc;
+    vc.f0_1 = ias_add(midi_f0, p[IAS_P_VCO_1_TUNING]); vc.depth_1 = p[IAS_P_VCO_1_MOD_DEPTH]; vc.phi_1 = p[IAS_P_VCO_1_INITIAL_PHASE];
+    vc.f0_2 = ias_add(midi_f0, p[IAS_P_VCO_2_TUNING]); vc.depth_2 = p[IAS_P_VCO_2_MOD_DEPTH]; vc.phi_2 = p[IAS_P_VCO_2_INITIAL_PHASE];
+    vc.kpart = ias_partials_k(midi_f0, vc.depth_2);
+    vc.shape = p[IAS_P_VCO_2_SHAPE];
+    vc.shape_gain = ias_sub(1.0f, ias_div(vc.shape, 2.0f));
+    vc.lvl0 = p[IAS_P_MIXER_VCO_1]; vc.lvl1 = p[IAS_P_MIXER_VCO_2]; vc.lvl2 = p[IAS_P_MIXER_NOISE];
+
+    double ph1 = 0.0, ph2 = 0.0;
+    float peak = 0.0f;
+    for (int j = 0; j < T; ++j) {
+      int i0, i1; float w0, w1;
+      ias_interp_pos(j, scale, Tc, i0, i1, w0, w1);
+      float m[5];
+      for (int k = 0; k < 5; ++k) m[k] = ias_lerp(ctrl[k * Tc + i0], ctrl[k * Tc + i1], w0, w1);
+      ph1 += (double)ias_vco_inc(vc.f0_1, vc.depth_1, m[0], sr);
+      ph2 += (double)ias_vco_inc(vc.f0_2, vc.depth_2, m[2], sr);
+      const float a1 = ias_add((float)ph1, vc.phi_1), a2 = ias_add((float)ph2, vc.phi_2);
+      const float o = ias_mix_sample(a1, a2, m[1], m[3], m[4], noise[(size_t)b * T + j], vc);
+      mixed[j] = o;
+      peak = fmaxf(peak, fabsf(o));
+    }
+    if (mixed_out) memcpy(mixed_out + (size_t)b * T, mixed.data(), sizeof(float) * T);
+    for (int j = 0; j < T; ++j)
+      audio[(size_t)b * T + j] = (peak > 1.0f) ? ias_div(mixed[j], peak) : mixed[j];
+  }
+  return 0;
+}
