@@ -1,0 +1,67 @@
+/* C ABI of libias_hip.so -- the MI355X (gfx950) kernels of the inverse-audio-synthesis inner loop.
+ *
+ * The reference (turian/inverse-audio-synthesis) is pure Python and has no FFI layer; its boundary
+ * for this path is a set of Python classes.  Each entry point below names the
+ * reference interface it stands behind.  All pointers are DEVICE pointers unless said otherwise,
+ * tensors are contiguous fp32, `stream` is a hipStream_t (NULL = default stream).  Outputs and
+ * workspaces are caller-allocated; nothing is allocated, freed or synchronised inside a call, so
+ * every call can be captured into a hipGraph.  Return value: 0 (IAS_OK) or a negative IAS_ERR_*.
+ */
+#ifndef IAS_HIP_H
+#define IAS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IAS_OK 0
+#define IAS_ERR_ARG (-1)
+#define IAS_ERR_UNSUPPORTED (-2)
+#define IAS_ERR_LAUNCH (-3)
+#define IAS_ERR_WORKSPACE (-4)
+
+/* Library version (major*100 + minor). */
+int ias_version(void);
+
+/* dst[0..n) = src[0..n) with 16-byte accesses; n % 4 == 0.  Bench calibration of the HBM rate. */
+int ias_stream_copy(const float* src, float* dst, long long n, void* stream);
+
+/* ---- Voice render: torchsynth.synth.Voice as called at
+ * reference vicreg_audio_params.py:86-94,114; audio_to_params.py:196-203,215,240-257; pretrain.py:75.
+ * B voices, T = buffer_size samples, Tc = control buffer size (buffer_size_seconds * 441). */
+
+/* Bytes of workspace ias_voice_render needs (ctrl signals, per-voice constants, tile sums, peaks). */
+long long ias_voice_workspace_bytes(int B, int T, int Tc);
+
+/* Control-rate pass only: params01 [B,78] in [0,1] (registration order, voice_spec.py) ->
+ * ctrl [B,5,Tc] (mod-matrix outputs) and vconst [B] x 64 bytes (IasVoiceConst). */
+int ias_voice_control(const float* params01, float* ctrl, void* vconst, int B, int Tc, int control_rate,
+                      void* stream);
+
+/* Voice.output(): params01 [B,78], noise [B,T] (the fixed Noise(seed=13) buffer) -> audio [B,T].
+ * normalize != 0 applies torchsynth's normalize_if_clipping (row / max(|row|) when the max > 1). */
+int ias_voice_render(const float* params01, const float* noise, float* audio, void* workspace,
+                     long long workspace_bytes, int B, int T, int Tc, int sample_rate, int control_rate,
+                     int normalize, void* stream);
+
+/* Copy the B row peaks (max |x| before normalisation) of the last render out of the workspace. */
+int ias_voice_read_peaks(const void* workspace, float* peaks, int B, int T, int Tc, void* stream);
+
+/* ---- PQMF: reference pqmf.py:46-55 (PQMF.forward/analysis/synthesis), K = taps + 1 (odd). */
+
+/* Output frames of analysis: floor((T + 2*(K-1)/2 - K) / N) + 1, or a negative error. */
+int ias_pqmf_out_len(int T, int N, int K);
+
+/* analysis: x [B,T] (= [B,1,T]), H [N,K] (= buffer H[N,1,K]) -> z [B,N,L]   (pqmf.py:49-50).
+ * mean/stdv [N] (both or neither, may be NULL): fused (z - mean[k]) / stdv[k] of
+ * AudioEmbedding._preprocess (reference audioembed.py:41,49). */
+int ias_pqmf_analysis(const float* x, const float* H, float* z, const float* mean, const float* stdv,
+                      int B, int T, int N, int K, void* stream);
+
+/* synthesis: z [B,N,L], G [N,K] (= buffer G[1,N,K]) -> out [B, L*N] (= [B,1,L*N])   (pqmf.py:52-55). */
+int ias_pqmf_synthesis(const float* z, const float* G, float* out, int B, int L, int N, int K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IAS_HIP_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of the C-ABI HIP library (``csrc/libias_hip.so``, declared in ``include/ias_hip.h``).
+
+The product path has no CPU fallback: if the library is missing or a call returns a
+non-zero status, an exception is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libias_hip.so")
+
+_ERRORS = {
+    -1: "IAS_ERR_ARG (bad pointer or dimension)",
+    -2: "IAS_ERR_UNSUPPORTED (shape outside the kernel's limits)",
+    -3: "IAS_ERR_LAUNCH (HIP launch failed)",
+    -4: "IAS_ERR_WORKSPACE (workspace too small)",
+}
+
+_c = ctypes
+_P, _I, _LL = _c.c_void_p, _c.c_int, _c.c_longlong
+_F = _c.c_float
+
+# name -> (restype, argtypes).  Must list every symbol include/ias_hip.h declares.
+SYMBOLS = {
+    "ias_version": (_I, []),
+    "ias_stream_copy": (_I, [_P, _P, _LL, _P]),
+    "ias_voice_workspace_bytes": (_LL, [_I, _I, _I]),
+    "ias_voice_control": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ias_voice_render": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _P]),
+    "ias_voice_read_peaks": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ias_pqmf_out_len": (_I, [_I, _I, _I]),
+    "ias_pqmf_analysis": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_pqmf_synthesis": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load libias_hip.so (once).  Raises HipLibraryMissing if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C inverse-audio-synthesis_amd/csrc`.  There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what} failed: {_ERRORS.get(status, status)}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("inverse-audio-synthesis_amd kernels need tensors on a ROCm device (no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError("tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError(f"expected float32, got {t.dtype}")

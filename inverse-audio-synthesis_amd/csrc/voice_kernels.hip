@@ -1,0 +1,396 @@
+// Voice render for MI355X (gfx950): control-rate pass + audio-rate pass.
+//
+// Replaces torchsynth's Voice.output() as the reference drives it
+// (/root/reference/vicreg_audio_params.py:86-94,114; audio_to_params.py:215,240-257).
+// Arithmetic contract: csrc/voice_math.h (== oracle/synth_oracle.py, math "cr").
+//
+// Kernels
+//   voice_control_kernel   one workgroup per voice: 78 params -> 6 ADSRs, 2 LFOs,
+//                          4x5 mod matrix -> ctrl[B][5][Tc] + IasVoiceConst[B].
+//   voice_audio_kernel<0>  per (tile, voice): phase increments of both VCOs, reduced to
+//                          one fp64 tile sum each (sums of fp32 increments below 2^19
+//                          are exact in fp64, so any summation order gives the same bits).
+//   voice_audio_kernel<1>  per (tile, voice): increments again, fp64 scan with the tile
+//                          carry, oscillators, VCAs, mixer -> unnormalised audio, row peak.
+//   voice_normalize_kernel audio = peak > 1 ? x / peak : x   (torchsynth normalize_if_clipping)
+//
+// HBM traffic per audio sample: noise 4 B read + 4 B write (pass 1), 4 B read + 4 B write
+// (normalise).  Control-rate traffic is < 0.1 %.
+#include "voice_math.h"
+#include "voice_table.h"
+
+#define VOICE_THREADS 256
+#define VOICE_WAVES (VOICE_THREADS / 64)
+#define VOICE_SPT 16                          // samples per thread
+#define VOICE_TILE (VOICE_THREADS * VOICE_SPT)  // 4096 samples per workgroup
+#define VOICE_CHUNKS (VOICE_SPT / 4)
+
+__constant__ IasParamRange c_param_table[IAS_NPARAMS] = IAS_PARAM_TABLE_INIT;
+
+// ------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------ control rate
+// LDS: p[80] | env[6][Tc] | lfo[2][Tc] | scratch
+__global__ __launch_bounds__(VOICE_THREADS) void voice_control_kernel(
+    const float* __restrict__ params01, float* __restrict__ ctrl, IasVoiceConst* __restrict__ vconst,
+    int Tc, float control_rate) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* p = smem;
+  float* env = smem + 80;
+  float* lfo = env + 6 * Tc;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float eps = (float)IAS_EPS;
+
+  if (tid < IAS_NPARAMS) {
+    const IasParamRange r = c_param_table[tid];
+    p[tid] = ias_map_param(params01[(size_t)b * IAS_NPARAMS + tid], (float)r.lo, (float)r.span,
+                           (float)r.curve, r.symmetric);
+  }
+  __syncthreads();
+  const float midi_f0 = p[IAS_P_KEYBOARD_MIDI_F0], note_on = p[IAS_P_KEYBOARD_DURATION];
+
+  // env order: adsr_1, adsr_2, lfo_1_amp, lfo_2_amp, lfo_1_rate, lfo_2_rate
+  for (int i = tid; i < 6 * Tc; i += VOICE_THREADS) {
+    const int a = i / Tc, t = i - a * Tc;
+    int base;
+    switch (a) {
+      case 0: base = IAS_P_ADSR_1_ATTACK; break;
+      case 1: base = IAS_P_ADSR_2_ATTACK; break;
+      case 2: base = IAS_P_LFO_1_AMP_ADSR_ATTACK; break;
+      case 3: base = IAS_P_LFO_2_AMP_ADSR_ATTACK; break;
+      case 4: base = IAS_P_LFO_1_RATE_ADSR_ATTACK; break;
+      default: base = IAS_P_LFO_2_RATE_ADSR_ATTACK; break;
+    }
+    IasAdsr e;
+    e.attack = p[base]; e.decay = p[base + 1]; e.sustain = p[base + 2];
+    e.release = p[base + 3]; e.alpha = p[base + 4];
+    env[i] = ias_adsr(t, e, note_on, control_rate, eps);
+  }
+  __syncthreads();
+
+  // LFO phase: waves 0/1 scan lfo_1/lfo_2 (fp64 accumulate, fp32 per-sample round).
+  if (wave < 2) {
+    const int l = wave;
+    const float* q = p + (l == 0 ? IAS_P_LFO_1_FREQUENCY : IAS_P_LFO_2_FREQUENCY);
+    const float freq = q[0], depth = q[1], phi = q[2];
+    double carry = 0.0;
+    for (int t0 = 0; t0 < Tc; t0 += 64) {
+      const int t = t0 + lane;
+      double inc = 0.0;
+      if (t < Tc) inc = (double)ias_lfo_inc(freq, depth, env[(4 + l) * Tc + t], control_rate);
+      const double s = wave_incl_scan(inc, lane) + carry;
+      if (t < Tc) lfo[l * Tc + t] = ias_add((float)s, phi);
+      carry = __shfl(s, 63, 64);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * Tc; i += VOICE_THREADS) {
+    const int l = i / Tc, t = i - l * Tc;
+    const float* q = p + (l == 0 ? IAS_P_LFO_1_FREQUENCY : IAS_P_LFO_2_FREQUENCY);
+    float mode[5];
+    ias_lfo_mode(q + 3, mode);
+    lfo[i] = ias_mul(ias_lfo_shape_mix(lfo[i], mode), env[(2 + l) * Tc + t]);
+  }
+  __syncthreads();
+
+  const float* w = p + IAS_P_MOD_MATRIX_ADSR_1_TO_VCO_1_PITCH;  // [input k][output j]
+  float* out = ctrl + (size_t)b * IAS_NCTRL * Tc;
+  for (int i = tid; i < IAS_NCTRL * Tc; i += VOICE_THREADS) {
+    const int j = i / Tc, t = i - j * Tc;
+    float o = ias_mul(w[0 * 5 + j], env[0 * Tc + t]);
+    o = ias_fma(w[1 * 5 + j], env[1 * Tc + t], o);
+    o = ias_fma(w[2 * 5 + j], lfo[0 * Tc + t], o);
+    o = ias_fma(w[3 * 5 + j], lfo[1 * Tc + t], o);
+    out[i] = o;
+  }
+  if (tid == 0) {
+    IasVoiceConst vc;
+    vc.f0_1 = ias_add(midi_f0, p[IAS_P_VCO_1_TUNING]);
+    vc.depth_1 = p[IAS_P_VCO_1_MOD_DEPTH];
+    vc.phi_1 = p[IAS_P_VCO_1_INITIAL_PHASE];
+    vc.f0_2 = ias_add(midi_f0, p[IAS_P_VCO_2_TUNING]);
+    vc.depth_2 = p[IAS_P_VCO_2_MOD_DEPTH];
+    vc.phi_2 = p[IAS_P_VCO_2_INITIAL_PHASE];
+    vc.kpart = ias_partials_k(midi_f0, vc.depth_2);
+    vc.shape = p[IAS_P_VCO_2_SHAPE];
+    vc.shape_gain = ias_sub(1.0f, ias_div(vc.shape, 2.0f));
+    vc.lvl0 = p[IAS_P_MIXER_VCO_1];
+    vc.lvl1 = p[IAS_P_MIXER_VCO_2];
+    vc.lvl2 = p[IAS_P_MIXER_NOISE];
+    vc.pad[0] = vc.pad[1] = vc.pad[2] = vc.pad[3] = 0.0f;
+    vconst[b] = vc;
+  }
+}
+
+// -------------------------------------------------------------------- audio rate
+#define VOICE_MAXCTRL 96  // control points staged per tile (tile * (Tc-1)/(T-1) + 3 must fit)
+
+template <int PASS>
+__global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
+    const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst,
+    const float* __restrict__ noise, float* __restrict__ audio, double* __restrict__ tilesum,
+    unsigned* __restrict__ rowpeak, int T, int Tc, int ntiles, float sample_rate, float scale) {
+  __shared__ float s_ctrl[IAS_NCTRL][VOICE_MAXCTRL];
+  __shared__ double s_wsum[2][VOICE_WAVES];
+  __shared__ double s_carry[2];
+  __shared__ float s_max[VOICE_WAVES];
+
+  const int tile = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j_tile = tile * VOICE_TILE;
+  const int j_last = min(j_tile + VOICE_TILE, T) - 1;
+
+  // stage the control points this tile interpolates between
+  int c_lo, c_hi;
+  {
+    int i0, i1; float w0, w1;
+    ias_interp_pos(j_tile, scale, Tc, i0, i1, w0, w1);
+    c_lo = i0;
+    ias_interp_pos(j_last, scale, Tc, i0, i1, w0, w1);
+    c_hi = i1;
+  }
+  const int ncp = c_hi - c_lo + 1;  // host guarantees ncp <= VOICE_MAXCTRL
+  const float* cb = ctrl + (size_t)b * IAS_NCTRL * Tc;
+  for (int i = tid; i < IAS_NCTRL * ncp; i += VOICE_THREADS) {
+    const int k = i / ncp, c = i - k * ncp;
+    s_ctrl[k][c] = cb[k * Tc + c_lo + c];
+  }
+  const IasVoiceConst vc = vconst[b];
+  if (PASS == 1 && wave == 0) {
+    // carry-in = sum of the preceding tiles' increments (exact in fp64)
+    const double* ts = tilesum + (size_t)b * 2 * ntiles;
+    double a1 = 0.0, a2 = 0.0;
+    for (int t = lane; t < tile; t += 64) { a1 += ts[t]; a2 += ts[ntiles + t]; }
+    a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (lane == 0) { s_carry[0] = a1; s_carry[1] = a2; }
+  }
+  __syncthreads();
+
+  // phase A: increments (kept in registers) and per-wave totals
+  float inc1[VOICE_SPT], inc2[VOICE_SPT];
+  double tot1 = 0.0, tot2 = 0.0;
+  const int j_wave = j_tile + wave * (64 * VOICE_SPT);
+#pragma unroll
+  for (int c = 0; c < VOICE_CHUNKS; ++c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j_wave + c * 256 + lane * 4 + e;
+      float a = 0.0f, d = 0.0f;
+      if (j < T) {
+        int i0, i1; float w0, w1;
+        ias_interp_pos(j, scale, Tc, i0, i1, w0, w1);
+        i0 -= c_lo; i1 -= c_lo;
+        const float pm1 = ias_lerp(s_ctrl[0][i0], s_ctrl[0][i1], w0, w1);
+        const float pm2 = ias_lerp(s_ctrl[2][i0], s_ctrl[2][i1], w0, w1);
+        a = ias_vco_inc(vc.f0_1, vc.depth_1, pm1, sample_rate);
+        d = ias_vco_inc(vc.f0_2, vc.depth_2, pm2, sample_rate);
+      }
+      inc1[c * 4 + e] = a; inc2[c * 4 + e] = d;
+      tot1 += (double)a; tot2 += (double)d;
+    }
+  }
+  tot1 = wave_sum(tot1); tot2 = wave_sum(tot2);
+  if (lane == 0) { s_wsum[0][wave] = tot1; s_wsum[1][wave] = tot2; }
+  __syncthreads();
+
+  if (PASS == 0) {
+    if (tid == 0) {
+      double a1 = 0.0, a2 = 0.0;
+      for (int w = 0; w < VOICE_WAVES; ++w) { a1 += s_wsum[0][w]; a2 += s_wsum[1][w]; }
+      tilesum[(size_t)b * 2 * ntiles + tile] = a1;
+      tilesum[(size_t)b * 2 * ntiles + ntiles + tile] = a2;
+    }
+    return;
+  }
+
+  // phase B: scan + oscillators
+  double run1 = s_carry[0], run2 = s_carry[1];
+  for (int w = 0; w < wave; ++w) { run1 += s_wsum[0][w]; run2 += s_wsum[1][w]; }
+  float pk = 0.0f;
+  const float* nrow = noise + (size_t)b * T;
+  float* arow = audio + (size_t)b * T;
+  const bool vec_ok = (T & 3) == 0;
+#pragma unroll
+  for (int c = 0; c < VOICE_CHUNKS; ++c) {
+    const int j0 = j_wave + c * 256 + lane * 4;
+    double l1[4], l2[4];
+    l1[0] = (double)inc1[c * 4]; l2[0] = (double)inc2[c * 4];
+#pragma unroll
+    for (int e = 1; e < 4; ++e) {
+      l1[e] = l1[e - 1] + (double)inc1[c * 4 + e];
+      l2[e] = l2[e - 1] + (double)inc2[c * 4 + e];
+    }
+    const double in1 = wave_incl_scan(l1[3], lane), in2 = wave_incl_scan(l2[3], lane);
+    const double base1 = run1 + (in1 - l1[3]), base2 = run2 + (in2 - l2[3]);
+    run1 += __shfl(in1, 63, 64); run2 += __shfl(in2, 63, 64);
+
+    float nz[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec_ok && j0 + 3 < T) {
+      const float4 v = *reinterpret_cast<const float4*>(nrow + j0);
+      nz[0] = v.x; nz[1] = v.y; nz[2] = v.z; nz[3] = v.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (j0 + e < T) nz[e] = nrow[j0 + e];
+    }
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + e;
+      o[e] = 0.0f;
+      if (j < T) {
+        int i0, i1; float w0, w1;
+        ias_interp_pos(j, scale, Tc, i0, i1, w0, w1);
+        i0 -= c_lo; i1 -= c_lo;
+        const float amp1 = ias_lerp(s_ctrl[1][i0], s_ctrl[1][i1], w0, w1);
+        const float amp2 = ias_lerp(s_ctrl[3][i0], s_ctrl[3][i1], w0, w1);
+        const float ampn = ias_lerp(s_ctrl[4][i0], s_ctrl[4][i1], w0, w1);
+        const float a1 = ias_add((float)(base1 + l1[e]), vc.phi_1);
+        const float a2 = ias_add((float)(base2 + l2[e]), vc.phi_2);
+        o[e] = ias_mix_sample(a1, a2, amp1, amp2, ampn, nz[e], vc);
+        pk = fmaxf(pk, fabsf(o[e]));
+      }
+    }
+    if (vec_ok && j0 + 3 < T) {
+      *reinterpret_cast<float4*>(arow + j0) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (j0 + e < T) arow[j0 + e] = o[e];
+    }
+  }
+  pk = wave_max(pk);
+  if (lane == 0) s_max[wave] = pk;
+  __syncthreads();
+  if (tid == 0) {
+    float m = s_max[0];
+    for (int w = 1; w < VOICE_WAVES; ++w) m = fmaxf(m, s_max[w]);
+    atomicMax(rowpeak + b, __float_as_uint(m));  // m >= 0: uint order == float order
+  }
+}
+
+__global__ __launch_bounds__(256) void voice_normalize_kernel(float* __restrict__ audio,
+                                                              const unsigned* __restrict__ rowpeak,
+                                                              int T, int nvec_per_row) {
+  const int b = blockIdx.y;
+  const float peak = __uint_as_float(rowpeak[b]);
+  if (!(peak > 1.0f)) return;
+  float* row = audio + (size_t)b * T;
+  if ((T & 3) == 0) {
+    float4* r4 = reinterpret_cast<float4*>(row);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nvec_per_row; i += gridDim.x * blockDim.x) {
+      float4 v = r4[i];
+      v.x = ias_div(v.x, peak); v.y = ias_div(v.y, peak);
+      v.z = ias_div(v.z, peak); v.w = ias_div(v.w, peak);
+      r4[i] = v;
+    }
+  } else {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < T; i += gridDim.x * blockDim.x)
+      row[i] = ias_div(row[i], peak);
+  }
+}
+
+// ------------------------------------------------------------------------ C ABI
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct VoiceWs {
+  size_t off_ctrl, off_vconst, off_tilesum, off_peak, total;
+  int ntiles;
+};
+static VoiceWs voice_ws_layout(int B, int T, int Tc) {
+  VoiceWs w;
+  w.ntiles = (T + VOICE_TILE - 1) / VOICE_TILE;
+  size_t o = 0;
+  w.off_ctrl = o;    o = align_up(o + sizeof(float) * (size_t)B * IAS_NCTRL * Tc, 256);
+  w.off_vconst = o;  o = align_up(o + sizeof(IasVoiceConst) * (size_t)B, 256);
+  w.off_tilesum = o; o = align_up(o + sizeof(double) * (size_t)B * 2 * w.ntiles, 256);
+  w.off_peak = o;    o = align_up(o + sizeof(unsigned) * (size_t)B, 256);
+  w.total = o;
+  return w;
+}
+
+extern "C" long long ias_voice_workspace_bytes(int B, int T, int Tc) {
+  if (B <= 0 || T <= 0 || Tc <= 1) return IAS_ERR_ARG;
+  return (long long)voice_ws_layout(B, T, Tc).total;
+}
+
+static int voice_check_dims(int B, int T, int Tc) {
+  if (B <= 0 || T <= 1 || Tc <= 1 || B > 65535) return IAS_ERR_ARG;
+  // control points touched by one tile must fit the LDS stage
+  const double span = (double)VOICE_TILE * (double)(Tc - 1) / (double)(T - 1);
+  if (span + 4.0 > (double)VOICE_MAXCTRL) return IAS_ERR_UNSUPPORTED;
+  return IAS_OK;
+}
+
+extern "C" int ias_voice_control(const float* params01, float* ctrl, void* vconst, int B, int Tc,
+                                 int control_rate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!params01 || !ctrl || !vconst || B <= 0 || Tc <= 1 || control_rate <= 0) return IAS_ERR_ARG;
+  const size_t lds = sizeof(float) * (80 + 8 * (size_t)Tc);
+  if (lds > 160 * 1024) return IAS_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)voice_control_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(voice_control_kernel, dim3(B), dim3(VOICE_THREADS), lds, stream, params01, ctrl,
+                     (IasVoiceConst*)vconst, Tc, (float)control_rate);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+extern "C" int ias_voice_render(const float* params01, const float* noise, float* audio, void* workspace,
+                                long long workspace_bytes, int B, int T, int Tc, int sample_rate,
+                                int control_rate, int normalize, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!params01 || !noise || !audio || !workspace || sample_rate <= 0 || control_rate <= 0) return IAS_ERR_ARG;
+  int rc = voice_check_dims(B, T, Tc);
+  if (rc) return rc;
+  const VoiceWs w = voice_ws_layout(B, T, Tc);
+  if ((size_t)workspace_bytes < w.total) return IAS_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  float* ctrl = (float*)(ws + w.off_ctrl);
+  IasVoiceConst* vconst = (IasVoiceConst*)(ws + w.off_vconst);
+  double* tilesum = (double*)(ws + w.off_tilesum);
+  unsigned* peak = (unsigned*)(ws + w.off_peak);
+
+  rc = ias_voice_control(params01, ctrl, vconst, B, Tc, control_rate, stream_);
+  if (rc) return rc;
+  if (hipMemsetAsync(peak, 0, sizeof(unsigned) * (size_t)B, stream) != hipSuccess) return IAS_ERR_LAUNCH;
+  const float scale = (float)(Tc - 1) / (float)(T - 1);
+  const dim3 grid(w.ntiles, B), block(VOICE_THREADS);
+  hipLaunchKernelGGL(voice_audio_kernel<0>, grid, block, 0, stream, ctrl, vconst, noise, audio, tilesum, peak,
+                     T, Tc, w.ntiles, (float)sample_rate, scale);
+  hipLaunchKernelGGL(voice_audio_kernel<1>, grid, block, 0, stream, ctrl, vconst, noise, audio, tilesum, peak,
+                     T, Tc, w.ntiles, (float)sample_rate, scale);
+  if (normalize) {
+    const int nvec = T / 4;
+    int gx = (nvec + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(voice_normalize_kernel, dim3(gx, B), dim3(256), 0, stream, audio, peak, T, nvec);
+  }
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+// Row peaks (|x| max before normalisation) of the last render, for tests/diagnostics.
+extern "C" int ias_voice_read_peaks(const void* workspace, float* peaks_dev, int B, int T, int Tc, void* stream_) {
+  if (!workspace || !peaks_dev) return IAS_ERR_ARG;
+  const VoiceWs w = voice_ws_layout(B, T, Tc);
+  if (hipMemcpyAsync(peaks_dev, (const char*)workspace + w.off_peak, sizeof(float) * (size_t)B,
+                     hipMemcpyDeviceToDevice, (hipStream_t)stream_) != hipSuccess)
+    return IAS_ERR_LAUNCH;
+  return IAS_OK;
+}

@@ -1,0 +1,88 @@
+"""PQMF filterbank module -- drop-in for /root/reference/pqmf.py:9-55 on MI355X.
+
+Same constructor, attributes (``N, taps, cutoff, beta, pad_fn``), registered buffers
+(``H [N,1,taps+1]``, ``G [1,N,taps+1]``, ``updown_filter [N,N,N]`` -> identical
+state_dict keys) and methods (``forward == analysis``, ``synthesis``).  The filter design
+is host-side numpy/scipy at construction; analysis/synthesis run the HIP kernels of
+csrc/pqmf_kernels.hip (synthesis in polyphase form -- the zero-stuffed tensor of
+pqmf.py:53 is never materialised).
+"""
+import numpy as np
+import torch
+from scipy import signal as _sig
+
+from . import _lib
+
+
+def design_filters(N, taps, cutoff, beta):
+    """Kaiser-windowed prototype, cosine-modulated into N analysis/synthesis filters."""
+    proto = _sig.firwin(taps + 1, cutoff, window=("kaiser", beta))
+    k = np.arange(N)[:, None]
+    n = np.arange(taps + 1)[None, :] - ((taps - 1) / 2)
+    arg = (2 * k + 1) * (np.pi / (2 * N)) * n
+    phase = ((-1.0) ** k) * np.pi / 4
+    H = 2 * proto[None, :] * np.cos(arg + phase)
+    G = 2 * proto[None, :] * np.cos(arg - phase)
+    return H, G
+
+
+def pqmf_analysis(x, H, mean=None, std=None):
+    """x [B,1,T] or [B,T] fp32 on a ROCm device, H [N,1,K] -> z [B,N,L].
+
+    ``mean``/``std`` ([N] device tensors) fuse the per-band normalisation of
+    /root/reference/audioembed.py:49 into the store.
+    """
+    lib = _lib.load()
+    if x.dim() == 3:
+        assert x.shape[1] == 1, "PQMF analysis takes one input channel"
+    x2 = x.reshape(x.shape[0], -1).contiguous()
+    Hc = H.reshape(H.shape[0], -1).contiguous()
+    _lib.require_f32(x2, Hc, mean, std)
+    B, T = x2.shape
+    N, K = Hc.shape
+    L = lib.ias_pqmf_out_len(T, N, K)
+    _lib.check(min(L, 0), "ias_pqmf_out_len")
+    z = torch.empty((B, N, L), dtype=torch.float32, device=x2.device)
+    st = lib.ias_pqmf_analysis(_lib.ptr(x2), _lib.ptr(Hc), _lib.ptr(z), _lib.ptr(mean), _lib.ptr(std),
+                               B, T, N, K, _lib.stream())
+    _lib.check(st, "ias_pqmf_analysis")
+    return z
+
+
+def pqmf_synthesis(z, G):
+    """z [B,N,L], G [1,N,K] -> [B,1,L*N]."""
+    lib = _lib.load()
+    zc = z.contiguous()
+    Gc = G.reshape(-1, G.shape[-1]).contiguous()
+    _lib.require_f32(zc, Gc)
+    B, N, L = zc.shape
+    assert Gc.shape[0] == N
+    out = torch.empty((B, 1, L * N), dtype=torch.float32, device=zc.device)
+    st = lib.ias_pqmf_synthesis(_lib.ptr(zc), _lib.ptr(Gc), _lib.ptr(out), B, L, N, Gc.shape[1], _lib.stream())
+    _lib.check(st, "ias_pqmf_synthesis")
+    return out
+
+
+class PQMF(torch.nn.Module):
+    def __init__(self, N=4, taps=62, cutoff=0.15, beta=9.0):
+        super().__init__()
+        self.N = N
+        self.taps = taps
+        self.cutoff = cutoff
+        self.beta = beta
+        H, G = design_filters(N, taps, cutoff, beta)
+        self.register_buffer("H", torch.from_numpy(H[:, None, :]).float())
+        self.register_buffer("G", torch.from_numpy(G[None, :, :]).float())
+        updown = torch.zeros((N, N, N)).float()
+        updown[torch.arange(N), torch.arange(N), 0] = 1.0
+        self.register_buffer("updown_filter", updown)
+        self.pad_fn = torch.nn.ConstantPad1d(taps // 2, 0.0)
+
+    def forward(self, x):
+        return self.analysis(x)
+
+    def analysis(self, x):
+        return pqmf_analysis(x, self.H)
+
+    def synthesis(self, x):
+        return pqmf_synthesis(x, self.G)

@@ -1,0 +1,183 @@
+"""``SynthConfig`` / ``Voice`` look-alikes of the torchsynth objects the reference uses.
+
+Reference call sites (the classes themselves live in the absent third-party
+``torchsynth``, /root/reference/requirements.txt:1):
+  SynthConfig(batch_size=, reproducible=, sample_rate=, buffer_size_seconds=)
+      /root/reference/vicreg_audio_params.py:86-91, audio_to_params.py:196-201
+  Voice(synthconfig=), .to(device), voice(batch_idx) -> (audio, params, is_train)
+      /root/reference/vicreg_audio_params.py:92-94,114; pretrain.py:75
+  voice.get_parameters(), getattr(voice, module).set_parameter_0to1(name, value),
+  voice.freeze_parameters(keys), voice.unfreeze_all_parameters(), voice(None)
+      /root/reference/audio_to_params.py:240-257
+
+The render itself is the HIP path (csrc/voice_kernels.hip); parameter sampling stays on
+the host with torch's CPU generator so that seeds mean the same thing as in the oracle.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import voice_spec as S
+
+
+class SynthConfig:
+    def __init__(self, batch_size=128, sample_rate=44100, buffer_size_seconds=4.0,
+                 control_rate=S.CONTROL_RATE, reproducible=True, no_grad=True, debug=False, eps=S.EPS):
+        self.batch_size = int(batch_size)
+        self.sample_rate = int(sample_rate)
+        self.buffer_size_seconds = float(buffer_size_seconds)
+        self.buffer_size = int(self.buffer_size_seconds * self.sample_rate)
+        self.control_rate = int(control_rate)
+        self.control_buffer_size = int(self.buffer_size_seconds * self.control_rate)
+        self.reproducible = bool(reproducible)
+        self.no_grad = bool(no_grad)
+        self.debug = bool(debug)
+        self.eps = float(eps)
+        assert self.control_rate == S.CONTROL_RATE and self.eps == S.EPS, \
+            "the HIP control kernel is built for control_rate=441, eps=1e-6"
+
+
+class _ModuleView:
+    """What ``getattr(voice, module_name)`` returns: per-module parameter access."""
+
+    def __init__(self, voice, name):
+        self._voice = voice
+        self._name = name
+
+    def set_parameter_0to1(self, parameter_id, value):
+        self._voice._set_column(S.INDEX[(self._name, parameter_id)], value)
+
+    def get_parameter_0to1(self, parameter_id):
+        return self._voice.params01[:, S.INDEX[(self._name, parameter_id)]]
+
+
+def sample_params01(batch_size, batch_idx):
+    """Voice.randomize(seed=batch_idx) on the host: [B,78] uniforms, registration order.
+
+    torchsynth draws sub-batches of 32 voices (seed = global sub-batch number) and assigns
+    the columns in sorted-name order; a batch that is not a multiple of 32 is one block
+    seeded with batch_idx.
+    """
+    names = [f"{m}.{n}" for (m, n, *_r) in S.PARAMS]
+    order = sorted(range(S.NPARAMS), key=lambda i: names[i])
+    g = torch.Generator(device="cpu")
+    sub = S.REPRODUCIBLE_SUBBATCH
+    if batch_size % sub == 0:
+        blocks = []
+        for i in range(batch_size // sub):
+            g.manual_seed(int(batch_idx) * (batch_size // sub) + i)
+            blocks.append(torch.rand((sub, S.NPARAMS), generator=g))
+        drawn = torch.cat(blocks, 0)
+    else:
+        g.manual_seed(int(batch_idx))
+        drawn = torch.rand((batch_size, S.NPARAMS), generator=g)
+    inv = torch.empty(S.NPARAMS, dtype=torch.long)
+    inv[torch.tensor(order)] = torch.arange(S.NPARAMS)
+    return drawn[:, inv].contiguous()
+
+
+class Voice(nn.Module):
+    def __init__(self, synthconfig=None, nebula="default"):
+        super().__init__()
+        self.synthconfig = synthconfig if synthconfig is not None else SynthConfig()
+        c = self.synthconfig
+        g = torch.Generator(device="cpu").manual_seed(S.NOISE_SEED)
+        noise = torch.rand((c.batch_size, c.buffer_size), generator=g) * 2.0 - 1.0
+        self.register_buffer("noise", noise, persistent=False)
+        self.register_buffer("params01", torch.full((c.batch_size, S.NPARAMS), 0.5), persistent=False)
+        self._frozen = set()
+        self._workspace = None
+        for mod, _plist in S.MODULES:
+            object.__setattr__(self, "_view_" + mod, _ModuleView(self, mod))
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            view = self.__dict__.get("_view_" + name)
+            if view is None:
+                raise
+            return view
+
+    # ---- torchsynth-style parameter API ----
+    @property
+    def batch_size(self):
+        return self.synthconfig.batch_size
+
+    def get_parameters(self, include_frozen=True):
+        out = OrderedDict()
+        for i, (mod, name, *_r) in enumerate(S.PARAMS):
+            if include_frozen or (mod, name) not in self._frozen:
+                out[(mod, name)] = self.params01[:, i]
+        return out
+
+    def freeze_parameters(self, keys):
+        for k in keys:
+            self._frozen.add(tuple(k))
+
+    def unfreeze_all_parameters(self):
+        self._frozen.clear()
+
+    def set_parameters01(self, params01):
+        assert params01.shape == self.params01.shape
+        self.params01.copy_(params01.detach().to(self.params01.dtype))
+
+    def _set_column(self, idx, value):
+        value = torch.as_tensor(value, dtype=torch.float32, device=self.params01.device)
+        assert value.numel() in (1, self.batch_size)
+        self.params01[:, idx] = value.detach().reshape(-1)
+
+    def randomize(self, seed):
+        new = sample_params01(self.batch_size, seed).to(self.params01.device)
+        if self._frozen:
+            keep = torch.tensor([(m, n) in self._frozen for (m, n, *_r) in S.PARAMS], device=new.device)
+            new = torch.where(keep.unsqueeze(0), self.params01, new)
+        self.params01.copy_(new)
+
+    def _is_train(self, batch_idx):
+        B = self.batch_size
+        if batch_idx is None:
+            return torch.ones(B, dtype=torch.bool, device=self.params01.device)
+        idx = torch.arange(B * int(batch_idx), B * (int(batch_idx) + 1))
+        return ((idx // S.REPRODUCIBLE_SUBBATCH) % 10 != 9).to(self.params01.device)
+
+    # ---- render ----
+    def render(self, params01=None, normalize=True):
+        """HIP render of ``params01`` ([B,78] in 0..1, default: the stored ones) -> audio [B,T]."""
+        c = self.synthconfig
+        p = self.params01 if params01 is None else params01
+        p = p.detach().to(torch.float32).contiguous()
+        assert p.shape == (c.batch_size, S.NPARAMS)
+        lib = _lib.load()
+        _lib.require_f32(p, self.noise)
+        need = lib.ias_voice_workspace_bytes(c.batch_size, c.buffer_size, c.control_buffer_size)
+        if need < 0:
+            _lib.check(int(need), "ias_voice_workspace_bytes")
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != p.device:
+            self._workspace = torch.empty(int(need), dtype=torch.uint8, device=p.device)
+        audio = torch.empty((c.batch_size, c.buffer_size), dtype=torch.float32, device=p.device)
+        st = lib.ias_voice_render(_lib.ptr(p), _lib.ptr(self.noise), _lib.ptr(audio), _lib.ptr(self._workspace),
+                                  self._workspace.numel(), c.batch_size, c.buffer_size, c.control_buffer_size,
+                                  c.sample_rate, c.control_rate, 1 if normalize else 0, _lib.stream())
+        _lib.check(st, "ias_voice_render")
+        return audio
+
+    def control_signals(self, params01=None):
+        """Mod-matrix outputs [B,5,Tc] of the control-rate kernel (diagnostics / tests)."""
+        c = self.synthconfig
+        p = (self.params01 if params01 is None else params01).detach().to(torch.float32).contiguous()
+        lib = _lib.load()
+        ctrl = torch.empty((c.batch_size, 5, c.control_buffer_size), dtype=torch.float32, device=p.device)
+        vconst = torch.empty((c.batch_size, 16), dtype=torch.float32, device=p.device)
+        st = lib.ias_voice_control(_lib.ptr(p), _lib.ptr(ctrl), _lib.ptr(vconst), c.batch_size,
+                                   c.control_buffer_size, c.control_rate, _lib.stream())
+        _lib.check(st, "ias_voice_control")
+        return ctrl, vconst
+
+    def forward(self, batch_idx=None):
+        if batch_idx is not None:
+            self.randomize(batch_idx)
+        audio = self.render()
+        return audio, self.params01.clone(), self._is_train(batch_idx)

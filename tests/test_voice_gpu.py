@@ -1,0 +1,91 @@
+"""HIP Voice render vs the oracle (math "cr") through the C ABI.  Tolerance: 1e-4 on rendered audio
+(BASELINE.json north_star), measured as max |a - ref| (audio is peak-normalised to <= 1, so this is
+also relative to full scale) and as relative L2."""
+import pytest
+import torch
+
+from oracle import synth_oracle as so
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+AUDIO_TOL = 1e-4
+
+
+def _voice(dev, B, sr, sec):
+    from inverse_audio_synthesis_amd.voice import SynthConfig, Voice
+    return Voice(SynthConfig(batch_size=B, sample_rate=sr, buffer_size_seconds=sec, reproducible=False)).to(dev)
+
+
+@pytest.mark.parametrize("B,sr,sec,seed", [(4, 16000, 1.0, 0), (8, 44100, 4.0, 1), (32, 44100, 4.0, 5)])
+def test_render_matches_oracle(lib, dev, B, sr, sec, seed):
+    v = _voice(dev, B, sr, sec)
+    audio, params, is_train = v(seed)
+    cfg = so.VoiceConfig(batch_size=B, sample_rate=sr, buffer_size_seconds=sec)
+    assert torch.equal(params.cpu(), so.sample_params01(cfg, seed))
+    assert torch.equal(is_train.cpu(), so.is_train(cfg, seed))
+    assert torch.equal(v.noise.cpu(), so.make_noise(cfg))
+    ref, parts = so.render_from_params01(cfg, params.cpu(), so.make_noise(cfg), "cr", True)
+    ctrl, _ = v.control_signals()
+    assert torch.equal(ctrl.cpu(), parts["ctrl"]), "control-rate signals must be bit-exact"
+    a = audio.cpu()
+    assert a.shape == ref.shape and not torch.isnan(a).any()
+    assert (a - ref).abs().max().item() <= AUDIO_TOL
+    assert rel_l2(a, ref) <= AUDIO_TOL
+
+
+def test_unnormalised_and_peaks(lib, dev):
+    v = _voice(dev, 8, 44100, 4.0)
+    v.randomize(2)
+    cfg = so.VoiceConfig(batch_size=8)
+    ref, parts = so.render_from_params01(cfg, v.params01.cpu(), so.make_noise(cfg), "cr", True)
+    raw = v.render(normalize=False).cpu()
+    assert (raw - parts["mixed"]).abs().max().item() <= 4e-4 * max(1.0, parts["peak"].max().item())
+    out = v.render().cpu()
+    assert out.abs().max().item() <= 1.0 + 1e-6
+    assert (parts["peak"] > 1).any(), "seed 2 should contain clipping voices"
+
+
+def test_set_parameter_api_and_render_none(lib, dev):
+    """audio_to_params.py:240-257 sequence: set_parameter_0to1 per (module, name), freeze, voice(None)."""
+    v = _voice(dev, 4, 16000, 1.0)
+    target = torch.rand(4, 78, generator=torch.Generator().manual_seed(11))
+    for (mod, name), col in zip(v.get_parameters().keys(), target.T):
+        getattr(v, mod).set_parameter_0to1(name, col.to(dev))
+    v.freeze_parameters(v.get_parameters().keys())
+    audio, params, _ = v(None)
+    v.unfreeze_all_parameters()
+    assert torch.equal(params.cpu(), target)
+    cfg = so.VoiceConfig(batch_size=4, sample_rate=16000, buffer_size_seconds=1.0)
+    ref = so.render_from_params01(cfg, target, so.make_noise(cfg), "cr")
+    assert (audio.cpu() - ref).abs().max().item() <= AUDIO_TOL
+    # frozen parameters survive randomize()
+    v.freeze_parameters([("keyboard", "midi_f0")])
+    before = v.params01[:, 0].clone()
+    v.randomize(3)
+    assert torch.equal(v.params01[:, 0], before)
+
+
+def test_full_batch_properties(lib, dev):
+    """BASELINE size (128 x 4 s): determinism, per-voice independence of the batch, peak bound."""
+    v = _voice(dev, 128, 44100, 4.0)
+    a1, p, _ = v(7)
+    a2 = v.render()
+    assert torch.equal(a1, a2), "render must be deterministic"
+    assert a1.abs().max().item() <= 1.0 + 1e-6 and not torch.isnan(a1).any()
+    # voices are independent: rendering rows 0..7 alone (same noise rows) gives the same audio
+    v8 = _voice(dev, 8, 44100, 4.0)
+    assert torch.equal(v8.noise, v.noise[:8])
+    a8 = v8.render(p[:8].to(dev))
+    assert torch.equal(a8, a1[:8])
+    # spot-check a few rows against the oracle
+    cfg = so.VoiceConfig(batch_size=8)
+    ref = so.render_from_params01(cfg, p[:8].cpu(), so.make_noise(cfg), "cr")
+    assert (a1[:8].cpu() - ref).abs().max().item() <= AUDIO_TOL
+
+
+def test_bad_arguments_fail_loudly(lib, dev):
+    v = _voice(dev, 4, 16000, 1.0)
+    with pytest.raises(RuntimeError):
+        v.render(torch.rand(4, 78))  # CPU tensor: no CPU fallback
+    from inverse_audio_synthesis_amd import _lib
+    assert lib.ias_voice_render(None, None, None, None, 0, 4, 16000, 441, 16000, 441, 1, None) == -1
