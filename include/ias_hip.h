@@ -38,6 +38,11 @@ long long ias_voice_workspace_bytes(int B, int T, int Tc);
 int ias_voice_control(const float* params01, float* ctrl, void* vconst, int B, int Tc, int control_rate,
                       void* stream);
 
+/* Same as ias_voice_control plus the intermediates dbg [B,10,Tc]: rows 0-5 the envelopes
+ * (adsr_1, adsr_2, lfo_1_amp, lfo_2_amp, lfo_1_rate, lfo_2_rate), 6-7 the LFO phases, 8-9 the LFO outputs. */
+int ias_voice_control_debug(const float* params01, float* ctrl, void* vconst, float* dbg, int B, int Tc,
+                            int control_rate, void* stream);
+
 /* Voice.output(): params01 [B,78], noise [B,T] (the fixed Noise(seed=13) buffer) -> audio [B,T].
  * normalize != 0 applies torchsynth's normalize_if_clipping (row / max(|row|) when the max > 1). */
 int ias_voice_render(const float* params01, const float* noise, float* audio, void* workspace,
@@ -60,6 +65,31 @@ int ias_pqmf_analysis(const float* x, const float* H, float* z, const float* mea
 
 /* synthesis: z [B,N,L], G [N,K] (= buffer G[1,N,K]) -> out [B, L*N] (= [B,1,L*N])   (pqmf.py:52-55). */
 int ias_pqmf_synthesis(const float* z, const float* G, float* out, int B, int L, int N, int K, void* stream);
+
+/* ---- STFT / mel spectral losses.  No live reference code: spec = the commented mel block at
+ * reference conf/config.yaml:51-61 and its use at audio_to_params.py:150-153 (torchaudio
+ * MelSpectrogram semantics), plus the auraloss TODO at audio_to_params.py:233. */
+
+/* Frames of a center=True STFT: 1 + T / hop (needs T > n_fft/2 for reflect padding). */
+int ias_stft_num_frames(int T, int n_fft, int hop);
+
+/* Number of [3]-double partial records ias_stft writes when loss_mode != 0. */
+long long ias_stft_partials_count(int B, int T, int n_fft, int hop);
+
+/* Framed STFT of audio [B,T]: window [n_fft] (zero-padded, centred), reflect padding, one-sided.
+ * twiddle [n_fft][2] = (cos, -sin)(2 pi j / n_fft).  Per-bin value by value_mode: 1 |X|, 2 |X|^2,
+ * 3 sqrt(max(|X|^2, eps)).  Optional mel projection as packed triangular filters
+ * (mel_start/mel_count/mel_woff [n_out], mel_w); with NULL mel_* n_out must be n_fft/2+1.
+ * out [B,F,n_out] (frames-major) or NULL; target [B,F,n_out] + partials required when
+ * loss_mode is 1 (sum |v-t|) or 2 (MR-STFT sums {(t-v)^2, t^2, |log v - log t|}).
+ * n_fft in {512, 1024, 2048}. */
+int ias_stft(const float* audio, const float* window, const float* twiddle, const int* mel_start,
+             const int* mel_count, const int* mel_woff, const float* mel_w, float* out, const float* target,
+             double* partials, int B, int T, int n_fft, int hop, int n_out, int value_mode, int loss_mode,
+             float eps, void* stream);
+
+/* sums[3] (doubles) = column sums of partials [n][3], fixed order (deterministic). */
+int ias_reduce_partials(const double* partials, long long n, double* sums, void* stream);
 
 #ifdef __cplusplus
 }

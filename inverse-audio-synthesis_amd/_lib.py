@@ -28,11 +28,16 @@ SYMBOLS = {
     "ias_stream_copy": (_I, [_P, _P, _LL, _P]),
     "ias_voice_workspace_bytes": (_LL, [_I, _I, _I]),
     "ias_voice_control": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ias_voice_control_debug": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ias_voice_render": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _P]),
     "ias_voice_read_peaks": (_I, [_P, _P, _I, _I, _I, _P]),
     "ias_pqmf_out_len": (_I, [_I, _I, _I]),
     "ias_pqmf_analysis": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_pqmf_synthesis": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_stft_num_frames": (_I, [_I, _I, _I]),
+    "ias_stft_partials_count": (_LL, [_I, _I, _I, _I]),
+    "ias_stft": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "ias_reduce_partials": (_I, [_P, _LL, _P, _P]),
 }
 
 _lib = None

@@ -1,0 +1,327 @@
+// Framed STFT -> power / magnitude -> (optional) mel filterbank -> spectrogram or fused L1 / MR-STFT
+// partial sums, for MI355X (gfx950).
+//
+// The reference has no live spectral-loss code; the spec is the commented mel block
+// /root/reference/conf/config.yaml:51-61 and its use /root/reference/audio_to_params.py:150-153
+// (torchaudio MelSpectrogram semantics: hann window, center=True, reflect pad, onesided, power 2,
+// slaney-normalised htk mel filterbank), plus the auraloss TODOs (audio_to_params.py:233).
+//
+// One wave computes one frame: the n_fft real samples are packed into n_fft/2 complex points,
+// transformed by an in-register radix-R pass (R = n_fft/128) followed by two radix-8 passes that
+// exchange through LDS (n_fft/2 = R*8*8), then unpacked to the n_fft/2+1 one-sided bins.  All
+// arithmetic fp32 (no bf16 DFT-as-GEMM: it would not hold the 1e-3 loss tolerance).
+// A workgroup (4 waves) stages the samples of FPB consecutive frames in LDS once (frames overlap),
+// so every audio sample is read from HBM ~once: algorithmic bytes = 4 B in per sample
+// + 4*bins/hop B out (or the same to read a cached target).
+#include "ias_common.h"
+
+#define SP_THREADS 256
+#define SP_WAVES 4
+#define SP_FPB 8   // frames per workgroup
+
+struct cpx { float x, y; };
+__device__ __forceinline__ cpx cmk(float x, float y) { cpx r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return cmk(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cpx csub(cpx a, cpx b) { return cmk(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cpx cmul(cpx a, cpx b) { return cmk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cpx cmul_negi(cpx a) { return cmk(a.y, -a.x); }  // a * (-i)
+
+// forward DFTs (kernel e^{-2 pi i nk/R}), in place, natural order
+__device__ __forceinline__ void dft4(cpx& v0, cpx& v1, cpx& v2, cpx& v3) {
+  const cpx t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3), t3 = cmul_negi(csub(v1, v3));
+  v0 = cadd(t0, t2); v1 = cadd(t1, t3); v2 = csub(t0, t2); v3 = csub(t1, t3);
+}
+__device__ __forceinline__ void dft8(cpx* v) {
+  cpx e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+  cpx o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+  dft4(e0, e1, e2, e3);
+  dft4(o0, o1, o2, o3);
+  const float h = 0.70710678118654752f;
+  o1 = cmk((o1.x + o1.y) * h, (o1.y - o1.x) * h);    // * W8^1 = (1 - i)/sqrt2
+  o2 = cmul_negi(o2);                                 // * W8^2 = -i
+  o3 = cmk((o3.y - o3.x) * h, -(o3.x + o3.y) * h);   // * W8^3 = (-1 - i)/sqrt2
+  v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+  v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+  v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+  v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+__device__ __forceinline__ void dft16(cpx* v) {
+  cpx e[8], o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+  dft8(e);
+  dft8(o);
+  // W16^k, k = 0..7
+  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+  const cpx w[8] = {cmk(1.f, 0.f), cmk(c1, -s1), cmk(h, -h), cmk(s1, -c1),
+                    cmk(0.f, -1.f), cmk(-s1, -c1), cmk(-h, -h), cmk(-c1, -s1)};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const cpx t = cmul(o[k], w[k]);
+    v[k] = cadd(e[k], t);
+    v[k + 8] = csub(e[k], t);
+  }
+}
+template <int R> __device__ __forceinline__ void dftR(cpx* v);
+template <> __device__ __forceinline__ void dftR<4>(cpx* v) { dft4(v[0], v[1], v[2], v[3]); }
+template <> __device__ __forceinline__ void dftR<8>(cpx* v) { dft8(v); }
+template <> __device__ __forceinline__ void dftR<16>(cpx* v) { dft16(v); }
+
+__device__ __forceinline__ int reflect_index(int i, int T) {
+  if (i < 0) i = -i;
+  if (i >= T) i = 2 * (T - 1) - i;
+  return i;
+}
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+struct SpecArgs {
+  const float* audio;      // [B,T]
+  const float* window;     // [n_fft] (win_length window zero-padded, centred)
+  const float2* twiddle;   // [n_fft]  (cos, -sin)(2 pi j / n_fft)
+  const int* mel_start;    // [n_out] first bin of each filter (mel mode) or null (raw bins)
+  const int* mel_count;    // [n_out]
+  const int* mel_woff;     // [n_out] offset into mel_w
+  const float* mel_w;      // packed non-zero filter weights
+  float* out;              // [B,F,n_out] or null
+  const float* target;     // [B,F,n_out] or null
+  double* partials;        // [gridDim.x*gridDim.y][3] or null
+  int T, F, hop, n_out;
+  int value_mode;          // 1: |X|, 2: |X|^2, 3: sqrt(max(|X|^2, eps))
+  int loss_mode;           // 0: none, 1: sum |v - t|, 2: MR-STFT sums {(t-v)^2, t^2, |log v - log t|}
+  float eps;
+};
+
+template <int LOG2N>
+__global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
+  constexpr int NFFT = 1 << LOG2N, N2 = NFFT / 2, R = N2 / 64, NPAIR = 8 * R, NP_IT = (NPAIR + 63) / 64;
+  constexpr int SCR = NPAIR * 9;   // padded [k1*8+c][9] complex scratch
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int span = (SP_FPB - 1) * a.hop + NFFT;
+  float* s_win = smem;                                   // NFFT
+  float2* s_tw = reinterpret_cast<float2*>(s_win + NFFT);  // NFFT
+  float* s_in = reinterpret_cast<float*>(s_tw + NFFT);   // span (rounded up to even)
+  const int span_pad = (span + 3) & ~3;
+  cpx* s_scr = reinterpret_cast<cpx*>(s_in + span_pad);  // SP_WAVES * 2 * SCR
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, f0 = blockIdx.x * SP_FPB;
+  const float* arow = a.audio + (size_t)b * a.T;
+
+  for (int i = tid; i < NFFT; i += SP_THREADS) { s_win[i] = a.window[i]; s_tw[i] = a.twiddle[i]; }
+  const int g0 = f0 * a.hop - N2;
+  for (int i = tid; i < span; i += SP_THREADS) s_in[i] = arow[reflect_index(g0 + i, a.T)];
+  __syncthreads();
+
+  cpx* sA = s_scr + wave * 2 * SCR;
+  cpx* sB = sA + SCR;
+  float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+
+  for (int it = 0; it < SP_FPB / SP_WAVES; ++it) {
+    const int fi = it * SP_WAVES + wave;
+    const int f = f0 + fi;
+    const bool live = f < a.F;   // uniform per wave; barriers below are executed by every wave
+    const float* fin = s_in + fi * a.hop;
+
+    // pass 1: radix-R over n1 (points 64*n1 + lane), twiddle W_N2^(lane*k1), scatter to [k1][c][a]
+    cpx v[R];
+#pragma unroll
+    for (int n1 = 0; n1 < R; ++n1) {
+      const int m = 2 * (64 * n1 + lane);
+      v[n1] = cmk(fin[m] * s_win[m], fin[m + 1] * s_win[m + 1]);
+    }
+    dftR<R>(v);
+    {
+      const int c = lane & 7, aa = lane >> 3;
+#pragma unroll
+      for (int k1 = 0; k1 < R; ++k1) {
+        const float2 w = s_tw[2 * lane * k1];
+        sA[(k1 * 8 + c) * 9 + aa] = cmul(v[k1], cmk(w.x, w.y));
+      }
+    }
+    __syncthreads();
+    // pass 2: radix-8 over a for each (k1, c); twiddle W_64^(c*d); scatter to [k1][d][c]
+#pragma unroll
+    for (int i = 0; i < NP_IT; ++i) {
+      const int p = lane + 64 * i;
+      if (p < NPAIR) {
+        const int k1 = p >> 3, c = p & 7;
+        cpx u[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u[q] = sA[p * 9 + q];
+        dft8(u);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          const float2 w = s_tw[(NFFT / 64) * c * d];
+          sB[(k1 * 8 + d) * 9 + c] = cmul(u[d], cmk(w.x, w.y));
+        }
+      }
+    }
+    __syncthreads();
+    // pass 3: radix-8 over c for each (k1, d) -> Z[k1 + R*d + 8R*e], natural order into sA
+#pragma unroll
+    for (int i = 0; i < NP_IT; ++i) {
+      const int p = lane + 64 * i;
+      if (p < NPAIR) {
+        const int k1 = p >> 3, d = p & 7;
+        cpx u[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u[q] = sB[p * 9 + q];
+        dft8(u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sA[k1 + R * d + 8 * R * e] = u[e];
+      }
+    }
+    __syncthreads();
+    // unpack the packed real FFT: bins k and N2-k from Z[k], Z[N2-k]; values into sB (as floats)
+    float* P = reinterpret_cast<float*>(sB);
+    for (int k = lane; k <= N2 / 2; k += 64) {
+      const cpx zk = sA[k], zn = sA[(N2 - k) & (N2 - 1)];
+      const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+      const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+      const float2 w = s_tw[k];
+      const cpx t = cmul(cmk(w.x, w.y), zo);
+      const cpx xk = cadd(ze, t);              // X[k]
+      const cpx xn = cmk(ze.x - t.x, -(ze.y - t.y));  // X[N2-k] = conj(ze - t)
+      float pk = xk.x * xk.x + xk.y * xk.y, pn = xn.x * xn.x + xn.y * xn.y;
+      if (a.value_mode == 1) { pk = sqrtf(pk); pn = sqrtf(pn); }
+      else if (a.value_mode == 3) { pk = sqrtf(fmaxf(pk, a.eps)); pn = sqrtf(fmaxf(pn, a.eps)); }
+      P[k] = pk;
+      P[N2 - k] = pn;
+    }
+    __syncthreads();
+    // epilogue: mel projection (or raw bins), store / fused loss sums
+    if (live) {
+      const size_t row = ((size_t)b * a.F + f) * a.n_out;
+      for (int m = lane; m < a.n_out; m += 64) {
+        float val;
+        if (a.mel_start != nullptr) {
+          const int s = a.mel_start[m], n = a.mel_count[m];
+          const float* w = a.mel_w + a.mel_woff[m];
+          val = 0.f;
+          for (int j = 0; j < n; ++j) val = fmaf(w[j], P[s + j], val);
+        } else {
+          val = P[m];
+        }
+        if (a.out != nullptr) a.out[row + m] = val;
+        if (a.loss_mode == 1) {
+          l0 += fabsf(val - a.target[row + m]);
+        } else if (a.loss_mode == 2) {
+          const float t = a.target[row + m];
+          const float d = t - val;
+          l0 = fmaf(d, d, l0);
+          l1 = fmaf(t, t, l1);
+          l2 += fabsf(logf(val) - logf(t));
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (a.partials != nullptr) {
+    __shared__ float s_red[SP_WAVES][3];
+    l0 = wave_sum_f(l0); l1 = wave_sum_f(l1); l2 = wave_sum_f(l2);
+    if (lane == 0) { s_red[wave][0] = l0; s_red[wave][1] = l1; s_red[wave][2] = l2; }
+    __syncthreads();
+    if (tid < 3) {
+      double s = 0.0;
+      for (int w = 0; w < SP_WAVES; ++w) s += (double)s_red[w][tid];
+      a.partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + tid] = s;
+    }
+  }
+}
+
+// sums[0..2] = sum over n partial triples (fixed order: deterministic)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, long long n,
+                                                              double* __restrict__ sums) {
+  __shared__ double s[256][3];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 256) {
+    a0 += partials[i * 3]; a1 += partials[i * 3 + 1]; a2 += partials[i * 3 + 2];
+  }
+  s[threadIdx.x][0] = a0; s[threadIdx.x][1] = a1; s[threadIdx.x][2] = a2;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (threadIdx.x < d)
+      for (int k = 0; k < 3; ++k) s[threadIdx.x][k] += s[threadIdx.x + d][k];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) sums[threadIdx.x] = s[0][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------ C ABI
+extern "C" int ias_stft_num_frames(int T, int n_fft, int hop) {
+  if (T <= n_fft / 2 || hop <= 0 || n_fft <= 0) return IAS_ERR_ARG;
+  return 1 + T / hop;   // center=True: 1 + (T + 2*(n_fft/2) - n_fft) / hop
+}
+
+extern "C" long long ias_stft_partials_count(int B, int T, int n_fft, int hop) {
+  const int F = ias_stft_num_frames(T, n_fft, hop);
+  if (F < 0 || B <= 0) return IAS_ERR_ARG;
+  return (long long)B * ((F + SP_FPB - 1) / SP_FPB);
+}
+
+// Framed STFT of audio [B,T] (hann/any window [n_fft], center=True, reflect pad), per-bin value by
+// value_mode (1 |X|, 2 |X|^2, 3 sqrt(max(|X|^2, eps))), optional mel projection given as packed
+// filters (mel_start/count/woff [n_out], mel_w), n_out = n_mels or n_fft/2+1 when mel_* are NULL.
+//   out      [B,F,n_out] or NULL : the spectrogram (frames-major layout)
+//   target   [B,F,n_out] or NULL : with loss_mode 1 (sum |v-t|) or 2 (MR-STFT sums)
+//   partials [ias_stft_partials_count][3] doubles, required when loss_mode != 0
+// twiddle [n_fft] float2 = (cos, -sin)(2 pi j / n_fft), computed by the caller in fp64.
+extern "C" int ias_stft(const float* audio, const float* window, const float* twiddle, const int* mel_start,
+                        const int* mel_count, const int* mel_woff, const float* mel_w, float* out,
+                        const float* target, double* partials, int B, int T, int n_fft, int hop, int n_out,
+                        int value_mode, int loss_mode, float eps, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!audio || !window || !twiddle || B <= 0 || B > 65535 || n_out <= 0) return IAS_ERR_ARG;
+  if (value_mode < 1 || value_mode > 3 || loss_mode < 0 || loss_mode > 2) return IAS_ERR_ARG;
+  if (loss_mode != 0 && (!target || !partials)) return IAS_ERR_ARG;
+  if (loss_mode == 0 && !out) return IAS_ERR_ARG;
+  const bool mel = mel_start != nullptr;
+  if (mel && (!mel_count || !mel_woff || !mel_w)) return IAS_ERR_ARG;
+  if (!mel && n_out != n_fft / 2 + 1) return IAS_ERR_ARG;
+  const int F = ias_stft_num_frames(T, n_fft, hop);
+  if (F < 0) return IAS_ERR_ARG;
+  if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return IAS_ERR_UNSUPPORTED;
+  if (hop > n_fft) return IAS_ERR_UNSUPPORTED;
+
+  SpecArgs a;
+  a.audio = audio; a.window = window; a.twiddle = (const float2*)twiddle;
+  a.mel_start = mel_start; a.mel_count = mel_count; a.mel_woff = mel_woff; a.mel_w = mel_w;
+  a.out = out; a.target = target; a.partials = partials;
+  a.T = T; a.F = F; a.hop = hop; a.n_out = n_out;
+  a.value_mode = value_mode; a.loss_mode = loss_mode; a.eps = eps;
+
+  const int N2 = n_fft / 2, R = N2 / 64, scr = 8 * R * 9;
+  const int span = (SP_FPB - 1) * hop + n_fft;
+  const size_t lds = sizeof(float) * n_fft + sizeof(float2) * n_fft + sizeof(float) * ((span + 3) & ~3) +
+                     sizeof(cpx) * SP_WAVES * 2 * scr;
+  if (lds > 150 * 1024) return IAS_ERR_UNSUPPORTED;
+  const dim3 grid((F + SP_FPB - 1) / SP_FPB, B), block(SP_THREADS);
+  switch (n_fft) {
+    case 512:
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)stft_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(stft_kernel<9>, grid, block, lds, stream, a);
+      break;
+    case 1024:
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)stft_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(stft_kernel<10>, grid, block, lds, stream, a);
+      break;
+    default:
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)stft_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(stft_kernel<11>, grid, block, lds, stream, a);
+      break;
+  }
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+// sums[3] (doubles) = column sums of partials [n][3], in a fixed order.
+extern "C" int ias_reduce_partials(const double* partials, long long n, double* sums, void* stream_) {
+  if (!partials || !sums || n <= 0) return IAS_ERR_ARG;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, partials, n, sums);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}

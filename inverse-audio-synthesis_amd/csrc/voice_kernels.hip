@@ -51,6 +51,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // LDS: p[80] | env[6][Tc] | lfo[2][Tc] | scratch
 __global__ __launch_bounds__(VOICE_THREADS) void voice_control_kernel(
     const float* __restrict__ params01, float* __restrict__ ctrl, IasVoiceConst* __restrict__ vconst,
+    float* __restrict__ dbg /* optional [B][10][Tc]: env0..5, lfo phase 0/1, lfo out 0/1 */,
     int Tc, float control_rate) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* p = smem;
@@ -102,6 +103,11 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_control_kernel(
     }
   }
   __syncthreads();
+  if (dbg != nullptr) {
+    float* d = dbg + (size_t)b * 10 * Tc;
+    for (int i = tid; i < 8 * Tc; i += VOICE_THREADS) d[i] = env[i];  // env[6][Tc] then lfo phase [2][Tc]
+  }
+  __syncthreads();
   for (int i = tid; i < 2 * Tc; i += VOICE_THREADS) {
     const int l = i / Tc, t = i - l * Tc;
     const float* q = p + (l == 0 ? IAS_P_LFO_1_FREQUENCY : IAS_P_LFO_2_FREQUENCY);
@@ -111,14 +117,16 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_control_kernel(
   }
   __syncthreads();
 
+  if (dbg != nullptr) {
+    float* d = dbg + (size_t)b * 10 * Tc + 8 * Tc;
+    for (int i = tid; i < 2 * Tc; i += VOICE_THREADS) d[i] = lfo[i];
+  }
   const float* w = p + IAS_P_MOD_MATRIX_ADSR_1_TO_VCO_1_PITCH;  // [input k][output j]
   float* out = ctrl + (size_t)b * IAS_NCTRL * Tc;
   for (int i = tid; i < IAS_NCTRL * Tc; i += VOICE_THREADS) {
     const int j = i / Tc, t = i - j * Tc;
-    float o = ias_mul(w[0 * 5 + j], env[0 * Tc + t]);
-    o = ias_fma(w[1 * 5 + j], env[1 * Tc + t], o);
-    o = ias_fma(w[2 * 5 + j], lfo[0 * Tc + t], o);
-    o = ias_fma(w[3 * 5 + j], lfo[1 * Tc + t], o);
+    const float o = ias_dot4_cr(w[0 * 5 + j], w[1 * 5 + j], w[2 * 5 + j], w[3 * 5 + j],
+                                    env[0 * Tc + t], env[1 * Tc + t], lfo[0 * Tc + t], lfo[1 * Tc + t]);
     out[i] = o;
   }
   if (tid == 0) {
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_control_kernel(
 }
 
 // -------------------------------------------------------------------- audio rate
-#define VOICE_MAXCTRL 96  // control points staged per tile (tile * (Tc-1)/(T-1) + 3 must fit)
+#define VOICE_MAXCTRL 320  // control points staged per tile (covers sample rates down to ~6 kHz)
 
 template <int PASS>
 __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
@@ -338,8 +346,8 @@ static int voice_check_dims(int B, int T, int Tc) {
   return IAS_OK;
 }
 
-extern "C" int ias_voice_control(const float* params01, float* ctrl, void* vconst, int B, int Tc,
-                                 int control_rate, void* stream_) {
+static int voice_control_launch(const float* params01, float* ctrl, void* vconst, float* dbg, int B, int Tc,
+                                int control_rate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!params01 || !ctrl || !vconst || B <= 0 || Tc <= 1 || control_rate <= 0) return IAS_ERR_ARG;
   const size_t lds = sizeof(float) * (80 + 8 * (size_t)Tc);
@@ -347,8 +355,20 @@ extern "C" int ias_voice_control(const float* params01, float* ctrl, void* vcons
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)voice_control_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(voice_control_kernel, dim3(B), dim3(VOICE_THREADS), lds, stream, params01, ctrl,
-                     (IasVoiceConst*)vconst, Tc, (float)control_rate);
+                     (IasVoiceConst*)vconst, dbg, Tc, (float)control_rate);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+extern "C" int ias_voice_control(const float* params01, float* ctrl, void* vconst, int B, int Tc,
+                                 int control_rate, void* stream_) {
+  return voice_control_launch(params01, ctrl, vconst, nullptr, B, Tc, control_rate, stream_);
+}
+
+// Same, plus the control-rate intermediates dbg [B][10][Tc] (6 envelopes, 2 LFO phases, 2 LFO outputs).
+extern "C" int ias_voice_control_debug(const float* params01, float* ctrl, void* vconst, float* dbg, int B,
+                                       int Tc, int control_rate, void* stream_) {
+  if (!dbg) return IAS_ERR_ARG;
+  return voice_control_launch(params01, ctrl, vconst, dbg, B, Tc, control_rate, stream_);
 }
 
 extern "C" int ias_voice_render(const float* params01, const float* noise, float* audio, void* workspace,

@@ -5,8 +5,9 @@
 // Semantics: the restatement of torchsynth's Voice.output() documented in
 // oracle/synth_oracle.py, math mode "cr": every fp32 elementary operation is
 // correctly rounded (transcendentals are evaluated in fp64 and rounded once),
-// reductions follow the order torch's CPU kernels use (bmm = fma chain in k,
-// 5-element sum = (((a0+a4)+a1)+a2)+a3, linear upsample = fma(w0,a,w1*b)).
+// the small dot products / sums on the oscillator-phase path (LFO shape mix, LFO mode
+// normalisation, mod matrix) are fp64-accumulated and rounded once, the linear
+// upsample is fl(fl(w0*a)+fl(w1*b)), the final mixer a left-to-right mul/add chain.
 // Reference call sites: /root/reference/vicreg_audio_params.py:86-94,114,
 // /root/reference/audio_to_params.py:215,240-257.
 #pragma once
@@ -130,18 +131,27 @@ IAS_HD float ias_lfo_shape_mix(float arg, const float* mode) {
   const float rsaw = ias_sub(1.0f, saw);
   float tri = ias_mul(2.0f, saw);
   if (tri > 1.0f) tri = ias_sub(2.0f, tri);
-  float o = ias_mul(mode[0], c);
-  o = ias_fma(mode[1], tri, o);
-  o = ias_fma(mode[2], saw, o);
-  o = ias_fma(mode[3], rsaw, o);
-  o = ias_fma(mode[4], sq, o);
-  return o;
+  double o = (double)mode[0] * (double)c;   // products of two floats are exact in fp64
+  o += (double)mode[1] * (double)tri;
+  o += (double)mode[2] * (double)saw;
+  o += (double)mode[3] * (double)rsaw;
+  o += (double)mode[4] * (double)sq;
+  return (float)o;
+}
+
+// mod-matrix row: sum_k w[k]*s[k], fp64 accumulate, rounded once
+IAS_HD float ias_dot4_cr(float w0, float w1, float w2, float w3, float s0, float s1, float s2, float s3) {
+  double o = (double)w0 * (double)s0;
+  o += (double)w1 * (double)s1;
+  o += (double)w2 * (double)s2;
+  o += (double)w3 * (double)s3;
+  return (float)o;
 }
 
 IAS_HD void ias_lfo_mode(const float* p5, float* mode) {
   float m[5];
   for (int k = 0; k < 5; ++k) m[k] = ias_mul(p5[k], p5[k]);  // pow(x, 2) correctly rounded
-  const float s = ias_add(ias_add(ias_add(ias_add(m[0], m[4]), m[1]), m[2]), m[3]);
+  const float s = (float)((double)m[0] + (double)m[1] + (double)m[2] + (double)m[3] + (double)m[4]);
   for (int k = 0; k < 5; ++k) mode[k] = ias_div(m[k], s);
 }
 
@@ -156,7 +166,7 @@ IAS_HD void ias_interp_pos(int j, float scale, int Tc, int& i0, int& i1, float& 
   w1 = fminf(fmaxf(ias_sub(real, (float)k), 0.0f), 1.0f);
   w0 = ias_sub(1.0f, w1);
 }
-IAS_HD float ias_lerp(float a, float b, float w0, float w1) { return ias_fma(w0, a, ias_mul(w1, b)); }
+IAS_HD float ias_lerp(float a, float b, float w0, float w1) { return ias_add(ias_mul(w0, a), ias_mul(w1, b)); }
 
 IAS_HD float ias_midi_to_hz(float midi) {
   return ias_mul(440.0f, ias_exp2_cr(ias_div(ias_sub(midi, 69.0f), 12.0f)));
@@ -185,7 +195,7 @@ IAS_HD float ias_mix_sample(float arg1, float arg2, float amp1, float amp2, floa
                                    ias_add(1.0f, ias_mul(vc.shape, cosf(arg2)))), amp2);
   const float nz = ias_mul(noise, ampn);
   float o = ias_mul(vc.lvl0, v1);
-  o = ias_fma(vc.lvl1, v2, o);
-  o = ias_fma(vc.lvl2, nz, o);
+  o = ias_add(o, ias_mul(vc.lvl1, v2));
+  o = ias_add(o, ias_mul(vc.lvl2, nz));
   return o;
 }

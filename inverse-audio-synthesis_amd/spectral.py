@@ -1,0 +1,203 @@
+"""STFT / mel spectral losses on the HIP path (csrc/spectral_kernels.hip).
+
+The reference has no live spectral-loss code.  This module implements the spec it left behind:
+  * ``MelSpectrogram`` with the argument names/defaults of the commented config block
+    /root/reference/conf/config.yaml:51-61 (torchaudio.transforms.MelSpectrogram semantics),
+  * ``MelSpectrogramL1``: ``mean(|mel(audio) - mel(pred_audio)|)`` of the commented training
+    code /root/reference/audio_to_params.py:150-153,
+  * ``STFTL1`` (BASELINE config #1 "STFT L1 loss") and ``MultiResolutionSTFTLoss`` (the auraloss
+    TODO at audio_to_params.py:233; auraloss defaults).
+Filterbank / window / twiddle tables are built once on the host; every per-sample operation runs
+in the HIP kernel.  Forward only (the reference never differentiates this path).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+VALUE_MAG, VALUE_POWER, VALUE_MAG_CLAMPED = 1, 2, 3
+LOSS_NONE, LOSS_L1, LOSS_MRSTFT = 0, 1, 2
+
+
+def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm="slaney", mel_scale="htk"):
+    """Triangular mel filterbank [n_freqs, n_mels] (torchaudio.functional.melscale_fbanks, htk scale)."""
+    assert mel_scale == "htk", "only the htk mel scale of conf/config.yaml is implemented"
+    to_mel = lambda f: 2595.0 * math.log10(1.0 + f / 700.0)
+    freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    mel_pts = torch.linspace(to_mel(f_min), to_mel(f_max), n_mels + 2)
+    hz_pts = 700.0 * (10.0 ** (mel_pts / 2595.0) - 1.0)
+    width = hz_pts[1:] - hz_pts[:-1]
+    dist = hz_pts.unsqueeze(0) - freqs.unsqueeze(1)
+    falling = (-1.0 * dist[:, :-2]) / width[:-1]
+    rising = dist[:, 2:] / width[1:]
+    fb = torch.max(torch.zeros(1), torch.min(falling, rising))
+    if norm == "slaney":
+        fb = fb * (2.0 / (hz_pts[2:n_mels + 2] - hz_pts[:n_mels])).unsqueeze(0)
+    else:
+        assert norm is None
+    return fb
+
+
+class STFTPlan(nn.Module):
+    """Device tables for one (n_fft, win_length, hop, optional mel filterbank) configuration."""
+
+    def __init__(self, n_fft=1024, win_length=None, hop_length=None, n_mels=None, sample_rate=44100,
+                 f_min=0.0, f_max=None, norm="slaney", mel_scale="htk"):
+        super().__init__()
+        assert n_fft in (512, 1024, 2048), "HIP STFT kernel supports n_fft 512/1024/2048"
+        self.n_fft = n_fft
+        self.win_length = n_fft if win_length is None else win_length
+        self.hop_length = self.win_length // 2 if hop_length is None else hop_length
+        assert self.win_length <= n_fft and 0 < self.hop_length <= n_fft
+        win = torch.hann_window(self.win_length)
+        left = (n_fft - self.win_length) // 2
+        window = torch.zeros(n_fft)
+        window[left:left + self.win_length] = win
+        j = torch.arange(n_fft, dtype=torch.float64) * (2.0 * math.pi / n_fft)
+        twiddle = torch.stack([torch.cos(j), -torch.sin(j)], dim=1).float()
+        self.register_buffer("window", window, persistent=False)
+        self.register_buffer("twiddle", twiddle.contiguous(), persistent=False)
+        self.n_mels = n_mels
+        if n_mels is not None:
+            f_max = float(sample_rate // 2) if f_max is None else f_max
+            fb = melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate, norm, mel_scale)
+            self.register_buffer("fb", fb, persistent=False)
+            start, count, woff, w = [], [], [], []
+            for m in range(n_mels):
+                nz = torch.nonzero(fb[:, m]).flatten()
+                if nz.numel() == 0:
+                    start.append(0); count.append(0); woff.append(len(w))
+                    continue
+                s, e = int(nz[0]), int(nz[-1]) + 1
+                start.append(s); count.append(e - s); woff.append(len(w))
+                w.extend(fb[s:e, m].tolist())
+            self.register_buffer("mel_start", torch.tensor(start, dtype=torch.int32), persistent=False)
+            self.register_buffer("mel_count", torch.tensor(count, dtype=torch.int32), persistent=False)
+            self.register_buffer("mel_woff", torch.tensor(woff, dtype=torch.int32), persistent=False)
+            self.register_buffer("mel_w", torch.tensor(w if w else [0.0], dtype=torch.float32), persistent=False)
+            self.n_out = n_mels
+        else:
+            self.n_out = n_fft // 2 + 1
+
+    def num_frames(self, T):
+        F = _lib.load().ias_stft_num_frames(T, self.n_fft, self.hop_length)
+        _lib.check(min(F, 0), "ias_stft_num_frames (need T > n_fft/2 for reflect padding)")
+        return F
+
+    def _call(self, audio, out, target, partials, value_mode, loss_mode, eps):
+        lib = _lib.load()
+        B, T = audio.shape
+        mel = self.n_mels is not None
+        st = lib.ias_stft(_lib.ptr(audio), _lib.ptr(self.window), _lib.ptr(self.twiddle),
+                          _lib.ptr(self.mel_start) if mel else None, _lib.ptr(self.mel_count) if mel else None,
+                          _lib.ptr(self.mel_woff) if mel else None, _lib.ptr(self.mel_w) if mel else None,
+                          _lib.ptr(out), _lib.ptr(target), _lib.ptr(partials), B, T, self.n_fft, self.hop_length,
+                          self.n_out, value_mode, loss_mode, float(eps), _lib.stream())
+        _lib.check(st, "ias_stft")
+
+    @staticmethod
+    def _audio2d(audio):
+        a = audio.reshape(audio.shape[0], -1) if audio.dim() == 3 else audio
+        assert a.dim() == 2
+        a = a.contiguous()
+        _lib.require_f32(a)
+        return a
+
+    def values(self, audio, value_mode=VALUE_POWER, eps=0.0):
+        """-> [B, frames, n_out] (frames-major) spectrogram values."""
+        a = self._audio2d(audio)
+        out = torch.empty((a.shape[0], self.num_frames(a.shape[1]), self.n_out), dtype=torch.float32, device=a.device)
+        self._call(a, out, None, None, value_mode, LOSS_NONE, eps)
+        return out
+
+    def loss_sums(self, audio, target_values, value_mode, loss_mode, eps=0.0):
+        """Fused STFT + comparison with cached target values -> 3 fp64 sums on the device."""
+        a = self._audio2d(audio)
+        lib = _lib.load()
+        F = self.num_frames(a.shape[1])
+        assert target_values.shape == (a.shape[0], F, self.n_out) and target_values.is_contiguous()
+        n = lib.ias_stft_partials_count(a.shape[0], a.shape[1], self.n_fft, self.hop_length)
+        partials = torch.empty((n, 3), dtype=torch.float64, device=a.device)
+        self._call(a, None, target_values, partials, value_mode, loss_mode, eps)
+        sums = torch.empty(3, dtype=torch.float64, device=a.device)
+        _lib.check(lib.ias_reduce_partials(_lib.ptr(partials), n, _lib.ptr(sums), _lib.stream()), "ias_reduce_partials")
+        return sums
+
+
+class MelSpectrogram(nn.Module):
+    """conf/config.yaml:51-61 block -> [B, n_mels, frames] (torchaudio layout; a transposed view of
+    the kernel's frames-major output)."""
+
+    def __init__(self, sample_rate=44100, n_fft=1024, win_length=None, hop_length=512, center=True,
+                 pad_mode="reflect", power=2.0, norm="slaney", onesided=True, n_mels=128, mel_scale="htk",
+                 f_min=0.0, f_max=None):
+        super().__init__()
+        assert center and pad_mode == "reflect" and onesided, "kernel implements center/reflect/onesided"
+        assert power in (1.0, 2.0)
+        self.power = power
+        self.plan = STFTPlan(n_fft, win_length, hop_length, n_mels, sample_rate, f_min, f_max, norm, mel_scale)
+
+    @property
+    def value_mode(self):
+        return VALUE_POWER if self.power == 2.0 else VALUE_MAG
+
+    def frames_major(self, audio):
+        return self.plan.values(audio, self.value_mode)
+
+    def forward(self, audio):
+        return self.frames_major(audio).transpose(1, 2)
+
+
+class MelSpectrogramL1(nn.Module):
+    """mean(|mel(audio) - mel(target)|)   (audio_to_params.py:150-153)."""
+
+    def __init__(self, **mel_kwargs):
+        super().__init__()
+        self.mel = MelSpectrogram(**mel_kwargs)
+
+    def target(self, target_audio):
+        """Cacheable frames-major mel of the target audio."""
+        return self.mel.frames_major(target_audio)
+
+    def forward(self, audio, target_audio=None, target_mel=None):
+        if target_mel is None:
+            target_mel = self.target(target_audio)
+        sums = self.mel.plan.loss_sums(audio, target_mel, self.mel.value_mode, LOSS_L1)
+        return (sums[0] / target_mel.numel()).float()
+
+
+class STFTL1(nn.Module):
+    """mean | |STFT(a)|^p - |STFT(b)|^p |  (BASELINE config #1 "STFT L1 loss")."""
+
+    def __init__(self, n_fft=1024, hop_length=512, win_length=None, power=1.0):
+        super().__init__()
+        assert power in (1.0, 2.0)
+        self.value_mode = VALUE_POWER if power == 2.0 else VALUE_MAG
+        self.plan = STFTPlan(n_fft, win_length, hop_length)
+
+    def forward(self, audio, target_audio):
+        tgt = self.plan.values(target_audio, self.value_mode)
+        sums = self.plan.loss_sums(audio, tgt, self.value_mode, LOSS_L1)
+        return (sums[0] / tgt.numel()).float()
+
+
+class MultiResolutionSTFTLoss(nn.Module):
+    """auraloss.freq.MultiResolutionSTFTLoss defaults: per resolution spectral convergence
+    ||Y|-|X||_F/||Y||_F + L1(log|X|, log|Y|), averaged over resolutions (x = prediction, y = target)."""
+
+    def __init__(self, fft_sizes=(1024, 2048, 512), hop_sizes=(120, 240, 50), win_lengths=(600, 1200, 240),
+                 eps=1e-8):
+        super().__init__()
+        self.eps = eps
+        self.plans = nn.ModuleList([STFTPlan(n, w, h) for n, h, w in zip(fft_sizes, hop_sizes, win_lengths)])
+
+    def forward(self, x, y):
+        total = None
+        for plan in self.plans:
+            tgt = plan.values(y, VALUE_MAG_CLAMPED, self.eps)
+            s = plan.loss_sums(x, tgt, VALUE_MAG_CLAMPED, LOSS_MRSTFT, self.eps)
+            term = torch.sqrt(s[0]) / torch.sqrt(s[1]) + s[2] / tgt.numel()
+            total = term if total is None else total + term
+        return (total / len(self.plans)).float()

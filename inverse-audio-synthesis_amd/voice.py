@@ -164,6 +164,19 @@ class Voice(nn.Module):
         _lib.check(st, "ias_voice_render")
         return audio
 
+    def control_debug(self, params01=None):
+        """Control-rate intermediates [B,10,Tc] (envelopes, LFO phases, LFO outputs) for tests."""
+        c = self.synthconfig
+        p = (self.params01 if params01 is None else params01).detach().to(torch.float32).contiguous()
+        lib = _lib.load()
+        ctrl = torch.empty((c.batch_size, 5, c.control_buffer_size), dtype=torch.float32, device=p.device)
+        vconst = torch.empty((c.batch_size, 16), dtype=torch.float32, device=p.device)
+        dbg = torch.empty((c.batch_size, 10, c.control_buffer_size), dtype=torch.float32, device=p.device)
+        st = lib.ias_voice_control_debug(_lib.ptr(p), _lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(dbg), c.batch_size,
+                                         c.control_buffer_size, c.control_rate, _lib.stream())
+        _lib.check(st, "ias_voice_control_debug")
+        return dbg
+
     def control_signals(self, params01=None):
         """Mod-matrix outputs [B,5,Tc] of the control-rate kernel (diagnostics / tests)."""
         c = self.synthconfig

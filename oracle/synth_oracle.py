@@ -17,10 +17,16 @@ linear/align_corners).  Two math modes:
 
 * ``math="torch"``  transcendental ops (pow/exp2/log2/cos at control rate, exp2 at
   audio rate) are the fp32 torch CPU ops (SLEEF, <=1 ulp, CPU-ISA dependent).
-* ``math="cr"``     the same ops evaluated in float64 and rounded once to fp32
-  ("correctly rounded" fp32 op).  This is the bit-reproducible definition the HIP
-  kernels implement; the difference between the two modes is the irreducible
-  libm-to-libm spread of the reference itself (quantified in tests and DESIGN.md).
+* ``math="cr"``     a fully specified, host-independent arithmetic: transcendental
+  ops are evaluated in float64 and rounded once to fp32 ("correctly rounded"),
+  the small matmuls / sums that feed the oscillator phase (LFO shape mix, LFO mode
+  normalisation, mod matrix) are float64-accumulated dot products rounded once
+  (torch's fp32 BLAS / vectorised reductions round differently from host to host),
+  the linear upsample is written out as fl(fl(w0*a)+fl(w1*b)) and the final mixer
+  as a left-to-right mul/add chain.  This is the bit-reproducible definition the
+  HIP kernels implement; the difference between the two modes is the irreducible
+  libm-to-libm / BLAS-to-BLAS spread of the reference itself (quantified in tests
+  and DESIGN.md).
 """
 import math
 
@@ -70,6 +76,33 @@ class _Math:
 
     def cos(self, x):
         return self._u(torch.cos, x)
+
+    def matmul(self, a, b):
+        """Small dot products on the phase path: fp64 accumulate, round once (cr)."""
+        return self._u(torch.matmul, a, b)
+
+    def sum1(self, x):
+        if self.cr:
+            return torch.sum(x.double(), dim=1, keepdim=True).float()
+        return torch.sum(x, dim=1, keepdim=True)
+
+    def cumsum1(self, x):
+        if self.cr:
+            return torch.cumsum(x.double(), dim=1).float()
+        return torch.cumsum(x, dim=1)  # torch CPU accumulates fp32 cumsum in double as well
+
+    def upsample(self, ctrl, cfg):
+        """nn.Upsample(size=T, mode="linear", align_corners=True) on [B,C,Tc]."""
+        if not self.cr:
+            return torch.nn.Upsample(size=cfg.buffer_size, mode="linear", align_corners=True)(ctrl)
+        Tc, T = ctrl.shape[-1], cfg.buffer_size
+        scale = torch.tensor(float(Tc - 1), dtype=torch.float32) / torch.tensor(float(T - 1), dtype=torch.float32)
+        real = scale * torch.arange(T, dtype=torch.float32)
+        i0 = torch.clamp(torch.floor(real).long(), max=Tc - 1)
+        i1 = i0 + (i0 < Tc - 1).long()
+        w1 = torch.clamp(real - i0.float(), 0.0, 1.0)
+        w0 = 1.0 - w1
+        return w0 * ctrl[..., i0] + w1 * ctrl[..., i1]
 
 
 # --------------------------------------------------------------------- parameters
@@ -171,10 +204,10 @@ def adsr(cfg, m, p, mod, note_on):
     return a * d * r
 
 
-def lfo(cfg, m, p, mod, rate_env):
+def lfo(cfg, m, p, mod, rate_env, return_phase=False):
     freq = p(mod, "frequency").unsqueeze(1)
     freq = torch.maximum(freq + p(mod, "mod_depth").unsqueeze(1) * rate_env, torch.tensor(0.0))
-    arg = torch.cumsum(TWO_PI * freq / cfg.control_rate, dim=1)
+    arg = m.cumsum1(TWO_PI * freq / cfg.control_rate)
     arg = arg + p(mod, "initial_phase").unsqueeze(1)
     cos = m.cos(arg + math.pi)
     square = torch.sign(cos)
@@ -187,12 +220,15 @@ def lfo(cfg, m, p, mod, rate_env):
     shapes = torch.stack([cos, tri, saw, revsaw, square], dim=1)
     mode = torch.stack([p(mod, s) for s in S.LFO_SHAPES], dim=1)
     mode = m.pow(mode, torch.tensor(S.LFO_EXPONENT))
-    mode = mode / torch.sum(mode, dim=1, keepdim=True)
-    return torch.matmul(mode.unsqueeze(1), shapes).squeeze(1)
+    mode = mode / m.sum1(mode)
+    out = m.matmul(mode.unsqueeze(1), shapes).squeeze(1)
+    return (out, arg) if return_phase else out
 
 
-def control_signals(cfg, params01, math_mode="torch"):
-    """-> (ctrl [B,5,Tc] fp32 mod-matrix outputs, p) ; order = S.MOD_OUTPUTS."""
+def control_signals(cfg, params01, math_mode="torch", return_debug=False):
+    """-> (ctrl [B,5,Tc] fp32 mod-matrix outputs, p) ; order = S.MOD_OUTPUTS.
+    return_debug adds [B,10,Tc]: adsr_1, adsr_2, lfo_1_amp, lfo_2_amp, lfo_1_rate, lfo_2_rate,
+    lfo_1 phase, lfo_2 phase, lfo_1 out, lfo_2 out."""
     m = _Math(math_mode)
     p = _P(params01, m)
     note_on = p("keyboard", "duration")
@@ -200,14 +236,19 @@ def control_signals(cfg, params01, math_mode="torch"):
     lfo_2_rate = adsr(cfg, m, p, "lfo_2_rate_adsr", note_on)
     lfo_1_amp = adsr(cfg, m, p, "lfo_1_amp_adsr", note_on)
     lfo_2_amp = adsr(cfg, m, p, "lfo_2_amp_adsr", note_on)
-    lfo_1 = lfo(cfg, m, p, "lfo_1", lfo_1_rate) * lfo_1_amp
-    lfo_2 = lfo(cfg, m, p, "lfo_2", lfo_2_rate) * lfo_2_amp
+    lfo_1, ph_1 = lfo(cfg, m, p, "lfo_1", lfo_1_rate, True)
+    lfo_2, ph_2 = lfo(cfg, m, p, "lfo_2", lfo_2_rate, True)
+    lfo_1 = lfo_1 * lfo_1_amp
+    lfo_2 = lfo_2 * lfo_2_amp
     adsr_1 = adsr(cfg, m, p, "adsr_1", note_on)
     adsr_2 = adsr(cfg, m, p, "adsr_2", note_on)
     w = torch.stack([p("mod_matrix", f"{i}->{o}") for i in S.MOD_INPUTS for o in S.MOD_OUTPUTS], dim=1)
     w = w.reshape(-1, len(S.MOD_INPUTS), len(S.MOD_OUTPUTS)).swapaxes(1, 2)
     mod = torch.stack([adsr_1, adsr_2, lfo_1, lfo_2], dim=1)
-    return torch.matmul(w, mod), p
+    if return_debug:
+        dbg = torch.stack([adsr_1, adsr_2, lfo_1_amp, lfo_2_amp, lfo_1_rate, lfo_2_rate, ph_1, ph_2, lfo_1, lfo_2], 1)
+        return m.matmul(w, mod), p, dbg
+    return m.matmul(w, mod), p
 
 
 # -------------------------------------------------------------------- audio rate
@@ -221,7 +262,7 @@ def vco_phase(cfg, m, p, mod, midi_f0, pitch_mod):
     f0 = (midi_f0 + p(mod, "tuning")).unsqueeze(1)
     control = torch.clamp(f0 + p(mod, "mod_depth").unsqueeze(1) * pitch_mod, 0.0, 127.0)
     hz = midi_to_hz(control, m)
-    arg = torch.cumsum(TWO_PI * hz / cfg.sample_rate, dim=1)
+    arg = m.cumsum1(TWO_PI * hz / cfg.sample_rate)
     return arg + p(mod, "initial_phase").unsqueeze(1)
 
 
@@ -229,8 +270,7 @@ def render_from_params01(cfg, params01, noise, math_mode="torch", return_parts=F
     """Voice.output() for explicit normalised parameters -> audio [B,T] fp32."""
     ctrl, p = control_signals(cfg, params01, math_mode)
     m = _Math(math_mode)
-    up = torch.nn.Upsample(size=cfg.buffer_size, mode="linear", align_corners=True)
-    upc = up(ctrl)  # [B,5,T]
+    upc = m.upsample(ctrl, cfg)  # [B,5,T]
     midi_f0 = p("keyboard", "midi_f0")
 
     arg1 = vco_phase(cfg, m, p, "vco_1", midi_f0, upc[:, 0])
@@ -247,8 +287,11 @@ def render_from_params01(cfg, params01, noise, math_mode="torch", return_parts=F
     noise_out = noise * upc[:, 4]
 
     lv = torch.stack([p("mixer", "vco_1"), p("mixer", "vco_2"), p("mixer", "noise")], dim=1)
-    sig = torch.stack([vco_1, vco_2, noise_out], dim=1)
-    mixed = torch.matmul(lv.unsqueeze(1), sig).squeeze(1)
+    if m.cr:
+        mixed = lv[:, 0:1] * vco_1 + lv[:, 1:2] * vco_2 + lv[:, 2:3] * noise_out
+    else:
+        sig = torch.stack([vco_1, vco_2, noise_out], dim=1)
+        mixed = torch.matmul(lv.unsqueeze(1), sig).squeeze(1)
     peak = torch.max(torch.abs(mixed), dim=1, keepdim=True)[0]
     audio = torch.where(peak > 1.0, mixed / peak, mixed)
     if return_parts:

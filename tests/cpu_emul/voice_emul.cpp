@@ -48,10 +48,8 @@ extern "C" int emul_voice_render(const float* params01, const float* noise, floa
     const float* w = p + IAS_P_MOD_MATRIX_ADSR_1_TO_VCO_1_PITCH;  // [input k][output j]
     for (int j = 0; j < 5; ++j)
       for (int t = 0; t < Tc; ++t) {
-        float o = ias_mul(w[0 * 5 + j], env[0 * Tc + t]);
-        o = ias_fma(w[1 * 5 + j], env[1 * Tc + t], o);
-        o = ias_fma(w[2 * 5 + j], lfo[0 * Tc + t], o);
-        o = ias_fma(w[3 * 5 + j], lfo[1 * Tc + t], o);
+        const float o = ias_dot4_cr(w[0 * 5 + j], w[1 * 5 + j], w[2 * 5 + j], w[3 * 5 + j],
+                                    env[0 * Tc + t], env[1 * Tc + t], lfo[0 * Tc + t], lfo[1 * Tc + t]);
         ctrl[j * Tc + t] = o;
       }
     if (ctrl_out) memcpy(ctrl_out + (size_t)b * 5 * Tc, ctrl.data(), sizeof(float) * 5 * Tc);

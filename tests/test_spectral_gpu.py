@@ -1,0 +1,97 @@
+"""HIP STFT / mel / spectral losses vs the oracle (torch.stft based), through the C ABI.
+Tolerances: spectral loss 1e-3 relative (BASELINE.json north_star); spectrogram values 1e-4 of the
+spectrogram's max (fp32 FFT vs torch's fp32 FFT)."""
+import pytest
+import torch
+
+from oracle import spectral_oracle as spo
+from helpers import randn
+
+pytestmark = pytest.mark.gpu
+LOSS_RTOL = 1e-3
+
+
+def _close_to_scale(a, ref, tol=1e-4):
+    scale = ref.abs().max().item()
+    err = (a - ref).abs().max().item()
+    assert err <= tol * scale, f"max err {err} vs scale {scale}"
+
+
+@pytest.mark.parametrize("B,T,sr", [(4, 16000, 16000), (2, 176400, 44100), (3, 5001, 22050)])
+def test_mel_spectrogram(lib, dev, B, T, sr):
+    from inverse_audio_synthesis_amd.spectral import MelSpectrogram
+    x = randn((B, T), 31 + B) * 0.3
+    ref = spo.mel_spectrogram(x, sample_rate=sr)
+    mel = MelSpectrogram(sample_rate=sr).to(dev)
+    out = mel(x.to(dev))
+    assert out.shape == ref.shape
+    _close_to_scale(out.cpu(), ref)
+    assert torch.equal(mel.plan.fb.cpu(), spo.melscale_fbanks(513, 0.0, float(sr // 2), 128, sr))
+
+
+@pytest.mark.parametrize("n_fft,hop,win,power", [(512, 50, 240, 1.0), (1024, 120, 600, 2.0), (2048, 240, 1200, 1.0),
+                                                 (1024, 512, None, 2.0), (2048, 2048, None, 2.0), (512, 77, 300, 2.0)])
+def test_raw_stft_all_sizes(lib, dev, n_fft, hop, win, power):
+    from inverse_audio_synthesis_amd.spectral import STFTPlan, VALUE_MAG, VALUE_POWER
+    x = randn((3, 20000), 7) * 0.5
+    ref = spo.spectrogram(x, n_fft, win, hop, power)  # [B, bins, frames]
+    plan = STFTPlan(n_fft, win, hop).to(dev)
+    out = plan.values(x.to(dev), VALUE_POWER if power == 2.0 else VALUE_MAG).transpose(1, 2)
+    assert out.shape == ref.shape
+    _close_to_scale(out.cpu(), ref)
+
+
+def test_mel_l1_loss(lib, dev):
+    from inverse_audio_synthesis_amd.spectral import MelSpectrogramL1
+    a, b = randn((4, 16000), 1) * 0.2, randn((4, 16000), 2) * 0.3
+    loss = MelSpectrogramL1(sample_rate=16000).to(dev)
+    got = loss(a.to(dev), b.to(dev)).item()
+    ref = spo.mel_l1(a, b, sample_rate=16000).item()
+    assert abs(got - ref) <= LOSS_RTOL * abs(ref)
+    # cached-target form gives the same value
+    tm = loss.target(b.to(dev))
+    assert loss(a.to(dev), target_mel=tm).item() == got
+
+
+def test_stft_l1_and_mrstft(lib, dev):
+    from inverse_audio_synthesis_amd.spectral import STFTL1, MultiResolutionSTFTLoss
+    a, b = randn((4, 16000), 3) * 0.2, randn((4, 16000), 4) * 0.25
+    got = STFTL1().to(dev)(a.to(dev), b.to(dev)).item()
+    ref = spo.stft_l1(a, b).item()
+    assert abs(got - ref) <= LOSS_RTOL * abs(ref)
+    got = MultiResolutionSTFTLoss().to(dev)(a.to(dev), b.to(dev)).item()
+    ref = spo.mrstft_loss(a, b)[0].item()
+    assert abs(got - ref) <= LOSS_RTOL * abs(ref)
+
+
+def test_short_and_ragged_inputs(lib, dev):
+    from inverse_audio_synthesis_amd.spectral import MelSpectrogram
+    mel = MelSpectrogram(sample_rate=16000).to(dev)
+    for T in (513, 600, 1023, 1024, 1025, 4097):
+        x = randn((2, T), T)
+        ref = spo.mel_spectrogram(x, sample_rate=16000)
+        out = mel(x.to(dev))
+        assert out.shape == ref.shape
+        _close_to_scale(out.cpu(), ref)
+    with pytest.raises(RuntimeError):
+        mel(torch.zeros(1, 512, device=dev))  # reflect padding needs T > n_fft/2
+
+
+def test_full_size_properties(lib, dev):
+    """BASELINE size 128 x 176400: loss(a,a)=0, power-2 mel is 2-homogeneous, loss is symmetric."""
+    from inverse_audio_synthesis_amd.spectral import MelSpectrogramL1
+    g = torch.Generator(device="cpu").manual_seed(9)
+    a = (torch.rand((128, 176400), generator=g) - 0.5).to(dev)
+    b = (torch.rand((128, 176400), generator=g) - 0.5).to(dev)
+    loss = MelSpectrogramL1().to(dev)
+    ma = loss.target(a)
+    assert ma.shape == (128, 345, 128)
+    assert loss(a, target_mel=ma).item() == 0.0
+    m2 = loss.target(2.0 * a)
+    assert (m2 - 4.0 * ma).abs().max().item() <= 1e-4 * ma.abs().max().item()
+    lab, lba = loss(a, b).item(), loss(b, a).item()
+    assert abs(lab - lba) <= 1e-6 * abs(lab)
+    # rows are independent: the first 4 rows alone give the same mel
+    assert torch.equal(loss.target(a[:4]), ma[:4])
+    ref = spo.mel_spectrogram(a[:2].cpu())
+    _close_to_scale(ma[:2].transpose(1, 2).cpu(), ref)
