@@ -17,7 +17,7 @@
 
 #define SP_THREADS 256
 #define SP_WAVES 4
-#define SP_FPB 8   // frames per workgroup
+#define SP_FPB_MAX 8   // frames per workgroup (8, or 4 when the staged span would not fit LDS)
 
 struct cpx { float x, y; };
 __device__ __forceinline__ cpx cmk(float x, float y) { cpx r; r.x = x; r.y = y; return r; }
@@ -96,7 +96,7 @@ struct SpecArgs {
   float eps;
 };
 
-template <int LOG2N>
+template <int LOG2N, int SP_FPB>
 __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
   constexpr int NFFT = 1 << LOG2N, N2 = NFFT / 2, R = N2 / 64, NPAIR = 8 * R, NP_IT = (NPAIR + 63) / 64;
   constexpr int SCR = NPAIR * 9;   // padded [k1*8+c][9] complex scratch
@@ -259,10 +259,21 @@ extern "C" int ias_stft_num_frames(int T, int n_fft, int hop) {
   return 1 + T / hop;   // center=True: 1 + (T + 2*(n_fft/2) - n_fft) / hop
 }
 
+static size_t stft_lds_bytes(int n_fft, int hop, int fpb) {
+  const int R = n_fft / 128, scr = 8 * R * 9;
+  const int span = (fpb - 1) * hop + n_fft;
+  return sizeof(float) * n_fft + sizeof(float2) * n_fft + sizeof(float) * ((span + 3) & ~3) +
+         sizeof(cpx) * SP_WAVES * 2 * scr;
+}
+static int stft_fpb(int n_fft, int hop) {
+  return stft_lds_bytes(n_fft, hop, SP_FPB_MAX) <= 80 * 1024 ? SP_FPB_MAX : 4;
+}
+
 extern "C" long long ias_stft_partials_count(int B, int T, int n_fft, int hop) {
   const int F = ias_stft_num_frames(T, n_fft, hop);
   if (F < 0 || B <= 0) return IAS_ERR_ARG;
-  return (long long)B * ((F + SP_FPB - 1) / SP_FPB);
+  const int fpb = stft_fpb(n_fft, hop);
+  return (long long)B * ((F + fpb - 1) / fpb);
 }
 
 // Framed STFT of audio [B,T] (hann/any window [n_fft], center=True, reflect pad), per-bin value by
@@ -296,26 +307,23 @@ extern "C" int ias_stft(const float* audio, const float* window, const float* tw
   a.T = T; a.F = F; a.hop = hop; a.n_out = n_out;
   a.value_mode = value_mode; a.loss_mode = loss_mode; a.eps = eps;
 
-  const int N2 = n_fft / 2, R = N2 / 64, scr = 8 * R * 9;
-  const int span = (SP_FPB - 1) * hop + n_fft;
-  const size_t lds = sizeof(float) * n_fft + sizeof(float2) * n_fft + sizeof(float) * ((span + 3) & ~3) +
-                     sizeof(cpx) * SP_WAVES * 2 * scr;
+  const int fpb = stft_fpb(n_fft, hop);
+  const size_t lds = stft_lds_bytes(n_fft, hop, fpb);
   if (lds > 150 * 1024) return IAS_ERR_UNSUPPORTED;
-  const dim3 grid((F + SP_FPB - 1) / SP_FPB, B), block(SP_THREADS);
-  switch (n_fft) {
-    case 512:
-      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)stft_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(stft_kernel<9>, grid, block, lds, stream, a);
-      break;
-    case 1024:
-      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)stft_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(stft_kernel<10>, grid, block, lds, stream, a);
-      break;
-    default:
-      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)stft_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(stft_kernel<11>, grid, block, lds, stream, a);
-      break;
+  const dim3 grid((F + fpb - 1) / fpb, B), block(SP_THREADS);
+#define IAS_STFT_LAUNCH(LOG2N, FPB)                                                                              \
+  do {                                                                                                           \
+    if (lds > 64 * 1024)                                                                                         \
+      (void)hipFuncSetAttribute((const void*)stft_kernel<LOG2N, FPB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                       \
+    hipLaunchKernelGGL((stft_kernel<LOG2N, FPB>), grid, block, lds, stream, a);                                  \
+  } while (0)
+  if (fpb == 8) {
+    if (n_fft == 512) IAS_STFT_LAUNCH(9, 8); else if (n_fft == 1024) IAS_STFT_LAUNCH(10, 8); else IAS_STFT_LAUNCH(11, 8);
+  } else {
+    if (n_fft == 512) IAS_STFT_LAUNCH(9, 4); else if (n_fft == 1024) IAS_STFT_LAUNCH(10, 4); else IAS_STFT_LAUNCH(11, 4);
   }
+#undef IAS_STFT_LAUNCH
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
