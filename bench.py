@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds rendered+lossed per second (BASELINE.json metric).
+
+One step = one pass of the hot path over one batch resident in HBM:
+    Voice render (78 params -> [B,T] audio)  ->  PQMF(3) analysis  ->  mel-spectrogram L1 vs a cached
+    target mel, at BASELINE config #2: batch 128 x 4 s @ 44.1 kHz per GPU (weak scaling: every rank
+    renders its own batch, seeds 1000+rank / 2000+rank; no data-path collective).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line with the driver's contract fields plus "roofline" (dominant kernel,
+HIP-event timed inside the timed region) and "cpu_baseline" (the oracle timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured float4-copy rate
+SAMPLE_RATE, SECONDS, BATCH = 44100, 4.0, 128
+# Algorithmic HBM bytes per audio sample: render = 4 B noise read + 4 B audio write.
+RENDER_BYTES_PER_SAMPLE = 8
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8, help="voices in the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(cpu_batch):
+    """The oracle (torch-CPU restatement, math="torch": the ops the reference would issue) timed on the
+    host cores over a bounded sample of the same workload: render + PQMF(3) + mel-L1 of cpu_batch voices."""
+    from oracle import pqmf_oracle as po
+    from oracle import spectral_oracle as spo
+    from oracle import synth_oracle as so
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = so.VoiceConfig(batch_size=cpu_batch, sample_rate=SAMPLE_RATE, buffer_size_seconds=SECONDS)
+    noise = so.make_noise(cfg)
+    g = torch.Generator().manual_seed(1000)
+    params = torch.rand(cpu_batch, 78, generator=g)
+    tgt = so.render_from_params01(cfg, torch.rand(cpu_batch, 78, generator=torch.Generator().manual_seed(2000)),
+                                  noise, "torch")
+    tgt_mel = spo.mel_spectrogram(tgt, sample_rate=SAMPLE_RATE)
+    H, _, _ = po.design(3)
+
+    def step():
+        audio = so.render_from_params01(cfg, params, noise, "torch")
+        z = po.analysis(audio.unsqueeze(1), H, 3, 62)
+        loss = torch.mean(torch.abs(spo.mel_spectrogram(audio, sample_rate=SAMPLE_RATE) - tgt_mel))
+        return z, loss
+
+    step()  # warm-up (thread pool, allocator)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 50:
+            break
+    return {
+        "value": round(cpu_batch * SECONDS * reps / el, 2),
+        "unit": "audio-s/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{reps} passes of render+PQMF(3)+mel-L1 over {cpu_batch} voices x {SECONDS:g} s @ {SAMPLE_RATE} Hz "
+                  f"(oracle, torch CPU ops, {el:.1f} s)",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from inverse_audio_synthesis_amd import _lib
+    from inverse_audio_synthesis_amd.pqmf import PQMF
+    from inverse_audio_synthesis_amd.spectral import MelSpectrogramL1
+    from inverse_audio_synthesis_amd.voice import SynthConfig, Voice
+    _lib.load()
+
+    B = args.batch
+    cfg = SynthConfig(batch_size=B, sample_rate=SAMPLE_RATE, buffer_size_seconds=SECONDS, reproducible=False)
+    T = cfg.buffer_size
+    voice = Voice(cfg).to(dev)
+    gram = PQMF(N=3).to(dev)
+    mel_l1 = MelSpectrogramL1(sample_rate=SAMPLE_RATE).to(dev)
+    params = torch.rand(B, 78, generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
+    tgt_params = torch.rand(B, 78, generator=torch.Generator().manual_seed(2000 + rank)).to(dev)
+    target_mel = mel_l1.target(voice.render(tgt_params)).clone()
+    voice.set_parameters01(params)
+
+    ev = {"begin": [], "end": []}
+    instrument = {"on": False}
+
+    def hook(name, phase):
+        if instrument["on"] and name == "oscillators":
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev[phase].append(e)
+
+    def step():
+        audio = voice.render_staged(on_stage=hook)
+        z = gram(audio.unsqueeze(1))
+        loss = mel_l1(audio, target_mel=target_mel)
+        return audio, z, loss
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- warm-up (eager), optional hipGraph capture of one step
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    launch = "eager"
+    graph = None
+    if not args.no_graph:
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = step()
+            graph.replay()
+            torch.cuda.synchronize()
+            launch = "hipgraph"
+        except Exception as e:  # noqa: BLE001 -- report and fall back to eager launches
+            sys.stderr.write(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly\n")
+            graph = None
+            torch.cuda.synchronize()
+
+    run = graph.replay if graph is not None else step
+
+    # ---- timed region: EXACTLY K steps between barrier+synchronize brackets
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    loss_value = out[2].item()
+
+    # ---- dominant-kernel timing with HIP events on the launch stream (eager pass over K steps:
+    # events cannot be read back from inside a replayed graph)
+    instrument["on"] = True
+    torch.cuda.synchronize()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    instrument["on"] = False
+    osc_ms = [b.elapsed_time(e) for b, e in zip(ev["begin"], ev["end"])]
+    osc_ms_avg = sum(osc_ms) / len(osc_ms)
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * SECONDS * args.steps / elapsed
+    algo_bytes = RENDER_BYTES_PER_SAMPLE * B * T
+    achieved = algo_bytes / (osc_ms_avg * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("voice_audio_kernel<1>", {}).get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+
+    result = {
+        "metric": "audio-seconds rendered+lossed/sec (whole node), batch=128 4s@44.1kHz",
+        "value": round(value, 1),
+        "unit": "audio-s/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: torchsynth-style Voice render + PQMF(3) analysis + mel-L1 loss, "
+                        f"batch {B} x {SECONDS:g} s @ {SAMPLE_RATE} Hz per GPU",
+            "batch_per_gpu": B, "samples_per_voice": T, "launch": launch, "loss": loss_value,
+        },
+        "roofline": {
+            "kernel": "voice_audio_kernel<1> (scan + oscillators + mixer)",
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "avg_launch_ms": round(osc_ms_avg, 4), "algorithmic_bytes_per_launch": algo_bytes,
+        },
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,6 +49,12 @@ int ias_voice_render(const float* params01, const float* noise, float* audio, vo
                      long long workspace_bytes, int B, int T, int Tc, int sample_rate, int control_rate,
                      int normalize, void* stream);
 
+/* One stage of ias_voice_render on a workspace ias_voice_control(params01, ws.ctrl, ws.vconst) has
+ * filled (ias_voice_render = control + stages 0,1[,2]): 0 per-tile fp64 phase sums, 1 scan +
+ * oscillators + mixer -> unnormalised audio and row peaks, 2 normalize_if_clipping in place. */
+int ias_voice_stage(int stage, const float* noise, float* audio, void* workspace, long long workspace_bytes,
+                    int B, int T, int Tc, int sample_rate, void* stream);
+
 /* Copy the B row peaks (max |x| before normalisation) of the last render out of the workspace. */
 int ias_voice_read_peaks(const void* workspace, float* peaks, int B, int T, int Tc, void* stream);
 

@@ -30,6 +30,7 @@ SYMBOLS = {
     "ias_voice_control": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ias_voice_control_debug": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ias_voice_render": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _P]),
+    "ias_voice_stage": (_I, [_I, _P, _P, _P, _LL, _I, _I, _I, _I, _P]),
     "ias_voice_read_peaks": (_I, [_P, _P, _I, _I, _I, _P]),
     "ias_pqmf_out_len": (_I, [_I, _I, _I]),
     "ias_pqmf_analysis": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -371,31 +371,33 @@ extern "C" int ias_voice_control_debug(const float* params01, float* ctrl, void*
   return voice_control_launch(params01, ctrl, vconst, dbg, B, Tc, control_rate, stream_);
 }
 
-extern "C" int ias_voice_render(const float* params01, const float* noise, float* audio, void* workspace,
-                                long long workspace_bytes, int B, int T, int Tc, int sample_rate,
-                                int control_rate, int normalize, void* stream_) {
+// One stage of the render on an already-filled workspace (ias_voice_control must have run into it):
+//   stage 0: per-tile fp64 phase sums      (voice_audio_kernel<0>)
+//   stage 1: scan + oscillators + mixer -> unnormalised audio, row peaks (voice_audio_kernel<1>)
+//   stage 2: normalize_if_clipping in place (voice_normalize_kernel)
+extern "C" int ias_voice_stage(int stage, const float* noise, float* audio, void* workspace,
+                               long long workspace_bytes, int B, int T, int Tc, int sample_rate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!params01 || !noise || !audio || !workspace || sample_rate <= 0 || control_rate <= 0) return IAS_ERR_ARG;
+  if (!noise || !audio || !workspace || sample_rate <= 0 || stage < 0 || stage > 2) return IAS_ERR_ARG;
   int rc = voice_check_dims(B, T, Tc);
   if (rc) return rc;
   const VoiceWs w = voice_ws_layout(B, T, Tc);
   if ((size_t)workspace_bytes < w.total) return IAS_ERR_WORKSPACE;
   char* ws = (char*)workspace;
-  float* ctrl = (float*)(ws + w.off_ctrl);
-  IasVoiceConst* vconst = (IasVoiceConst*)(ws + w.off_vconst);
+  const float* ctrl = (const float*)(ws + w.off_ctrl);
+  const IasVoiceConst* vconst = (const IasVoiceConst*)(ws + w.off_vconst);
   double* tilesum = (double*)(ws + w.off_tilesum);
   unsigned* peak = (unsigned*)(ws + w.off_peak);
-
-  rc = ias_voice_control(params01, ctrl, vconst, B, Tc, control_rate, stream_);
-  if (rc) return rc;
-  if (hipMemsetAsync(peak, 0, sizeof(unsigned) * (size_t)B, stream) != hipSuccess) return IAS_ERR_LAUNCH;
   const float scale = (float)(Tc - 1) / (float)(T - 1);
   const dim3 grid(w.ntiles, B), block(VOICE_THREADS);
-  hipLaunchKernelGGL(voice_audio_kernel<0>, grid, block, 0, stream, ctrl, vconst, noise, audio, tilesum, peak,
-                     T, Tc, w.ntiles, (float)sample_rate, scale);
-  hipLaunchKernelGGL(voice_audio_kernel<1>, grid, block, 0, stream, ctrl, vconst, noise, audio, tilesum, peak,
-                     T, Tc, w.ntiles, (float)sample_rate, scale);
-  if (normalize) {
+  if (stage == 0) {
+    hipLaunchKernelGGL(voice_audio_kernel<0>, grid, block, 0, stream, ctrl, vconst, noise, audio, tilesum, peak,
+                       T, Tc, w.ntiles, (float)sample_rate, scale);
+  } else if (stage == 1) {
+    if (hipMemsetAsync(peak, 0, sizeof(unsigned) * (size_t)B, stream) != hipSuccess) return IAS_ERR_LAUNCH;
+    hipLaunchKernelGGL(voice_audio_kernel<1>, grid, block, 0, stream, ctrl, vconst, noise, audio, tilesum, peak,
+                       T, Tc, w.ntiles, (float)sample_rate, scale);
+  } else {
     const int nvec = T / 4;
     int gx = (nvec + 255) / 256;
     if (gx > 64) gx = 64;
@@ -403,6 +405,21 @@ extern "C" int ias_voice_render(const float* params01, const float* noise, float
     hipLaunchKernelGGL(voice_normalize_kernel, dim3(gx, B), dim3(256), 0, stream, audio, peak, T, nvec);
   }
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+extern "C" int ias_voice_render(const float* params01, const float* noise, float* audio, void* workspace,
+                                long long workspace_bytes, int B, int T, int Tc, int sample_rate,
+                                int control_rate, int normalize, void* stream_) {
+  if (!params01 || !noise || !audio || !workspace || sample_rate <= 0 || control_rate <= 0) return IAS_ERR_ARG;
+  int rc = voice_check_dims(B, T, Tc);
+  if (rc) return rc;
+  const VoiceWs w = voice_ws_layout(B, T, Tc);
+  if ((size_t)workspace_bytes < w.total) return IAS_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  rc = ias_voice_control(params01, (float*)(ws + w.off_ctrl), ws + w.off_vconst, B, Tc, control_rate, stream_);
+  for (int stage = 0; stage < (normalize ? 3 : 2) && rc == IAS_OK; ++stage)
+    rc = ias_voice_stage(stage, noise, audio, workspace, workspace_bytes, B, T, Tc, sample_rate, stream_);
+  return rc;
 }
 
 // Row peaks (|x| max before normalisation) of the last render, for tests/diagnostics.

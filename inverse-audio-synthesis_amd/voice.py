@@ -164,6 +164,33 @@ class Voice(nn.Module):
         _lib.check(st, "ias_voice_render")
         return audio
 
+    def render_staged(self, params01=None, on_stage=None):
+        """The same render issued stage by stage (control, phase sums, oscillators, normalise);
+        ``on_stage(name, phase)`` is called with phase "begin"/"end" around each (bench event hooks)."""
+        c = self.synthconfig
+        p = (self.params01 if params01 is None else params01).detach().to(torch.float32).contiguous()
+        lib = _lib.load()
+        need = int(lib.ias_voice_workspace_bytes(c.batch_size, c.buffer_size, c.control_buffer_size))
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != p.device:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=p.device)
+        ws = self._workspace
+        audio = torch.empty((c.batch_size, c.buffer_size), dtype=torch.float32, device=p.device)
+        hook = on_stage or (lambda name, phase: None)
+        # workspace layout: ctrl first, vconst second (csrc/voice_kernels.hip voice_ws_layout)
+        ctrl_bytes = (4 * c.batch_size * 5 * c.control_buffer_size + 255) // 256 * 256
+        hook("control", "begin")
+        st = lib.ias_voice_control(_lib.ptr(p), _lib.ptr(ws), _lib.ptr(ws[ctrl_bytes:]), c.batch_size,
+                                   c.control_buffer_size, c.control_rate, _lib.stream())
+        _lib.check(st, "ias_voice_control")
+        hook("control", "end")
+        for stage, name in enumerate(("phase_sums", "oscillators", "normalize")):
+            hook(name, "begin")
+            st = lib.ias_voice_stage(stage, _lib.ptr(self.noise), _lib.ptr(audio), _lib.ptr(ws), ws.numel(),
+                                     c.batch_size, c.buffer_size, c.control_buffer_size, c.sample_rate, _lib.stream())
+            _lib.check(st, f"ias_voice_stage({name})")
+            hook(name, "end")
+        return audio
+
     def control_debug(self, params01=None):
         """Control-rate intermediates [B,10,Tc] (envelopes, LFO phases, LFO outputs) for tests."""
         c = self.synthconfig
