@@ -97,6 +97,20 @@ int ias_stft(const float* audio, const float* window, const float* twiddle, cons
 /* sums[3] (doubles) = column sums of partials [n][3], fixed order (deterministic). */
 int ias_reduce_partials(const double* partials, long long n, double* sums, void* stream);
 
+/* ---- VICReg loss: reference vicreg.py:35-58 (VICReg.loss) and :73-76 (off_diagonal). */
+
+/* Workspace bytes for ias_vicreg_loss (bf16 transposed centred copies, column stats, partials). */
+long long ias_vicreg_workspace_bytes(int B, int D);
+
+/* Byte offset inside that workspace of colstats [4][D] fp32 (mean_x, mean_y, sum (x-mean)^2, same for y),
+ * valid after ias_vicreg_loss. */
+long long ias_vicreg_colstats_offset(int B, int D);
+
+/* x, y [B,D] fp32 -> out[4] = (loss, repr_loss, std_loss, cov_loss).  cfg_batch: the CONFIGURED batch
+ * size whose (cfg_batch - 1) divides the covariance (vicreg.py:47-48 reads it from cfg, not from x). */
+int ias_vicreg_loss(const float* x, const float* y, float* out, void* workspace, long long workspace_bytes,
+                    int B, int D, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

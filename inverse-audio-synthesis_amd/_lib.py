@@ -39,6 +39,9 @@ SYMBOLS = {
     "ias_stft_partials_count": (_LL, [_I, _I, _I, _I]),
     "ias_stft": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "ias_reduce_partials": (_I, [_P, _LL, _P, _P]),
+    "ias_vicreg_workspace_bytes": (_LL, [_I, _I]),
+    "ias_vicreg_colstats_offset": (_LL, [_I, _I]),
+    "ias_vicreg_loss": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
 }
 
 _lib = None

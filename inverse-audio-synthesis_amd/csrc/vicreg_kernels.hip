@@ -1,0 +1,302 @@
+// VICReg loss for MI355X (gfx950): invariance MSE + variance hinge + off-diagonal covariance^2.
+//
+// Replaces /root/reference/vicreg.py:35-58 (VICReg.loss) and :73-76 (off_diagonal):
+//   repr = mse(x, y); x -= mean_b(x); std = sqrt(var_unbiased + 1e-4); std_loss = mean(relu(1 - std))/2 (+ y)
+//   cov = x^T x / (cfg.vicreg.batch_size - 1)   <- the CONFIGURED batch size, not x.shape[0]
+//   cov_loss = sum_{i != j} cov_ij^2 / embeddim (+ y);  loss = sim*repr + std*std_loss + cov*cov_loss
+//
+// Kernels
+//   vicreg_colstats_kernel  per 64 columns: column mean (fp32), centred sum of squares, sum (x-y)^2,
+//                           and the centred matrix cast to bf16 and TRANSPOSED to Xt[D][Kpad]
+//                           (feature-major, batch contiguous) through an LDS tile -- centring is done
+//                           in fp32 BEFORE the bf16 cast.
+//   vicreg_gram_kernel      C = Xt Xt^T on the matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate),
+//                           128x128 output tile per workgroup, upper-triangular tiles only (C is
+//                           symmetric: off-diagonal tiles count twice); the D x D matrix is never
+//                           stored: each tile is squared, summed (diagonal elements skipped) and
+//                           reduced to one fp64 partial.
+//   vicreg_finish_kernel    fixed-order reduction of all partials -> (loss, repr, std, cov).
+// The Gram is the one dense contraction of the path: 2*B*D^2 flops nominal per branch
+// (vicreg.py:47-48), of which the symmetric half is executed.
+#include "ias_common.h"
+#include <hip/hip_bf16.h>
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define VC_COLS 64        // columns per colstats workgroup
+#define VC_THREADS 256
+#define GT 128            // gram output tile (GT x GT)
+#define GK 64             // k-chunk staged per iteration
+#define GLD (GK + 8)      // LDS row stride in bf16 (144 B: breaks the 128-B row bank aliasing)
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  return __builtin_bit_cast(unsigned short, __float2bfloat16(f));
+}
+
+// x, y: [B, D] fp32.  Xt_*: [D][Kpad] bf16 (zero padded in k).  colstats: [4][D] = mean_x, mean_y, m2_x, m2_y
+// msepart: [gridDim.x] fp64.
+__global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, unsigned short* __restrict__ Xt_x,
+    unsigned short* __restrict__ Xt_y, float* __restrict__ colstats, double* __restrict__ msepart, int B, int D,
+    int Kpad) {
+  __shared__ float s_red[4][VC_THREADS / 64][VC_COLS];
+  __shared__ float s_mean[2][VC_COLS];
+  __shared__ unsigned short s_tile[2][VC_COLS][64 + 2];
+  __shared__ double s_mse[VC_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j0 = blockIdx.x * VC_COLS, j = j0 + lane;
+  const bool jok = j < D;
+
+  // pass 1: column sums (wave w takes rows w, w+4, ...), sum (x-y)^2
+  float sx = 0.f, sy = 0.f, se = 0.f;
+  for (int b = wave; b < B; b += VC_THREADS / 64) {
+    if (jok) {
+      const float xv = x[(size_t)b * D + j], yv = y[(size_t)b * D + j];
+      sx += xv; sy += yv;
+      const float d = xv - yv;
+      se = fmaf(d, d, se);
+    }
+  }
+  s_red[0][wave][lane] = sx; s_red[1][wave][lane] = sy;
+  // mse: reduce within the wave, then across waves
+  for (int d = 32; d > 0; d >>= 1) se += __shfl_xor(se, d, 64);
+  if (lane == 0) s_mse[wave] = (double)se;
+  __syncthreads();
+  if (wave == 0) {
+    float mx = 0.f, my = 0.f;
+    for (int w = 0; w < VC_THREADS / 64; ++w) { mx += s_red[0][w][lane]; my += s_red[1][w][lane]; }
+    s_mean[0][lane] = mx / (float)B;
+    s_mean[1][lane] = my / (float)B;
+    if (lane == 0) {
+      double m = 0.0;
+      for (int w = 0; w < VC_THREADS / 64; ++w) m += s_mse[w];
+      msepart[blockIdx.x] = m;
+    }
+  }
+  __syncthreads();
+  const float mx = s_mean[0][lane], my = s_mean[1][lane];
+
+  // pass 2: centred sum of squares + bf16 transpose, 64 rows at a time
+  float qx = 0.f, qy = 0.f;
+  for (int b0 = 0; b0 < Kpad; b0 += 64) {
+    for (int r = wave; r < 64; r += VC_THREADS / 64) {
+      const int b = b0 + r;
+      float cx = 0.f, cy = 0.f;
+      if (jok && b < B) {
+        cx = x[(size_t)b * D + j] - mx;
+        cy = y[(size_t)b * D + j] - my;
+        qx = fmaf(cx, cx, qx);
+        qy = fmaf(cy, cy, qy);
+      }
+      s_tile[0][lane][r] = f2bf(cx);
+      s_tile[1][lane][r] = f2bf(cy);
+    }
+    __syncthreads();
+    // write out: 64 columns x 64 k as 128-byte rows; thread -> (column c = tid/4, 16 k values)
+    {
+      const int c = tid >> 2, part = tid & 3;
+      if (j0 + c < D) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          unsigned short* dst = (m == 0 ? Xt_x : Xt_y) + (size_t)(j0 + c) * Kpad + b0 + part * 16;
+          unsigned int pk[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            pk[e] = (unsigned int)s_tile[m][c][part * 16 + 2 * e] | ((unsigned int)s_tile[m][c][part * 16 + 2 * e + 1] << 16);
+          uint4* d4 = reinterpret_cast<uint4*>(dst);
+          d4[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+          d4[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  s_red[2][wave][lane] = qx; s_red[3][wave][lane] = qy;
+  __syncthreads();
+  if (wave == 0 && jok) {
+    float ax = 0.f, ay = 0.f;
+    for (int w = 0; w < VC_THREADS / 64; ++w) { ax += s_red[2][w][lane]; ay += s_red[3][w][lane]; }
+    colstats[0 * (size_t)D + j] = mx;
+    colstats[1 * (size_t)D + j] = my;
+    colstats[2 * (size_t)D + j] = ax;
+    colstats[3 * (size_t)D + j] = ay;
+  }
+}
+
+// One upper-triangular 128x128 tile of C = Xt Xt^T per workgroup; partial[tile] = sum of squares of
+// the tile's off-diagonal elements (x2 for tiles above the diagonal).
+__global__ __launch_bounds__(256) void vicreg_gram_kernel(const unsigned short* __restrict__ Xt,
+                                                          double* __restrict__ partials, int D, int Kpad,
+                                                          int ntile) {
+  __shared__ __attribute__((aligned(16))) unsigned short s_a[GT][GLD];
+  __shared__ __attribute__((aligned(16))) unsigned short s_b[GT][GLD];
+  __shared__ double s_part[4];
+  // linear upper-triangular index -> (ti, tj), ti <= tj
+  int t = blockIdx.x, ti = 0;
+  {
+    int rowlen = ntile;
+    while (t >= rowlen) { t -= rowlen; --rowlen; ++ti; }
+  }
+  const int tj = ti + t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;      // 2 x 2 waves, 64 x 64 each
+  const int r = lane & 31, h = lane >> 5;
+  const int row0 = ti * GT, col0 = tj * GT;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+  for (int k0 = 0; k0 < Kpad; k0 += GK) {
+    // stage A (rows row0..+127) and B (rows col0..+127): 128 rows x 128 B each, 16 B per thread x 4
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (tid >> 3) + 32 * i, ch = tid & 7;
+      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+      if (row0 + rr < D) va = *reinterpret_cast<const uint4*>(Xt + (size_t)(row0 + rr) * Kpad + k0 + ch * 8);
+      if (col0 + rr < D) vb = *reinterpret_cast<const uint4*>(Xt + (size_t)(col0 + rr) * Kpad + k0 + ch * 8);
+      *reinterpret_cast<uint4*>(&s_a[rr][ch * 8]) = va;
+      *reinterpret_cast<uint4*>(&s_b[rr][ch * 8]) = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < GK / 16; ++ks) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        fa[m] = *reinterpret_cast<const bf16x8*>(&s_a[wr * 64 + m * 32 + r][ks * 16 + h * 8]);
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        fb[n] = *reinterpret_cast<const bf16x8*>(&s_b[wc * 64 + n * 32 + r][ks * 16 + h * 8]);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: sum of squares; C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  float s = 0.f;
+  const bool diag_tile = (ti == tj);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = acc[m][n][e];
+        if (diag_tile) {
+          const int row = wr * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int col = wc * 64 + n * 32 + r;
+          if (row != col) s = fmaf(v, v, s);
+        } else {
+          s = fmaf(v, v, s);
+        }
+      }
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+  if (lane == 0) s_part[wave] = (double)s;
+  __syncthreads();
+  if (tid == 0) {
+    const double tot = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    partials[blockIdx.x] = diag_tile ? tot : 2.0 * tot;
+  }
+}
+
+// out[0..3] = loss, repr_loss, std_loss, cov_loss (fp32)
+__global__ __launch_bounds__(256) void vicreg_finish_kernel(const float* __restrict__ colstats,
+                                                            const double* __restrict__ msepart, int nmse,
+                                                            const double* __restrict__ gram_x,
+                                                            const double* __restrict__ gram_y, int ngram, int B, int D,
+                                                            int cfg_batch, float sim_coeff, float std_coeff,
+                                                            float cov_coeff, float* __restrict__ out) {
+  __shared__ double s[256][4];
+  double mse = 0.0, hinge = 0.0, gx = 0.0, gy = 0.0;
+  for (int i = threadIdx.x; i < nmse; i += 256) mse += msepart[i];
+  for (int i = threadIdx.x; i < ngram; i += 256) { gx += gram_x[i]; gy += gram_y[i]; }
+  const float inv_bm1 = 1.0f / (float)(B - 1);
+  for (int j = threadIdx.x; j < D; j += 256) {
+    const float sdx = sqrtf(colstats[2 * (size_t)D + j] * inv_bm1 + 0.0001f);
+    const float sdy = sqrtf(colstats[3 * (size_t)D + j] * inv_bm1 + 0.0001f);
+    hinge += (double)fmaxf(1.0f - sdx, 0.f) + (double)fmaxf(1.0f - sdy, 0.f);
+  }
+  s[threadIdx.x][0] = mse; s[threadIdx.x][1] = hinge; s[threadIdx.x][2] = gx; s[threadIdx.x][3] = gy;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (threadIdx.x < d)
+      for (int k = 0; k < 4; ++k) s[threadIdx.x][k] += s[threadIdx.x + d][k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double repr = s[0][0] / ((double)B * (double)D);
+    const double stdl = s[0][1] / (2.0 * (double)D);
+    const double den = (double)(cfg_batch - 1);
+    const double cov = (s[0][2] + s[0][3]) / (den * den) / (double)D;
+    out[0] = (float)((double)sim_coeff * repr + (double)std_coeff * stdl + (double)cov_coeff * cov);
+    out[1] = (float)repr;
+    out[2] = (float)stdl;
+    out[3] = (float)cov;
+  }
+}
+
+// ------------------------------------------------------------------------ C ABI
+static inline size_t vc_align(size_t x) { return (x + 255) / 256 * 256; }
+struct VicregWs { size_t xt_x, xt_y, colstats, mse, gram_x, gram_y, total; int Kpad, ntile, ngram, nmse; };
+static VicregWs vicreg_ws(int B, int D) {
+  VicregWs w;
+  w.Kpad = (B + GK - 1) / GK * GK;
+  w.ntile = (D + GT - 1) / GT;
+  w.ngram = w.ntile * (w.ntile + 1) / 2;
+  w.nmse = (D + VC_COLS - 1) / VC_COLS;
+  size_t o = 0;
+  w.xt_x = o;     o = vc_align(o + sizeof(unsigned short) * (size_t)D * w.Kpad);
+  w.xt_y = o;     o = vc_align(o + sizeof(unsigned short) * (size_t)D * w.Kpad);
+  w.colstats = o; o = vc_align(o + sizeof(float) * 4 * (size_t)D);
+  w.mse = o;      o = vc_align(o + sizeof(double) * w.nmse);
+  w.gram_x = o;   o = vc_align(o + sizeof(double) * w.ngram);
+  w.gram_y = o;   o = vc_align(o + sizeof(double) * w.ngram);
+  w.total = o;
+  return w;
+}
+
+extern "C" long long ias_vicreg_workspace_bytes(int B, int D) {
+  if (B < 2 || D < 1) return IAS_ERR_ARG;
+  return (long long)vicreg_ws(B, D).total;
+}
+
+// x, y [B,D] fp32 -> out[4] = (loss, repr_loss, std_loss, cov_loss).  cfg_batch = the configured batch
+// size whose (cfg_batch - 1) divides the covariance (vicreg.py:47-48).  After the call the workspace
+// holds colstats [4][D] (mean_x, mean_y, centred sum of squares x / y) at ias_vicreg_colstats_offset().
+extern "C" int ias_vicreg_loss(const float* x, const float* y, float* out, void* workspace, long long workspace_bytes,
+                               int B, int D, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff,
+                               void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !y || !out || !workspace || B < 2 || D < 1 || cfg_batch < 2) return IAS_ERR_ARG;
+  const VicregWs w = vicreg_ws(B, D);
+  if ((size_t)workspace_bytes < w.total) return IAS_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  unsigned short* xt_x = (unsigned short*)(ws + w.xt_x);
+  unsigned short* xt_y = (unsigned short*)(ws + w.xt_y);
+  float* colstats = (float*)(ws + w.colstats);
+  double* mse = (double*)(ws + w.mse);
+  double* gram_x = (double*)(ws + w.gram_x);
+  double* gram_y = (double*)(ws + w.gram_y);
+  hipLaunchKernelGGL(vicreg_colstats_kernel, dim3(w.nmse), dim3(VC_THREADS), 0, stream, x, y, xt_x, xt_y, colstats,
+                     mse, B, D, w.Kpad);
+  hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_x, gram_x, D, w.Kpad, w.ntile);
+  hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_y, gram_y, D, w.Kpad, w.ntile);
+  hipLaunchKernelGGL(vicreg_finish_kernel, dim3(1), dim3(256), 0, stream, colstats, mse, w.nmse, gram_x, gram_y,
+                     w.ngram, B, D, cfg_batch, sim_coeff, std_coeff, cov_coeff, out);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+extern "C" long long ias_vicreg_colstats_offset(int B, int D) {
+  if (B < 2 || D < 1) return IAS_ERR_ARG;
+  return (long long)vicreg_ws(B, D).colstats;
+}

@@ -1,0 +1,145 @@
+"""VICReg model + loss -- drop-in for /root/reference/vicreg.py on MI355X.
+
+Same public names and contracts: ``VICReg(cfg, backbone_audio, backbone_param)`` with
+``.forward(audio, params) -> (x, y)`` and ``.loss(x, y) -> (loss, repr_loss, std_loss, cov_loss)``
+(vicreg.py:11-58), ``Projector(cfg, reprdim)`` (:61-70), ``off_diagonal`` (:73-76),
+``FullGatherLayer`` (:79-95, which in the reference raises NameError because ``dist`` is never
+imported -- here it works, over RCCL), ``exclude_bias_and_norm`` (:98-99).
+
+The loss forward is the HIP path (csrc/vicreg_kernels.hip: fp32 column statistics, bf16 MFMA Gram with
+fp32 accumulation, fused off-diagonal square-sum).  The backward is closed-form fp32 on the device and
+uses the B x B Gram identity  d cov_loss / d xc = 4/((Bc-1)^2 D) * ((xc xc^T) xc - xc diag(xc^T xc)),
+so no D x D matrix is ever materialised in either direction.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+class _VICRegLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, cfg_batch, sim_coeff, std_coeff, cov_coeff):
+        lib = _lib.load()
+        xc, yc = x.detach().contiguous(), y.detach().contiguous()
+        _lib.require_f32(xc, yc)
+        assert xc.shape == yc.shape and xc.dim() == 2
+        B, D = xc.shape
+        need = lib.ias_vicreg_workspace_bytes(B, D)
+        _lib.check(min(int(need), 0), "ias_vicreg_workspace_bytes")
+        ws = torch.empty(int(need), dtype=torch.uint8, device=xc.device)
+        out = torch.empty(4, dtype=torch.float32, device=xc.device)
+        st = lib.ias_vicreg_loss(_lib.ptr(xc), _lib.ptr(yc), _lib.ptr(out), _lib.ptr(ws), ws.numel(), B, D,
+                                 int(cfg_batch), float(sim_coeff), float(std_coeff), float(cov_coeff), _lib.stream())
+        _lib.check(st, "ias_vicreg_loss")
+        ctx.save_for_backward(xc, yc)
+        ctx.consts = (int(cfg_batch), float(sim_coeff), float(std_coeff), float(cov_coeff))
+        return out[0], out[1], out[2], out[3]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_repr, g_std, g_cov):
+        x, y = ctx.saved_tensors
+        cfg_batch, sim, std, cov = ctx.consts
+        B, D = x.shape
+        a = g_loss * sim + g_repr
+        b = g_loss * std + g_std
+        c = g_loss * cov + g_cov
+        d_repr = (x - y) * (2.0 / (B * D))
+
+        def branch(v):
+            vc = v - v.mean(dim=0)
+            m2 = (vc * vc).sum(dim=0)
+            s = torch.sqrt(m2 / (B - 1) + 0.0001)
+            d_std = -(s < 1).to(v.dtype) / (2.0 * D * (B - 1) * s) * vc
+            gram = vc @ vc.T
+            d_cov = (gram @ vc - vc * m2) * (4.0 / ((cfg_batch - 1) ** 2 * D))
+            return b * d_std + c * d_cov
+
+        gx = a * d_repr + branch(x)
+        gy = -a * d_repr + branch(y)
+        return gx, gy, None, None, None, None
+
+
+def vicreg_loss(x, y, cfg_batch_size, sim_coeff=25.0, std_coeff=25.0, cov_coeff=1.0):
+    """(loss, repr_loss, std_loss, cov_loss) of vicreg.py:35-58 for x, y [B, D] on a ROCm device."""
+    return _VICRegLossFn.apply(x, y, cfg_batch_size, sim_coeff, std_coeff, cov_coeff)
+
+
+class VICReg(nn.Module):
+    def __init__(self, cfg, backbone_audio, backbone_param, gather_distributed=False):
+        super().__init__()
+        self.cfg = cfg
+        self.reprdim = cfg.dim
+        self.embeddim = cfg.embeddim
+        self.backbone_audio = backbone_audio
+        self.backbone_param = backbone_param
+        self.projector = Projector(cfg, self.reprdim)
+        # the reference keeps the cross-rank gather commented out (vicreg.py:38-39); opt-in here
+        self.gather_distributed = gather_distributed
+
+    def forward(self, audio, params):
+        x = self.projector(self.backbone_audio(audio))
+        y = self.projector(self.backbone_param(params))
+        return x, y
+
+    def loss(self, x, y):
+        assert x.shape[1] == self.embeddim
+        if self.gather_distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            x = torch.cat(FullGatherLayer.apply(x), dim=0)
+            y = torch.cat(FullGatherLayer.apply(y), dim=0)
+        v = self.cfg.vicreg
+        return vicreg_loss(x, y, v.batch_size, v.sim_coeff, v.std_coeff, v.cov_coeff)
+
+
+def Projector(cfg, reprdim):
+    widths = [int(w) for w in (f"{reprdim}-{cfg.vicreg.mlp}" % cfg.embeddim).split("-")]
+    layers = []
+    for fan_in, fan_out in zip(widths[:-2], widths[1:-1]):
+        layers += [nn.Linear(fan_in, fan_out), nn.BatchNorm1d(fan_out), nn.ReLU(True)]
+    layers.append(nn.Linear(widths[-2], widths[-1], bias=False))
+    return nn.Sequential(*layers)
+
+
+def off_diagonal(x):
+    """All elements i != j of a square matrix, row-major order (vicreg.py:73-76)."""
+    n, m = x.shape
+    assert n == m
+    return x.flatten()[:-1].view(n - 1, n + 1)[:, 1:].flatten()
+
+
+class FullGatherLayer(torch.autograd.Function):
+    """Gather a tensor from every rank with gradient support (vicreg.py:79-95).
+
+    forward : all_gather -> tuple of world_size tensors (RCCL over xGMI when the backend is nccl).
+    backward: the reference stacks the incoming grads, all_reduces the whole [W, B_l, D] stack and keeps
+              slice [rank]; that is a reduce_scatter, which moves W times fewer bytes -- used when the
+              backend provides it (RCCL), with the all_reduce form as the gloo fallback.  Same result.
+    """
+
+    @staticmethod
+    def forward(ctx, x):
+        world = dist.get_world_size()
+        x = x.contiguous()
+        if dist.get_backend() == "nccl":
+            flat = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+            dist.all_gather_into_tensor(flat, x)
+            return tuple(flat[i] for i in range(world))
+        output = [torch.zeros_like(x) for _ in range(world)]
+        dist.all_gather(output, x)
+        return tuple(output)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        stacked = torch.stack(grads).contiguous()
+        if dist.get_backend() == "nccl":
+            out = torch.empty_like(stacked[0])
+            dist.reduce_scatter_tensor(out, stacked)
+            return out
+        dist.all_reduce(stacked)
+        return stacked[dist.get_rank()]
+
+
+def exclude_bias_and_norm(p):
+    return p.ndim == 1

@@ -1,0 +1,95 @@
+"""HIP VICReg loss vs the reference's golden values and the oracle, through the C ABI.
+
+Tolerances: repr/std losses are fp32 reductions (1e-5 rel).  cov_loss comes from a bf16 MFMA Gram with
+fp32 accumulation (north_star names bf16; it states no bar): measured error is ~1e-4 relative, asserted
+at 2e-3.  The backward is fp32 closed form: compared with autograd through the oracle at 1e-4."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vicreg_oracle as vo
+from helpers import randn
+
+pytestmark = pytest.mark.gpu
+COV_RTOL = 2e-3
+
+
+def _check(out, ref):
+    loss, rep, std, cov = [float(o) for o in out]
+    assert abs(rep - ref[1]) <= 1e-5 * abs(ref[1])
+    assert abs(std - ref[2]) <= 1e-5 * abs(ref[2])
+    assert abs(cov - ref[3]) <= COV_RTOL * abs(ref[3])
+    assert abs(loss - ref[0]) <= COV_RTOL * abs(ref[0])
+
+
+@pytest.mark.parametrize("tag", ["tiny", "b16", "b128", "denom_quirk", "b1024"])
+def test_loss_golden(lib, dev, golden_dir, tag):
+    from inverse_audio_synthesis_amd.vicreg import vicreg_loss
+    g = np.load(os.path.join(golden_dir, "vicreg_loss.npz"))
+    B, D, cfgB, s1, s2 = [int(v) for v in g[tag + "_meta"]]
+    x, y = randn((B, D), s1), randn((B, D), s2) * 0.7 + 0.1
+    out = vicreg_loss(x.to(dev), y.to(dev), cfgB)
+    _check(out, g[tag + "_out"])
+
+
+@pytest.mark.parametrize("B,D", [(2, 1), (3, 64), (17, 130), (64, 127), (200, 1000)])
+def test_loss_ragged_shapes(lib, dev, B, D):
+    from inverse_audio_synthesis_amd.vicreg import vicreg_loss
+    x, y = randn((B, D), 1) * 1.3 + 0.2, randn((B, D), 2) * 0.5
+    ref = [o.item() for o in vo.loss(x, y, B, D, 10.0, 5.0, 2.0)]
+    out = [o.item() for o in vicreg_loss(x.to(dev), y.to(dev), B, 10.0, 5.0, 2.0)]
+    assert abs(out[1] - ref[1]) <= 1e-5 * abs(ref[1])
+    assert abs(out[2] - ref[2]) <= 1e-5 * max(abs(ref[2]), 1e-3)
+    assert abs(out[3] - ref[3]) <= COV_RTOL * max(abs(ref[3]), 1e-6)
+    assert abs(out[0] - ref[0]) <= COV_RTOL * abs(ref[0])
+
+
+def test_backward_matches_autograd_of_oracle(lib, dev):
+    from inverse_audio_synthesis_amd.vicreg import vicreg_loss
+    B, D, cfgB = 32, 256, 48
+    x0, y0 = randn((B, D), 5) * 0.8, randn((B, D), 6) * 1.1 + 0.3   # std < 1 and > 1 columns both occur
+    xr, yr = x0.clone().requires_grad_(), y0.clone().requires_grad_()
+    ref = vo.loss(xr, yr, cfgB, D)
+    (ref[0] + 0.5 * ref[1] - 2.0 * ref[2] + 3.0 * ref[3]).backward()
+    xg, yg = x0.to(dev).requires_grad_(), y0.to(dev).requires_grad_()
+    out = vicreg_loss(xg, yg, cfgB)
+    (out[0] + 0.5 * out[1] - 2.0 * out[2] + 3.0 * out[3]).backward()
+    for got, want in ((xg.grad.cpu(), xr.grad), (yg.grad.cpu(), yr.grad)):
+        assert (got - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+
+
+def test_module_api_and_offdiagonal(lib, dev, golden_dir):
+    from inverse_audio_synthesis_amd.vicreg import VICReg, off_diagonal, exclude_bias_and_norm
+    g = np.load(os.path.join(golden_dir, "vicreg_loss.npz"))
+    assert np.array_equal(off_diagonal(torch.from_numpy(g["offdiag7_in"]).to(dev)).cpu().numpy(), g["offdiag7_out"])
+    cfg = types.SimpleNamespace(dim=32, embeddim=96, vicreg=types.SimpleNamespace(
+        batch_size=8, mlp="64-64-%d", sim_coeff=25.0, std_coeff=25.0, cov_coeff=1.0))
+    model = VICReg(cfg, torch.nn.Identity(), torch.nn.Identity()).to(dev)
+    assert [type(m).__name__ for m in model.projector] == ["Linear", "BatchNorm1d", "ReLU", "Linear", "BatchNorm1d", "ReLU", "Linear"]
+    assert model.projector[-1].bias is None and model.projector[-1].out_features == 96
+    x, y = torch.from_numpy(g["tiny_x"]).to(dev), torch.from_numpy(g["tiny_y"]).to(dev)
+    _check(model.loss(x, y), g["tiny_out"])
+    assert exclude_bias_and_norm(torch.zeros(3)) and not exclude_bias_and_norm(torch.zeros(3, 3))
+
+
+def test_full_size_properties(lib, dev):
+    """BASELINE sizes (128 and 1024 x 8192): x == y gives repr 0; permuting the batch leaves every term
+    unchanged (up to fp32 sum order); scaling x,y by c scales cov_loss by c^4."""
+    from inverse_audio_synthesis_amd.vicreg import vicreg_loss
+    for B in (128, 1024):
+        g = torch.Generator(device="cpu").manual_seed(B)
+        x = torch.randn((B, 8192), generator=g).to(dev)
+        y = (torch.randn((B, 8192), generator=g) * 0.5).to(dev)
+        out = [o.item() for o in vicreg_loss(x, y, B)]
+        same = [o.item() for o in vicreg_loss(x, x.clone(), B)]
+        assert same[1] == 0.0
+        perm = torch.randperm(B, generator=g).to(dev)
+        outp = [o.item() for o in vicreg_loss(x[perm], y[perm], B)]
+        for a, b in zip(out, outp):
+            assert abs(a - b) <= 1e-4 * abs(a)
+        out2 = [o.item() for o in vicreg_loss(2.0 * x, 2.0 * y, B)]
+        assert abs(out2[3] - 16.0 * out[3]) <= 1e-3 * 16.0 * out[3]
+        assert abs(out2[1] - 4.0 * out[1]) <= 1e-5 * 4.0 * out[1]
