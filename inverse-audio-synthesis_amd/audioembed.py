@@ -1,0 +1,53 @@
+"""AudioEmbedding -- drop-in for /root/reference/audioembed.py:5-72.
+
+audio [B,1,176400] -> PQMF(3) [B,3,58800] -> reshape [B,3,240,245] -> per-channel normalise ->
+``vision_model.features`` [B,576,8,8] -> conv7..conv1 (kernel 2, 8->1 spatial) -> [B,dim].
+Same constructor, submodule names (conv1..conv7) and methods (``_preprocess``, ``forward``, ``features``).
+When ``gram`` is this package's PQMF and ``img_preprocess`` is a ``ChannelNormalize``, the PQMF, the
+reshape (a pure view) and the normalisation run as ONE HIP kernel (the fused epilogue of
+csrc/pqmf_kernels.hip) instead of a 90 MB intermediate read + write.
+"""
+import torch
+import torch.nn as nn
+
+from .pqmf import PQMF, pqmf_analysis
+
+
+class ChannelNormalize(nn.Module):
+    """(x - mean_c) / std_c on [B,C,H,W] -- what torchvision.transforms.Normalize does
+    (reference vicreg_audio_params.py:60-62 with ImageNet constants)."""
+
+    def __init__(self, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+        super().__init__()
+        self.register_buffer("mean", torch.tensor(mean, dtype=torch.float32), persistent=False)
+        self.register_buffer("std", torch.tensor(std, dtype=torch.float32), persistent=False)
+
+    def forward(self, x):
+        return (x - self.mean.view(1, -1, 1, 1)) / self.std.view(1, -1, 1, 1)
+
+
+class AudioEmbedding(nn.Module):
+    def __init__(self, gram, vision_model, img_preprocess, dim):
+        super().__init__()
+        self.gram = gram
+        self.vision_model = vision_model
+        self.img_preprocess = img_preprocess
+        self.dim = dim
+        self.conv7 = nn.Conv2d(in_channels=576, out_channels=dim, kernel_size=2)
+        for i in range(6, 0, -1):
+            setattr(self, f"conv{i}", nn.Conv2d(in_channels=dim, out_channels=dim, kernel_size=2))
+
+    def _preprocess(self, audio):
+        if isinstance(self.gram, PQMF) and isinstance(self.img_preprocess, ChannelNormalize) and self.gram.N == 3:
+            z = pqmf_analysis(audio, self.gram.H, self.img_preprocess.mean, self.img_preprocess.std)
+            return z.reshape(-1, 3, 240, 245)
+        return self.img_preprocess(self.gram(audio).reshape(-1, 3, 240, 245))
+
+    def forward(self, audio):
+        t = self.vision_model.features(self._preprocess(audio))
+        for i in range(7, 0, -1):
+            t = getattr(self, f"conv{i}")(t)
+        return t.view(-1, self.dim)
+
+    def features(self, audio):
+        return self.forward(audio)

@@ -1,0 +1,120 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm).
+
+The reference's only parallelism is Lightning ``strategy: "ddp"`` (/root/reference/conf/config.yaml:8 ->
+pretrain.py:98): every rank renders its own batch, gradients are averaged.  Here:
+  * ``init_from_env``     rendezvous from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torchrun contract).
+  * ``GradBucketer``      bucketed gradient all-reduce overlapped with backward.  Gradients live as views
+                          of a few large flat buffers (no pack/unpack copies); a bucket's all-reduce is
+                          issued on RCCL's stream as soon as its last gradient is written.  xGMI is
+                          point-to-point (7 links x ~153 GB/s per GPU) and ring collectives are per-link
+                          bound, so buckets are few and large (default 128 MiB) rather than NVSwitch-sized.
+  * ``all_reduce_mean``   the ``sync_dist=True`` metric reduction of vicreg_audio_params.py:117-120.
+The embedding gather of vicreg.py:79-95 is ``vicreg.FullGatherLayer``.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group if WORLD_SIZE > 1.  -> (rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def all_reduce_mean(t):
+    """Mean of a (scalar) tensor over ranks; identity on one rank."""
+    if world_size() == 1:
+        return t
+    t = t.detach().clone()
+    dist.all_reduce(t)
+    return t / world_size()
+
+
+class GradBucketer:
+    """Bucketed, backward-overlapped gradient averaging for ``module`` (replicas only: no SyncBN,
+    matching the reference's plain DDP)."""
+
+    def __init__(self, module, bucket_bytes=128 << 20):
+        self.world = world_size()
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.buckets = []      # (flat buffer, [params])
+        self._pending = {}     # bucket index -> grads still to arrive this step
+        self._work = []
+        # reverse registration order ~ the order gradients become ready in backward
+        cur, cur_bytes = [], 0
+        for p in reversed(self.params):
+            nbytes = p.numel() * p.element_size()
+            if cur and (cur_bytes + nbytes > bucket_bytes or cur[0].dtype != p.dtype):
+                self._seal(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._seal(cur)
+        self._bucket_of = {}
+        for bi, (_flat, plist) in enumerate(self.buckets):
+            for p in plist:
+                self._bucket_of[p] = bi
+                p.register_post_accumulate_grad_hook(self._on_grad)
+        self.begin_step()
+
+    def _seal(self, plist):
+        flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
+        off = 0
+        for p in plist:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.buckets.append((flat, plist))
+
+    def begin_step(self):
+        """Zero the flat gradient buffers (call instead of optimizer.zero_grad())."""
+        self._work = []
+        for bi, (flat, plist) in enumerate(self.buckets):
+            flat.zero_()
+            self._pending[bi] = len(plist)
+
+    def _on_grad(self, p):
+        bi = self._bucket_of[p]
+        flat, plist = self.buckets[bi]
+        if p.grad.data_ptr() < flat.data_ptr() or p.grad.data_ptr() >= flat.data_ptr() + flat.numel() * flat.element_size():
+            # autograd replaced the view (first backward): copy into the bucket and re-point
+            off = sum(q.numel() for q in plist[:plist.index(p)])
+            view = flat[off:off + p.numel()].view_as(p)
+            view.copy_(p.grad)
+            p.grad = view
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0 and self.world > 1:
+            self._work.append(dist.all_reduce(flat, async_op=True))
+
+    def finish(self):
+        """Wait for the outstanding all-reduces and turn sums into means."""
+        if self.world == 1:
+            return
+        # parameters that received no gradient this step still have to take part in the collective
+        for bi, (flat, _plist) in enumerate(self.buckets):
+            if self._pending[bi] > 0:
+                self._work.append(dist.all_reduce(flat, async_op=True))
+                self._pending[bi] = 0
+        for w in self._work:
+            w.wait()
+        self._work = []
+        for flat, _plist in self.buckets:
+            flat.div_(self.world)

@@ -1,0 +1,95 @@
+"""LARS + linear-warmup/cosine schedule, as the reference configures them.
+
+/root/reference/vicreg_audio_params.py:134-151: ``flash.core.optimizers.LARS(params, weight_decay=wd,
+lr = batch_size / 256 * base_lr)`` and ``pl_bolts LinearWarmupCosineAnnealingLR(optimizer,
+warmup_epochs, max_epochs, warmup_start_lr, eta_min)`` stepped every optimizer step (:154-165).
+Neither package is in this image; both are restated from their published definitions (LARS: You et
+al. 2017 as implemented by lightning-flash/bolts: trust ratio on parameters with weight decay, then
+plain momentum-SGD; default momentum 0, trust_coefficient 1e-3, eps 1e-8).  The update is issued as
+multi-tensor (``torch._foreach``) ops: a handful of launches per step instead of ~6 per parameter.
+"""
+import math
+
+import torch
+
+
+class LARS(torch.optim.Optimizer):
+    def __init__(self, params, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False,
+                 trust_coefficient=0.001, eps=1e-8):
+        assert lr >= 0 and momentum >= 0 and weight_decay >= 0
+        defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
+                        nesterov=nesterov, trust_coefficient=trust_coefficient, eps=eps)
+        super().__init__(params, defaults)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            gs = [p.grad for p in ps]
+            wd, lr, mom = group["weight_decay"], group["lr"], group["momentum"]
+            if wd != 0:
+                p_norm = torch._foreach_norm(ps)
+                g_norm = torch._foreach_norm(gs)
+                pn, gn = torch.stack(p_norm), torch.stack(g_norm)
+                ratio = torch.where((pn != 0) & (gn != 0),
+                                    pn / (gn + pn * wd + group["eps"]) * group["trust_coefficient"],
+                                    torch.ones_like(pn))
+                upd = torch._foreach_add(gs, ps, alpha=wd)
+                torch._foreach_mul_(upd, list(ratio.unbind(0)))
+            else:
+                upd = [g.clone() for g in gs]
+            if mom != 0:
+                bufs = []
+                for p, u in zip(ps, upd):
+                    st = self.state[p]
+                    if "momentum_buffer" not in st:
+                        st["momentum_buffer"] = u.clone()
+                    else:
+                        st["momentum_buffer"].mul_(mom).add_(u, alpha=1 - group["dampening"])
+                    bufs.append(st["momentum_buffer"])
+                upd = torch._foreach_add(upd, bufs, alpha=mom) if group["nesterov"] else bufs
+            torch._foreach_add_(ps, upd, alpha=-lr)
+        return loss
+
+
+class LinearWarmupCosineAnnealingLR:
+    """Closed form of pl_bolts' scheduler; ``step()`` once per optimizer step ("epochs" are steps here,
+    exactly as the reference uses it with interval="step")."""
+
+    def __init__(self, optimizer, warmup_epochs, max_epochs, warmup_start_lr=0.0, eta_min=0.0):
+        self.optimizer = optimizer
+        self.warmup_epochs, self.max_epochs = int(warmup_epochs), int(max_epochs)
+        self.warmup_start_lr, self.eta_min = float(warmup_start_lr), float(eta_min)
+        self.base_lrs = [g["lr"] for g in optimizer.param_groups]
+        self.last_epoch = 0
+        self._apply()
+
+    def lr_at(self, epoch, base_lr):
+        if epoch < self.warmup_epochs:
+            return self.warmup_start_lr + epoch * (base_lr - self.warmup_start_lr) / max(self.warmup_epochs - 1, 1)
+        span = max(self.max_epochs - self.warmup_epochs, 1)
+        return self.eta_min + 0.5 * (base_lr - self.eta_min) * (1 + math.cos(math.pi * (epoch - self.warmup_epochs) / span))
+
+    def _apply(self):
+        for g, base in zip(self.optimizer.param_groups, self.base_lrs):
+            g["lr"] = self.lr_at(self.last_epoch, base)
+
+    def step(self):
+        self.last_epoch += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return [g["lr"] for g in self.optimizer.param_groups]
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd):
+        self.last_epoch = sd["last_epoch"]
+        self._apply()
