@@ -6,50 +6,57 @@
 // and, optionally fused into the analysis epilogue, the per-band normalisation of
 // /root/reference/audioembed.py:41,49 ((z - mean_c) / std_c, torchvision Normalize).
 //
-// Fast path (N=3, K=63 -- the reference's live configuration, vicreg_audio_params.py:40):
-// a workgroup stages (FT-1)*N+K input samples in LDS once, every lane produces 4
-// consecutive frames of all 3 bands from a 72-sample register window (18 ds_read_b128),
-// filter taps come through the scalar cache, every store is 16 B/lane (1 KiB per wave).
+// Fast path (N=3 or 4, K=63 -- N=3 is the reference's live configuration,
+// vicreg_audio_params.py:40): polyphase FIR out of LDS, see pqmf_analysis_fast_kernel.
 // Algorithmic HBM bytes: 4 B in + 4 B out per audio sample.
 #include "ias_common.h"
 
 #define PQ_THREADS 256
 
-template <int N, int K, int R>
+// Polyphase form: with j = N*q + p, z_k[f] = sum_p sum_q H_k[N*q+p] * x_p[f+q], x_p[m] = x[N*m + p - pad].
+// The workgroup de-interleaves its input span into the N polyphase rows in LDS; a lane owns R = 4
+// adjacent frames and slides a 4-value register window along each row (one new ds_read_b32 per
+// (q, p) step feeds 4 frames x N bands = 12 FMAs), so registers stay ~50/lane and LDS reads are
+// 1/10 of the FMA count.  Taps are wave-uniform scalar-cache loads.
+template <int N, int K>
 __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_fast_kernel(
     const float* __restrict__ x, const float* __restrict__ H, float* __restrict__ z,
     const float* __restrict__ mean, const float* __restrict__ stdv, int T, int L, int pad) {
+  constexpr int R = 4;
   constexpr int FT = PQ_THREADS * R;            // frames per workgroup
-  constexpr int SPAN = (FT - 1) * N + K;        // input samples per workgroup
-  constexpr int WIN = (R - 1) * N + K;          // input samples per lane
-  constexpr int WIN4 = (WIN + 3) / 4;
-  constexpr int LDS_FLOATS = ((PQ_THREADS - 1) * R * N + WIN4 * 4 + 3) / 4 * 4;
-  static_assert((R * N) % 4 == 0, "lane window must start 16-byte aligned");
-  __shared__ __attribute__((aligned(16))) float s_x[LDS_FLOATS];
+  constexpr int Q = (K + N - 1) / N;            // taps per polyphase branch
+  constexpr int QP = (Q + 3) / 4 * 4;           // padded to whole groups of 4 steps (zero taps)
+  constexpr int MLEN = FT + QP + 4;             // polyphase positions per row
+  // x_p[m] lives at index m + (m >> 5): lanes read m = 4*lane + c, and the extra +1 per 32 positions
+  // spreads the 32 lanes of a group over all 32 banks (plain m: 4-way conflict).
+  constexpr int MROW = ((MLEN + (MLEN >> 5) + 31) / 32) * 32 + 11;   // row stride: rows start 11 banks apart
+  constexpr int SPAN = N * (FT + QP + 4);       // input samples staged per workgroup (zeros past T)
+  static_assert(N <= 4, "tap table holds up to 4 bands per 16-byte entry");
+  __shared__ float s_xp[N][MROW];
 
   const int b = blockIdx.y, tid = threadIdx.x;
   const int f_tile = blockIdx.x * FT;
-  const long long start = (long long)f_tile * N - pad;   // sample index of s_x[0]
+  const long long start = (long long)f_tile * N - pad;   // sample index of polyphase position (m=0, p=0)
   const float* xr = x + (size_t)b * T;
 
-  // stage: aligned 16-byte global loads, shifted dword LDS writes
+  // stage: aligned 16-byte global loads, de-interleaved dword LDS writes
   const long long g0 = start >= 0 ? (start & ~3LL) : -(((-start) + 3) & ~3LL);
-  const int nvec = (int)((start + LDS_FLOATS - g0 + 3) / 4);
+  const int nvec = (int)((start + SPAN - g0 + 3) / 4);
   const bool vec_ok = (T & 3) == 0;
   for (int v = tid; v < nvec; v += PQ_THREADS) {
     const long long g = g0 + 4LL * v;
     float e[4];
     if (vec_ok && g >= 0 && g + 3 < T) {
-      const float4 q = *reinterpret_cast<const float4*>(xr + g);
-      e[0] = q.x; e[1] = q.y; e[2] = q.z; e[3] = q.w;
+      const float4 q4 = *reinterpret_cast<const float4*>(xr + g);
+      e[0] = q4.x; e[1] = q4.y; e[2] = q4.z; e[3] = q4.w;
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) e[i] = (g + i >= 0 && g + i < T) ? xr[g + i] : 0.0f;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long li = g + i - start;
-      if (li >= 0 && li < LDS_FLOATS) s_x[li] = e[i];
+      const int li = (int)(g + i - start);
+      if (li >= 0 && li < SPAN) { const int m = li / N; s_xp[li % N][m + (m >> 5)] = e[i]; }
     }
   }
   __syncthreads();
@@ -60,21 +67,33 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_fast_kernel(
 #pragma unroll
     for (int k = 0; k < N; ++k) acc[r][k] = 0.0f;
 
-  const float4* win = reinterpret_cast<const float4*>(s_x + tid * (R * N));
+  // Circular 4-value window per polyphase row: at step q, frame r reads w[p][(q + r) & 3] and the
+  // slot (q + 3) & 3 ... is refilled with x_p[4*tid + q + 4] for the next step.  The q loop is a real
+  // (rolled) loop over groups of 4 steps, so the slot indices are compile-time inside the body and
+  // hipcc cannot hoist the ~130 LDS reads of a full unroll (that cost 256 VGPRs, 1 wave per SIMD).  Taps are
+  // wave-uniform scalar loads (an LDS tap table made the kernel LDS-bound: 4 SIMDs share one LDS).
+  float w[N][4];
 #pragma unroll
-  for (int v = 0; v < WIN4; ++v) {
-    const float4 q = win[v];
-    const float xv[4] = {q.x, q.y, q.z, q.w};
+  for (int p = 0; p < N; ++p)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i = v * 4 + e;
+    for (int i = 0; i < 4; ++i) { const int m = R * tid + i; w[p][i] = s_xp[p][m + (m >> 5)]; }
+#pragma unroll 1
+  for (int q4 = 0; q4 < QP / 4; ++q4) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int j = i - r * N;
-        if (j >= 0 && j < K) {
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int mn = R * tid + 4 * q4 + s4 + 4;        // position refilled into slot s4
+      const int xi = mn + (mn >> 5);
 #pragma unroll
-          for (int k = 0; k < N; ++k) acc[r][k] = fmaf(xv[e], H[k * K + j], acc[r][k]);
-        }
+      for (int p = 0; p < N; ++p) {
+        const int j = (4 * q4 + s4) * N + p;           // wave-uniform tap index -> scalar loads
+        float hv[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) hv[k] = (j < K) ? H[k * K + j] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int k = 0; k < N; ++k) acc[r][k] = fmaf(w[p][(s4 + r) & 3], hv[k], acc[r][k]);
+        w[p][s4] = s_xp[p][xi];   // slot s4 held x_p[.. + q]; now x_p[.. + q + 4]
       }
     }
   }
@@ -86,12 +105,12 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_fast_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) o[r] = acc[r][k];
     if (mean != nullptr) {
-      const float m = mean[k], s = stdv[k];
+      const float m = mean[k], sd = stdv[k];
 #pragma unroll
-      for (int r = 0; r < R; ++r) o[r] = (o[r] - m) / s;
+      for (int r = 0; r < R; ++r) o[r] = (o[r] - m) / sd;
     }
     float* zr = z + ((size_t)b * N + k) * L;
-    if (R == 4 && (L & 3) == 0 && f0 + 3 < L) {
+    if ((L & 3) == 0 && f0 + 3 < L) {
       *reinterpret_cast<float4*>(zr + f0) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
 #pragma unroll
@@ -166,11 +185,11 @@ extern "C" int ias_pqmf_analysis(const float* x, const float* H, float* z, const
   if (L <= 0) return IAS_ERR_ARG;
   if (N == 3 && K == 63) {
     constexpr int FT = PQ_THREADS * 4;
-    hipLaunchKernelGGL((pqmf_analysis_fast_kernel<3, 63, 4>), dim3((L + FT - 1) / FT, B), dim3(PQ_THREADS), 0,
+    hipLaunchKernelGGL((pqmf_analysis_fast_kernel<3, 63>), dim3((L + FT - 1) / FT, B), dim3(PQ_THREADS), 0,
                        stream, x, H, z, mean, stdv, T, L, pad);
   } else if (N == 4 && K == 63) {
     constexpr int FT = PQ_THREADS * 4;
-    hipLaunchKernelGGL((pqmf_analysis_fast_kernel<4, 63, 4>), dim3((L + FT - 1) / FT, B), dim3(PQ_THREADS), 0,
+    hipLaunchKernelGGL((pqmf_analysis_fast_kernel<4, 63>), dim3((L + FT - 1) / FT, B), dim3(PQ_THREADS), 0,
                        stream, x, H, z, mean, stdv, T, L, pad);
   } else {
     hipLaunchKernelGGL(pqmf_analysis_generic_kernel, dim3((L + PQ_THREADS - 1) / PQ_THREADS, N, B),
