@@ -34,14 +34,15 @@ int ias_stream_copy(const float* src, float* dst, long long n, void* stream);
 long long ias_voice_workspace_bytes(int B, int T, int Tc);
 
 /* Control-rate pass only: params01 [B,78] in [0,1] (registration order, voice_spec.py) ->
- * ctrl [B,5,Tc] (mod-matrix outputs) and vconst [B] x 64 bytes (IasVoiceConst). */
-int ias_voice_control(const float* params01, float* ctrl, void* vconst, int B, int Tc, int control_rate,
-                      void* stream);
+ * ctrl [B,5,Tc] (mod-matrix outputs) and vconst [B] x 64 bytes (IasVoiceConst).  env [B,6,Tc] is
+ * scratch that receives the six envelopes (adsr_1, adsr_2, lfo_1_amp, lfo_2_amp, lfo_1_rate, lfo_2_rate). */
+int ias_voice_control(const float* params01, float* ctrl, void* vconst, float* env, int B, int Tc,
+                      int control_rate, void* stream);
 
-/* Same as ias_voice_control plus the intermediates dbg [B,10,Tc]: rows 0-5 the envelopes
- * (adsr_1, adsr_2, lfo_1_amp, lfo_2_amp, lfo_1_rate, lfo_2_rate), 6-7 the LFO phases, 8-9 the LFO outputs. */
-int ias_voice_control_debug(const float* params01, float* ctrl, void* vconst, float* dbg, int B, int Tc,
-                            int control_rate, void* stream);
+/* Same as ias_voice_control plus the intermediates dbg [B,10,Tc]: rows 0-5 the envelopes,
+ * 6-7 the LFO phases, 8-9 the LFO outputs. */
+int ias_voice_control_debug(const float* params01, float* ctrl, void* vconst, float* env, float* dbg, int B,
+                            int Tc, int control_rate, void* stream);
 
 /* Voice.output(): params01 [B,78], noise [B,T] (the fixed Noise(seed=13) buffer) -> audio [B,T].
  * normalize != 0 applies torchsynth's normalize_if_clipping (row / max(|row|) when the max > 1). */
@@ -50,10 +51,15 @@ int ias_voice_render(const float* params01, const float* noise, float* audio, vo
                      int normalize, void* stream);
 
 /* One stage of ias_voice_render on a workspace ias_voice_control(params01, ws.ctrl, ws.vconst) has
- * filled (ias_voice_render = control + stages 0,1[,2]): 0 per-tile fp64 phase sums, 1 scan +
- * oscillators + mixer -> unnormalised audio and row peaks, 2 normalize_if_clipping in place. */
+ * filled (ias_voice_render = control + stage 0 [+ stage 1]): 0 the single-pass audio-rate kernel
+ * (phase increments, chained fp64 scan across tiles, oscillators, mixer -> unnormalised audio and row
+ * peaks), 1 normalize_if_clipping in place. */
 int ias_voice_stage(int stage, const float* noise, float* audio, void* workspace, long long workspace_bytes,
                     int B, int T, int Tc, int sample_rate, void* stream);
+
+/* status[0] (device) = 0 if the last render's tile chain completed, 1 if a workgroup's bounded wait for
+ * its predecessors expired (the audio of that call is then invalid). */
+int ias_voice_read_status(const void* workspace, unsigned* status, int B, int T, int Tc, void* stream);
 
 /* Copy the B row peaks (max |x| before normalisation) of the last render out of the workspace. */
 int ias_voice_read_peaks(const void* workspace, float* peaks, int B, int T, int Tc, void* stream);

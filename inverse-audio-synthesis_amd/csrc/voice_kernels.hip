@@ -5,13 +5,13 @@
 // Arithmetic contract: csrc/voice_math.h (== oracle/synth_oracle.py, math "cr").
 //
 // Kernels
-//   voice_control_kernel   one workgroup per voice: 78 params -> 6 ADSRs, 2 LFOs,
-//                          4x5 mod matrix -> ctrl[B][5][Tc] + IasVoiceConst[B].
-//   voice_audio_kernel<0>  per (tile, voice): phase increments of both VCOs, reduced to
-//                          one fp64 tile sum each (sums of fp32 increments below 2^19
-//                          are exact in fp64, so any summation order gives the same bits).
-//   voice_audio_kernel<1>  per (tile, voice): increments again, fp64 scan with the tile
-//                          carry, oscillators, VCAs, mixer -> unnormalised audio, row peak.
+//   voice_env_kernel       one workgroup per (envelope, voice): the six ADSR envelopes [B][6][Tc].
+//   voice_lfo_mod_kernel   one workgroup per voice: 2 LFOs (fp64 phase scan), 4x5 mod matrix
+//                          -> ctrl[B][5][Tc] + IasVoiceConst[B].
+//   voice_audio_kernel     per (tile, voice), ONE pass: phase increments of both VCOs, fp64 scan
+//                          chained across the tiles of a row (ticketed look-back; fp64 sums of
+//                          fp32 increments below 2^19 are exact, so any summation order gives the
+//                          same bits), oscillators, VCAs, mixer -> unnormalised audio, row peak.
 //   voice_normalize_kernel audio = peak > 1 ? x / peak : x   (torchsynth normalize_if_clipping)
 //
 // HBM traffic per audio sample: noise 4 B read + 4 B write (pass 1), 4 B read + 4 B write
@@ -48,9 +48,47 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ------------------------------------------------------------------ control rate
-// LDS: p[80] | env[6][Tc] | lfo[2][Tc] | scratch
-__global__ __launch_bounds__(VOICE_THREADS) void voice_control_kernel(
-    const float* __restrict__ params01, float* __restrict__ ctrl, IasVoiceConst* __restrict__ vconst,
+__device__ __forceinline__ float mapped_param(const float* __restrict__ params01, int b, int idx) {
+  const IasParamRange r = c_param_table[idx];
+  return ias_map_param(params01[(size_t)b * IAS_NPARAMS + idx], (float)r.lo, (float)r.span, (float)r.curve,
+                       r.symmetric);
+}
+
+__device__ __forceinline__ int adsr_base(int a) {
+  // env order: adsr_1, adsr_2, lfo_1_amp, lfo_2_amp, lfo_1_rate, lfo_2_rate
+  switch (a) {
+    case 0: return IAS_P_ADSR_1_ATTACK;
+    case 1: return IAS_P_ADSR_2_ATTACK;
+    case 2: return IAS_P_LFO_1_AMP_ADSR_ATTACK;
+    case 3: return IAS_P_LFO_2_AMP_ADSR_ATTACK;
+    case 4: return IAS_P_LFO_1_RATE_ADSR_ATTACK;
+    default: return IAS_P_LFO_2_RATE_ADSR_ATTACK;
+  }
+}
+
+// One workgroup per (envelope, voice): env[b][a][t] for all control samples t.  768 workgroups at
+// B = 128 fill the chip; the three fp64 pow() per sample dominate, so saturated ramps (base exactly
+// 0 or 1, where pow is exact) skip it.
+__global__ __launch_bounds__(VOICE_THREADS) void voice_env_kernel(const float* __restrict__ params01,
+                                                                  float* __restrict__ env, int Tc,
+                                                                  float control_rate) {
+  __shared__ float s_p[8];
+  const int a = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  if (tid < 5) s_p[tid] = mapped_param(params01, b, adsr_base(a) + tid);
+  if (tid == 5) s_p[5] = mapped_param(params01, b, IAS_P_KEYBOARD_DURATION);
+  __syncthreads();
+  IasAdsr e;
+  e.attack = s_p[0]; e.decay = s_p[1]; e.sustain = s_p[2]; e.release = s_p[3]; e.alpha = s_p[4];
+  const float note_on = s_p[5], eps = (float)IAS_EPS;
+  float* out = env + ((size_t)b * 6 + a) * Tc;
+  for (int t = tid; t < Tc; t += VOICE_THREADS) out[t] = ias_adsr(t, e, note_on, control_rate, eps);
+}
+
+// One workgroup per voice: LFO phases (fp64 scan), LFO shapes, 4x5 mod matrix -> ctrl, IasVoiceConst.
+// LDS: p[80] | env[6][Tc] | lfo[2][Tc]
+__global__ __launch_bounds__(VOICE_THREADS) void voice_lfo_mod_kernel(
+    const float* __restrict__ params01, const float* __restrict__ env_g, float* __restrict__ ctrl,
+    IasVoiceConst* __restrict__ vconst,
     float* __restrict__ dbg /* optional [B][10][Tc]: env0..5, lfo phase 0/1, lfo out 0/1 */,
     int Tc, float control_rate) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -58,34 +96,12 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_control_kernel(
   float* env = smem + 80;
   float* lfo = env + 6 * Tc;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float eps = (float)IAS_EPS;
 
-  if (tid < IAS_NPARAMS) {
-    const IasParamRange r = c_param_table[tid];
-    p[tid] = ias_map_param(params01[(size_t)b * IAS_NPARAMS + tid], (float)r.lo, (float)r.span,
-                           (float)r.curve, r.symmetric);
-  }
+  if (tid < IAS_NPARAMS) p[tid] = mapped_param(params01, b, tid);
+  const float* eg = env_g + (size_t)b * 6 * Tc;
+  for (int i = tid; i < 6 * Tc; i += VOICE_THREADS) env[i] = eg[i];
   __syncthreads();
-  const float midi_f0 = p[IAS_P_KEYBOARD_MIDI_F0], note_on = p[IAS_P_KEYBOARD_DURATION];
-
-  // env order: adsr_1, adsr_2, lfo_1_amp, lfo_2_amp, lfo_1_rate, lfo_2_rate
-  for (int i = tid; i < 6 * Tc; i += VOICE_THREADS) {
-    const int a = i / Tc, t = i - a * Tc;
-    int base;
-    switch (a) {
-      case 0: base = IAS_P_ADSR_1_ATTACK; break;
-      case 1: base = IAS_P_ADSR_2_ATTACK; break;
-      case 2: base = IAS_P_LFO_1_AMP_ADSR_ATTACK; break;
-      case 3: base = IAS_P_LFO_2_AMP_ADSR_ATTACK; break;
-      case 4: base = IAS_P_LFO_1_RATE_ADSR_ATTACK; break;
-      default: base = IAS_P_LFO_2_RATE_ADSR_ATTACK; break;
-    }
-    IasAdsr e;
-    e.attack = p[base]; e.decay = p[base + 1]; e.sustain = p[base + 2];
-    e.release = p[base + 3]; e.alpha = p[base + 4];
-    env[i] = ias_adsr(t, e, note_on, control_rate, eps);
-  }
-  __syncthreads();
+  const float midi_f0 = p[IAS_P_KEYBOARD_MIDI_F0];
 
   // LFO phase: waves 0/1 scan lfo_1/lfo_2 (fp64 accumulate, fp32 per-sample round).
   if (wave < 2) {
@@ -125,9 +141,8 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_control_kernel(
   float* out = ctrl + (size_t)b * IAS_NCTRL * Tc;
   for (int i = tid; i < IAS_NCTRL * Tc; i += VOICE_THREADS) {
     const int j = i / Tc, t = i - j * Tc;
-    const float o = ias_dot4_cr(w[0 * 5 + j], w[1 * 5 + j], w[2 * 5 + j], w[3 * 5 + j],
-                                    env[0 * Tc + t], env[1 * Tc + t], lfo[0 * Tc + t], lfo[1 * Tc + t]);
-    out[i] = o;
+    out[i] = ias_dot4_cr(w[0 * 5 + j], w[1 * 5 + j], w[2 * 5 + j], w[3 * 5 + j],
+                         env[0 * Tc + t], env[1 * Tc + t], lfo[0 * Tc + t], lfo[1 * Tc + t]);
   }
   if (tid == 0) {
     IasVoiceConst vc;
@@ -150,19 +165,41 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_control_kernel(
 
 // -------------------------------------------------------------------- audio rate
 #define VOICE_MAXCTRL 320  // control points staged per tile (covers sample rates down to ~6 kHz)
+#define VOICE_SPIN_LIMIT (1u << 24)
+#define VOICE_READY_BIT 0x8000000000000000ull
 
-template <int PASS>
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+// Single pass over the row with a chained scan across tiles ("decoupled look-back"):
+//   ticket  -> (voice, tile); tickets are handed out in launch order, so every predecessor tile of
+//              the same voice has already started when a workgroup begins (no dependence on dispatch
+//              order or placement: a workgroup only ever waits for workgroups with smaller tickets,
+//              and those publish before they wait).
+//   phase A -> the tile's 2 x 4096 phase increments (kept in registers) and their fp64 sums.  Sums of
+//              fp32 increments below 2^19 are exact in fp64, so the order of summation is irrelevant
+//              and the result is bit-identical to the sequential double accumulation of the oracle.
+//   publish -> one 8-byte write-through store per VCO: the sum's bits with the sign bit as READY flag
+//              (sums are >= 0).  The datum is its own flag (MI355X guide, Guideline 16 form R2).
+//   wait    -> wave 0 polls the predecessors' words with relaxed agent-scope loads (L1 bypass),
+//              bounded spins, and adds them up: the tile's carry-in.
+//   phase B -> fp64 scan with the carry, round to fp32, + phi, oscillators, VCAs, mixer, row peak.
 __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
     const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst,
-    const float* __restrict__ noise, float* __restrict__ audio, double* __restrict__ tilesum,
-    unsigned* __restrict__ rowpeak, int T, int Tc, int ntiles, float sample_rate, float scale) {
+    const float* __restrict__ noise, float* __restrict__ audio, unsigned long long* agg /* [B][ntiles][2] */,
+    unsigned int* ticket_status /* [0] ticket counter, [1] spin-timeout flag */,
+    unsigned* __restrict__ rowpeak, int T, int Tc, int ntiles, double inv_sample_rate, float scale) {
   __shared__ float s_ctrl[IAS_NCTRL][VOICE_MAXCTRL];
   __shared__ double s_wsum[2][VOICE_WAVES];
   __shared__ double s_carry[2];
   __shared__ float s_max[VOICE_WAVES];
+  __shared__ unsigned s_ticket;
 
-  const int tile = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_ticket = __hip_atomic_fetch_add((gu32*)ticket_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int ticket = (int)s_ticket;
+  const int b = ticket / ntiles, tile = ticket - b * ntiles;
   const int j_tile = tile * VOICE_TILE;
   const int j_last = min(j_tile + VOICE_TILE, T) - 1;
 
@@ -182,14 +219,6 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
     s_ctrl[k][c] = cb[k * Tc + c_lo + c];
   }
   const IasVoiceConst vc = vconst[b];
-  if (PASS == 1 && wave == 0) {
-    // carry-in = sum of the preceding tiles' increments (exact in fp64)
-    const double* ts = tilesum + (size_t)b * 2 * ntiles;
-    double a1 = 0.0, a2 = 0.0;
-    for (int t = lane; t < tile; t += 64) { a1 += ts[t]; a2 += ts[ntiles + t]; }
-    a1 = wave_sum(a1); a2 = wave_sum(a2);
-    if (lane == 0) { s_carry[0] = a1; s_carry[1] = a2; }
-  }
   __syncthreads();
 
   // phase A: increments (kept in registers) and per-wave totals
@@ -208,8 +237,8 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
         i0 -= c_lo; i1 -= c_lo;
         const float pm1 = ias_lerp(s_ctrl[0][i0], s_ctrl[0][i1], w0, w1);
         const float pm2 = ias_lerp(s_ctrl[2][i0], s_ctrl[2][i1], w0, w1);
-        a = ias_vco_inc(vc.f0_1, vc.depth_1, pm1, sample_rate);
-        d = ias_vco_inc(vc.f0_2, vc.depth_2, pm2, sample_rate);
+        a = ias_vco_inc_fast(vc.f0_1, vc.depth_1, pm1, inv_sample_rate);
+        d = ias_vco_inc_fast(vc.f0_2, vc.depth_2, pm2, inv_sample_rate);
       }
       inc1[c * 4 + e] = a; inc2[c * 4 + e] = d;
       tot1 += (double)a; tot2 += (double)d;
@@ -219,15 +248,43 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
   if (lane == 0) { s_wsum[0][wave] = tot1; s_wsum[1][wave] = tot2; }
   __syncthreads();
 
-  if (PASS == 0) {
-    if (tid == 0) {
-      double a1 = 0.0, a2 = 0.0;
-      for (int w = 0; w < VOICE_WAVES; ++w) { a1 += s_wsum[0][w]; a2 += s_wsum[1][w]; }
-      tilesum[(size_t)b * 2 * ntiles + tile] = a1;
-      tilesum[(size_t)b * 2 * ntiles + ntiles + tile] = a2;
+  // publish this tile's sums, then collect the predecessors' (wave 0)
+  gu64* row = (gu64*)(agg + ((size_t)b * ntiles) * 2);
+  if (wave == 0) {
+    if (lane < 2) {
+      double a = 0.0;
+      for (int w = 0; w < VOICE_WAVES; ++w) a += s_wsum[lane][w];
+      __hip_atomic_store(row + tile * 2 + lane, (unsigned long long)__double_as_longlong(a) | VOICE_READY_BIT,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    return;
+    double a1 = 0.0, a2 = 0.0;
+    bool timeout = false;
+    for (int t0 = 0; t0 < tile; t0 += 64) {
+      const int t = t0 + lane;
+      unsigned long long x1 = VOICE_READY_BIT, x2 = VOICE_READY_BIT;
+      unsigned spins = 0;
+      for (;;) {
+        if (t < tile) {
+          x1 = __hip_atomic_load(row + t * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          x2 = __hip_atomic_load(row + t * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const bool ok = (x1 & x2 & VOICE_READY_BIT) != 0;
+        if (__all(ok)) break;
+        if (++spins > VOICE_SPIN_LIMIT) { timeout = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (t < tile) {
+        a1 += __longlong_as_double((long long)(x1 & ~VOICE_READY_BIT));
+        a2 += __longlong_as_double((long long)(x2 & ~VOICE_READY_BIT));
+      }
+    }
+    a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (lane == 0) {
+      s_carry[0] = a1; s_carry[1] = a2;
+      if (timeout) __hip_atomic_store((gu32*)ticket_status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
+  __syncthreads();
 
   // phase B: scan + oscillators
   double run1 = s_carry[0], run2 = s_carry[1];
@@ -272,7 +329,7 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
         const float ampn = ias_lerp(s_ctrl[4][i0], s_ctrl[4][i1], w0, w1);
         const float a1 = ias_add((float)(base1 + l1[e]), vc.phi_1);
         const float a2 = ias_add((float)(base2 + l2[e]), vc.phi_2);
-        o[e] = ias_mix_sample(a1, a2, amp1, amp2, ampn, nz[e], vc);
+        o[e] = ias_mix_sample_dev(a1, a2, amp1, amp2, ampn, nz[e], vc);
         pk = fmaxf(pk, fabsf(o[e]));
       }
     }
@@ -318,7 +375,7 @@ __global__ __launch_bounds__(256) void voice_normalize_kernel(float* __restrict_
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct VoiceWs {
-  size_t off_ctrl, off_vconst, off_tilesum, off_peak, total;
+  size_t off_ctrl, off_vconst, off_env, off_sync, sync_bytes, off_agg, off_peak, total;
   int ntiles;
 };
 static VoiceWs voice_ws_layout(int B, int T, int Tc) {
@@ -327,8 +384,14 @@ static VoiceWs voice_ws_layout(int B, int T, int Tc) {
   size_t o = 0;
   w.off_ctrl = o;    o = align_up(o + sizeof(float) * (size_t)B * IAS_NCTRL * Tc, 256);
   w.off_vconst = o;  o = align_up(o + sizeof(IasVoiceConst) * (size_t)B, 256);
-  w.off_tilesum = o; o = align_up(o + sizeof(double) * (size_t)B * 2 * w.ntiles, 256);
-  w.off_peak = o;    o = align_up(o + sizeof(unsigned) * (size_t)B, 256);
+  w.off_env = o;     o = align_up(o + sizeof(float) * (size_t)B * 6 * Tc, 256);
+  // words zeroed before every launch, in one block of their own (multiple of 16 bytes):
+  // [ticket, timeout flag, pad, pad][agg: B*ntiles*2 u64][row peaks: B u32]
+  w.off_sync = o;
+  w.off_agg = o + 16;
+  w.off_peak = w.off_agg + sizeof(unsigned long long) * (size_t)B * 2 * w.ntiles;
+  w.sync_bytes = align_up(w.off_peak + sizeof(unsigned) * (size_t)B - w.off_sync, 16);
+  o = align_up(w.off_sync + w.sync_bytes, 256);
   w.total = o;
   return w;
 }
@@ -346,39 +409,42 @@ static int voice_check_dims(int B, int T, int Tc) {
   return IAS_OK;
 }
 
-static int voice_control_launch(const float* params01, float* ctrl, void* vconst, float* dbg, int B, int Tc,
-                                int control_rate, void* stream_) {
+static int voice_control_launch(const float* params01, float* ctrl, void* vconst, float* env, float* dbg, int B,
+                                int Tc, int control_rate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!params01 || !ctrl || !vconst || B <= 0 || Tc <= 1 || control_rate <= 0) return IAS_ERR_ARG;
+  if (!params01 || !ctrl || !vconst || !env || B <= 0 || B > 65535 || Tc <= 1 || control_rate <= 0) return IAS_ERR_ARG;
   const size_t lds = sizeof(float) * (80 + 8 * (size_t)Tc);
   if (lds > 160 * 1024) return IAS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(voice_env_kernel, dim3(6, B), dim3(VOICE_THREADS), 0, stream, params01, env, Tc,
+                     (float)control_rate);
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)voice_control_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(voice_control_kernel, dim3(B), dim3(VOICE_THREADS), lds, stream, params01, ctrl,
+    (void)hipFuncSetAttribute((const void*)voice_lfo_mod_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(voice_lfo_mod_kernel, dim3(B), dim3(VOICE_THREADS), lds, stream, params01, env, ctrl,
                      (IasVoiceConst*)vconst, dbg, Tc, (float)control_rate);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
-extern "C" int ias_voice_control(const float* params01, float* ctrl, void* vconst, int B, int Tc,
+// env: scratch [B][6][Tc] floats (the six envelopes), also an output for diagnostics.
+extern "C" int ias_voice_control(const float* params01, float* ctrl, void* vconst, float* env, int B, int Tc,
                                  int control_rate, void* stream_) {
-  return voice_control_launch(params01, ctrl, vconst, nullptr, B, Tc, control_rate, stream_);
+  return voice_control_launch(params01, ctrl, vconst, env, nullptr, B, Tc, control_rate, stream_);
 }
 
 // Same, plus the control-rate intermediates dbg [B][10][Tc] (6 envelopes, 2 LFO phases, 2 LFO outputs).
-extern "C" int ias_voice_control_debug(const float* params01, float* ctrl, void* vconst, float* dbg, int B,
-                                       int Tc, int control_rate, void* stream_) {
+extern "C" int ias_voice_control_debug(const float* params01, float* ctrl, void* vconst, float* env, float* dbg,
+                                       int B, int Tc, int control_rate, void* stream_) {
   if (!dbg) return IAS_ERR_ARG;
-  return voice_control_launch(params01, ctrl, vconst, dbg, B, Tc, control_rate, stream_);
+  return voice_control_launch(params01, ctrl, vconst, env, dbg, B, Tc, control_rate, stream_);
 }
 
 // One stage of the render on an already-filled workspace (ias_voice_control must have run into it):
-//   stage 0: per-tile fp64 phase sums      (voice_audio_kernel<0>)
-//   stage 1: scan + oscillators + mixer -> unnormalised audio, row peaks (voice_audio_kernel<1>)
-//   stage 2: normalize_if_clipping in place (voice_normalize_kernel)
+//   stage 0: single-pass audio-rate kernel: phase increments, chained fp64 scan across tiles,
+//            oscillators + mixer -> unnormalised audio, row peaks (voice_audio_kernel)
+//   stage 1: normalize_if_clipping in place (voice_normalize_kernel)
 extern "C" int ias_voice_stage(int stage, const float* noise, float* audio, void* workspace,
                                long long workspace_bytes, int B, int T, int Tc, int sample_rate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!noise || !audio || !workspace || sample_rate <= 0 || stage < 0 || stage > 2) return IAS_ERR_ARG;
+  if (!noise || !audio || !workspace || sample_rate <= 0 || stage < 0 || stage > 1) return IAS_ERR_ARG;
   int rc = voice_check_dims(B, T, Tc);
   if (rc) return rc;
   const VoiceWs w = voice_ws_layout(B, T, Tc);
@@ -386,17 +452,14 @@ extern "C" int ias_voice_stage(int stage, const float* noise, float* audio, void
   char* ws = (char*)workspace;
   const float* ctrl = (const float*)(ws + w.off_ctrl);
   const IasVoiceConst* vconst = (const IasVoiceConst*)(ws + w.off_vconst);
-  double* tilesum = (double*)(ws + w.off_tilesum);
   unsigned* peak = (unsigned*)(ws + w.off_peak);
-  const float scale = (float)(Tc - 1) / (float)(T - 1);
-  const dim3 grid(w.ntiles, B), block(VOICE_THREADS);
   if (stage == 0) {
-    hipLaunchKernelGGL(voice_audio_kernel<0>, grid, block, 0, stream, ctrl, vconst, noise, audio, tilesum, peak,
-                       T, Tc, w.ntiles, (float)sample_rate, scale);
-  } else if (stage == 1) {
-    if (hipMemsetAsync(peak, 0, sizeof(unsigned) * (size_t)B, stream) != hipSuccess) return IAS_ERR_LAUNCH;
-    hipLaunchKernelGGL(voice_audio_kernel<1>, grid, block, 0, stream, ctrl, vconst, noise, audio, tilesum, peak,
-                       T, Tc, w.ntiles, (float)sample_rate, scale);
+    // ticket, timeout flag, tile aggregates and row peaks are re-zeroed on every call
+    if (hipMemsetAsync(ws + w.off_sync, 0, w.sync_bytes, stream) != hipSuccess) return IAS_ERR_LAUNCH;
+    const float scale = (float)(Tc - 1) / (float)(T - 1);
+    hipLaunchKernelGGL(voice_audio_kernel, dim3(w.ntiles * B), dim3(VOICE_THREADS), 0, stream, ctrl, vconst, noise,
+                       audio, (unsigned long long*)(ws + w.off_agg), (unsigned int*)(ws + w.off_sync), peak, T, Tc,
+                       w.ntiles, 1.0 / (double)sample_rate, scale);
   } else {
     const int nvec = T / 4;
     int gx = (nvec + 255) / 256;
@@ -416,10 +479,21 @@ extern "C" int ias_voice_render(const float* params01, const float* noise, float
   const VoiceWs w = voice_ws_layout(B, T, Tc);
   if ((size_t)workspace_bytes < w.total) return IAS_ERR_WORKSPACE;
   char* ws = (char*)workspace;
-  rc = ias_voice_control(params01, (float*)(ws + w.off_ctrl), ws + w.off_vconst, B, Tc, control_rate, stream_);
-  for (int stage = 0; stage < (normalize ? 3 : 2) && rc == IAS_OK; ++stage)
+  rc = ias_voice_control(params01, (float*)(ws + w.off_ctrl), ws + w.off_vconst, (float*)(ws + w.off_env), B, Tc,
+                         control_rate, stream_);
+  for (int stage = 0; stage < (normalize ? 2 : 1) && rc == IAS_OK; ++stage)
     rc = ias_voice_stage(stage, noise, audio, workspace, workspace_bytes, B, T, Tc, sample_rate, stream_);
   return rc;
+}
+
+// 0 if the last render's tile chain completed, 1 if a workgroup gave up waiting (output invalid).
+extern "C" int ias_voice_read_status(const void* workspace, unsigned* status_dev, int B, int T, int Tc, void* stream_) {
+  if (!workspace || !status_dev) return IAS_ERR_ARG;
+  const VoiceWs w = voice_ws_layout(B, T, Tc);
+  if (hipMemcpyAsync(status_dev, (const char*)workspace + w.off_sync + 4, sizeof(unsigned), hipMemcpyDeviceToDevice,
+                     (hipStream_t)stream_) != hipSuccess)
+    return IAS_ERR_LAUNCH;
+  return IAS_OK;
 }
 
 // Row peaks (|x| max before normalisation) of the last render, for tests/diagnostics.

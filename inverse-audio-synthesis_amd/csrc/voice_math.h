@@ -64,6 +64,31 @@ IAS_HD float ias_exp2_cr(float t) {
   return (float)ldexp(p, (int)n);
 }
 
+// Same value as ias_exp2_cr for |t| <= 64 (the pitch path has t in [-5.75, 4.84]): degree-10
+// near-minimax polynomial for 2^f on [-0.5, 0.5] (max relative error 3.2e-16 before the final
+// rounding; coefficients from a Chebyshev fit in 80-bit arithmetic, scripts in DESIGN.md).
+IAS_HD float ias_exp2_cr_fast(float t) {
+  const float n = rintf(t);
+  const double f = (double)(t - n);
+  double p = 7.072587226569927e-09;
+  p = fma(p, f, 1.0208690586037056e-07);
+  p = fma(p, f, 1.3215442576793237e-06);
+  p = fma(p, f, 1.5252657258547322e-05);
+  p = fma(p, f, 0.00015403530441763784);
+  p = fma(p, f, 0.001333355823016814);
+  p = fma(p, f, 0.0096181291076068692);
+  p = fma(p, f, 0.055504108664447695);
+  p = fma(p, f, 0.24022650695910097);
+  p = fma(p, f, 0.69314718055994995);
+  p = fma(p, f, 1.0);
+  return (float)ldexp(p, (int)n);
+}
+
+// fl32(a / d) for a divisor d whose odd part is small (12, audio sample rates): the fp64 product
+// with the rounded reciprocal, rounded once to fp32, equals the IEEE fp32 quotient because a
+// quotient by such a d can never lie within 2^-53 (relative) of a rounding midpoint.
+IAS_HD float ias_div_by_recip(float a, double recip) { return (float)((double)a * recip); }
+
 // ---- parameter range mapping (torchsynth ModuleParameterRange.from_0to1) ----
 // lo = fl32(minimum); span = fl32(maximum - minimum) (non-symmetric) or
 // fl32((maximum - minimum) / 2) (symmetric), both rounded from the double table.
@@ -92,6 +117,8 @@ IAS_HD float ias_ramp(int t, float duration, float start, int has_start, int inv
   r = ias_add(ias_div(ias_add(r, eps), dur), eps);
   r = fminf(r, 1.0f);
   if (inverse && dur > 0.0f) r = ias_sub(1.0f, r);
+  // saturated ramps: pow(1, a) = 1 and pow(0, a) = 0 exactly (alpha is in [0.1, 6])
+  if (r == 1.0f || (r == 0.0f && alpha > 0.0f)) return r;
   return ias_pow_cr(r, alpha);
 }
 
@@ -179,12 +206,56 @@ IAS_HD float ias_vco_inc(float f0, float depth, float pitch_mod, float sample_ra
   return ias_div(ias_mul((float)IAS_TWO_PI_D, ias_midi_to_hz(c)), sample_rate);
 }
 
+// bit-identical to ias_vco_inc, cheaper: no IEEE fp32 divisions, short exp2 polynomial.
+IAS_HD float ias_vco_inc_fast(float f0, float depth, float pitch_mod, double inv_sample_rate) {
+  float c = ias_add(f0, ias_mul(depth, pitch_mod));
+  c = fminf(fmaxf(c, 0.0f), 127.0f);
+  const float t = ias_div_by_recip(ias_sub(c, 69.0f), 1.0 / 12.0);
+  const float hz = ias_mul(440.0f, ias_exp2_cr_fast(t));
+  return ias_div_by_recip(ias_mul((float)IAS_TWO_PI_D, hz), inv_sample_rate);
+}
+
 IAS_HD float ias_partials_k(float midi_f0, float depth_2) {
   const float max_pitch = ias_add(midi_f0, fmaxf(depth_2, 0.0f));
   const float max_f0 = ias_midi_to_hz(max_pitch);
   const float partials = ias_div(12000.0f, ias_mul(max_f0, ias_log10_cr(max_f0)));
   return ias_mul((float)IAS_PI_D, partials);
 }
+
+#if defined(__HIPCC__)
+// sin/cos of an fp32 angle up to ~1e6 rad: revolutions in fp64 (error ~1e-11 rev), fractional part,
+// gfx950 v_sin_f32 / v_cos_f32 (inputs in revolutions; measured max abs error 1.3e-7).
+__device__ __forceinline__ void ias_sincos_dev(float a, float& s, float& c) {
+  const double v = (double)a * 0.15915494309189535;
+  const float fr = (float)(v - rint(v));
+  s = __builtin_amdgcn_sinf(fr);
+  c = __builtin_amdgcn_cosf(fr);
+}
+__device__ __forceinline__ float ias_cos_dev(float a) {
+  const double v = (double)a * 0.15915494309189535;
+  return __builtin_amdgcn_cosf((float)(v - rint(v)));
+}
+// tanh(z) = sign(z) (1 - e^{-2|z|}) / (1 + e^{-2|z|})   (v_exp_f32 + v_rcp_f32; max abs error 1.3e-7)
+__device__ __forceinline__ float ias_tanh_dev(float z) {
+  const float t = __builtin_amdgcn_exp2f(-2.885390081777927f * fabsf(z));
+  const float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+  return z < 0.0f ? -r : r;
+}
+// ias_mix_sample with the device transcendentals (not amplified by the phase: ~1e-7 absolute).
+__device__ __forceinline__ float ias_mix_sample_dev(float arg1, float arg2, float amp1, float amp2, float ampn,
+                                                    float noise, const IasVoiceConst& vc) {
+  float s2, c2;
+  ias_sincos_dev(arg2, s2, c2);
+  const float v1 = ias_mul(ias_cos_dev(arg1), amp1);
+  const float sq = ias_tanh_dev(ias_mul(ias_mul(vc.kpart, s2), 0.5f));
+  const float v2 = ias_mul(ias_mul(ias_mul(vc.shape_gain, sq), ias_add(1.0f, ias_mul(vc.shape, c2))), amp2);
+  const float nz = ias_mul(noise, ampn);
+  float o = ias_mul(vc.lvl0, v1);
+  o = ias_add(o, ias_mul(vc.lvl1, v2));
+  o = ias_add(o, ias_mul(vc.lvl2, nz));
+  return o;
+}
+#endif
 
 // unnormalised mixer output for one sample, given both phases (fp32, phi added).
 IAS_HD float ias_mix_sample(float arg1, float arg2, float amp1, float amp2, float ampn,

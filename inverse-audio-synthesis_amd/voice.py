@@ -176,20 +176,31 @@ class Voice(nn.Module):
         ws = self._workspace
         audio = torch.empty((c.batch_size, c.buffer_size), dtype=torch.float32, device=p.device)
         hook = on_stage or (lambda name, phase: None)
-        # workspace layout: ctrl first, vconst second (csrc/voice_kernels.hip voice_ws_layout)
-        ctrl_bytes = (4 * c.batch_size * 5 * c.control_buffer_size + 255) // 256 * 256
+        # workspace layout: ctrl, vconst (64 B per voice), env (csrc/voice_kernels.hip voice_ws_layout)
+        a256 = lambda n: (n + 255) // 256 * 256
+        ctrl_bytes = a256(4 * c.batch_size * 5 * c.control_buffer_size)
+        env_off = ctrl_bytes + a256(64 * c.batch_size)
         hook("control", "begin")
-        st = lib.ias_voice_control(_lib.ptr(p), _lib.ptr(ws), _lib.ptr(ws[ctrl_bytes:]), c.batch_size,
-                                   c.control_buffer_size, c.control_rate, _lib.stream())
+        st = lib.ias_voice_control(_lib.ptr(p), _lib.ptr(ws), _lib.ptr(ws[ctrl_bytes:]), _lib.ptr(ws[env_off:]),
+                                   c.batch_size, c.control_buffer_size, c.control_rate, _lib.stream())
         _lib.check(st, "ias_voice_control")
         hook("control", "end")
-        for stage, name in enumerate(("phase_sums", "oscillators", "normalize")):
+        for stage, name in enumerate(("oscillators", "normalize")):
             hook(name, "begin")
             st = lib.ias_voice_stage(stage, _lib.ptr(self.noise), _lib.ptr(audio), _lib.ptr(ws), ws.numel(),
                                      c.batch_size, c.buffer_size, c.control_buffer_size, c.sample_rate, _lib.stream())
             _lib.check(st, f"ias_voice_stage({name})")
             hook(name, "end")
         return audio
+
+    def chain_status(self):
+        """0 if the last render's cross-tile scan completed; 1 if a bounded wait expired (tests)."""
+        c = self.synthconfig
+        st = torch.zeros(1, dtype=torch.int32, device=self._workspace.device)
+        _lib.check(_lib.load().ias_voice_read_status(_lib.ptr(self._workspace), _lib.ptr(st), c.batch_size,
+                                                     c.buffer_size, c.control_buffer_size, _lib.stream()),
+                   "ias_voice_read_status")
+        return int(st.item())
 
     def control_debug(self, params01=None):
         """Control-rate intermediates [B,10,Tc] (envelopes, LFO phases, LFO outputs) for tests."""
@@ -199,7 +210,8 @@ class Voice(nn.Module):
         ctrl = torch.empty((c.batch_size, 5, c.control_buffer_size), dtype=torch.float32, device=p.device)
         vconst = torch.empty((c.batch_size, 16), dtype=torch.float32, device=p.device)
         dbg = torch.empty((c.batch_size, 10, c.control_buffer_size), dtype=torch.float32, device=p.device)
-        st = lib.ias_voice_control_debug(_lib.ptr(p), _lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(dbg), c.batch_size,
+        env = torch.empty((c.batch_size, 6, c.control_buffer_size), dtype=torch.float32, device=p.device)
+        st = lib.ias_voice_control_debug(_lib.ptr(p), _lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(env), _lib.ptr(dbg), c.batch_size,
                                          c.control_buffer_size, c.control_rate, _lib.stream())
         _lib.check(st, "ias_voice_control_debug")
         return dbg
@@ -211,7 +223,8 @@ class Voice(nn.Module):
         lib = _lib.load()
         ctrl = torch.empty((c.batch_size, 5, c.control_buffer_size), dtype=torch.float32, device=p.device)
         vconst = torch.empty((c.batch_size, 16), dtype=torch.float32, device=p.device)
-        st = lib.ias_voice_control(_lib.ptr(p), _lib.ptr(ctrl), _lib.ptr(vconst), c.batch_size,
+        env = torch.empty((c.batch_size, 6, c.control_buffer_size), dtype=torch.float32, device=p.device)
+        st = lib.ias_voice_control(_lib.ptr(p), _lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(env), c.batch_size,
                                    c.control_buffer_size, c.control_rate, _lib.stream())
         _lib.check(st, "ias_voice_control")
         return ctrl, vconst

@@ -82,3 +82,20 @@ extern "C" int emul_voice_render(const float* params01, const float* noise, floa
   }
   return 0;
 }
+
+// Counts inputs on which the cheaper device formulations differ from the specification ones.
+extern "C" long long emul_check_fast_paths(const float* pm, long long n, float f0, float depth, int sample_rate) {
+  long long bad = 0;
+  const float sr = (float)sample_rate;
+  const double inv_sr = 1.0 / (double)sample_rate;
+  for (long long i = 0; i < n; ++i) {
+    const float a = ias_vco_inc(f0, depth, pm[i], sr), b = ias_vco_inc_fast(f0, depth, pm[i], inv_sr);
+    if (a != b) ++bad;
+    const float t = pm[i] * 10.0f - 5.0f;
+    if (ias_exp2_cr(t) != ias_exp2_cr_fast(t)) ++bad;
+    const float w = pm[i] * 7000.0f;
+    if (ias_div(w, sr) != ias_div_by_recip(w, inv_sr)) ++bad;
+    if (ias_div(t, 12.0f) != ias_div_by_recip(t, 1.0 / 12.0)) ++bad;
+  }
+  return bad;
+}

@@ -89,3 +89,14 @@ def test_bad_arguments_fail_loudly(lib, dev):
         v.render(torch.rand(4, 78))  # CPU tensor: no CPU fallback
     from inverse_audio_synthesis_amd import _lib
     assert lib.ias_voice_render(None, None, None, None, 0, 4, 16000, 441, 16000, 441, 1, None) == -1
+
+
+def test_tile_chain_completes_and_debug_rows(lib, dev):
+    """The cross-tile scan of the single-pass kernel reports no expired wait, and the control-rate
+    intermediates (envelopes, LFO phases, LFO outputs) are bit-exact against the oracle."""
+    v = _voice(dev, 16, 44100, 4.0)
+    v(4)
+    assert v.chain_status() == 0
+    cfg = so.VoiceConfig(batch_size=16)
+    _, _, ref_dbg = so.control_signals(cfg, v.params01.cpu(), "cr", True)
+    assert torch.equal(v.control_debug().cpu(), ref_dbg)

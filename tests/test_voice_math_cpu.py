@@ -71,3 +71,16 @@ def test_torch_vs_cr_math_spread_is_documented():
     b = so.render_from_params01(cfg, p01, noise, "cr")
     rel = ((a - b).norm() / b.norm()).item()
     assert rel < 5e-2
+
+
+def test_fast_formulations_are_bit_identical(emul):
+    """The cheaper device formulations (fp64-reciprocal divisions, degree-10 exp2 polynomial) give the
+    same fp32 bits as the specification ones, for the sample rates the configs use."""
+    import ctypes as C
+    emul.emul_check_fast_paths.restype = C.c_longlong
+    n = 2_000_000
+    for seed, sr in enumerate((16000, 22050, 44100, 48000, 96000)):
+        pm = torch.rand(n, generator=torch.Generator().manual_seed(seed))
+        bad = emul.emul_check_fast_paths(C.c_void_p(pm.data_ptr()), C.c_longlong(n), C.c_float(57.3 + seed),
+                                         C.c_float(31.0 - 9 * seed), C.c_int(sr))
+        assert bad == 0, f"{bad} mismatches at sample rate {sr}"
