@@ -91,12 +91,12 @@ long long ias_stft_partials_count(int B, int T, int n_fft, int hop);
 /* Framed STFT of audio [B,T]: window [n_fft] (zero-padded, centred), reflect padding, one-sided.
  * twiddle [n_fft][2] = (cos, -sin)(2 pi j / n_fft).  Per-bin value by value_mode: 1 |X|, 2 |X|^2,
  * 3 sqrt(max(|X|^2, eps)).  Optional mel projection as packed triangular filters
- * (mel_start/mel_count/mel_woff [n_out], mel_w); with NULL mel_* n_out must be n_fft/2+1.
+ * (mel_start/mel_count/mel_woff [n_out], mel_w [mel_nnz]); with NULL mel_* n_out must be n_fft/2+1.
  * out [B,F,n_out] (frames-major) or NULL; target [B,F,n_out] + partials required when
  * loss_mode is 1 (sum |v-t|) or 2 (MR-STFT sums {(t-v)^2, t^2, |log v - log t|}).
  * n_fft in {512, 1024, 2048}. */
 int ias_stft(const float* audio, const float* window, const float* twiddle, const int* mel_start,
-             const int* mel_count, const int* mel_woff, const float* mel_w, float* out, const float* target,
+             const int* mel_count, const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
              double* partials, int B, int T, int n_fft, int hop, int n_out, int value_mode, int loss_mode,
              float eps, void* stream);
 

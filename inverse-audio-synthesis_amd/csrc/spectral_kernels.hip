@@ -90,41 +90,85 @@ struct SpecArgs {
   float* out;              // [B,F,n_out] or null
   const float* target;     // [B,F,n_out] or null
   double* partials;        // [gridDim.x*gridDim.y][3] or null
-  int T, F, hop, n_out;
+  int T, F, hop, n_out, mel_nnz;
   int value_mode;          // 1: |X|, 2: |X|^2, 3: sqrt(max(|X|^2, eps))
   int loss_mode;           // 0: none, 1: sum |v - t|, 2: MR-STFT sums {(t-v)^2, t^2, |log v - log t|}
   float eps;
 };
 
+// LDS traffic inside one wave only needs ordering, not a workgroup barrier: the waves of a workgroup
+// work on different frames with private scratch.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <int LOG2N, int SP_FPB>
 __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
   constexpr int NFFT = 1 << LOG2N, N2 = NFFT / 2, R = N2 / 64, NPAIR = 8 * R, NP_IT = (NPAIR + 63) / 64;
-  constexpr int SCR = NPAIR * 9;   // padded [k1*8+c][9] complex scratch
+  constexpr int SCR = NPAIR * 9;          // padded [k1*8+c][9] complex scratch, reused in place by every pass
+  constexpr int NUNP = (N2 / 2) / 64 + 1; // unpack iterations per lane
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int span = (SP_FPB - 1) * a.hop + NFFT;
-  float* s_win = smem;                                   // NFFT
-  float2* s_tw = reinterpret_cast<float2*>(s_win + NFFT);  // NFFT
-  float* s_in = reinterpret_cast<float*>(s_tw + NFFT);   // span (rounded up to even)
   const int span_pad = (span + 3) & ~3;
-  cpx* s_scr = reinterpret_cast<cpx*>(s_in + span_pad);  // SP_WAVES * 2 * SCR
+  float* s_in = smem;                                        // span
+  cpx* s_scr = reinterpret_cast<cpx*>(s_in + span_pad);      // SP_WAVES * SCR
+  float* s_melw = reinterpret_cast<float*>(s_scr + SP_WAVES * SCR);   // a.mel_nnz (mel mode)
+  int* s_meli = reinterpret_cast<int*>(s_melw + ((a.mel_nnz + 3) & ~3));  // [3][n_out]: start, count, woff
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y, f0 = blockIdx.x * SP_FPB;
   const float* arow = a.audio + (size_t)b * a.T;
+  const bool mel = a.mel_start != nullptr;
 
-  for (int i = tid; i < NFFT; i += SP_THREADS) { s_win[i] = a.window[i]; s_tw[i] = a.twiddle[i]; }
   const int g0 = f0 * a.hop - N2;
   for (int i = tid; i < span; i += SP_THREADS) s_in[i] = arow[reflect_index(g0 + i, a.T)];
+  if (mel) {
+    for (int i = tid; i < a.mel_nnz; i += SP_THREADS) s_melw[i] = a.mel_w[i];
+    for (int i = tid; i < a.n_out; i += SP_THREADS) {
+      s_meli[i] = a.mel_start[i];
+      s_meli[a.n_out + i] = a.mel_count[i];
+      s_meli[2 * a.n_out + i] = a.mel_woff[i];
+    }
+  }
+
+  // frame-invariant per-lane tables, held in registers for the whole workgroup:
+  //   window of the lane's 2R samples, pass-1 twiddles W_N2^(lane*k1), pass-2 twiddles W_64^(c*d),
+  //   unpack twiddles W_NFFT^k
+  float win[2 * R];
+  cpx tw1[R], tw2[NP_IT][8], twu[NUNP];
+#pragma unroll
+  for (int n1 = 0; n1 < R; ++n1) {
+    const int m = 2 * (64 * n1 + lane);
+    win[2 * n1] = a.window[m];
+    win[2 * n1 + 1] = a.window[m + 1];
+    const float2 w = a.twiddle[2 * lane * n1];
+    tw1[n1] = cmk(w.x, w.y);
+  }
+#pragma unroll
+  for (int i = 0; i < NP_IT; ++i) {
+    const int c = (lane + 64 * i) & 7;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const float2 w = a.twiddle[(NFFT / 64) * c * d];
+      tw2[i][d] = cmk(w.x, w.y);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NUNP; ++i) {
+    const int k = lane + 64 * i;
+    const float2 w = a.twiddle[k <= N2 / 2 ? k : 0];
+    twu[i] = cmk(w.x, w.y);
+  }
   __syncthreads();
 
-  cpx* sA = s_scr + wave * 2 * SCR;
-  cpx* sB = sA + SCR;
+  cpx* sA = s_scr + wave * SCR;
   float l0 = 0.f, l1 = 0.f, l2 = 0.f;
 
   for (int it = 0; it < SP_FPB / SP_WAVES; ++it) {
     const int fi = it * SP_WAVES + wave;
     const int f = f0 + fi;
-    const bool live = f < a.F;   // uniform per wave; barriers below are executed by every wave
+    const bool live = f < a.F;   // wave-uniform
     const float* fin = s_in + fi * a.hop;
 
     // pass 1: radix-R over n1 (points 64*n1 + lane), twiddle W_N2^(lane*k1), scatter to [k1][c][a]
@@ -132,78 +176,95 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
 #pragma unroll
     for (int n1 = 0; n1 < R; ++n1) {
       const int m = 2 * (64 * n1 + lane);
-      v[n1] = cmk(fin[m] * s_win[m], fin[m + 1] * s_win[m + 1]);
+      v[n1] = cmk(fin[m] * win[2 * n1], fin[m + 1] * win[2 * n1 + 1]);
     }
     dftR<R>(v);
     {
       const int c = lane & 7, aa = lane >> 3;
 #pragma unroll
-      for (int k1 = 0; k1 < R; ++k1) {
-        const float2 w = s_tw[2 * lane * k1];
-        sA[(k1 * 8 + c) * 9 + aa] = cmul(v[k1], cmk(w.x, w.y));
+      for (int k1 = 0; k1 < R; ++k1) sA[(k1 * 8 + c) * 9 + aa] = cmul(v[k1], tw1[k1]);
+    }
+    wave_lds_sync();
+    // pass 2: radix-8 over a for each (k1, c); twiddle W_64^(c*d); scatter (in place) to [k1][d][c]
+    cpx u[NP_IT][8];
+#pragma unroll
+    for (int i = 0; i < NP_IT; ++i) {
+      const int p = lane + 64 * i;
+      if (p < NPAIR) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u[i][q] = sA[p * 9 + q];
       }
     }
-    __syncthreads();
-    // pass 2: radix-8 over a for each (k1, c); twiddle W_64^(c*d); scatter to [k1][d][c]
+    wave_lds_sync();   // every read of the [k1][c][a] image is in registers before it is overwritten
 #pragma unroll
     for (int i = 0; i < NP_IT; ++i) {
       const int p = lane + 64 * i;
       if (p < NPAIR) {
         const int k1 = p >> 3, c = p & 7;
-        cpx u[8];
+        dft8(u[i]);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) u[q] = sA[p * 9 + q];
-        dft8(u);
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-          const float2 w = s_tw[(NFFT / 64) * c * d];
-          sB[(k1 * 8 + d) * 9 + c] = cmul(u[d], cmk(w.x, w.y));
-        }
+        for (int d = 0; d < 8; ++d) sA[(k1 * 8 + d) * 9 + c] = cmul(u[i][d], tw2[i][d]);
       }
     }
-    __syncthreads();
-    // pass 3: radix-8 over c for each (k1, d) -> Z[k1 + R*d + 8R*e], natural order into sA
+    wave_lds_sync();
+    // pass 3: radix-8 over c for each (k1, d) -> Z[k1 + R*d + 8R*e], natural order (in place)
+#pragma unroll
+    for (int i = 0; i < NP_IT; ++i) {
+      const int p = lane + 64 * i;
+      if (p < NPAIR) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u[i][q] = sA[p * 9 + q];
+      }
+    }
+    wave_lds_sync();
 #pragma unroll
     for (int i = 0; i < NP_IT; ++i) {
       const int p = lane + 64 * i;
       if (p < NPAIR) {
         const int k1 = p >> 3, d = p & 7;
-        cpx u[8];
+        dft8(u[i]);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) u[q] = sB[p * 9 + q];
-        dft8(u);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sA[k1 + R * d + 8 * R * e] = u[e];
+        for (int e = 0; e < 8; ++e) sA[k1 + R * d + 8 * R * e] = u[i][e];
       }
     }
-    __syncthreads();
-    // unpack the packed real FFT: bins k and N2-k from Z[k], Z[N2-k]; values into sB (as floats)
-    float* P = reinterpret_cast<float*>(sB);
-    for (int k = lane; k <= N2 / 2; k += 64) {
-      const cpx zk = sA[k], zn = sA[(N2 - k) & (N2 - 1)];
-      const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-      const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-      const float2 w = s_tw[k];
-      const cpx t = cmul(cmk(w.x, w.y), zo);
-      const cpx xk = cadd(ze, t);              // X[k]
-      const cpx xn = cmk(ze.x - t.x, -(ze.y - t.y));  // X[N2-k] = conj(ze - t)
-      float pk = xk.x * xk.x + xk.y * xk.y, pn = xn.x * xn.x + xn.y * xn.y;
-      if (a.value_mode == 1) { pk = sqrtf(pk); pn = sqrtf(pn); }
-      else if (a.value_mode == 3) { pk = sqrtf(fmaxf(pk, a.eps)); pn = sqrtf(fmaxf(pn, a.eps)); }
-      P[k] = pk;
-      P[N2 - k] = pn;
+    wave_lds_sync();
+    // unpack the packed real FFT: bins k and N2-k from Z[k], Z[N2-k]; values written as floats P[0..N2]
+    float pk[NUNP], pn[NUNP];
+#pragma unroll
+    for (int i = 0; i < NUNP; ++i) {
+      const int k = lane + 64 * i;
+      pk[i] = pn[i] = 0.f;
+      if (k <= N2 / 2) {
+        const cpx zk = sA[k], zn = sA[(N2 - k) & (N2 - 1)];
+        const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        const cpx t = cmul(twu[i], zo);
+        const cpx xk = cadd(ze, t);                     // X[k]
+        const cpx xn = cmk(ze.x - t.x, -(ze.y - t.y));  // X[N2-k] = conj(ze - t)
+        float vk = xk.x * xk.x + xk.y * xk.y, vn = xn.x * xn.x + xn.y * xn.y;
+        if (a.value_mode == 1) { vk = sqrtf(vk); vn = sqrtf(vn); }
+        else if (a.value_mode == 3) { vk = sqrtf(fmaxf(vk, a.eps)); vn = sqrtf(fmaxf(vn, a.eps)); }
+        pk[i] = vk; pn[i] = vn;
+      }
     }
-    __syncthreads();
+    wave_lds_sync();   // all Z reads done before P overwrites the scratch
+    float* P = reinterpret_cast<float*>(sA);
+#pragma unroll
+    for (int i = 0; i < NUNP; ++i) {
+      const int k = lane + 64 * i;
+      if (k <= N2 / 2) { P[k] = pk[i]; P[N2 - k] = pn[i]; }
+    }
+    wave_lds_sync();
     // epilogue: mel projection (or raw bins), store / fused loss sums
     if (live) {
       const size_t row = ((size_t)b * a.F + f) * a.n_out;
       for (int m = lane; m < a.n_out; m += 64) {
         float val;
-        if (a.mel_start != nullptr) {
-          const int s = a.mel_start[m], n = a.mel_count[m];
-          const float* w = a.mel_w + a.mel_woff[m];
+        if (mel) {
+          const int s0 = s_meli[m], n = s_meli[a.n_out + m];
+          const float* w = s_melw + s_meli[2 * a.n_out + m];
           val = 0.f;
-          for (int j = 0; j < n; ++j) val = fmaf(w[j], P[s + j], val);
+          for (int j = 0; j < n; ++j) val = fmaf(w[j], P[s0 + j], val);
         } else {
           val = P[m];
         }
@@ -219,18 +280,18 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
         }
       }
     }
-    __syncthreads();
+    wave_lds_sync();
   }
 
   if (a.partials != nullptr) {
-    __shared__ float s_red[SP_WAVES][3];
+    __shared__ float s_red[SP_WAVES][4];
     l0 = wave_sum_f(l0); l1 = wave_sum_f(l1); l2 = wave_sum_f(l2);
     if (lane == 0) { s_red[wave][0] = l0; s_red[wave][1] = l1; s_red[wave][2] = l2; }
     __syncthreads();
     if (tid < 3) {
-      double s = 0.0;
-      for (int w = 0; w < SP_WAVES; ++w) s += (double)s_red[w][tid];
-      a.partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + tid] = s;
+      double sacc = 0.0;
+      for (int w = 0; w < SP_WAVES; ++w) sacc += (double)s_red[w][tid];
+      a.partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + tid] = sacc;
     }
   }
 }
@@ -259,14 +320,14 @@ extern "C" int ias_stft_num_frames(int T, int n_fft, int hop) {
   return 1 + T / hop;   // center=True: 1 + (T + 2*(n_fft/2) - n_fft) / hop
 }
 
-static size_t stft_lds_bytes(int n_fft, int hop, int fpb) {
+static size_t stft_lds_bytes(int n_fft, int hop, int fpb, int mel_nnz, int n_out) {
   const int R = n_fft / 128, scr = 8 * R * 9;
   const int span = (fpb - 1) * hop + n_fft;
-  return sizeof(float) * n_fft + sizeof(float2) * n_fft + sizeof(float) * ((span + 3) & ~3) +
-         sizeof(cpx) * SP_WAVES * 2 * scr;
+  return sizeof(float) * ((span + 3) & ~3) + sizeof(cpx) * SP_WAVES * scr + sizeof(float) * ((mel_nnz + 3) & ~3) +
+         sizeof(int) * 3 * (mel_nnz ? n_out : 0);
 }
 static int stft_fpb(int n_fft, int hop) {
-  return stft_lds_bytes(n_fft, hop, SP_FPB_MAX) <= 80 * 1024 ? SP_FPB_MAX : 4;
+  return stft_lds_bytes(n_fft, hop, SP_FPB_MAX, 0, 0) <= 56 * 1024 ? SP_FPB_MAX : 4;
 }
 
 extern "C" long long ias_stft_partials_count(int B, int T, int n_fft, int hop) {
@@ -282,9 +343,10 @@ extern "C" long long ias_stft_partials_count(int B, int T, int n_fft, int hop) {
 //   out      [B,F,n_out] or NULL : the spectrogram (frames-major layout)
 //   target   [B,F,n_out] or NULL : with loss_mode 1 (sum |v-t|) or 2 (MR-STFT sums)
 //   partials [ias_stft_partials_count][3] doubles, required when loss_mode != 0
+// mel_nnz = number of packed filter weights in mel_w (ignored without a filterbank).
 // twiddle [n_fft] float2 = (cos, -sin)(2 pi j / n_fft), computed by the caller in fp64.
 extern "C" int ias_stft(const float* audio, const float* window, const float* twiddle, const int* mel_start,
-                        const int* mel_count, const int* mel_woff, const float* mel_w, float* out,
+                        const int* mel_count, const int* mel_woff, const float* mel_w, int mel_nnz, float* out,
                         const float* target, double* partials, int B, int T, int n_fft, int hop, int n_out,
                         int value_mode, int loss_mode, float eps, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -293,7 +355,7 @@ extern "C" int ias_stft(const float* audio, const float* window, const float* tw
   if (loss_mode != 0 && (!target || !partials)) return IAS_ERR_ARG;
   if (loss_mode == 0 && !out) return IAS_ERR_ARG;
   const bool mel = mel_start != nullptr;
-  if (mel && (!mel_count || !mel_woff || !mel_w)) return IAS_ERR_ARG;
+  if (mel && (!mel_count || !mel_woff || !mel_w || mel_nnz <= 0)) return IAS_ERR_ARG;
   if (!mel && n_out != n_fft / 2 + 1) return IAS_ERR_ARG;
   const int F = ias_stft_num_frames(T, n_fft, hop);
   if (F < 0) return IAS_ERR_ARG;
@@ -304,11 +366,11 @@ extern "C" int ias_stft(const float* audio, const float* window, const float* tw
   a.audio = audio; a.window = window; a.twiddle = (const float2*)twiddle;
   a.mel_start = mel_start; a.mel_count = mel_count; a.mel_woff = mel_woff; a.mel_w = mel_w;
   a.out = out; a.target = target; a.partials = partials;
-  a.T = T; a.F = F; a.hop = hop; a.n_out = n_out;
+  a.T = T; a.F = F; a.hop = hop; a.n_out = n_out; a.mel_nnz = mel ? mel_nnz : 0;
   a.value_mode = value_mode; a.loss_mode = loss_mode; a.eps = eps;
 
   const int fpb = stft_fpb(n_fft, hop);
-  const size_t lds = stft_lds_bytes(n_fft, hop, fpb);
+  const size_t lds = stft_lds_bytes(n_fft, hop, fpb, a.mel_nnz, n_out);
   if (lds > 150 * 1024) return IAS_ERR_UNSUPPORTED;
   const dim3 grid((F + fpb - 1) / fpb, B), block(SP_THREADS);
 #define IAS_STFT_LAUNCH(LOG2N, FPB)                                                                              \

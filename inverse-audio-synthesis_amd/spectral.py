@@ -93,7 +93,7 @@ class STFTPlan(nn.Module):
         st = lib.ias_stft(_lib.ptr(audio), _lib.ptr(self.window), _lib.ptr(self.twiddle),
                           _lib.ptr(self.mel_start) if mel else None, _lib.ptr(self.mel_count) if mel else None,
                           _lib.ptr(self.mel_woff) if mel else None, _lib.ptr(self.mel_w) if mel else None,
-                          _lib.ptr(out), _lib.ptr(target), _lib.ptr(partials), B, T, self.n_fft, self.hop_length,
+                          int(self.mel_w.numel()) if mel else 0, _lib.ptr(out), _lib.ptr(target), _lib.ptr(partials), B, T, self.n_fft, self.hop_length,
                           self.n_out, value_mode, loss_mode, float(eps), _lib.stream())
         _lib.check(st, "ias_stft")
 
