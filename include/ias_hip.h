@@ -88,20 +88,28 @@ int ias_stft_num_frames(int T, int n_fft, int hop);
 /* Number of [3]-double partial records ias_stft writes when loss_mode != 0. */
 long long ias_stft_partials_count(int B, int T, int n_fft, int hop);
 
-/* Framed STFT of audio [B,T]: window [n_fft] (zero-padded, centred), reflect padding, one-sided.
- * twiddle [n_fft][2] = (cos, -sin)(2 pi j / n_fft).  Per-bin value by value_mode: 1 |X|, 2 |X|^2,
- * 3 sqrt(max(|X|^2, eps)).  Optional mel projection as packed triangular filters
- * (mel_start/mel_count/mel_woff [n_out], mel_w [mel_nnz]); with NULL mel_* n_out must be n_fft/2+1.
+/* HOST helpers: length (floats) and contents of the lane-major window/twiddle table block the kernel
+ * keeps in registers.  window_host [n_fft] = the analysis window zero-padded and centred to n_fft
+ * (host memory), out_host [ias_stft_tables_len(n_fft)] (host memory; copy it to the device once). */
+int ias_stft_tables_len(int n_fft);
+int ias_stft_build_tables(int n_fft, const float* window_host, float* out_host);
+
+/* Framed STFT of audio [B,T] (center=True, reflect padding, one-sided); tables = device copy of the
+ * ias_stft_build_tables block.  Per-bin value by value_mode: 1 |X|, 2 |X|^2, 3 sqrt(max(|X|^2, eps)).
+ * Optional mel projection as packed triangular filters (mel_start/mel_count/mel_woff [n_out],
+ * mel_w [mel_nnz]); with NULL mel_* n_out must be n_fft/2+1.
  * out [B,F,n_out] (frames-major) or NULL; target [B,F,n_out] + partials required when
  * loss_mode is 1 (sum |v-t|) or 2 (MR-STFT sums {(t-v)^2, t^2, |log v - log t|}).
  * n_fft in {512, 1024, 2048}. */
-int ias_stft(const float* audio, const float* window, const float* twiddle, const int* mel_start,
-             const int* mel_count, const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
+int ias_stft(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
+             const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
              double* partials, int B, int T, int n_fft, int hop, int n_out, int value_mode, int loss_mode,
              float eps, void* stream);
 
-/* sums[3] (doubles) = column sums of partials [n][3], fixed order (deterministic). */
-int ias_reduce_partials(const double* partials, long long n, double* sums, void* stream);
+/* sums[3] (doubles) = column sums of partials [n][3], fixed order (deterministic); when mean_out is not
+ * NULL also mean_out[0] = (float)(sums[0] * scale). */
+int ias_reduce_partials(const double* partials, long long n, double* sums, double scale, float* mean_out,
+                        void* stream);
 
 /* ---- VICReg loss: reference vicreg.py:35-58 (VICReg.loss) and :73-76 (off_diagonal). */
 

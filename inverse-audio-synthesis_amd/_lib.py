@@ -38,8 +38,10 @@ SYMBOLS = {
     "ias_pqmf_synthesis": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_stft_num_frames": (_I, [_I, _I, _I]),
     "ias_stft_partials_count": (_LL, [_I, _I, _I, _I]),
-    "ias_stft": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
-    "ias_reduce_partials": (_I, [_P, _LL, _P, _P]),
+    "ias_stft_tables_len": (_I, [_I]),
+    "ias_stft_build_tables": (_I, [_I, _P, _P]),
+    "ias_stft": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "ias_reduce_partials": (_I, [_P, _LL, _P, _c.c_double, _P, _P]),
     "ias_vicreg_workspace_bytes": (_LL, [_I, _I]),
     "ias_vicreg_colstats_offset": (_LL, [_I, _I]),
     "ias_vicreg_loss": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),

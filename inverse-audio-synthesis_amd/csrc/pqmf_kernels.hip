@@ -12,6 +12,77 @@
 #include "ias_common.h"
 
 #define PQ_THREADS 256
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Register state of one lane of the polyphase FIR: accumulator pairs and the two pair windows.
+template <int N, int K>
+struct PqmfWindow {
+  f32x2 accp[2][N];
+  f32x2 wa[N][4], wb[N][4];
+  const float* rows;
+  int mrow, m0;
+
+  __device__ __forceinline__ float xat(int p, int m) const { return rows[p * mrow + m + (m >> 5)]; }
+
+  __device__ __forceinline__ void init(const float* rows_, int mrow_, int m_first) {
+    rows = rows_; mrow = mrow_; m0 = m_first;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int k = 0; k < N; ++k) accp[h][k] = (f32x2){0.0f, 0.0f};
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+      float v[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) v[i] = xat(p, m0 + i);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wa[p][i] = (f32x2){v[2 * i], v[2 * i + 1]};
+        wb[p][i] = (f32x2){v[2 * i + 1], v[2 * i + 2]};
+      }
+    }
+  }
+
+  // One group of 4 polyphase steps q = 4*q4 + s4.  ROT: physical slot of logical pair i is (i+ROT)&3.
+  // FULL: every tap index of the group is < K (no checks); otherwise steps/taps beyond K are skipped
+  // at compile time (q4 is then a compile-time-known value K / (4N)).
+  template <int ROT, bool FULL>
+  __device__ __forceinline__ void group(const float* __restrict__ H, int q4) {
+    constexpr int QF = K / (4 * N);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+      for (int p = 0; p < N; ++p) {
+        const int jc = (4 * QF + s4) * N + p;            // tap index when !FULL (compile time)
+        if (!FULL && jc >= K) continue;
+        const int j = FULL ? (4 * q4 + s4) * N + p : jc;  // wave-uniform -> scalar loads
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          const float hk = H[k * K + j];
+          const f32x2 h2 = (f32x2){hk, hk};
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int slot = ((s4 >> 1) + h + ROT) & 3;
+            const f32x2 xw = (s4 & 1) ? wb[p][slot] : wa[p][slot];
+            accp[h][k] = __builtin_elementwise_fma(xw, h2, accp[h][k]);
+          }
+        }
+      }
+    }
+    if (FULL) {
+      // slide by 4 positions: logical pairs 2,3 become 0,1 (same registers, ROT advances by 2 in the
+      // caller); the freed slots take positions m0+8 .. m0+11 (+12 for the odd-offset window)
+      const int mn = m0 + 4 * q4 + 8;
+#pragma unroll
+      for (int p = 0; p < N; ++p) {
+        const float n0 = xat(p, mn), n1 = xat(p, mn + 1), n2 = xat(p, mn + 2), n3 = xat(p, mn + 3),
+                    n4 = xat(p, mn + 4);
+        wa[p][(0 + ROT) & 3] = (f32x2){n0, n1}; wa[p][(1 + ROT) & 3] = (f32x2){n2, n3};
+        wb[p][(0 + ROT) & 3] = (f32x2){n1, n2}; wb[p][(1 + ROT) & 3] = (f32x2){n3, n4};
+      }
+    }
+  }
+};
 
 // Polyphase form: with j = N*q + p, z_k[f] = sum_p sum_q H_k[N*q+p] * x_p[f+q], x_p[m] = x[N*m + p - pad].
 // The workgroup de-interleaves its input span into the N polyphase rows in LDS; a lane owns R = 4
@@ -26,11 +97,11 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_fast_kernel(
   constexpr int FT = PQ_THREADS * R;            // frames per workgroup
   constexpr int Q = (K + N - 1) / N;            // taps per polyphase branch
   constexpr int QP = (Q + 3) / 4 * 4;           // padded to whole groups of 4 steps (zero taps)
-  constexpr int MLEN = FT + QP + 4;             // polyphase positions per row
+  constexpr int MLEN = FT + QP + 12;            // polyphase positions per row (incl. window look-ahead)
   // x_p[m] lives at index m + (m >> 5): lanes read m = 4*lane + c, and the extra +1 per 32 positions
   // spreads the 32 lanes of a group over all 32 banks (plain m: 4-way conflict).
   constexpr int MROW = ((MLEN + (MLEN >> 5) + 31) / 32) * 32 + 11;   // row stride: rows start 11 banks apart
-  constexpr int SPAN = N * (FT + QP + 4);       // input samples staged per workgroup (zeros past T)
+  constexpr int SPAN = N * MLEN;                // input samples staged per workgroup (zeros past T)
   static_assert(N <= 4, "tap table holds up to 4 bands per 16-byte entry");
   __shared__ float s_xp[N][MROW];
 
@@ -61,42 +132,34 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_fast_kernel(
   }
   __syncthreads();
 
+  // gfx950 issues a plain fp32 VALU op for a wave64 in 4 cycles; only v_pk_fma_f32 (two FMAs per
+  // lane) reaches the fp32 peak.  Frames are therefore processed as even-aligned register PAIRS:
+  //   accp[h][k] = (acc[2h][k], acc[2h+1][k]),  h = 0, 1
+  //   wa[p][i] = (x_p[m0 + 2i], x_p[m0 + 2i + 1])      pairs starting at even offsets
+  //   wb[p][i] = (x_p[m0 + 2i + 1], x_p[m0 + 2i + 2])  pairs starting at odd offsets
+  // with m0 = 4*tid + 4*q4 (logical index i; the physical slot is (i + ROT) & 3 so that sliding the
+  // window by 4 positions moves no registers).  At step s4 (q = 4*q4 + s4) frame pair h needs
+  // x_p[m0 + s4 + 2h + {0,1}]: wa[(s4 >> 1) + h] for even s4, wb[(s4 >> 1) + h] for odd s4.
+  PqmfWindow<N, K> win;
+  win.init(&s_xp[0][0], MROW, R * tid);
+  constexpr int QF = K / (4 * N);        // groups of 4 steps in which every tap index is < K
+#pragma unroll 1
+  for (int q4 = 0; q4 + 1 < QF; q4 += 2) {
+    win.template group<0, true>(H, q4);
+    win.template group<2, true>(H, q4 + 1);
+  }
+  if (QF & 1) win.template group<0, true>(H, QF - 1);
+  if (4 * QF < Q) {
+    // remaining steps (fewer than a group, tap indices checked at compile time)
+    if (QF & 1) win.template group<2, false>(H, QF); else win.template group<0, false>(H, QF);
+  }
+  f32x2 (&accp)[2][N] = win.accp;
+
   float acc[R][N];
 #pragma unroll
-  for (int r = 0; r < R; ++r)
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int k = 0; k < N; ++k) acc[r][k] = 0.0f;
-
-  // Circular 4-value window per polyphase row: at step q, frame r reads w[p][(q + r) & 3] and the
-  // slot (q + 3) & 3 ... is refilled with x_p[4*tid + q + 4] for the next step.  The q loop is a real
-  // (rolled) loop over groups of 4 steps, so the slot indices are compile-time inside the body and
-  // hipcc cannot hoist the ~130 LDS reads of a full unroll (that cost 256 VGPRs, 1 wave per SIMD).  Taps are
-  // wave-uniform scalar loads (an LDS tap table made the kernel LDS-bound: 4 SIMDs share one LDS).
-  float w[N][4];
-#pragma unroll
-  for (int p = 0; p < N; ++p)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int m = R * tid + i; w[p][i] = s_xp[p][m + (m >> 5)]; }
-#pragma unroll 1
-  for (int q4 = 0; q4 < QP / 4; ++q4) {
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const int mn = R * tid + 4 * q4 + s4 + 4;        // position refilled into slot s4
-      const int xi = mn + (mn >> 5);
-#pragma unroll
-      for (int p = 0; p < N; ++p) {
-        const int j = (4 * q4 + s4) * N + p;           // wave-uniform tap index -> scalar loads
-        float hv[N];
-#pragma unroll
-        for (int k = 0; k < N; ++k) hv[k] = (j < K) ? H[k * K + j] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-          for (int k = 0; k < N; ++k) acc[r][k] = fmaf(w[p][(s4 + r) & 3], hv[k], acc[r][k]);
-        w[p][s4] = s_xp[p][xi];   // slot s4 held x_p[.. + q]; now x_p[.. + q + 4]
-      }
-    }
-  }
+    for (int k = 0; k < N; ++k) { acc[2 * h][k] = accp[h][k].x; acc[2 * h + 1][k] = accp[h][k].y; }
 
   const int f0 = f_tile + tid * R;
 #pragma unroll

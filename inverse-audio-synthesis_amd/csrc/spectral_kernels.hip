@@ -19,7 +19,7 @@
 #define SP_WAVES 4
 #define SP_FPB_MAX 8   // frames per workgroup (8, or 4 when the staged span would not fit LDS)
 
-struct cpx { float x, y; };
+struct __attribute__((aligned(8))) cpx { float x, y; };   // 8-byte aligned: LDS accesses become ds_*_b64
 __device__ __forceinline__ cpx cmk(float x, float y) { cpx r; r.x = x; r.y = y; return r; }
 __device__ __forceinline__ cpx cadd(cpx a, cpx b) { return cmk(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cpx csub(cpx a, cpx b) { return cmk(a.x - b.x, a.y - b.y); }
@@ -81,8 +81,7 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 
 struct SpecArgs {
   const float* audio;      // [B,T]
-  const float* window;     // [n_fft] (win_length window zero-padded, centred)
-  const float2* twiddle;   // [n_fft]  (cos, -sin)(2 pi j / n_fft)
+  const float* tables;     // lane-major window / twiddle tables (ias_stft_build_tables)
   const int* mel_start;    // [n_out] first bin of each filter (mel mode) or null (raw bins)
   const int* mel_count;    // [n_out]
   const int* mel_woff;     // [n_out] offset into mel_w
@@ -91,6 +90,7 @@ struct SpecArgs {
   const float* target;     // [B,F,n_out] or null
   double* partials;        // [gridDim.x*gridDim.y][3] or null
   int T, F, hop, n_out, mel_nnz;
+  int groups;              // frame groups (of SP_FPB frames) each workgroup walks through
   int value_mode;          // 1: |X|, 2: |X|^2, 3: sqrt(max(|X|^2, eps))
   int loss_mode;           // 0: none, 1: sum |v - t|, 2: MR-STFT sums {(t-v)^2, t^2, |log v - log t|}
   float eps;
@@ -117,12 +117,10 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
   int* s_meli = reinterpret_cast<int*>(s_melw + ((a.mel_nnz + 3) & ~3));  // [3][n_out]: start, count, woff
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.y, f0 = blockIdx.x * SP_FPB;
+  const int b = blockIdx.y;
   const float* arow = a.audio + (size_t)b * a.T;
   const bool mel = a.mel_start != nullptr;
 
-  const int g0 = f0 * a.hop - N2;
-  for (int i = tid; i < span; i += SP_THREADS) s_in[i] = arow[reflect_index(g0 + i, a.T)];
   if (mel) {
     for (int i = tid; i < a.mel_nnz; i += SP_THREADS) s_melw[i] = a.mel_w[i];
     for (int i = tid; i < a.n_out; i += SP_THREADS) {
@@ -132,38 +130,64 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
     }
   }
 
-  // frame-invariant per-lane tables, held in registers for the whole workgroup:
-  //   window of the lane's 2R samples, pass-1 twiddles W_N2^(lane*k1), pass-2 twiddles W_64^(c*d),
-  //   unpack twiddles W_NFFT^k
+  // frame-invariant per-lane tables, held in registers for the whole workgroup (coalesced loads from
+  // the lane-major table block): window of the lane's 2R samples, pass-1 twiddles W_N2^(lane*k1),
+  // pass-2 twiddles W_64^(c*d), unpack twiddles W_NFFT^k
   float win[2 * R];
   cpx tw1[R], tw2[NP_IT][8], twu[NUNP];
+  {
+    const float* tb = a.tables + lane;
 #pragma unroll
-  for (int n1 = 0; n1 < R; ++n1) {
-    const int m = 2 * (64 * n1 + lane);
-    win[2 * n1] = a.window[m];
-    win[2 * n1 + 1] = a.window[m + 1];
-    const float2 w = a.twiddle[2 * lane * n1];
-    tw1[n1] = cmk(w.x, w.y);
+    for (int e = 0; e < 2 * R; ++e) win[e] = tb[64 * e];
+    tb += 64 * 2 * R;
+#pragma unroll
+    for (int n1 = 0; n1 < R; ++n1) tw1[n1] = cmk(tb[64 * (2 * n1)], tb[64 * (2 * n1 + 1)]);
+    tb += 64 * 2 * R;
+#pragma unroll
+    for (int i = 0; i < NP_IT; ++i)
+#pragma unroll
+      for (int d = 0; d < 8; ++d) tw2[i][d] = cmk(tb[64 * (2 * (8 * i + d))], tb[64 * (2 * (8 * i + d) + 1)]);
+    tb += 64 * 2 * 8 * NP_IT;
+#pragma unroll
+    for (int i = 0; i < NUNP; ++i) twu[i] = cmk(tb[64 * (2 * i)], tb[64 * (2 * i + 1)]);
   }
-#pragma unroll
-  for (int i = 0; i < NP_IT; ++i) {
-    const int c = (lane + 64 * i) & 7;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      const float2 w = a.twiddle[(NFFT / 64) * c * d];
-      tw2[i][d] = cmk(w.x, w.y);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < NUNP; ++i) {
-    const int k = lane + 64 * i;
-    const float2 w = a.twiddle[k <= N2 / 2 ? k : 0];
-    twu[i] = cmk(w.x, w.y);
-  }
-  __syncthreads();
 
   cpx* sA = s_scr + wave * SCR;
   float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+
+  for (int grp = 0; grp < a.groups; ++grp) {
+  const int f0 = (blockIdx.x * a.groups + grp) * SP_FPB;
+  if (f0 >= a.F) break;   // workgroup-uniform
+  __syncthreads();        // previous group's frames are done with s_in
+  {
+    // stage the samples of SP_FPB consecutive frames (reflect padding at the row ends)
+    const int g0 = f0 * a.hop - N2;
+    if (((g0 | a.T) & 3) == 0) {
+      // all 16-byte loads of the group are issued before the first LDS write (one memory round trip)
+      constexpr int NV = 6;   // covers spans up to 6 * 1024 samples; longer spans loop
+      for (int base = 0; base < span; base += SP_THREADS * 4 * NV) {
+        float4 q[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int i = base + (tid + SP_THREADS * v) * 4, g = g0 + i;
+          q[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (i + 3 < span && g >= 0 && g + 3 < a.T) q[v] = *reinterpret_cast<const float4*>(arow + g);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int i = base + (tid + SP_THREADS * v) * 4, g = g0 + i;
+          if (i + 3 < span && g >= 0 && g + 3 < a.T) {
+            *reinterpret_cast<float4*>(s_in + i) = q[v];
+          } else {
+            for (int e = 0; e < 4; ++e) if (i + e < span) s_in[i + e] = arow[reflect_index(g + e, a.T)];
+          }
+        }
+      }
+    } else {
+      for (int i = tid; i < span; i += SP_THREADS) s_in[i] = arow[reflect_index(g0 + i, a.T)];
+    }
+  }
+  __syncthreads();
 
   for (int it = 0; it < SP_FPB / SP_WAVES; ++it) {
     const int fi = it * SP_WAVES + wave;
@@ -173,10 +197,19 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
 
     // pass 1: radix-R over n1 (points 64*n1 + lane), twiddle W_N2^(lane*k1), scatter to [k1][c][a]
     cpx v[R];
+    if (((fi * a.hop) & 1) == 0) {   // wave-uniform: frame start 8-byte aligned -> one ds_read_b64 per point
+      const cpx* fin2 = reinterpret_cast<const cpx*>(fin);
 #pragma unroll
-    for (int n1 = 0; n1 < R; ++n1) {
-      const int m = 2 * (64 * n1 + lane);
-      v[n1] = cmk(fin[m] * win[2 * n1], fin[m + 1] * win[2 * n1 + 1]);
+      for (int n1 = 0; n1 < R; ++n1) {
+        const cpx q = fin2[64 * n1 + lane];
+        v[n1] = cmk(q.x * win[2 * n1], q.y * win[2 * n1 + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int n1 = 0; n1 < R; ++n1) {
+        const int m = 2 * (64 * n1 + lane);
+        v[n1] = cmk(fin[m] * win[2 * n1], fin[m + 1] * win[2 * n1 + 1]);
+      }
     }
     dftR<R>(v);
     {
@@ -207,7 +240,8 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
       }
     }
     wave_lds_sync();
-    // pass 3: radix-8 over c for each (k1, d) -> Z[k1 + R*d + 8R*e], natural order (in place)
+    // pass 3: radix-8 over c for each (k1, d) -> Z[k1 + R*d + 8R*e], natural order padded by one
+    // complex per 8 (position k + k/8: the 16 lanes of a ds_write_b64 group then hit distinct banks)
 #pragma unroll
     for (int i = 0; i < NP_IT; ++i) {
       const int p = lane + 64 * i;
@@ -224,7 +258,7 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
         const int k1 = p >> 3, d = p & 7;
         dft8(u[i]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sA[k1 + R * d + 8 * R * e] = u[i][e];
+        for (int e = 0; e < 8; ++e) { const int k = k1 + R * d + 8 * R * e; sA[k + (k >> 3)] = u[i][e]; }
       }
     }
     wave_lds_sync();
@@ -235,7 +269,8 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
       const int k = lane + 64 * i;
       pk[i] = pn[i] = 0.f;
       if (k <= N2 / 2) {
-        const cpx zk = sA[k], zn = sA[(N2 - k) & (N2 - 1)];
+        const int kn = (N2 - k) & (N2 - 1);
+        const cpx zk = sA[k + (k >> 3)], zn = sA[kn + (kn >> 3)];
         const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
         const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
         const cpx t = cmul(twu[i], zo);
@@ -282,6 +317,7 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
     }
     wave_lds_sync();
   }
+  }  // groups
 
   if (a.partials != nullptr) {
     __shared__ float s_red[SP_WAVES][4];
@@ -296,22 +332,25 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
   }
 }
 
-// sums[0..2] = sum over n partial triples (fixed order: deterministic)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, long long n,
-                                                              double* __restrict__ sums) {
-  __shared__ double s[256][3];
+// sums[0..2] = sum over n partial triples (fixed order: deterministic); optionally
+// mean_out[0] = (float)(sums[0] * scale)  (the L1 mean, without further elementwise launches)
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __restrict__ partials, long long n,
+                                                               double* __restrict__ sums, double scale,
+                                                               float* __restrict__ mean_out) {
+  __shared__ double s[1024][3];
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  for (long long i = threadIdx.x; i < n; i += 256) {
+  for (long long i = threadIdx.x; i < n; i += 1024) {
     a0 += partials[i * 3]; a1 += partials[i * 3 + 1]; a2 += partials[i * 3 + 2];
   }
   s[threadIdx.x][0] = a0; s[threadIdx.x][1] = a1; s[threadIdx.x][2] = a2;
   __syncthreads();
-  for (int d = 128; d > 0; d >>= 1) {
+  for (int d = 512; d > 0; d >>= 1) {
     if (threadIdx.x < d)
       for (int k = 0; k < 3; ++k) s[threadIdx.x][k] += s[threadIdx.x + d][k];
     __syncthreads();
   }
   if (threadIdx.x < 3) sums[threadIdx.x] = s[0][threadIdx.x];
+  if (threadIdx.x == 0 && mean_out != nullptr) mean_out[0] = (float)(s[0][0] * scale);
 }
 
 // ------------------------------------------------------------------------ C ABI
@@ -329,28 +368,87 @@ static size_t stft_lds_bytes(int n_fft, int hop, int fpb, int mel_nnz, int n_out
 static int stft_fpb(int n_fft, int hop) {
   return stft_lds_bytes(n_fft, hop, SP_FPB_MAX, 0, 0) <= 56 * 1024 ? SP_FPB_MAX : 4;
 }
+// Frame groups per workgroup: the per-lane tables are loaded once per workgroup, so a workgroup walks
+// through several groups; sized so that B * gridDim.x is about one resident round (4 workgroups per CU).
+static int stft_groups(int B, int F, int fpb) {
+  const int total = (F + fpb - 1) / fpb;
+  int per_row = 1024 / B;
+  if (per_row < 1) per_row = 1;
+  int g = (total + per_row - 1) / per_row;
+  if (g < 1) g = 1;
+  if (g > 16) g = 16;
+  return g;
+}
+static int stft_grid_x(int B, int F, int n_fft, int hop) {
+  const int fpb = stft_fpb(n_fft, hop);
+  const int total = (F + fpb - 1) / fpb;
+  const int g = stft_groups(B, F, fpb);
+  return (total + g - 1) / g;
+}
 
 extern "C" long long ias_stft_partials_count(int B, int T, int n_fft, int hop) {
   const int F = ias_stft_num_frames(T, n_fft, hop);
   if (F < 0 || B <= 0) return IAS_ERR_ARG;
-  const int fpb = stft_fpb(n_fft, hop);
-  return (long long)B * ((F + fpb - 1) / fpb);
+  return (long long)B * stft_grid_x(B, F, n_fft, hop);
 }
 
-// Framed STFT of audio [B,T] (hann/any window [n_fft], center=True, reflect pad), per-bin value by
-// value_mode (1 |X|, 2 |X|^2, 3 sqrt(max(|X|^2, eps))), optional mel projection given as packed
-// filters (mel_start/count/woff [n_out], mel_w), n_out = n_mels or n_fft/2+1 when mel_* are NULL.
+// Lane-major constant tables of the STFT kernel, built on the HOST from the (zero-padded, centred)
+// window [n_fft]: floats = 64 * (2R + 2R + 16*NP_IT + 2*NUNP) with R = n_fft/128.
+extern "C" int ias_stft_tables_len(int n_fft) {
+  if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return IAS_ERR_UNSUPPORTED;
+  const int N2 = n_fft / 2, R = N2 / 64, np_it = (8 * R + 63) / 64, nunp = (N2 / 2) / 64 + 1;
+  return 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp);
+}
+
+extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float* out_host) {
+  const int len = ias_stft_tables_len(n_fft);
+  if (len < 0) return len;
+  if (!window_host || !out_host) return IAS_ERR_ARG;
+  const int N2 = n_fft / 2, R = N2 / 64, np_it = (8 * R + 63) / 64, nunp = (N2 / 2) / 64 + 1;
+  const double w0 = 6.283185307179586 / (double)n_fft;
+  float* o = out_host;
+  for (int e = 0; e < 2 * R; ++e)
+    for (int l = 0; l < 64; ++l) o[64 * e + l] = window_host[2 * (64 * (e >> 1) + l) + (e & 1)];
+  o += 64 * 2 * R;
+  for (int n1 = 0; n1 < R; ++n1)
+    for (int l = 0; l < 64; ++l) {
+      const double ang = w0 * (double)(2 * l * n1);
+      o[64 * (2 * n1) + l] = (float)cos(ang);
+      o[64 * (2 * n1 + 1) + l] = (float)(-sin(ang));
+    }
+  o += 64 * 2 * R;
+  for (int i = 0; i < np_it; ++i)
+    for (int d = 0; d < 8; ++d)
+      for (int l = 0; l < 64; ++l) {
+        const int c = (l + 64 * i) & 7;
+        const double ang = w0 * (double)((n_fft / 64) * c * d);
+        o[64 * (2 * (8 * i + d)) + l] = (float)cos(ang);
+        o[64 * (2 * (8 * i + d) + 1) + l] = (float)(-sin(ang));
+      }
+  o += 64 * 2 * 8 * np_it;
+  for (int i = 0; i < nunp; ++i)
+    for (int l = 0; l < 64; ++l) {
+      const int k = l + 64 * i;
+      const double ang = w0 * (double)(k <= N2 / 2 ? k : 0);
+      o[64 * (2 * i) + l] = (float)cos(ang);
+      o[64 * (2 * i + 1) + l] = (float)(-sin(ang));
+    }
+  return IAS_OK;
+}
+
+// Framed STFT of audio [B,T] (center=True, reflect pad); window and twiddles come as the device copy of
+// the ias_stft_build_tables block.  Per-bin value by value_mode (1 |X|, 2 |X|^2, 3 sqrt(max(|X|^2, eps))),
+// optional mel projection given as packed filters (mel_start/count/woff [n_out], mel_w [mel_nnz]);
+// n_out = n_mels, or n_fft/2+1 when mel_* are NULL.
 //   out      [B,F,n_out] or NULL : the spectrogram (frames-major layout)
 //   target   [B,F,n_out] or NULL : with loss_mode 1 (sum |v-t|) or 2 (MR-STFT sums)
 //   partials [ias_stft_partials_count][3] doubles, required when loss_mode != 0
-// mel_nnz = number of packed filter weights in mel_w (ignored without a filterbank).
-// twiddle [n_fft] float2 = (cos, -sin)(2 pi j / n_fft), computed by the caller in fp64.
-extern "C" int ias_stft(const float* audio, const float* window, const float* twiddle, const int* mel_start,
-                        const int* mel_count, const int* mel_woff, const float* mel_w, int mel_nnz, float* out,
-                        const float* target, double* partials, int B, int T, int n_fft, int hop, int n_out,
-                        int value_mode, int loss_mode, float eps, void* stream_) {
+extern "C" int ias_stft(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
+                        const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
+                        double* partials, int B, int T, int n_fft, int hop, int n_out, int value_mode,
+                        int loss_mode, float eps, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!audio || !window || !twiddle || B <= 0 || B > 65535 || n_out <= 0) return IAS_ERR_ARG;
+  if (!audio || !tables || B <= 0 || B > 65535 || n_out <= 0) return IAS_ERR_ARG;
   if (value_mode < 1 || value_mode > 3 || loss_mode < 0 || loss_mode > 2) return IAS_ERR_ARG;
   if (loss_mode != 0 && (!target || !partials)) return IAS_ERR_ARG;
   if (loss_mode == 0 && !out) return IAS_ERR_ARG;
@@ -363,16 +461,17 @@ extern "C" int ias_stft(const float* audio, const float* window, const float* tw
   if (hop > n_fft) return IAS_ERR_UNSUPPORTED;
 
   SpecArgs a;
-  a.audio = audio; a.window = window; a.twiddle = (const float2*)twiddle;
+  a.audio = audio; a.tables = tables;
   a.mel_start = mel_start; a.mel_count = mel_count; a.mel_woff = mel_woff; a.mel_w = mel_w;
   a.out = out; a.target = target; a.partials = partials;
   a.T = T; a.F = F; a.hop = hop; a.n_out = n_out; a.mel_nnz = mel ? mel_nnz : 0;
   a.value_mode = value_mode; a.loss_mode = loss_mode; a.eps = eps;
 
   const int fpb = stft_fpb(n_fft, hop);
+  a.groups = stft_groups(B, F, fpb);
   const size_t lds = stft_lds_bytes(n_fft, hop, fpb, a.mel_nnz, n_out);
   if (lds > 150 * 1024) return IAS_ERR_UNSUPPORTED;
-  const dim3 grid((F + fpb - 1) / fpb, B), block(SP_THREADS);
+  const dim3 grid(stft_grid_x(B, F, n_fft, hop), B), block(SP_THREADS);
 #define IAS_STFT_LAUNCH(LOG2N, FPB)                                                                              \
   do {                                                                                                           \
     if (lds > 64 * 1024)                                                                                         \
@@ -389,9 +488,12 @@ extern "C" int ias_stft(const float* audio, const float* window, const float* tw
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
-// sums[3] (doubles) = column sums of partials [n][3], in a fixed order.
-extern "C" int ias_reduce_partials(const double* partials, long long n, double* sums, void* stream_) {
+// sums[3] (doubles) = column sums of partials [n][3], in a fixed order; if mean_out != NULL also
+// mean_out[0] = (float)(sums[0] * scale).
+extern "C" int ias_reduce_partials(const double* partials, long long n, double* sums, double scale, float* mean_out,
+                                   void* stream_) {
   if (!partials || !sums || n <= 0) return IAS_ERR_ARG;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, partials, n, sums);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream_, partials, n, sums, scale,
+                     mean_out);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }

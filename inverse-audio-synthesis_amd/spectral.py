@@ -10,6 +10,7 @@ The reference has no live spectral-loss code.  This module implements the spec i
 Filterbank / window / twiddle tables are built once on the host; every per-sample operation runs
 in the HIP kernel.  Forward only (the reference never differentiates this path).
 """
+import ctypes
 import math
 
 import torch
@@ -55,10 +56,16 @@ class STFTPlan(nn.Module):
         left = (n_fft - self.win_length) // 2
         window = torch.zeros(n_fft)
         window[left:left + self.win_length] = win
-        j = torch.arange(n_fft, dtype=torch.float64) * (2.0 * math.pi / n_fft)
-        twiddle = torch.stack([torch.cos(j), -torch.sin(j)], dim=1).float()
         self.register_buffer("window", window, persistent=False)
-        self.register_buffer("twiddle", twiddle.contiguous(), persistent=False)
+        # lane-major window/twiddle tables of the kernel, built on the host by the C library
+        lib = _lib.load()
+        n_tab = lib.ias_stft_tables_len(n_fft)
+        _lib.check(min(n_tab, 0), "ias_stft_tables_len")
+        tables = torch.empty(n_tab, dtype=torch.float32)
+        wc = window.contiguous()
+        _lib.check(lib.ias_stft_build_tables(n_fft, ctypes.c_void_p(wc.data_ptr()), ctypes.c_void_p(tables.data_ptr())),
+                   "ias_stft_build_tables")
+        self.register_buffer("tables", tables, persistent=False)
         self.n_mels = n_mels
         if n_mels is not None:
             f_max = float(sample_rate // 2) if f_max is None else f_max
@@ -90,7 +97,7 @@ class STFTPlan(nn.Module):
         lib = _lib.load()
         B, T = audio.shape
         mel = self.n_mels is not None
-        st = lib.ias_stft(_lib.ptr(audio), _lib.ptr(self.window), _lib.ptr(self.twiddle),
+        st = lib.ias_stft(_lib.ptr(audio), _lib.ptr(self.tables),
                           _lib.ptr(self.mel_start) if mel else None, _lib.ptr(self.mel_count) if mel else None,
                           _lib.ptr(self.mel_woff) if mel else None, _lib.ptr(self.mel_w) if mel else None,
                           int(self.mel_w.numel()) if mel else 0, _lib.ptr(out), _lib.ptr(target), _lib.ptr(partials), B, T, self.n_fft, self.hop_length,
@@ -112,8 +119,9 @@ class STFTPlan(nn.Module):
         self._call(a, out, None, None, value_mode, LOSS_NONE, eps)
         return out
 
-    def loss_sums(self, audio, target_values, value_mode, loss_mode, eps=0.0):
-        """Fused STFT + comparison with cached target values -> 3 fp64 sums on the device."""
+    def loss_sums(self, audio, target_values, value_mode, loss_mode, eps=0.0, mean_scale=None):
+        """Fused STFT + comparison with cached target values -> 3 fp64 sums on the device
+        (with ``mean_scale``: -> the fp32 scalar sums[0] * mean_scale, computed by the same kernel)."""
         a = self._audio2d(audio)
         lib = _lib.load()
         F = self.num_frames(a.shape[1])
@@ -122,8 +130,11 @@ class STFTPlan(nn.Module):
         partials = torch.empty((n, 3), dtype=torch.float64, device=a.device)
         self._call(a, None, target_values, partials, value_mode, loss_mode, eps)
         sums = torch.empty(3, dtype=torch.float64, device=a.device)
-        _lib.check(lib.ias_reduce_partials(_lib.ptr(partials), n, _lib.ptr(sums), _lib.stream()), "ias_reduce_partials")
-        return sums
+        mean = torch.empty((), dtype=torch.float32, device=a.device) if mean_scale is not None else None
+        _lib.check(lib.ias_reduce_partials(_lib.ptr(partials), n, _lib.ptr(sums),
+                                           float(mean_scale) if mean_scale is not None else 0.0,
+                                           _lib.ptr(mean), _lib.stream()), "ias_reduce_partials")
+        return sums if mean is None else mean
 
 
 class MelSpectrogram(nn.Module):
@@ -164,8 +175,8 @@ class MelSpectrogramL1(nn.Module):
     def forward(self, audio, target_audio=None, target_mel=None):
         if target_mel is None:
             target_mel = self.target(target_audio)
-        sums = self.mel.plan.loss_sums(audio, target_mel, self.mel.value_mode, LOSS_L1)
-        return (sums[0] / target_mel.numel()).float()
+        return self.mel.plan.loss_sums(audio, target_mel, self.mel.value_mode, LOSS_L1,
+                                       mean_scale=1.0 / target_mel.numel())
 
 
 class STFTL1(nn.Module):
@@ -179,8 +190,7 @@ class STFTL1(nn.Module):
 
     def forward(self, audio, target_audio):
         tgt = self.plan.values(target_audio, self.value_mode)
-        sums = self.plan.loss_sums(audio, tgt, self.value_mode, LOSS_L1)
-        return (sums[0] / tgt.numel()).float()
+        return self.plan.loss_sums(audio, tgt, self.value_mode, LOSS_L1, mean_scale=1.0 / tgt.numel())
 
 
 class MultiResolutionSTFTLoss(nn.Module):
