@@ -10,9 +10,9 @@
 // transformed by an in-register radix-R pass (R = n_fft/128) followed by two radix-8 passes that
 // exchange through LDS (n_fft/2 = R*8*8), then unpacked to the n_fft/2+1 one-sided bins.  All
 // arithmetic fp32 (no bf16 DFT-as-GEMM: it would not hold the 1e-3 loss tolerance).
-// A workgroup (4 waves) stages the samples of FPB consecutive frames in LDS once (frames overlap),
-// so every audio sample is read from HBM ~once: algorithmic bytes = 4 B in per sample
-// + 4*bins/hop B out (or the same to read a cached target).
+// Frames are read straight from global memory (8 B per lane, 512 B per wave instruction); frames
+// overlap, so the second touch of a sample is served by L1/L2 and every audio sample comes from HBM
+// ~once: algorithmic bytes = 4 B in per sample + 4*bins/hop B out (or the same to read a cached target).
 #include "ias_common.h"
 
 #define SP_THREADS 256
@@ -97,22 +97,46 @@ struct SpecArgs {
 };
 
 // LDS traffic inside one wave only needs ordering, not a workgroup barrier: the waves of a workgroup
-// work on different frames with private scratch.
+// work on different frames with private scratch.  Only LDS (lgkm) is waited for: global loads of the
+// next frame stay in flight across these points.
 __device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 
+// Loads the 2R samples of frame f that lane `lane` owns in pass 1 (points 64*n1 + lane, n1 < R).
+// Interior frames on 8-byte-aligned rows: R coalesced 8-byte loads (512 B per wave instruction);
+// frames that touch the row ends (reflect padding) or odd alignments: per-sample indexing.
+template <int R, int N2>
+__device__ __forceinline__ void load_frame(const float* __restrict__ arow, int T, int hop, int f, int lane,
+                                           float (&x)[2 * R]) {
+  const int g0 = f * hop - N2;
+  if (g0 >= 0 && g0 + 2 * N2 <= T && (((g0 | T) & 1) == 0)) {
+    const float2* p = reinterpret_cast<const float2*>(arow + g0) + lane;
+#pragma unroll
+    for (int n1 = 0; n1 < R; ++n1) { const float2 q = p[64 * n1]; x[2 * n1] = q.x; x[2 * n1 + 1] = q.y; }
+  } else {
+#pragma unroll
+    for (int n1 = 0; n1 < R; ++n1) {
+      const int m = g0 + 2 * (64 * n1 + lane);
+      x[2 * n1] = arow[reflect_index(m, T)];
+      x[2 * n1 + 1] = arow[reflect_index(m + 1, T)];
+    }
+  }
+}
+
+// One wave per frame, no staging: every wave reads its frame straight from global memory (frames
+// overlap, so the second touch of a sample is an L1/L2 hit), prefetching the next frame while it
+// transforms the current one.  A workgroup (4 waves) walks through a.groups * SP_FPB consecutive frames
+// of one row, wave w taking frames w, w+4, ...; LDS holds only the per-wave FFT scratch and the mel
+// tables, and there is no workgroup barrier in the frame loop.
 template <int LOG2N, int SP_FPB>
 __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
   constexpr int NFFT = 1 << LOG2N, N2 = NFFT / 2, R = N2 / 64, NPAIR = 8 * R, NP_IT = (NPAIR + 63) / 64;
   constexpr int SCR = NPAIR * 9;          // padded [k1*8+c][9] complex scratch, reused in place by every pass
   constexpr int NUNP = (N2 / 2) / 64 + 1; // unpack iterations per lane
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int span = (SP_FPB - 1) * a.hop + NFFT;
-  const int span_pad = (span + 3) & ~3;
-  float* s_in = smem;                                        // span
-  cpx* s_scr = reinterpret_cast<cpx*>(s_in + span_pad);      // SP_WAVES * SCR
+  cpx* s_scr = reinterpret_cast<cpx*>(smem);                           // SP_WAVES * SCR
   float* s_melw = reinterpret_cast<float*>(s_scr + SP_WAVES * SCR);   // a.mel_nnz (mel mode)
   int* s_meli = reinterpret_cast<int*>(s_melw + ((a.mel_nnz + 3) & ~3));  // [3][n_out]: start, count, woff
 
@@ -151,66 +175,25 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
 #pragma unroll
     for (int i = 0; i < NUNP; ++i) twu[i] = cmk(tb[64 * (2 * i)], tb[64 * (2 * i + 1)]);
   }
+  __syncthreads();   // mel tables visible; the only workgroup barrier before the final reduction
 
   cpx* sA = s_scr + wave * SCR;
   float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+  const int f_begin = blockIdx.x * a.groups * SP_FPB;
+  const int f_end = min(f_begin + a.groups * SP_FPB, a.F);
 
-  for (int grp = 0; grp < a.groups; ++grp) {
-  const int f0 = (blockIdx.x * a.groups + grp) * SP_FPB;
-  if (f0 >= a.F) break;   // workgroup-uniform
-  __syncthreads();        // previous group's frames are done with s_in
-  {
-    // stage the samples of SP_FPB consecutive frames (reflect padding at the row ends)
-    const int g0 = f0 * a.hop - N2;
-    if (((g0 | a.T) & 3) == 0) {
-      // all 16-byte loads of the group are issued before the first LDS write (one memory round trip)
-      constexpr int NV = 6;   // covers spans up to 6 * 1024 samples; longer spans loop
-      for (int base = 0; base < span; base += SP_THREADS * 4 * NV) {
-        float4 q[NV];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          const int i = base + (tid + SP_THREADS * v) * 4, g = g0 + i;
-          q[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (i + 3 < span && g >= 0 && g + 3 < a.T) q[v] = *reinterpret_cast<const float4*>(arow + g);
-        }
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          const int i = base + (tid + SP_THREADS * v) * 4, g = g0 + i;
-          if (i + 3 < span && g >= 0 && g + 3 < a.T) {
-            *reinterpret_cast<float4*>(s_in + i) = q[v];
-          } else {
-            for (int e = 0; e < 4; ++e) if (i + e < span) s_in[i + e] = arow[reflect_index(g + e, a.T)];
-          }
-        }
-      }
-    } else {
-      for (int i = tid; i < span; i += SP_THREADS) s_in[i] = arow[reflect_index(g0 + i, a.T)];
-    }
-  }
-  __syncthreads();
+  float xc[2 * R], xn[2 * R];
+  int f = f_begin + wave;
+  if (f < f_end) load_frame<R, N2>(arow, a.T, a.hop, f, lane, xc);
 
-  for (int it = 0; it < SP_FPB / SP_WAVES; ++it) {
-    const int fi = it * SP_WAVES + wave;
-    const int f = f0 + fi;
-    const bool live = f < a.F;   // wave-uniform
-    const float* fin = s_in + fi * a.hop;
+  for (; f < f_end; f += SP_WAVES) {
+    const bool more = f + SP_WAVES < f_end;   // wave-uniform
+    if (more) load_frame<R, N2>(arow, a.T, a.hop, f + SP_WAVES, lane, xn);
 
     // pass 1: radix-R over n1 (points 64*n1 + lane), twiddle W_N2^(lane*k1), scatter to [k1][c][a]
     cpx v[R];
-    if (((fi * a.hop) & 1) == 0) {   // wave-uniform: frame start 8-byte aligned -> one ds_read_b64 per point
-      const cpx* fin2 = reinterpret_cast<const cpx*>(fin);
 #pragma unroll
-      for (int n1 = 0; n1 < R; ++n1) {
-        const cpx q = fin2[64 * n1 + lane];
-        v[n1] = cmk(q.x * win[2 * n1], q.y * win[2 * n1 + 1]);
-      }
-    } else {
-#pragma unroll
-      for (int n1 = 0; n1 < R; ++n1) {
-        const int m = 2 * (64 * n1 + lane);
-        v[n1] = cmk(fin[m] * win[2 * n1], fin[m + 1] * win[2 * n1 + 1]);
-      }
-    }
+    for (int n1 = 0; n1 < R; ++n1) v[n1] = cmk(xc[2 * n1] * win[2 * n1], xc[2 * n1 + 1] * win[2 * n1 + 1]);
     dftR<R>(v);
     {
       const int c = lane & 7, aa = lane >> 3;
@@ -275,8 +258,8 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
         const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
         const cpx t = cmul(twu[i], zo);
         const cpx xk = cadd(ze, t);                     // X[k]
-        const cpx xn = cmk(ze.x - t.x, -(ze.y - t.y));  // X[N2-k] = conj(ze - t)
-        float vk = xk.x * xk.x + xk.y * xk.y, vn = xn.x * xn.x + xn.y * xn.y;
+        const cpx xq = cmk(ze.x - t.x, -(ze.y - t.y));  // X[N2-k] = conj(ze - t)
+        float vk = xk.x * xk.x + xk.y * xk.y, vn = xq.x * xq.x + xq.y * xq.y;
         if (a.value_mode == 1) { vk = sqrtf(vk); vn = sqrtf(vn); }
         else if (a.value_mode == 3) { vk = sqrtf(fmaxf(vk, a.eps)); vn = sqrtf(fmaxf(vn, a.eps)); }
         pk[i] = vk; pn[i] = vn;
@@ -291,33 +274,61 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
     }
     wave_lds_sync();
     // epilogue: mel projection (or raw bins), store / fused loss sums
-    if (live) {
+    {
       const size_t row = ((size_t)b * a.F + f) * a.n_out;
-      for (int m = lane; m < a.n_out; m += 64) {
-        float val;
+      for (int m0 = 0; m0 < a.n_out; m0 += 128) {
+        // two outputs per lane (m0 + lane, m0 + 64 + lane) advance together, 4 taps per trip, all LDS
+        // reads of a trip issued before the first use: the filter loop is latency-, not work-bound
+        const int ma = m0 + lane, mb = m0 + 64 + lane;
+        const bool oka = ma < a.n_out, okb = mb < a.n_out;
+        float va = 0.f, vb = 0.f;
         if (mel) {
-          const int s0 = s_meli[m], n = s_meli[a.n_out + m];
-          const float* w = s_melw + s_meli[2 * a.n_out + m];
-          val = 0.f;
-          for (int j = 0; j < n; ++j) val = fmaf(w[j], P[s0 + j], val);
+          const int sa = oka ? s_meli[ma] : 0, na = oka ? s_meli[a.n_out + ma] : 0;
+          const int sb = okb ? s_meli[mb] : 0, nb = okb ? s_meli[a.n_out + mb] : 0;
+          const float* wa = s_melw + (oka ? s_meli[2 * a.n_out + ma] : 0);
+          const float* wb = s_melw + (okb ? s_meli[2 * a.n_out + mb] : 0);
+          int nmax = max(na, nb);
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d, 64));
+          for (int j = 0; j < nmax; j += 4) {
+            float pa[4], pb[4], ca[4], cb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool ia = j + e < na, ib = j + e < nb;
+              pa[e] = P[ia ? sa + j + e : 0]; ca[e] = ia ? wa[j + e] : 0.f;
+              pb[e] = P[ib ? sb + j + e : 0]; cb[e] = ib ? wb[j + e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { va = fmaf(ca[e], pa[e], va); vb = fmaf(cb[e], pb[e], vb); }
+          }
         } else {
-          val = P[m];
+          va = oka ? P[ma] : 0.f;
+          vb = okb ? P[mb] : 0.f;
         }
-        if (a.out != nullptr) a.out[row + m] = val;
+        float ta = 0.f, tb = 0.f;
+        if (a.loss_mode != 0) {
+          if (oka) ta = a.target[row + ma];
+          if (okb) tb = a.target[row + mb];
+        }
+        if (a.out != nullptr) {
+          if (oka) a.out[row + ma] = va;
+          if (okb) a.out[row + mb] = vb;
+        }
         if (a.loss_mode == 1) {
-          l0 += fabsf(val - a.target[row + m]);
+          if (oka) l0 += fabsf(va - ta);
+          if (okb) l0 += fabsf(vb - tb);
         } else if (a.loss_mode == 2) {
-          const float t = a.target[row + m];
-          const float d = t - val;
-          l0 = fmaf(d, d, l0);
-          l1 = fmaf(t, t, l1);
-          l2 += fabsf(logf(val) - logf(t));
+          if (oka) { const float d = ta - va; l0 = fmaf(d, d, l0); l1 = fmaf(ta, ta, l1); l2 += fabsf(logf(va) - logf(ta)); }
+          if (okb) { const float d = tb - vb; l0 = fmaf(d, d, l0); l1 = fmaf(tb, tb, l1); l2 += fabsf(logf(vb) - logf(tb)); }
         }
       }
     }
     wave_lds_sync();
+    if (more) {
+#pragma unroll
+      for (int e = 0; e < 2 * R; ++e) xc[e] = xn[e];
+    }
   }
-  }  // groups
 
   if (a.partials != nullptr) {
     __shared__ float s_red[SP_WAVES][4];
@@ -361,12 +372,12 @@ extern "C" int ias_stft_num_frames(int T, int n_fft, int hop) {
 
 static size_t stft_lds_bytes(int n_fft, int hop, int fpb, int mel_nnz, int n_out) {
   const int R = n_fft / 128, scr = 8 * R * 9;
-  const int span = (fpb - 1) * hop + n_fft;
-  return sizeof(float) * ((span + 3) & ~3) + sizeof(cpx) * SP_WAVES * scr + sizeof(float) * ((mel_nnz + 3) & ~3) +
-         sizeof(int) * 3 * (mel_nnz ? n_out : 0);
+  (void)hop; (void)fpb;
+  return sizeof(cpx) * SP_WAVES * scr + sizeof(float) * ((mel_nnz + 3) & ~3) + sizeof(int) * 3 * (mel_nnz ? n_out : 0);
 }
 static int stft_fpb(int n_fft, int hop) {
-  return stft_lds_bytes(n_fft, hop, SP_FPB_MAX, 0, 0) <= 56 * 1024 ? SP_FPB_MAX : 4;
+  (void)n_fft; (void)hop;
+  return SP_FPB_MAX;   // frames per group; nothing is staged any more, so the span never limits it
 }
 // Frame groups per workgroup: the per-lane tables are loaded once per workgroup, so a workgroup walks
 // through several groups; sized so that B * gridDim.x is about one resident round (4 workgroups per CU).
@@ -458,7 +469,6 @@ extern "C" int ias_stft(const float* audio, const float* tables, const int* mel_
   const int F = ias_stft_num_frames(T, n_fft, hop);
   if (F < 0) return IAS_ERR_ARG;
   if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return IAS_ERR_UNSUPPORTED;
-  if (hop > n_fft) return IAS_ERR_UNSUPPORTED;
 
   SpecArgs a;
   a.audio = audio; a.tables = tables;
