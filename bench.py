@@ -194,7 +194,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("voice_audio_kernel<1>", {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("voice_audio_kernel", {}).get("hbm_bytes_per_launch")
         except Exception:  # noqa: BLE001
             traffic = None
 
@@ -217,7 +217,7 @@ def main():
             "batch_per_gpu": B, "samples_per_voice": T, "launch": launch, "loss": loss_value,
         },
         "roofline": {
-            "kernel": "voice_audio_kernel<1> (scan + oscillators + mixer)",
+            "kernel": "voice_audio_kernel (phase increments + chained fp64 scan + oscillators + mixer)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "avg_launch_ms": round(osc_ms_avg, 4), "algorithmic_bytes_per_launch": algo_bytes,
