@@ -154,27 +154,18 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
     }
   }
 
-  // frame-invariant per-lane tables, held in registers for the whole workgroup (coalesced loads from
-  // the lane-major table block): window of the lane's 2R samples, pass-1 twiddles W_N2^(lane*k1),
-  // pass-2 twiddles W_64^(c*d), unpack twiddles W_NFFT^k
-  float win[2 * R];
-  cpx tw1[R], tw2[NP_IT][8], twu[NUNP];
-  {
-    const float* tb = a.tables + lane;
-#pragma unroll
-    for (int e = 0; e < 2 * R; ++e) win[e] = tb[64 * e];
-    tb += 64 * 2 * R;
-#pragma unroll
-    for (int n1 = 0; n1 < R; ++n1) tw1[n1] = cmk(tb[64 * (2 * n1)], tb[64 * (2 * n1 + 1)]);
-    tb += 64 * 2 * R;
-#pragma unroll
-    for (int i = 0; i < NP_IT; ++i)
-#pragma unroll
-      for (int d = 0; d < 8; ++d) tw2[i][d] = cmk(tb[64 * (2 * (8 * i + d))], tb[64 * (2 * (8 * i + d) + 1)]);
-    tb += 64 * 2 * 8 * NP_IT;
-#pragma unroll
-    for (int i = 0; i < NUNP; ++i) twu[i] = cmk(tb[64 * (2 * i)], tb[64 * (2 * i + 1)]);
-  }
+  // frame-invariant per-lane tables (window of the lane's 2R samples, pass-1 twiddles W_N2^(lane*k1),
+  // pass-2 twiddles W_64^(c*d), unpack twiddles W_NFFT^k): one lane-major copy per workgroup in LDS.
+  // Holding them in registers cost 58 VGPRs and capped the kernel at 2-3 waves per SIMD, too few to
+  // cover the ~2900-cycle global-load latency measured per frame; conflict-free ds_read_b32 instead
+  // (166 -> 86 VGPRs, 120 -> 104 us).
+  constexpr int NTAB = 64 * (2 * R + 2 * R + 16 * NP_IT + 2 * NUNP);
+  float* s_tab = reinterpret_cast<float*>(s_meli + 3 * (mel ? a.n_out : 0));
+  for (int i = tid; i < NTAB; i += SP_THREADS) s_tab[i] = a.tables[i];
+  const float* t_win = s_tab + lane;
+  const float* t_tw1 = t_win + 64 * 2 * R;
+  const float* t_tw2 = t_tw1 + 64 * 2 * R;
+  const float* t_twu = t_tw2 + 64 * 2 * 8 * NP_IT;
   __syncthreads();   // mel tables visible; the only workgroup barrier before the final reduction
 
   cpx* sA = s_scr + wave * SCR;
@@ -193,12 +184,14 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
     // pass 1: radix-R over n1 (points 64*n1 + lane), twiddle W_N2^(lane*k1), scatter to [k1][c][a]
     cpx v[R];
 #pragma unroll
-    for (int n1 = 0; n1 < R; ++n1) v[n1] = cmk(xc[2 * n1] * win[2 * n1], xc[2 * n1 + 1] * win[2 * n1 + 1]);
+    for (int n1 = 0; n1 < R; ++n1)
+      v[n1] = cmk(xc[2 * n1] * t_win[64 * (2 * n1)], xc[2 * n1 + 1] * t_win[64 * (2 * n1 + 1)]);
     dftR<R>(v);
     {
       const int c = lane & 7, aa = lane >> 3;
 #pragma unroll
-      for (int k1 = 0; k1 < R; ++k1) sA[(k1 * 8 + c) * 9 + aa] = cmul(v[k1], tw1[k1]);
+      for (int k1 = 0; k1 < R; ++k1)
+        sA[(k1 * 8 + c) * 9 + aa] = cmul(v[k1], cmk(t_tw1[64 * (2 * k1)], t_tw1[64 * (2 * k1 + 1)]));
     }
     wave_lds_sync();
     // pass 2: radix-8 over a for each (k1, c); twiddle W_64^(c*d); scatter (in place) to [k1][d][c]
@@ -219,7 +212,8 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
         const int k1 = p >> 3, c = p & 7;
         dft8(u[i]);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) sA[(k1 * 8 + d) * 9 + c] = cmul(u[i][d], tw2[i][d]);
+        for (int d = 0; d < 8; ++d)
+          sA[(k1 * 8 + d) * 9 + c] = cmul(u[i][d], cmk(t_tw2[64 * (2 * (8 * i + d))], t_tw2[64 * (2 * (8 * i + d) + 1)]));
       }
     }
     wave_lds_sync();
@@ -256,7 +250,7 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
         const cpx zk = sA[k + (k >> 3)], zn = sA[kn + (kn >> 3)];
         const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
         const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-        const cpx t = cmul(twu[i], zo);
+        const cpx t = cmul(cmk(t_twu[64 * (2 * i)], t_twu[64 * (2 * i + 1)]), zo);
         const cpx xk = cadd(ze, t);                     // X[k]
         const cpx xq = cmk(ze.x - t.x, -(ze.y - t.y));  // X[N2-k] = conj(ze - t)
         float vk = xk.x * xk.x + xk.y * xk.y, vn = xq.x * xq.x + xq.y * xq.y;
@@ -373,7 +367,10 @@ extern "C" int ias_stft_num_frames(int T, int n_fft, int hop) {
 static size_t stft_lds_bytes(int n_fft, int hop, int fpb, int mel_nnz, int n_out) {
   const int R = n_fft / 128, scr = 8 * R * 9;
   (void)hop; (void)fpb;
-  return sizeof(cpx) * SP_WAVES * scr + sizeof(float) * ((mel_nnz + 3) & ~3) + sizeof(int) * 3 * (mel_nnz ? n_out : 0);
+  const int np_it = (8 * R + 63) / 64, nunp = (n_fft / 4) / 64 + 1;
+  const int ntab = 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp);
+  return sizeof(cpx) * SP_WAVES * scr + sizeof(float) * ((mel_nnz + 3) & ~3) + sizeof(int) * 3 * (mel_nnz ? n_out : 0) +
+         sizeof(float) * ntab;
 }
 static int stft_fpb(int n_fft, int hop) {
   (void)n_fft; (void)hop;
