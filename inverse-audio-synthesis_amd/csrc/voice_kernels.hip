@@ -28,12 +28,24 @@
 __constant__ IasParamRange c_param_table[IAS_NPARAMS] = IAS_PARAM_TABLE_INIT;
 
 // ------------------------------------------------------------------ wave helpers
+// Inclusive wave64 scan of doubles with DPP moves (no LDS crossbar, no selects): Hillis-Steele inside
+// each row of 16 lanes (row_shr:d shifts zeros in), then row_bcast:15 / row_bcast:31 carry the row totals
+// across rows.  Every step adds +0.0 where nothing arrives, which is exact.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const double o = __shfl_up(v, d, 64);
-    if (lane >= d) v += o;
-  }
+  (void)lane;
+  v += dpp_move<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_move<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_move<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_move<0x118, 0xf>(v);   // row_shr:8
+  v += dpp_move<0x142, 0xa>(v);   // row_bcast:15 -> rows 1 and 3
+  v += dpp_move<0x143, 0xc>(v);   // row_bcast:31 -> rows 2 and 3
   return v;
 }
 __device__ __forceinline__ double wave_sum(double v) {
@@ -225,21 +237,22 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
   float inc1[VOICE_SPT], inc2[VOICE_SPT];
   double tot1 = 0.0, tot2 = 0.0;
   const int j_wave = j_tile + wave * (64 * VOICE_SPT);
+  // (branch-free: samples past the end of the row are computed for the clamped index and masked,
+  // so the four samples of a lane form straight-line code the compiler can pack two by two)
 #pragma unroll
   for (int c = 0; c < VOICE_CHUNKS; ++c) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int j = j_wave + c * 256 + lane * 4 + e;
-      float a = 0.0f, d = 0.0f;
-      if (j < T) {
-        int i0, i1; float w0, w1;
-        ias_interp_pos(j, scale, Tc, i0, i1, w0, w1);
-        i0 -= c_lo; i1 -= c_lo;
-        const float pm1 = ias_lerp(s_ctrl[0][i0], s_ctrl[0][i1], w0, w1);
-        const float pm2 = ias_lerp(s_ctrl[2][i0], s_ctrl[2][i1], w0, w1);
-        a = ias_vco_inc_fast(vc.f0_1, vc.depth_1, pm1, inv_sample_rate);
-        d = ias_vco_inc_fast(vc.f0_2, vc.depth_2, pm2, inv_sample_rate);
-      }
+      const int jc = min(j, T - 1);
+      int i0, i1; float w0, w1;
+      ias_interp_pos_fast(jc, scale, Tc, i0, i1, w0, w1);
+      i0 -= c_lo; i1 -= c_lo;
+      const float pm1 = ias_lerp(s_ctrl[0][i0], s_ctrl[0][i1], w0, w1);
+      const float pm2 = ias_lerp(s_ctrl[2][i0], s_ctrl[2][i1], w0, w1);
+      float a = ias_vco_inc_fast(vc.f0_1, vc.depth_1, pm1, inv_sample_rate);
+      float d = ias_vco_inc_fast(vc.f0_2, vc.depth_2, pm2, inv_sample_rate);
+      if (j >= T) { a = 0.0f; d = 0.0f; }
       inc1[c * 4 + e] = a; inc2[c * 4 + e] = d;
       tot1 += (double)a; tot2 += (double)d;
     }
@@ -319,19 +332,17 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int j = j0 + e;
-      o[e] = 0.0f;
-      if (j < T) {
-        int i0, i1; float w0, w1;
-        ias_interp_pos(j, scale, Tc, i0, i1, w0, w1);
-        i0 -= c_lo; i1 -= c_lo;
-        const float amp1 = ias_lerp(s_ctrl[1][i0], s_ctrl[1][i1], w0, w1);
-        const float amp2 = ias_lerp(s_ctrl[3][i0], s_ctrl[3][i1], w0, w1);
-        const float ampn = ias_lerp(s_ctrl[4][i0], s_ctrl[4][i1], w0, w1);
-        const float a1 = ias_add((float)(base1 + l1[e]), vc.phi_1);
-        const float a2 = ias_add((float)(base2 + l2[e]), vc.phi_2);
-        o[e] = ias_mix_sample_dev(a1, a2, amp1, amp2, ampn, nz[e], vc);
-        pk = fmaxf(pk, fabsf(o[e]));
-      }
+      const int jc = min(j, T - 1);
+      int i0, i1; float w0, w1;
+      ias_interp_pos_fast(jc, scale, Tc, i0, i1, w0, w1);
+      i0 -= c_lo; i1 -= c_lo;
+      const float amp1 = ias_lerp(s_ctrl[1][i0], s_ctrl[1][i1], w0, w1);
+      const float amp2 = ias_lerp(s_ctrl[3][i0], s_ctrl[3][i1], w0, w1);
+      const float ampn = ias_lerp(s_ctrl[4][i0], s_ctrl[4][i1], w0, w1);
+      const float a1 = ias_add((float)(base1 + l1[e]), vc.phi_1);
+      const float a2 = ias_add((float)(base2 + l2[e]), vc.phi_2);
+      o[e] = ias_mix_sample_dev(a1, a2, amp1, amp2, ampn, nz[e], vc);
+      if (j < T) pk = fmaxf(pk, fabsf(o[e]));
     }
     if (vec_ok && j0 + 3 < T) {
       *reinterpret_cast<float4*>(arow + j0) = make_float4(o[0], o[1], o[2], o[3]);

@@ -12,6 +12,11 @@
 // /root/reference/audio_to_params.py:215,240-257.
 #pragma once
 #include "ias_common.h"
+#if !defined(__HIPCC__)
+#include <algorithm>
+using std::min;
+using std::max;
+#endif
 
 #define IAS_PI_D 3.141592653589793
 #define IAS_TWO_PI_D 6.283185307179586
@@ -191,6 +196,17 @@ IAS_HD void ias_interp_pos(int j, float scale, int Tc, int& i0, int& i1, float& 
   i0 = k;
   i1 = k + (k < Tc - 1 ? 1 : 0);
   w1 = fminf(fmaxf(ias_sub(real, (float)k), 0.0f), 1.0f);
+  w0 = ias_sub(1.0f, w1);
+}
+// Same values as ias_interp_pos without the clamps, which are provably inactive: 0 <= scale*j < Tc for
+// every sample index j < T (scale = fl((Tc-1)/(T-1))), so floor = trunc, the index never exceeds Tc-1
+// and real - floor(real) is already in [0, 1).
+IAS_HD void ias_interp_pos_fast(int j, float scale, int Tc, int& i0, int& i1, float& w0, float& w1) {
+  const float real = ias_mul(scale, (float)j);
+  const int k = (int)real;
+  i0 = k;
+  i1 = min(k + 1, Tc - 1);
+  w1 = ias_sub(real, (float)k);
   w0 = ias_sub(1.0f, w1);
 }
 IAS_HD float ias_lerp(float a, float b, float w0, float w1) { return ias_add(ias_mul(w0, a), ias_mul(w1, b)); }
