@@ -34,8 +34,9 @@ int ias_stream_copy(const float* src, float* dst, long long n, void* stream);
 long long ias_voice_workspace_bytes(int B, int T, int Tc);
 
 /* Control-rate pass only: params01 [B,78] in [0,1] (registration order, voice_spec.py) ->
- * ctrl [B,5,Tc] (mod-matrix outputs) and vconst [B] x 64 bytes (IasVoiceConst).  env [B,6,Tc] is
- * scratch that receives the six envelopes (adsr_1, adsr_2, lfo_1_amp, lfo_2_amp, lfo_1_rate, lfo_2_rate). */
+ * ctrl [B,5,Tc] (mod-matrix outputs) and vconst [B] x 64 bytes (IasVoiceConst).  env [B,8,Tc] is
+ * scratch that receives the six envelopes (adsr_1, adsr_2, lfo_1_amp, lfo_2_amp, lfo_1_rate, lfo_2_rate)
+ * and the two LFO outputs. */
 int ias_voice_control(const float* params01, float* ctrl, void* vconst, float* env, int B, int Tc,
                       int control_rate, void* stream);
 

@@ -6,8 +6,8 @@
 //
 // Kernels
 //   voice_env_kernel       one workgroup per (envelope, voice): the six ADSR envelopes [B][6][Tc].
-//   voice_lfo_mod_kernel   one workgroup per voice: 2 LFOs (fp64 phase scan), 4x5 mod matrix
-//                          -> ctrl[B][5][Tc] + IasVoiceConst[B].
+//   voice_lfo_kernel       one workgroup per (LFO, voice): fp64 phase scan, five shapes, amplitude.
+//   voice_modmix_kernel    4x5 mod matrix -> ctrl[B][5][Tc] + IasVoiceConst[B].
 //   voice_audio_kernel     per (tile, voice), ONE pass: phase increments of both VCOs, fp64 scan
 //                          chained across the tiles of a row (ticketed look-back; fp64 sums of
 //                          fp32 increments below 2^19 are exact, so any summation order gives the
@@ -92,71 +92,93 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_env_kernel(const float* _
   IasAdsr e;
   e.attack = s_p[0]; e.decay = s_p[1]; e.sustain = s_p[2]; e.release = s_p[3]; e.alpha = s_p[4];
   const float note_on = s_p[5], eps = (float)IAS_EPS;
-  float* out = env + ((size_t)b * 6 + a) * Tc;
-  for (int t = tid; t < Tc; t += VOICE_THREADS) out[t] = ias_adsr(t, e, note_on, control_rate, eps);
+  // flat heads of the decay / release ramps: the same for every t before the ramp starts
+  if (tid == 0) s_p[6] = ias_adsr_heads(e, note_on, control_rate, eps).decay_head;
+  if (tid == 64) s_p[7] = ias_adsr_heads(e, note_on, control_rate, eps).release_head;
+  __syncthreads();
+  IasAdsrHeads heads;
+  heads.decay_head = s_p[6]; heads.release_head = s_p[7];
+  float* out = env + ((size_t)b * 8 + a) * Tc;   // sig rows 0-5
+  for (int t = tid; t < Tc; t += VOICE_THREADS) out[t] = ias_adsr_headed(t, e, note_on, control_rate, eps, heads);
 }
 
-// One workgroup per voice: LFO phases (fp64 scan), LFO shapes, 4x5 mod matrix -> ctrl, IasVoiceConst.
-// LDS: p[80] | env[6][Tc] | lfo[2][Tc]
-__global__ __launch_bounds__(VOICE_THREADS) void voice_lfo_mod_kernel(
-    const float* __restrict__ params01, const float* __restrict__ env_g, float* __restrict__ ctrl,
-    IasVoiceConst* __restrict__ vconst,
-    float* __restrict__ dbg /* optional [B][10][Tc]: env0..5, lfo phase 0/1, lfo out 0/1 */,
+// One workgroup per (LFO, voice): phase scan (fp64 accumulate, fp32 per-sample round), the five LFO
+// shapes, amplitude envelope -> sig[b][6 + l][t].   sig rows: 0-5 envelopes (voice_env_kernel), 6-7 LFOs.
+__global__ __launch_bounds__(VOICE_THREADS) void voice_lfo_kernel(
+    const float* __restrict__ params01, float* __restrict__ sig,
+    float* __restrict__ dbg /* optional [B][10][Tc]: receives LFO phases (rows 6,7) and outputs (rows 8,9) */,
     int Tc, float control_rate) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* p = smem;
-  float* env = smem + 80;
-  float* lfo = env + 6 * Tc;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-  if (tid < IAS_NPARAMS) p[tid] = mapped_param(params01, b, tid);
-  const float* eg = env_g + (size_t)b * 6 * Tc;
-  for (int i = tid; i < 6 * Tc; i += VOICE_THREADS) env[i] = eg[i];
+  double* s_wtot = reinterpret_cast<double*>(smem);   // VOICE_WAVES wave totals
+  double* s_sum = s_wtot + VOICE_WAVES;               // Tc wave-local inclusive sums
+  __shared__ float s_q[8];
+  const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qbase = (l == 0) ? IAS_P_LFO_1_FREQUENCY : IAS_P_LFO_2_FREQUENCY;
+  if (tid < 8) s_q[tid] = mapped_param(params01, b, qbase + tid);
   __syncthreads();
-  const float midi_f0 = p[IAS_P_KEYBOARD_MIDI_F0];
+  const float freq = s_q[0], depth = s_q[1], phi = s_q[2];
+  const float* rate_env = sig + ((size_t)b * 8 + 4 + l) * Tc;
+  const float* amp_env = sig + ((size_t)b * 8 + 2 + l) * Tc;
 
-  // LFO phase: waves 0/1 scan lfo_1/lfo_2 (fp64 accumulate, fp32 per-sample round).
-  if (wave < 2) {
-    const int l = wave;
-    const float* q = p + (l == 0 ? IAS_P_LFO_1_FREQUENCY : IAS_P_LFO_2_FREQUENCY);
-    const float freq = q[0], depth = q[1], phi = q[2];
-    double carry = 0.0;
-    for (int t0 = 0; t0 < Tc; t0 += 64) {
-      const int t = t0 + lane;
-      double inc = 0.0;
-      if (t < Tc) inc = (double)ias_lfo_inc(freq, depth, env[(4 + l) * Tc + t], control_rate);
-      const double s = wave_incl_scan(inc, lane) + carry;
-      if (t < Tc) lfo[l * Tc + t] = ias_add((float)s, phi);
-      carry = __shfl(s, 63, 64);
+  // each wave scans a contiguous quarter of the control buffer in chunks of 64, then the quarters are
+  // chained through LDS (fp64; the order differs from a sequential loop only below 1e-16 relative,
+  // which the per-sample rounding to fp32 absorbs)
+  const int per_wave = ((Tc + VOICE_WAVES - 1) / VOICE_WAVES + 63) / 64 * 64;
+  const int t_begin = wave * per_wave, t_end = min(t_begin + per_wave, Tc);
+  double carry = 0.0;
+  for (int t0 = t_begin; t0 < t_end; t0 += 64) {
+    const int t = t0 + lane;
+    double inc = 0.0;
+    if (t < t_end) inc = (double)ias_lfo_inc(freq, depth, rate_env[t], control_rate);
+    const double sc = wave_incl_scan(inc, lane) + carry;
+    carry = __shfl(sc, 63, 64);
+    if (t < t_end) s_sum[t] = sc;   // wave-local inclusive sum; the preceding waves' totals are added below
+  }
+  if (lane == 0) s_wtot[wave] = carry;
+  __syncthreads();
+  double base = 0.0;
+  for (int w = 0; w < wave; ++w) base += s_wtot[w];
+  float mode[5];
+  ias_lfo_mode(s_q + 3, mode);
+  float* out = sig + ((size_t)b * 8 + 6 + l) * Tc;
+  for (int t = t_begin + lane; t < t_end; t += 64) {
+    const double ph = base + s_sum[t];
+    const float arg = ias_add((float)ph, phi);
+    const float o = ias_mul(ias_lfo_shape_mix(arg, mode), amp_env[t]);
+    out[t] = o;
+    if (dbg != nullptr) {
+      dbg[((size_t)b * 10 + 6 + l) * Tc + t] = arg;
+      dbg[((size_t)b * 10 + 8 + l) * Tc + t] = o;
     }
   }
-  __syncthreads();
-  if (dbg != nullptr) {
-    float* d = dbg + (size_t)b * 10 * Tc;
-    for (int i = tid; i < 8 * Tc; i += VOICE_THREADS) d[i] = env[i];  // env[6][Tc] then lfo phase [2][Tc]
-  }
-  __syncthreads();
-  for (int i = tid; i < 2 * Tc; i += VOICE_THREADS) {
-    const int l = i / Tc, t = i - l * Tc;
-    const float* q = p + (l == 0 ? IAS_P_LFO_1_FREQUENCY : IAS_P_LFO_2_FREQUENCY);
-    float mode[5];
-    ias_lfo_mode(q + 3, mode);
-    lfo[i] = ias_mul(ias_lfo_shape_mix(lfo[i], mode), env[(2 + l) * Tc + t]);
-  }
-  __syncthreads();
+}
 
-  if (dbg != nullptr) {
-    float* d = dbg + (size_t)b * 10 * Tc + 8 * Tc;
-    for (int i = tid; i < 2 * Tc; i += VOICE_THREADS) d[i] = lfo[i];
+// ctrl[b][j][t] = sum_k w[k][j] * sig_k[t] (4x5 mod matrix, fp64-accumulated dot) and IasVoiceConst[b].
+__global__ __launch_bounds__(VOICE_THREADS) void voice_modmix_kernel(
+    const float* __restrict__ params01, const float* __restrict__ sig, float* __restrict__ ctrl,
+    IasVoiceConst* __restrict__ vconst, float* __restrict__ dbg, int Tc) {
+  __shared__ float s_w[20];
+  __shared__ float s_p[IAS_NPARAMS];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (tid < 20) s_w[tid] = mapped_param(params01, b, IAS_P_MOD_MATRIX_ADSR_1_TO_VCO_1_PITCH + tid);
+  if (blockIdx.x == 0 && tid >= 64 && tid < 64 + IAS_NPARAMS) s_p[tid - 64] = mapped_param(params01, b, tid - 64);
+  __syncthreads();
+  const float* sb = sig + (size_t)b * 8 * Tc;
+  const int t = blockIdx.x * VOICE_THREADS + tid;
+  if (t < Tc) {
+    const float e0 = sb[t], e1 = sb[Tc + t], l0 = sb[6 * Tc + t], l1 = sb[7 * Tc + t];
+    float* out = ctrl + (size_t)b * IAS_NCTRL * Tc;
+#pragma unroll
+    for (int j = 0; j < IAS_NCTRL; ++j)
+      out[j * Tc + t] = ias_dot4_cr(s_w[j], s_w[5 + j], s_w[10 + j], s_w[15 + j], e0, e1, l0, l1);
+    if (dbg != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) dbg[((size_t)b * 10 + r) * Tc + t] = sb[r * Tc + t];
+    }
   }
-  const float* w = p + IAS_P_MOD_MATRIX_ADSR_1_TO_VCO_1_PITCH;  // [input k][output j]
-  float* out = ctrl + (size_t)b * IAS_NCTRL * Tc;
-  for (int i = tid; i < IAS_NCTRL * Tc; i += VOICE_THREADS) {
-    const int j = i / Tc, t = i - j * Tc;
-    out[i] = ias_dot4_cr(w[0 * 5 + j], w[1 * 5 + j], w[2 * 5 + j], w[3 * 5 + j],
-                         env[0 * Tc + t], env[1 * Tc + t], lfo[0 * Tc + t], lfo[1 * Tc + t]);
-  }
-  if (tid == 0) {
+  if (blockIdx.x == 0 && tid == 0) {
+    const float* p = s_p;
+    const float midi_f0 = p[IAS_P_KEYBOARD_MIDI_F0];
     IasVoiceConst vc;
     vc.f0_1 = ias_add(midi_f0, p[IAS_P_VCO_1_TUNING]);
     vc.depth_1 = p[IAS_P_VCO_1_MOD_DEPTH];
@@ -395,7 +417,7 @@ static VoiceWs voice_ws_layout(int B, int T, int Tc) {
   size_t o = 0;
   w.off_ctrl = o;    o = align_up(o + sizeof(float) * (size_t)B * IAS_NCTRL * Tc, 256);
   w.off_vconst = o;  o = align_up(o + sizeof(IasVoiceConst) * (size_t)B, 256);
-  w.off_env = o;     o = align_up(o + sizeof(float) * (size_t)B * 6 * Tc, 256);
+  w.off_env = o;     o = align_up(o + sizeof(float) * (size_t)B * 8 * Tc, 256);
   // words zeroed before every launch, in one block of their own (multiple of 16 bytes):
   // [ticket, timeout flag, pad, pad][agg: B*ntiles*2 u64][row peaks: B u32]
   w.off_sync = o;
@@ -420,22 +442,24 @@ static int voice_check_dims(int B, int T, int Tc) {
   return IAS_OK;
 }
 
-static int voice_control_launch(const float* params01, float* ctrl, void* vconst, float* env, float* dbg, int B,
+static int voice_control_launch(const float* params01, float* ctrl, void* vconst, float* sig, float* dbg, int B,
                                 int Tc, int control_rate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!params01 || !ctrl || !vconst || !env || B <= 0 || B > 65535 || Tc <= 1 || control_rate <= 0) return IAS_ERR_ARG;
-  const size_t lds = sizeof(float) * (80 + 8 * (size_t)Tc);
+  if (!params01 || !ctrl || !vconst || !sig || B <= 0 || B > 65535 || Tc <= 1 || control_rate <= 0) return IAS_ERR_ARG;
+  const size_t lds = sizeof(double) * (VOICE_WAVES + (size_t)Tc);
   if (lds > 160 * 1024) return IAS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(voice_env_kernel, dim3(6, B), dim3(VOICE_THREADS), 0, stream, params01, env, Tc,
+  hipLaunchKernelGGL(voice_env_kernel, dim3(6, B), dim3(VOICE_THREADS), 0, stream, params01, sig, Tc,
                      (float)control_rate);
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)voice_lfo_mod_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(voice_lfo_mod_kernel, dim3(B), dim3(VOICE_THREADS), lds, stream, params01, env, ctrl,
-                     (IasVoiceConst*)vconst, dbg, Tc, (float)control_rate);
+    (void)hipFuncSetAttribute((const void*)voice_lfo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(voice_lfo_kernel, dim3(2, B), dim3(VOICE_THREADS), lds, stream, params01, sig, dbg, Tc,
+                     (float)control_rate);
+  hipLaunchKernelGGL(voice_modmix_kernel, dim3((Tc + VOICE_THREADS - 1) / VOICE_THREADS, B), dim3(VOICE_THREADS), 0,
+                     stream, params01, sig, ctrl, (IasVoiceConst*)vconst, dbg, Tc);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
-// env: scratch [B][6][Tc] floats (the six envelopes), also an output for diagnostics.
+// env: scratch [B][8][Tc] floats (six envelopes + two LFO outputs), also an output for diagnostics.
 extern "C" int ias_voice_control(const float* params01, float* ctrl, void* vconst, float* env, int B, int Tc,
                                  int control_rate, void* stream_) {
   return voice_control_launch(params01, ctrl, vconst, env, nullptr, B, Tc, control_rate, stream_);

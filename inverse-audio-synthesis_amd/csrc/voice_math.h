@@ -129,6 +129,36 @@ IAS_HD float ias_ramp(int t, float duration, float start, int has_start, int inv
 
 struct IasAdsr { float attack, decay, sustain, release, alpha; };
 
+// ias_ramp with the value of its flat head supplied: for t <= start*control_rate the clamped ramp
+// position is 0, so the ramp (and its pow) is the same number for all those t -- `head` = ias_ramp at
+// t = 0.  Bit-identical to ias_ramp; at most one of an ADSR's three ramps is outside its head /
+// saturated region at any t, which cuts the fp64 pow() count by ~3x.
+IAS_HD float ias_ramp_headed(int t, float duration, float start, int inverse, float alpha, float control_rate,
+                             float eps, float head) {
+  if (ias_sub((float)t, ias_mul(start, control_rate)) <= 0.0f) return head;
+  return ias_ramp(t, duration, start, 1, inverse, alpha, control_rate, eps);
+}
+
+struct IasAdsrHeads { float decay_head, release_head; };
+IAS_HD IasAdsrHeads ias_adsr_heads(const IasAdsr& e, float note_on, float control_rate, float eps) {
+  const float new_attack = fminf(e.attack, note_on);
+  const float new_decay = fminf(fmaxf(ias_sub(note_on, e.attack), 0.0f), e.decay);
+  IasAdsrHeads h;
+  h.decay_head = ias_ramp(0, new_decay, new_attack, 1, 1, e.alpha, control_rate, eps);
+  h.release_head = ias_ramp(0, e.release, note_on, 1, 1, e.alpha, control_rate, eps);
+  return h;
+}
+IAS_HD float ias_adsr_headed(int t, const IasAdsr& e, float note_on, float control_rate, float eps,
+                             const IasAdsrHeads& h) {
+  const float new_attack = fminf(e.attack, note_on);
+  const float new_decay = fminf(fmaxf(ias_sub(note_on, e.attack), 0.0f), e.decay);
+  const float a = ias_ramp(t, new_attack, 0.0f, 0, 0, e.alpha, control_rate, eps);
+  const float dr = ias_ramp_headed(t, new_decay, new_attack, 1, e.alpha, control_rate, eps, h.decay_head);
+  const float d = ias_add(ias_mul(ias_sub(1.0f, e.sustain), dr), e.sustain);
+  const float r = ias_ramp_headed(t, e.release, note_on, 1, e.alpha, control_rate, eps, h.release_head);
+  return ias_mul(ias_mul(a, d), r);
+}
+
 IAS_HD float ias_adsr(int t, const IasAdsr& e, float note_on, float control_rate, float eps) {
   const float new_attack = fminf(e.attack, note_on);
   const float new_decay = fminf(fmaxf(ias_sub(note_on, e.attack), 0.0f), e.decay);

@@ -210,7 +210,7 @@ class Voice(nn.Module):
         ctrl = torch.empty((c.batch_size, 5, c.control_buffer_size), dtype=torch.float32, device=p.device)
         vconst = torch.empty((c.batch_size, 16), dtype=torch.float32, device=p.device)
         dbg = torch.empty((c.batch_size, 10, c.control_buffer_size), dtype=torch.float32, device=p.device)
-        env = torch.empty((c.batch_size, 6, c.control_buffer_size), dtype=torch.float32, device=p.device)
+        env = torch.empty((c.batch_size, 8, c.control_buffer_size), dtype=torch.float32, device=p.device)
         st = lib.ias_voice_control_debug(_lib.ptr(p), _lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(env), _lib.ptr(dbg), c.batch_size,
                                          c.control_buffer_size, c.control_rate, _lib.stream())
         _lib.check(st, "ias_voice_control_debug")
@@ -223,7 +223,7 @@ class Voice(nn.Module):
         lib = _lib.load()
         ctrl = torch.empty((c.batch_size, 5, c.control_buffer_size), dtype=torch.float32, device=p.device)
         vconst = torch.empty((c.batch_size, 16), dtype=torch.float32, device=p.device)
-        env = torch.empty((c.batch_size, 6, c.control_buffer_size), dtype=torch.float32, device=p.device)
+        env = torch.empty((c.batch_size, 8, c.control_buffer_size), dtype=torch.float32, device=p.device)
         st = lib.ias_voice_control(_lib.ptr(p), _lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(env), c.batch_size,
                                    c.control_buffer_size, c.control_rate, _lib.stream())
         _lib.check(st, "ias_voice_control")

@@ -99,3 +99,22 @@ extern "C" long long emul_check_fast_paths(const float* pm, long long n, float f
   }
   return bad;
 }
+
+// Counts control samples where the "headed" ADSR (cached flat ramp heads) differs from ias_adsr.
+extern "C" long long emul_check_adsr_headed(const float* p5n /* [n][6]: attack, decay, sustain, release, alpha, note_on */,
+                                            long long n, int Tc, int control_rate) {
+  long long bad = 0;
+  const float cr = (float)control_rate, eps = (float)IAS_EPS;
+  for (long long i = 0; i < n; ++i) {
+    IasAdsr e;
+    e.attack = p5n[6 * i]; e.decay = p5n[6 * i + 1]; e.sustain = p5n[6 * i + 2];
+    e.release = p5n[6 * i + 3]; e.alpha = p5n[6 * i + 4];
+    const float note_on = p5n[6 * i + 5];
+    const IasAdsrHeads h = ias_adsr_heads(e, note_on, cr, eps);
+    for (int t = 0; t < Tc; ++t) {
+      const float a = ias_adsr(t, e, note_on, cr, eps), b = ias_adsr_headed(t, e, note_on, cr, eps, h);
+      if (!(a == b) && !(a != a && b != b)) ++bad;
+    }
+  }
+  return bad;
+}

@@ -84,3 +84,21 @@ def test_fast_formulations_are_bit_identical(emul):
         bad = emul.emul_check_fast_paths(C.c_void_p(pm.data_ptr()), C.c_longlong(n), C.c_float(57.3 + seed),
                                          C.c_float(31.0 - 9 * seed), C.c_int(sr))
         assert bad == 0, f"{bad} mismatches at sample rate {sr}"
+
+
+def test_headed_adsr_is_bit_identical(emul):
+    """The env kernel caches the flat head of the decay / release ramps; same bits as the plain ADSR,
+    including zero durations and notes shorter than the attack."""
+    import ctypes as C
+    emul.emul_check_adsr_headed.restype = C.c_longlong
+    g = torch.Generator().manual_seed(3)
+    n = 400
+    p = torch.rand(n, 6, generator=g)
+    p[:, 0] *= 2.0; p[:, 1] *= 2.0; p[:, 3] *= 5.0; p[:, 4] = 0.1 + 5.9 * p[:, 4]; p[:, 5] = 0.01 + 3.99 * p[:, 5]
+    p[:20, 0] = 0.0          # zero attack
+    p[20:40, 1] = 0.0        # zero decay
+    p[40:60, 3] = 0.0        # zero release
+    p[60:80, 5] = 0.01       # note shorter than the attack
+    p = p.contiguous()
+    bad = emul.emul_check_adsr_headed(C.c_void_p(p.data_ptr()), C.c_longlong(n), C.c_int(1764), C.c_int(441))
+    assert bad == 0
