@@ -19,12 +19,17 @@
 #define SP_WAVES 4
 #define SP_FPB_MAX 8   // frames per workgroup (8, or 4 when the staged span would not fit LDS)
 
-struct __attribute__((aligned(8))) cpx { float x, y; };   // 8-byte aligned: LDS accesses become ds_*_b64
-__device__ __forceinline__ cpx cmk(float x, float y) { cpx r; r.x = x; r.y = y; return r; }
-__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return cmk(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cpx csub(cpx a, cpx b) { return cmk(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ cpx cmul(cpx a, cpx b) { return cmk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ cpx cmul_negi(cpx a) { return cmk(a.y, -a.x); }  // a * (-i)
+// Complex numbers as 2-wide vectors: gfx950 issues a plain fp32 VALU op per wave64 in 4 cycles and only
+// the packed forms (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) reach the fp32 peak, so complex add/sub
+// are one packed op and a complex multiply is pk_mul + pk_fma.  8-byte aligned: LDS accesses are ds_*_b64.
+typedef float cpx __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cpx cmk(float x, float y) { return (cpx){x, y}; }
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return a + b; }
+__device__ __forceinline__ cpx csub(cpx a, cpx b) { return a - b; }
+__device__ __forceinline__ cpx cmul(cpx a, cpx b) {
+  return __builtin_elementwise_fma((cpx){-a.y, a.y}, (cpx){b.y, b.x}, (cpx){a.x, a.x} * b);
+}
+__device__ __forceinline__ cpx cmul_negi(cpx a) { return (cpx){a.y, -a.x}; }  // a * (-i)
 
 // forward DFTs (kernel e^{-2 pi i nk/R}), in place, natural order
 __device__ __forceinline__ void dft4(cpx& v0, cpx& v1, cpx& v2, cpx& v3) {
@@ -37,9 +42,9 @@ __device__ __forceinline__ void dft8(cpx* v) {
   dft4(e0, e1, e2, e3);
   dft4(o0, o1, o2, o3);
   const float h = 0.70710678118654752f;
-  o1 = cmk((o1.x + o1.y) * h, (o1.y - o1.x) * h);    // * W8^1 = (1 - i)/sqrt2
+  o1 = (o1 + cmul_negi(o1)) * h;                      // * W8^1 = (1 - i)/sqrt2
   o2 = cmul_negi(o2);                                 // * W8^2 = -i
-  o3 = cmk((o3.y - o3.x) * h, -(o3.x + o3.y) * h);   // * W8^3 = (-1 - i)/sqrt2
+  o3 = (cmul_negi(o3) - o3) * h;                      // * W8^3 = (-1 - i)/sqrt2
   v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
   v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
   v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
