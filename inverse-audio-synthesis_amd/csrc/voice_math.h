@@ -272,10 +272,17 @@ IAS_HD float ias_partials_k(float midi_f0, float depth_2) {
 // sin/cos of an fp32 angle up to ~1e6 rad: revolutions in fp64 (error ~1e-11 rev), fractional part,
 // gfx950 v_sin_f32 / v_cos_f32 (inputs in revolutions; measured max abs error 1.3e-7).
 __device__ __forceinline__ void ias_sincos_dev(float a, float& s, float& c) {
+  // The square-wave shaper multiplies sin by up to ~2500 before tanh, so sin needs RELATIVE accuracy at
+  // its zero crossings.  Reduce (still in fp64) to a quarter revolution r2 in [-0.25, 0.25] around the
+  // nearest zero crossing: sin(2 pi r) = (-1)^q sin(2 pi r2), r2 = r - q/2, q = rint(2 r); the fp32 r2
+  // then has full relative precision where sin is small.
   const double v = (double)a * 0.15915494309189535;
-  const float fr = (float)(v - rint(v));
-  s = __builtin_amdgcn_sinf(fr);
-  c = __builtin_amdgcn_cosf(fr);
+  const double r = v - rint(v);
+  const double q = rint(r + r);
+  const float r2 = (float)fma(q, -0.5, r);
+  const float sg = ((int)q & 1) ? -1.0f : 1.0f;
+  s = sg * __builtin_amdgcn_sinf(r2);
+  c = sg * __builtin_amdgcn_cosf(r2);
 }
 __device__ __forceinline__ float ias_cos_dev(float a) {
   const double v = (double)a * 0.15915494309189535;

@@ -100,3 +100,23 @@ def test_tile_chain_completes_and_debug_rows(lib, dev):
     cfg = so.VoiceConfig(batch_size=16)
     _, _, ref_dbg = so.control_signals(cfg, v.params01.cpu(), "cr", True)
     assert torch.equal(v.control_debug().cpu(), ref_dbg)
+
+
+def test_low_pitch_square_shaper_accuracy(lib, dev):
+    """Lowest notes: the partials constant is ~1600, so the square-saw shaper multiplies sin by ~2500
+    before tanh; sin must be accurate relative to its zero crossings for the 1e-4 bar to hold."""
+    from oracle import synth_spec as S
+    B = 8
+    v = _voice(dev, B, 44100, 4.0)
+    p = so.sample_params01(so.VoiceConfig(batch_size=B), 9)
+    p[:, S.INDEX[("keyboard", "midi_f0")]] = torch.linspace(0.0, 0.12, B)
+    p[:, S.INDEX[("vco_2", "mod_depth")]] = 0.5          # symmetric curve centre: depth 0
+    p[:, S.INDEX[("vco_2", "tuning")]] = 0.5
+    p[:, S.INDEX[("mixer", "vco_2")]] = 1.0
+    p[:, S.INDEX[("mixer", "vco_1")]] = 0.0
+    p[:, S.INDEX[("mixer", "noise")]] = 0.0
+    p[:, S.INDEX[("mod_matrix", "adsr_1->vco_2_amp")]] = 1.0
+    cfg = so.VoiceConfig(batch_size=B)
+    ref = so.render_from_params01(cfg, p, so.make_noise(cfg), "cr")
+    got = v.render(p.to(dev)).cpu()
+    assert (got - ref).abs().max().item() <= AUDIO_TOL
