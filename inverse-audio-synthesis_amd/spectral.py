@@ -51,7 +51,7 @@ class STFTPlan(nn.Module):
         self.n_fft = n_fft
         self.win_length = n_fft if win_length is None else win_length
         self.hop_length = self.win_length // 2 if hop_length is None else hop_length
-        assert self.win_length <= n_fft and 0 < self.hop_length <= n_fft
+        assert self.win_length <= n_fft and self.hop_length > 0
         win = torch.hann_window(self.win_length)
         left = (n_fft - self.win_length) // 2
         window = torch.zeros(n_fft)
