@@ -223,7 +223,9 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
     const float* __restrict__ noise, float* __restrict__ audio, unsigned long long* agg /* [B][ntiles][2] */,
     unsigned int* ticket_status /* [0] ticket counter, [1] spin-timeout flag */,
     unsigned* __restrict__ rowpeak, int T, int Tc, int ntiles, double inv_sample_rate, float scale) {
-  __shared__ float s_ctrl[IAS_NCTRL][VOICE_MAXCTRL];
+  // control points as (c[i], c[i+1]) pairs: one ds_read_b64 fetches both ends of a lerp, and the clamp of
+  // the upper index at the end of the buffer is folded into the table
+  __shared__ float2 s_ctrl[IAS_NCTRL][VOICE_MAXCTRL];
   __shared__ double s_wsum[2][VOICE_WAVES];
   __shared__ double s_carry[2];
   __shared__ float s_max[VOICE_WAVES];
@@ -250,7 +252,8 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
   const float* cb = ctrl + (size_t)b * IAS_NCTRL * Tc;
   for (int i = tid; i < IAS_NCTRL * ncp; i += VOICE_THREADS) {
     const int k = i / ncp, c = i - k * ncp;
-    s_ctrl[k][c] = cb[k * Tc + c_lo + c];
+    const float* row = cb + k * Tc;
+    s_ctrl[k][c] = make_float2(row[c_lo + c], row[min(c_lo + c + 1, Tc - 1)]);
   }
   const IasVoiceConst vc = vconst[b];
   __syncthreads();
@@ -269,9 +272,10 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
       const int jc = min(j, T - 1);
       int i0, i1; float w0, w1;
       ias_interp_pos_fast(jc, scale, Tc, i0, i1, w0, w1);
-      i0 -= c_lo; i1 -= c_lo;
-      const float pm1 = ias_lerp(s_ctrl[0][i0], s_ctrl[0][i1], w0, w1);
-      const float pm2 = ias_lerp(s_ctrl[2][i0], s_ctrl[2][i1], w0, w1);
+      i0 -= c_lo;
+      const float2 q1 = s_ctrl[0][i0], q2 = s_ctrl[2][i0];
+      const float pm1 = ias_lerp(q1.x, q1.y, w0, w1);
+      const float pm2 = ias_lerp(q2.x, q2.y, w0, w1);
       float a = ias_vco_inc_fast(vc.f0_1, vc.depth_1, pm1, inv_sample_rate);
       float d = ias_vco_inc_fast(vc.f0_2, vc.depth_2, pm2, inv_sample_rate);
       if (j >= T) { a = 0.0f; d = 0.0f; }
@@ -357,10 +361,11 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
       const int jc = min(j, T - 1);
       int i0, i1; float w0, w1;
       ias_interp_pos_fast(jc, scale, Tc, i0, i1, w0, w1);
-      i0 -= c_lo; i1 -= c_lo;
-      const float amp1 = ias_lerp(s_ctrl[1][i0], s_ctrl[1][i1], w0, w1);
-      const float amp2 = ias_lerp(s_ctrl[3][i0], s_ctrl[3][i1], w0, w1);
-      const float ampn = ias_lerp(s_ctrl[4][i0], s_ctrl[4][i1], w0, w1);
+      i0 -= c_lo;
+      const float2 r1 = s_ctrl[1][i0], r2 = s_ctrl[3][i0], r3 = s_ctrl[4][i0];
+      const float amp1 = ias_lerp(r1.x, r1.y, w0, w1);
+      const float amp2 = ias_lerp(r2.x, r2.y, w0, w1);
+      const float ampn = ias_lerp(r3.x, r3.y, w0, w1);
       const float a1 = ias_add((float)(base1 + l1[e]), vc.phi_1);
       const float a2 = ias_add((float)(base2 + l2[e]), vc.phi_2);
       o[e] = ias_mix_sample_dev(a1, a2, amp1, amp2, ampn, nz[e], vc);
