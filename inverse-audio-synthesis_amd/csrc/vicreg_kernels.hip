@@ -25,7 +25,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define VC_COLS 64        // columns per colstats workgroup
-#define VC_THREADS 256
+#define VC_THREADS 1024  // 16 waves per workgroup: the column pass is latency-bound with few workgroups
 #define GT 128            // gram output tile (GT x GT)
 #define GK 64             // k-chunk staged per iteration
 #define GLD (GK + 8)      // LDS row stride in bf16 (144 B: breaks the 128-B row bank aliasing)
@@ -38,8 +38,8 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 // msepart: [gridDim.x] fp64.
 __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
     const float* __restrict__ x, const float* __restrict__ y, unsigned short* __restrict__ Xt_x,
-    unsigned short* __restrict__ Xt_y, float* __restrict__ colstats, double* __restrict__ msepart, int B, int D,
-    int Kpad) {
+    unsigned short* __restrict__ Xt_y, float* __restrict__ colstats, double* __restrict__ msepart,
+    double* __restrict__ hingepart, int B, int D, int Kpad) {
   __shared__ float s_red[4][VC_THREADS / 64][VC_COLS];
   __shared__ float s_mean[2][VC_COLS];
   __shared__ unsigned short s_tile[2][VC_COLS][64 + 2];
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
     // write out: 64 columns x 64 k as 128-byte rows; thread -> (column c = tid/4, 16 k values)
     {
       const int c = tid >> 2, part = tid & 3;
-      if (j0 + c < D) {
+      if (tid < 4 * VC_COLS && j0 + c < D) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           unsigned short* dst = (m == 0 ? Xt_x : Xt_y) + (size_t)(j0 + c) * Kpad + b0 + part * 16;
@@ -121,6 +121,18 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
     colstats[1 * (size_t)D + j] = my;
     colstats[2 * (size_t)D + j] = ax;
     colstats[3 * (size_t)D + j] = ay;
+  }
+  // variance hinge of this workgroup's columns: sum_j relu(1 - sqrt(var_j + 1e-4)) for x and y
+  if (wave == 0) {
+    float h = 0.f;
+    if (jok) {
+      float ax = 0.f, ay = 0.f;
+      for (int w = 0; w < VC_THREADS / 64; ++w) { ax += s_red[2][w][lane]; ay += s_red[3][w][lane]; }
+      const float inv_bm1 = 1.0f / (float)(B - 1);
+      h = fmaxf(1.0f - sqrtf(ax * inv_bm1 + 0.0001f), 0.f) + fmaxf(1.0f - sqrtf(ay * inv_bm1 + 0.0001f), 0.f);
+    }
+    for (int d = 32; d > 0; d >>= 1) h += __shfl_xor(h, d, 64);
+    if (lane == 0) hingepart[blockIdx.x] = (double)h;
   }
 }
 
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(256) void vicreg_gram_kernel(const unsigned short* 
 }
 
 // out[0..3] = loss, repr_loss, std_loss, cov_loss (fp32)
-__global__ __launch_bounds__(256) void vicreg_finish_kernel(const float* __restrict__ colstats,
+__global__ __launch_bounds__(256) void vicreg_finish_kernel(const double* __restrict__ hingepart,
                                                             const double* __restrict__ msepart, int nmse,
                                                             const double* __restrict__ gram_x,
                                                             const double* __restrict__ gram_y, int ngram, int B, int D,
@@ -220,12 +232,7 @@ __global__ __launch_bounds__(256) void vicreg_finish_kernel(const float* __restr
   double mse = 0.0, hinge = 0.0, gx = 0.0, gy = 0.0;
   for (int i = threadIdx.x; i < nmse; i += 256) mse += msepart[i];
   for (int i = threadIdx.x; i < ngram; i += 256) { gx += gram_x[i]; gy += gram_y[i]; }
-  const float inv_bm1 = 1.0f / (float)(B - 1);
-  for (int j = threadIdx.x; j < D; j += 256) {
-    const float sdx = sqrtf(colstats[2 * (size_t)D + j] * inv_bm1 + 0.0001f);
-    const float sdy = sqrtf(colstats[3 * (size_t)D + j] * inv_bm1 + 0.0001f);
-    hinge += (double)fmaxf(1.0f - sdx, 0.f) + (double)fmaxf(1.0f - sdy, 0.f);
-  }
+  for (int i = threadIdx.x; i < nmse; i += 256) hinge += hingepart[i];
   s[threadIdx.x][0] = mse; s[threadIdx.x][1] = hinge; s[threadIdx.x][2] = gx; s[threadIdx.x][3] = gy;
   __syncthreads();
   for (int d = 128; d > 0; d >>= 1) {
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(256) void vicreg_finish_kernel(const float* __restr
 
 // ------------------------------------------------------------------------ C ABI
 static inline size_t vc_align(size_t x) { return (x + 255) / 256 * 256; }
-struct VicregWs { size_t xt_x, xt_y, colstats, mse, gram_x, gram_y, total; int Kpad, ntile, ngram, nmse; };
+struct VicregWs { size_t xt_x, xt_y, colstats, mse, hinge, gram_x, gram_y, total; int Kpad, ntile, ngram, nmse; };
 static VicregWs vicreg_ws(int B, int D) {
   VicregWs w;
   w.Kpad = (B + GK - 1) / GK * GK;
@@ -259,6 +266,7 @@ static VicregWs vicreg_ws(int B, int D) {
   w.xt_y = o;     o = vc_align(o + sizeof(unsigned short) * (size_t)D * w.Kpad);
   w.colstats = o; o = vc_align(o + sizeof(float) * 4 * (size_t)D);
   w.mse = o;      o = vc_align(o + sizeof(double) * w.nmse);
+  w.hinge = o;    o = vc_align(o + sizeof(double) * w.nmse);
   w.gram_x = o;   o = vc_align(o + sizeof(double) * w.ngram);
   w.gram_y = o;   o = vc_align(o + sizeof(double) * w.ngram);
   w.total = o;
@@ -285,13 +293,14 @@ extern "C" int ias_vicreg_loss(const float* x, const float* y, float* out, void*
   unsigned short* xt_y = (unsigned short*)(ws + w.xt_y);
   float* colstats = (float*)(ws + w.colstats);
   double* mse = (double*)(ws + w.mse);
+  double* hinge = (double*)(ws + w.hinge);
   double* gram_x = (double*)(ws + w.gram_x);
   double* gram_y = (double*)(ws + w.gram_y);
   hipLaunchKernelGGL(vicreg_colstats_kernel, dim3(w.nmse), dim3(VC_THREADS), 0, stream, x, y, xt_x, xt_y, colstats,
-                     mse, B, D, w.Kpad);
+                     mse, hinge, B, D, w.Kpad);
   hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_x, gram_x, D, w.Kpad, w.ntile);
   hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_y, gram_y, D, w.Kpad, w.ntile);
-  hipLaunchKernelGGL(vicreg_finish_kernel, dim3(1), dim3(256), 0, stream, colstats, mse, w.nmse, gram_x, gram_y,
+  hipLaunchKernelGGL(vicreg_finish_kernel, dim3(1), dim3(256), 0, stream, hinge, mse, w.nmse, gram_x, gram_y,
                      w.ngram, B, D, cfg_batch, sim_coeff, std_coeff, cov_coeff, out);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }

@@ -22,20 +22,19 @@ using std::max;
 #define IAS_TWO_PI_D 6.283185307179586
 
 // ---- exactly-rounded fp32 primitives (no contraction, no reassociation) ----
-#if defined(__HIP_DEVICE_COMPILE__)
-IAS_HD float ias_mul(float a, float b) { return __fmul_rn(a, b); }
-IAS_HD float ias_add(float a, float b) { return __fadd_rn(a, b); }
-IAS_HD float ias_sub(float a, float b) { return __fsub_rn(a, b); }
-IAS_HD float ias_div(float a, float b) { return __fdiv_rn(a, b); }
-IAS_HD float ias_fma(float a, float b, float c) { return __fmaf_rn(a, b, c); }
-#else
-// host build is compiled with -ffp-contract=off, so plain ops are exact.
+// Plain operators under "fp contract(off)": every * and + below is one correctly rounded IEEE operation
+// and can never be fused into an FMA, on the host and on the device alike.  (The HIP __fmul_rn-style
+// intrinsics give the same values but are opaque calls that keep the compiler from packing two
+// samples into v_pk_mul_f32 / v_pk_add_f32.)  The translation units that include this header are also
+// compiled with -ffp-contract=off.
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
 IAS_HD float ias_mul(float a, float b) { return a * b; }
 IAS_HD float ias_add(float a, float b) { return a + b; }
 IAS_HD float ias_sub(float a, float b) { return a - b; }
 IAS_HD float ias_div(float a, float b) { return a / b; }
 IAS_HD float ias_fma(float a, float b, float c) { return fmaf(a, b, c); }
-#endif
 
 // ---- correctly rounded fp32 transcendentals (fp64 evaluate, round once) ----
 IAS_HD float ias_pow_cr(float x, float a) { return (float)pow((double)x, (double)a); }
