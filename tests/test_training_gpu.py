@@ -74,3 +74,22 @@ def test_audio_to_params_test_step_renders_prediction(lib, dev):
     assert not model.voice._frozen, "unfreeze_all_parameters must run after the render"
     # vicreg stays frozen
     assert all(not p.requires_grad for p in model.vicreg.parameters())
+
+
+def test_retrieval_finds_the_same_voice(lib, dev):
+    """evaluate_audio_representations.py:202-231 counterpart: a bank item queried with its own audio is its
+    own nearest neighbour at distance ~0."""
+    from inverse_audio_synthesis_amd.config import load_config
+    from inverse_audio_synthesis_amd.harness import VicregAudioParams
+    from inverse_audio_synthesis_amd.retrieval import build_bank, embed_audio, nearest
+    from conftest import ROOT
+    import os
+    cfg = load_config(os.path.join(ROOT, "conf"), "config", SMALL)
+    torch.manual_seed(1)
+    m = VicregAudioParams(cfg).to(dev)
+    bank, params = build_bank(m, [0, 1, 2])
+    assert bank.shape == (12, 64) and params.shape == (12, 78)
+    audio, _, _ = m.voice(1)
+    dist, idx = nearest(embed_audio(m, audio), bank, k=2)
+    assert idx[:, 0].tolist() == [4, 5, 6, 7]
+    assert dist[:, 0].max().item() <= 1e-3 * max(dist[:, 1].min().item(), 1e-6) + 1e-4
