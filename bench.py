@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="finish a step's PQMF / spectral loss before the next step's render starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8, help="voices in the CPU baseline sample")
     return ap.parse_args()
@@ -123,19 +125,39 @@ def main():
             e.record()
             ev[phase].append(e)
 
-    # PQMF and the spectral loss both depend only on the rendered audio: they run on two HIP streams
-    # (fork/join inside the captured graph) so the VALU-bound FIR overlaps the LDS/latency-bound STFT.
-    side = torch.cuda.Stream()
+    # Dataflow of one step: render -> audio -> {PQMF, spectral loss}.  The two consumers depend only on the
+    # audio, so they run on two side HIP streams; with double-buffered audio the NEXT step's render (VALU
+    # bound) starts while this step's PQMF / STFT (LDS / latency bound) are still running.  All K steps and
+    # their cross-stream dependencies are captured once into one hipGraph and replayed.
+    side_a, side_b = torch.cuda.Stream(), torch.cuda.Stream()
+    audio_bufs = [torch.empty((B, T), dtype=torch.float32, device=dev) for _ in range(2)]
+    last = {}
 
-    def step():
-        audio = voice.render_staged(on_stage=hook)
+    def run_steps(k, pipelined=True):
         main = torch.cuda.current_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            loss = mel_l1(audio, target_mel=target_mel)
-        z = gram(audio.unsqueeze(1))
-        main.wait_stream(side)
-        return audio, z, loss
+        consumed = [None, None]
+        for i in range(k):
+            buf = i & 1
+            if consumed[buf] is not None:          # buffer free again: both readers of step i-2 are done
+                for e in consumed[buf]:
+                    main.wait_event(e)
+            audio = voice.render_staged(on_stage=hook, out=audio_bufs[buf])
+            rendered = main.record_event()
+            side_a.wait_event(rendered)
+            side_b.wait_event(rendered)
+            with torch.cuda.stream(side_a):
+                z = gram(audio.unsqueeze(1))
+                ea = side_a.record_event()
+            with torch.cuda.stream(side_b):
+                loss = mel_l1(audio, target_mel=target_mel)
+                eb = side_b.record_event()
+            consumed[buf] = (ea, eb)
+            if not pipelined:
+                main.wait_event(ea)
+                main.wait_event(eb)
+            last["z"], last["loss"] = z, loss
+        main.wait_stream(side_a)
+        main.wait_stream(side_b)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -143,23 +165,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # ---- warm-up (eager), optional hipGraph capture of one step
-    for _ in range(max(args.warmup, 1)):
-        out = step()
+    pipelined = not args.no_pipeline
+    # ---- warm-up (eager), optional hipGraph capture of the K-step schedule
+    run_steps(max(args.warmup, 2), pipelined)
     torch.cuda.synchronize()
     launch = "eager"
     graph = None
     if not args.no_graph:
         try:
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                step()
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = step()
+                run_steps(args.steps, pipelined)
             graph.replay()
             torch.cuda.synchronize()
             launch = "hipgraph"
@@ -168,27 +184,26 @@ def main():
             graph = None
             torch.cuda.synchronize()
 
-    run = graph.replay if graph is not None else step
-
     # ---- timed region: EXACTLY K steps between barrier+synchronize brackets
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
+    if graph is not None:
+        graph.replay()
+    else:
+        run_steps(args.steps, pipelined)
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    loss_value = out[2].item()
+    loss_value = last["loss"].item()
 
     # ---- dominant-kernel timing with HIP events on the launch stream (eager pass over K steps:
     # events cannot be read back from inside a replayed graph)
     instrument["on"] = True
     torch.cuda.synchronize()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps, pipelined=False)
     torch.cuda.synchronize()
     instrument["on"] = False
     osc_ms = [b.elapsed_time(e) for b, e in zip(ev["begin"], ev["end"])]
@@ -222,7 +237,7 @@ def main():
         "config": {
             "workload": "BASELINE configs[1]: torchsynth-style Voice render + PQMF(3) analysis + mel-L1 loss, "
                         f"batch {B} x {SECONDS:g} s @ {SAMPLE_RATE} Hz per GPU",
-            "batch_per_gpu": B, "samples_per_voice": T, "launch": launch, "streams": 2, "loss": loss_value,
+            "batch_per_gpu": B, "samples_per_voice": T, "launch": launch, "streams": 3, "pipelined": pipelined, "loss": loss_value,
         },
         "roofline": {
             "kernel": "voice_audio_kernel (phase increments + chained fp64 scan + oscillators + mixer)",

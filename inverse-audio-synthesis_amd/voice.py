@@ -164,9 +164,10 @@ class Voice(nn.Module):
         _lib.check(st, "ias_voice_render")
         return audio
 
-    def render_staged(self, params01=None, on_stage=None):
-        """The same render issued stage by stage (control, phase sums, oscillators, normalise);
-        ``on_stage(name, phase)`` is called with phase "begin"/"end" around each (bench event hooks)."""
+    def render_staged(self, params01=None, on_stage=None, out=None):
+        """The same render issued stage by stage (control, oscillators, normalise);
+        ``on_stage(name, phase)`` is called with phase "begin"/"end" around each (bench event hooks).
+        ``out``: optional preallocated [B,T] fp32 buffer (double-buffered pipelines)."""
         c = self.synthconfig
         p = (self.params01 if params01 is None else params01).detach().to(torch.float32).contiguous()
         lib = _lib.load()
@@ -174,7 +175,11 @@ class Voice(nn.Module):
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != p.device:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=p.device)
         ws = self._workspace
-        audio = torch.empty((c.batch_size, c.buffer_size), dtype=torch.float32, device=p.device)
+        if out is None:
+            audio = torch.empty((c.batch_size, c.buffer_size), dtype=torch.float32, device=p.device)
+        else:
+            assert out.shape == (c.batch_size, c.buffer_size) and out.dtype == torch.float32 and out.is_contiguous()
+            audio = out
         hook = on_stage or (lambda name, phase: None)
         # workspace layout: ctrl, vconst (64 B per voice), env (csrc/voice_kernels.hip voice_ws_layout)
         a256 = lambda n: (n + 255) // 256 * 256
