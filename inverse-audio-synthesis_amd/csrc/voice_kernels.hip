@@ -222,10 +222,14 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
     const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst,
     const float* __restrict__ noise, float* __restrict__ audio, unsigned long long* agg /* [B][ntiles][2] */,
     unsigned int* ticket_status /* [0] ticket counter, [1] spin-timeout flag */,
-    unsigned* __restrict__ rowpeak, int T, int Tc, int ntiles, double inv_sample_rate, float scale) {
+    unsigned* __restrict__ rowpeak, int T, int Tc, int ntiles, double inv_sample_rate, float scale, int maxctrl) {
   // control points as (c[i], c[i+1]) pairs: one ds_read_b64 fetches both ends of a lerp, and the clamp of
   // the upper index at the end of the buffer is folded into the table
-  __shared__ float2 s_ctrl[IAS_NCTRL][VOICE_MAXCTRL];
+  // dynamic LDS: s_inc [2][VOICE_SPT][VOICE_THREADS] floats (the tile's phase increments wait here between
+  // phase A and phase B instead of in 32 VGPRs) | s_ctrl [IAS_NCTRL][maxctrl] float2
+  extern __shared__ __attribute__((aligned(16))) float dyn_smem[];
+  float* s_inc = dyn_smem;
+  float2* s_ctrl = reinterpret_cast<float2*>(dyn_smem + 2 * VOICE_SPT * VOICE_THREADS);
   __shared__ double s_wsum[2][VOICE_WAVES];
   __shared__ double s_carry[2];
   __shared__ float s_max[VOICE_WAVES];
@@ -253,13 +257,12 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
   for (int i = tid; i < IAS_NCTRL * ncp; i += VOICE_THREADS) {
     const int k = i / ncp, c = i - k * ncp;
     const float* row = cb + k * Tc;
-    s_ctrl[k][c] = make_float2(row[c_lo + c], row[min(c_lo + c + 1, Tc - 1)]);
+    s_ctrl[k * maxctrl + c] = make_float2(row[c_lo + c], row[min(c_lo + c + 1, Tc - 1)]);
   }
   const IasVoiceConst vc = vconst[b];
   __syncthreads();
 
   // phase A: increments (kept in registers) and per-wave totals
-  float inc1[VOICE_SPT], inc2[VOICE_SPT];
   double tot1 = 0.0, tot2 = 0.0;
   const int j_wave = j_tile + wave * (64 * VOICE_SPT);
   // (branch-free: samples past the end of the row are computed for the clamped index and masked,
@@ -273,13 +276,14 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
       int i0, i1; float w0, w1;
       ias_interp_pos_fast(jc, scale, Tc, i0, i1, w0, w1);
       i0 -= c_lo;
-      const float2 q1 = s_ctrl[0][i0], q2 = s_ctrl[2][i0];
+      const float2 q1 = s_ctrl[i0], q2 = s_ctrl[2 * maxctrl + i0];
       const float pm1 = ias_lerp(q1.x, q1.y, w0, w1);
       const float pm2 = ias_lerp(q2.x, q2.y, w0, w1);
       float a = ias_vco_inc_fast(vc.f0_1, vc.depth_1, pm1, inv_sample_rate);
       float d = ias_vco_inc_fast(vc.f0_2, vc.depth_2, pm2, inv_sample_rate);
       if (j >= T) { a = 0.0f; d = 0.0f; }
-      inc1[c * 4 + e] = a; inc2[c * 4 + e] = d;
+      s_inc[(c * 4 + e) * VOICE_THREADS + tid] = a;
+      s_inc[(VOICE_SPT + c * 4 + e) * VOICE_THREADS + tid] = d;
       tot1 += (double)a; tot2 += (double)d;
     }
   }
@@ -336,11 +340,12 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
   for (int c = 0; c < VOICE_CHUNKS; ++c) {
     const int j0 = j_wave + c * 256 + lane * 4;
     double l1[4], l2[4];
-    l1[0] = (double)inc1[c * 4]; l2[0] = (double)inc2[c * 4];
+    l1[0] = (double)s_inc[(c * 4) * VOICE_THREADS + tid];
+    l2[0] = (double)s_inc[(VOICE_SPT + c * 4) * VOICE_THREADS + tid];
 #pragma unroll
     for (int e = 1; e < 4; ++e) {
-      l1[e] = l1[e - 1] + (double)inc1[c * 4 + e];
-      l2[e] = l2[e - 1] + (double)inc2[c * 4 + e];
+      l1[e] = l1[e - 1] + (double)s_inc[(c * 4 + e) * VOICE_THREADS + tid];
+      l2[e] = l2[e - 1] + (double)s_inc[(VOICE_SPT + c * 4 + e) * VOICE_THREADS + tid];
     }
     const double in1 = wave_incl_scan(l1[3], lane), in2 = wave_incl_scan(l2[3], lane);
     const double base1 = run1 + (in1 - l1[3]), base2 = run2 + (in2 - l2[3]);
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
       int i0, i1; float w0, w1;
       ias_interp_pos_fast(jc, scale, Tc, i0, i1, w0, w1);
       i0 -= c_lo;
-      const float2 r1 = s_ctrl[1][i0], r2 = s_ctrl[3][i0], r3 = s_ctrl[4][i0];
+      const float2 r1 = s_ctrl[maxctrl + i0], r2 = s_ctrl[3 * maxctrl + i0], r3 = s_ctrl[4 * maxctrl + i0];
       const float amp1 = ias_lerp(r1.x, r1.y, w0, w1);
       const float amp2 = ias_lerp(r2.x, r2.y, w0, w1);
       const float ampn = ias_lerp(r3.x, r3.y, w0, w1);
@@ -439,11 +444,16 @@ extern "C" long long ias_voice_workspace_bytes(int B, int T, int Tc) {
   return (long long)voice_ws_layout(B, T, Tc).total;
 }
 
+// control points one tile can touch (+ the pair look-ahead and rounding slack)
+static int voice_maxctrl(int T, int Tc) {
+  return (int)((double)VOICE_TILE * (double)(Tc - 1) / (double)(T - 1)) + 6;
+}
+
 static int voice_check_dims(int B, int T, int Tc) {
   if (B <= 0 || T <= 1 || Tc <= 1 || B > 65535) return IAS_ERR_ARG;
   // control points touched by one tile must fit the LDS stage
   const double span = (double)VOICE_TILE * (double)(Tc - 1) / (double)(T - 1);
-  if (span + 4.0 > (double)VOICE_MAXCTRL) return IAS_ERR_UNSUPPORTED;
+  if (span + 6.0 > (double)VOICE_MAXCTRL) return IAS_ERR_UNSUPPORTED;   // keeps the LDS image under ~45 KB
   return IAS_OK;
 }
 
@@ -497,9 +507,11 @@ extern "C" int ias_voice_stage(int stage, const float* noise, float* audio, void
     // ticket, timeout flag, tile aggregates and row peaks are re-zeroed on every call
     if (hipMemsetAsync(ws + w.off_sync, 0, w.sync_bytes, stream) != hipSuccess) return IAS_ERR_LAUNCH;
     const float scale = (float)(Tc - 1) / (float)(T - 1);
-    hipLaunchKernelGGL(voice_audio_kernel, dim3(w.ntiles * B), dim3(VOICE_THREADS), 0, stream, ctrl, vconst, noise,
+    const int maxctrl = voice_maxctrl(T, Tc);
+    const size_t lds = sizeof(float) * 2 * VOICE_SPT * VOICE_THREADS + sizeof(float2) * IAS_NCTRL * (size_t)maxctrl;
+    hipLaunchKernelGGL(voice_audio_kernel, dim3(w.ntiles * B), dim3(VOICE_THREADS), lds, stream, ctrl, vconst, noise,
                        audio, (unsigned long long*)(ws + w.off_agg), (unsigned int*)(ws + w.off_sync), peak, T, Tc,
-                       w.ntiles, 1.0 / (double)sample_rate, scale);
+                       w.ntiles, 1.0 / (double)sample_rate, scale, maxctrl);
   } else {
     const int nvec = T / 4;
     int gx = (nvec + 255) / 256;
