@@ -19,10 +19,12 @@
 #include "voice_math.h"
 #include "voice_table.h"
 
-#define VOICE_THREADS 256
+#define VOICE_THREADS 256                     // control-rate kernels
 #define VOICE_WAVES (VOICE_THREADS / 64)
-#define VOICE_SPT 16                          // samples per thread
-#define VOICE_TILE (VOICE_THREADS * VOICE_SPT)  // 4096 samples per workgroup
+#define AUDIO_THREADS 256                     // audio-rate kernel (512-thread tiles measured no faster)
+#define AUDIO_WAVES (AUDIO_THREADS / 64)
+#define VOICE_SPT 16                          // samples per thread (8 and 12 measured slower: per-tile latencies)
+#define VOICE_TILE (AUDIO_THREADS * VOICE_SPT)  // 4096 samples per workgroup
 #define VOICE_CHUNKS (VOICE_SPT / 4)
 
 __constant__ IasParamRange c_param_table[IAS_NPARAMS] = IAS_PARAM_TABLE_INIT;
@@ -206,7 +208,7 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 
 // Single pass over the row with a chained scan across tiles ("decoupled look-back"):
-//   ticket  -> (voice, tile); tickets are handed out in launch order, so every predecessor tile of
+//   ticket  -> (tile, voice), tile-major; tickets are handed out in launch order, so every predecessor tile of
 //              the same voice has already started when a workgroup begins (no dependence on dispatch
 //              order or placement: a workgroup only ever waits for workgroups with smaller tickets,
 //              and those publish before they wait).
@@ -218,28 +220,32 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 //   wait    -> wave 0 polls the predecessors' words with relaxed agent-scope loads (L1 bypass),
 //              bounded spins, and adds them up: the tile's carry-in.
 //   phase B -> fp64 scan with the carry, round to fp32, + phi, oscillators, VCAs, mixer, row peak.
-__global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
+__global__ __launch_bounds__(AUDIO_THREADS) void voice_audio_kernel(
     const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst,
     const float* __restrict__ noise, float* __restrict__ audio, unsigned long long* agg /* [B][ntiles][2] */,
     unsigned int* ticket_status /* [0] ticket counter, [1] spin-timeout flag */,
     unsigned* __restrict__ rowpeak, int T, int Tc, int ntiles, double inv_sample_rate, float scale, int maxctrl) {
   // control points as (c[i], c[i+1]) pairs: one ds_read_b64 fetches both ends of a lerp, and the clamp of
   // the upper index at the end of the buffer is folded into the table
-  // dynamic LDS: s_inc [2][VOICE_SPT][VOICE_THREADS] floats (the tile's phase increments wait here between
+  // dynamic LDS: s_inc [2][VOICE_SPT][AUDIO_THREADS] floats (the tile's phase increments wait here between
   // phase A and phase B instead of in 32 VGPRs) | s_ctrl [IAS_NCTRL][maxctrl] float2
   extern __shared__ __attribute__((aligned(16))) float dyn_smem[];
   float* s_inc = dyn_smem;
-  float2* s_ctrl = reinterpret_cast<float2*>(dyn_smem + 2 * VOICE_SPT * VOICE_THREADS);
-  __shared__ double s_wsum[2][VOICE_WAVES];
+  float2* s_ctrl = reinterpret_cast<float2*>(dyn_smem + 2 * VOICE_SPT * AUDIO_THREADS);
+  __shared__ double s_wsum[2][AUDIO_WAVES];
   __shared__ double s_carry[2];
-  __shared__ float s_max[VOICE_WAVES];
+  __shared__ float s_max[AUDIO_WAVES];
   __shared__ unsigned s_ticket;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_ticket = __hip_atomic_fetch_add((gu32*)ticket_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const int ticket = (int)s_ticket;
-  const int b = ticket / ntiles, tile = ticket - b * ntiles;
+  // tile-major order: the predecessors of (tile, b) are the tickets (tile', b), tile' < tile, i.e. at least
+  // B tickets older -- they have normally published long before this workgroup polls.  (Row-major order,
+  // where the predecessor is the previous ticket, spent 42 % of the wave time in the look-back wait.)
+  const int nvoices = gridDim.x / ntiles;
+  const int tile = ticket / nvoices, b = ticket - tile * nvoices;
   const int j_tile = tile * VOICE_TILE;
   const int j_last = min(j_tile + VOICE_TILE, T) - 1;
 
@@ -254,37 +260,53 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
   }
   const int ncp = c_hi - c_lo + 1;  // host guarantees ncp <= VOICE_MAXCTRL
   const float* cb = ctrl + (size_t)b * IAS_NCTRL * Tc;
-  for (int i = tid; i < IAS_NCTRL * ncp; i += VOICE_THREADS) {
+  for (int i = tid; i < IAS_NCTRL * ncp; i += AUDIO_THREADS) {
     const int k = i / ncp, c = i - k * ncp;
     const float* row = cb + k * Tc;
     s_ctrl[k * maxctrl + c] = make_float2(row[c_lo + c], row[min(c_lo + c + 1, Tc - 1)]);
   }
   const IasVoiceConst vc = vconst[b];
   __syncthreads();
+  // early look-back: the predecessors' words are requested here, after the staging barrier (tile-major
+  // tickets make the predecessors ~3 us older: by now they have normally published) and examined only
+  // after phase A, which hides the round trip
+  gu64* row = (gu64*)(agg + ((size_t)b * ntiles) * 2);
+  unsigned long long early1 = VOICE_READY_BIT, early2 = VOICE_READY_BIT;
+  if (wave == 0 && lane < tile) {
+    early1 = __hip_atomic_load(row + lane * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    early2 = __hip_atomic_load(row + lane * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+
+  const int j_wave = j_tile + wave * (64 * VOICE_SPT);
+  const float* nrow = noise + (size_t)b * T;
+  const bool vec_ok = (T & 3) == 0;
 
   // phase A: increments (kept in registers) and per-wave totals
   double tot1 = 0.0, tot2 = 0.0;
-  const int j_wave = j_tile + wave * (64 * VOICE_SPT);
   // (branch-free: samples past the end of the row are computed for the clamped index and masked,
   // so the four samples of a lane form straight-line code the compiler can pack two by two)
 #pragma unroll
   for (int c = 0; c < VOICE_CHUNKS; ++c) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int j = j_wave + c * 256 + lane * 4 + e;
-      const int jc = min(j, T - 1);
-      int i0, i1; float w0, w1;
-      ias_interp_pos_fast(jc, scale, Tc, i0, i1, w0, w1);
-      i0 -= c_lo;
-      const float2 q1 = s_ctrl[i0], q2 = s_ctrl[2 * maxctrl + i0];
-      const float pm1 = ias_lerp(q1.x, q1.y, w0, w1);
-      const float pm2 = ias_lerp(q2.x, q2.y, w0, w1);
-      float a = ias_vco_inc_fast(vc.f0_1, vc.depth_1, pm1, inv_sample_rate);
-      float d = ias_vco_inc_fast(vc.f0_2, vc.depth_2, pm2, inv_sample_rate);
-      if (j >= T) { a = 0.0f; d = 0.0f; }
-      s_inc[(c * 4 + e) * VOICE_THREADS + tid] = a;
-      s_inc[(VOICE_SPT + c * 4 + e) * VOICE_THREADS + tid] = d;
-      tot1 += (double)a; tot2 += (double)d;
+    for (int h = 0; h < 2; ++h) {   // two samples at a time (packed fp32)
+      const int j = j_wave + c * 256 + lane * 4 + 2 * h;
+      int k[2]; ias_f2 w0, w1;
+      ias_interp_pair(min(j, T - 1), min(j + 1, T - 1), scale, k, w0, w1);
+      const int i0 = k[0] - c_lo, i1 = k[1] - c_lo;
+      const ias_f2 pm1 = ias_lerp_pair(s_ctrl[i0], s_ctrl[i1], w0, w1);
+      const ias_f2 pm2 = ias_lerp_pair(s_ctrl[2 * maxctrl + i0], s_ctrl[2 * maxctrl + i1], w0, w1);
+      ias_f2 a = ias_vco_inc_pair(vc.f0_1, vc.depth_1, pm1, inv_sample_rate);
+      ias_f2 d = ias_vco_inc_pair(vc.f0_2, vc.depth_2, pm2, inv_sample_rate);
+      if (j >= T) { a.x = 0.0f; d.x = 0.0f; }
+      if (j + 1 >= T) { a.y = 0.0f; d.y = 0.0f; }
+      const int e0 = c * 4 + 2 * h;
+      s_inc[e0 * AUDIO_THREADS + tid] = a.x;
+      s_inc[(e0 + 1) * AUDIO_THREADS + tid] = a.y;
+      s_inc[(VOICE_SPT + e0) * AUDIO_THREADS + tid] = d.x;
+      s_inc[(VOICE_SPT + e0 + 1) * AUDIO_THREADS + tid] = d.y;
+      tot1 += (double)a.x; tot1 += (double)a.y;
+      tot2 += (double)d.x; tot2 += (double)d.y;
     }
   }
   tot1 = wave_sum(tot1); tot2 = wave_sum(tot2);
@@ -292,11 +314,10 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
   __syncthreads();
 
   // publish this tile's sums, then collect the predecessors' (wave 0)
-  gu64* row = (gu64*)(agg + ((size_t)b * ntiles) * 2);
   if (wave == 0) {
     if (lane < 2) {
       double a = 0.0;
-      for (int w = 0; w < VOICE_WAVES; ++w) a += s_wsum[lane][w];
+      for (int w = 0; w < AUDIO_WAVES; ++w) a += s_wsum[lane][w];
       __hip_atomic_store(row + tile * 2 + lane, (unsigned long long)__double_as_longlong(a) | VOICE_READY_BIT,
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -304,17 +325,19 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
     bool timeout = false;
     for (int t0 = 0; t0 < tile; t0 += 64) {
       const int t = t0 + lane;
-      unsigned long long x1 = VOICE_READY_BIT, x2 = VOICE_READY_BIT;
+      unsigned long long x1 = VOICE_READY_BIT, x2 = VOICE_READY_BIT;   // lanes without a predecessor: ready
+      if (t0 == 0) { x1 = early1; x2 = early2; }
+      else if (t < tile) { x1 = 0; x2 = 0; }
       unsigned spins = 0;
-      for (;;) {
-        if (t < tile) {
+      bool ok = (x1 & x2 & VOICE_READY_BIT) != 0;
+      while (!__all(ok)) {                        // wave-uniform loop condition
+        if (++spins > VOICE_SPIN_LIMIT) { timeout = true; break; }
+        if (!ok) {
           x1 = __hip_atomic_load(row + t * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           x2 = __hip_atomic_load(row + t * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = (x1 & x2 & VOICE_READY_BIT) != 0;
         }
-        const bool ok = (x1 & x2 & VOICE_READY_BIT) != 0;
-        if (__all(ok)) break;
-        if (++spins > VOICE_SPIN_LIMIT) { timeout = true; break; }
-        __builtin_amdgcn_s_sleep(2);
+        if (!__all(ok)) __builtin_amdgcn_s_sleep(2);
       }
       if (t < tile) {
         a1 += __longlong_as_double((long long)(x1 & ~VOICE_READY_BIT));
@@ -333,19 +356,17 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
   double run1 = s_carry[0], run2 = s_carry[1];
   for (int w = 0; w < wave; ++w) { run1 += s_wsum[0][w]; run2 += s_wsum[1][w]; }
   float pk = 0.0f;
-  const float* nrow = noise + (size_t)b * T;
   float* arow = audio + (size_t)b * T;
-  const bool vec_ok = (T & 3) == 0;
 #pragma unroll
   for (int c = 0; c < VOICE_CHUNKS; ++c) {
     const int j0 = j_wave + c * 256 + lane * 4;
     double l1[4], l2[4];
-    l1[0] = (double)s_inc[(c * 4) * VOICE_THREADS + tid];
-    l2[0] = (double)s_inc[(VOICE_SPT + c * 4) * VOICE_THREADS + tid];
+    l1[0] = (double)s_inc[(c * 4) * AUDIO_THREADS + tid];
+    l2[0] = (double)s_inc[(VOICE_SPT + c * 4) * AUDIO_THREADS + tid];
 #pragma unroll
     for (int e = 1; e < 4; ++e) {
-      l1[e] = l1[e - 1] + (double)s_inc[(c * 4 + e) * VOICE_THREADS + tid];
-      l2[e] = l2[e - 1] + (double)s_inc[(VOICE_SPT + c * 4 + e) * VOICE_THREADS + tid];
+      l1[e] = l1[e - 1] + (double)s_inc[(c * 4 + e) * AUDIO_THREADS + tid];
+      l2[e] = l2[e - 1] + (double)s_inc[(VOICE_SPT + c * 4 + e) * AUDIO_THREADS + tid];
     }
     const double in1 = wave_incl_scan(l1[3], lane), in2 = wave_incl_scan(l2[3], lane);
     const double base1 = run1 + (in1 - l1[3]), base2 = run2 + (in2 - l2[3]);
@@ -361,20 +382,20 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
     }
     float o[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int j = j0 + e;
-      const int jc = min(j, T - 1);
-      int i0, i1; float w0, w1;
-      ias_interp_pos_fast(jc, scale, Tc, i0, i1, w0, w1);
-      i0 -= c_lo;
-      const float2 r1 = s_ctrl[maxctrl + i0], r2 = s_ctrl[3 * maxctrl + i0], r3 = s_ctrl[4 * maxctrl + i0];
-      const float amp1 = ias_lerp(r1.x, r1.y, w0, w1);
-      const float amp2 = ias_lerp(r2.x, r2.y, w0, w1);
-      const float ampn = ias_lerp(r3.x, r3.y, w0, w1);
-      const float a1 = ias_add((float)(base1 + l1[e]), vc.phi_1);
-      const float a2 = ias_add((float)(base2 + l2[e]), vc.phi_2);
-      o[e] = ias_mix_sample_dev(a1, a2, amp1, amp2, ampn, nz[e], vc);
-      if (j < T) pk = fmaxf(pk, fabsf(o[e]));
+    for (int h = 0; h < 2; ++h) {   // two samples at a time (packed fp32)
+      const int j = j0 + 2 * h;
+      int k[2]; ias_f2 w0, w1;
+      ias_interp_pair(min(j, T - 1), min(j + 1, T - 1), scale, k, w0, w1);
+      const int i0 = k[0] - c_lo, i1 = k[1] - c_lo;
+      const ias_f2 amp1 = ias_lerp_pair(s_ctrl[maxctrl + i0], s_ctrl[maxctrl + i1], w0, w1);
+      const ias_f2 amp2 = ias_lerp_pair(s_ctrl[3 * maxctrl + i0], s_ctrl[3 * maxctrl + i1], w0, w1);
+      const ias_f2 ampn = ias_lerp_pair(s_ctrl[4 * maxctrl + i0], s_ctrl[4 * maxctrl + i1], w0, w1);
+      const ias_f2 a1 = (ias_f2){(float)(base1 + l1[2 * h]), (float)(base1 + l1[2 * h + 1])} + vc.phi_1;
+      const ias_f2 a2 = (ias_f2){(float)(base2 + l2[2 * h]), (float)(base2 + l2[2 * h + 1])} + vc.phi_2;
+      const ias_f2 om = ias_mix_pair_dev(a1, a2, amp1, amp2, ampn, (ias_f2){nz[2 * h], nz[2 * h + 1]}, vc);
+      o[2 * h] = om.x; o[2 * h + 1] = om.y;
+      if (j < T) pk = fmaxf(pk, fabsf(om.x));
+      if (j + 1 < T) pk = fmaxf(pk, fabsf(om.y));
     }
     if (vec_ok && j0 + 3 < T) {
       *reinterpret_cast<float4*>(arow + j0) = make_float4(o[0], o[1], o[2], o[3]);
@@ -388,7 +409,7 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_audio_kernel(
   __syncthreads();
   if (tid == 0) {
     float m = s_max[0];
-    for (int w = 1; w < VOICE_WAVES; ++w) m = fmaxf(m, s_max[w]);
+    for (int w = 1; w < AUDIO_WAVES; ++w) m = fmaxf(m, s_max[w]);
     atomicMax(rowpeak + b, __float_as_uint(m));  // m >= 0: uint order == float order
   }
 }
@@ -508,8 +529,10 @@ extern "C" int ias_voice_stage(int stage, const float* noise, float* audio, void
     if (hipMemsetAsync(ws + w.off_sync, 0, w.sync_bytes, stream) != hipSuccess) return IAS_ERR_LAUNCH;
     const float scale = (float)(Tc - 1) / (float)(T - 1);
     const int maxctrl = voice_maxctrl(T, Tc);
-    const size_t lds = sizeof(float) * 2 * VOICE_SPT * VOICE_THREADS + sizeof(float2) * IAS_NCTRL * (size_t)maxctrl;
-    hipLaunchKernelGGL(voice_audio_kernel, dim3(w.ntiles * B), dim3(VOICE_THREADS), lds, stream, ctrl, vconst, noise,
+    const size_t lds = sizeof(float) * 2 * VOICE_SPT * AUDIO_THREADS + sizeof(float2) * IAS_NCTRL * (size_t)maxctrl;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)voice_audio_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(voice_audio_kernel, dim3(w.ntiles * B), dim3(AUDIO_THREADS), lds, stream, ctrl, vconst, noise,
                        audio, (unsigned long long*)(ws + w.off_agg), (unsigned int*)(ws + w.off_sync), peak, T, Tc,
                        w.ntiles, 1.0 / (double)sample_rate, scale, maxctrl);
   } else {

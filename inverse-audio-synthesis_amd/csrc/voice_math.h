@@ -307,6 +307,52 @@ __device__ __forceinline__ float ias_mix_sample_dev(float arg1, float arg2, floa
   o = ias_add(o, ias_mul(vc.lvl2, nz));
   return o;
 }
+
+// ---- two samples at a time: gfx950 issues a plain fp32 VALU op for a wave64 in 4 cycles and only the
+// packed forms (v_pk_mul_f32 / v_pk_add_f32) reach the fp32 peak, so the fp32 half of the per-sample
+// arithmetic is written on 2-wide vectors (same operations, same rounding, per component).
+typedef float ias_f2 __attribute__((ext_vector_type(2)));
+
+// ias_interp_pos_fast for samples (j0, j1): truncated control index k[2] and the lerp weights.
+__device__ __forceinline__ void ias_interp_pair(int j0, int j1, float scale, int (&k)[2], ias_f2& w0, ias_f2& w1) {
+  const ias_f2 real = scale * (ias_f2){(float)j0, (float)j1};
+  k[0] = (int)real.x; k[1] = (int)real.y;
+  w1 = real - (ias_f2){(float)k[0], (float)k[1]};
+  w0 = 1.0f - w1;
+}
+// lerp of two samples from their (c[i], c[i+1]) table entries
+__device__ __forceinline__ ias_f2 ias_lerp_pair(float2 q0, float2 q1, ias_f2 w0, ias_f2 w1) {
+  return w0 * (ias_f2){q0.x, q1.x} + w1 * (ias_f2){q0.y, q1.y};
+}
+// ias_vco_inc_fast for two samples
+__device__ __forceinline__ ias_f2 ias_vco_inc_pair(float f0, float depth, ias_f2 pm, double inv_sample_rate) {
+  ias_f2 c = f0 + depth * pm;
+  c.x = fminf(fmaxf(c.x, 0.0f), 127.0f);
+  c.y = fminf(fmaxf(c.y, 0.0f), 127.0f);
+  const ias_f2 s = c - 69.0f;
+  const ias_f2 e = {ias_exp2_cr_fast(ias_div_by_recip(s.x, 1.0 / 12.0)),
+                    ias_exp2_cr_fast(ias_div_by_recip(s.y, 1.0 / 12.0))};
+  const ias_f2 w = (float)IAS_TWO_PI_D * (440.0f * e);
+  return (ias_f2){ias_div_by_recip(w.x, inv_sample_rate), ias_div_by_recip(w.y, inv_sample_rate)};
+}
+// ias_mix_sample_dev for two samples
+__device__ __forceinline__ ias_f2 ias_mix_pair_dev(ias_f2 arg1, ias_f2 arg2, ias_f2 amp1, ias_f2 amp2, ias_f2 ampn,
+                                                   ias_f2 noise, const IasVoiceConst& vc) {
+  float sx, sy, cx, cy;
+  ias_sincos_dev(arg2.x, sx, cx);
+  ias_sincos_dev(arg2.y, sy, cy);
+  const ias_f2 s2 = {sx, sy}, c2 = {cx, cy};
+  const ias_f2 c1 = {ias_cos_dev(arg1.x), ias_cos_dev(arg1.y)};
+  const ias_f2 v1 = c1 * amp1;
+  const ias_f2 z = (vc.kpart * s2) * 0.5f;
+  const ias_f2 sq = {ias_tanh_dev(z.x), ias_tanh_dev(z.y)};
+  const ias_f2 v2 = ((vc.shape_gain * sq) * (1.0f + vc.shape * c2)) * amp2;
+  const ias_f2 nz = noise * ampn;
+  ias_f2 o = vc.lvl0 * v1;
+  o = o + vc.lvl1 * v2;
+  o = o + vc.lvl2 * nz;
+  return o;
+}
 #endif
 
 // unnormalised mixer output for one sample, given both phases (fp32, phi added).
