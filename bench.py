@@ -125,24 +125,47 @@ def main():
             e.record()
             ev[phase].append(e)
 
-    # Dataflow of one step: render -> audio -> {PQMF, spectral loss}.  The two consumers depend only on the
+    # Dataflow of one step: control-rate pass -> audio-rate render -> audio -> {PQMF, spectral loss}.  The two consumers depend only on the
     # audio, so they run on two side HIP streams; with double-buffered audio the NEXT step's render (VALU
     # bound) starts while this step's PQMF / STFT (LDS / latency bound) are still running.  All K steps and
     # their cross-stream dependencies are captured once into one hipGraph and replayed.
-    side_a, side_b = torch.cuda.Stream(), torch.cuda.Stream()
+    side_a, side_b, side_c = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
     audio_bufs = [torch.empty((B, T), dtype=torch.float32, device=dev) for _ in range(2)]
+    workspaces = [voice.new_workspace(dev) for _ in range(2)]
     last = {}
 
     def run_steps(k, pipelined=True):
         main = torch.cuda.current_stream()
         consumed = [None, None]
+        ws_free = [None, None]      # audio pass that last read workspace[buf] has finished
+        side_c.wait_stream(main)
+
+        def issue_control(i):
+            # the small control-rate kernels of step i go to their own stream with a private workspace,
+            # so they run beside the previous step's audio-rate kernel instead of ahead of it
+            buf = i & 1
+            with torch.cuda.stream(side_c):
+                if ws_free[buf] is not None:
+                    side_c.wait_event(ws_free[buf])
+                voice.render_control(workspaces[buf])
+                return side_c.record_event()
+
+        ctrl_done = issue_control(0)
         for i in range(k):
             buf = i & 1
             if consumed[buf] is not None:          # buffer free again: both readers of step i-2 are done
                 for e in consumed[buf]:
                     main.wait_event(e)
-            audio = voice.render_staged(on_stage=hook, out=audio_bufs[buf])
-            rendered = main.record_event()
+            main.wait_event(ctrl_done)
+            if pipelined and i + 1 < k:
+                ctrl_done_next = issue_control(i + 1)
+            audio = voice.render_audio(workspaces[buf], out=audio_bufs[buf], on_stage=hook)
+            ws_free[buf] = main.record_event()
+            if not (pipelined and i + 1 < k) and i + 1 < k:
+                ctrl_done_next = issue_control(i + 1)
+            if i + 1 < k:
+                ctrl_done = ctrl_done_next
+            rendered = ws_free[buf]
             side_a.wait_event(rendered)
             side_b.wait_event(rendered)
             with torch.cuda.stream(side_a):
@@ -158,6 +181,7 @@ def main():
             last["z"], last["loss"] = z, loss
         main.wait_stream(side_a)
         main.wait_stream(side_b)
+        main.wait_stream(side_c)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -239,7 +263,7 @@ def main():
         "config": {
             "workload": "BASELINE configs[1]: torchsynth-style Voice render + PQMF(3) analysis + mel-L1 loss, "
                         f"batch {B} x {SECONDS:g} s @ {SAMPLE_RATE} Hz per GPU",
-            "batch_per_gpu": B, "samples_per_voice": T, "launch": launch, "streams": 3, "pipelined": pipelined, "loss": loss_value,
+            "batch_per_gpu": B, "samples_per_voice": T, "launch": launch, "streams": 4, "pipelined": pipelined, "loss": loss_value,
         },
         "roofline": {
             "kernel": "voice_audio_kernel (phase increments + chained fp64 scan + oscillators + mixer)",

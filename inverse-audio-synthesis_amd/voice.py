@@ -164,39 +164,56 @@ class Voice(nn.Module):
         _lib.check(st, "ias_voice_render")
         return audio
 
-    def render_staged(self, params01=None, on_stage=None, out=None):
-        """The same render issued stage by stage (control, oscillators, normalise);
-        ``on_stage(name, phase)`` is called with phase "begin"/"end" around each (bench event hooks).
-        ``out``: optional preallocated [B,T] fp32 buffer (double-buffered pipelines)."""
+    def new_workspace(self, device=None):
+        """A private workspace for double-buffered pipelines (see ``render_control`` / ``render_audio``)."""
+        c = self.synthconfig
+        need = int(_lib.load().ias_voice_workspace_bytes(c.batch_size, c.buffer_size, c.control_buffer_size))
+        return torch.empty(need, dtype=torch.uint8, device=device or self.params01.device)
+
+    def render_control(self, workspace, params01=None):
+        """Control-rate pass only (78 params -> control signals + per-voice constants) into ``workspace``."""
         c = self.synthconfig
         p = (self.params01 if params01 is None else params01).detach().to(torch.float32).contiguous()
         lib = _lib.load()
-        need = int(lib.ias_voice_workspace_bytes(c.batch_size, c.buffer_size, c.control_buffer_size))
-        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != p.device:
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=p.device)
-        ws = self._workspace
-        if out is None:
-            audio = torch.empty((c.batch_size, c.buffer_size), dtype=torch.float32, device=p.device)
-        else:
-            assert out.shape == (c.batch_size, c.buffer_size) and out.dtype == torch.float32 and out.is_contiguous()
-            audio = out
-        hook = on_stage or (lambda name, phase: None)
         # workspace layout: ctrl, vconst (64 B per voice), env (csrc/voice_kernels.hip voice_ws_layout)
         a256 = lambda n: (n + 255) // 256 * 256
         ctrl_bytes = a256(4 * c.batch_size * 5 * c.control_buffer_size)
         env_off = ctrl_bytes + a256(64 * c.batch_size)
-        hook("control", "begin")
-        st = lib.ias_voice_control(_lib.ptr(p), _lib.ptr(ws), _lib.ptr(ws[ctrl_bytes:]), _lib.ptr(ws[env_off:]),
-                                   c.batch_size, c.control_buffer_size, c.control_rate, _lib.stream())
+        st = lib.ias_voice_control(_lib.ptr(p), _lib.ptr(workspace), _lib.ptr(workspace[ctrl_bytes:]),
+                                   _lib.ptr(workspace[env_off:]), c.batch_size, c.control_buffer_size, c.control_rate,
+                                   _lib.stream())
         _lib.check(st, "ias_voice_control")
-        hook("control", "end")
-        for stage, name in enumerate(("oscillators", "normalize")):
+
+    def render_audio(self, workspace, out=None, on_stage=None, normalize=True):
+        """Audio-rate pass (+ normalise) from a workspace ``render_control`` has filled -> audio [B,T]."""
+        c = self.synthconfig
+        lib = _lib.load()
+        if out is None:
+            audio = torch.empty((c.batch_size, c.buffer_size), dtype=torch.float32, device=workspace.device)
+        else:
+            assert out.shape == (c.batch_size, c.buffer_size) and out.dtype == torch.float32 and out.is_contiguous()
+            audio = out
+        hook = on_stage or (lambda name, phase: None)
+        for stage, name in enumerate(("oscillators", "normalize")[: 2 if normalize else 1]):
             hook(name, "begin")
-            st = lib.ias_voice_stage(stage, _lib.ptr(self.noise), _lib.ptr(audio), _lib.ptr(ws), ws.numel(),
+            st = lib.ias_voice_stage(stage, _lib.ptr(self.noise), _lib.ptr(audio), _lib.ptr(workspace), workspace.numel(),
                                      c.batch_size, c.buffer_size, c.control_buffer_size, c.sample_rate, _lib.stream())
             _lib.check(st, f"ias_voice_stage({name})")
             hook(name, "end")
         return audio
+
+    def render_staged(self, params01=None, on_stage=None, out=None):
+        """The same render issued stage by stage (control, oscillators, normalise);
+        ``on_stage(name, phase)`` is called with phase "begin"/"end" around each (bench event hooks).
+        ``out``: optional preallocated [B,T] fp32 buffer (double-buffered pipelines)."""
+        p = self.params01 if params01 is None else params01
+        if self._workspace is None or self._workspace.device != p.device:
+            self._workspace = self.new_workspace(p.device)
+        hook = on_stage or (lambda name, phase: None)
+        hook("control", "begin")
+        self.render_control(self._workspace, p)
+        hook("control", "end")
+        return self.render_audio(self._workspace, out=out, on_stage=on_stage)
 
     def chain_status(self):
         """0 if the last render's cross-tile scan completed; 1 if a bounded wait expired (tests)."""
