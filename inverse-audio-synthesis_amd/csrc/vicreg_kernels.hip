@@ -221,6 +221,130 @@ __global__ __launch_bounds__(256) void vicreg_gram_kernel(const unsigned short* 
   }
 }
 
+// Fast path for Kpad == 128 (batch <= 128: the whole contraction depth fits one pass).  One workgroup walks
+// through up to GS column tiles of one row strip: the strip's A fragments (its 128 rows x K = 128) are loaded
+// once into registers (64 VGPRs per lane), the 128 x 128 B panels stream through a double-buffered LDS
+// image whose next tile is fetched (global -> registers) while the current one feeds the matrix cores and
+// is written to LDS afterwards.  Both branches (x and y) are one launch.
+#define GS 4               // column tiles per workgroup
+#define GBLD (128 + 8)     // LDS row stride in bf16 (272 B)
+
+__device__ __forceinline__ void strip_item(int item, int ntile, int& ti, int& g) {
+  // items enumerate (ti, g) with g < ceil((ntile - ti) / GS), row-major
+  ti = 0;
+  for (;;) {
+    const int ng = (ntile - ti + GS - 1) / GS;
+    if (item < ng) break;
+    item -= ng; ++ti;
+  }
+  g = item;
+}
+
+__global__ __launch_bounds__(256, 2) void vicreg_gram_strip_kernel(const unsigned short* __restrict__ Xt_x,
+                                                                    const unsigned short* __restrict__ Xt_y,
+                                                                    double* __restrict__ part_x,
+                                                                    double* __restrict__ part_y, int D, int ntile,
+                                                                    int nitems) {
+  __shared__ __attribute__((aligned(16))) unsigned short s_b[2][GT][GBLD];
+  __shared__ double s_part[4];
+  const int branch = blockIdx.x / nitems, item = blockIdx.x - branch * nitems;
+  const unsigned short* Xt = branch ? Xt_y : Xt_x;
+  int ti, g;
+  strip_item(item, ntile, ti, g);
+  const int tj0 = ti + g * GS, tj1 = min(tj0 + GS, ntile);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int row0 = ti * GT;
+
+  // A fragments of this wave's 64 rows, all 8 k-steps (K = 128)
+  bf16x8 fa[2][8];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int row = row0 + wr * 64 + m * 32 + r;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row < D) v = *reinterpret_cast<const uint4*>(Xt + (size_t)row * 128 + ks * 16 + h * 8);
+      fa[m][ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+
+  // stage loads of one B tile: 128 rows x 256 B = 2048 x 16 B, 8 per thread
+  uint4 stage[8];
+  auto fetch = [&](int tj) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i, rr = idx >> 4, ch = idx & 15;
+      const int row = tj * GT + rr;
+      stage[i] = make_uint4(0, 0, 0, 0);
+      if (row < D) stage[i] = *reinterpret_cast<const uint4*>(Xt + (size_t)row * 128 + ch * 8);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i, rr = idx >> 4, ch = idx & 15;
+      *reinterpret_cast<uint4*>(&s_b[buf][rr][ch * 8]) = stage[i];
+    }
+  };
+
+  fetch(tj0);
+  commit(0);
+  __syncthreads();
+  float s_off = 0.f, s_dia = 0.f;
+  int buf = 0;
+  for (int tj = tj0; tj < tj1; ++tj) {
+    const bool more = tj + 1 < tj1;
+    if (more) fetch(tj + 1);            // in flight while the matrix cores work on this tile
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      bf16x8 fb[2];
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        fb[n] = *reinterpret_cast<const bf16x8*>(&s_b[buf][wc * 64 + n * 32 + r][ks * 16 + h * 8]);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][ks], fb[n], acc[m][n], 0, 0, 0);
+    }
+    const bool diag_tile = (ti == tj);
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc[m][n][e];
+          if (diag_tile) {
+            const int row = wr * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int col = wc * 64 + n * 32 + r;
+            if (row != col) s = fmaf(v, v, s);
+          } else {
+            s = fmaf(v, v, s);
+          }
+        }
+    if (diag_tile) s_dia += s; else s_off += s;
+    if (more) commit(buf ^ 1);          // other buffer: nobody reads it during this tile
+    __syncthreads();
+    buf ^= 1;
+  }
+  float tot = s_dia + 2.0f * s_off;
+  for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
+  if (lane == 0) s_part[wave] = (double)tot;
+  __syncthreads();
+  if (tid == 0) (branch ? part_y : part_x)[item] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
 // out[0..3] = loss, repr_loss, std_loss, cov_loss (fp32)
 __global__ __launch_bounds__(256) void vicreg_finish_kernel(const double* __restrict__ hingepart,
                                                             const double* __restrict__ msepart, int nmse,
@@ -258,6 +382,7 @@ struct VicregWs { size_t xt_x, xt_y, colstats, mse, hinge, gram_x, gram_y, total
 static VicregWs vicreg_ws(int B, int D) {
   VicregWs w;
   w.Kpad = (B + GK - 1) / GK * GK;
+  if (w.Kpad == 64) w.Kpad = 128;   // the strip kernel's depth (zero padded)
   w.ntile = (D + GT - 1) / GT;
   w.ngram = w.ntile * (w.ntile + 1) / 2;
   w.nmse = (D + VC_COLS - 1) / VC_COLS;
@@ -298,10 +423,20 @@ extern "C" int ias_vicreg_loss(const float* x, const float* y, float* out, void*
   double* gram_y = (double*)(ws + w.gram_y);
   hipLaunchKernelGGL(vicreg_colstats_kernel, dim3(w.nmse), dim3(VC_THREADS), 0, stream, x, y, xt_x, xt_y, colstats,
                      mse, hinge, B, D, w.Kpad);
-  hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_x, gram_x, D, w.Kpad, w.ntile);
-  hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_y, gram_y, D, w.Kpad, w.ntile);
+  int ngram = w.ngram;
+  if (w.Kpad == 128) {
+    // strip kernel: items (ti, group of GS column tiles), both branches in one launch
+    int nitems = 0;
+    for (int ti = 0; ti < w.ntile; ++ti) nitems += (w.ntile - ti + GS - 1) / GS;
+    hipLaunchKernelGGL(vicreg_gram_strip_kernel, dim3(2 * nitems), dim3(256), 0, stream, xt_x, xt_y, gram_x, gram_y, D,
+                       w.ntile, nitems);
+    ngram = nitems;
+  } else {
+    hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_x, gram_x, D, w.Kpad, w.ntile);
+    hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_y, gram_y, D, w.Kpad, w.ntile);
+  }
   hipLaunchKernelGGL(vicreg_finish_kernel, dim3(1), dim3(256), 0, stream, hinge, mse, w.nmse, gram_x, gram_y,
-                     w.ngram, B, D, cfg_batch, sim_coeff, std_coeff, cov_coeff, out);
+                     ngram, B, D, cfg_batch, sim_coeff, std_coeff, cov_coeff, out);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
