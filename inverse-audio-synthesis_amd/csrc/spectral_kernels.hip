@@ -165,16 +165,27 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
   // cover the ~2900-cycle global-load latency measured per frame; conflict-free ds_read_b32 instead
   // (166 -> 86 VGPRs, 120 -> 104 us).
   constexpr int NTAB = 64 * (2 * R + 2 * R + 16 * NP_IT + 2 * NUNP);
-  float* s_tab = reinterpret_cast<float*>(s_meli + 3 * (mel ? a.n_out : 0));
-  for (int i = tid; i < NTAB; i += SP_THREADS) s_tab[i] = a.tables[i];
-  const float* t_win = s_tab + lane;
-  const float* t_tw1 = t_win + 64 * 2 * R;
-  const float* t_tw2 = t_tw1 + 64 * 2 * R;
-  const float* t_twu = t_tw2 + 64 * 2 * 8 * NP_IT;
+  // (the global block is [entry][lane]; the LDS copy interleaves entries 2p, 2p+1 per lane so that a window
+  // pair or a (cos, -sin) twiddle is one conflict-free ds_read_b64)
+  cpx* s_tab = reinterpret_cast<cpx*>(s_meli + ((3 * (mel ? a.n_out : 0) + 1) & ~1));
+  for (int i = tid; i < NTAB / 2; i += SP_THREADS) {
+    const int pp = i >> 6, l = i & 63;
+    s_tab[i] = cmk(a.tables[64 * (2 * pp) + l], a.tables[64 * (2 * pp + 1) + l]);
+  }
+  const cpx* t_win = s_tab + lane;          // [n1]   -> (win[2 n1], win[2 n1 + 1])
+  const cpx* t_tw1 = t_win + 64 * R;        // [k1]   -> W_N2^(lane k1)
+  const cpx* t_tw2 = t_tw1 + 64 * R;        // [8i+d] -> W_64^(c d)
+  const cpx* t_twu = t_tw2 + 64 * 8 * NP_IT;  // [i]  -> W_NFFT^(lane + 64 i)
   __syncthreads();   // mel tables visible; the only workgroup barrier before the final reduction
 
   cpx* sA = s_scr + wave * SCR;
   float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+  // filter descriptors of this lane's first two outputs (all of them when n_out <= 128): frame-invariant
+  int h_sa = 0, h_na = 0, h_wa = 0, h_sb = 0, h_nb = 0, h_wb = 0;
+  if (mel) {
+    if (lane < a.n_out) { h_sa = s_meli[lane]; h_na = s_meli[a.n_out + lane]; h_wa = s_meli[2 * a.n_out + lane]; }
+    if (lane + 64 < a.n_out) { h_sb = s_meli[lane + 64]; h_nb = s_meli[a.n_out + lane + 64]; h_wb = s_meli[2 * a.n_out + lane + 64]; }
+  }
   const int f_begin = blockIdx.x * a.groups * SP_FPB;
   const int f_end = min(f_begin + a.groups * SP_FPB, a.F);
 
@@ -190,13 +201,13 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
     cpx v[R];
 #pragma unroll
     for (int n1 = 0; n1 < R; ++n1)
-      v[n1] = cmk(xc[2 * n1] * t_win[64 * (2 * n1)], xc[2 * n1 + 1] * t_win[64 * (2 * n1 + 1)]);
+      v[n1] = cmk(xc[2 * n1], xc[2 * n1 + 1]) * t_win[64 * n1];
     dftR<R>(v);
     {
       const int c = lane & 7, aa = lane >> 3;
 #pragma unroll
       for (int k1 = 0; k1 < R; ++k1)
-        sA[(k1 * 8 + c) * 9 + aa] = cmul(v[k1], cmk(t_tw1[64 * (2 * k1)], t_tw1[64 * (2 * k1 + 1)]));
+        sA[(k1 * 8 + c) * 9 + aa] = cmul(v[k1], t_tw1[64 * k1]);
     }
     wave_lds_sync();
     // pass 2: radix-8 over a for each (k1, c); twiddle W_64^(c*d); scatter (in place) to [k1][d][c]
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
         dft8(u[i]);
 #pragma unroll
         for (int d = 0; d < 8; ++d)
-          sA[(k1 * 8 + d) * 9 + c] = cmul(u[i][d], cmk(t_tw2[64 * (2 * (8 * i + d))], t_tw2[64 * (2 * (8 * i + d) + 1)]));
+          sA[(k1 * 8 + d) * 9 + c] = cmul(u[i][d], t_tw2[64 * (8 * i + d)]);
       }
     }
     wave_lds_sync();
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
         const cpx zk = sA[k + (k >> 3)], zn = sA[kn + (kn >> 3)];
         const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
         const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-        const cpx t = cmul(cmk(t_twu[64 * (2 * i)], t_twu[64 * (2 * i + 1)]), zo);
+        const cpx t = cmul(t_twu[64 * i], zo);
         const cpx xk = cadd(ze, t);                     // X[k]
         const cpx xq = cmk(ze.x - t.x, -(ze.y - t.y));  // X[N2-k] = conj(ze - t)
         float vk = xk.x * xk.x + xk.y * xk.y, vn = xq.x * xq.x + xq.y * xq.y;
@@ -282,10 +293,13 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
         const bool oka = ma < a.n_out, okb = mb < a.n_out;
         float va = 0.f, vb = 0.f;
         if (mel) {
-          const int sa = oka ? s_meli[ma] : 0, na = oka ? s_meli[a.n_out + ma] : 0;
-          const int sb = okb ? s_meli[mb] : 0, nb = okb ? s_meli[a.n_out + mb] : 0;
-          const float* wa = s_melw + (oka ? s_meli[2 * a.n_out + ma] : 0);
-          const float* wb = s_melw + (okb ? s_meli[2 * a.n_out + mb] : 0);
+          int sa = h_sa, na = h_na, sb = h_sb, nb = h_nb, woa = h_wa, wob = h_wb;
+          if (m0 != 0) {   // outputs beyond the first 128: descriptors from LDS
+            sa = oka ? s_meli[ma] : 0; na = oka ? s_meli[a.n_out + ma] : 0; woa = oka ? s_meli[2 * a.n_out + ma] : 0;
+            sb = okb ? s_meli[mb] : 0; nb = okb ? s_meli[a.n_out + mb] : 0; wob = okb ? s_meli[2 * a.n_out + mb] : 0;
+          }
+          const float* wa = s_melw + woa;
+          const float* wb = s_melw + wob;
           int nmax = max(na, nb);
 #pragma unroll
           for (int d = 32; d > 0; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d, 64));
@@ -375,7 +389,7 @@ static size_t stft_lds_bytes(int n_fft, int hop, int fpb, int mel_nnz, int n_out
   const int np_it = (8 * R + 63) / 64, nunp = (n_fft / 4) / 64 + 1;
   const int ntab = 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp);
   return sizeof(cpx) * SP_WAVES * scr + sizeof(float) * ((mel_nnz + 3) & ~3) + sizeof(int) * 3 * (mel_nnz ? n_out : 0) +
-         sizeof(float) * ntab;
+         sizeof(float) * ntab + 8;
 }
 static int stft_fpb(int n_fft, int hop) {
   (void)n_fft; (void)hop;
