@@ -70,11 +70,19 @@ int ias_voice_read_peaks(const void* workspace, float* peaks, int B, int T, int 
 /* Output frames of analysis: floor((T + 2*(K-1)/2 - K) / N) + 1, or a negative error. */
 int ias_pqmf_out_len(int T, int N, int K);
 
+/* Transposed, zero-padded tap table of the fast path: ias_pqmf_packed_taps_len(N, K) floats (0 = no fast path
+ * for this N, K); ias_pqmf_pack_taps fills packed (device, 8-byte aligned) from H [N,K] (device); re-run when H
+ * changes. */
+int ias_pqmf_packed_taps_len(int N, int K);
+int ias_pqmf_pack_taps(const float* H, float* packed, int N, int K, void* stream);
+
 /* analysis: x [B,T] (= [B,1,T]), H [N,K] (= buffer H[N,1,K]) -> z [B,N,L]   (pqmf.py:49-50).
+ * packed: the ias_pqmf_pack_taps table of H, or NULL (generic one-lane-per-output kernel, same sums in the same
+ * order, several times slower).
  * mean/stdv [N] (both or neither, may be NULL): fused (z - mean[k]) / stdv[k] of
  * AudioEmbedding._preprocess (reference audioembed.py:41,49). */
-int ias_pqmf_analysis(const float* x, const float* H, float* z, const float* mean, const float* stdv,
-                      int B, int T, int N, int K, void* stream);
+int ias_pqmf_analysis(const float* x, const float* H, const float* packed, float* z, const float* mean,
+                      const float* stdv, int B, int T, int N, int K, void* stream);
 
 /* synthesis: z [B,N,L], G [N,K] (= buffer G[1,N,K]) -> out [B, L*N] (= [B,1,L*N])   (pqmf.py:52-55). */
 int ias_pqmf_synthesis(const float* z, const float* G, float* out, int B, int L, int N, int K, void* stream);

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libias_hip.so")
+LIB_PATH = os.environ.get("IAS_HIP_LIB") or os.path.join(_HERE, "csrc", "libias_hip.so")
 
 _ERRORS = {
     -1: "IAS_ERR_ARG (bad pointer or dimension)",
@@ -34,7 +34,9 @@ SYMBOLS = {
     "ias_voice_read_status": (_I, [_P, _P, _I, _I, _I, _P]),
     "ias_voice_read_peaks": (_I, [_P, _P, _I, _I, _I, _P]),
     "ias_pqmf_out_len": (_I, [_I, _I, _I]),
-    "ias_pqmf_analysis": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_pqmf_packed_taps_len": (_I, [_I, _I]),
+    "ias_pqmf_pack_taps": (_I, [_P, _P, _I, _I, _P]),
+    "ias_pqmf_analysis": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_pqmf_synthesis": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_stft_num_frames": (_I, [_I, _I, _I]),
     "ias_stft_partials_count": (_LL, [_I, _I, _I, _I]),

@@ -10,175 +10,229 @@
 // vicreg_audio_params.py:40): polyphase FIR out of LDS, see pqmf_analysis_fast_kernel.
 // Algorithmic HBM bytes: 4 B in + 4 B out per audio sample.
 #include "ias_common.h"
+#include <cstdint>
 
 #define PQ_THREADS 256
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const float* lds_cfloat_ptr;
+typedef __attribute__((address_space(3))) const volatile f32x2* lds_cvpair_ptr;
 
-// Register state of one lane of the polyphase FIR: accumulator pairs and the two pair windows.
+// acc += xw * (HALF ? hp.y : hp.x) on both lanes; hp is a wave-uniform pair held in SGPRs.  v_pk_fma_f32 takes
+// the SGPR pair directly and op_sel / op_sel_hi pick which half feeds each lane (checked on gfx950 with
+// scripts/diag/pk_opsel.hip), so a tap costs no VGPR and no v_mov splat.
+template <int HALF>
+__device__ __forceinline__ void pk_fma_bcast(f32x2& acc, const f32x2 xw, const f32x2 hp) {
+  if (HALF == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(xw), "s"(hp));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(xw), "s"(hp));
+}
+
 template <int N, int K>
-struct PqmfWindow {
-  f32x2 accp[2][N];
-  f32x2 wa[N][4], wb[N][4];
-  const float* rows;
-  int mrow, m0;
+struct PqmfFast {
+  static constexpr int R = 4;                          // frames per lane: two adjacent pairs, 128 frames apart
+  static constexpr int FT = PQ_THREADS * R;            // frames per workgroup
+  static constexpr int Q = (K + N - 1) / N;            // taps per polyphase branch
+  static constexpr int U = 2;                          // steps per pipeline stage (U*N*N even: pair parity static)
+  static constexpr int NST = Q / U;                    // full stages; stage NST holds the Q % U tail steps
+  static constexpr int COLS = FT + Q - 1;              // polyphase positions a workgroup touches
+  static constexpr int ROW = (COLS + 31) / 32 * 32 + 2;   // even: pairs stay 8-byte aligned in every row
+  static constexpr int TABLE = (NST + 1) * U * N * N;  // floats of the transposed tap table, zero past K (the
+                                                       // pipeline always loads one whole stage ahead)
+};
 
-  __device__ __forceinline__ float xat(int p, int m) const { return rows[p * mrow + m + (m >> 5)]; }
+// One pipeline stage = U polyphase steps: their frame pairs and taps in registers.  The frame pairs
+// (x_p[c+q], x_p[c+q+1]) are 8-byte aligned in the even copy of the rows when q is even and in the odd copy
+// (shifted by one position) when q is odd, so each is one ds_read_b64 at an immediate offset.
+template <int N, int ROW, int U>
+struct PqmfStage {
+  static constexpr int NH = U * N * N / 2;
+  f32x2 xa[U][N], xb[U][N], h[NH];
 
-  __device__ __forceinline__ void init(const float* rows_, int mrow_, int m_first) {
-    rows = rows_; mrow = mrow_; m0 = m_first;
+  // volatile reads: each pair stays its own ds_read_b64 (256 B/clk; merged into ds_read2_b64 / ds_read2st64_b64
+  // the same bytes move at a quarter of that rate) and they are issued here, not where the FMAs want them
+  __device__ __forceinline__ void load(lds_cfloat_ptr ra, const f32x2* __restrict__ taps) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int s = 0; s < U; ++s) {
+      const int off = (s & 1) ? N * ROW + s - 1 : s;    // odd copy holds x_p[c+1] at c
 #pragma unroll
-      for (int k = 0; k < N; ++k) accp[h][k] = (f32x2){0.0f, 0.0f};
-#pragma unroll
-    for (int p = 0; p < N; ++p) {
-      float v[9];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) v[i] = xat(p, m0 + i);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        wa[p][i] = (f32x2){v[2 * i], v[2 * i + 1]};
-        wb[p][i] = (f32x2){v[2 * i + 1], v[2 * i + 2]};
+      for (int p = 0; p < N; ++p) {
+        xa[s][p] = *(lds_cvpair_ptr)(ra + p * ROW + off);
+        xb[s][p] = *(lds_cvpair_ptr)(ra + p * ROW + off + 128);
       }
     }
+#pragma unroll
+    for (int i = 0; i < NH; ++i) h[i] = taps[i];
   }
 
-  // One group of 4 polyphase steps q = 4*q4 + s4.  ROT: physical slot of logical pair i is (i+ROT)&3.
-  // FULL: every tap index of the group is < K (no checks); otherwise steps/taps beyond K are skipped
-  // at compile time (q4 is then a compile-time-known value K / (4N)).
-  template <int ROT, bool FULL>
-  __device__ __forceinline__ void group(const float* __restrict__ H, int q4) {
-    constexpr int QF = K / (4 * N);
+  // Everything this stage loaded has arrived.  LDS and scalar-cache loads share one counter and scalar loads
+  // return out of order, so a wait placed at the first FMA would also drain the NEXT stage's loads issued just
+  // before it; using the registers here (no instruction) puts the compiler's wait ahead of those loads.
+  __device__ __forceinline__ void arrived() const {
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
+    for (int s = 0; s < U; ++s)
 #pragma unroll
-      for (int p = 0; p < N; ++p) {
-        const int jc = (4 * QF + s4) * N + p;            // tap index when !FULL (compile time)
-        if (!FULL && jc >= K) continue;
-        const int j = FULL ? (4 * q4 + s4) * N + p : jc;  // wave-uniform -> scalar loads
+      for (int p = 0; p < N; ++p) asm volatile("" ::"v"(xa[s][p]), "v"(xb[s][p]));
+#pragma unroll
+    for (int i = 0; i < NH; ++i) asm volatile("" ::"s"(h[i]));
+  }
+
+  template <int STEPS>
+  __device__ __forceinline__ void fma(f32x2 (&acc)[N][2]) const {
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+      for (int p = 0; p < N; ++p)
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-          const float hk = H[k * K + j];
-          const f32x2 h2 = (f32x2){hk, hk};
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int slot = ((s4 >> 1) + h + ROT) & 3;
-            const f32x2 xw = (s4 & 1) ? wb[p][slot] : wa[p][slot];
-            accp[h][k] = __builtin_elementwise_fma(xw, h2, accp[h][k]);
-          }
+          const int t = (s * N + p) * N + k;
+          if (t & 1) { pk_fma_bcast<1>(acc[k][0], xa[s][p], h[t >> 1]); pk_fma_bcast<1>(acc[k][1], xb[s][p], h[t >> 1]); }
+          else       { pk_fma_bcast<0>(acc[k][0], xa[s][p], h[t >> 1]); pk_fma_bcast<0>(acc[k][1], xb[s][p], h[t >> 1]); }
         }
-      }
-    }
-    if (FULL) {
-      // slide by 4 positions: logical pairs 2,3 become 0,1 (same registers, ROT advances by 2 in the
-      // caller); the freed slots take positions m0+8 .. m0+11 (+12 for the odd-offset window)
-      const int mn = m0 + 4 * q4 + 8;
-#pragma unroll
-      for (int p = 0; p < N; ++p) {
-        const float n0 = xat(p, mn), n1 = xat(p, mn + 1), n2 = xat(p, mn + 2), n3 = xat(p, mn + 3),
-                    n4 = xat(p, mn + 4);
-        wa[p][(0 + ROT) & 3] = (f32x2){n0, n1}; wa[p][(1 + ROT) & 3] = (f32x2){n2, n3};
-        wb[p][(0 + ROT) & 3] = (f32x2){n1, n2}; wb[p][(1 + ROT) & 3] = (f32x2){n3, n4};
-      }
-    }
   }
 };
 
-// Polyphase form: with j = N*q + p, z_k[f] = sum_p sum_q H_k[N*q+p] * x_p[f+q], x_p[m] = x[N*m + p - pad].
-// The workgroup de-interleaves its input span into the N polyphase rows in LDS; a lane owns R = 4
-// adjacent frames and slides a 4-value register window along each row (one new ds_read_b32 per
-// (q, p) step feeds 4 frames x N bands = 12 FMAs), so registers stay ~50/lane and LDS reads are
-// 1/10 of the FMA count.  Taps are wave-uniform scalar-cache loads.
+// Polyphase form: with j = N*q + p, z_k[f] = sum_q sum_p H_k[N*q+p] * x_p[f+q], x_p[m] = x[N*m + p - pad].
+// The workgroup de-interleaves its input span into the N polyphase rows in LDS (lane c loads the N samples of
+// column c and writes one dword per row: coalesced, conflict-free, no index division), twice: rows [0, N) hold
+// x_p[c] at c, rows [N, 2N) hold x_p[c+1] at c.  A lane owns the adjacent frames (2*lane, 2*lane+1) of its
+// wave's 256-frame span and the same pair 128 frames on; every operand pair of v_pk_fma_f32 is then one aligned
+// ds_read_b64 (256 B/clk, lanes 8 B apart: no conflicts, no swizzle, no register shuffling).  Taps come from the
+// transposed table Pt[j*N + k] = H[k][j] (ias_pqmf_pack_taps) through the scalar cache into SGPR pairs
+// (pk_fma_bcast), so the VALU stream is the FMAs plus a handful of loop instructions.
+// Workgroups are persistent: each walks tiles t = blockIdx.x, + gridDim.x, ... of the (batch row, 1024-frame tile)
+// list and loads the next tile's samples into registers before it computes the current one, so the ~3000-cycle
+// global-load latency overlaps the FMAs instead of preceding them.
 template <int N, int K>
 __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_fast_kernel(
-    const float* __restrict__ x, const float* __restrict__ H, float* __restrict__ z,
-    const float* __restrict__ mean, const float* __restrict__ stdv, int T, int L, int pad) {
-  constexpr int R = 4;
-  constexpr int FT = PQ_THREADS * R;            // frames per workgroup
-  constexpr int Q = (K + N - 1) / N;            // taps per polyphase branch
-  constexpr int QP = (Q + 3) / 4 * 4;           // padded to whole groups of 4 steps (zero taps)
-  constexpr int MLEN = FT + QP + 12;            // polyphase positions per row (incl. window look-ahead)
-  // x_p[m] lives at index m + (m >> 5): lanes read m = 4*lane + c, and the extra +1 per 32 positions
-  // spreads the 32 lanes of a group over all 32 banks (plain m: 4-way conflict).
-  constexpr int MROW = ((MLEN + (MLEN >> 5) + 31) / 32) * 32 + 11;   // row stride: rows start 11 banks apart
-  constexpr int SPAN = N * MLEN;                // input samples staged per workgroup (zeros past T)
-  static_assert(N <= 4, "tap table holds up to 4 bands per 16-byte entry");
-  __shared__ float s_xp[N][MROW];
+    const float* __restrict__ x, const float* __restrict__ Pt, float* __restrict__ z,
+    const float* __restrict__ mean, const float* __restrict__ stdv, int T, int L, int pad, int tiles_x,
+    int ntiles) {
+  using C = PqmfFast<N, K>;
+  constexpr int FT = C::FT, Q = C::Q, U = C::U, COLS = C::COLS, ROW = C::ROW, NST = C::NST;
+  constexpr int NH = U * N * N / 2;
+  constexpr int NIT = (COLS + PQ_THREADS - 1) / PQ_THREADS;   // columns staged per thread
+  static_assert((U * N * N) % 2 == 0 && U % 2 == 0 && NST % 2 == 0, "tap pair / row copy parity must not depend on the loop counter; stages are consumed in pairs");
+  __shared__ __attribute__((aligned(16))) float s_xp[2 * N * ROW];
 
-  const int b = blockIdx.y, tid = threadIdx.x;
-  const int f_tile = blockIdx.x * FT;
-  const long long start = (long long)f_tile * N - pad;   // sample index of polyphase position (m=0, p=0)
-  const float* xr = x + (size_t)b * T;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  float e[NIT][N];
 
-  // stage: aligned 16-byte global loads, de-interleaved dword LDS writes
-  const long long g0 = start >= 0 ? (start & ~3LL) : -(((-start) + 3) & ~3LL);
-  const int nvec = (int)((start + SPAN - g0 + 3) / 4);
-  const bool vec_ok = (T & 3) == 0;
-  for (int v = tid; v < nvec; v += PQ_THREADS) {
-    const long long g = g0 + 4LL * v;
-    float e[4];
-    if (vec_ok && g >= 0 && g + 3 < T) {
-      const float4 q4 = *reinterpret_cast<const float4*>(xr + g);
-      e[0] = q4.x; e[1] = q4.y; e[2] = q4.z; e[3] = q4.w;
-    } else {
+  // Column c of tile t holds samples g .. g+N-1, g = N*(f_tile + c) - pad.  The loads are unconditional and
+  // branch-free (a join would make the compiler wait for them on the spot): the address is clamped into the row
+  // and the few columns that stick out of it (first / last tile of a row) are sorted out when they are consumed.
+  auto load_tile = [&](int t) {
+    const int b = t / tiles_x;
+    const int g_tile = (t - b * tiles_x) * FT * N - pad;
+    const float* xr = x + (size_t)b * T;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) e[i] = (g + i >= 0 && g + i < T) ? xr[g + i] : 0.0f;
+    for (int it = 0; it < NIT; ++it) {
+      const int c = min(tid + it * PQ_THREADS, COLS - 1);
+      const int gc = min(max(g_tile + c * N, 0), T - N);
+#pragma unroll
+      for (int p = 0; p < N; ++p) e[it][p] = xr[gc + p];
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  load_tile(t);
+  for (; t < ntiles; t += gridDim.x) {
+    const int b = t / tiles_x;
+    const int f_tile = (t - b * tiles_x) * FT;
+    const int g_tile = f_tile * N - pad;
+    if (g_tile < 0 || g_tile + COLS * N > T) {
+      // edge tile: move each sample to its place (the clamped load is shifted by g - gc) and zero what lies
+      // outside the row
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = min(tid + it * PQ_THREADS, COLS - 1);
+        const int g = g_tile + c * N;
+        const int d = g - min(max(g, 0), T - N);
+        float v[N];
+#pragma unroll
+        for (int p = 0; p < N; ++p) {
+          float sel = 0.0f;
+#pragma unroll
+          for (int s2 = 0; s2 < N; ++s2) sel = (p + d == s2) ? e[it][s2] : sel;
+          v[p] = (g + p >= 0 && g + p < T) ? sel : 0.0f;
+        }
+#pragma unroll
+        for (int p = 0; p < N; ++p) e[it][p] = v[p];
+      }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int li = (int)(g + i - start);
-      if (li >= 0 && li < SPAN) { const int m = li / N; s_xp[li % N][m + (m >> 5)] = e[i]; }
+    for (int it = 0; it < NIT; ++it) {
+      const int c = tid + it * PQ_THREADS;
+      if (c < COLS) {
+#pragma unroll
+        for (int p = 0; p < N; ++p) s_xp[p * ROW + c] = e[it][p];
+        if (c > 0) {
+#pragma unroll
+          for (int p = 0; p < N; ++p) s_xp[(N + p) * ROW + c - 1] = e[it][p];
+        }
+      }
     }
-  }
-  __syncthreads();
+    __syncthreads();
+    load_tile(min(t + (int)gridDim.x, ntiles - 1));   // the last round reloads a tile nobody will use
 
-  // gfx950 issues a plain fp32 VALU op for a wave64 in 4 cycles; only v_pk_fma_f32 (two FMAs per
-  // lane) reaches the fp32 peak.  Frames are therefore processed as even-aligned register PAIRS:
-  //   accp[h][k] = (acc[2h][k], acc[2h+1][k]),  h = 0, 1
-  //   wa[p][i] = (x_p[m0 + 2i], x_p[m0 + 2i + 1])      pairs starting at even offsets
-  //   wb[p][i] = (x_p[m0 + 2i + 1], x_p[m0 + 2i + 2])  pairs starting at odd offsets
-  // with m0 = 4*tid + 4*q4 (logical index i; the physical slot is (i + ROT) & 3 so that sliding the
-  // window by 4 positions moves no registers).  At step s4 (q = 4*q4 + s4) frame pair h needs
-  // x_p[m0 + s4 + 2h + {0,1}]: wa[(s4 >> 1) + h] for even s4, wb[(s4 >> 1) + h] for odd s4.
-  PqmfWindow<N, K> win;
-  win.init(&s_xp[0][0], MROW, R * tid);
-  constexpr int QF = K / (4 * N);        // groups of 4 steps in which every tap index is < K
+    lds_cfloat_ptr ra = (lds_cfloat_ptr)s_xp + wave * 256 + 2 * lane;
+    const f32x2* taps = reinterpret_cast<const f32x2*>(Pt);
+    f32x2 acc[N][2];
+#pragma unroll
+    for (int k = 0; k < N; ++k) { acc[k][0] = (f32x2){0.0f, 0.0f}; acc[k][1] = (f32x2){0.0f, 0.0f}; }
+
+    PqmfStage<N, ROW, U> sa;
+    if constexpr (4 * NH <= 40) {
+      // two-stage software pipeline over the Q steps: stage i+1 is in flight while stage i feeds the FMAs
+      PqmfStage<N, ROW, U> sb;
+      sa.load(ra, taps);
 #pragma unroll 1
-  for (int q4 = 0; q4 + 1 < QF; q4 += 2) {
-    win.template group<0, true>(H, q4);
-    win.template group<2, true>(H, q4 + 1);
-  }
-  if (QF & 1) win.template group<0, true>(H, QF - 1);
-  if (4 * QF < Q) {
-    // remaining steps (fewer than a group, tap indices checked at compile time)
-    if (QF & 1) win.template group<2, false>(H, QF); else win.template group<0, false>(H, QF);
-  }
-  f32x2 (&accp)[2][N] = win.accp;
-
-  float acc[R][N];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int k = 0; k < N; ++k) { acc[2 * h][k] = accp[h][k].x; acc[2 * h + 1][k] = accp[h][k].y; }
-
-  const int f0 = f_tile + tid * R;
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    float o[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) o[r] = acc[r][k];
-    if (mean != nullptr) {
-      const float m = mean[k], sd = stdv[k];
-#pragma unroll
-      for (int r = 0; r < R; ++r) o[r] = (o[r] - m) / sd;
-    }
-    float* zr = z + ((size_t)b * N + k) * L;
-    if ((L & 3) == 0 && f0 + 3 < L) {
-      *reinterpret_cast<float4*>(zr + f0) = make_float4(o[0], o[1], o[2], o[3]);
+      for (int i = 0; i < NST; i += 2) {
+        sa.arrived();
+        sb.load(ra + U, taps + NH);
+        sa.template fma<U>(acc);
+        ra += 2 * U;
+        taps += 2 * NH;
+        sb.arrived();
+        sa.load(ra, taps);
+        sb.template fma<U>(acc);
+      }
+      sa.arrived();
     } else {
-#pragma unroll
-      for (int r = 0; r < R; ++r) if (f0 + r < L) zr[f0 + r] = o[r];
+      // N = 4: the taps of two stages do not fit the SGPR file next to everything else; one stage at a time
+#pragma unroll 1
+      for (int i = 0; i < NST; ++i) {
+        sa.load(ra, taps);
+        sa.template fma<U>(acc);
+        ra += U;
+        taps += NH;
+      }
+      if (Q % U) sa.load(ra, taps);
     }
+    sa.template fma<Q % U>(acc);   // tail steps (the table is zero past K)
+
+    const int f0 = f_tile + wave * 256 + 2 * lane;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      f32x2 o[2] = {acc[k][0], acc[k][1]};
+      if (mean != nullptr) {
+        const float m = mean[k], sd = stdv[k];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { o[r].x = (o[r].x - m) / sd; o[r].y = (o[r].y - m) / sd; }
+      }
+      float* zr = z + ((size_t)b * N + k) * L;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int f = f0 + 128 * r;
+        if ((L & 1) == 0 && f + 1 < L) {
+          *reinterpret_cast<f32x2*>(zr + f) = o[r];
+        } else {
+          if (f < L) zr[f] = o[r].x;
+          if (f + 1 < L) zr[f + 1] = o[r].y;
+        }
+      }
+    }
+    __syncthreads();   // every wave is done reading the rows before the next tile overwrites them
   }
 }
 
@@ -228,7 +282,44 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_synthesis_kernel(
   out[(size_t)b * To + t] = acc;
 }
 
+// Pt[j*N + k] = H[k][j] for j < K, zero padding up to the table length
+__global__ void pqmf_pack_taps_kernel(const float* __restrict__ H, float* __restrict__ Pt, int N, int K, int len) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  const int j = i / N, k = i - j * N;
+  Pt[i] = j < K ? H[k * K + j] : 0.0f;
+}
+
 // ------------------------------------------------------------------------ C ABI
+// Workgroups of the persistent fast kernel: what fits on the chip at once (LDS-limited, 6 per CU).
+static int pqmf_resident_blocks() {
+  static int blocks = 0;
+  if (blocks == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    blocks = cus * 6;
+  }
+  return blocks;
+}
+
+// Floats of the transposed tap table (whole polyphase steps, whole pairs); 0 when (N, K) has no fast path.
+extern "C" int ias_pqmf_packed_taps_len(int N, int K) {
+  if (N == 3 && K == 63) return PqmfFast<3, 63>::TABLE;
+  if (N == 4 && K == 63) return PqmfFast<4, 63>::TABLE;
+  return 0;
+}
+
+// packed [ias_pqmf_packed_taps_len] (device, 8-byte aligned) <- H [N,K] (device).  Re-run whenever H changes.
+extern "C" int ias_pqmf_pack_taps(const float* H, float* packed, int N, int K, void* stream_) {
+  const int len = ias_pqmf_packed_taps_len(N, K);
+  if (!H || !packed || len == 0 || ((uintptr_t)packed & 7)) return IAS_ERR_ARG;
+  hipLaunchKernelGGL(pqmf_pack_taps_kernel, dim3((len + 255) / 256), dim3(256), 0, (hipStream_t)stream_, H,
+                     packed, N, K, len);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
 extern "C" int ias_pqmf_out_len(int T, int N, int K) {
   const int pad = (K - 1) / 2;
   if (T <= 0 || N <= 0 || K <= 0 || T + 2 * pad < K) return IAS_ERR_ARG;
@@ -238,22 +329,28 @@ extern "C" int ias_pqmf_out_len(int T, int N, int K) {
 // x [B,T] (the reference's [B,1,T]), H [N,K] (module buffer H[N,1,K]), z [B,N,L].
 // mean/stdv: optional device pointers [N] (both or neither) for the fused
 // AudioEmbedding._preprocess normalisation.
-extern "C" int ias_pqmf_analysis(const float* x, const float* H, float* z, const float* mean, const float* stdv,
-                                 int B, int T, int N, int K, void* stream_) {
+// packed: ias_pqmf_pack_taps table of H; NULL (or an (N, K) without a fast path) runs the generic kernel.
+extern "C" int ias_pqmf_analysis(const float* x, const float* H, const float* packed, float* z, const float* mean,
+                                 const float* stdv, int B, int T, int N, int K, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !H || !z || B <= 0 || B > 65535 || N <= 0 || N > 65535 || K <= 0 || (K & 1) == 0) return IAS_ERR_ARG;
   if ((mean == nullptr) != (stdv == nullptr)) return IAS_ERR_ARG;
   const int pad = (K - 1) / 2;  // == taps // 2 for K = taps + 1, taps even
   const int L = ias_pqmf_out_len(T, N, K);
   if (L <= 0) return IAS_ERR_ARG;
-  if (N == 3 && K == 63) {
-    constexpr int FT = PQ_THREADS * 4;
-    hipLaunchKernelGGL((pqmf_analysis_fast_kernel<3, 63>), dim3((L + FT - 1) / FT, B), dim3(PQ_THREADS), 0,
-                       stream, x, H, z, mean, stdv, T, L, pad);
-  } else if (N == 4 && K == 63) {
-    constexpr int FT = PQ_THREADS * 4;
-    hipLaunchKernelGGL((pqmf_analysis_fast_kernel<4, 63>), dim3((L + FT - 1) / FT, B), dim3(PQ_THREADS), 0,
-                       stream, x, H, z, mean, stdv, T, L, pad);
+  if (packed && ((uintptr_t)packed & 7)) return IAS_ERR_ARG;
+  if (packed && (N == 3 || N == 4) && K == 63 && T >= N && (long long)L * N + 2 * K < 0x7fffffffLL) {
+    constexpr int FT = PqmfFast<3, 63>::FT;
+    const int tiles_x = (L + FT - 1) / FT;
+    const long long ntiles = (long long)tiles_x * B;
+    if (ntiles > 0x7fffffffLL) return IAS_ERR_ARG;
+    const int grid = (int)(ntiles < pqmf_resident_blocks() ? ntiles : pqmf_resident_blocks());
+    if (N == 3)
+      hipLaunchKernelGGL((pqmf_analysis_fast_kernel<3, 63>), dim3(grid), dim3(PQ_THREADS), 0, stream, x, packed, z,
+                         mean, stdv, T, L, pad, tiles_x, (int)ntiles);
+    else
+      hipLaunchKernelGGL((pqmf_analysis_fast_kernel<4, 63>), dim3(grid), dim3(PQ_THREADS), 0, stream, x, packed, z,
+                         mean, stdv, T, L, pad, tiles_x, (int)ntiles);
   } else {
     hipLaunchKernelGGL(pqmf_analysis_generic_kernel, dim3((L + PQ_THREADS - 1) / PQ_THREADS, N, B),
                        dim3(PQ_THREADS), 0, stream, x, H, z, mean, stdv, T, L, N, K, pad);

@@ -26,6 +26,26 @@ def design_filters(N, taps, cutoff, beta):
     return H, G
 
 
+def _packed_taps(H, Hc, N, K):
+    """Duplicated (h, h) tap table of H for the fast kernel.
+
+    Kept as an attribute of the caller's H tensor object together with the tensor version and address it was
+    packed from, so an in-place write to H (or a new H) packs again.
+    """
+    lib = _lib.load()
+    n = lib.ias_pqmf_packed_taps_len(N, K)
+    if n <= 0:
+        return None
+    tag = (Hc.data_ptr(), H._version)
+    hit = getattr(H, "_ias_packed_taps", None)
+    if hit is None or hit[0] != tag:
+        packed = torch.empty(n, dtype=torch.float32, device=Hc.device)
+        _lib.check(lib.ias_pqmf_pack_taps(_lib.ptr(Hc), _lib.ptr(packed), N, K, _lib.stream()), "ias_pqmf_pack_taps")
+        hit = (tag, packed)
+        H._ias_packed_taps = hit
+    return hit[1]
+
+
 def pqmf_analysis(x, H, mean=None, std=None):
     """x [B,1,T] or [B,T] fp32 on a ROCm device, H [N,1,K] -> z [B,N,L].
 
@@ -43,8 +63,8 @@ def pqmf_analysis(x, H, mean=None, std=None):
     L = lib.ias_pqmf_out_len(T, N, K)
     _lib.check(min(L, 0), "ias_pqmf_out_len")
     z = torch.empty((B, N, L), dtype=torch.float32, device=x2.device)
-    st = lib.ias_pqmf_analysis(_lib.ptr(x2), _lib.ptr(Hc), _lib.ptr(z), _lib.ptr(mean), _lib.ptr(std),
-                               B, T, N, K, _lib.stream())
+    st = lib.ias_pqmf_analysis(_lib.ptr(x2), _lib.ptr(Hc), _lib.ptr(_packed_taps(H, Hc, N, K)), _lib.ptr(z),
+                               _lib.ptr(mean), _lib.ptr(std), B, T, N, K, _lib.stream())
     _lib.check(st, "ias_pqmf_analysis")
     return z
 

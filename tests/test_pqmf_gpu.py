@@ -83,3 +83,30 @@ def test_full_size_linearity_and_shift(lib, dev):
     sh[:, :, 3:] = a[:, :, :-3]
     zsh = m(sh)
     assert (zsh[:, :, 12:-12] - za[:, :, 11:-13]).abs().max().item() <= 1e-5
+
+
+def test_packed_taps_follow_filter_updates(lib, dev):
+    """The packed tap table of the fast path is rebuilt when H is written in place or replaced, and the C-ABI call
+    without it (packed = NULL: generic kernel, same j-ascending FMA chain) gives the same output."""
+    from inverse_audio_synthesis_amd import _lib
+    from inverse_audio_synthesis_amd.pqmf import pqmf_analysis
+    m = _mod(dev, 3)
+    x = randn((2, 1, 9000), 77).to(dev)
+    z0 = m(x).clone()
+    with torch.no_grad():
+        m.H.mul_(0.5)
+    z1 = m(x)
+    np.testing.assert_allclose(z1.cpu().numpy(), po.analysis(x.cpu(), m.H.cpu(), 3, 62).numpy(), atol=TOL)
+    assert not torch.equal(z0, z1)
+    for seed in range(3):                     # fresh filters, possibly at a recycled address
+        H = (randn((3, 1, 63), 500 + seed) * 0.1).to(dev)
+        np.testing.assert_allclose(pqmf_analysis(x, H).cpu().numpy(), po.analysis(x.cpu(), H.cpu(), 3, 62).numpy(),
+                                   atol=TOL)
+        del H
+    z2 = torch.empty_like(z1)
+    Hc = m.H.reshape(3, 63).contiguous()
+    x2 = x.reshape(2, -1)
+    st = lib.ias_pqmf_analysis(_lib.ptr(x2), _lib.ptr(Hc), None, _lib.ptr(z2), None, None, 2, 9000, 3, 63,
+                               _lib.stream())
+    assert st == 0
+    np.testing.assert_allclose(z2.cpu().numpy(), z1.cpu().numpy(), atol=1e-6)
