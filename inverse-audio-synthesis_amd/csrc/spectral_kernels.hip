@@ -19,9 +19,9 @@
 #define SP_WAVES 4
 #define SP_FPB_MAX 8   // frames per workgroup (8, or 4 when the staged span would not fit LDS)
 
-// Complex numbers as 2-wide vectors: gfx950 issues a plain fp32 VALU op per wave64 in 4 cycles and only
-// the packed forms (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) reach the fp32 peak, so complex add/sub
-// are one packed op and a complex multiply is pk_mul + pk_fma.  8-byte aligned: LDS accesses are ds_*_b64.
+// Complex numbers as 2-wide vectors: complex add/sub are one packed op and a complex multiply is pk_mul +
+// pk_fma (a packed fp32 op costs the SIMD 4 clocks, two plain ones 2 + 2: the same arithmetic time, fewer
+// instructions to issue).  8-byte aligned: LDS accesses are ds_*_b64.
 typedef float cpx __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cpx cmk(float x, float y) { return (cpx){x, y}; }
 __device__ __forceinline__ cpx cadd(cpx a, cpx b) { return a + b; }

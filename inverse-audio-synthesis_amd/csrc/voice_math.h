@@ -308,9 +308,9 @@ __device__ __forceinline__ float ias_mix_sample_dev(float arg1, float arg2, floa
   return o;
 }
 
-// ---- two samples at a time: gfx950 issues a plain fp32 VALU op for a wave64 in 4 cycles and only the
-// packed forms (v_pk_mul_f32 / v_pk_add_f32) reach the fp32 peak, so the fp32 half of the per-sample
-// arithmetic is written on 2-wide vectors (same operations, same rounding, per component).
+// ---- two samples at a time: the fp32 half of the per-sample arithmetic is written on 2-wide vectors
+// (v_pk_mul_f32 / v_pk_add_f32: same operations, same rounding, per component; a packed op takes the SIMD
+// as long as its two plain halves, so this halves the instruction count, not the arithmetic time).
 typedef float ias_f2 __attribute__((ext_vector_type(2)));
 
 // ias_interp_pos_fast for samples (j0, j1): truncated control index k[2] and the lerp weights.
