@@ -70,6 +70,20 @@ int ias_voice_read_peaks(const void* workspace, float* peaks, int B, int T, int 
 /* Output frames of analysis: floor((T + 2*(K-1)/2 - K) / N) + 1, or a negative error. */
 int ias_pqmf_out_len(int T, int N, int K);
 
+/* ---- backward of the audio-rate render (the audio -> params -> synth -> loss loop the
+ * reference left commented out, audio_to_params.py:56-172; torchsynth's modules are differentiable torch code) ----
+ * ctrl [B,5,Tc] and vconst [B] (64 B each) are ias_voice_control's outputs for the same parameters; noise [B,T];
+ * g_mixed [B,T] = d loss / d (un-normalised mix).  Scratch: planes [B, ias_voice_grad_nplanes(), T] fp32,
+ * tile_sums [B, ias_voice_grad_tiles(T), 2] fp64.  Outputs: g_ctrl [B,5,Tc] fp32 = d loss / d ctrl;
+ * partials [B, ias_voice_grad_tiles(T), ias_voice_grad_nscalars()] fp64, whose sum over tiles is d loss / d of the
+ * per-voice constants f0_1 depth_1 phi_1 f0_2 depth_2 phi_2 kpart shape gain lvl0 lvl1 lvl2. */
+int ias_voice_grad_tiles(int T);
+int ias_voice_grad_nscalars(void);
+int ias_voice_grad_nplanes(void);
+int ias_voice_backward(const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
+                       float* planes, double* tile_sums, double* partials, float* g_ctrl, int B, int T, int Tc,
+                       int sample_rate, void* stream);
+
 /* Transposed, zero-padded tap table of the fast path: ias_pqmf_packed_taps_len(N, K) floats (0 = no fast path
  * for this N, K); ias_pqmf_pack_taps fills packed (device, 8-byte aligned) from H [N,K] (device); re-run when H
  * changes. */

@@ -33,6 +33,10 @@ SYMBOLS = {
     "ias_voice_stage": (_I, [_I, _P, _P, _P, _LL, _I, _I, _I, _I, _P]),
     "ias_voice_read_status": (_I, [_P, _P, _I, _I, _I, _P]),
     "ias_voice_read_peaks": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ias_voice_grad_tiles": (_I, [_I]),
+    "ias_voice_grad_nscalars": (_I, []),
+    "ias_voice_grad_nplanes": (_I, []),
+    "ias_voice_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_pqmf_out_len": (_I, [_I, _I, _I]),
     "ias_pqmf_packed_taps_len": (_I, [_I, _I]),
     "ias_pqmf_pack_taps": (_I, [_P, _P, _I, _I, _P]),

@@ -1,0 +1,305 @@
+// Backward of the audio-rate Voice render for MI355X (gfx950): d loss / d (control-rate signals, per-voice
+// constants) given d loss / d (un-normalised mix).
+//
+// The reference never differentiates through its synth -- the audio -> params -> synth -> mel-L1 loop is the
+// abandoned block /root/reference/audio_to_params.py:56-172.  This file is the
+// adjoint of csrc/voice_kernels.hip:voice_audio_kernel, i.e. of
+//   upc   = Upsample(linear, align_corners)(ctrl)                                   [B,5,T]
+//   arg_v = cumsum(2 pi * 440 * 2^((clamp(f0_v + depth_v * upc_pitch_v, 0, 127) - 69) / 12) / sr) + phi_v
+//   mixed = lvl0 * cos(arg_1) * upc_amp1
+//         + lvl1 * gain * tanh(kpart * sin(arg_2) / 2) * (1 + shape * cos(arg_2)) * upc_amp2
+//         + lvl2 * noise * upc_ampn
+// with torch.autograd's conventions (clamp passes the gradient on the closed interval).  The control-rate part
+// (78 parameters -> ctrl, constants) is differentiated on the host side by torch (voice_grad.py).
+//
+// Four passes over the [B,T] row, all with workgroup = one tile of GRAD_TILE consecutive samples:
+//   K0 increments  : the forward's phase increments (same correctly-rounded arithmetic, voice_math.h) -> planes
+//                    inc_1, inc_2 (sign bit set where the pitch clamp is active) + their fp64 tile sums
+//   K1 sample grads: phases = exact fp64 prefix of the increments (tile sums of the earlier tiles + in-tile
+//                    scan), oscillators, then g_amp1, g_amp2, g_ampn, g_arg1, g_arg2 per sample + per-tile
+//                    partial sums for the constants (lvl*, kpart, shape, gain, phi*)
+//   K2 pitch grads : g_cumsum -> suffix sums of g_arg (fp64, tile totals of the later tiles + in-tile reverse
+//                    scan) * d inc / d pitch -> g_pitchmod per sample, partial sums for f0 and depth
+//   K3 upsample^T  : g_ctrl[b,row,i] = sum_t W[t,i] * g_upc[b,row,t]  (a gather per control point: fixed
+//                    order, no atomics -> bit-reproducible)
+// Planes are caller-owned scratch [B,7,T] fp32; partials [B,ntiles,IAS_GRAD_NS] fp64 are summed by the caller.
+#include "ias_common.h"
+#include "voice_math.h"
+
+#define GRAD_THREADS 256
+#define GRAD_WAVES (GRAD_THREADS / 64)
+#define GRAD_CHUNKS 16
+#define GRAD_TILE (GRAD_THREADS * GRAD_CHUNKS)
+#define IAS_GRAD_NS 12      // f0_1 depth_1 phi_1 f0_2 depth_2 phi_2 kpart shape gain lvl0 lvl1 lvl2
+#define IAS_GRAD_PLANES 7   // inc_1 inc_2 | g_amp1 g_amp2 g_ampn | g_arg1->g_pm1 g_arg2->g_pm2
+
+enum { GS_F0_1 = 0, GS_DEPTH_1, GS_PHI_1, GS_F0_2, GS_DEPTH_2, GS_PHI_2, GS_KPART, GS_SHAPE, GS_GAIN, GS_LVL0, GS_LVL1,
+       GS_LVL2 };
+enum { PL_INC1 = 0, PL_INC2, PL_GAMP1, PL_GAMP2, PL_GAMPN, PL_GARG1, PL_GARG2 };
+
+__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_total(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// Inclusive scan of one value per thread over the workgroup (thread order); returns the scanned value and
+// adds the workgroup total to `carry` (same value in every thread).  s_w: GRAD_WAVES doubles of LDS.
+__device__ __forceinline__ double block_incl_scan(double v, double& carry, double* s_w, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  double s = wave_incl_scan(v, lane);
+  __syncthreads();                       // s_w free again
+  if (lane == 63) s_w[wave] = s;
+  __syncthreads();
+  double before = 0.0, total = 0.0;
+#pragma unroll
+  for (int w = 0; w < GRAD_WAVES; ++w) {
+    const double x = s_w[w];
+    if (w < wave) before += x;
+    total += x;
+  }
+  s += before + carry;
+  carry += total;
+  return s;
+}
+
+// Workgroup sum of NS per-thread doubles -> out[NS] (thread 0 writes); fixed order.
+template <int NS>
+__device__ __forceinline__ void block_sums(const double (&acc)[NS], double* out, double* s_red /* [GRAD_WAVES][NS] */, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const double t = wave_total(acc[k]);
+    if (lane == 0) s_red[wave * NS + k] = t;
+  }
+  __syncthreads();
+  if (tid < NS) {
+    double t = 0.0;
+    for (int w = 0; w < GRAD_WAVES; ++w) t += s_red[w * NS + tid];
+    out[tid] = t;
+  }
+}
+
+__device__ __forceinline__ float grad_lerp(const float* __restrict__ row, int i0, int i1, float w0, float w1) {
+  return ias_lerp(row[i0], row[i1], w0, w1);
+}
+
+// ------------------------------------------------------------------------------------------------ K0
+__global__ __launch_bounds__(GRAD_THREADS) void voice_grad_inc_kernel(
+    const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst, float* __restrict__ planes,
+    double* __restrict__ tile_sums /* [B][ntiles][2] */, int T, int Tc, int ntiles, double inv_sample_rate,
+    float scale) {
+  __shared__ double s_red[GRAD_WAVES * 2];
+  const int tid = threadIdx.x, tile = blockIdx.x, b = blockIdx.y;
+  const IasVoiceConst vc = vconst[b];
+  const float* cb = ctrl + (size_t)b * IAS_NCTRL * Tc;
+  float* p1 = planes + ((size_t)b * IAS_GRAD_PLANES + PL_INC1) * T;
+  float* p2 = planes + ((size_t)b * IAS_GRAD_PLANES + PL_INC2) * T;
+  double acc[2] = {0.0, 0.0};
+  for (int it = 0; it < GRAD_CHUNKS; ++it) {
+    const int j = tile * GRAD_TILE + it * GRAD_THREADS + tid;
+    if (j < T) {
+      int i0, i1; float w0, w1;
+      ias_interp_pos_fast(j, scale, Tc, i0, i1, w0, w1);
+      const float pm1 = grad_lerp(cb, i0, i1, w0, w1);
+      const float pm2 = grad_lerp(cb + 2 * Tc, i0, i1, w0, w1);
+      const float a = ias_vco_inc_fast(vc.f0_1, vc.depth_1, pm1, inv_sample_rate);
+      const float d = ias_vco_inc_fast(vc.f0_2, vc.depth_2, pm2, inv_sample_rate);
+      // torch.clamp passes the gradient on [0, 127]; outside, the increment is stored negated as the flag
+      const float c1 = ias_add(vc.f0_1, ias_mul(vc.depth_1, pm1)), c2 = ias_add(vc.f0_2, ias_mul(vc.depth_2, pm2));
+      p1[j] = (c1 >= 0.0f && c1 <= 127.0f) ? a : -a;
+      p2[j] = (c2 >= 0.0f && c2 <= 127.0f) ? d : -d;
+      acc[0] += (double)a;
+      acc[1] += (double)d;
+    }
+  }
+  block_sums<2>(acc, tile_sums + ((size_t)b * ntiles + tile) * 2, s_red, tid);
+}
+
+// ------------------------------------------------------------------------------------------------ K1
+__global__ __launch_bounds__(GRAD_THREADS) void voice_grad_sample_kernel(
+    const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst, const float* __restrict__ noise,
+    const float* __restrict__ g_mixed, float* __restrict__ planes, const double* __restrict__ tile_sums,
+    double* __restrict__ partials /* [B][ntiles][IAS_GRAD_NS] */, int T, int Tc, int ntiles, float scale) {
+  __shared__ double s_w[GRAD_WAVES];
+  __shared__ double s_red[GRAD_WAVES * 8];
+  const int tid = threadIdx.x, tile = blockIdx.x, b = blockIdx.y;
+  const IasVoiceConst vc = vconst[b];
+  const float* cb = ctrl + (size_t)b * IAS_NCTRL * Tc;
+  float* pl = planes + (size_t)b * IAS_GRAD_PLANES * T;
+  const float* nrow = noise + (size_t)b * T;
+  const float* grow = g_mixed + (size_t)b * T;
+
+  // carry-in: the increments of the earlier tiles (fp64 sums of fp32 values below 2^19 are exact)
+  double carry1 = 0.0, carry2 = 0.0;
+  for (int t = 0; t < tile; ++t) {
+    carry1 += tile_sums[((size_t)b * ntiles + t) * 2];
+    carry2 += tile_sums[((size_t)b * ntiles + t) * 2 + 1];
+  }
+  // lvl0 lvl1 lvl2 kpart shape gain phi_1 phi_2
+  double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int it = 0; it < GRAD_CHUNKS; ++it) {
+    const int j = tile * GRAD_TILE + it * GRAD_THREADS + tid;
+    const bool ok = j < T;
+    const double inc1 = ok ? (double)fabsf(pl[(size_t)PL_INC1 * T + j]) : 0.0;
+    const double inc2 = ok ? (double)fabsf(pl[(size_t)PL_INC2 * T + j]) : 0.0;
+    const double cum1 = block_incl_scan(inc1, carry1, s_w, tid);
+    const double cum2 = block_incl_scan(inc2, carry2, s_w, tid);
+    if (!ok) continue;
+    const float arg1 = ias_add((float)cum1, vc.phi_1), arg2 = ias_add((float)cum2, vc.phi_2);
+    int i0, i1; float w0, w1;
+    ias_interp_pos_fast(j, scale, Tc, i0, i1, w0, w1);
+    const float amp1 = grad_lerp(cb + 1 * Tc, i0, i1, w0, w1);
+    const float amp2 = grad_lerp(cb + 3 * Tc, i0, i1, w0, w1);
+    const float ampn = grad_lerp(cb + 4 * Tc, i0, i1, w0, w1);
+    float s1, c1, s2, c2;
+    ias_sincos_dev(arg1, s1, c1);
+    ias_sincos_dev(arg2, s2, c2);
+    const float th = ias_tanh_dev(vc.kpart * s2 * 0.5f);
+    const float env2 = 1.0f + vc.shape * c2;
+    const float core2 = vc.shape_gain * th * env2;
+    const float nz = nrow[j];
+    const float g = grow[j];
+    pl[(size_t)PL_GAMP1 * T + j] = g * vc.lvl0 * c1;
+    pl[(size_t)PL_GAMP2 * T + j] = g * vc.lvl1 * core2;
+    pl[(size_t)PL_GAMPN * T + j] = g * vc.lvl2 * nz;
+    const float g_arg1 = -g * vc.lvl0 * amp1 * s1;
+    const float ga2 = g * vc.lvl1 * amp2;                      // d loss / d (gain * tanh * env2)
+    const float sech2 = 1.0f - th * th;
+    const float g_arg2 = ga2 * vc.shape_gain * (sech2 * (0.5f * vc.kpart) * c2 * env2 - th * vc.shape * s2);
+    pl[(size_t)PL_GARG1 * T + j] = g_arg1;
+    pl[(size_t)PL_GARG2 * T + j] = g_arg2;
+    acc[0] += (double)(g * c1 * amp1);
+    acc[1] += (double)(g * core2 * amp2);
+    acc[2] += (double)(g * nz * ampn);
+    acc[3] += (double)(ga2 * vc.shape_gain * sech2 * (0.5f * s2) * env2);
+    acc[4] += (double)(ga2 * vc.shape_gain * th * c2);
+    acc[5] += (double)(ga2 * th * env2);
+    acc[6] += (double)g_arg1;
+    acc[7] += (double)g_arg2;
+  }
+  __shared__ double s_out[8];
+  block_sums<8>(acc, s_out, s_red, tid);
+  __syncthreads();
+  if (tid == 0) {
+    double* o = partials + ((size_t)b * ntiles + tile) * IAS_GRAD_NS;
+    o[GS_LVL0] = s_out[0]; o[GS_LVL1] = s_out[1]; o[GS_LVL2] = s_out[2];
+    o[GS_KPART] = s_out[3]; o[GS_SHAPE] = s_out[4]; o[GS_GAIN] = s_out[5];
+    o[GS_PHI_1] = s_out[6]; o[GS_PHI_2] = s_out[7];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ K2
+__global__ __launch_bounds__(GRAD_THREADS) void voice_grad_pitch_kernel(
+    const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst, float* __restrict__ planes,
+    double* __restrict__ partials, int T, int Tc, int ntiles, float scale) {
+  __shared__ double s_w[GRAD_WAVES];
+  __shared__ double s_red[GRAD_WAVES * 4];
+  const int tid = threadIdx.x, tile = blockIdx.x, b = blockIdx.y;
+  const IasVoiceConst vc = vconst[b];
+  const float* cb = ctrl + (size_t)b * IAS_NCTRL * Tc;
+  float* pl = planes + (size_t)b * IAS_GRAD_PLANES * T;
+  // carry-in of the reverse scan: g_arg totals of the later tiles (K1 left them in the phi slots)
+  double carry1 = 0.0, carry2 = 0.0;
+  for (int t = ntiles - 1; t > tile; --t) {
+    carry1 += partials[((size_t)b * ntiles + t) * IAS_GRAD_NS + GS_PHI_1];
+    carry2 += partials[((size_t)b * ntiles + t) * IAS_GRAD_NS + GS_PHI_2];
+  }
+  const double k = 0.6931471805599453 / 12.0;   // d inc / d pitch = inc * ln2 / 12
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};        // f0_1 depth_1 f0_2 depth_2
+  for (int it = GRAD_CHUNKS - 1; it >= 0; --it) {
+    const int j = tile * GRAD_TILE + it * GRAD_THREADS + (GRAD_THREADS - 1 - tid);   // descending in tid
+    const bool ok = j < T;
+    const double ga1 = ok ? (double)pl[(size_t)PL_GARG1 * T + j] : 0.0;
+    const double ga2 = ok ? (double)pl[(size_t)PL_GARG2 * T + j] : 0.0;
+    const double suf1 = block_incl_scan(ga1, carry1, s_w, tid);
+    const double suf2 = block_incl_scan(ga2, carry2, s_w, tid);
+    if (!ok) continue;
+    const float inc1 = pl[(size_t)PL_INC1 * T + j], inc2 = pl[(size_t)PL_INC2 * T + j];
+    const double gc1 = inc1 > 0.0f ? suf1 * ((double)inc1 * k) : 0.0;
+    const double gc2 = inc2 > 0.0f ? suf2 * ((double)inc2 * k) : 0.0;
+    int i0, i1; float w0, w1;
+    ias_interp_pos_fast(j, scale, Tc, i0, i1, w0, w1);
+    const float pm1 = grad_lerp(cb, i0, i1, w0, w1);
+    const float pm2 = grad_lerp(cb + 2 * Tc, i0, i1, w0, w1);
+    acc[0] += gc1; acc[1] += gc1 * (double)pm1;
+    acc[2] += gc2; acc[3] += gc2 * (double)pm2;
+    pl[(size_t)PL_GARG1 * T + j] = (float)(gc1 * (double)vc.depth_1);
+    pl[(size_t)PL_GARG2 * T + j] = (float)(gc2 * (double)vc.depth_2);
+  }
+  __shared__ double s_out[4];
+  block_sums<4>(acc, s_out, s_red, tid);
+  __syncthreads();
+  if (tid == 0) {
+    double* o = partials + ((size_t)b * ntiles + tile) * IAS_GRAD_NS;
+    o[GS_F0_1] = s_out[0]; o[GS_DEPTH_1] = s_out[1]; o[GS_F0_2] = s_out[2]; o[GS_DEPTH_2] = s_out[3];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ K3
+// one wave per (control point, row): the samples whose lerp touches control point i lie in
+// [ (i-1)/scale, (i+1)/scale ]; each is tested with the forward's own index arithmetic.
+__global__ __launch_bounds__(GRAD_THREADS) void voice_grad_ctrl_kernel(
+    const float* __restrict__ planes, float* __restrict__ g_ctrl /* [B][5][Tc] */, int T, int Tc, float scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * GRAD_WAVES + wave, row = blockIdx.y, b = blockIdx.z;
+  if (i >= Tc) return;
+  const int plane_of_row[IAS_NCTRL] = {PL_GARG1, PL_GAMP1, PL_GARG2, PL_GAMP2, PL_GAMPN};
+  const float* src = planes + ((size_t)b * IAS_GRAD_PLANES + plane_of_row[row]) * T;
+  const double inv = 1.0 / (double)scale;
+  long long ta = (long long)floor((double)(i - 1) * inv) - 2, tb = (long long)ceil((double)(i + 1) * inv) + 2;
+  if (ta < 0) ta = 0;
+  if (tb > T - 1) tb = T - 1;
+  double acc = 0.0;
+  for (long long t = ta + lane; t <= tb; t += 64) {
+    int i0, i1; float w0, w1;
+    ias_interp_pos_fast((int)t, scale, Tc, i0, i1, w0, w1);
+    const float g = src[t];
+    if (i0 == i) acc += (double)w0 * (double)g;
+    if (i1 == i) acc += (double)w1 * (double)g;
+  }
+  acc = wave_total(acc);
+  if (lane == 0) g_ctrl[((size_t)b * IAS_NCTRL + row) * Tc + i] = (float)acc;
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" int ias_voice_grad_tiles(int T) { return T > 0 ? (T + GRAD_TILE - 1) / GRAD_TILE : IAS_ERR_ARG; }
+extern "C" int ias_voice_grad_nscalars(void) { return IAS_GRAD_NS; }
+extern "C" int ias_voice_grad_nplanes(void) { return IAS_GRAD_PLANES; }
+
+// ctrl [B,5,Tc], vconst [B] (64 B each): the outputs of ias_voice_control for the same parameters;
+// noise [B,T]; g_mixed [B,T] = d loss / d (un-normalised mix);
+// planes [B, ias_voice_grad_nplanes(), T] fp32 scratch; tile_sums [B, ntiles, 2] fp64 scratch;
+// partials [B, ntiles, ias_voice_grad_nscalars()] fp64 out (sum over tiles = gradient of the per-voice
+// constants in the order f0_1 depth_1 phi_1 f0_2 depth_2 phi_2 kpart shape gain lvl0 lvl1 lvl2);
+// g_ctrl [B,5,Tc] fp32 out.  ntiles = ias_voice_grad_tiles(T).
+extern "C" int ias_voice_backward(const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
+                                  float* planes, double* tile_sums, double* partials, float* g_ctrl, int B, int T,
+                                  int Tc, int sample_rate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!ctrl || !vconst || !noise || !g_mixed || !planes || !tile_sums || !partials || !g_ctrl) return IAS_ERR_ARG;
+  if (B <= 0 || B > 65535 || T <= 1 || Tc <= 1 || sample_rate <= 0) return IAS_ERR_ARG;
+  const int ntiles = (T + GRAD_TILE - 1) / GRAD_TILE;
+  if (ntiles > 65535) return IAS_ERR_UNSUPPORTED;
+  const float scale = (float)(Tc - 1) / (float)(T - 1);
+  const IasVoiceConst* vc = (const IasVoiceConst*)vconst;
+  const dim3 grid(ntiles, B), block(GRAD_THREADS);
+  hipLaunchKernelGGL(voice_grad_inc_kernel, grid, block, 0, stream, ctrl, vc, planes, tile_sums, T, Tc, ntiles,
+                     1.0 / (double)sample_rate, scale);
+  hipLaunchKernelGGL(voice_grad_sample_kernel, grid, block, 0, stream, ctrl, vc, noise, g_mixed, planes, tile_sums,
+                     partials, T, Tc, ntiles, scale);
+  hipLaunchKernelGGL(voice_grad_pitch_kernel, grid, block, 0, stream, ctrl, vc, planes, partials, T, Tc, ntiles,
+                     scale);
+  hipLaunchKernelGGL(voice_grad_ctrl_kernel, dim3((Tc + GRAD_WAVES - 1) / GRAD_WAVES, IAS_NCTRL, B), block, 0, stream,
+                     planes, g_ctrl, T, Tc, scale);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}

@@ -145,9 +145,17 @@ class Voice(nn.Module):
 
     # ---- render ----
     def render(self, params01=None, normalize=True):
-        """HIP render of ``params01`` ([B,78] in 0..1, default: the stored ones) -> audio [B,T]."""
-        c = self.synthconfig
+        """HIP render of ``params01`` ([B,78] in 0..1, default: the stored ones) -> audio [B,T].
+
+        Differentiable with respect to ``params01`` when it requires grad (``voice_grad.py``)."""
         p = self.params01 if params01 is None else params01
+        if torch.is_grad_enabled() and p.requires_grad:
+            from .voice_grad import render_with_grad
+            return render_with_grad(self, p, normalize)
+        return self._render_nograd(p, normalize)
+
+    def _render_nograd(self, p, normalize=True):
+        c = self.synthconfig
         p = p.detach().to(torch.float32).contiguous()
         assert p.shape == (c.batch_size, S.NPARAMS)
         lib = _lib.load()
@@ -214,6 +222,14 @@ class Voice(nn.Module):
         self.render_control(self._workspace, p)
         hook("control", "end")
         return self.render_audio(self._workspace, out=out, on_stage=on_stage)
+
+    def read_peaks(self):
+        """Row peaks max|mix| [B] of the last render (before normalisation)."""
+        c = self.synthconfig
+        pk = torch.empty(c.batch_size, dtype=torch.float32, device=self._workspace.device)
+        _lib.check(_lib.load().ias_voice_read_peaks(_lib.ptr(self._workspace), _lib.ptr(pk), c.batch_size, c.buffer_size,
+                                                    c.control_buffer_size, _lib.stream()), "ias_voice_read_peaks")
+        return pk
 
     def chain_status(self):
         """0 if the last render's cross-tile scan completed; 1 if a bounded wait expired (tests)."""

@@ -1,0 +1,203 @@
+"""Gradient of the Voice render with respect to the normalised parameters.
+
+The reference never got this far: the audio -> params -> synth -> mel-L1 training loop is the commented-out block
+/root/reference/audio_to_params.py:56-172 (torchsynth's own modules are differentiable torch code, which is what
+that block relied on).  Here the render is a hand-written HIP kernel, so its adjoint is one too:
+
+* audio rate ([B,T] work): ``csrc/voice_grad_kernels.hip`` (``ias_voice_backward``) turns d loss / d mix into
+  d loss / d (control-rate signals [B,5,Tc]) and d loss / d (12 per-voice constants);
+* control rate ([B,Tc] work, a few thousand points per voice): the 78 parameters -> (control signals, constants) map
+  is restated below with differentiable torch ops, evaluated in fp64 on the device, and torch's autograd carries
+  the two gradients above back to the parameters.  The values that reach the audio-rate kernels always come from
+  the HIP control kernels; this graph is only differentiated, and ``tests/test_voice_grad_gpu.py`` checks that its
+  forward values agree with the HIP control kernels.
+"""
+import math
+
+import torch
+
+from . import _lib
+from . import voice_spec as S
+
+TWO_PI = 2.0 * math.pi
+# order of the per-voice constants in ias_voice_backward's partials (csrc/voice_grad_kernels.hip GS_*)
+SCALARS = ("f0_1", "depth_1", "phi_1", "f0_2", "depth_2", "phi_2", "kpart", "shape", "gain", "lvl0", "lvl1", "lvl2")
+
+
+_ADSRS = ("adsr_1", "adsr_2", "lfo_1_amp_adsr", "lfo_2_amp_adsr", "lfo_1_rate_adsr", "lfo_2_rate_adsr")
+_LFOS = ("lfo_1", "lfo_2")
+_TABLE = {}
+
+
+def _table(device, dtype):
+    """Range table of the 78 parameters as [78] tensors (lo, hi, 1/curve, symmetric)."""
+    key = (str(device), dtype)
+    if key not in _TABLE:
+        cols = list(zip(*[(lo, hi, 1.0 / curve, 1.0 if sym else 0.0) for (_m, _n, lo, hi, curve, sym) in S.PARAMS]))
+        _TABLE[key] = tuple(torch.tensor(c, dtype=dtype, device=device) for c in cols)
+    return _TABLE[key]
+
+
+def _from_0to1(params01):
+    """torchsynth ModuleParameterRange.from_0to1 for all 78 columns at once: [B,78] in 0..1 -> parameter values.
+
+    non-symmetric: lo + (hi-lo) u^(1/curve);  symmetric: lo + (hi-lo)/2 (sign(d) |d|^(1/curve) + 1), d = 2u-1.
+    (x^(1/curve) as exp2(log2(x)/curve); the base is kept off zero so that autograd stays finite there.)"""
+    lo, hi, inv_curve, sym = _table(params01.device, params01.dtype)
+    tiny = 1e-300 if params01.dtype == torch.float64 else 1e-30
+    un = torch.exp2(torch.log2(params01.clamp_min(tiny)) * inv_curve)
+    dist = 2.0 * params01 - 1.0
+    us = torch.exp2(torch.log2(dist.abs().clamp_min(tiny)) * inv_curve) * torch.sign(dist)
+    return torch.where(sym > 0.5, lo + (hi - lo) * 0.5 * (us + 1.0), lo + (hi - lo) * un)
+
+
+class _Params:
+    """p(module, name) -> [B];  p.many(modules, name) -> [B, len(modules)]."""
+
+    def __init__(self, params01):
+        self.v = _from_0to1(params01)
+
+    def __call__(self, mod, name):
+        return self.v[:, S.INDEX[(mod, name)]]
+
+    def many(self, mods, name):
+        return self.v[:, [S.INDEX[(m, name)] for m in mods]]
+
+
+def _ramp(cfg, duration, alpha, start=None, inverse=False):
+    """duration, start [B,E] seconds, alpha [B,E,1] -> [B,E,Tc]."""
+    dur = (duration * cfg.control_rate).unsqueeze(-1)
+    ramp = torch.arange(cfg.control_buffer_size, dtype=duration.dtype, device=duration.device).expand(*duration.shape, -1)
+    if start is not None:
+        ramp = ramp - (start * cfg.control_rate).unsqueeze(-1)
+    ramp = torch.clamp_min(ramp, 0.0)
+    # a zero duration makes the ramp +inf -> 1; guarded divisor so that autograd does not produce 0 * inf = nan
+    safe = torch.where(dur > 0.0, dur, torch.ones_like(dur))
+    ramp = torch.where(dur > 0.0, torch.clamp_max((ramp + S.EPS) / safe + S.EPS, 1.0), torch.ones_like(ramp))
+    if inverse:
+        ramp = torch.where(dur > 0.0, 1.0 - ramp, ramp)
+    # d/dx x^alpha at x = 0 is taken as 0 (autograd would give inf * 0 = nan for alpha < 1)
+    return torch.pow(ramp.clamp_min(1e-300), alpha)
+
+
+def _adsrs(cfg, p, mods, note_on):
+    """All envelopes of ``mods`` in one pass -> [B, len(mods), Tc]."""
+    attack, decay, sustain = p.many(mods, "attack"), p.many(mods, "decay"), p.many(mods, "sustain")
+    release, alpha = p.many(mods, "release"), p.many(mods, "alpha").unsqueeze(-1)
+    note_on = note_on.unsqueeze(1).expand_as(attack)
+    new_attack = torch.minimum(attack, note_on)
+    new_decay = torch.minimum(torch.clamp_min(note_on - attack, 0.0), decay)
+    a = _ramp(cfg, new_attack, alpha)
+    sus = sustain.unsqueeze(-1)
+    d = (1.0 - sus) * _ramp(cfg, new_decay, alpha, start=new_attack, inverse=True) + sus
+    r = _ramp(cfg, release, alpha, start=note_on, inverse=True)
+    return a * d * r
+
+
+def _lfos(cfg, p, mods, rate_env):
+    """Both LFOs in one pass: rate_env [B,2,Tc] -> [B,2,Tc]."""
+    freq = p.many(mods, "frequency").unsqueeze(-1)
+    freq = torch.clamp_min(freq + p.many(mods, "mod_depth").unsqueeze(-1) * rate_env, 0.0)
+    arg = torch.cumsum(TWO_PI * freq / cfg.control_rate, dim=-1) + p.many(mods, "initial_phase").unsqueeze(-1)
+    cos = torch.cos(arg + math.pi)
+    square = (torch.sign(cos) + 1.0) / 2.0
+    cos = (cos + 1.0) / 2.0
+    saw = torch.remainder(arg, TWO_PI) / TWO_PI
+    revsaw = 1.0 - saw
+    tri = 2.0 * saw
+    tri = torch.where(tri > 1.0, 2.0 - tri, tri)
+    shapes = torch.stack([cos, tri, saw, revsaw, square], dim=2)              # [B,2,5,Tc]
+    mode = torch.stack([p.many(mods, s) for s in S.LFO_SHAPES], dim=2)        # [B,2,5]
+    mode = torch.pow(mode, S.LFO_EXPONENT)
+    mode = mode / torch.sum(mode, dim=2, keepdim=True)
+    return (mode.unsqueeze(-1) * shapes).sum(dim=2)
+
+
+def _midi_to_hz(midi):
+    return 440.0 * torch.exp2((midi - 69.0) / 12.0)
+
+
+def control_graph(params01, cfg):
+    """Differentiable restatement of the control-rate pass (csrc/voice_kernels.hip voice_env / voice_lfo /
+    voice_modmix kernels): params01 [B,78] -> (ctrl [B,5,Tc], constants [B,12] in ``SCALARS`` order).
+    The six envelopes, the two LFOs and the 78 range maps are each evaluated as one batched expression (a few
+    dozen device kernels instead of a few thousand)."""
+    p = _Params(params01)
+    env = _adsrs(cfg, p, _ADSRS, p("keyboard", "duration"))                  # [B,6,Tc]
+    lfo = _lfos(cfg, p, _LFOS, env[:, 4:6]) * env[:, 2:4]
+    w = torch.stack([p("mod_matrix", f"{i}->{o}") for i in S.MOD_INPUTS for o in S.MOD_OUTPUTS], dim=1)
+    w = w.reshape(-1, len(S.MOD_INPUTS), len(S.MOD_OUTPUTS)).swapaxes(1, 2)
+    ctrl = torch.matmul(w, torch.cat([env[:, 0:2], lfo], dim=1))
+
+    midi_f0 = p("keyboard", "midi_f0")
+    depth_2 = p("vco_2", "mod_depth")
+    max_f0 = _midi_to_hz(midi_f0 + torch.clamp_min(depth_2, 0.0))
+    kpart = math.pi * 12000.0 / (max_f0 * torch.log10(max_f0))
+    shape = p("vco_2", "shape")
+    scal = torch.stack([
+        midi_f0 + p("vco_1", "tuning"), p("vco_1", "mod_depth"), p("vco_1", "initial_phase"),
+        midi_f0 + p("vco_2", "tuning"), depth_2, p("vco_2", "initial_phase"),
+        kpart, shape, 1.0 - shape / 2.0,
+        p("mixer", "vco_1"), p("mixer", "vco_2"), p("mixer", "noise")], dim=1)
+    return ctrl, scal
+
+
+def audio_rate_backward(voice, params01, g_mixed):
+    """HIP adjoint of the audio-rate render: g_mixed [B,T] -> (g_ctrl [B,5,Tc] fp32, g_constants [B,12] fp64)."""
+    c = voice.synthconfig
+    lib = _lib.load()
+    B, T, Tc = c.batch_size, c.buffer_size, c.control_buffer_size
+    g_mixed = g_mixed.to(torch.float32).contiguous()
+    _lib.require_f32(g_mixed, voice.noise)
+    ctrl, vconst = voice.control_signals(params01)
+    dev = g_mixed.device
+    ntiles = lib.ias_voice_grad_tiles(T)
+    planes = torch.empty((B, lib.ias_voice_grad_nplanes(), T), dtype=torch.float32, device=dev)
+    tile_sums = torch.empty((B, ntiles, 2), dtype=torch.float64, device=dev)
+    partials = torch.empty((B, ntiles, lib.ias_voice_grad_nscalars()), dtype=torch.float64, device=dev)
+    g_ctrl = torch.empty((B, 5, Tc), dtype=torch.float32, device=dev)
+    st = lib.ias_voice_backward(_lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(voice.noise), _lib.ptr(g_mixed),
+                                _lib.ptr(planes), _lib.ptr(tile_sums), _lib.ptr(partials), _lib.ptr(g_ctrl),
+                                B, T, Tc, c.sample_rate, _lib.stream())
+    _lib.check(st, "ias_voice_backward")
+    return g_ctrl, partials.sum(dim=1)
+
+
+class _RenderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params01, voice, normalize):
+        p = params01.detach().to(torch.float32).contiguous()
+        audio = voice._render_nograd(p, normalize)
+        peaks = voice.read_peaks() if normalize else None
+        ctx.voice, ctx.normalize = voice, normalize
+        ctx.save_for_backward(p, audio, peaks)
+        return audio
+
+    @staticmethod
+    def backward(ctx, g_audio):
+        p, audio, peaks = ctx.saved_tensors
+        voice = ctx.voice
+        g = g_audio.to(torch.float32)
+        if ctx.normalize:
+            # audio = mixed / peak on rows with peak > 1 (peak = max |mixed|, attained at t*):
+            #   g_mixed = g / peak, and the peak itself takes -sign(mixed[t*]) * sum_t g[t] audio[t] / peak at t*
+            clip = peaks > 1.0
+            pk = torch.where(clip, peaks, torch.ones_like(peaks)).unsqueeze(1)
+            g_mixed = g / pk
+            dot = (g * audio).sum(dim=1)
+            tstar = audio.abs().argmax(dim=1, keepdim=True)
+            corr = -torch.sign(audio.gather(1, tstar)).squeeze(1) * dot / pk.squeeze(1)
+            g_mixed.scatter_add_(1, tstar, torch.where(clip, corr, torch.zeros_like(corr)).unsqueeze(1))
+        else:
+            g_mixed = g
+        g_ctrl, g_scal = audio_rate_backward(voice, p, g_mixed)
+        with torch.enable_grad():
+            pd = p.double().requires_grad_(True)
+            ctrl_t, scal_t = control_graph(pd, voice.synthconfig)
+            (g_p,) = torch.autograd.grad([ctrl_t, scal_t], pd, [g_ctrl.double(), g_scal])
+        return g_p.to(torch.float32), None, None
+
+
+def render_with_grad(voice, params01, normalize=True):
+    """audio [B,T] = voice render of params01 [B,78], differentiable with respect to params01."""
+    return _RenderFn.apply(params01, voice, normalize)

@@ -54,8 +54,10 @@ class VoiceConfig:
 
 class _Math:
     def __init__(self, mode):
-        assert mode in ("torch", "cr")
+        # "f64": the "torch" op sequence evaluated in double (the gradient reference of tests/test_voice_grad_gpu.py)
+        assert mode in ("torch", "cr", "f64")
         self.cr = mode == "cr"
+        self.dtype = torch.float64 if mode == "f64" else torch.float32
 
     def _u(self, fn, *xs):
         if self.cr:
@@ -63,6 +65,9 @@ class _Math:
         return fn(*xs)
 
     def pow(self, x, a):
+        if self.dtype == torch.float64:
+            # gradient reference: d/dx x^a at x = 0 is taken as 0 (autograd gives inf * 0 = nan for a < 1)
+            return torch.pow(x.clamp_min(1e-300), a)
         return self._u(torch.pow, x, a)
 
     def exp2(self, x):
@@ -171,7 +176,7 @@ class _P:
     def __init__(self, params01, m):
         self.v = {}
         for i, (mod, name, lo, hi, curve, sym) in enumerate(S.PARAMS):
-            self.v[(mod, name)] = from_0to1(params01[:, i].float(), lo, hi, curve, sym, m)
+            self.v[(mod, name)] = from_0to1(params01[:, i].to(m.dtype), lo, hi, curve, sym, m)
 
     def __call__(self, mod, name):
         return self.v[(mod, name)]
@@ -184,8 +189,11 @@ def _ramp(cfg, m, duration, alpha, start=None, inverse=False):
     if start is not None:
         ramp = ramp - (start * cfg.control_rate).unsqueeze(1)
     ramp = torch.maximum(ramp, torch.tensor(0.0))
-    ramp = (ramp + S.EPS) / dur + S.EPS
-    ramp = torch.minimum(ramp, torch.tensor(1.0))
+    # dur == 0 gives +inf -> 1 after the minimum; written with a guarded divisor (same values) so that autograd
+    # does not produce 0 * inf = nan for the duration's gradient
+    safe = torch.where(dur > 0.0, dur, torch.ones_like(dur))
+    ramp = torch.where(dur > 0.0, (ramp + S.EPS) / safe + S.EPS, torch.full_like(ramp, float("inf")) + 0.0 * dur)
+    ramp = torch.minimum(ramp, torch.tensor(1.0, dtype=ramp.dtype))
     if inverse:
         ramp = torch.where(dur > 0.0, 1.0 - ramp, ramp)
     return m.pow(ramp, alpha)

@@ -1,0 +1,108 @@
+"""Gradient of the HIP Voice render w.r.t. the 78 normalised parameters (csrc/voice_grad_kernels.hip + the torch
+control graph of voice_grad.py) against torch.autograd through the oracle evaluated in fp64 (math "f64").
+
+The reference has no backward of its own to compare with (audio_to_params.py:56-172 is commented
+out), so the oracle's autograd IS the definition.  Tolerance: the HIP forward rounds the oscillator phases to fp32
+as the reference does (the fp64 oracle does not), which perturbs each per-sample gradient term by ~1e-3 relative;
+sums over the row average that down.  Asserted: relative L2 error per voice <= 2e-2 and <= 5e-3 over the batch."""
+import pytest
+import torch
+
+from oracle import synth_oracle as so
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _voice(dev, B, sr, sec):
+    from inverse_audio_synthesis_amd.voice import SynthConfig, Voice
+    return Voice(SynthConfig(batch_size=B, sample_rate=sr, buffer_size_seconds=sec, reproducible=False)).to(dev)
+
+
+def _oracle_grad(cfg, params01, noise, w, normalize=True):
+    p = params01.double().requires_grad_(True)
+    if normalize:
+        a = so.render_from_params01(cfg, p, noise, "f64")
+    else:
+        a = so.render_from_params01(cfg, p, noise, "f64", return_parts=True)[1]["mixed"]
+    (g,) = torch.autograd.grad((a * w.double()).sum(), p)
+    return g
+
+
+def test_control_graph_matches_hip_control_kernels(lib, dev):
+    from inverse_audio_synthesis_amd.voice_grad import control_graph
+    v = _voice(dev, 8, 44100, 4.0)
+    for seed in (0, 2):
+        p = so.sample_params01(so.VoiceConfig(8, 44100, 4.0), seed).to(dev)
+        ctrl, vconst = v.control_signals(p)
+        ctrl_t, scal_t = control_graph(p.double(), v.synthconfig)
+        # the LFO saw / square shapes jump: a control point that sits on a jump may fall on either side in fp32
+        # vs fp64, so a handful of isolated points differ by up to the jump height
+        err = (ctrl_t.float() - ctrl).abs().flatten()
+        assert (err > 2e-5).float().mean().item() <= 1e-3 and err.mean().item() <= 1e-5
+        # IasVoiceConst: f0_1 depth_1 phi_1 f0_2 depth_2 phi_2 kpart shape gain lvl0 lvl1 lvl2
+        got = vconst[:, :12].double()
+        assert ((scal_t - got).abs() / (1.0 + got.abs())).max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("B,sr,sec,seed,normalize", [(4, 16000, 1.0, 0, True), (4, 16000, 1.0, 2, True),
+                                                     (4, 16000, 1.0, 1, False), (2, 44100, 4.0, 3, True)])
+def test_gradient_matches_oracle_autograd(lib, dev, B, sr, sec, seed, normalize):
+    cfg = so.VoiceConfig(B, sr, sec)
+    v = _voice(dev, B, sr, sec)
+    p0 = so.sample_params01(cfg, seed)
+    w = torch.randn((B, cfg.buffer_size), generator=torch.Generator().manual_seed(100 + seed))
+    ref = _oracle_grad(cfg, p0, so.make_noise(cfg), w, normalize)
+    p = p0.to(dev).requires_grad_(True)
+    audio = v.render(p, normalize=normalize)
+    assert audio.requires_grad
+    (audio * w.to(dev)).sum().backward()
+    g = p.grad.cpu().double()
+    assert g.shape == (B, 78) and torch.isfinite(g).all()
+    per_voice = [rel_l2(g[b], ref[b]) for b in range(B)]
+    assert max(per_voice) <= 2e-2, per_voice
+    assert rel_l2(g, ref) <= 5e-3
+    # parameters the audio does not depend on get exactly zero, the rest the right sign
+    dead = ref.abs() == 0
+    assert (g[dead] == 0).all()
+    big = ref.abs() >= 1e-3 * ref.abs().max(dim=1, keepdim=True)[0]
+    assert (torch.sign(g[big]) == torch.sign(ref[big])).all()
+
+
+def test_gradient_is_deterministic_and_leaves_forward_untouched(lib, dev):
+    v = _voice(dev, 4, 16000, 1.0)
+    p0 = so.sample_params01(so.VoiceConfig(4, 16000, 1.0), 5).to(dev)
+    plain = v.render(p0)
+    grads = []
+    for _ in range(2):
+        p = p0.clone().requires_grad_(True)
+        a = v.render(p)
+        assert torch.equal(a.detach(), plain)
+        a.square().mean().backward()
+        grads.append(p.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    with torch.no_grad():
+        assert not v.render(p0.clone().requires_grad_(True)).requires_grad
+
+
+def test_gradient_descent_on_audio_loss_reduces_it(lib, dev):
+    """A few steps of plain gradient descent on the mixer levels and VCO amplitudes' sources of a rendered target:
+    the loss must go down (end-to-end sign / scale sanity of the whole chain)."""
+    from inverse_audio_synthesis_amd import voice_spec as S
+    cfg = so.VoiceConfig(4, 16000, 1.0)
+    v = _voice(dev, 4, 16000, 1.0)
+    target_p = so.sample_params01(cfg, 7).to(dev)
+    target = v.render(target_p, normalize=False)
+    cols = [S.INDEX[("mixer", n)] for n in ("vco_1", "vco_2", "noise")]
+    p = target_p.clone()
+    p[:, cols] = 0.5
+    losses = []
+    for _ in range(25):
+        q = p.clone().requires_grad_(True)
+        loss = (v.render(q, normalize=False) - target).square().mean()
+        loss.backward()
+        losses.append(loss.item())
+        step = torch.zeros_like(p)
+        step[:, cols] = q.grad[:, cols]
+        p = (p - 0.5 * step / step.abs().max().clamp_min(1e-12) * 0.05).clamp(0.01, 0.99)
+    assert losses[-1] < 0.5 * losses[0], losses
