@@ -129,6 +129,16 @@ int ias_stft(const float* audio, const float* tables, const int* mel_start, cons
              double* partials, int B, int T, int n_fft, int hop, int n_out, int value_mode, int loss_mode,
              float eps, void* stream);
 
+/* Backward of the L1 spectral losses (the reference's mel-L1 loop audio_to_params.py:150-153 is
+ * commented out and would have used torchaudio's differentiable modules):
+ *   g_audio [B,T] = g_loss[0] * d (scale * sum |V(audio) - target|) / d audio,  V = (mel of) |STFT|^power.
+ * window [n_fft] on the device; mel_* as for ias_stft (NULL = linear bins, n_out = n_fft/2+1); target [B,F,n_out]
+ * frames-major; power 1 or 2; g_loss a device scalar (NULL = 1); frame_grad [B,F,n_fft] fp32 scratch. */
+int ias_stft_l1_backward(const float* audio, const float* window, const int* mel_start, const int* mel_count,
+                         const int* mel_woff, const float* mel_w, const float* target, const float* g_loss,
+                         float* frame_grad, float* g_audio, int B, int T, int n_fft, int hop, int n_out, int power,
+                         float scale, void* stream);
+
 /* sums[3] (doubles) = column sums of partials [n][3], fixed order (deterministic); when mean_out is not
  * NULL also mean_out[0] = (float)(sums[0] * scale). */
 int ias_reduce_partials(const double* partials, long long n, double* sums, double scale, float* mean_out,

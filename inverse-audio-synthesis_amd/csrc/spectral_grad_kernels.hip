@@ -1,0 +1,202 @@
+// Backward of the L1 spectral losses for MI355X (gfx950): d mean|V(audio) - target| / d audio, V = (mel of) the
+// power or magnitude STFT.
+//
+// The reference never differentiates a spectral loss -- its mel-L1 training loop is the commented-out block
+// /root/reference/audio_to_params.py:150-153 over the MelSpectrogram of conf/config.yaml:51-61 (torchaudio modules,
+// differentiable torch code).  This is the adjoint of csrc/spectral_kernels.hip's forward for LOSS_L1
+// (the audio -> params -> synth -> mel-L1 loop).
+//
+//   frame   x_f[n] = w[n] * pad_reflect(a)[f*hop + n]                 X_f = DFT_N(x_f), bins 0..N/2
+//   values  P = |X|^2,  V = P (power 2) or sqrt(P) (power 1),  O = melW^T V or V
+//   loss    L = scale * sum |O - target|
+//   adjoint gO = scale * sign(O - target);  gV = melW gO or gO;  gP = gV (power) or gV / (2 sqrt P);
+//           G[k] = 2 gP[k] X[k];  g x_f[n] = Re sum_{k<=N/2} G[k] e^{+2 pi i k n / N}   (upper half zero, no Hermitian
+//           doubling: each one-sided bin enters the loss once);  g a = reflect-pad^T overlap-add (w * g x_f)
+//
+// K_a one workgroup per frame: forward FFT, the adjoint chain, inverse FFT -> frame_grad [B,F,N] (scratch).
+// K_b one lane per audio sample: gathers the frames (and reflected positions) that cover it in a fixed order --
+//     no atomics across workgroups, bit-reproducible.
+// The FFT is a plain Stockham radix-2 through LDS (natural order in and out, twiddles from an LDS table built with
+// sincospif); the backward is a first correct path, not yet tuned like the forward.
+#include "ias_common.h"
+
+#define SG_THREADS 256
+typedef float2 sg_cpx;
+
+__device__ __forceinline__ sg_cpx sg_mul(sg_cpx a, sg_cpx b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// In-place-ish Stockham FFT of N points held in `a` (scratch `b`); returns the buffer that holds the result.
+// SIGN -1: forward e^{-i..}, +1: inverse (unnormalised).  tab[j] = e^{-2 pi i j / N}, j < N/2.
+template <int SIGN>
+__device__ sg_cpx* sg_fft(sg_cpx* a, sg_cpx* b, const sg_cpx* tab, int N, int log2n, int tid) {
+  sg_cpx* x = a;
+  sg_cpx* y = b;
+  for (int st = 0; st < log2n; ++st) {
+    const int s = 1 << st;            // stride; sequence length n = N / s, m = n / 2
+    const int m = N >> (st + 1);
+    __syncthreads();
+    for (int t = tid; t < N / 2; t += SG_THREADS) {
+      const int p = t >> st, q = t & (s - 1);
+      sg_cpx w = tab[p * s];
+      if (SIGN > 0) w.y = -w.y;
+      const sg_cpx u = x[q + s * p], v = x[q + s * (p + m)];
+      y[q + s * (2 * p)] = make_float2(u.x + v.x, u.y + v.y);
+      y[q + s * (2 * p + 1)] = sg_mul(make_float2(u.x - v.x, u.y - v.y), w);
+    }
+    sg_cpx* tmp = x; x = y; y = tmp;
+  }
+  __syncthreads();
+  return x;
+}
+
+struct SgArgs {
+  const float* audio;     // [B,T]
+  const float* window;    // [N]
+  const int* mel_start;   // CSR mel filters (NULL: linear bins)
+  const int* mel_count;
+  const int* mel_woff;
+  const float* mel_w;
+  const float* target;    // [B,F,n_out]
+  float* frame_grad;      // [B,F,N]
+  int T, F, N, log2n, hop, n_out, power2;
+  float scale;
+};
+
+__global__ __launch_bounds__(SG_THREADS) void stft_grad_frames_kernel(SgArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float sg_smem[];
+  const int N = g.N, NB = N / 2 + 1, tid = threadIdx.x, f = blockIdx.x, b = blockIdx.y;
+  sg_cpx* bufa = reinterpret_cast<sg_cpx*>(sg_smem);
+  sg_cpx* bufb = bufa + N;
+  sg_cpx* tab = bufb + N;                    // N/2
+  float* sP = reinterpret_cast<float*>(tab + N / 2);   // NB (+ pad)
+  float* sGV = sP + (NB + 3);                // NB
+  float* sGO = sGV + (NB + 3);               // n_out
+
+  const int pad = N / 2;
+  const float* arow = g.audio + (size_t)b * g.T;
+  for (int j = tid; j < N / 2; j += SG_THREADS) {
+    float s, c;
+    sincospif(2.0f * (float)j / (float)N, &s, &c);
+    tab[j] = make_float2(c, -s);
+  }
+  for (int n = tid; n < N; n += SG_THREADS) {
+    int r = f * g.hop + n - pad;
+    if (r < 0) r = -r;
+    if (r >= g.T) r = 2 * (g.T - 1) - r;
+    bufa[n] = make_float2(g.window[n] * arow[r], 0.0f);
+  }
+  sg_cpx* X = sg_fft<-1>(bufa, bufb, tab, N, g.log2n, tid);
+  sg_cpx* other = (X == bufa) ? bufb : bufa;
+
+  for (int k = tid; k < NB; k += SG_THREADS) {
+    const float p = X[k].x * X[k].x + X[k].y * X[k].y;
+    sP[k] = g.power2 ? p : sqrtf(p);         // V
+    sGV[k] = 0.0f;
+  }
+  __syncthreads();
+  const float* trow = g.target + ((size_t)b * g.F + f) * g.n_out;
+  for (int o = tid; o < g.n_out; o += SG_THREADS) {
+    float v;
+    if (g.mel_start) {
+      const int s0 = g.mel_start[o], cnt = g.mel_count[o];
+      const float* w = g.mel_w + g.mel_woff[o];
+      v = 0.0f;
+      for (int c = 0; c < cnt; ++c) v = fmaf(w[c], sP[s0 + c], v);
+    } else {
+      v = sP[o];
+    }
+    const float d = v - trow[o];
+    sGO[o] = d > 0.0f ? g.scale : (d < 0.0f ? -g.scale : 0.0f);
+  }
+  __syncthreads();
+  if (g.mel_start) {
+    // a bin lies under at most two triangular filters: the (commutative) sum of two terms does not depend on the
+    // order of the LDS atomics
+    for (int o = tid; o < g.n_out; o += SG_THREADS) {
+      const int s0 = g.mel_start[o], cnt = g.mel_count[o];
+      const float* w = g.mel_w + g.mel_woff[o];
+      const float go = sGO[o];
+      for (int c = 0; c < cnt; ++c) atomicAdd(&sGV[s0 + c], w[c] * go);
+    }
+  } else {
+    for (int k = tid; k < NB; k += SG_THREADS) sGV[k] = sGO[k];
+  }
+  __syncthreads();
+  // G[k] = 2 gP[k] X[k] on the one-sided bins, zero above; written to the other buffer's place of X
+  for (int k = tid; k < N; k += SG_THREADS) {
+    sg_cpx o = make_float2(0.0f, 0.0f);
+    if (k < NB) {
+      float gp = sGV[k];
+      if (!g.power2) gp = sP[k] > 0.0f ? gp / (2.0f * sP[k]) : 0.0f;   // d sqrt(P) / dP, 0 at P = 0
+      o = make_float2(2.0f * gp * X[k].x, 2.0f * gp * X[k].y);
+    }
+    other[k] = o;
+  }
+  sg_cpx* Y = sg_fft<+1>(other, X, tab, N, g.log2n, tid);
+  float* out = g.frame_grad + ((size_t)b * g.F + f) * N;
+  for (int n = tid; n < N; n += SG_THREADS) out[n] = g.window[n] * Y[n].x;
+}
+
+// g_audio[b,j] = g_loss * sum over the padded positions q that read audio[j] (itself and its reflections) of the
+// frames covering q.
+__global__ __launch_bounds__(SG_THREADS) void stft_grad_ola_kernel(const float* __restrict__ frame_grad,
+                                                                   const float* __restrict__ g_loss,
+                                                                   float* __restrict__ g_audio, int T, int F, int N,
+                                                                   int hop) {
+  const int j = blockIdx.x * SG_THREADS + threadIdx.x, b = blockIdx.y;
+  if (j >= T) return;
+  const int pad = N / 2;
+  const float* fg = frame_grad + (size_t)b * F * N;
+  int qs[3];
+  int nq = 0;
+  qs[nq++] = j + pad;
+  if (j >= 1 && j <= pad) qs[nq++] = pad - j;
+  if (j <= T - 2 && j >= T - 1 - pad) qs[nq++] = pad + 2 * (T - 1) - j;
+  float acc = 0.0f;
+  for (int i = 0; i < nq; ++i) {
+    const int q = qs[i];
+    int f_hi = q / hop;
+    if (f_hi > F - 1) f_hi = F - 1;
+    int f_lo = q - N + 1 <= 0 ? 0 : (q - N + 1 + hop - 1) / hop;
+    for (int f = f_lo; f <= f_hi; ++f) acc += fg[(size_t)f * N + (q - f * hop)];
+  }
+  g_audio[(size_t)b * T + j] = g_loss ? acc * g_loss[0] : acc;
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+// d (scale * sum |V(audio) - target|) / d audio, times the device scalar g_loss[0] (NULL = 1).
+//   audio [B,T]; window [n_fft] (device); mel_* : the forward's CSR filterbank (NULL = linear bins, n_out = n_fft/2+1);
+//   target [B,F,n_out] frames-major (what ias_stft wrote for the target); power: 1 (magnitude) or 2 (power);
+//   frame_grad [B,F,n_fft] fp32 scratch; g_audio [B,T] out.  F = ias_stft_num_frames(T, n_fft, hop).
+extern "C" int ias_stft_l1_backward(const float* audio, const float* window, const int* mel_start,
+                                    const int* mel_count, const int* mel_woff, const float* mel_w,
+                                    const float* target, const float* g_loss, float* frame_grad, float* g_audio,
+                                    int B, int T, int n_fft, int hop, int n_out, int power, float scale,
+                                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!audio || !window || !target || !frame_grad || !g_audio || B <= 0 || B > 65535 || hop <= 0) return IAS_ERR_ARG;
+  if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return IAS_ERR_UNSUPPORTED;
+  if (power != 1 && power != 2) return IAS_ERR_UNSUPPORTED;
+  if (T <= n_fft / 2) return IAS_ERR_ARG;
+  const bool mel = mel_start != nullptr;
+  if (mel && (!mel_count || !mel_woff || !mel_w)) return IAS_ERR_ARG;
+  if (!mel && n_out != n_fft / 2 + 1) return IAS_ERR_ARG;
+  if (n_out <= 0 || n_out > n_fft / 2 + 1) return IAS_ERR_ARG;
+  const int F = 1 + T / hop;
+  if (F > 2147483647 / n_fft) return IAS_ERR_UNSUPPORTED;
+  SgArgs g;
+  g.audio = audio; g.window = window; g.mel_start = mel_start; g.mel_count = mel_count; g.mel_woff = mel_woff;
+  g.mel_w = mel_w; g.target = target; g.frame_grad = frame_grad;
+  g.T = T; g.F = F; g.N = n_fft; g.log2n = n_fft == 512 ? 9 : (n_fft == 1024 ? 10 : 11); g.hop = hop;
+  g.n_out = n_out; g.power2 = power == 2; g.scale = scale;
+  const int NB = n_fft / 2 + 1;
+  const size_t lds = sizeof(sg_cpx) * (2 * (size_t)n_fft + n_fft / 2) + sizeof(float) * (2 * (size_t)(NB + 3) + n_out);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)stft_grad_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(stft_grad_frames_kernel, dim3(F, B), dim3(SG_THREADS), lds, stream, g);
+  hipLaunchKernelGGL(stft_grad_ola_kernel, dim3((T + SG_THREADS - 1) / SG_THREADS, B), dim3(SG_THREADS), 0, stream,
+                     frame_grad, g_loss, g_audio, T, F, n_fft, hop);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}

@@ -3,7 +3,10 @@
 ``VicregAudioParams``  /root/reference/vicreg_audio_params.py:33-165  (voice -> audio/param backbones ->
                        shared projector -> VICReg loss; metric names vicreg/{name}/{loss,repr_loss,std_loss,cov_loss})
 ``AudioToParams``      /root/reference/audio_to_params.py:177-312     (frozen VICReg -> MLP -> params;
-                       loss = MSE of projected param embeddings; test step re-renders predicted params)
+                       loss = MSE of projected param embeddings; test step re-renders predicted params).
+                       ``audio_to_params.loss: mel_l1`` switches to the objective of the commented-out
+                       ``train_audio_to_params_through_torchsynth`` (audio_to_params.py:56-172): predicted params ->
+                       Voice render -> mel-L1 against the true audio, differentiated through the HIP synth.
 Both keep the reference's attribute names (gram, vision_model, img_preprocess, paramembed, audio_repr,
 vicreg, synthconfig, voice / audio_repr_to_params) so state_dict keys line up.  ``_step`` returns the
 loss and fills ``self.logged`` with the metrics the reference passes to ``self.log``.
@@ -18,6 +21,7 @@ from .paramembed import AudioRepresentationToParams, ParamEmbed
 from .pqmf import PQMF
 from .vicreg import VICReg
 from .vision import mobilenet_v3_small
+from .spectral import MelSpectrogramL1
 from .voice import SynthConfig, Voice
 
 
@@ -92,6 +96,13 @@ class AudioToParams(nn.Module):
         self.voice = Voice(synthconfig=SynthConfig(batch_size=a.batch_size, reproducible=cfg.torchsynth.reproducible,
                                                    sample_rate=cfg.torchsynth.rate,
                                                    buffer_size_seconds=cfg.torchsynth.buffer_size_seconds))
+        self.loss_kind = a.get("loss", "embedding_mse")
+        assert self.loss_kind in ("embedding_mse", "mel_l1"), self.loss_kind
+        if self.loss_kind == "mel_l1":
+            m = cfg.mel
+            self.mel_l1 = MelSpectrogramL1(sample_rate=cfg.torchsynth.rate, n_fft=m.n_fft, win_length=m.win_length,
+                                           hop_length=m.hop_length, center=m.center, pad_mode=m.pad_mode, power=m.power,
+                                           norm=m.norm, onesided=m.onesided, n_mels=m.n_mels, mel_scale=m.mel_scale)
         self.logged = {}
         self.last_predicted_audio = None
 
@@ -120,6 +131,12 @@ class AudioToParams(nn.Module):
         frozen_vicreg_loss = F.mse_loss(true_params_embedding, true_audio_embedding)
         self.logged = {f"audio_to_params/{name}/loss": repr_loss.detach(),
                        f"audio_to_params/{name}/frozen_vicreg_loss": frozen_vicreg_loss.detach()}
+        loss = repr_loss
+        if self.loss_kind == "mel_l1":
+            # audio =(vicreg)=> repr =(MLP)=> params =(synth)=> audio, true vs predicted mel (audio_to_params.py:66-70,150-153)
+            predicted_audio = self.voice.render(predicted_params)
+            loss = self.mel_l1(predicted_audio, target_audio=audio.squeeze(1))
+            self.logged[f"audio_to_params/{name}/mel_l1_error"] = loss.detach()
         if name == "test":
             # set -> freeze -> voice(None) -> unfreeze, exactly the sequence of audio_to_params.py:240-257
             for (mod, pname), value in zip(self.voice.get_parameters().keys(), predicted_params.T):
@@ -129,7 +146,7 @@ class AudioToParams(nn.Module):
                 predicted_audio, _pp, _it = self.voice(None)
                 self.voice.unfreeze_all_parameters()
             self.last_predicted_audio = (audio.detach(), predicted_audio.detach())
-        return repr_loss
+        return loss
 
     def training_step(self, batch, batch_idx=None):
         return self._step(batch, batch_idx, "train")

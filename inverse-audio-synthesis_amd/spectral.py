@@ -8,7 +8,9 @@ The reference has no live spectral-loss code.  This module implements the spec i
   * ``STFTL1`` (BASELINE config #1 "STFT L1 loss") and ``MultiResolutionSTFTLoss`` (the auraloss
     TODO at audio_to_params.py:233; auraloss defaults).
 Filterbank / window / twiddle tables are built once on the host; every per-sample operation runs
-in the HIP kernel.  Forward only (the reference never differentiates this path).
+in the HIP kernel.  The L1 losses (``MelSpectrogramL1``, ``STFTL1``) are differentiable with respect to the audio
+(``csrc/spectral_grad_kernels.hip``): with ``Voice.render`` that closes the audio -> params -> synth -> mel-L1 loop
+the reference left commented out (audio_to_params.py:56-172).  ``MultiResolutionSTFTLoss`` is forward only.
 """
 import ctypes
 import math
@@ -137,6 +139,44 @@ class STFTPlan(nn.Module):
         return sums if mean is None else mean
 
 
+class _L1LossFn(torch.autograd.Function):
+    """mean |V(audio) - target| with the fused HIP forward and the HIP adjoint w.r.t. the audio."""
+
+    @staticmethod
+    def forward(ctx, audio, plan, target_values, value_mode):
+        a = plan._audio2d(audio)
+        ctx.plan, ctx.value_mode, ctx.shape = plan, value_mode, audio.shape
+        ctx.save_for_backward(a, target_values)
+        return plan.loss_sums(a, target_values, value_mode, LOSS_L1, mean_scale=1.0 / target_values.numel())
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        a, target = ctx.saved_tensors
+        plan = ctx.plan
+        lib = _lib.load()
+        B, T = a.shape
+        F = plan.num_frames(T)
+        mel = plan.n_mels is not None
+        frame_grad = torch.empty((B, F, plan.n_fft), dtype=torch.float32, device=a.device)
+        g_audio = torch.empty_like(a)
+        gl = g_loss.to(torch.float32).reshape(1).contiguous()
+        st = lib.ias_stft_l1_backward(
+            _lib.ptr(a), _lib.ptr(plan.window), _lib.ptr(plan.mel_start) if mel else None,
+            _lib.ptr(plan.mel_count) if mel else None, _lib.ptr(plan.mel_woff) if mel else None,
+            _lib.ptr(plan.mel_w) if mel else None, _lib.ptr(target), _lib.ptr(gl), _lib.ptr(frame_grad),
+            _lib.ptr(g_audio), B, T, plan.n_fft, plan.hop_length, plan.n_out,
+            2 if ctx.value_mode == VALUE_POWER else 1, 1.0 / target.numel(), _lib.stream())
+        _lib.check(st, "ias_stft_l1_backward")
+        return g_audio.reshape(ctx.shape), None, None, None
+
+
+def _l1_loss(plan, audio, target_values, value_mode):
+    if torch.is_grad_enabled() and audio.requires_grad:
+        assert value_mode in (VALUE_POWER, VALUE_MAG)
+        return _L1LossFn.apply(audio, plan, target_values, value_mode)
+    return plan.loss_sums(audio, target_values, value_mode, LOSS_L1, mean_scale=1.0 / target_values.numel())
+
+
 class MelSpectrogram(nn.Module):
     """conf/config.yaml:51-61 block -> [B, n_mels, frames] (torchaudio layout; a transposed view of
     the kernel's frames-major output)."""
@@ -175,8 +215,7 @@ class MelSpectrogramL1(nn.Module):
     def forward(self, audio, target_audio=None, target_mel=None):
         if target_mel is None:
             target_mel = self.target(target_audio)
-        return self.mel.plan.loss_sums(audio, target_mel, self.mel.value_mode, LOSS_L1,
-                                       mean_scale=1.0 / target_mel.numel())
+        return _l1_loss(self.mel.plan, audio, target_mel.detach(), self.mel.value_mode)
 
 
 class STFTL1(nn.Module):
@@ -189,8 +228,8 @@ class STFTL1(nn.Module):
         self.plan = STFTPlan(n_fft, win_length, hop_length)
 
     def forward(self, audio, target_audio):
-        tgt = self.plan.values(target_audio, self.value_mode)
-        return self.plan.loss_sums(audio, tgt, self.value_mode, LOSS_L1, mean_scale=1.0 / tgt.numel())
+        tgt = self.plan.values(target_audio.detach(), self.value_mode)
+        return _l1_loss(self.plan, audio, tgt, self.value_mode)
 
 
 class MultiResolutionSTFTLoss(nn.Module):

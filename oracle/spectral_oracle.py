@@ -40,7 +40,7 @@ def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm="slaney"):
 def spectrogram(x, n_fft=1024, win_length=None, hop_length=512, power=2.0, center=True, pad_mode="reflect"):
     """torchaudio Spectrogram (hann window, normalized=False, onesided) -> [B, n_fft/2+1, frames]."""
     win_length = n_fft if win_length is None else win_length
-    window = torch.hann_window(win_length)
+    window = torch.hann_window(win_length).to(x.dtype)   # fp64 input: the gradient reference of the tests
     spec = torch.stft(x, n_fft, hop_length, win_length, window, center=center, pad_mode=pad_mode,
                       normalized=False, onesided=True, return_complex=True)
     mag = spec.abs()
@@ -53,7 +53,7 @@ def mel_spectrogram(x, sample_rate=44100, n_fft=1024, win_length=None, hop_lengt
     spec = spectrogram(x, n_fft, win_length, hop_length, power)
     f_max = float(sample_rate // 2) if f_max is None else f_max
     fb = melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate, norm)
-    return torch.matmul(spec.transpose(-1, -2), fb).transpose(-1, -2)
+    return torch.matmul(spec.transpose(-1, -2), fb.to(spec.dtype)).transpose(-1, -2)
 
 
 def mel_l1(audio, target_audio, **kw):
