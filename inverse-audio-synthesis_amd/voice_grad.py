@@ -27,6 +27,7 @@ SCALARS = ("f0_1", "depth_1", "phi_1", "f0_2", "depth_2", "phi_2", "kpart", "sha
 _ADSRS = ("adsr_1", "adsr_2", "lfo_1_amp_adsr", "lfo_2_amp_adsr", "lfo_1_rate_adsr", "lfo_2_rate_adsr")
 _LFOS = ("lfo_1", "lfo_2")
 _TABLE = {}
+_INDEX = {}
 
 
 def _table(device, dtype):
@@ -61,7 +62,11 @@ class _Params:
         return self.v[:, S.INDEX[(mod, name)]]
 
     def many(self, mods, name):
-        return self.v[:, [S.INDEX[(m, name)] for m in mods]]
+        key = (str(self.v.device), mods, name)
+        idx = _INDEX.get(key)
+        if idx is None:   # device index tensors are built once (a host->device copy is not capturable)
+            idx = _INDEX[key] = torch.tensor([S.INDEX[(m, name)] for m in mods], dtype=torch.long, device=self.v.device)
+        return self.v.index_select(1, idx)
 
 
 def _ramp(cfg, duration, alpha, start=None, inverse=False):
@@ -125,7 +130,8 @@ def control_graph(params01, cfg):
     p = _Params(params01)
     env = _adsrs(cfg, p, _ADSRS, p("keyboard", "duration"))                  # [B,6,Tc]
     lfo = _lfos(cfg, p, _LFOS, env[:, 4:6]) * env[:, 2:4]
-    w = torch.stack([p("mod_matrix", f"{i}->{o}") for i in S.MOD_INPUTS for o in S.MOD_OUTPUTS], dim=1)
+    i0 = S.INDEX[("mod_matrix", f"{S.MOD_INPUTS[0]}->{S.MOD_OUTPUTS[0]}")]     # the 20 weights are consecutive columns
+    w = p.v[:, i0:i0 + len(S.MOD_INPUTS) * len(S.MOD_OUTPUTS)]
     w = w.reshape(-1, len(S.MOD_INPUTS), len(S.MOD_OUTPUTS)).swapaxes(1, 2)
     ctrl = torch.matmul(w, torch.cat([env[:, 0:2], lfo], dim=1))
 
@@ -163,6 +169,62 @@ def audio_rate_backward(voice, params01, g_mixed):
     return g_ctrl, partials.sum(dim=1)
 
 
+def _control_backward_eager(cfg, p, g_ctrl, g_scal):
+    with torch.enable_grad():
+        pd = p.double().requires_grad_(True)
+        ctrl_t, scal_t = control_graph(pd, cfg)
+        (g_p,) = torch.autograd.grad([ctrl_t, scal_t], pd, [g_ctrl.double(), g_scal])
+    return g_p
+
+
+class _ControlBackwardGraph:
+    """The control graph's forward + backward is a few hundred tiny device kernels with static shapes: captured
+    once per (batch, control length, device) into a hipGraph and replayed on static buffers (host launch time
+    4.5 ms -> one graph launch)."""
+
+    def __init__(self, cfg, B, device):
+        Tc = cfg.control_buffer_size
+        self.p = torch.full((B, S.NPARAMS), 0.5, dtype=torch.float32, device=device)
+        self.g_ctrl = torch.zeros((B, 5, Tc), dtype=torch.float32, device=device)
+        self.g_scal = torch.zeros((B, len(SCALARS)), dtype=torch.float64, device=device)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):                      # warm-up outside the capture (allocator, lazy inits)
+                _control_backward_eager(cfg, self.p, self.g_ctrl, self.g_scal)
+        torch.cuda.current_stream(device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = _control_backward_eager(cfg, self.p, self.g_ctrl, self.g_scal)
+
+    def __call__(self, p, g_ctrl, g_scal):
+        self.p.copy_(p)
+        self.g_ctrl.copy_(g_ctrl)
+        self.g_scal.copy_(g_scal)
+        self.graph.replay()
+        return self.out.clone()
+
+
+_GRAPHS = {}
+
+
+def _control_backward(cfg, p, g_ctrl, g_scal):
+    """d loss / d params01 [B,78] (fp64) from the gradients of the control signals and per-voice constants."""
+    if torch.cuda.is_current_stream_capturing():
+        return _control_backward_eager(cfg, p, g_ctrl, g_scal)
+    key = (p.shape[0], cfg.control_buffer_size, cfg.control_rate, str(p.device))
+    runner = _GRAPHS.get(key)
+    if runner is None:
+        try:
+            runner = _ControlBackwardGraph(cfg, p.shape[0], p.device)
+        except RuntimeError:                          # capture not possible here: plain launches
+            runner = False
+        _GRAPHS[key] = runner
+    if runner is False:
+        return _control_backward_eager(cfg, p, g_ctrl, g_scal)
+    return runner(p, g_ctrl, g_scal)
+
+
 class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, params01, voice, normalize):
@@ -191,10 +253,7 @@ class _RenderFn(torch.autograd.Function):
         else:
             g_mixed = g
         g_ctrl, g_scal = audio_rate_backward(voice, p, g_mixed)
-        with torch.enable_grad():
-            pd = p.double().requires_grad_(True)
-            ctrl_t, scal_t = control_graph(pd, voice.synthconfig)
-            (g_p,) = torch.autograd.grad([ctrl_t, scal_t], pd, [g_ctrl.double(), g_scal])
+        g_p = _control_backward(voice.synthconfig, p, g_ctrl, g_scal)
         return g_p.to(torch.float32), None, None
 
 
