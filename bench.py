@@ -34,12 +34,13 @@ RENDER_BYTES_PER_SAMPLE = 8
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish a step's PQMF / spectral loss before the next step's render starts")
+    ap.add_argument("--buffers", type=int, default=2, help="audio buffers / workspaces in flight (pipeline depth)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8, help="voices in the CPU baseline sample")
     return ap.parse_args()
@@ -131,20 +132,21 @@ def main():
     # bound) starts while this step's PQMF / STFT (LDS / latency bound) are still running.  All K steps and
     # their cross-stream dependencies are captured once into one hipGraph and replayed.
     side_a, side_b, side_c = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
-    audio_bufs = [torch.empty((B, T), dtype=torch.float32, device=dev) for _ in range(2)]
-    workspaces = [voice.new_workspace(dev) for _ in range(2)]
+    nbuf = max(2, args.buffers)
+    audio_bufs = [torch.empty((B, T), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    workspaces = [voice.new_workspace(dev) for _ in range(nbuf)]
     last = {}
 
     def run_steps(k, pipelined=True):
         main = torch.cuda.current_stream()
-        consumed = [None, None]
-        ws_free = [None, None]      # audio pass that last read workspace[buf] has finished
+        consumed = [None] * nbuf
+        ws_free = [None] * nbuf     # audio pass that last read workspace[buf] has finished
         side_c.wait_stream(main)
 
         def issue_control(i):
             # the small control-rate kernels of step i go to their own stream with a private workspace,
             # so they run beside the previous step's audio-rate kernel instead of ahead of it
-            buf = i & 1
+            buf = i % nbuf
             with torch.cuda.stream(side_c):
                 if ws_free[buf] is not None:
                     side_c.wait_event(ws_free[buf])
@@ -153,8 +155,8 @@ def main():
 
         ctrl_done = issue_control(0)
         for i in range(k):
-            buf = i & 1
-            if consumed[buf] is not None:          # buffer free again: both readers of step i-2 are done
+            buf = i % nbuf
+            if consumed[buf] is not None:          # buffer free again: both readers of step i-nbuf are done
                 for e in consumed[buf]:
                     main.wait_event(e)
             main.wait_event(ctrl_done)
