@@ -16,7 +16,7 @@
 // K_a one workgroup per frame: forward FFT, the adjoint chain, inverse FFT -> frame_grad [B,F,N] (scratch).
 // K_b one lane per audio sample: gathers the frames (and reflected positions) that cover it in a fixed order --
 //     no atomics across workgroups, bit-reproducible.
-// The FFT is a plain Stockham radix-2 through LDS (natural order in and out, twiddles from an LDS table built with
+// The FFT is a plain Stockham radix-4 through LDS (natural order in and out, twiddles from an LDS table built with
 // sincospif); the backward is a first correct path, not yet tuned like the forward.
 #include "ias_common.h"
 
@@ -27,23 +27,41 @@ __device__ __forceinline__ sg_cpx sg_mul(sg_cpx a, sg_cpx b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-// In-place-ish Stockham FFT of N points held in `a` (scratch `b`); returns the buffer that holds the result.
+// Stockham autosort FFT of N points held in `a` (scratch `b`), natural order in and out; returns the buffer that
+// holds the result.  Radix-4 stages while the remaining length allows, one radix-2 stage when log2(N) is odd.
 // SIGN -1: forward e^{-i..}, +1: inverse (unnormalised).  tab[j] = e^{-2 pi i j / N}, j < N/2.
 template <int SIGN>
 __device__ sg_cpx* sg_fft(sg_cpx* a, sg_cpx* b, const sg_cpx* tab, int N, int log2n, int tid) {
   sg_cpx* x = a;
   sg_cpx* y = b;
-  for (int st = 0; st < log2n; ++st) {
-    const int s = 1 << st;            // stride; sequence length n = N / s, m = n / 2
-    const int m = N >> (st + 1);
+  int st = 0;                          // log2 of the stride s; sequence length n = N >> st
+  for (; st + 2 <= log2n; st += 2) {
+    const int s = 1 << st, m = N >> (st + 2);
+    __syncthreads();
+    for (int t = tid; t < N / 4; t += SG_THREADS) {
+      const int p = t >> st, q = t & (s - 1);
+      sg_cpx w1 = tab[p * s], w2 = tab[2 * p * s];
+      if (SIGN > 0) { w1.y = -w1.y; w2.y = -w2.y; }
+      const sg_cpx w3 = sg_mul(w1, w2);
+      const sg_cpx c0 = x[q + s * p], c1 = x[q + s * (p + m)], c2 = x[q + s * (p + 2 * m)], c3 = x[q + s * (p + 3 * m)];
+      const sg_cpx apc = make_float2(c0.x + c2.x, c0.y + c2.y), amc = make_float2(c0.x - c2.x, c0.y - c2.y);
+      const sg_cpx bpd = make_float2(c1.x + c3.x, c1.y + c3.y), bmd = make_float2(c1.x - c3.x, c1.y - c3.y);
+      // forward: -i (b - d) = (bmd.y, -bmd.x); inverse: +i (b - d) = (-bmd.y, bmd.x)
+      const sg_cpx jb = SIGN < 0 ? make_float2(bmd.y, -bmd.x) : make_float2(-bmd.y, bmd.x);
+      y[q + s * (4 * p)] = make_float2(apc.x + bpd.x, apc.y + bpd.y);
+      y[q + s * (4 * p + 1)] = sg_mul(make_float2(amc.x + jb.x, amc.y + jb.y), w1);
+      y[q + s * (4 * p + 2)] = sg_mul(make_float2(apc.x - bpd.x, apc.y - bpd.y), w2);
+      y[q + s * (4 * p + 3)] = sg_mul(make_float2(amc.x - jb.x, amc.y - jb.y), w3);
+    }
+    sg_cpx* tmp = x; x = y; y = tmp;
+  }
+  if (st < log2n) {                    // last stage, n = 2: no twiddles
+    const int s = 1 << st;
     __syncthreads();
     for (int t = tid; t < N / 2; t += SG_THREADS) {
-      const int p = t >> st, q = t & (s - 1);
-      sg_cpx w = tab[p * s];
-      if (SIGN > 0) w.y = -w.y;
-      const sg_cpx u = x[q + s * p], v = x[q + s * (p + m)];
-      y[q + s * (2 * p)] = make_float2(u.x + v.x, u.y + v.y);
-      y[q + s * (2 * p + 1)] = sg_mul(make_float2(u.x - v.x, u.y - v.y), w);
+      const sg_cpx u = x[t], v = x[t + s];
+      y[t] = make_float2(u.x + v.x, u.y + v.y);
+      y[t + s] = make_float2(u.x - v.x, u.y - v.y);
     }
     sg_cpx* tmp = x; x = y; y = tmp;
   }

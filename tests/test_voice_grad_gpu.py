@@ -106,3 +106,18 @@ def test_gradient_descent_on_audio_loss_reduces_it(lib, dev):
         step[:, cols] = q.grad[:, cols]
         p = (p - 0.5 * step / step.abs().max().clamp_min(1e-12) * 0.05).clamp(0.01, 0.99)
     assert losses[-1] < 0.5 * losses[0], losses
+
+
+def test_full_batch_gradient_rows_match_small_batch(lib, dev):
+    """Headline size (B=128, 4 s @ 44.1 kHz): finite gradients, and voices are independent -- the first 8 rows equal
+    the gradient of a batch of those 8 voices alone (same kernels, different grid), bit for bit."""
+    B, T = 128, 176400
+    v, v8 = _voice(dev, B, 44100, 4.0), _voice(dev, 8, 44100, 4.0)
+    p0 = torch.rand(B, 78, generator=torch.Generator().manual_seed(1000)).to(dev)
+    w = torch.randn((B, T), generator=torch.Generator().manual_seed(5)).to(dev)
+    p = p0.clone().requires_grad_(True)
+    (v.render(p) * w).sum().backward()
+    assert torch.isfinite(p.grad).all()
+    q = p0[:8].clone().requires_grad_(True)
+    (v8.render(q) * w[:8]).sum().backward()
+    assert torch.equal(p.grad[:8], q.grad)
