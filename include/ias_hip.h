@@ -84,15 +84,16 @@ int ias_voice_backward(const float* ctrl, const void* vconst, const float* noise
                        float* planes, double* tile_sums, double* partials, float* g_ctrl, int B, int T, int Tc,
                        int sample_rate, void* stream);
 
-/* Transposed, zero-padded tap table of the fast path: ias_pqmf_packed_taps_len(N, K) floats (0 = no fast path
- * for this N, K); ias_pqmf_pack_taps fills packed (device, 8-byte aligned) from H [N,K] (device); re-run when H
+/* Transposed, zero-padded tap table: ias_pqmf_packed_taps_len(N, K) floats -- the fast kernel's layout for N = 3, 4
+ * with K = 63, the wide kernel's [K][8|16|32|64] layout for other N <= 64 with K <= 255, 0 otherwise (generic
+ * kernel only); ias_pqmf_pack_taps fills packed (device, 8-byte aligned) from H [N,K] (device); re-run when H
  * changes. */
 int ias_pqmf_packed_taps_len(int N, int K);
 int ias_pqmf_pack_taps(const float* H, float* packed, int N, int K, void* stream);
 
 /* analysis: x [B,T] (= [B,1,T]), H [N,K] (= buffer H[N,1,K]) -> z [B,N,L]   (pqmf.py:49-50).
  * packed: the ias_pqmf_pack_taps table of H, or NULL (generic one-lane-per-output kernel, same sums in the same
- * order, several times slower).
+ * order, 10-100x slower).
  * mean/stdv [N] (both or neither, may be NULL): fused (z - mean[k]) / stdv[k] of
  * AudioEmbedding._preprocess (reference audioembed.py:41,49). */
 int ias_pqmf_analysis(const float* x, const float* H, const float* packed, float* z, const float* mean,

@@ -236,6 +236,76 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_fast_kernel(
   }
 }
 
+// Wide analysis (any N <= 64, any odd K <= 255): a small GEMM z[k][f] = sum_j H[k][j] * x[N*f + j - pad].
+// The workgroup stages its input span in LDS de-interleaved by N (row = sample index mod N, one frame per column,
+// odd row stride: staging writes and compute reads are conflict-free for every N, including N = 64 where frames are
+// 64 samples apart).  A lane owns one frame and HB = NPAD/2 bands (the two halves of the workgroup's waves take
+// the two halves of the bands): per tap one ds_read_b32 feeds HB FMAs whose taps are SGPR operands, loaded from the
+// zero-padded transposed table Pt[j][NPAD] through the scalar cache.
+#define PQW_FRAMES 128
+template <int NPAD>
+__global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_wide_kernel(
+    const float* __restrict__ x, const float* __restrict__ Pt, float* __restrict__ z,
+    const float* __restrict__ mean, const float* __restrict__ stdv, int T, int L, int N, int K, int pad,
+    int rs /* LDS row stride (odd) */) {
+  constexpr int HB = NPAD / 2;
+  extern __shared__ __attribute__((aligned(16))) float s_rows[];   // [N][rs]
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int f0 = blockIdx.x * PQW_FRAMES;
+  const float* xr = x + (size_t)b * T;
+  const long long g0 = (long long)f0 * N - pad;              // sample index of tile element 0
+  const int span = N * (PQW_FRAMES - 1) + K;                // tile elements the frames touch
+  const bool pow2 = (N & (N - 1)) == 0;
+  const int sh = 31 - __builtin_clz(N);
+  for (int i = tid; i < span; i += PQ_THREADS) {
+    const long long g = g0 + i;
+    const float v = (g >= 0 && g < T) ? xr[g] : 0.0f;
+    const int col = pow2 ? (i >> sh) : (i / N);
+    const int row = i - col * N;
+    s_rows[row * rs + col] = v;
+  }
+  __syncthreads();
+
+  const int fl = tid & (PQW_FRAMES - 1);                    // frame within the tile
+  const int half = __builtin_amdgcn_readfirstlane(tid >> 7);     // wave-uniform band half
+  const float* taps = Pt + half * HB;
+  float acc[HB];
+#pragma unroll
+  for (int k = 0; k < HB; ++k) acc[k] = 0.0f;
+  int row = 0, colq = 0;                                    // tap j sits in row j mod N, column fl + j div N
+  for (int j = 0; j < K; ++j) {
+    const float xv = s_rows[row * rs + colq + fl];
+    const float* tj = taps + (size_t)j * NPAD;
+#pragma unroll
+    for (int k = 0; k < HB; ++k) acc[k] = fmaf(xv, tj[k], acc[k]);
+    if (++row == N) { row = 0; ++colq; }
+  }
+  const int f = f0 + fl;
+  if (f >= L) return;
+#pragma unroll
+  for (int k = 0; k < HB; ++k) {
+    const int band = half * HB + k;
+    if (band < N) {
+      float o = acc[k];
+      if (mean != nullptr) o = (o - mean[band]) / stdv[band];
+      z[((size_t)b * N + band) * L + f] = o;
+    }
+  }
+}
+
+// Pt[j*NPAD + k] = H[k][j] for k < N, zero for the padded bands
+__global__ void pqmf_pack_wide_kernel(const float* __restrict__ H, float* __restrict__ Pt, int N, int K, int npad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * npad) return;
+  const int j = i / npad, k = i - j * npad;
+  Pt[i] = k < N ? H[k * K + j] : 0.0f;
+}
+
+static int pqmf_wide_npad(int N, int K) {
+  if (N < 1 || N > 64 || K < 1 || K > 255) return 0;
+  return N <= 8 ? 8 : (N <= 16 ? 16 : (N <= 32 ? 32 : 64));
+}
+
 // Generic analysis (any N, K): one lane per output element.
 __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_generic_kernel(
     const float* __restrict__ x, const float* __restrict__ H, float* __restrict__ z,
@@ -308,15 +378,19 @@ static int pqmf_resident_blocks() {
 extern "C" int ias_pqmf_packed_taps_len(int N, int K) {
   if (N == 3 && K == 63) return PqmfFast<3, 63>::TABLE;
   if (N == 4 && K == 63) return PqmfFast<4, 63>::TABLE;
-  return 0;
+  return K * pqmf_wide_npad(N, K);   // wide kernel: [K][NPAD]; 0 when only the generic kernel applies
 }
 
 // packed [ias_pqmf_packed_taps_len] (device, 8-byte aligned) <- H [N,K] (device).  Re-run whenever H changes.
 extern "C" int ias_pqmf_pack_taps(const float* H, float* packed, int N, int K, void* stream_) {
   const int len = ias_pqmf_packed_taps_len(N, K);
   if (!H || !packed || len == 0 || ((uintptr_t)packed & 7)) return IAS_ERR_ARG;
-  hipLaunchKernelGGL(pqmf_pack_taps_kernel, dim3((len + 255) / 256), dim3(256), 0, (hipStream_t)stream_, H,
-                     packed, N, K, len);
+  if ((N == 3 || N == 4) && K == 63)
+    hipLaunchKernelGGL(pqmf_pack_taps_kernel, dim3((len + 255) / 256), dim3(256), 0, (hipStream_t)stream_, H,
+                       packed, N, K, len);
+  else
+    hipLaunchKernelGGL(pqmf_pack_wide_kernel, dim3((len + 255) / 256), dim3(256), 0, (hipStream_t)stream_, H,
+                       packed, N, K, pqmf_wide_npad(N, K));
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
@@ -329,7 +403,8 @@ extern "C" int ias_pqmf_out_len(int T, int N, int K) {
 // x [B,T] (the reference's [B,1,T]), H [N,K] (module buffer H[N,1,K]), z [B,N,L].
 // mean/stdv: optional device pointers [N] (both or neither) for the fused
 // AudioEmbedding._preprocess normalisation.
-// packed: ias_pqmf_pack_taps table of H; NULL (or an (N, K) without a fast path) runs the generic kernel.
+// packed: ias_pqmf_pack_taps table of H (fast kernel for N = 3, 4 with K = 63; wide kernel for other N <= 64);
+// NULL, or an (N, K) for which ias_pqmf_packed_taps_len is 0, runs the generic one-lane-per-output kernel.
 extern "C" int ias_pqmf_analysis(const float* x, const float* H, const float* packed, float* z, const float* mean,
                                  const float* stdv, int B, int T, int N, int K, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -351,6 +426,21 @@ extern "C" int ias_pqmf_analysis(const float* x, const float* H, const float* pa
     else
       hipLaunchKernelGGL((pqmf_analysis_fast_kernel<4, 63>), dim3(grid), dim3(PQ_THREADS), 0, stream, x, packed, z,
                          mean, stdv, T, L, pad, tiles_x, (int)ntiles);
+  } else if (packed && !((N == 3 || N == 4) && K == 63) /* those tables have the fast kernel's layout */ &&
+             pqmf_wide_npad(N, K) && (long long)L * N + 2 * K < 0x7fffffffLL) {
+    const int npad = pqmf_wide_npad(N, K);
+    int rs = PQW_FRAMES + (K + N - 1) / N + 1;
+    rs |= 1;
+    const size_t lds = sizeof(float) * (size_t)N * rs;
+    const dim3 grid((L + PQW_FRAMES - 1) / PQW_FRAMES, B), block(PQ_THREADS);
+#define IAS_PQW_LAUNCH(NP)                                                                                      \
+    hipLaunchKernelGGL((pqmf_analysis_wide_kernel<NP>), grid, block, lds, stream, x, packed, z, mean, stdv, T, L, N, \
+                       K, pad, rs)
+    if (npad == 8) IAS_PQW_LAUNCH(8);
+    else if (npad == 16) IAS_PQW_LAUNCH(16);
+    else if (npad == 32) IAS_PQW_LAUNCH(32);
+    else IAS_PQW_LAUNCH(64);
+#undef IAS_PQW_LAUNCH
   } else {
     hipLaunchKernelGGL(pqmf_analysis_generic_kernel, dim3((L + PQ_THREADS - 1) / PQ_THREADS, N, B),
                        dim3(PQ_THREADS), 0, stream, x, H, z, mean, stdv, T, L, N, K, pad);

@@ -40,7 +40,11 @@ def test_analysis_golden_full_length(lib, dev, golden_dir):
         np.testing.assert_allclose(checks(z), g[f"full_{tag}_checks"], rtol=1e-5)
 
 
-@pytest.mark.parametrize("N,taps,T", [(3, 62, 176400), (4, 62, 4099), (8, 30, 5000), (64, 62, 20000), (2, 62, 77)])
+# N = 3, 4 with 62 taps: fast kernel; other N <= 64 with K <= 255: wide kernel (pow2 and non-pow2 N, K > N and
+# K < N, ragged T); N > 64 or K > 255: generic kernel
+@pytest.mark.parametrize("N,taps,T", [(3, 62, 176400), (4, 62, 4099), (8, 30, 5000), (64, 62, 20000), (2, 62, 77),
+                                      (5, 62, 12345), (33, 20, 9999), (64, 254, 30000), (16, 62, 1),
+                                      (96, 62, 20000), (4, 300, 5000)])
 def test_analysis_vs_oracle(lib, dev, N, taps, T):
     kw = dict(taps=taps) if taps == 62 else dict(taps=taps, cutoff=0.07, beta=7.0)
     m = _mod(dev, N, **kw)
