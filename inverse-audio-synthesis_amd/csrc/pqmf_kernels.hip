@@ -339,15 +339,14 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_synthesis_kernel(
   if (rem < 0) rem += N;
   const int j0 = (N - rem) % N;
   float acc = 0.0f;
-  for (int k = 0; k < N; ++k) {
-    const float* zr = z + ((size_t)b * N + k) * L;
-    const float* g = G + (size_t)k * K;
+  const float* zb = z + (size_t)b * N * L;
+  for (int j = j0; j < K; j += N) {
+    const int u = t - pad + j;            // position in the zero-stuffed signal
+    if (u < 0 || u >= To) continue;
+    const int m = u / N;                  // the frame that lands there (u % N == 0 by construction of j0)
     float a = 0.0f;
-    for (int j = j0; j < K; j += N) {
-      const int u = t - pad + j;          // position in the zero-stuffed signal
-      if (u >= 0 && u < To) a = fmaf(g[j], zr[u / N] * (float)N, a);
-    }
-    acc += a;
+    for (int k = 0; k < N; ++k) a = fmaf(G[(size_t)k * K + j], zb[(size_t)k * L + m], a);
+    acc = fmaf(a, (float)N, acc);
   }
   out[(size_t)b * To + t] = acc;
 }
