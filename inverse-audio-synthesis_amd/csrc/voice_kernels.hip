@@ -224,7 +224,8 @@ __global__ __launch_bounds__(AUDIO_THREADS) void voice_audio_kernel(
     const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst,
     const float* __restrict__ noise, float* __restrict__ audio, unsigned long long* agg /* [B][ntiles][2] */,
     unsigned int* ticket_status /* [0] ticket counter, [1] spin-timeout flag */,
-    unsigned* __restrict__ rowpeak, int T, int Tc, int ntiles, double inv_sample_rate, float scale, int maxctrl) {
+    unsigned* __restrict__ rowpeak, int T, int Tc, int ntiles, double inv_sample_rate, float sr_f, float sr_r,
+    float scale, int maxctrl) {
   // control points as (c[i], c[i+1]) pairs: one ds_read_b64 fetches both ends of a lerp, and the clamp of
   // the upper index at the end of the buffer is folded into the table
   // dynamic LDS: s_inc [2][VOICE_SPT][AUDIO_THREADS] floats (the tile's phase increments wait here between
@@ -296,8 +297,8 @@ __global__ __launch_bounds__(AUDIO_THREADS) void voice_audio_kernel(
       const int i0 = k[0] - c_lo, i1 = k[1] - c_lo;
       const ias_f2 pm1 = ias_lerp_pair(s_ctrl[i0], s_ctrl[i1], w0, w1);
       const ias_f2 pm2 = ias_lerp_pair(s_ctrl[2 * maxctrl + i0], s_ctrl[2 * maxctrl + i1], w0, w1);
-      ias_f2 a = ias_vco_inc_pair(vc.f0_1, vc.depth_1, pm1, inv_sample_rate);
-      ias_f2 d = ias_vco_inc_pair(vc.f0_2, vc.depth_2, pm2, inv_sample_rate);
+      ias_f2 a = ias_vco_inc_pair(vc.f0_1, vc.depth_1, pm1, inv_sample_rate, sr_f, sr_r);
+      ias_f2 d = ias_vco_inc_pair(vc.f0_2, vc.depth_2, pm2, inv_sample_rate, sr_f, sr_r);
       if (j >= T) { a.x = 0.0f; d.x = 0.0f; }
       if (j + 1 >= T) { a.y = 0.0f; d.y = 0.0f; }
       const int e0 = c * 4 + 2 * h;
@@ -528,13 +529,14 @@ extern "C" int ias_voice_stage(int stage, const float* noise, float* audio, void
     // ticket, timeout flag, tile aggregates and row peaks are re-zeroed on every call
     if (hipMemsetAsync(ws + w.off_sync, 0, w.sync_bytes, stream) != hipSuccess) return IAS_ERR_LAUNCH;
     const float scale = (float)(Tc - 1) / (float)(T - 1);
+    const float sr_f = ias_div_fma_rate_ok(sample_rate) ? (float)sample_rate : 0.0f;   // 0: fp64 reciprocal path
     const int maxctrl = voice_maxctrl(T, Tc);
     const size_t lds = sizeof(float) * 2 * VOICE_SPT * AUDIO_THREADS + sizeof(float2) * IAS_NCTRL * (size_t)maxctrl;
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)voice_audio_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(voice_audio_kernel, dim3(w.ntiles * B), dim3(AUDIO_THREADS), lds, stream, ctrl, vconst, noise,
                        audio, (unsigned long long*)(ws + w.off_agg), (unsigned int*)(ws + w.off_sync), peak, T, Tc,
-                       w.ntiles, 1.0 / (double)sample_rate, scale, maxctrl);
+                       w.ntiles, 1.0 / (double)sample_rate, sr_f, sr_f > 0.0f ? 1.0f / sr_f : 0.0f, scale, maxctrl);
   } else {
     const int nvec = T / 4;
     int gx = (nvec + 255) / 256;

@@ -93,6 +93,23 @@ IAS_HD float ias_exp2_cr_fast(float t) {
 // quotient by such a d can never lie within 2^-53 (relative) of a rounding midpoint.
 IAS_HD float ias_div_by_recip(float a, double recip) { return (float)((double)a * recip); }
 
+// fl32(a / d) from three fp32 operations: q0 = fl(a r), e = a - d q0 (exact in the FMA), q = fl(q0 + e r), with
+// r = fl32(1/d).  Correctly rounded for every input the render can produce, checked EXHAUSTIVELY on the host
+// (scripts/diag/div_by_const_check.c: all fp32 a with 1e-30 <= |a| <= 128 for d = 12; all 1 <= a <= 1e6 for
+// d in {16000, 22050, 32000, 44100, 48000, 96000}; a = 0 gives 0); it only fails where e underflows (|a/d| < 2^-126),
+// far from the pitches (|c - 69| is 0 or >= 2^-18) and angular frequencies (>= 51 rad/s) of this path.
+// 6 SIMD clocks instead of the 12 of convert / fp64 multiply / convert.
+IAS_HD float ias_div_fma(float a, float d, float r) {
+  const float q0 = a * r;
+  const float e = fmaf(-d, q0, a);
+  return fmaf(e, r, q0);
+}
+// sample rates for which ias_div_fma has been verified (others use ias_div_by_recip)
+IAS_HD int ias_div_fma_rate_ok(int sample_rate) {
+  return sample_rate == 16000 || sample_rate == 22050 || sample_rate == 32000 || sample_rate == 44100 ||
+         sample_rate == 48000 || sample_rate == 96000;
+}
+
 // ---- parameter range mapping (torchsynth ModuleParameterRange.from_0to1) ----
 // lo = fl32(minimum); span = fl32(maximum - minimum) (non-symmetric) or
 // fl32((maximum - minimum) / 2) (symmetric), both rounded from the double table.
@@ -324,15 +341,18 @@ __device__ __forceinline__ void ias_interp_pair(int j0, int j1, float scale, int
 __device__ __forceinline__ ias_f2 ias_lerp_pair(float2 q0, float2 q1, ias_f2 w0, ias_f2 w1) {
   return w0 * (ias_f2){q0.x, q1.x} + w1 * (ias_f2){q0.y, q1.y};
 }
-// ias_vco_inc_fast for two samples
-__device__ __forceinline__ ias_f2 ias_vco_inc_pair(float f0, float depth, ias_f2 pm, double inv_sample_rate) {
+// ias_vco_inc_fast for two samples.  sr_f / sr_r: the sample rate and fl32 of its reciprocal when the rate is one
+// ias_div_fma is verified for (sr_f > 0), otherwise the fp64 reciprocal product is used.
+__device__ __forceinline__ ias_f2 ias_vco_inc_pair(float f0, float depth, ias_f2 pm, double inv_sample_rate,
+                                                   float sr_f, float sr_r) {
   ias_f2 c = f0 + depth * pm;
   c.x = fminf(fmaxf(c.x, 0.0f), 127.0f);
   c.y = fminf(fmaxf(c.y, 0.0f), 127.0f);
   const ias_f2 s = c - 69.0f;
-  const ias_f2 e = {ias_exp2_cr_fast(ias_div_by_recip(s.x, 1.0 / 12.0)),
-                    ias_exp2_cr_fast(ias_div_by_recip(s.y, 1.0 / 12.0))};
+  const float r12 = 1.0f / 12.0f;
+  const ias_f2 e = {ias_exp2_cr_fast(ias_div_fma(s.x, 12.0f, r12)), ias_exp2_cr_fast(ias_div_fma(s.y, 12.0f, r12))};
   const ias_f2 w = (float)IAS_TWO_PI_D * (440.0f * e);
+  if (sr_f > 0.0f) return (ias_f2){ias_div_fma(w.x, sr_f, sr_r), ias_div_fma(w.y, sr_f, sr_r)};
   return (ias_f2){ias_div_by_recip(w.x, inv_sample_rate), ias_div_by_recip(w.y, inv_sample_rate)};
 }
 // ias_mix_sample_dev for two samples

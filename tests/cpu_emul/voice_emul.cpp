@@ -96,6 +96,13 @@ extern "C" long long emul_check_fast_paths(const float* pm, long long n, float f
     const float w = pm[i] * 7000.0f;
     if (ias_div(w, sr) != ias_div_by_recip(w, inv_sr)) ++bad;
     if (ias_div(t, 12.0f) != ias_div_by_recip(t, 1.0 / 12.0)) ++bad;
+    // the three-FMA quotient of the render kernel (exhaustive proof: scripts/diag/div_by_const_check.c)
+    const float s69 = pm[i] * 127.0f - 69.0f;
+    if (ias_div(s69, 12.0f) != ias_div_fma(s69, 12.0f, 1.0f / 12.0f)) ++bad;
+    if (ias_div_fma_rate_ok(sample_rate)) {
+      const float wf = 51.0f + pm[i] * 80000.0f;
+      if (ias_div(wf, sr) != ias_div_fma(wf, sr, 1.0f / sr)) ++bad;
+    }
   }
   return bad;
 }
