@@ -25,7 +25,11 @@
 #define AUDIO_WAVES (AUDIO_THREADS / 64)
 #define VOICE_SPT 16                          // samples per thread (8 and 12 measured slower: per-tile latencies)
 #define VOICE_TILE (AUDIO_THREADS * VOICE_SPT)  // 4096 samples per workgroup
-#define VOICE_CHUNKS (VOICE_SPT / 4)
+#ifndef VOICE_RUN
+#define VOICE_RUN 4                            // consecutive samples of a lane within one chunk (one wave scan per chunk);
+                                              // 8 halves the scans but costs a wave of occupancy (110 VGPRs): same time
+#endif
+#define VOICE_CHUNKS (VOICE_SPT / VOICE_RUN)
 
 __constant__ IasParamRange c_param_table[IAS_NPARAMS] = IAS_PARAM_TABLE_INIT;
 
@@ -290,8 +294,8 @@ __global__ __launch_bounds__(AUDIO_THREADS) void voice_audio_kernel(
 #pragma unroll
   for (int c = 0; c < VOICE_CHUNKS; ++c) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {   // two samples at a time (packed fp32)
-      const int j = j_wave + c * 256 + lane * 4 + 2 * h;
+    for (int h = 0; h < VOICE_RUN / 2; ++h) {   // two samples at a time (packed fp32)
+      const int j = j_wave + c * (64 * VOICE_RUN) + lane * VOICE_RUN + 2 * h;
       int k[2]; ias_f2 w0, w1;
       ias_interp_pair(min(j, T - 1), min(j + 1, T - 1), scale, k, w0, w1);
       const int i0 = k[0] - c_lo, i1 = k[1] - c_lo;
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(AUDIO_THREADS) void voice_audio_kernel(
       ias_f2 d = ias_vco_inc_pair(vc.f0_2, vc.depth_2, pm2, inv_sample_rate, sr_f, sr_r);
       if (j >= T) { a.x = 0.0f; d.x = 0.0f; }
       if (j + 1 >= T) { a.y = 0.0f; d.y = 0.0f; }
-      const int e0 = c * 4 + 2 * h;
+      const int e0 = c * VOICE_RUN + 2 * h;
       s_inc[e0 * AUDIO_THREADS + tid] = a.x;
       s_inc[(e0 + 1) * AUDIO_THREADS + tid] = a.y;
       s_inc[(VOICE_SPT + e0) * AUDIO_THREADS + tid] = d.x;
@@ -360,30 +364,36 @@ __global__ __launch_bounds__(AUDIO_THREADS) void voice_audio_kernel(
   float* arow = audio + (size_t)b * T;
 #pragma unroll
   for (int c = 0; c < VOICE_CHUNKS; ++c) {
-    const int j0 = j_wave + c * 256 + lane * 4;
-    double l1[4], l2[4];
-    l1[0] = (double)s_inc[(c * 4) * AUDIO_THREADS + tid];
-    l2[0] = (double)s_inc[(VOICE_SPT + c * 4) * AUDIO_THREADS + tid];
+    constexpr int RN = VOICE_RUN;
+    const int j0 = j_wave + c * (64 * RN) + lane * RN;
+    double l1[RN], l2[RN];
+    l1[0] = (double)s_inc[(c * RN) * AUDIO_THREADS + tid];
+    l2[0] = (double)s_inc[(VOICE_SPT + c * RN) * AUDIO_THREADS + tid];
 #pragma unroll
-    for (int e = 1; e < 4; ++e) {
-      l1[e] = l1[e - 1] + (double)s_inc[(c * 4 + e) * AUDIO_THREADS + tid];
-      l2[e] = l2[e - 1] + (double)s_inc[(VOICE_SPT + c * 4 + e) * AUDIO_THREADS + tid];
+    for (int e = 1; e < RN; ++e) {
+      l1[e] = l1[e - 1] + (double)s_inc[(c * RN + e) * AUDIO_THREADS + tid];
+      l2[e] = l2[e - 1] + (double)s_inc[(VOICE_SPT + c * RN + e) * AUDIO_THREADS + tid];
     }
-    const double in1 = wave_incl_scan(l1[3], lane), in2 = wave_incl_scan(l2[3], lane);
-    const double base1 = run1 + (in1 - l1[3]), base2 = run2 + (in2 - l2[3]);
+    const double in1 = wave_incl_scan(l1[RN - 1], lane), in2 = wave_incl_scan(l2[RN - 1], lane);
+    const double base1 = run1 + (in1 - l1[RN - 1]), base2 = run2 + (in2 - l2[RN - 1]);
     run1 += __shfl(in1, 63, 64); run2 += __shfl(in2, 63, 64);
 
-    float nz[4] = {0.f, 0.f, 0.f, 0.f};
-    if (vec_ok && j0 + 3 < T) {
-      const float4 v = *reinterpret_cast<const float4*>(nrow + j0);
-      nz[0] = v.x; nz[1] = v.y; nz[2] = v.z; nz[3] = v.w;
+    float nz[RN];
+#pragma unroll
+    for (int e = 0; e < RN; ++e) nz[e] = 0.f;
+    if (vec_ok && j0 + RN - 1 < T) {
+#pragma unroll
+      for (int q = 0; q < RN / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(nrow + j0 + 4 * q);
+        nz[4 * q] = v.x; nz[4 * q + 1] = v.y; nz[4 * q + 2] = v.z; nz[4 * q + 3] = v.w;
+      }
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (j0 + e < T) nz[e] = nrow[j0 + e];
+      for (int e = 0; e < RN; ++e) if (j0 + e < T) nz[e] = nrow[j0 + e];
     }
-    float o[4];
+    float o[RN];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {   // two samples at a time (packed fp32)
+    for (int h = 0; h < RN / 2; ++h) {   // two samples at a time (packed fp32)
       const int j = j0 + 2 * h;
       int k[2]; ias_f2 w0, w1;
       ias_interp_pair(min(j, T - 1), min(j + 1, T - 1), scale, k, w0, w1);
@@ -398,11 +408,13 @@ __global__ __launch_bounds__(AUDIO_THREADS) void voice_audio_kernel(
       if (j < T) pk = fmaxf(pk, fabsf(om.x));
       if (j + 1 < T) pk = fmaxf(pk, fabsf(om.y));
     }
-    if (vec_ok && j0 + 3 < T) {
-      *reinterpret_cast<float4*>(arow + j0) = make_float4(o[0], o[1], o[2], o[3]);
+    if (vec_ok && j0 + RN - 1 < T) {
+#pragma unroll
+      for (int q = 0; q < RN / 4; ++q)
+        *reinterpret_cast<float4*>(arow + j0 + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (j0 + e < T) arow[j0 + e] = o[e];
+      for (int e = 0; e < RN; ++e) if (j0 + e < T) arow[j0 + e] = o[e];
     }
   }
   pk = wave_max(pk);
