@@ -16,7 +16,10 @@ def _voice(dev, B, sr, sec):
     return Voice(SynthConfig(batch_size=B, sample_rate=sr, buffer_size_seconds=sec, reproducible=False)).to(dev)
 
 
-@pytest.mark.parametrize("B,sr,sec,seed", [(4, 16000, 1.0, 0), (8, 44100, 4.0, 1), (32, 44100, 4.0, 5)])
+# 11025 Hz is not among the sample rates the three-FMA division is verified for: that case runs the fp64
+# reciprocal path of the increment (voice_math.h ias_div_fma_rate_ok)
+@pytest.mark.parametrize("B,sr,sec,seed", [(4, 16000, 1.0, 0), (8, 44100, 4.0, 1), (32, 44100, 4.0, 5),
+                                           (4, 11025, 2.0, 6), (4, 48000, 1.5, 7)])
 def test_render_matches_oracle(lib, dev, B, sr, sec, seed):
     v = _voice(dev, B, sr, sec)
     audio, params, is_train = v(seed)
