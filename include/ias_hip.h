@@ -84,6 +84,13 @@ int ias_voice_backward(const float* ctrl, const void* vconst, const float* noise
                        float* planes, double* tile_sums, double* partials, float* g_ctrl, int B, int T, int Tc,
                        int sample_rate, void* stream);
 
+/* Control-rate half of the same backward: params01 [B,78], g_ctrl [B,5,Tc] fp32 and g_scal [B,12] fp64 (g_ctrl of
+ * ias_voice_backward and the sum over tiles of its partials) -> g_params01 [B,78] fp32.  One launch instead of the
+ * several hundred small torch kernels of voice_grad.control_graph + autograd (which remains the definition and the
+ * test reference).  IAS_ERR_UNSUPPORTED when Tc does not fit LDS (> ~3000 points) or control_rate != 441. */
+int ias_voice_control_backward(const float* params01, const float* g_ctrl, const double* g_scal, float* g_params01,
+                               int B, int Tc, int control_rate, void* stream);
+
 /* Transposed, zero-padded tap table: ias_pqmf_packed_taps_len(N, K) floats -- the fast kernel's layout for N = 3, 4
  * with K = 63, the wide kernel's [K][8|16|32|64] layout for other N <= 64 with K <= 255, 0 otherwise (generic
  * kernel only); ias_pqmf_pack_taps fills packed (device, 8-byte aligned) from H [N,K] (device); re-run when H

@@ -37,6 +37,7 @@ SYMBOLS = {
     "ias_voice_grad_nscalars": (_I, []),
     "ias_voice_grad_nplanes": (_I, []),
     "ias_voice_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_voice_control_backward": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ias_pqmf_out_len": (_I, [_I, _I, _I]),
     "ias_pqmf_packed_taps_len": (_I, [_I, _I]),
     "ias_pqmf_pack_taps": (_I, [_P, _P, _I, _I, _P]),

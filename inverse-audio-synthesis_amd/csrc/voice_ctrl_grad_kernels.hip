@@ -1,0 +1,329 @@
+// Backward of the control-rate pass of the Voice render for MI355X (gfx950):
+//   (d loss / d ctrl [B,5,Tc], d loss / d constants [B,12])  ->  d loss / d params01 [B,78].
+//
+// Adjoint of csrc/voice_kernels.hip's voice_env / voice_lfo / voice_modmix kernels (torchsynth-style ADSR, LFO,
+// ModulationMixer, parameter ranges), with torch.autograd's conventions where the functions have kinks
+// (clamp passes the gradient on the closed side, minimum splits ties, sign() has zero gradient) and 0 where autograd
+// would produce nan (0^alpha ramps, zero-length segments).  Same function as voice_grad.py:control_graph + autograd,
+// which remains the definition and the test reference (tests/test_voice_grad_gpu.py); this kernel replaces ~600
+// small torch kernels (2.1 ms at B=128) by one launch.  The reference has no counterpart: its loop through the
+// synth is commented out (/root/reference/audio_to_params.py:56-172).
+//
+// One workgroup per voice; everything in fp64 (a few thousand points per voice: the cost is nowhere).  A thread owns
+// a contiguous run of control points, so the two cumulative sums (LFO phase forward, its gradient backward) are a
+// local loop plus one workgroup scan.  Values needed twice are recomputed rather than stored (an ADSR value is three
+// pow() calls); LDS holds the LFO phases, their gradients and the six envelope gradients.
+#include "ias_common.h"
+#include "voice_table.h"
+
+#define CG_THREADS 256
+#define CG_NSCAL 12
+
+__constant__ IasParamRange c_cg_table[78] = IAS_PARAM_TABLE_INIT;
+
+__device__ __forceinline__ double cg_wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+// sum over the workgroup, result in every thread; s_red: CG_THREADS/64 doubles
+__device__ __forceinline__ double cg_block_sum(double v, double* s_red, int tid) {
+  v = cg_wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) s_red[tid >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < CG_THREADS / 64; ++w) t += s_red[w];
+  return t;
+}
+// exclusive prefix of one value per thread (thread order); REVERSE: suffix instead
+template <bool REVERSE>
+__device__ __forceinline__ double cg_block_excl_scan(double v, double* s_scan /* CG_THREADS */, int tid) {
+  __syncthreads();
+  s_scan[tid] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (!REVERSE) { for (int i = 0; i < tid; ++i) t += s_scan[i]; }
+  else { for (int i = CG_THREADS - 1; i > tid; --i) t += s_scan[i]; }
+  return t;
+}
+
+struct CgAdsr { double attack, decay, sustain, release, alpha; };
+struct CgRampGrad { double duration, start, alpha; };
+
+// ramp value (after the pow) at control index i; the pieces the backward needs come back through the pointers
+__device__ __forceinline__ double cg_ramp(int i, double duration, double alpha, double start, bool has_start,
+                                          bool inverse, double cr, double* y_out, double* q_out, double* t_out,
+                                          bool* t_live) {
+  const double dur = duration * cr;
+  double t = (double)i;
+  bool live = true;
+  if (has_start) { t -= start * cr; live = t >= 0.0; if (t < 0.0) t = 0.0; }
+  double q = 1.0, y;
+  if (dur > 0.0) { q = (t + IAS_EPS) / dur + IAS_EPS; y = q <= 1.0 ? q : 1.0; if (inverse) y = 1.0 - y; }
+  else y = 1.0;
+  *y_out = y; *q_out = q; *t_out = t; *t_live = live;
+  return pow(y >= 1e-300 ? y : 1e-300, alpha);
+}
+// accumulate d/d(duration, start, alpha) of g * ramp
+__device__ __forceinline__ void cg_ramp_back(double g, double val, double y, double q, double t, bool t_live,
+                                             double duration, double alpha, bool has_start, bool inverse, double cr,
+                                             CgRampGrad& acc) {
+  if (g == 0.0) return;
+  const double yc = y >= 1e-300 ? y : 1e-300;
+  acc.alpha += g * val * log(yc);
+  if (y < 1e-300) return;                       // clamp_min: no gradient below the floor (0^alpha ramps)
+  const double dur = duration * cr;
+  if (!(dur > 0.0) || q > 1.0) return;          // constant ramp / saturated at 1
+  double gq = g * alpha * pow(yc, alpha - 1.0);
+  if (inverse) gq = -gq;
+  acc.duration += -gq * (t + IAS_EPS) / (dur * dur) * cr;
+  if (has_start && t_live) acc.start += -(gq / dur) * cr;
+}
+
+__device__ __forceinline__ double cg_adsr(int i, const CgAdsr& e, double note_on, double cr) {
+  const double na = fmin(e.attack, note_on);
+  const double nd = fmin(fmax(note_on - e.attack, 0.0), e.decay);
+  double y, q, t; bool l;
+  const double a = cg_ramp(i, na, e.alpha, 0.0, false, false, cr, &y, &q, &t, &l);
+  const double d = (1.0 - e.sustain) * cg_ramp(i, nd, e.alpha, na, true, true, cr, &y, &q, &t, &l) + e.sustain;
+  const double r = cg_ramp(i, e.release, e.alpha, note_on, true, true, cr, &y, &q, &t, &l);
+  return a * d * r;
+}
+
+// the five LFO shapes at phase arg and their derivatives d shape / d arg
+__device__ __forceinline__ void cg_lfo_shapes(double arg, double* sh, double* dsh) {
+  const double two_pi = 6.283185307179586, pi = 3.141592653589793;
+  const double c = cos(arg + pi);
+  sh[0] = (c + 1.0) * 0.5;                       dsh[0] = -sin(arg + pi) * 0.5;
+  double m = fmod(arg, two_pi);
+  if (m < 0.0) m += two_pi;
+  const double saw = m / two_pi;
+  const double tri2 = 2.0 * saw;
+  sh[1] = tri2 > 1.0 ? 2.0 - tri2 : tri2;        dsh[1] = tri2 > 1.0 ? -1.0 / pi : 1.0 / pi;
+  sh[2] = saw;                                   dsh[2] = 1.0 / two_pi;
+  sh[3] = 1.0 - saw;                             dsh[3] = -1.0 / two_pi;
+  sh[4] = ((c > 0.0 ? 1.0 : (c < 0.0 ? -1.0 : 0.0)) + 1.0) * 0.5;   dsh[4] = 0.0;
+}
+
+__global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
+    const float* __restrict__ params01, const float* __restrict__ g_ctrl, const double* __restrict__ g_scal,
+    float* __restrict__ g_params01, int Tc, int ppt /* points per thread */, double cr) {
+  extern __shared__ __attribute__((aligned(16))) double cg_smem[];
+  double* s_arg = cg_smem;                 // [2][Tc] LFO phases
+  double* s_garg = s_arg + 2 * Tc;         // [2][Tc] d loss / d phase
+  float* s_genv = reinterpret_cast<float*>(s_garg + 2 * Tc);   // [6][Tc] d loss / d envelope
+  __shared__ double s_v[78], s_dv[78], s_gv[78];
+  __shared__ double s_red[CG_THREADS / 64], s_scan[CG_THREADS];
+
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int i_lo = min(tid * ppt, Tc), i_hi = min(i_lo + ppt, Tc);
+  const double two_pi = 6.283185307179586;
+
+  // ---- parameter values and d value / d params01 (ModuleParameterRange.from_0to1)
+  if (tid < 78) {
+    const IasParamRange r = c_cg_table[tid];
+    const double u = (double)params01[(size_t)b * 78 + tid];
+    const double ic = 1.0 / r.curve;
+    double v, dv;
+    if (!r.symmetric) {
+      const double uc = u >= 1e-300 ? u : 1e-300;
+      v = r.lo + r.span * pow(uc, ic);
+      dv = u >= 1e-300 ? r.span * ic * pow(uc, ic - 1.0) : 0.0;
+    } else {
+      const double dist = 2.0 * u - 1.0, ad = fabs(dist);
+      const double ac = ad >= 1e-300 ? ad : 1e-300;
+      const double sg = dist > 0.0 ? 1.0 : (dist < 0.0 ? -1.0 : 0.0);
+      v = r.lo + r.span * (sg * pow(ac, ic) + 1.0);
+      dv = ad >= 1e-300 ? r.span * ic * pow(ac, ic - 1.0) * 2.0 : 0.0;   // sign(d)^2 = 1
+    }
+    s_v[tid] = v; s_dv[tid] = dv; s_gv[tid] = 0.0;
+  }
+  __syncthreads();
+  const double note_on = s_v[IAS_P_KEYBOARD_DURATION];
+  const int adsr_base[6] = {IAS_P_ADSR_1_ATTACK, IAS_P_ADSR_2_ATTACK, IAS_P_LFO_1_AMP_ADSR_ATTACK,
+                            IAS_P_LFO_2_AMP_ADSR_ATTACK, IAS_P_LFO_1_RATE_ADSR_ATTACK, IAS_P_LFO_2_RATE_ADSR_ATTACK};
+  const int lfo_base[2] = {IAS_P_LFO_1_FREQUENCY, IAS_P_LFO_2_FREQUENCY};
+  CgAdsr env[6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) {
+    const int o = adsr_base[e];
+    env[e].attack = s_v[o]; env[e].decay = s_v[o + 1]; env[e].sustain = s_v[o + 2];
+    env[e].release = s_v[o + 3]; env[e].alpha = s_v[o + 4];
+  }
+
+  // ---- LFO phases: arg[i] = cumsum(2 pi max(f + depth * rate_env, 0) / cr) + phi
+  for (int m = 0; m < 2; ++m) {
+    const double f = s_v[lfo_base[m]], dep = s_v[lfo_base[m] + 1], phi = s_v[lfo_base[m] + 2];
+    double run = 0.0;
+    for (int i = i_lo; i < i_hi; ++i) {
+      const double fr = fmax(f + dep * cg_adsr(i, env[4 + m], note_on, cr), 0.0);
+      run += two_pi * fr / cr;
+      s_arg[m * Tc + i] = run;
+    }
+    const double before = cg_block_excl_scan<false>(run, s_scan, tid);
+    for (int i = i_lo; i < i_hi; ++i) s_arg[m * Tc + i] += before + phi;
+  }
+  __syncthreads();
+
+  // ---- mod matrix, LFO output: per point sources and their gradients
+  double mode[2][5], msum[2];
+  for (int m = 0; m < 2; ++m) {
+    msum[m] = 0.0;
+    for (int s = 0; s < 5; ++s) { const double p = s_v[lfo_base[m] + 3 + s]; mode[m][s] = p * p; msum[m] += mode[m][s]; }
+    for (int s = 0; s < 5; ++s) mode[m][s] /= msum[m];
+  }
+  double w[5][4];
+  for (int k = 0; k < 4; ++k)
+    for (int o = 0; o < 5; ++o) w[o][k] = s_v[IAS_P_MOD_MATRIX_ADSR_1_TO_VCO_1_PITCH + k * 5 + o];
+  const float* gc = g_ctrl + (size_t)b * 5 * Tc;
+  double gw[5][4], gmode[2][5];
+  for (int o = 0; o < 5; ++o) for (int k = 0; k < 4; ++k) gw[o][k] = 0.0;
+  for (int m = 0; m < 2; ++m) for (int s = 0; s < 5; ++s) gmode[m][s] = 0.0;
+  for (int i = i_lo; i < i_hi; ++i) {
+    double src[4], mix[2], sh[2][5], dsh[2][5], amp[2];
+    src[0] = cg_adsr(i, env[0], note_on, cr);
+    src[1] = cg_adsr(i, env[1], note_on, cr);
+    for (int m = 0; m < 2; ++m) {
+      cg_lfo_shapes(s_arg[m * Tc + i], sh[m], dsh[m]);
+      mix[m] = 0.0;
+      for (int s = 0; s < 5; ++s) mix[m] += mode[m][s] * sh[m][s];
+      amp[m] = cg_adsr(i, env[2 + m], note_on, cr);
+      src[2 + m] = mix[m] * amp[m];
+    }
+    double go[5], gsrc[4];
+    for (int o = 0; o < 5; ++o) go[o] = (double)gc[o * Tc + i];
+    for (int k = 0; k < 4; ++k) {
+      gsrc[k] = 0.0;
+      for (int o = 0; o < 5; ++o) { gsrc[k] += w[o][k] * go[o]; gw[o][k] += go[o] * src[k]; }
+    }
+    s_genv[0 * Tc + i] = (float)gsrc[0];
+    s_genv[1 * Tc + i] = (float)gsrc[1];
+    for (int m = 0; m < 2; ++m) {
+      s_genv[(2 + m) * Tc + i] = (float)(gsrc[2 + m] * mix[m]);
+      const double gmix = gsrc[2 + m] * amp[m];
+      double ga = 0.0;
+      for (int s = 0; s < 5; ++s) { gmode[m][s] += gmix * sh[m][s]; ga += mode[m][s] * dsh[m][s]; }
+      s_garg[m * Tc + i] = gmix * ga;
+    }
+  }
+  for (int o = 0; o < 5; ++o)
+    for (int k = 0; k < 4; ++k) {
+      const double t = cg_block_sum(gw[o][k], s_red, tid);
+      if (tid == 0) s_gv[IAS_P_MOD_MATRIX_ADSR_1_TO_VCO_1_PITCH + k * 5 + o] += t;
+    }
+  for (int m = 0; m < 2; ++m) {
+    double gm[5], dot = 0.0;
+    for (int s = 0; s < 5; ++s) { gm[s] = cg_block_sum(gmode[m][s], s_red, tid); dot += gm[s] * mode[m][s]; }
+    if (tid == 0)
+      for (int s = 0; s < 5; ++s)   // mode = p^2 / sum p^2
+        s_gv[lfo_base[m] + 3 + s] += (gm[s] - dot) / msum[m] * 2.0 * s_v[lfo_base[m] + 3 + s];
+  }
+
+  // ---- LFO phase gradient: reverse cumulative sum, then frequency / depth / rate envelope
+  for (int m = 0; m < 2; ++m) {
+    const double f = s_v[lfo_base[m]], dep = s_v[lfo_base[m] + 1];
+    double run = 0.0;
+    for (int i = i_hi - 1; i >= i_lo; --i) { run += s_garg[m * Tc + i]; s_garg[m * Tc + i] = run; }
+    const double after = cg_block_excl_scan<true>(run, s_scan, tid);
+    double gphi = (i_hi > i_lo) ? run : 0.0, gf = 0.0, gdep = 0.0;   // sum of g_arg over the thread's points
+    for (int i = i_lo; i < i_hi; ++i) {
+      const double ginc = s_garg[m * Tc + i] + after;       // sum_{i' >= i} g_arg[i']
+      const double renv = cg_adsr(i, env[4 + m], note_on, cr);
+      const double gfr = (f + dep * renv >= 0.0) ? ginc * two_pi / cr : 0.0;   // clamp_min passes at >= 0
+      gf += gfr; gdep += gfr * renv;
+      s_genv[(4 + m) * Tc + i] = (float)(gfr * dep);
+    }
+    gphi = cg_block_sum(gphi, s_red, tid);
+    gf = cg_block_sum(gf, s_red, tid);
+    gdep = cg_block_sum(gdep, s_red, tid);
+    if (tid == 0) { s_gv[lfo_base[m]] += gf; s_gv[lfo_base[m] + 1] += gdep; s_gv[lfo_base[m] + 2] += gphi; }
+  }
+  __syncthreads();
+
+  // ---- the six envelopes: env = A * D * R
+  double g_note_on = 0.0;
+  for (int e = 0; e < 6; ++e) {
+    const CgAdsr p = env[e];
+    const double na = fmin(p.attack, note_on);
+    const double nd0 = fmax(note_on - p.attack, 0.0);
+    const double nd = fmin(nd0, p.decay);
+    CgRampGrad ga = {0, 0, 0}, gd = {0, 0, 0}, gr = {0, 0, 0};
+    double gsus = 0.0;
+    for (int i = i_lo; i < i_hi; ++i) {
+      const double g = (double)s_genv[e * Tc + i];
+      double ya, qa, ta, yd, qd, td, yr, qr, tr; bool la, ld, lr;
+      const double a = cg_ramp(i, na, p.alpha, 0.0, false, false, cr, &ya, &qa, &ta, &la);
+      const double dr = cg_ramp(i, nd, p.alpha, na, true, true, cr, &yd, &qd, &td, &ld);
+      const double r = cg_ramp(i, p.release, p.alpha, note_on, true, true, cr, &yr, &qr, &tr, &lr);
+      const double d = (1.0 - p.sustain) * dr + p.sustain;
+      cg_ramp_back(g * d * r, a, ya, qa, ta, la, na, p.alpha, false, false, cr, ga);
+      cg_ramp_back(g * a * r * (1.0 - p.sustain), dr, yd, qd, td, ld, nd, p.alpha, true, true, cr, gd);
+      cg_ramp_back(g * a * d, r, yr, qr, tr, lr, p.release, p.alpha, true, true, cr, gr);
+      gsus += g * a * r * (1.0 - dr);
+    }
+    // durations / starts back to attack, decay, release, note_on
+    //   new_attack = min(attack, note_on)           (ramp A duration, ramp D start)
+    //   new_decay  = min(max(note_on - attack, 0), decay)   (ramp D duration)
+    //   release                                      (ramp R duration), note_on (ramp R start)
+    const double g_na = cg_block_sum(ga.duration + gd.start, s_red, tid);
+    const double g_nd = cg_block_sum(gd.duration, s_red, tid);
+    const double g_rel = cg_block_sum(gr.duration, s_red, tid);
+    const double g_no_r = cg_block_sum(gr.start, s_red, tid);
+    const double g_alpha = cg_block_sum(ga.alpha + gd.alpha + gr.alpha, s_red, tid);
+    const double g_sus = cg_block_sum(gsus, s_red, tid);
+    if (tid == 0) {
+      double g_att = 0.0, g_dec = 0.0, g_no = g_no_r;
+      // torch.minimum: the smaller argument takes the gradient, a tie splits it
+      if (p.attack < note_on) g_att += g_na; else if (p.attack > note_on) g_no += g_na; else { g_att += 0.5 * g_na; g_no += 0.5 * g_na; }
+      double g_nd0 = 0.0;
+      if (nd0 < p.decay) g_nd0 = g_nd; else if (nd0 > p.decay) g_dec += g_nd; else { g_nd0 = 0.5 * g_nd; g_dec += 0.5 * g_nd; }
+      if (note_on - p.attack >= 0.0) { g_no += g_nd0; g_att -= g_nd0; }      // clamp_min passes at >= 0
+      const int o = adsr_base[e];
+      s_gv[o] += g_att; s_gv[o + 1] += g_dec; s_gv[o + 2] += g_sus; s_gv[o + 3] += g_rel; s_gv[o + 4] += g_alpha;
+      g_note_on += g_no;
+    }
+  }
+
+  // ---- per-voice constants and the chain to params01
+  if (tid == 0) {
+    const double* gs = g_scal + (size_t)b * CG_NSCAL;
+    s_gv[IAS_P_KEYBOARD_DURATION] += g_note_on;
+    const double midi = s_v[IAS_P_KEYBOARD_MIDI_F0], dep2 = s_v[IAS_P_VCO_2_MOD_DEPTH];
+    const double F = 440.0 * exp2((midi + fmax(dep2, 0.0) - 69.0) / 12.0);
+    const double lg = log10(F);
+    // kpart = pi * 12000 / (F log10 F)
+    const double dk_dF = -3.141592653589793 * 12000.0 * (lg + 0.4342944819032518) / (F * lg * F * lg);
+    const double dk_dP = dk_dF * F * 0.6931471805599453 / 12.0;
+    s_gv[IAS_P_KEYBOARD_MIDI_F0] += gs[0] + gs[3] + gs[6] * dk_dP;
+    s_gv[IAS_P_VCO_1_TUNING] += gs[0];
+    s_gv[IAS_P_VCO_1_MOD_DEPTH] += gs[1];
+    s_gv[IAS_P_VCO_1_INITIAL_PHASE] += gs[2];
+    s_gv[IAS_P_VCO_2_TUNING] += gs[3];
+    s_gv[IAS_P_VCO_2_MOD_DEPTH] += gs[4] + (dep2 >= 0.0 ? gs[6] * dk_dP : 0.0);
+    s_gv[IAS_P_VCO_2_INITIAL_PHASE] += gs[5];
+    s_gv[IAS_P_VCO_2_SHAPE] += gs[7] - 0.5 * gs[8];
+    s_gv[IAS_P_MIXER_VCO_1] += gs[9];
+    s_gv[IAS_P_MIXER_VCO_2] += gs[10];
+    s_gv[IAS_P_MIXER_NOISE] += gs[11];
+  }
+  __syncthreads();
+  if (tid < 78) g_params01[(size_t)b * 78 + tid] = (float)(s_gv[tid] * s_dv[tid]);
+}
+
+// params01 [B,78]; g_ctrl [B,5,Tc] fp32 and g_scal [B,12] fp64 (ias_voice_backward's g_ctrl and the tile sum of its
+// partials); g_params01 [B,78] out.  IAS_ERR_UNSUPPORTED when the control buffer does not fit LDS (Tc > ~3000):
+// the caller then differentiates voice_grad.control_graph with torch.
+extern "C" int ias_voice_control_backward(const float* params01, const float* g_ctrl, const double* g_scal,
+                                          float* g_params01, int B, int Tc, int control_rate, void* stream_) {
+  if (!params01 || !g_ctrl || !g_scal || !g_params01 || B <= 0 || Tc <= 1 || control_rate <= 0) return IAS_ERR_ARG;
+  if (control_rate != IAS_CONTROL_RATE) return IAS_ERR_UNSUPPORTED;
+  const size_t lds = sizeof(double) * 4 * (size_t)Tc + sizeof(float) * 6 * (size_t)Tc;
+  if (lds > 150 * 1024) return IAS_ERR_UNSUPPORTED;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)voice_ctrl_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int ppt = (Tc + CG_THREADS - 1) / CG_THREADS;
+  hipLaunchKernelGGL(voice_ctrl_grad_kernel, dim3(B), dim3(CG_THREADS), lds, (hipStream_t)stream_, params01, g_ctrl,
+                     g_scal, g_params01, Tc, ppt, (double)control_rate);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}

@@ -6,11 +6,12 @@ that block relied on).  Here the render is a hand-written HIP kernel, so its adj
 
 * audio rate ([B,T] work): ``csrc/voice_grad_kernels.hip`` (``ias_voice_backward``) turns d loss / d mix into
   d loss / d (control-rate signals [B,5,Tc]) and d loss / d (12 per-voice constants);
-* control rate ([B,Tc] work, a few thousand points per voice): the 78 parameters -> (control signals, constants) map
-  is restated below with differentiable torch ops, evaluated in fp64 on the device, and torch's autograd carries
-  the two gradients above back to the parameters.  The values that reach the audio-rate kernels always come from
-  the HIP control kernels; this graph is only differentiated, and ``tests/test_voice_grad_gpu.py`` checks that its
-  forward values agree with the HIP control kernels.
+* control rate ([B,Tc] work, a few thousand points per voice): ``csrc/voice_ctrl_grad_kernels.hip``
+  (``ias_voice_control_backward``) carries the two gradients above back to the 78 parameters.  Its DEFINITION is
+  ``control_graph`` below -- the 78 parameters -> (control signals, constants) map restated with differentiable torch
+  ops in fp64 -- differentiated by torch's autograd: the kernel is tested against it, it is the fallback for control
+  buffers too long for LDS, and ``tests/test_voice_grad_gpu.py`` checks that its forward values agree with the HIP
+  control kernels of the render.
 """
 import math
 
@@ -208,8 +209,26 @@ class _ControlBackwardGraph:
 _GRAPHS = {}
 
 
-def _control_backward(cfg, p, g_ctrl, g_scal):
-    """d loss / d params01 [B,78] (fp64) from the gradients of the control signals and per-voice constants."""
+def _control_backward_hip(cfg, p, g_ctrl, g_scal):
+    """The same adjoint as one HIP launch (csrc/voice_ctrl_grad_kernels.hip); None if the shape is unsupported."""
+    lib = _lib.load()
+    g_ctrl = g_ctrl.to(torch.float32).contiguous()
+    g_scal = g_scal.to(torch.float64).contiguous()
+    out = torch.empty((p.shape[0], S.NPARAMS), dtype=torch.float32, device=p.device)
+    st = lib.ias_voice_control_backward(_lib.ptr(p), _lib.ptr(g_ctrl), _lib.ptr(g_scal), _lib.ptr(out), p.shape[0],
+                                        cfg.control_buffer_size, cfg.control_rate, _lib.stream())
+    if st == -2:      # IAS_ERR_UNSUPPORTED: control buffer too long for LDS -> torch graph
+        return None
+    _lib.check(st, "ias_voice_control_backward")
+    return out
+
+
+def _control_backward(cfg, p, g_ctrl, g_scal, use_hip=True):
+    """d loss / d params01 [B,78] from the gradients of the control signals and per-voice constants."""
+    if use_hip:
+        out = _control_backward_hip(cfg, p, g_ctrl, g_scal)
+        if out is not None:
+            return out
     if torch.cuda.is_current_stream_capturing():
         return _control_backward_eager(cfg, p, g_ctrl, g_scal)
     key = (p.shape[0], cfg.control_buffer_size, cfg.control_rate, str(p.device))
