@@ -16,7 +16,7 @@
 #include "ias_common.h"
 #include "voice_table.h"
 
-#define CG_THREADS 256
+#define CG_THREADS 512    // 8 waves per voice (2 per SIMD; 16 would cap the kernel at 128 VGPRs and spill)
 #define CG_NSCAL 12
 
 __constant__ IasParamRange c_cg_table[78] = IAS_PARAM_TABLE_INIT;
@@ -36,15 +36,22 @@ __device__ __forceinline__ double cg_block_sum(double v, double* s_red, int tid)
   for (int w = 0; w < CG_THREADS / 64; ++w) t += s_red[w];
   return t;
 }
-// exclusive prefix of one value per thread (thread order); REVERSE: suffix instead
+// exclusive prefix of one value per thread (thread order); REVERSE: suffix instead.  s_scan: CG_THREADS/64 doubles
 template <bool REVERSE>
-__device__ __forceinline__ double cg_block_excl_scan(double v, double* s_scan /* CG_THREADS */, int tid) {
+__device__ __forceinline__ double cg_block_excl_scan(double v, double* s_scan, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  double incl = v;                       // inclusive scan inside the wave (towards higher lanes; REVERSE: lower)
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double o = REVERSE ? __shfl_down(incl, d, 64) : __shfl_up(incl, d, 64);
+    if (REVERSE ? (lane + d < 64) : (lane >= d)) incl += o;
+  }
   __syncthreads();
-  s_scan[tid] = v;
+  if (lane == (REVERSE ? 0 : 63)) s_scan[wave] = incl;
   __syncthreads();
-  double t = 0.0;
-  if (!REVERSE) { for (int i = 0; i < tid; ++i) t += s_scan[i]; }
-  else { for (int i = CG_THREADS - 1; i > tid; --i) t += s_scan[i]; }
+  double t = incl - v;
+  if (!REVERSE) { for (int w = 0; w < wave; ++w) t += s_scan[w]; }
+  else { for (int w = CG_THREADS / 64 - 1; w > wave; --w) t += s_scan[w]; }
   return t;
 }
 
@@ -54,7 +61,7 @@ struct CgRampGrad { double duration, start, alpha; };
 // ramp value (after the pow) at control index i; the pieces the backward needs come back through the pointers
 __device__ __forceinline__ double cg_ramp(int i, double duration, double alpha, double start, bool has_start,
                                           bool inverse, double cr, double* y_out, double* q_out, double* t_out,
-                                          bool* t_live) {
+                                          bool* t_live, double head = -1.0) {
   const double dur = duration * cr;
   double t = (double)i;
   bool live = true;
@@ -63,6 +70,8 @@ __device__ __forceinline__ double cg_ramp(int i, double duration, double alpha, 
   if (dur > 0.0) { q = (t + IAS_EPS) / dur + IAS_EPS; y = q <= 1.0 ? q : 1.0; if (inverse) y = 1.0 - y; }
   else y = 1.0;
   *y_out = y; *q_out = q; *t_out = t; *t_live = live;
+  if (y == 1.0) return 1.0;                      // saturated attack ramps, zero-length segments: no pow()
+  if (has_start && !live && head >= 0.0) return head;   // flat head before the segment starts: same value for all i
   return pow(y >= 1e-300 ? y : 1e-300, alpha);
 }
 // accumulate d/d(duration, start, alpha) of g * ramp
@@ -75,19 +84,30 @@ __device__ __forceinline__ void cg_ramp_back(double g, double val, double y, dou
   if (y < 1e-300) return;                       // clamp_min: no gradient below the floor (0^alpha ramps)
   const double dur = duration * cr;
   if (!(dur > 0.0) || q > 1.0) return;          // constant ramp / saturated at 1
-  double gq = g * alpha * pow(yc, alpha - 1.0);
+  double gq = g * alpha * val / yc;             // alpha * y^(alpha-1)
   if (inverse) gq = -gq;
   acc.duration += -gq * (t + IAS_EPS) / (dur * dur) * cr;
   if (has_start && t_live) acc.start += -(gq / dur) * cr;
 }
 
-__device__ __forceinline__ double cg_adsr(int i, const CgAdsr& e, double note_on, double cr) {
+// values of the decay and release ramps on their flat heads (index 0), computed once per envelope
+struct CgHeads { double d, r; };
+__device__ __forceinline__ CgHeads cg_heads(const CgAdsr& e, double note_on, double cr) {
+  const double na = fmin(e.attack, note_on);
+  const double nd = fmin(fmax(note_on - e.attack, 0.0), e.decay);
+  double y, q, t; bool l;
+  CgHeads h;
+  h.d = cg_ramp(-1, nd, e.alpha, na, true, true, cr, &y, &q, &t, &l);        // t clamps to 0 for any i < start
+  h.r = cg_ramp(-1, e.release, e.alpha, note_on, true, true, cr, &y, &q, &t, &l);
+  return h;
+}
+__device__ __forceinline__ double cg_adsr(int i, const CgAdsr& e, double note_on, double cr, const CgHeads& h) {
   const double na = fmin(e.attack, note_on);
   const double nd = fmin(fmax(note_on - e.attack, 0.0), e.decay);
   double y, q, t; bool l;
   const double a = cg_ramp(i, na, e.alpha, 0.0, false, false, cr, &y, &q, &t, &l);
-  const double d = (1.0 - e.sustain) * cg_ramp(i, nd, e.alpha, na, true, true, cr, &y, &q, &t, &l) + e.sustain;
-  const double r = cg_ramp(i, e.release, e.alpha, note_on, true, true, cr, &y, &q, &t, &l);
+  const double d = (1.0 - e.sustain) * cg_ramp(i, nd, e.alpha, na, true, true, cr, &y, &q, &t, &l, h.d) + e.sustain;
+  const double r = cg_ramp(i, e.release, e.alpha, note_on, true, true, cr, &y, &q, &t, &l, h.r);
   return a * d * r;
 }
 
@@ -114,7 +134,7 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
   double* s_garg = s_arg + 2 * Tc;         // [2][Tc] d loss / d phase
   float* s_genv = reinterpret_cast<float*>(s_garg + 2 * Tc);   // [6][Tc] d loss / d envelope
   __shared__ double s_v[78], s_dv[78], s_gv[78];
-  __shared__ double s_red[CG_THREADS / 64], s_scan[CG_THREADS];
+  __shared__ double s_red[CG_THREADS / 64], s_scan[CG_THREADS / 64];
 
   const int tid = threadIdx.x, b = blockIdx.x;
   const int i_lo = min(tid * ppt, Tc), i_hi = min(i_lo + ppt, Tc);
@@ -151,13 +171,16 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
     env[e].attack = s_v[o]; env[e].decay = s_v[o + 1]; env[e].sustain = s_v[o + 2];
     env[e].release = s_v[o + 3]; env[e].alpha = s_v[o + 4];
   }
+  CgHeads heads[6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) heads[e] = cg_heads(env[e], note_on, cr);
 
   // ---- LFO phases: arg[i] = cumsum(2 pi max(f + depth * rate_env, 0) / cr) + phi
   for (int m = 0; m < 2; ++m) {
     const double f = s_v[lfo_base[m]], dep = s_v[lfo_base[m] + 1], phi = s_v[lfo_base[m] + 2];
     double run = 0.0;
     for (int i = i_lo; i < i_hi; ++i) {
-      const double fr = fmax(f + dep * cg_adsr(i, env[4 + m], note_on, cr), 0.0);
+      const double fr = fmax(f + dep * cg_adsr(i, env[4 + m], note_on, cr, heads[4 + m]), 0.0);
       run += two_pi * fr / cr;
       s_arg[m * Tc + i] = run;
     }
@@ -182,13 +205,13 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
   for (int m = 0; m < 2; ++m) for (int s = 0; s < 5; ++s) gmode[m][s] = 0.0;
   for (int i = i_lo; i < i_hi; ++i) {
     double src[4], mix[2], sh[2][5], dsh[2][5], amp[2];
-    src[0] = cg_adsr(i, env[0], note_on, cr);
-    src[1] = cg_adsr(i, env[1], note_on, cr);
+    src[0] = cg_adsr(i, env[0], note_on, cr, heads[0]);
+    src[1] = cg_adsr(i, env[1], note_on, cr, heads[1]);
     for (int m = 0; m < 2; ++m) {
       cg_lfo_shapes(s_arg[m * Tc + i], sh[m], dsh[m]);
       mix[m] = 0.0;
       for (int s = 0; s < 5; ++s) mix[m] += mode[m][s] * sh[m][s];
-      amp[m] = cg_adsr(i, env[2 + m], note_on, cr);
+      amp[m] = cg_adsr(i, env[2 + m], note_on, cr, heads[2 + m]);
       src[2 + m] = mix[m] * amp[m];
     }
     double go[5], gsrc[4];
@@ -229,7 +252,7 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
     double gphi = (i_hi > i_lo) ? run : 0.0, gf = 0.0, gdep = 0.0;   // sum of g_arg over the thread's points
     for (int i = i_lo; i < i_hi; ++i) {
       const double ginc = s_garg[m * Tc + i] + after;       // sum_{i' >= i} g_arg[i']
-      const double renv = cg_adsr(i, env[4 + m], note_on, cr);
+      const double renv = cg_adsr(i, env[4 + m], note_on, cr, heads[4 + m]);
       const double gfr = (f + dep * renv >= 0.0) ? ginc * two_pi / cr : 0.0;   // clamp_min passes at >= 0
       gf += gfr; gdep += gfr * renv;
       s_genv[(4 + m) * Tc + i] = (float)(gfr * dep);
@@ -254,8 +277,8 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
       const double g = (double)s_genv[e * Tc + i];
       double ya, qa, ta, yd, qd, td, yr, qr, tr; bool la, ld, lr;
       const double a = cg_ramp(i, na, p.alpha, 0.0, false, false, cr, &ya, &qa, &ta, &la);
-      const double dr = cg_ramp(i, nd, p.alpha, na, true, true, cr, &yd, &qd, &td, &ld);
-      const double r = cg_ramp(i, p.release, p.alpha, note_on, true, true, cr, &yr, &qr, &tr, &lr);
+      const double dr = cg_ramp(i, nd, p.alpha, na, true, true, cr, &yd, &qd, &td, &ld, heads[e].d);
+      const double r = cg_ramp(i, p.release, p.alpha, note_on, true, true, cr, &yr, &qr, &tr, &lr, heads[e].r);
       const double d = (1.0 - p.sustain) * dr + p.sustain;
       cg_ramp_back(g * d * r, a, ya, qa, ta, la, na, p.alpha, false, false, cr, ga);
       cg_ramp_back(g * a * r * (1.0 - p.sustain), dr, yd, qd, td, ld, nd, p.alpha, true, true, cr, gd);
