@@ -20,22 +20,23 @@
 //                    partial sums for the constants (lvl*, kpart, shape, gain, phi*)
 //   K2 pitch grads : g_cumsum -> suffix sums of g_arg (fp64, tile totals of the later tiles + in-tile reverse
 //                    scan) * d inc / d pitch -> g_pitchmod per sample, partial sums for f0 and depth
-//   K3 upsample^T  : g_ctrl[b,row,i] = sum_t W[t,i] * g_upc[b,row,t]  (a gather per control point: fixed
-//                    order, no atomics -> bit-reproducible)
-// Planes are caller-owned scratch [B,7,T] fp32; partials [B,ntiles,IAS_GRAD_NS] fp64 are summed by the caller.
+//   K3 upsample^T  : g_ctrl[b,row,i] = sum_t W[t,i] * g_upc[b,row,t] as per-interval sums (every sample read once,
+//                    staged in LDS, summed in a fixed order, no atomics -> bit-reproducible) + a combine pass
+// Planes are caller-owned scratch [B,8,T] fp32; partials [B,ntiles,IAS_GRAD_NS] fp64 are summed by the caller.
 #include "ias_common.h"
 #include "voice_math.h"
+#include <cstdint>
 
 #define GRAD_THREADS 256
 #define GRAD_WAVES (GRAD_THREADS / 64)
 #define GRAD_CHUNKS 16
 #define GRAD_TILE (GRAD_THREADS * GRAD_CHUNKS)
 #define IAS_GRAD_NS 12      // f0_1 depth_1 phi_1 f0_2 depth_2 phi_2 kpart shape gain lvl0 lvl1 lvl2
-#define IAS_GRAD_PLANES 7   // inc_1 inc_2 | g_amp1 g_amp2 g_ampn | g_arg1->g_pm1 g_arg2->g_pm2
+#define IAS_GRAD_PLANES 8   // inc_1 inc_2 | g_amp1 g_amp2 g_ampn | g_arg1->g_pm1 g_arg2->g_pm2 | interval sums of K3
 
 enum { GS_F0_1 = 0, GS_DEPTH_1, GS_PHI_1, GS_F0_2, GS_DEPTH_2, GS_PHI_2, GS_KPART, GS_SHAPE, GS_GAIN, GS_LVL0, GS_LVL1,
        GS_LVL2 };
-enum { PL_INC1 = 0, PL_INC2, PL_GAMP1, PL_GAMP2, PL_GAMPN, PL_GARG1, PL_GARG2 };
+enum { PL_INC1 = 0, PL_INC2, PL_GAMP1, PL_GAMP2, PL_GAMPN, PL_GARG1, PL_GARG2, PL_AB };
 
 __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
 #pragma unroll
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_sample_kernel(
   }
   // lvl0 lvl1 lvl2 kpart shape gain phi_1 phi_2
   double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  // (requesting all 16 chunks' inputs up front was measured: 194 VGPRs, 330 -> 490 us -- occupancy matters more here)
   for (int it = 0; it < GRAD_CHUNKS; ++it) {
     const int j = tile * GRAD_TILE + it * GRAD_THREADS + tid;
     const bool ok = j < T;
@@ -246,29 +248,102 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_pitch_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ K3
-// one wave per (control point, row): the samples whose lerp touches control point i lie in
-// [ (i-1)/scale, (i+1)/scale ]; each is tested with the forward's own index arithmetic.
+// Transposed linear upsample.  Sample j lerps between control points i0(j) = trunc(scale * j) and i0 + 1 with
+// weights (w0, w1), so g_ctrl[i] = A[i] + B[i-1] with the per-INTERVAL sums A[k] = sum_{i0(j)=k} w0 g,
+// B[k] = sum_{i0(j)=k} w1 g: every sample is read once.  A workgroup takes CT_INTERVALS consecutive intervals of
+// one row: their samples are one contiguous run (i0 is monotone), staged as (w0 g, w1 g) in LDS by coalesced
+// loads, then each wave sums whole intervals in a fixed order (no atomics: bit-reproducible).
+#define CT_INTERVALS 40
+#define CT_SUB 6              // threads per interval in the reduction (CT_INTERVALS * CT_SUB <= GRAD_THREADS)
+#define CT_CAP 4608          // staged samples per workgroup (host checks (CT_INTERVALS + 1) * (1/scale + 2) <= cap)
+
+// the voice's interval sums [5][Tc][2] fp64 live in its spare scratch plane (8-byte aligned inside it)
+__device__ __forceinline__ double* ct_interval_sums(float* planes, int b, int T) {
+  const uintptr_t p = (uintptr_t)(planes + ((size_t)b * IAS_GRAD_PLANES + PL_AB) * T);
+  return reinterpret_cast<double*>((p + 7) & ~(uintptr_t)7);
+}
+
+// first sample index whose control index is >= k (T if there is none); exact w.r.t. the forward's fp32 arithmetic
+__device__ __forceinline__ int ct_first_sample(int k, float scale, int T) {
+  if (k <= 0) return 0;
+  long long j = (long long)ceil((double)k / (double)scale);
+  if (j > T) j = T;
+  while (j > 0 && (int)ias_mul(scale, (float)(j - 1)) >= k) --j;
+  while (j < T && (int)ias_mul(scale, (float)j) < k) ++j;
+  return (int)j;
+}
+
 __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_ctrl_kernel(
-    const float* __restrict__ planes, float* __restrict__ g_ctrl /* [B][5][Tc] */, int T, int Tc, float scale) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * GRAD_WAVES + wave, row = blockIdx.y, b = blockIdx.z;
-  if (i >= Tc) return;
+    float* __restrict__ planes, int T, int Tc, float scale) {
+  __shared__ float s_p0[CT_CAP], s_p1[CT_CAP];
+  __shared__ int s_start[CT_INTERVALS + 1];
+  __shared__ int s_range[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k0 = blockIdx.x * CT_INTERVALS, row = blockIdx.y, b = blockIdx.z;
+  const int k1 = min(k0 + CT_INTERVALS, Tc), nk = k1 - k0;
   const int plane_of_row[IAS_NCTRL] = {PL_GARG1, PL_GAMP1, PL_GARG2, PL_GAMP2, PL_GAMPN};
   const float* src = planes + ((size_t)b * IAS_GRAD_PLANES + plane_of_row[row]) * T;
-  const double inv = 1.0 / (double)scale;
-  long long ta = (long long)floor((double)(i - 1) * inv) - 2, tb = (long long)ceil((double)(i + 1) * inv) + 2;
-  if (ta < 0) ta = 0;
-  if (tb > T - 1) tb = T - 1;
-  double acc = 0.0;
-  for (long long t = ta + lane; t <= tb; t += 64) {
-    int i0, i1; float w0, w1;
-    ias_interp_pos_fast((int)t, scale, Tc, i0, i1, w0, w1);
-    const float g = src[t];
-    if (i0 == i) acc += (double)w0 * (double)g;
-    if (i1 == i) acc += (double)w1 * (double)g;
+  if (tid < 2) s_range[tid] = ct_first_sample(tid == 0 ? k0 : k1, scale, T);
+  if (tid <= CT_INTERVALS) s_start[tid] = -1;
+  __syncthreads();
+  const int j_lo = s_range[0], n = s_range[1] - s_range[0];
+  float v_g[CT_CAP / GRAD_THREADS];
+#pragma unroll
+  for (int q = 0; q < CT_CAP / GRAD_THREADS; ++q) {          // all loads in flight before the first use
+    const int o = tid + q * GRAD_THREADS;
+    v_g[q] = o < n ? src[j_lo + o] : 0.0f;
   }
-  acc = wave_total(acc);
-  if (lane == 0) g_ctrl[((size_t)b * IAS_NCTRL + row) * Tc + i] = (float)acc;
+#pragma unroll
+  for (int q = 0; q < CT_CAP / GRAD_THREADS; ++q) {
+    const int o = tid + q * GRAD_THREADS;
+    if (o >= n) break;
+    const int j = j_lo + o;
+    int i0, i1; float w0, w1;
+    ias_interp_pos_fast(j, scale, Tc, i0, i1, w0, w1);
+    const float g = v_g[q];
+    s_p0[o] = w0 * g;
+    s_p1[o] = w1 * g;
+    if (o == 0 || (int)ias_mul(scale, (float)(j - 1)) != i0) s_start[i0 - k0] = o;   // first sample of its interval
+  }
+  if (tid == 0) s_start[nk] = n;
+  __syncthreads();
+  // CT_SUB threads per interval, each a strided run of its samples; then one thread adds the CT_SUB partial sums in
+  // a fixed order.  (A wave per interval with shuffle reductions was 3x slower: 12 dependent LDS-latency shuffles
+  // per interval.)
+  __shared__ double s_part[CT_INTERVALS][CT_SUB][2];
+  {
+    const int kk = tid / CT_SUB, sub = tid % CT_SUB;
+    if (kk < nk) {
+      const int lo = s_start[kk];
+      int hi = n;                                      // next interval that has samples (every one does for Tc <= T)
+      for (int q = kk + 1; q <= nk; ++q) if (s_start[q] >= 0) { hi = s_start[q]; break; }
+      double a = 0.0, c = 0.0;
+      if (lo >= 0)
+        for (int o = lo + sub; o < hi; o += CT_SUB) { a += (double)s_p0[o]; c += (double)s_p1[o]; }
+      s_part[kk][sub][0] = a; s_part[kk][sub][1] = c;
+    }
+  }
+  __syncthreads();
+  if (tid < nk) {
+    double a = 0.0, c = 0.0;
+#pragma unroll
+    for (int sub = 0; sub < CT_SUB; ++sub) { a += s_part[tid][sub][0]; c += s_part[tid][sub][1]; }
+    double* out = ct_interval_sums(planes, b, T) + ((size_t)row * Tc + k0) * 2;
+    out[2 * tid] = a; out[2 * tid + 1] = c;
+  }
+}
+
+// g_ctrl[i] = A[i] + B[i-1]; the last control point is its own upper neighbour (i1 = min(i0 + 1, Tc - 1))
+__global__ __launch_bounds__(GRAD_THREADS) void voice_grad_ctrl_combine_kernel(float* __restrict__ planes,
+                                                                               float* __restrict__ g_ctrl, int T,
+                                                                               int Tc) {
+  const int i = blockIdx.x * GRAD_THREADS + threadIdx.x, row = blockIdx.y, b = blockIdx.z;
+  if (i >= Tc) return;
+  const double* p = ct_interval_sums(planes, b, T) + (size_t)row * Tc * 2;
+  double v = p[2 * i];
+  if (i > 0) v += p[2 * (i - 1) + 1];
+  if (i == Tc - 1) v += p[2 * i + 1];
+  g_ctrl[((size_t)b * IAS_NCTRL + row) * Tc + i] = (float)v;
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -291,6 +366,9 @@ extern "C" int ias_voice_backward(const float* ctrl, const void* vconst, const f
   const int ntiles = (T + GRAD_TILE - 1) / GRAD_TILE;
   if (ntiles > 65535) return IAS_ERR_UNSUPPORTED;
   const float scale = (float)(Tc - 1) / (float)(T - 1);
+  // K3 stages CT_INTERVALS + 1 control intervals of samples in LDS and keeps its interval sums in the spare plane
+  if ((double)(CT_INTERVALS + 1) * ((double)(T - 1) / (double)(Tc - 1) + 2.0) > (double)CT_CAP) return IAS_ERR_UNSUPPORTED;
+  if ((size_t)IAS_NCTRL * Tc * 2 * sizeof(double) + 8 > (size_t)T * sizeof(float)) return IAS_ERR_UNSUPPORTED;
   const IasVoiceConst* vc = (const IasVoiceConst*)vconst;
   const dim3 grid(ntiles, B), block(GRAD_THREADS);
   hipLaunchKernelGGL(voice_grad_inc_kernel, grid, block, 0, stream, ctrl, vc, planes, tile_sums, T, Tc, ntiles,
@@ -299,7 +377,9 @@ extern "C" int ias_voice_backward(const float* ctrl, const void* vconst, const f
                      partials, T, Tc, ntiles, scale);
   hipLaunchKernelGGL(voice_grad_pitch_kernel, grid, block, 0, stream, ctrl, vc, planes, partials, T, Tc, ntiles,
                      scale);
-  hipLaunchKernelGGL(voice_grad_ctrl_kernel, dim3((Tc + GRAD_WAVES - 1) / GRAD_WAVES, IAS_NCTRL, B), block, 0, stream,
-                     planes, g_ctrl, T, Tc, scale);
+  hipLaunchKernelGGL(voice_grad_ctrl_kernel, dim3((Tc + CT_INTERVALS - 1) / CT_INTERVALS, IAS_NCTRL, B), block, 0,
+                     stream, planes, T, Tc, scale);
+  hipLaunchKernelGGL(voice_grad_ctrl_combine_kernel, dim3((Tc + GRAD_THREADS - 1) / GRAD_THREADS, IAS_NCTRL, B), block,
+                     0, stream, planes, g_ctrl, T, Tc);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
