@@ -25,6 +25,7 @@
 // Planes are caller-owned scratch [B,8,T] fp32; partials [B,ntiles,IAS_GRAD_NS] fp64 are summed by the caller.
 #include "ias_common.h"
 #include "voice_math.h"
+#include "wave_ops.h"
 #include <cstdint>
 
 #define GRAD_THREADS 256
@@ -38,19 +39,9 @@ enum { GS_F0_1 = 0, GS_DEPTH_1, GS_PHI_1, GS_F0_2, GS_DEPTH_2, GS_PHI_2, GS_KPAR
        GS_LVL2 };
 enum { PL_INC1 = 0, PL_INC2, PL_GAMP1, PL_GAMP2, PL_GAMPN, PL_GARG1, PL_GARG2, PL_AB };
 
-__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const double o = __shfl_up(v, d, 64);
-    if (lane >= d) v += o;
-  }
-  return v;
-}
-__device__ __forceinline__ double wave_total(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
-}
+// (wave_incl_scan: DPP moves, wave_ops.h -- a shuffle of doubles is two ds_bpermute round trips per step, and the
+// chunk loops below are chains of such scans)
+__device__ __forceinline__ double wave_total(double v) { return wave_sum(v); }
 
 // Inclusive scan of one value per thread over the workgroup (thread order); returns the scanned value and
 // adds the workgroup total to `carry` (same value in every thread).  s_w: GRAD_WAVES doubles of LDS.

@@ -17,6 +17,7 @@
 // HBM traffic per audio sample: noise 4 B read + 4 B write (pass 1), 4 B read + 4 B write
 // (normalise).  Control-rate traffic is < 0.1 %.
 #include "voice_math.h"
+#include "wave_ops.h"
 #include "voice_table.h"
 
 #define VOICE_THREADS 256                     // control-rate kernels
@@ -33,37 +34,7 @@
 
 __constant__ IasParamRange c_param_table[IAS_NPARAMS] = IAS_PARAM_TABLE_INIT;
 
-// ------------------------------------------------------------------ wave helpers
-// Inclusive wave64 scan of doubles with DPP moves (no LDS crossbar, no selects): Hillis-Steele inside
-// each row of 16 lanes (row_shr:d shifts zeros in), then row_bcast:15 / row_bcast:31 carry the row totals
-// across rows.  Every step adds +0.0 where nothing arrives, which is exact.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_move(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
-  (void)lane;
-  v += dpp_move<0x111, 0xf>(v);   // row_shr:1
-  v += dpp_move<0x112, 0xf>(v);   // row_shr:2
-  v += dpp_move<0x114, 0xf>(v);   // row_shr:4
-  v += dpp_move<0x118, 0xf>(v);   // row_shr:8
-  v += dpp_move<0x142, 0xa>(v);   // row_bcast:15 -> rows 1 and 3
-  v += dpp_move<0x143, 0xc>(v);   // row_bcast:31 -> rows 2 and 3
-  return v;
-}
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
-  return v;
-}
+// wave helpers (DPP scans, reductions): wave_ops.h
 
 // ------------------------------------------------------------------ control rate
 __device__ __forceinline__ float mapped_param(const float* __restrict__ params01, int b, int idx) {
