@@ -13,7 +13,8 @@
 //           G[k] = 2 gP[k] X[k];  g x_f[n] = Re sum_{k<=N/2} G[k] e^{+2 pi i k n / N}   (upper half zero, no Hermitian
 //           doubling: each one-sided bin enters the loss once);  g a = reflect-pad^T overlap-add (w * g x_f)
 //
-// K_a one workgroup per frame: forward FFT, the adjoint chain, inverse FFT -> frame_grad [B,F,N] (scratch).
+// K_a one workgroup per PAIR of frames (one complex FFT carries two real frames in each direction): forward FFT,
+//     the adjoint chain per frame, inverse FFT -> frame_grad [B,F,N] (scratch).
 // K_b one lane per audio sample: gathers the frames (and reflected positions) that cover it in a fixed order --
 //     no atomics across workgroups, bit-reproducible.
 // The FFT is a plain Stockham radix-4 through LDS (natural order in and out, twiddles from an LDS table built with
@@ -82,15 +83,30 @@ struct SgArgs {
   float scale;
 };
 
+// Two frames per workgroup share each FFT: z = x_a + i x_b has Z[k] = X_a[k] + i X_b[k], so
+//   X_a[k] = (Z[k] + conj Z[N-k]) / 2,   X_b[k] = (Z[k] - conj Z[N-k]) / (2i),
+// and on the way back the two REAL gradient frames come out of one inverse transform of H_a + i H_b, where H_r is
+// the Hermitian extension whose inverse DFT is y_r[n] = Re sum_{k<=N/2} G_r[k] e^{+i theta}:
+//   H_r[k] = G_r[k] / 2 = gP_r[k] X_r[k] (0 < k < N/2),  H_r[N-k] = conj H_r[k],  H_r[0] = G_r[0],  H_r[N/2] = G_r[N/2].
+__device__ __forceinline__ sg_cpx sg_frame_bin(const sg_cpx* Z, int k, int N, int which) {
+  const sg_cpx z = Z[k], zc = Z[(N - k) & (N - 1)];
+  // which 0: (z + conj zc)/2;  1: (z - conj zc)/(2i) = ((z.y + zc.y)/2, -(z.x - zc.x)/2)
+  return which == 0 ? make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y))
+                    : make_float2(0.5f * (z.y + zc.y), -0.5f * (z.x - zc.x));
+}
+
 __global__ __launch_bounds__(SG_THREADS) void stft_grad_frames_kernel(SgArgs g) {
   extern __shared__ __attribute__((aligned(16))) float sg_smem[];
-  const int N = g.N, NB = N / 2 + 1, tid = threadIdx.x, f = blockIdx.x, b = blockIdx.y;
+  const int N = g.N, NB = N / 2 + 1, tid = threadIdx.x, b = blockIdx.y;
+  const int fa = 2 * blockIdx.x;                 // frames fa and fa + 1 (the second may not exist)
+  const int nfr = min(2, g.F - fa);
   sg_cpx* bufa = reinterpret_cast<sg_cpx*>(sg_smem);
   sg_cpx* bufb = bufa + N;
   sg_cpx* tab = bufb + N;                    // N/2
-  float* sP = reinterpret_cast<float*>(tab + N / 2);   // NB (+ pad)
+  float* sP = reinterpret_cast<float*>(tab + N / 2);   // NB (+ pad): values of the frame being processed
   float* sGV = sP + (NB + 3);                // NB
   float* sGO = sGV + (NB + 3);               // n_out
+  float* sGP = sGO + ((g.n_out + 3) & ~3);   // [2][NB + 3]: d loss / d |X|^2 of the two frames
 
   const int pad = N / 2;
   const float* arow = g.audio + (size_t)b * g.T;
@@ -100,61 +116,84 @@ __global__ __launch_bounds__(SG_THREADS) void stft_grad_frames_kernel(SgArgs g) 
     tab[j] = make_float2(c, -s);
   }
   for (int n = tid; n < N; n += SG_THREADS) {
-    int r = f * g.hop + n - pad;
-    if (r < 0) r = -r;
-    if (r >= g.T) r = 2 * (g.T - 1) - r;
-    bufa[n] = make_float2(g.window[n] * arow[r], 0.0f);
+    float v[2] = {0.0f, 0.0f};
+    for (int r = 0; r < nfr; ++r) {
+      int q = (fa + r) * g.hop + n - pad;
+      if (q < 0) q = -q;
+      if (q >= g.T) q = 2 * (g.T - 1) - q;
+      v[r] = arow[q];
+    }
+    const float w = g.window[n];
+    bufa[n] = make_float2(w * v[0], w * v[1]);
   }
-  sg_cpx* X = sg_fft<-1>(bufa, bufb, tab, N, g.log2n, tid);
-  sg_cpx* other = (X == bufa) ? bufb : bufa;
+  sg_cpx* Z = sg_fft<-1>(bufa, bufb, tab, N, g.log2n, tid);
+  sg_cpx* other = (Z == bufa) ? bufb : bufa;
 
-  for (int k = tid; k < NB; k += SG_THREADS) {
-    const float p = X[k].x * X[k].x + X[k].y * X[k].y;
-    sP[k] = g.power2 ? p : sqrtf(p);         // V
-    sGV[k] = 0.0f;
-  }
-  __syncthreads();
-  const float* trow = g.target + ((size_t)b * g.F + f) * g.n_out;
-  for (int o = tid; o < g.n_out; o += SG_THREADS) {
-    float v;
-    if (g.mel_start) {
-      const int s0 = g.mel_start[o], cnt = g.mel_count[o];
-      const float* w = g.mel_w + g.mel_woff[o];
-      v = 0.0f;
-      for (int c = 0; c < cnt; ++c) v = fmaf(w[c], sP[s0 + c], v);
-    } else {
-      v = sP[o];
+  for (int r = 0; r < 2; ++r) {
+    float* gp = sGP + r * (NB + 3);
+    if (r >= nfr) {
+      for (int k = tid; k < NB; k += SG_THREADS) gp[k] = 0.0f;
+      continue;
     }
-    const float d = v - trow[o];
-    sGO[o] = d > 0.0f ? g.scale : (d < 0.0f ? -g.scale : 0.0f);
-  }
-  __syncthreads();
-  if (g.mel_start) {
-    // a bin lies under at most two triangular filters: the (commutative) sum of two terms does not depend on the
-    // order of the LDS atomics
+    for (int k = tid; k < NB; k += SG_THREADS) {
+      const sg_cpx x = sg_frame_bin(Z, k, N, r);
+      const float p = x.x * x.x + x.y * x.y;
+      sP[k] = g.power2 ? p : sqrtf(p);         // V
+      sGV[k] = 0.0f;
+    }
+    __syncthreads();
+    const float* trow = g.target + ((size_t)b * g.F + fa + r) * g.n_out;
     for (int o = tid; o < g.n_out; o += SG_THREADS) {
-      const int s0 = g.mel_start[o], cnt = g.mel_count[o];
-      const float* w = g.mel_w + g.mel_woff[o];
-      const float go = sGO[o];
-      for (int c = 0; c < cnt; ++c) atomicAdd(&sGV[s0 + c], w[c] * go);
+      float v;
+      if (g.mel_start) {
+        const int s0 = g.mel_start[o], cnt = g.mel_count[o];
+        const float* w = g.mel_w + g.mel_woff[o];
+        v = 0.0f;
+        for (int c = 0; c < cnt; ++c) v = fmaf(w[c], sP[s0 + c], v);
+      } else {
+        v = sP[o];
+      }
+      const float d = v - trow[o];
+      sGO[o] = d > 0.0f ? g.scale : (d < 0.0f ? -g.scale : 0.0f);
     }
-  } else {
-    for (int k = tid; k < NB; k += SG_THREADS) sGV[k] = sGO[k];
+    __syncthreads();
+    if (g.mel_start) {
+      // a bin lies under at most two triangular filters: the (commutative) sum of two terms does not depend on
+      // the order of the LDS atomics
+      for (int o = tid; o < g.n_out; o += SG_THREADS) {
+        const int s0 = g.mel_start[o], cnt = g.mel_count[o];
+        const float* w = g.mel_w + g.mel_woff[o];
+        const float go = sGO[o];
+        for (int c = 0; c < cnt; ++c) atomicAdd(&sGV[s0 + c], w[c] * go);
+      }
+    } else {
+      for (int k = tid; k < NB; k += SG_THREADS) sGV[k] = sGO[k];
+    }
+    __syncthreads();
+    for (int k = tid; k < NB; k += SG_THREADS) {
+      float v = sGV[k];
+      if (!g.power2) v = sP[k] > 0.0f ? v / (2.0f * sP[k]) : 0.0f;   // d sqrt(P) / dP, 0 at P = 0
+      gp[k] = v;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  // G[k] = 2 gP[k] X[k] on the one-sided bins, zero above; written to the other buffer's place of X
+  // inverse input H_a + i H_b (see above), natural order in `other`
   for (int k = tid; k < N; k += SG_THREADS) {
-    sg_cpx o = make_float2(0.0f, 0.0f);
-    if (k < NB) {
-      float gp = sGV[k];
-      if (!g.power2) gp = sP[k] > 0.0f ? gp / (2.0f * sP[k]) : 0.0f;   // d sqrt(P) / dP, 0 at P = 0
-      o = make_float2(2.0f * gp * X[k].x, 2.0f * gp * X[k].y);
+    const int kk = k <= N / 2 ? k : N - k;                   // the one-sided bin this entry mirrors
+    const bool edge = kk == 0 || kk == N / 2;
+    sg_cpx h[2];
+    for (int r = 0; r < 2; ++r) {
+      const sg_cpx x = sg_frame_bin(Z, kk, N, r);
+      const float gpv = sGP[r * (NB + 3) + kk] * (edge ? 2.0f : 1.0f);
+      h[r] = make_float2(gpv * x.x, edge ? 0.0f : (k <= N / 2 ? gpv * x.y : -gpv * x.y));
     }
-    other[k] = o;
+    other[k] = make_float2(h[0].x - h[1].y, h[0].y + h[1].x);   // H_a + i H_b
   }
-  sg_cpx* Y = sg_fft<+1>(other, X, tab, N, g.log2n, tid);
-  float* out = g.frame_grad + ((size_t)b * g.F + f) * N;
-  for (int n = tid; n < N; n += SG_THREADS) out[n] = g.window[n] * Y[n].x;
+  sg_cpx* Y = sg_fft<+1>(other, Z, tab, N, g.log2n, tid);
+  for (int r = 0; r < nfr; ++r) {
+    float* out = g.frame_grad + ((size_t)b * g.F + fa + r) * N;
+    for (int n = tid; n < N; n += SG_THREADS) out[n] = g.window[n] * (r == 0 ? Y[n].x : Y[n].y);
+  }
 }
 
 // g_audio[b,j] = g_loss * sum over the padded positions q that read audio[j] (itself and its reflections) of the
@@ -210,10 +249,11 @@ extern "C" int ias_stft_l1_backward(const float* audio, const float* window, con
   g.T = T; g.F = F; g.N = n_fft; g.log2n = n_fft == 512 ? 9 : (n_fft == 1024 ? 10 : 11); g.hop = hop;
   g.n_out = n_out; g.power2 = power == 2; g.scale = scale;
   const int NB = n_fft / 2 + 1;
-  const size_t lds = sizeof(sg_cpx) * (2 * (size_t)n_fft + n_fft / 2) + sizeof(float) * (2 * (size_t)(NB + 3) + n_out);
+  const size_t lds = sizeof(sg_cpx) * (2 * (size_t)n_fft + n_fft / 2) +
+                     sizeof(float) * (4 * (size_t)(NB + 3) + ((n_out + 3) & ~3));
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)stft_grad_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(stft_grad_frames_kernel, dim3(F, B), dim3(SG_THREADS), lds, stream, g);
+  hipLaunchKernelGGL(stft_grad_frames_kernel, dim3((F + 1) / 2, B), dim3(SG_THREADS), lds, stream, g);
   hipLaunchKernelGGL(stft_grad_ola_kernel, dim3((T + SG_THREADS - 1) / SG_THREADS, B), dim3(SG_THREADS), 0, stream,
                      frame_grad, g_loss, g_audio, T, F, n_fft, hop);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
