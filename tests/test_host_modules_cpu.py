@@ -60,3 +60,26 @@ def test_product_has_no_cpu_fallback():
     from inverse_audio_synthesis_amd.pqmf import PQMF
     with pytest.raises(RuntimeError):
         PQMF(N=3)(torch.zeros(1, 1, 1000))
+
+
+def test_control_graph_restates_the_oracle_control_pass():
+    """voice_grad.control_graph (the differentiable definition the HIP control backward is tested against) computes
+    the oracle's control signals and per-voice constants, and autograd through it gives the oracle's gradients."""
+    import importlib
+    import torch
+    from oracle import synth_oracle as so
+    vg = importlib.import_module("inverse_audio_synthesis_amd.voice_grad")
+    from inverse_audio_synthesis_amd.voice import SynthConfig
+    cfg_o = so.VoiceConfig(batch_size=4, sample_rate=16000, buffer_size_seconds=1.0)
+    cfg = SynthConfig(batch_size=4, sample_rate=16000, buffer_size_seconds=1.0, reproducible=False)
+    for seed in range(3):
+        p = so.sample_params01(cfg_o, seed).double().requires_grad_(True)
+        ctrl, scal = vg.control_graph(p, cfg)
+        octrl, op = so.control_signals(cfg_o, p, "f64")
+        assert (ctrl - octrl).abs().max().item() <= 1e-6
+        assert abs(scal[0, 0].item() - (op("keyboard", "midi_f0") + op("vco_1", "tuning"))[0].item()) <= 1e-9
+        w = torch.randn(ctrl.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
+        (g1,) = torch.autograd.grad((ctrl * w).sum(), p, retain_graph=True)
+        (g2,) = torch.autograd.grad((octrl * w).sum(), p)
+        assert torch.isfinite(g1).all()
+        assert ((g1 - g2).norm() / g2.norm()).item() <= 1e-6
