@@ -186,6 +186,12 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
     if (lane < a.n_out) { h_sa = s_meli[lane]; h_na = s_meli[a.n_out + lane]; h_wa = s_meli[2 * a.n_out + lane]; }
     if (lane + 64 < a.n_out) { h_sb = s_meli[lane + 64]; h_nb = s_meli[a.n_out + lane + 64]; h_wb = s_meli[2 * a.n_out + lane + 64]; }
   }
+  int h_nmaxa = h_na, h_nmaxb = h_nb;   // wave-wide longest filter of each output group (uniform)
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    h_nmaxa = max(h_nmaxa, __shfl_xor(h_nmaxa, d, 64));
+    h_nmaxb = max(h_nmaxb, __shfl_xor(h_nmaxb, d, 64));
+  }
   const int f_begin = blockIdx.x * a.groups * SP_FPB;
   const int f_end = min(f_begin + a.groups * SP_FPB, a.F);
 
@@ -300,19 +306,38 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
           }
           const float* wa = s_melw + woa;
           const float* wb = s_melw + wob;
-          int nmax = max(na, nb);
+          // the two outputs of a lane run as two loops with their own wave-wide trip counts: with mel filters the
+          // lower 64 outputs are a fifth as wide as the upper 64 (5 vs 27 bins at 128 mels / 513 bins), so a
+          // common loop spends most of its slots on zero weights.  The trip counts are frame-invariant: for the
+          // first 128 outputs they are reduced once, before the frame loop.
+          int nmaxa = h_nmaxa, nmaxb = h_nmaxb;
+          if (m0 != 0) {
+            nmaxa = na; nmaxb = nb;
 #pragma unroll
-          for (int d = 32; d > 0; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d, 64));
-          for (int j = 0; j < nmax; j += 4) {
-            float pa[4], pb[4], ca[4], cb[4];
+            for (int d = 32; d > 0; d >>= 1) {
+              nmaxa = max(nmaxa, __shfl_xor(nmaxa, d, 64));
+              nmaxb = max(nmaxb, __shfl_xor(nmaxb, d, 64));
+            }
+          }
+          for (int j = 0; j < nmaxa; j += 4) {
+            float pa[4], ca[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const bool ia = j + e < na, ib = j + e < nb;
+              const bool ia = j + e < na;
               pa[e] = P[ia ? sa + j + e : 0]; ca[e] = ia ? wa[j + e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) va = fmaf(ca[e], pa[e], va);
+          }
+          for (int j = 0; j < nmaxb; j += 4) {
+            float pb[4], cb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool ib = j + e < nb;
               pb[e] = P[ib ? sb + j + e : 0]; cb[e] = ib ? wb[j + e] : 0.f;
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { va = fmaf(ca[e], pa[e], va); vb = fmaf(cb[e], pb[e], vb); }
+            for (int e = 0; e < 4; ++e) vb = fmaf(cb[e], pb[e], vb);
           }
         } else {
           va = oka ? P[ma] : 0.f;
