@@ -22,10 +22,12 @@ __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
   v += dpp_move<0x143, 0xc>(v);   // row_bcast:31 -> rows 2 and 3
   return v;
 }
+// wave64 sum, the same value in every lane: the DPP scan's last lane, read back with v_readlane (a butterfly of
+// __shfl_xor on doubles is 12 dependent ds_bpermute round trips)
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
+  v = wave_incl_scan(v, 0);
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
