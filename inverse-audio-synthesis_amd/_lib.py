@@ -9,6 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# IAS_HIP_LIB: developer override used by scripts/diag to time alternative builds of the same C ABI
 LIB_PATH = os.environ.get("IAS_HIP_LIB") or os.path.join(_HERE, "csrc", "libias_hip.so")
 
 _ERRORS = {
