@@ -98,3 +98,30 @@ def test_stft_random_shapes(lib, dev):
         out = STFTPlan(n_fft, win, hop).to(dev).values(x.to(dev), VALUE_POWER).transpose(1, 2).cpu()
         assert out.shape == ref.shape, (n_fft, win, hop, T)
         assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item(), (n_fft, win, hop, T)
+
+
+def test_c_abi_rejects_bad_arguments(lib, dev):
+    """Every entry point returns a negative IAS_ERR_* for null pointers / impossible dimensions instead of launching
+    (the reference's behaviour at this boundary is a bare assert / exception)."""
+    from inverse_audio_synthesis_amd import _lib
+    z = torch.zeros(64, device=dev)
+    zd = torch.zeros(64, device=dev, dtype=torch.float64)
+    p = _lib.ptr
+    ARG, UNSUP = -1, -2
+    assert lib.ias_voice_backward(None, p(z), p(z), p(z), p(z), p(zd), p(zd), p(z), 1, 16000, 441, 16000, None) == ARG
+    assert lib.ias_voice_backward(p(z), p(z), p(z), p(z), p(z), p(zd), p(zd), p(z), 0, 16000, 441, 16000, None) == ARG
+    # a control rate too close to the sample rate: the transposed upsample cannot stage its intervals
+    assert lib.ias_voice_backward(p(z), p(z), p(z), p(z), p(z), p(zd), p(zd), p(z), 1, 64, 60, 16000, None) == UNSUP
+    assert lib.ias_voice_control_backward(None, p(z), p(zd), p(z), 1, 441, 441, None) == ARG
+    assert lib.ias_voice_control_backward(p(z), p(z), p(zd), p(z), 1, 441, 440, None) == UNSUP     # kernel is built for 441
+    assert lib.ias_voice_control_backward(p(z), p(z), p(zd), p(z), 1, 100000, 441, None) == UNSUP  # does not fit LDS
+    assert lib.ias_stft_l1_backward(p(z), p(z), None, None, None, None, p(z), None, p(z), p(z), 1, 4000, 1000, 256, 501,
+                                    2, 1.0, None) == UNSUP          # n_fft not 512 / 1024 / 2048
+    assert lib.ias_stft_l1_backward(p(z), p(z), None, None, None, None, p(z), None, p(z), p(z), 1, 400, 1024, 256, 513,
+                                    2, 1.0, None) == ARG            # T <= n_fft / 2: reflect padding impossible
+    assert lib.ias_stft_l1_backward(p(z), p(z), None, None, None, None, p(z), None, p(z), p(z), 1, 4000, 1024, 256, 128,
+                                    2, 1.0, None) == ARG            # linear bins need n_out = n_fft / 2 + 1
+    assert lib.ias_pqmf_pack_taps(p(z), p(z), 200, 63, None) == ARG                  # no packed layout for N > 64
+    assert lib.ias_pqmf_packed_taps_len(200, 63) == 0 and lib.ias_pqmf_packed_taps_len(3, 63) > 0
+    assert lib.ias_pqmf_analysis(p(z), p(z), None, p(z), None, None, 1, 64, 3, 62, None) == ARG   # even tap count
+    torch.cuda.synchronize()
