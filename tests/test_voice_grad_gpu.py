@@ -143,3 +143,22 @@ def test_hip_control_backward_matches_torch_graph(lib, dev, B, sr, sec):
         assert got is not None and torch.isfinite(got).all()
         for b in range(B):
             assert rel_l2(got[b].cpu(), ref[b].cpu()) <= 1e-5, (seed, b, rel_l2(got[b].cpu(), ref[b].cpu()))
+
+
+def test_gradient_is_finite_at_the_ends_of_the_parameter_ranges(lib, dev):
+    """Parameters at (almost) 0, 1 and mid-range: zero-length envelope segments, clamped pitches, unit ramps -- the
+    places where plain autograd produces 0 * inf.  The HIP gradient stays finite and matches the fp64 oracle's
+    (which uses the same 'gradient 0 at the kink' conventions) where that one is finite too."""
+    cfg = so.VoiceConfig(3, 16000, 1.0)
+    v = _voice(dev, 3, 16000, 1.0)
+    p0 = torch.stack([torch.full((78,), 0.999), torch.full((78,), 0.5), torch.full((78,), 1e-3)])
+    w = torch.randn((3, cfg.buffer_size), generator=torch.Generator().manual_seed(3))
+    p = p0.to(dev).requires_grad_(True)
+    (v.render(p) * w.to(dev)).sum().backward()
+    g = p.grad.cpu().double()
+    assert torch.isfinite(g).all()
+    ref = _oracle_grad(cfg, p0, so.make_noise(cfg), w, True)
+    ok = torch.isfinite(ref)
+    for b in range(3):
+        if ok[b].all() and ref[b].norm() > 0:
+            assert rel_l2(g[b], ref[b]) <= 5e-2, (b, rel_l2(g[b], ref[b]))
