@@ -137,15 +137,18 @@ int ias_stft(const float* audio, const float* tables, const int* mel_start, cons
              double* partials, int B, int T, int n_fft, int hop, int n_out, int value_mode, int loss_mode,
              float eps, void* stream);
 
-/* Backward of the L1 spectral losses (the reference's mel-L1 loop audio_to_params.py:150-153 is
- * commented out and would have used torchaudio's differentiable modules):
- *   g_audio [B,T] = g_loss[0] * d (scale * sum |V(audio) - target|) / d audio,  V = (mel of) |STFT|^power.
+/* Backward of the spectral losses w.r.t. the audio (the reference's mel-L1 loop
+ * audio_to_params.py:150-153 is commented out and would have used torchaudio's differentiable modules, its MR-STFT
+ * is the auraloss TODO at audio_to_params.py:233):
+ *   loss_mode 1: g_audio [B,T] = g_loss[0] * d (scale * sum |V(audio) - target|) / d audio, V = (mel of) |STFT|^power;
+ *   loss_mode 2: one resolution of the MR-STFT loss (linear bins, power 1, V = sqrt(max(|X|^2, eps))), cotangent
+ *                coef[0] (V - target) + coef[1] sign(V - target) / V with coef a device double[2].
  * window [n_fft] on the device; mel_* as for ias_stft (NULL = linear bins, n_out = n_fft/2+1); target [B,F,n_out]
  * frames-major; power 1 or 2; g_loss a device scalar (NULL = 1); frame_grad [B,F,n_fft] fp32 scratch. */
-int ias_stft_l1_backward(const float* audio, const float* window, const int* mel_start, const int* mel_count,
-                         const int* mel_woff, const float* mel_w, const float* target, const float* g_loss,
-                         float* frame_grad, float* g_audio, int B, int T, int n_fft, int hop, int n_out, int power,
-                         float scale, void* stream);
+int ias_stft_loss_backward(const float* audio, const float* window, const int* mel_start, const int* mel_count,
+                           const int* mel_woff, const float* mel_w, const float* target, const float* g_loss,
+                           const double* coef, float* frame_grad, float* g_audio, int B, int T, int n_fft, int hop,
+                           int n_out, int power, int loss_mode, float scale, float eps, void* stream);
 
 /* sums[3] (doubles) = column sums of partials [n][3], fixed order (deterministic); when mean_out is not
  * NULL also mean_out[0] = (float)(sums[0] * scale). */

@@ -80,7 +80,9 @@ struct SgArgs {
   const float* target;    // [B,F,n_out]
   float* frame_grad;      // [B,F,N]
   int T, F, N, log2n, hop, n_out, power2;
-  float scale;
+  int loss_mode;          // 1: scale * sum |V - t|;  2: MR-STFT term, V = sqrt(max(|X|^2, eps))
+  const double* coef;     // loss_mode 2: device [2] = {c0, c1}: gO = c0 (V - t) + c1 sign(V - t) / V
+  float scale, eps;
 };
 
 // Two frames per workgroup share each FFT: z = x_a + i x_b has Z[k] = X_a[k] + i X_b[k], so
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(SG_THREADS) void stft_grad_frames_kernel(SgArgs g) 
     for (int k = tid; k < NB; k += SG_THREADS) {
       const sg_cpx x = sg_frame_bin(Z, k, N, r);
       const float p = x.x * x.x + x.y * x.y;
-      sP[k] = g.power2 ? p : sqrtf(p);         // V
+      sP[k] = g.power2 ? p : sqrtf(g.loss_mode == 2 ? fmaxf(p, g.eps) : p);         // V
       sGV[k] = 0.0f;
     }
     __syncthreads();
@@ -154,7 +156,13 @@ __global__ __launch_bounds__(SG_THREADS) void stft_grad_frames_kernel(SgArgs g) 
         v = sP[o];
       }
       const float d = v - trow[o];
-      sGO[o] = d > 0.0f ? g.scale : (d < 0.0f ? -g.scale : 0.0f);
+      const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+      if (g.loss_mode == 2) {
+        // spectral convergence ||T - V||_F / ||T||_F and mean |log V - log T| (log is monotone: sign(V - T))
+        sGO[o] = (float)g.coef[0] * d + (float)g.coef[1] * sg / v;
+      } else {
+        sGO[o] = sg * g.scale;
+      }
     }
     __syncthreads();
     if (g.mel_start) {
@@ -172,7 +180,11 @@ __global__ __launch_bounds__(SG_THREADS) void stft_grad_frames_kernel(SgArgs g) 
     __syncthreads();
     for (int k = tid; k < NB; k += SG_THREADS) {
       float v = sGV[k];
-      if (!g.power2) v = sP[k] > 0.0f ? v / (2.0f * sP[k]) : 0.0f;   // d sqrt(P) / dP, 0 at P = 0
+      if (!g.power2) {
+        // d sqrt(P) / dP, 0 at P = 0; MR-STFT clamps P at eps first (clamp passes the gradient at P >= eps)
+        const bool live = g.loss_mode == 2 ? sP[k] > sqrtf(g.eps) : sP[k] > 0.0f;   // V == sqrt(eps): clamped bin
+        v = live ? v / (2.0f * sP[k]) : 0.0f;
+      }
       gp[k] = v;
     }
     __syncthreads();
@@ -223,19 +235,25 @@ __global__ __launch_bounds__(SG_THREADS) void stft_grad_ola_kernel(const float* 
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
-// d (scale * sum |V(audio) - target|) / d audio, times the device scalar g_loss[0] (NULL = 1).
+// loss_mode 1: d (scale * sum |V(audio) - target|) / d audio, times the device scalar g_loss[0] (NULL = 1).
+// loss_mode 2: one resolution of the MR-STFT loss (linear bins, power 1, V = sqrt(max(|X|^2, eps))):
+//   d / d audio of  c0' ||T - V||_F^2 / 2 ... given directly through its cotangent gO = coef[0] (V - T) +
+//   coef[1] sign(V - T) / V with the device doubles coef[2] (the caller derives them from the forward's sums:
+//   coef[0] = g / (sqrt(sum (T-V)^2) sqrt(sum T^2)), coef[1] = g / count, both divided by the number of resolutions).
 //   audio [B,T]; window [n_fft] (device); mel_* : the forward's CSR filterbank (NULL = linear bins, n_out = n_fft/2+1);
 //   target [B,F,n_out] frames-major (what ias_stft wrote for the target); power: 1 (magnitude) or 2 (power);
 //   frame_grad [B,F,n_fft] fp32 scratch; g_audio [B,T] out.  F = ias_stft_num_frames(T, n_fft, hop).
-extern "C" int ias_stft_l1_backward(const float* audio, const float* window, const int* mel_start,
-                                    const int* mel_count, const int* mel_woff, const float* mel_w,
-                                    const float* target, const float* g_loss, float* frame_grad, float* g_audio,
-                                    int B, int T, int n_fft, int hop, int n_out, int power, float scale,
-                                    void* stream_) {
+extern "C" int ias_stft_loss_backward(const float* audio, const float* window, const int* mel_start,
+                                      const int* mel_count, const int* mel_woff, const float* mel_w,
+                                      const float* target, const float* g_loss, const double* coef, float* frame_grad,
+                                      float* g_audio, int B, int T, int n_fft, int hop, int n_out, int power,
+                                      int loss_mode, float scale, float eps, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!audio || !window || !target || !frame_grad || !g_audio || B <= 0 || B > 65535 || hop <= 0) return IAS_ERR_ARG;
   if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return IAS_ERR_UNSUPPORTED;
   if (power != 1 && power != 2) return IAS_ERR_UNSUPPORTED;
+  if (loss_mode != 1 && loss_mode != 2) return IAS_ERR_UNSUPPORTED;
+  if (loss_mode == 2 && (!coef || power != 1 || mel_start != nullptr)) return IAS_ERR_ARG;
   if (T <= n_fft / 2) return IAS_ERR_ARG;
   const bool mel = mel_start != nullptr;
   if (mel && (!mel_count || !mel_woff || !mel_w)) return IAS_ERR_ARG;
@@ -248,6 +266,7 @@ extern "C" int ias_stft_l1_backward(const float* audio, const float* window, con
   g.mel_w = mel_w; g.target = target; g.frame_grad = frame_grad;
   g.T = T; g.F = F; g.N = n_fft; g.log2n = n_fft == 512 ? 9 : (n_fft == 1024 ? 10 : 11); g.hop = hop;
   g.n_out = n_out; g.power2 = power == 2; g.scale = scale;
+  g.loss_mode = loss_mode; g.coef = coef; g.eps = eps;
   const int NB = n_fft / 2 + 1;
   const size_t lds = sizeof(sg_cpx) * (2 * (size_t)n_fft + n_fft / 2) +
                      sizeof(float) * (4 * (size_t)(NB + 3) + ((n_out + 3) & ~3));

@@ -10,7 +10,8 @@ The reference has no live spectral-loss code.  This module implements the spec i
 Filterbank / window / twiddle tables are built once on the host; every per-sample operation runs
 in the HIP kernel.  The L1 losses (``MelSpectrogramL1``, ``STFTL1``) are differentiable with respect to the audio
 (``csrc/spectral_grad_kernels.hip``): with ``Voice.render`` that closes the audio -> params -> synth -> mel-L1 loop
-the reference left commented out (audio_to_params.py:56-172).  ``MultiResolutionSTFTLoss`` is forward only.
+the reference left commented out (audio_to_params.py:56-172); ``MultiResolutionSTFTLoss`` is differentiable with
+respect to its first argument (the prediction) through the same kernels.
 """
 import ctypes
 import math
@@ -160,13 +161,13 @@ class _L1LossFn(torch.autograd.Function):
         frame_grad = torch.empty((B, F, plan.n_fft), dtype=torch.float32, device=a.device)
         g_audio = torch.empty_like(a)
         gl = g_loss.to(torch.float32).reshape(1).contiguous()
-        st = lib.ias_stft_l1_backward(
+        st = lib.ias_stft_loss_backward(
             _lib.ptr(a), _lib.ptr(plan.window), _lib.ptr(plan.mel_start) if mel else None,
             _lib.ptr(plan.mel_count) if mel else None, _lib.ptr(plan.mel_woff) if mel else None,
-            _lib.ptr(plan.mel_w) if mel else None, _lib.ptr(target), _lib.ptr(gl), _lib.ptr(frame_grad),
+            _lib.ptr(plan.mel_w) if mel else None, _lib.ptr(target), _lib.ptr(gl), None, _lib.ptr(frame_grad),
             _lib.ptr(g_audio), B, T, plan.n_fft, plan.hop_length, plan.n_out,
-            2 if ctx.value_mode == VALUE_POWER else 1, 1.0 / target.numel(), _lib.stream())
-        _lib.check(st, "ias_stft_l1_backward")
+            2 if ctx.value_mode == VALUE_POWER else 1, LOSS_L1, 1.0 / target.numel(), 0.0, _lib.stream())
+        _lib.check(st, "ias_stft_loss_backward")
         return g_audio.reshape(ctx.shape), None, None, None
 
 
@@ -243,10 +244,53 @@ class MultiResolutionSTFTLoss(nn.Module):
         self.plans = nn.ModuleList([STFTPlan(n, w, h) for n, h, w in zip(fft_sizes, hop_sizes, win_lengths)])
 
     def forward(self, x, y):
-        total = None
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _MRSTFTFn.apply(x, self, y.detach())
+        return self._forward(x, y)[0]
+
+    def _forward(self, x, y):
+        total, saved = None, []
         for plan in self.plans:
             tgt = plan.values(y, VALUE_MAG_CLAMPED, self.eps)
             s = plan.loss_sums(x, tgt, VALUE_MAG_CLAMPED, LOSS_MRSTFT, self.eps)
             term = torch.sqrt(s[0]) / torch.sqrt(s[1]) + s[2] / tgt.numel()
             total = term if total is None else total + term
-        return (total / len(self.plans)).float()
+            saved.append((tgt, s))
+        return (total / len(self.plans)).float(), saved
+
+
+class _MRSTFTFn(torch.autograd.Function):
+    """MultiResolutionSTFTLoss with the HIP adjoint w.r.t. the prediction (the target gets no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, module, y):
+        a = STFTPlan._audio2d(x)
+        loss, saved = module._forward(a, y)
+        ctx.module, ctx.shape = module, x.shape
+        ctx.save_for_backward(a, *[t for pair in saved for t in pair])
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        a, *rest = ctx.saved_tensors
+        module = ctx.module
+        lib = _lib.load()
+        B, T = a.shape
+        nres = len(module.plans)
+        g_total = torch.zeros_like(a)
+        g64 = g_loss.to(torch.float64).reshape(())
+        for i, plan in enumerate(module.plans):
+            tgt, s = rest[2 * i], rest[2 * i + 1]
+            # d (sqrt(l0) / sqrt(l1)) / dV = (V - T) / (sqrt(l0) sqrt(l1));  d (l2 / count) / dV = sign(V - T) / (V count)
+            den = torch.sqrt(s[0]) * torch.sqrt(s[1])
+            c0 = torch.where(den > 0, g64 / (nres * den), torch.zeros_like(den))
+            coef = torch.stack([c0, g64 / (nres * tgt.numel())]).contiguous()
+            frame_grad = torch.empty((B, plan.num_frames(T), plan.n_fft), dtype=torch.float32, device=a.device)
+            g_audio = torch.empty_like(a)
+            st = lib.ias_stft_loss_backward(_lib.ptr(a), _lib.ptr(plan.window), None, None, None, None, _lib.ptr(tgt),
+                                            None, _lib.ptr(coef), _lib.ptr(frame_grad), _lib.ptr(g_audio), B, T,
+                                            plan.n_fft, plan.hop_length, plan.n_out, 1, LOSS_MRSTFT, 0.0,
+                                            float(module.eps), _lib.stream())
+            _lib.check(st, "ias_stft_loss_backward")
+            g_total += g_audio
+        return g_total.reshape(ctx.shape), None, None

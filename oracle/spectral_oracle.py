@@ -75,7 +75,7 @@ def mrstft_loss(x, y, fft_sizes=(1024, 2048, 512), hop_sizes=(120, 240, 50), win
     total = 0.0
     parts = []
     for n_fft, hop, win in zip(fft_sizes, hop_sizes, win_lengths):
-        w = torch.hann_window(win)
+        w = torch.hann_window(win).to(x.dtype)
         X = torch.stft(x, n_fft, hop, win, w, return_complex=True)
         Y = torch.stft(y, n_fft, hop, win, w, return_complex=True)
         xm = torch.sqrt(torch.clamp(X.real ** 2 + X.imag ** 2, min=eps))

@@ -46,6 +46,26 @@ def test_stft_l1_gradient(lib, dev, n_fft, hop, power, T):
     assert rel_l2(xa.grad.cpu().double(), ref) <= 2e-3
 
 
+@pytest.mark.parametrize("T", [16000, 30001])
+def test_mrstft_gradient(lib, dev, T):
+    """MultiResolutionSTFTLoss (auraloss defaults: three resolutions, spectral convergence + log-magnitude L1) w.r.t.
+    the prediction, against autograd through the oracle in fp64."""
+    from inverse_audio_synthesis_amd.spectral import MultiResolutionSTFTLoss
+    m = MultiResolutionSTFTLoss().to(dev)
+    x = randn((2, T), 21) * 0.1
+    y = randn((2, T), 22) * 0.1 + 0.05 * torch.sin(torch.arange(T) * 0.01)
+    ref_loss, ref = _oracle_grad(lambda a, t: spo.mrstft_loss(a, t)[0], x, y)
+    xa = x.to(dev).requires_grad_(True)
+    loss = m(xa, y.to(dev))
+    assert abs(loss.item() - ref_loss) <= 1e-3 * abs(ref_loss)
+    loss.backward()
+    g = xa.grad.cpu().double()
+    assert torch.isfinite(g).all()
+    assert rel_l2(g, ref) <= 5e-3, rel_l2(g, ref)
+    with torch.no_grad():
+        assert abs(m(x.to(dev), y.to(dev)).item() - loss.item()) <= 1e-7 * abs(loss.item())
+
+
 def test_gradient_is_deterministic_and_forward_unchanged(lib, dev):
     from inverse_audio_synthesis_amd.spectral import MelSpectrogramL1
     m = MelSpectrogramL1().to(dev)
