@@ -46,12 +46,44 @@ def _packed_taps(H, Hc, N, K):
     return hit[1]
 
 
+class _AnalysisFn(torch.autograd.Function):
+    """PQMF analysis, differentiable w.r.t. the audio.  The adjoint of the strided correlation
+    z[k,f] = sum_j H[k,j] x[N f + j - pad] is the polyphase synthesis kernel run with the time-reversed filters and
+    without its gain N (pad = (K-1)/2 makes the two index maps mirror images), cropped to the input length."""
+
+    @staticmethod
+    def forward(ctx, x, H, mean, std):
+        ctx.shape = x.shape
+        ctx.save_for_backward(H, std)
+        return _analysis_nograd(x, H, mean, std)
+
+    @staticmethod
+    def backward(ctx, g_z):
+        H, std = ctx.saved_tensors
+        T = ctx.shape[-1]
+        N = H.shape[0]
+        g = g_z.to(torch.float32)
+        if std is not None:
+            g = g / std.reshape(1, N, 1)
+        G = torch.flip(H.reshape(N, -1), dims=[1]).reshape(1, N, -1) / float(N)
+        g_x = pqmf_synthesis(g, G)[:, 0, :T]
+        if g_x.shape[-1] < T:
+            g_x = torch.nn.functional.pad(g_x, (0, T - g_x.shape[-1]))
+        return g_x.reshape(ctx.shape), None, None, None
+
+
 def pqmf_analysis(x, H, mean=None, std=None):
     """x [B,1,T] or [B,T] fp32 on a ROCm device, H [N,1,K] -> z [B,N,L].
 
     ``mean``/``std`` ([N] device tensors) fuse the per-band normalisation of
-    /root/reference/audioembed.py:49 into the store.
+    /root/reference/audioembed.py:49 into the store.  Differentiable with respect to ``x`` (not H).
     """
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _AnalysisFn.apply(x, H, mean, std)
+    return _analysis_nograd(x, H, mean, std)
+
+
+def _analysis_nograd(x, H, mean=None, std=None):
     lib = _lib.load()
     if x.dim() == 3:
         assert x.shape[1] == 1, "PQMF analysis takes one input channel"

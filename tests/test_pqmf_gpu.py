@@ -114,3 +114,29 @@ def test_packed_taps_follow_filter_updates(lib, dev):
                                _lib.stream())
     assert st == 0
     np.testing.assert_allclose(z2.cpu().numpy(), z1.cpu().numpy(), atol=1e-6)
+
+
+@pytest.mark.parametrize("N,taps,T", [(3, 62, 20000), (4, 62, 4099), (64, 62, 20000), (5, 30, 1234)])
+def test_analysis_gradient_matches_conv1d_autograd(lib, dev, N, taps, T):
+    """d/dx of PQMF.analysis (HIP: the synthesis kernel with reversed filters) against torch.autograd through the
+    reference's own formulation F.conv1d(x, H, padding=taps//2, stride=N) (pqmf.py:49-50) in fp64, also with the fused
+    per-band normalisation of AudioEmbedding._preprocess."""
+    from inverse_audio_synthesis_amd.pqmf import pqmf_analysis
+    kw = dict(taps=taps) if taps == 62 else dict(taps=taps, cutoff=0.07, beta=7.0)
+    m = _mod(dev, N, **kw)
+    x = randn((2, 1, T), 31)
+    xd = x.double().requires_grad_(True)
+    zr = torch.nn.functional.conv1d(xd, m.H.cpu().double(), padding=taps // 2, stride=N)
+    w = randn(tuple(zr.shape), 32)
+    (ref,) = torch.autograd.grad((zr * w.double()).sum(), xd, retain_graph=True)
+    xa = x.to(dev).requires_grad_(True)
+    (m(xa) * w.to(dev)).sum().backward()
+    assert xa.grad.shape == x.shape
+    np.testing.assert_allclose(xa.grad.cpu().numpy(), ref.float().numpy(), atol=2e-5 * float(ref.abs().max()) + 1e-6)
+    if N == 3:
+        mean, std = torch.tensor([0.1, 0.2, 0.3]).to(dev), torch.tensor([0.5, 2.0, 1.5]).to(dev)
+        xb = x.to(dev).requires_grad_(True)
+        (pqmf_analysis(xb, m.H, mean, std) * w.to(dev)).sum().backward()
+        (ref2,) = torch.autograd.grad(((zr - mean.cpu().double().reshape(1, 3, 1)) / std.cpu().double().reshape(1, 3, 1)
+                                       * w.double()).sum(), xd)
+        np.testing.assert_allclose(xb.grad.cpu().numpy(), ref2.float().numpy(), atol=2e-5 * float(ref2.abs().max()) + 1e-6)
