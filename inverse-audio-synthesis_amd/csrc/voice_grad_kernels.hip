@@ -43,24 +43,25 @@ enum { PL_INC1 = 0, PL_INC2, PL_GAMP1, PL_GAMP2, PL_GAMPN, PL_GARG1, PL_GARG2, P
 // chunk loops below are chains of such scans)
 __device__ __forceinline__ double wave_total(double v) { return wave_sum(v); }
 
-// Inclusive scan of one value per thread over the workgroup (thread order); returns the scanned value and
-// adds the workgroup total to `carry` (same value in every thread).  s_w: GRAD_WAVES doubles of LDS.
-__device__ __forceinline__ double block_incl_scan(double v, double& carry, double* s_w, int tid) {
+// Inclusive scans over the workgroup (thread order) of one value per thread and oscillator; the scanned values come
+// back in place and the workgroup totals are added to the carries (same value in every thread).
+// Both scans share one pair of barriers.  s_w: 2 * GRAD_WAVES doubles of LDS.
+__device__ __forceinline__ void block_incl_scan2(double& v1, double& v2, double& carry1, double& carry2, double* s_w,
+                                                 int tid) {
   const int lane = tid & 63, wave = tid >> 6;
-  double s = wave_incl_scan(v, lane);
+  double s1 = wave_incl_scan(v1, lane), s2 = wave_incl_scan(v2, lane);
   __syncthreads();                       // s_w free again
-  if (lane == 63) s_w[wave] = s;
+  if (lane == 63) { s_w[wave] = s1; s_w[GRAD_WAVES + wave] = s2; }
   __syncthreads();
-  double before = 0.0, total = 0.0;
+  double b1 = 0.0, t1 = 0.0, b2 = 0.0, t2 = 0.0;
 #pragma unroll
   for (int w = 0; w < GRAD_WAVES; ++w) {
-    const double x = s_w[w];
-    if (w < wave) before += x;
-    total += x;
+    const double x1 = s_w[w], x2 = s_w[GRAD_WAVES + w];
+    if (w < wave) { b1 += x1; b2 += x2; }
+    t1 += x1; t2 += x2;
   }
-  s += before + carry;
-  carry += total;
-  return s;
+  v1 = s1 + b1 + carry1; v2 = s2 + b2 + carry2;
+  carry1 += t1; carry2 += t2;
 }
 
 // Workgroup sum of NS per-thread doubles -> out[NS] (thread 0 writes); fixed order.
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_sample_kernel(
     const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst, const float* __restrict__ noise,
     const float* __restrict__ g_mixed, float* __restrict__ planes, const double* __restrict__ tile_sums,
     double* __restrict__ partials /* [B][ntiles][IAS_GRAD_NS] */, int T, int Tc, int ntiles, float scale) {
-  __shared__ double s_w[GRAD_WAVES];
+  __shared__ double s_w[2 * GRAD_WAVES];
   __shared__ double s_red[GRAD_WAVES * 8];
   const int tid = threadIdx.x, tile = blockIdx.x, b = blockIdx.y;
   const IasVoiceConst vc = vconst[b];
@@ -145,8 +146,8 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_sample_kernel(
     const bool ok = j < T;
     const double inc1 = ok ? (double)fabsf(pl[(size_t)PL_INC1 * T + j]) : 0.0;
     const double inc2 = ok ? (double)fabsf(pl[(size_t)PL_INC2 * T + j]) : 0.0;
-    const double cum1 = block_incl_scan(inc1, carry1, s_w, tid);
-    const double cum2 = block_incl_scan(inc2, carry2, s_w, tid);
+    double cum1 = inc1, cum2 = inc2;
+    block_incl_scan2(cum1, cum2, carry1, carry2, s_w, tid);
     if (!ok) continue;
     const float arg1 = ias_add((float)cum1, vc.phi_1), arg2 = ias_add((float)cum2, vc.phi_2);
     int i0, i1; float w0, w1;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_sample_kernel(
 __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_pitch_kernel(
     const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst, float* __restrict__ planes,
     double* __restrict__ partials, int T, int Tc, int ntiles, float scale) {
-  __shared__ double s_w[GRAD_WAVES];
+  __shared__ double s_w[2 * GRAD_WAVES];
   __shared__ double s_red[GRAD_WAVES * 4];
   const int tid = threadIdx.x, tile = blockIdx.x, b = blockIdx.y;
   const IasVoiceConst vc = vconst[b];
@@ -214,8 +215,8 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_pitch_kernel(
     const bool ok = j < T;
     const double ga1 = ok ? (double)pl[(size_t)PL_GARG1 * T + j] : 0.0;
     const double ga2 = ok ? (double)pl[(size_t)PL_GARG2 * T + j] : 0.0;
-    const double suf1 = block_incl_scan(ga1, carry1, s_w, tid);
-    const double suf2 = block_incl_scan(ga2, carry2, s_w, tid);
+    double suf1 = ga1, suf2 = ga2;
+    block_incl_scan2(suf1, suf2, carry1, carry2, s_w, tid);
     if (!ok) continue;
     const float inc1 = pl[(size_t)PL_INC1 * T + j], inc2 = pl[(size_t)PL_INC2 * T + j];
     const double gc1 = inc1 > 0.0f ? suf1 * ((double)inc1 * k) : 0.0;
