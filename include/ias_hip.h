@@ -146,7 +146,7 @@ int ias_stft(const float* audio, const float* tables, const int* mel_start, cons
  * window [n_fft] on the device; mel_* as for ias_stft (NULL = linear bins, n_out = n_fft/2+1); target [B,F,n_out]
  * frames-major; power 1 or 2; g_loss a device scalar (NULL = 1); frame_grad [B,F,n_fft] fp32 scratch. */
 int ias_stft_loss_backward(const float* audio, const float* window, const int* mel_start, const int* mel_count,
-                           const int* mel_woff, const float* mel_w, const float* target, const float* g_loss,
+                           const int* mel_woff, const float* mel_w, int mel_nnz, const float* target, const float* g_loss,
                            const double* coef, float* frame_grad, float* g_audio, int B, int T, int n_fft, int hop,
                            int n_out, int power, int loss_mode, float scale, float eps, void* stream);
 

@@ -22,6 +22,7 @@
 #include "ias_common.h"
 
 #define SG_THREADS 256
+#define SG_PAIRS 1         // frame pairs per workgroup (twiddle table and filterbank staged once)
 typedef float2 sg_cpx;
 
 __device__ __forceinline__ sg_cpx sg_mul(sg_cpx a, sg_cpx b) {
@@ -80,6 +81,7 @@ struct SgArgs {
   const float* target;    // [B,F,n_out]
   float* frame_grad;      // [B,F,N]
   int T, F, N, log2n, hop, n_out, power2;
+  int mel_nnz;            // entries of mel_w (0 without a mel projection)
   int loss_mode;          // 1: scale * sum |V - t|;  2: MR-STFT term, V = sqrt(max(|X|^2, eps))
   const double* coef;     // loss_mode 2: device [2] = {c0, c1}: gO = c0 (V - t) + c1 sign(V - t) / V
   float scale, eps;
@@ -100,15 +102,23 @@ __device__ __forceinline__ sg_cpx sg_frame_bin(const sg_cpx* Z, int k, int N, in
 __global__ __launch_bounds__(SG_THREADS) void stft_grad_frames_kernel(SgArgs g) {
   extern __shared__ __attribute__((aligned(16))) float sg_smem[];
   const int N = g.N, NB = N / 2 + 1, tid = threadIdx.x, b = blockIdx.y;
-  const int fa = 2 * blockIdx.x;                 // frames fa and fa + 1 (the second may not exist)
-  const int nfr = min(2, g.F - fa);
   sg_cpx* bufa = reinterpret_cast<sg_cpx*>(sg_smem);
   sg_cpx* bufb = bufa + N;
   sg_cpx* tab = bufb + N;                    // N/2
-  float* sP = reinterpret_cast<float*>(tab + N / 2);   // NB (+ pad): values of the frame being processed
-  float* sGV = sP + (NB + 3);                // NB
-  float* sGO = sGV + (NB + 3);               // n_out
-  float* sGP = sGO + ((g.n_out + 3) & ~3);   // [2][NB + 3]: d loss / d |X|^2 of the two frames
+  float* sP = reinterpret_cast<float*>(tab + N / 2);   // [2][NB + 3]: values V of the two frames
+  float* sGV = sP + 2 * (NB + 3);            // [2][NB + 3]: d loss / d V
+  float* sGO = sGV + 2 * (NB + 3);           // [2][n_out (+ pad)]: d loss / d output
+  float* sGP = sGO + 2 * ((g.n_out + 3) & ~3);   // [2][NB + 3]: d loss / d |X|^2
+  // the filterbank (CSR) is copied to LDS once per workgroup: the projection loops below are chains of dependent
+  // reads, and out of global memory each link costs an L2 round trip
+  float* sMW = sGP + 2 * (NB + 3);           // [mel_nnz]
+  int* sMI = reinterpret_cast<int*>(sMW + ((g.mel_nnz + 3) & ~3));   // [3][n_out]: start, count, woff
+  if (g.mel_start) {
+    for (int i = tid; i < g.mel_nnz; i += SG_THREADS) sMW[i] = g.mel_w[i];
+    for (int i = tid; i < g.n_out; i += SG_THREADS) {
+      sMI[i] = g.mel_start[i]; sMI[g.n_out + i] = g.mel_count[i]; sMI[2 * g.n_out + i] = g.mel_woff[i];
+    }
+  }
 
   const int pad = N / 2;
   const float* arow = g.audio + (size_t)b * g.T;
@@ -117,6 +127,12 @@ __global__ __launch_bounds__(SG_THREADS) void stft_grad_frames_kernel(SgArgs g) 
     sincospif(2.0f * (float)j / (float)N, &s, &c);
     tab[j] = make_float2(c, -s);
   }
+  // a workgroup walks through SG_PAIRS consecutive frame pairs with the tables above in place
+  for (int pp = 0; pp < SG_PAIRS; ++pp) {
+  const int fa = 2 * (blockIdx.x * SG_PAIRS + pp);   // frames fa and fa + 1 (the second may not exist)
+  if (fa >= g.F) break;
+  const int nfr = min(2, g.F - fa);
+  __syncthreads();                                   // previous pair done with the buffers
   for (int n = tid; n < N; n += SG_THREADS) {
     float v[2] = {0.0f, 0.0f};
     for (int r = 0; r < nfr; ++r) {
@@ -131,64 +147,69 @@ __global__ __launch_bounds__(SG_THREADS) void stft_grad_frames_kernel(SgArgs g) 
   sg_cpx* Z = sg_fft<-1>(bufa, bufb, tab, N, g.log2n, tid);
   sg_cpx* other = (Z == bufa) ? bufb : bufa;
 
-  for (int r = 0; r < 2; ++r) {
-    float* gp = sGP + r * (NB + 3);
-    if (r >= nfr) {
-      for (int k = tid; k < NB; k += SG_THREADS) gp[k] = 0.0f;
-      continue;
-    }
-    for (int k = tid; k < NB; k += SG_THREADS) {
+  // The value -> loss -> adjoint chain of BOTH frames at once: frame r uses row r of sP / sGV / sGO / sGP, and the
+  // projection phases run one thread per (frame, output) -- all 256 threads for 2 x 128 mel bands.
+  const int SB = NB + 3, SO = (g.n_out + 3) & ~3;
+  for (int i = tid; i < 2 * NB; i += SG_THREADS) {
+    const int r = i >= NB, k = i - r * NB;
+    float v = 0.0f;
+    if (r < nfr) {
       const sg_cpx x = sg_frame_bin(Z, k, N, r);
       const float p = x.x * x.x + x.y * x.y;
-      sP[k] = g.power2 ? p : sqrtf(g.loss_mode == 2 ? fmaxf(p, g.eps) : p);         // V
-      sGV[k] = 0.0f;
+      v = g.power2 ? p : sqrtf(g.loss_mode == 2 ? fmaxf(p, g.eps) : p);         // V
     }
-    __syncthreads();
-    const float* trow = g.target + ((size_t)b * g.F + fa + r) * g.n_out;
-    for (int o = tid; o < g.n_out; o += SG_THREADS) {
+    sP[r * SB + k] = v;
+    sGV[r * SB + k] = 0.0f;
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * g.n_out; i += SG_THREADS) {
+    const int r = i >= g.n_out, o = i - r * g.n_out;
+    float go = 0.0f;
+    if (r < nfr) {
+      const float* pr = sP + r * SB;
       float v;
       if (g.mel_start) {
-        const int s0 = g.mel_start[o], cnt = g.mel_count[o];
-        const float* w = g.mel_w + g.mel_woff[o];
+        const int s0 = sMI[o], cnt = sMI[g.n_out + o];
+        const float* w = sMW + sMI[2 * g.n_out + o];
         v = 0.0f;
-        for (int c = 0; c < cnt; ++c) v = fmaf(w[c], sP[s0 + c], v);
+        for (int c = 0; c < cnt; ++c) v = fmaf(w[c], pr[s0 + c], v);
       } else {
-        v = sP[o];
+        v = pr[o];
       }
-      const float d = v - trow[o];
+      const float d = v - g.target[((size_t)b * g.F + fa + r) * g.n_out + o];
       const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-      if (g.loss_mode == 2) {
-        // spectral convergence ||T - V||_F / ||T||_F and mean |log V - log T| (log is monotone: sign(V - T))
-        sGO[o] = (float)g.coef[0] * d + (float)g.coef[1] * sg / v;
-      } else {
-        sGO[o] = sg * g.scale;
-      }
+      // MR-STFT: spectral convergence ||T - V||_F / ||T||_F and mean |log V - log T| (log is monotone: sign(V - T))
+      go = g.loss_mode == 2 ? (float)g.coef[0] * d + (float)g.coef[1] * sg / v : sg * g.scale;
     }
-    __syncthreads();
-    if (g.mel_start) {
-      // a bin lies under at most two triangular filters: the (commutative) sum of two terms does not depend on
-      // the order of the LDS atomics
-      for (int o = tid; o < g.n_out; o += SG_THREADS) {
-        const int s0 = g.mel_start[o], cnt = g.mel_count[o];
-        const float* w = g.mel_w + g.mel_woff[o];
-        const float go = sGO[o];
-        for (int c = 0; c < cnt; ++c) atomicAdd(&sGV[s0 + c], w[c] * go);
-      }
-    } else {
-      for (int k = tid; k < NB; k += SG_THREADS) sGV[k] = sGO[k];
-    }
-    __syncthreads();
-    for (int k = tid; k < NB; k += SG_THREADS) {
-      float v = sGV[k];
-      if (!g.power2) {
-        // d sqrt(P) / dP, 0 at P = 0; MR-STFT clamps P at eps first (clamp passes the gradient at P >= eps)
-        const bool live = g.loss_mode == 2 ? sP[k] > sqrtf(g.eps) : sP[k] > 0.0f;   // V == sqrt(eps): clamped bin
-        v = live ? v / (2.0f * sP[k]) : 0.0f;
-      }
-      gp[k] = v;
-    }
-    __syncthreads();
+    sGO[r * SO + o] = go;
   }
+  __syncthreads();
+  if (g.mel_start) {
+    // a bin lies under at most two triangular filters: the (commutative) sum of two terms does not depend on the
+    // order of the LDS atomics
+    for (int i = tid; i < 2 * g.n_out; i += SG_THREADS) {
+      const int r = i >= g.n_out, o = i - r * g.n_out;
+      const int s0 = sMI[o], cnt = sMI[g.n_out + o];
+      const float* w = sMW + sMI[2 * g.n_out + o];
+      const float go = sGO[r * SO + o];
+      for (int c = 0; c < cnt; ++c) atomicAdd(&sGV[r * SB + s0 + c], w[c] * go);
+    }
+  } else {
+    for (int i = tid; i < 2 * NB; i += SG_THREADS) { const int r = i >= NB, k = i - r * NB; sGV[r * SB + k] = sGO[r * SO + k]; }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * NB; i += SG_THREADS) {
+    const int r = i >= NB, k = i - r * NB;
+    float v = sGV[r * SB + k];
+    if (!g.power2) {
+      // d sqrt(P) / dP, 0 at P = 0; MR-STFT clamps P at eps first (clamp passes the gradient at P >= eps)
+      const float pv = sP[r * SB + k];
+      const bool live = g.loss_mode == 2 ? pv > sqrtf(g.eps) : pv > 0.0f;   // V == sqrt(eps): clamped bin
+      v = live ? v / (2.0f * pv) : 0.0f;
+    }
+    sGP[r * SB + k] = v;
+  }
+  __syncthreads();
   // inverse input H_a + i H_b (see above), natural order in `other`
   for (int k = tid; k < N; k += SG_THREADS) {
     const int kk = k <= N / 2 ? k : N - k;                   // the one-sided bin this entry mirrors
@@ -206,6 +227,7 @@ __global__ __launch_bounds__(SG_THREADS) void stft_grad_frames_kernel(SgArgs g) 
     float* out = g.frame_grad + ((size_t)b * g.F + fa + r) * N;
     for (int n = tid; n < N; n += SG_THREADS) out[n] = g.window[n] * (r == 0 ? Y[n].x : Y[n].y);
   }
+  }   // frame pairs
 }
 
 // g_audio[b,j] = g_loss * sum over the padded positions q that read audio[j] (itself and its reflections) of the
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(SG_THREADS) void stft_grad_ola_kernel(const float* 
 //   target [B,F,n_out] frames-major (what ias_stft wrote for the target); power: 1 (magnitude) or 2 (power);
 //   frame_grad [B,F,n_fft] fp32 scratch; g_audio [B,T] out.  F = ias_stft_num_frames(T, n_fft, hop).
 extern "C" int ias_stft_loss_backward(const float* audio, const float* window, const int* mel_start,
-                                      const int* mel_count, const int* mel_woff, const float* mel_w,
+                                      const int* mel_count, const int* mel_woff, const float* mel_w, int mel_nnz,
                                       const float* target, const float* g_loss, const double* coef, float* frame_grad,
                                       float* g_audio, int B, int T, int n_fft, int hop, int n_out, int power,
                                       int loss_mode, float scale, float eps, void* stream_) {
@@ -256,7 +278,7 @@ extern "C" int ias_stft_loss_backward(const float* audio, const float* window, c
   if (loss_mode == 2 && (!coef || power != 1 || mel_start != nullptr)) return IAS_ERR_ARG;
   if (T <= n_fft / 2) return IAS_ERR_ARG;
   const bool mel = mel_start != nullptr;
-  if (mel && (!mel_count || !mel_woff || !mel_w)) return IAS_ERR_ARG;
+  if (mel && (!mel_count || !mel_woff || !mel_w || mel_nnz <= 0)) return IAS_ERR_ARG;
   if (!mel && n_out != n_fft / 2 + 1) return IAS_ERR_ARG;
   if (n_out <= 0 || n_out > n_fft / 2 + 1) return IAS_ERR_ARG;
   const int F = 1 + T / hop;
@@ -267,12 +289,16 @@ extern "C" int ias_stft_loss_backward(const float* audio, const float* window, c
   g.T = T; g.F = F; g.N = n_fft; g.log2n = n_fft == 512 ? 9 : (n_fft == 1024 ? 10 : 11); g.hop = hop;
   g.n_out = n_out; g.power2 = power == 2; g.scale = scale;
   g.loss_mode = loss_mode; g.coef = coef; g.eps = eps;
+  g.mel_nnz = mel ? mel_nnz : 0;
   const int NB = n_fft / 2 + 1;
   const size_t lds = sizeof(sg_cpx) * (2 * (size_t)n_fft + n_fft / 2) +
-                     sizeof(float) * (4 * (size_t)(NB + 3) + ((n_out + 3) & ~3));
+                     sizeof(float) * (6 * (size_t)(NB + 3) + 2 * ((n_out + 3) & ~3) + ((g.mel_nnz + 3) & ~3)) +
+                     sizeof(int) * 3 * (size_t)(mel ? n_out : 0);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)stft_grad_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(stft_grad_frames_kernel, dim3((F + 1) / 2, B), dim3(SG_THREADS), lds, stream, g);
+  const int pairs = (F + 1) / 2;
+  hipLaunchKernelGGL(stft_grad_frames_kernel, dim3((pairs + SG_PAIRS - 1) / SG_PAIRS, B), dim3(SG_THREADS), lds, stream,
+                     g);
   hipLaunchKernelGGL(stft_grad_ola_kernel, dim3((T + SG_THREADS - 1) / SG_THREADS, B), dim3(SG_THREADS), 0, stream,
                      frame_grad, g_loss, g_audio, T, F, n_fft, hop);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;

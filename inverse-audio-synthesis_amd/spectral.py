@@ -164,7 +164,8 @@ class _L1LossFn(torch.autograd.Function):
         st = lib.ias_stft_loss_backward(
             _lib.ptr(a), _lib.ptr(plan.window), _lib.ptr(plan.mel_start) if mel else None,
             _lib.ptr(plan.mel_count) if mel else None, _lib.ptr(plan.mel_woff) if mel else None,
-            _lib.ptr(plan.mel_w) if mel else None, _lib.ptr(target), _lib.ptr(gl), None, _lib.ptr(frame_grad),
+            _lib.ptr(plan.mel_w) if mel else None, int(plan.mel_w.numel()) if mel else 0, _lib.ptr(target), _lib.ptr(gl),
+            None, _lib.ptr(frame_grad),
             _lib.ptr(g_audio), B, T, plan.n_fft, plan.hop_length, plan.n_out,
             2 if ctx.value_mode == VALUE_POWER else 1, LOSS_L1, 1.0 / target.numel(), 0.0, _lib.stream())
         _lib.check(st, "ias_stft_loss_backward")
@@ -287,7 +288,7 @@ class _MRSTFTFn(torch.autograd.Function):
             coef = torch.stack([c0, g64 / (nres * tgt.numel())]).contiguous()
             frame_grad = torch.empty((B, plan.num_frames(T), plan.n_fft), dtype=torch.float32, device=a.device)
             g_audio = torch.empty_like(a)
-            st = lib.ias_stft_loss_backward(_lib.ptr(a), _lib.ptr(plan.window), None, None, None, None, _lib.ptr(tgt),
+            st = lib.ias_stft_loss_backward(_lib.ptr(a), _lib.ptr(plan.window), None, None, None, None, 0, _lib.ptr(tgt),
                                             None, _lib.ptr(coef), _lib.ptr(frame_grad), _lib.ptr(g_audio), B, T,
                                             plan.n_fft, plan.hop_length, plan.n_out, 1, LOSS_MRSTFT, 0.0,
                                             float(module.eps), _lib.stream())
