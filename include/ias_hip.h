@@ -107,7 +107,12 @@ int ias_pqmf_analysis(const float* x, const float* H, const float* packed, float
                       const float* stdv, int B, int T, int N, int K, void* stream);
 
 /* synthesis: z [B,N,L], G [N,K] (= buffer G[1,N,K]) -> out [B, L*N] (= [B,1,L*N])   (pqmf.py:52-55). */
-int ias_pqmf_synthesis(const float* z, const float* G, float* out, int B, int L, int N, int K, void* stream);
+/* packed: ias_pqmf_pack_synth_taps table of G (ias_pqmf_synth_taps_len floats; wide kernel for N <= 64, K <= 255),
+ * or NULL (generic kernel, several times slower). */
+int ias_pqmf_synth_taps_len(int N, int K);
+int ias_pqmf_pack_synth_taps(const float* G, float* packed, int N, int K, void* stream);
+int ias_pqmf_synthesis(const float* z, const float* G, const float* packed, float* out, int B, int L, int N, int K,
+                       void* stream);
 
 /* ---- STFT / mel spectral losses.  No live reference code: spec = the commented mel block at
  * reference conf/config.yaml:51-61 and its use at audio_to_params.py:150-153 (torchaudio

@@ -351,6 +351,90 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_synthesis_kernel(
   out[(size_t)b * To + t] = acc;
 }
 
+// Wide synthesis (any N <= 64, odd K <= 255).  With t = N m + r:  out[N m + r] = N sum_d sum_k Gt[d][k][r] z[k][m + d],
+// where phase r uses the taps j = j_r + N (d - c_r), j_r = (pad - r) mod N, c_r = (r - pad + j_r) / N, and Gt is
+// zero where that j falls outside [0, K) (ias_pqmf_pack_synth_taps folds the gain N in).  The workgroup stages
+// z[:, m0 + dmin .. m0 + 127 + dmax] in LDS (odd row stride); a lane owns one frame m and half of the phases: per
+// (d, k) one ds_read_b32 feeds HB FMAs with SGPR taps.  The tile's outputs go back through LDS so that the store to
+// out[N m0 ..] is contiguous (a lane's own outputs are N floats apart).
+struct PqmfSynthGeom { int dmin, nd; };
+static PqmfSynthGeom pqmf_synth_geom(int N, int K) {
+  const int pad = (K - 1) / 2;
+  int dmin = 1 << 30, dmax = -(1 << 30);
+  for (int r = 0; r < N; ++r) {
+    const int jr = ((pad - r) % N + N) % N;
+    if (jr >= K) continue;
+    const int cr = (r - pad + jr) / N;             // exact: r - pad + jr is a multiple of N
+    const int q = (K - 1 - jr) / N;                // last tap index of the phase
+    dmin = cr < dmin ? cr : dmin;
+    dmax = cr + q > dmax ? cr + q : dmax;
+  }
+  PqmfSynthGeom g = {dmin, dmax - dmin + 1};
+  return g;
+}
+
+template <int NPAD>
+__global__ __launch_bounds__(PQ_THREADS) void pqmf_synthesis_wide_kernel(
+    const float* __restrict__ z, const float* __restrict__ Gt, float* __restrict__ out, int L, int N, int dmin,
+    int nd, int rs /* LDS row stride (odd), >= 128 + nd - 1 and >= N + 1 scaled: see host */) {
+  constexpr int HB = NPAD / 2;
+  extern __shared__ __attribute__((aligned(16))) float s_zrows[];   // [N][rs]; reused as the output tile [128][N + 1]
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int m0 = blockIdx.x * PQW_FRAMES;
+  const int cols = PQW_FRAMES + nd - 1;
+  const float* zb = z + (size_t)b * N * L;
+  for (int i = tid; i < N * cols; i += PQ_THREADS) {
+    const int k = i / cols, c = i - k * cols;
+    const int m = m0 + dmin + c;
+    s_zrows[k * rs + c] = (m >= 0 && m < L) ? zb[(size_t)k * L + m] : 0.0f;
+  }
+  __syncthreads();
+  const int fl = tid & (PQW_FRAMES - 1);
+  const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
+  float acc[HB];
+#pragma unroll
+  for (int r = 0; r < HB; ++r) acc[r] = 0.0f;
+  for (int di = 0; di < nd; ++di) {
+    for (int k = 0; k < N; ++k) {
+      const float zv = s_zrows[k * rs + fl + di];
+      const float* t = Gt + ((size_t)(di * N + k)) * NPAD + half * HB;
+#pragma unroll
+      for (int r = 0; r < HB; ++r) acc[r] = fmaf(t[r], zv, acc[r]);
+    }
+  }
+  __syncthreads();                                   // every read of the staged rows is done
+  const int os = N + 1;                              // padded row stride of the output tile
+#pragma unroll
+  for (int r = 0; r < HB; ++r) {
+    const int ph = half * HB + r;
+    if (ph < N) s_zrows[fl * os + ph] = acc[r];
+  }
+  __syncthreads();
+  const long long t0 = (long long)m0 * N, To = (long long)L * N;
+  float* ob = out + (size_t)b * To;
+  for (int i = tid; i < PQW_FRAMES * N; i += PQ_THREADS) {
+    const int f = i / N, ph = i - f * N;
+    if (t0 + i < To) ob[t0 + i] = s_zrows[f * os + ph];
+  }
+}
+
+// Gt[(di*N + k)*NPAD + r] = N * G[k][j_r + N (dmin + di - c_r)] or 0
+__global__ void pqmf_pack_synth_kernel(const float* __restrict__ G, float* __restrict__ Gt, int N, int K, int npad,
+                                       int dmin, int nd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nd * N * npad) return;
+  const int r = i % npad, k = (i / npad) % N, di = i / (npad * N);
+  float v = 0.0f;
+  if (r < N) {
+    const int pad = (K - 1) / 2;
+    const int jr = ((pad - r) % N + N) % N;
+    const int cr = (r - pad + jr) / N;
+    const int q = dmin + di - cr, j = jr + N * q;
+    if (q >= 0 && j < K && jr < K) v = (float)N * G[k * K + j];
+  }
+  Gt[i] = v;
+}
+
 // Pt[j*N + k] = H[k][j] for j < K, zero padding up to the table length
 __global__ void pqmf_pack_taps_kernel(const float* __restrict__ H, float* __restrict__ Pt, int N, int K, int len) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -449,14 +533,53 @@ extern "C" int ias_pqmf_analysis(const float* x, const float* H, const float* pa
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
+// Floats of the synthesis tap table [nd][N][8|16|32|64] for the wide kernel (0: only the generic kernel applies).
+extern "C" int ias_pqmf_synth_taps_len(int N, int K) {
+  const int npad = pqmf_wide_npad(N, K);
+  if (!npad || (K & 1) == 0) return 0;
+  return pqmf_synth_geom(N, K).nd * N * npad;
+}
+// packed [ias_pqmf_synth_taps_len] (device) <- G [N,K] (device).  Re-run whenever G changes.
+extern "C" int ias_pqmf_pack_synth_taps(const float* G, float* packed, int N, int K, void* stream_) {
+  const int len = ias_pqmf_synth_taps_len(N, K);
+  if (!G || !packed || len == 0) return IAS_ERR_ARG;
+  const PqmfSynthGeom g = pqmf_synth_geom(N, K);
+  hipLaunchKernelGGL(pqmf_pack_synth_kernel, dim3((len + 255) / 256), dim3(256), 0, (hipStream_t)stream_, G, packed, N,
+                     K, pqmf_wide_npad(N, K), g.dmin, g.nd);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
 // z [B,N,L], G [N,K] (module buffer G[1,N,K]), out [B, L*N] (the reference's [B,1,L*N]).
-extern "C" int ias_pqmf_synthesis(const float* z, const float* G, float* out, int B, int L, int N, int K,
-                                  void* stream_) {
+// packed: ias_pqmf_pack_synth_taps table of G (wide kernel), or NULL (generic one-lane-per-output kernel).
+extern "C" int ias_pqmf_synthesis(const float* z, const float* G, const float* packed, float* out, int B, int L,
+                                  int N, int K, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!z || !G || !out || B <= 0 || B > 65535 || L <= 0 || N <= 0 || K <= 0 || (K & 1) == 0) return IAS_ERR_ARG;
   const int pad = (K - 1) / 2;
   const long long To = (long long)L * N;
   if (To > 0x7fffffffLL) return IAS_ERR_ARG;
+  if (packed && ias_pqmf_synth_taps_len(N, K) > 0) {
+    const PqmfSynthGeom g = pqmf_synth_geom(N, K);
+    const int npad = pqmf_wide_npad(N, K);
+    // LDS: z rows [N][rs] with rs >= 128 + nd - 1, reused as the output tile [128][N + 1]
+    int rs = PQW_FRAMES + g.nd - 1;
+    const int need_out = (PQW_FRAMES * (N + 1) + N - 1) / N;
+    if (rs < need_out) rs = need_out;
+    rs |= 1;
+    const size_t lds = sizeof(float) * (size_t)N * rs;
+    if (lds <= 64 * 1024) {
+      const dim3 grid((L + PQW_FRAMES - 1) / PQW_FRAMES, B), block(PQ_THREADS);
+#define IAS_PQS_LAUNCH(NP)                                                                                       \
+      hipLaunchKernelGGL((pqmf_synthesis_wide_kernel<NP>), grid, block, lds, stream, z, packed, out, L, N, g.dmin, \
+                         g.nd, rs)
+      if (npad == 8) IAS_PQS_LAUNCH(8);
+      else if (npad == 16) IAS_PQS_LAUNCH(16);
+      else if (npad == 32) IAS_PQS_LAUNCH(32);
+      else IAS_PQS_LAUNCH(64);
+#undef IAS_PQS_LAUNCH
+      return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+    }
+  }
   hipLaunchKernelGGL(pqmf_synthesis_kernel, dim3((int)((To + PQ_THREADS - 1) / PQ_THREADS), B), dim3(PQ_THREADS), 0,
                      stream, z, G, out, L, N, K, pad);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;

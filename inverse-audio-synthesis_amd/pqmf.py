@@ -101,6 +101,23 @@ def _analysis_nograd(x, H, mean=None, std=None):
     return z
 
 
+def _packed_synth_taps(G, Gc, N, K):
+    """Phase-major tap table of G for the wide synthesis kernel, cached on the caller's G tensor like the analysis one."""
+    lib = _lib.load()
+    n = lib.ias_pqmf_synth_taps_len(N, K)
+    if n <= 0:
+        return None
+    tag = (Gc.data_ptr(), G._version)
+    hit = getattr(G, "_ias_packed_synth_taps", None)
+    if hit is None or hit[0] != tag:
+        packed = torch.empty(n, dtype=torch.float32, device=Gc.device)
+        _lib.check(lib.ias_pqmf_pack_synth_taps(_lib.ptr(Gc), _lib.ptr(packed), N, K, _lib.stream()),
+                   "ias_pqmf_pack_synth_taps")
+        hit = (tag, packed)
+        G._ias_packed_synth_taps = hit
+    return hit[1]
+
+
 def pqmf_synthesis(z, G):
     """z [B,N,L], G [1,N,K] -> [B,1,L*N]."""
     lib = _lib.load()
@@ -110,7 +127,8 @@ def pqmf_synthesis(z, G):
     B, N, L = zc.shape
     assert Gc.shape[0] == N
     out = torch.empty((B, 1, L * N), dtype=torch.float32, device=zc.device)
-    st = lib.ias_pqmf_synthesis(_lib.ptr(zc), _lib.ptr(Gc), _lib.ptr(out), B, L, N, Gc.shape[1], _lib.stream())
+    st = lib.ias_pqmf_synthesis(_lib.ptr(zc), _lib.ptr(Gc), _lib.ptr(_packed_synth_taps(G, Gc, N, Gc.shape[1])),
+                                _lib.ptr(out), B, L, N, Gc.shape[1], _lib.stream())
     _lib.check(st, "ias_pqmf_synthesis")
     return out
 

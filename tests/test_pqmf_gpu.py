@@ -140,3 +140,17 @@ def test_analysis_gradient_matches_conv1d_autograd(lib, dev, N, taps, T):
         (ref2,) = torch.autograd.grad(((zr - mean.cpu().double().reshape(1, 3, 1)) / std.cpu().double().reshape(1, 3, 1)
                                        * w.double()).sum(), xd)
         np.testing.assert_allclose(xb.grad.cpu().numpy(), ref2.float().numpy(), atol=2e-5 * float(ref2.abs().max()) + 1e-6)
+
+
+# wide synthesis kernel (N <= 64, K <= 255) and the generic one beyond that, against the oracle's
+# conv_transpose1d + conv1d formulation (pqmf.py:52-55)
+@pytest.mark.parametrize("N,taps,L", [(3, 62, 5000), (4, 62, 1), (5, 30, 777), (8, 30, 1000), (33, 20, 300),
+                                      (64, 254, 400), (64, 62, 129), (96, 62, 200)])
+def test_synthesis_vs_oracle(lib, dev, N, taps, L):
+    kw = dict(taps=taps) if taps == 62 else dict(taps=taps, cutoff=0.07, beta=7.0)
+    m = _mod(dev, N, **kw)
+    z = randn((2, N, L), 700 + N)
+    ref = po.synthesis(z, m.G.cpu(), m.updown_filter.cpu(), N, taps)
+    got = m.synthesis(z.to(dev)).cpu()
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=1e-4 * max(1.0, float(ref.abs().max())))
