@@ -244,15 +244,22 @@ class MultiResolutionSTFTLoss(nn.Module):
         self.eps = eps
         self.plans = nn.ModuleList([STFTPlan(n, w, h) for n, h, w in zip(fft_sizes, hop_sizes, win_lengths)])
 
-    def forward(self, x, y):
-        if torch.is_grad_enabled() and x.requires_grad:
-            return _MRSTFTFn.apply(x, self, y.detach())
-        return self._forward(x, y)[0]
+    def target(self, y):
+        """Cacheable clamped magnitudes of the target at every resolution (pass as ``targets=`` to ``forward``)."""
+        return [plan.values(y.detach(), VALUE_MAG_CLAMPED, self.eps) for plan in self.plans]
 
-    def _forward(self, x, y):
+    def forward(self, x, y=None, targets=None):
+        """x = prediction; the target either as audio ``y`` or as the cached ``targets = self.target(y)``."""
+        assert (y is None) != (targets is None), "give the target audio or its cached magnitudes"
+        if targets is None:
+            targets = self.target(y)
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _MRSTFTFn.apply(x, self, *targets)
+        return self._forward(x, targets)[0]
+
+    def _forward(self, x, targets):
         total, saved = None, []
-        for plan in self.plans:
-            tgt = plan.values(y, VALUE_MAG_CLAMPED, self.eps)
+        for plan, tgt in zip(self.plans, targets):
             s = plan.loss_sums(x, tgt, VALUE_MAG_CLAMPED, LOSS_MRSTFT, self.eps)
             term = torch.sqrt(s[0]) / torch.sqrt(s[1]) + s[2] / tgt.numel()
             total = term if total is None else total + term
@@ -264,9 +271,9 @@ class _MRSTFTFn(torch.autograd.Function):
     """MultiResolutionSTFTLoss with the HIP adjoint w.r.t. the prediction (the target gets no gradient)."""
 
     @staticmethod
-    def forward(ctx, x, module, y):
+    def forward(ctx, x, module, *targets):
         a = STFTPlan._audio2d(x)
-        loss, saved = module._forward(a, y)
+        loss, saved = module._forward(a, targets)
         ctx.module, ctx.shape = module, x.shape
         ctx.save_for_backward(a, *[t for pair in saved for t in pair])
         return loss
@@ -294,4 +301,4 @@ class _MRSTFTFn(torch.autograd.Function):
                                             float(module.eps), _lib.stream())
             _lib.check(st, "ias_stft_loss_backward")
             g_total += g_audio
-        return g_total.reshape(ctx.shape), None, None
+        return (g_total.reshape(ctx.shape), None) + (None,) * len(module.plans)

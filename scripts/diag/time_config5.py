@@ -26,3 +26,5 @@ audio = timed("render", lambda: v.render(p))
 z = timed("pqmf64 analysis", lambda: gram(audio.unsqueeze(1)))
 timed("pqmf64 synthesis", lambda: gram.synthesis(z))
 timed("mrstft loss (3 res)", lambda: mr(audio, tgt))
+tg = mr.target(tgt)
+timed("mrstft, cached target", lambda: mr(audio, targets=tg))

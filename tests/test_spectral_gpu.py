@@ -95,3 +95,16 @@ def test_full_size_properties(lib, dev):
     assert torch.equal(loss.target(a[:4]), ma[:4])
     ref = spo.mel_spectrogram(a[:2].cpu())
     _close_to_scale(ma[:2].transpose(1, 2).cpu(), ref)
+
+
+def test_mrstft_cached_targets_equal_recomputed(lib, dev):
+    """MultiResolutionSTFTLoss.target(y) caches the target magnitudes (a fixed target is then not transformed again
+    every step); the loss is bit-identical either way."""
+    from inverse_audio_synthesis_amd.spectral import MultiResolutionSTFTLoss
+    m = MultiResolutionSTFTLoss().to(dev)
+    x, y = (randn((2, 20000), 41) * 0.1).to(dev), (randn((2, 20000), 42) * 0.1).to(dev)
+    tg = m.target(y)
+    assert len(tg) == 3
+    assert torch.equal(m(x, y), m(x, targets=tg))
+    with pytest.raises(AssertionError):
+        m(x)
