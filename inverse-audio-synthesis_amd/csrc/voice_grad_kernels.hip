@@ -140,12 +140,24 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_sample_kernel(
   }
   // lvl0 lvl1 lvl2 kpart shape gain phi_1 phi_2
   double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  // (requesting all 16 chunks' inputs up front was measured: 194 VGPRs, 330 -> 490 us -- occupancy matters more here)
+  // The chunk loop is a chain of workgroup scans (barriers): a chunk's global inputs are requested one chunk ahead
+  // so that their latency does not sit between the barriers.  (All 16 chunks up front: 194 VGPRs, 330 -> 490 us.)
+  auto fetch = [&](int it, float& a1, float& a2, float& nzv, float& gv) {
+    const int j = tile * GRAD_TILE + it * GRAD_THREADS + tid;
+    const bool ok = it < GRAD_CHUNKS && j < T;
+    a1 = ok ? fabsf(pl[(size_t)PL_INC1 * T + j]) : 0.0f;
+    a2 = ok ? fabsf(pl[(size_t)PL_INC2 * T + j]) : 0.0f;
+    nzv = ok ? nrow[j] : 0.0f;
+    gv = ok ? grow[j] : 0.0f;
+  };
+  float n_inc1, n_inc2, n_nz, n_g;
+  fetch(0, n_inc1, n_inc2, n_nz, n_g);
   for (int it = 0; it < GRAD_CHUNKS; ++it) {
     const int j = tile * GRAD_TILE + it * GRAD_THREADS + tid;
     const bool ok = j < T;
-    const double inc1 = ok ? (double)fabsf(pl[(size_t)PL_INC1 * T + j]) : 0.0;
-    const double inc2 = ok ? (double)fabsf(pl[(size_t)PL_INC2 * T + j]) : 0.0;
+    const double inc1 = (double)n_inc1, inc2 = (double)n_inc2;
+    const float nz = n_nz, g = n_g;
+    fetch(it + 1, n_inc1, n_inc2, n_nz, n_g);
     double cum1 = inc1, cum2 = inc2;
     block_incl_scan2(cum1, cum2, carry1, carry2, s_w, tid);
     if (!ok) continue;
@@ -161,8 +173,6 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_sample_kernel(
     const float th = ias_tanh_dev(vc.kpart * s2 * 0.5f);
     const float env2 = 1.0f + vc.shape * c2;
     const float core2 = vc.shape_gain * th * env2;
-    const float nz = nrow[j];
-    const float g = grow[j];
     pl[(size_t)PL_GAMP1 * T + j] = g * vc.lvl0 * c1;
     pl[(size_t)PL_GAMP2 * T + j] = g * vc.lvl1 * core2;
     pl[(size_t)PL_GAMPN * T + j] = g * vc.lvl2 * nz;
@@ -210,15 +220,25 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_pitch_kernel(
   }
   const double k = 0.6931471805599453 / 12.0;   // d inc / d pitch = inc * ln2 / 12
   double acc[4] = {0.0, 0.0, 0.0, 0.0};        // f0_1 depth_1 f0_2 depth_2
+  auto fetch = [&](int it, float& a1, float& a2, float& i1, float& i2) {   // one chunk ahead, see K1
+    const int j = tile * GRAD_TILE + it * GRAD_THREADS + (GRAD_THREADS - 1 - tid);
+    const bool ok = it >= 0 && j < T;
+    a1 = ok ? pl[(size_t)PL_GARG1 * T + j] : 0.0f;
+    a2 = ok ? pl[(size_t)PL_GARG2 * T + j] : 0.0f;
+    i1 = ok ? pl[(size_t)PL_INC1 * T + j] : 0.0f;
+    i2 = ok ? pl[(size_t)PL_INC2 * T + j] : 0.0f;
+  };
+  float n_ga1, n_ga2, n_inc1, n_inc2;
+  fetch(GRAD_CHUNKS - 1, n_ga1, n_ga2, n_inc1, n_inc2);
   for (int it = GRAD_CHUNKS - 1; it >= 0; --it) {
     const int j = tile * GRAD_TILE + it * GRAD_THREADS + (GRAD_THREADS - 1 - tid);   // descending in tid
     const bool ok = j < T;
-    const double ga1 = ok ? (double)pl[(size_t)PL_GARG1 * T + j] : 0.0;
-    const double ga2 = ok ? (double)pl[(size_t)PL_GARG2 * T + j] : 0.0;
+    const double ga1 = (double)n_ga1, ga2 = (double)n_ga2;
+    const float inc1 = n_inc1, inc2 = n_inc2;
+    fetch(it - 1, n_ga1, n_ga2, n_inc1, n_inc2);
     double suf1 = ga1, suf2 = ga2;
     block_incl_scan2(suf1, suf2, carry1, carry2, s_w, tid);
     if (!ok) continue;
-    const float inc1 = pl[(size_t)PL_INC1 * T + j], inc2 = pl[(size_t)PL_INC2 * T + j];
     const double gc1 = inc1 > 0.0f ? suf1 * ((double)inc1 * k) : 0.0;
     const double gc2 = inc2 > 0.0f ? suf2 * ((double)inc2 * k) : 0.0;
     int i0, i1; float w0, w1;
