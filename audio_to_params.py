@@ -23,10 +23,16 @@ def app(overrides=None):
     cfg = load_config(os.path.join(ROOT, "conf"), "config", overrides if overrides is not None else sys.argv[1:])
     # both Voices must render the same batch size
     cfg.vicreg.batch_size = cfg.audio_to_params.batch_size
+    from inverse_audio_synthesis_amd.trainer import load_reference_state_dict
+    torch.manual_seed(int(cfg.seed))     # before any module is built, as runsetup.py:22
     vicreg = VicregAudioParams(cfg)
     ckpt = os.path.join(ROOT, "vicreg.ckpt")
     if os.path.exists(ckpt):
-        vicreg.load_state_dict(torch.load(ckpt, map_location="cpu")["state_dict"])
+        # a checkpoint of this build, or one shaped like the reference's Lightning file (extra classifier / voice keys)
+        sd = torch.load(ckpt, map_location="cpu", weights_only=False)["state_dict"]
+        missing, unexpected, dropped = load_reference_state_dict(vicreg, sd)
+        if missing or unexpected:
+            print({"vicreg.ckpt": {"missing": missing, "unexpected": unexpected, "dropped": len(dropped)}}, flush=True)
     model = AudioToParams(cfg, vicreg)
     trainer = Trainer(cfg, model, stage="audio_to_params")
     history = trainer.fit()

@@ -42,18 +42,37 @@ def parse():
                     help="finish a step's PQMF / spectral loss before the next step's render starts")
     ap.add_argument("--buffers", type=int, default=2, help="audio buffers / workspaces in flight (pipeline depth)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8, help="voices in the CPU baseline sample")
+    ap.add_argument("--cpu-batch", type=int, default=32, help="voices in the CPU baseline sample")
+    ap.add_argument("--replays", type=int, default=0,
+                    help="timed regions of K steps each (0: as many as give >= 0.25 s of timed work, at least 20)")
     return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (one per GPU, RCCL
+    rendezvous on 127.0.0.1) BEFORE this process touches the GPU, wait for them, return the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    return max(abs(p.wait()) for p in procs)
 
 
 def cpu_baseline(cpu_batch):
     """The oracle (torch-CPU restatement, math="torch": the ops the reference would issue) timed on the
-    host cores over a bounded sample of the same workload: render + PQMF(3) + mel-L1 of cpu_batch voices."""
+    host cores over a bounded sample of the same workload: render + PQMF(3) + mel-L1 of cpu_batch voices.
+    Two thread counts are timed (all host threads, and at most 32 -- torch's CPU ops on [32, 176400] tensors stop
+    scaling long before 256 threads); the faster one is the reported value, both are named in `sample`."""
     from oracle import pqmf_oracle as po
     from oracle import spectral_oracle as spo
     from oracle import synth_oracle as so
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     cfg = so.VoiceConfig(batch_size=cpu_batch, sample_rate=SAMPLE_RATE, buffer_size_seconds=SECONDS)
     noise = so.make_noise(cfg)
     g = torch.Generator().manual_seed(1000)
@@ -69,26 +88,33 @@ def cpu_baseline(cpu_batch):
         loss = torch.mean(torch.abs(spo.mel_spectrogram(audio, sample_rate=SAMPLE_RATE) - tgt_mel))
         return z, loss
 
-    step()  # warm-up (thread pool, allocator)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        step()
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > 10.0 or reps >= 50:
-            break
+    runs = []
+    for threads in sorted({min(cores, 32), cores}):
+        torch.set_num_threads(threads)
+        step()  # warm-up (thread pool, allocator)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            step()
+            reps += 1
+            el = time.perf_counter() - t0
+            if (el > 8.0 and reps >= 5) or reps >= 200 or el > 40.0:
+                break
+        runs.append((cpu_batch * SECONDS * reps / el, threads, reps, el))
+    best = max(runs)
     return {
-        "value": round(cpu_batch * SECONDS * reps / el, 2),
+        "value": round(best[0], 2),
         "unit": "audio-s/s",
-        "cores": torch.get_num_threads(),
+        "cores": best[1],
         "kind": "port",
-        "sample": f"{reps} passes of render+PQMF(3)+mel-L1 over {cpu_batch} voices x {SECONDS:g} s @ {SAMPLE_RATE} Hz "
-                  f"(oracle, torch CPU ops, {el:.1f} s)",
+        "sample": f"render+PQMF(3)+mel-L1 over {cpu_batch} voices x {SECONDS:g} s @ {SAMPLE_RATE} Hz (oracle, torch CPU ops): "
+                  + "; ".join(f"{r[2]} passes in {r[3]:.1f} s on {r[1]} threads = {r[0]:.1f} audio-s/s" for r in runs),
     }
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -211,19 +237,36 @@ def main():
             graph = None
             torch.cuda.synchronize()
 
-    # ---- timed region: EXACTLY K steps between barrier+synchronize brackets
-    sync_all()
-    t0 = time.perf_counter()
-    if graph is not None:
-        graph.replay()
-    else:
-        run_steps(args.steps, pipelined)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    # ---- timed regions: each one is EXACTLY K steps between barrier+synchronize brackets; R of them are timed
+    # one after the other (a single 5 ms region is dominated by pipeline fill/drain and clock ramp) and the MEDIAN
+    # region gives `value` / `ms_per_step`; the fastest one is reported next to it.
+    def one_region():
+        sync_all()
+        t0 = time.perf_counter()
+        if graph is not None:
+            graph.replay()
+        else:
+            run_steps(args.steps, pipelined)
+        sync_all()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        return el
+
+    first = one_region()
+    replays = args.replays if args.replays > 0 else max(20, min(2000, int(0.25 / max(first, 1e-6)) + 1))
+    if world > 1:   # every rank must time the same number of regions
+        r = torch.tensor([replays], dtype=torch.int64, device=dev)
+        dist.broadcast(r, 0)
+        replays = int(r.item())
+    regions = sorted(one_region() for _ in range(replays))
+    elapsed = regions[len(regions) // 2]
+    elapsed_min = regions[0]
+    # the look-back chains of every render in the timed regions completed (a non-zero status word = NaN audio)
+    for w_ in workspaces:
+        assert voice.chain_status(w_) == 0, "voice render: a tile's bounded wait expired during the benchmark"
     loss_value = last["loss"].item()
 
     # ---- dominant-kernel timing with HIP events on the launch stream (eager: events cannot be read back
@@ -290,6 +333,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
+        "ms_per_step_min": round(elapsed_min / args.steps * 1e3, 4),
+        "timed_regions": replays, "timed_region_s": round(elapsed, 5), "timed_total_s": round(sum(regions), 4),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -304,6 +349,8 @@ def main():
             "kernel": "voice_audio_kernel (phase increments + chained fp64 scan + oscillators + mixer)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": "imported from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                              "kernel, gfx950 x2 read correction); not measured by this run",
             "avg_launch_ms": round(osc_ms_avg, 4), "algorithmic_bytes_per_launch": algo_bytes,
             "measured": "HIP events around K back-to-back launches of the stage (memset + kernel), not overlapped",
             "overlapped_avg_launch_ms": round(osc_ms_overlapped, 4),

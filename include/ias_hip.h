@@ -40,6 +40,12 @@ long long ias_voice_workspace_bytes(int B, int T, int Tc);
 int ias_voice_control(const float* params01, float* ctrl, void* vconst, float* env, int B, int Tc,
                       int control_rate, void* stream);
 
+/* ias_voice_control into the ctrl / vconst / env regions of an ias_voice_render workspace (workspace_bytes >=
+ * ias_voice_workspace_bytes(B, T, Tc)); followed by ias_voice_stage calls on the same workspace it is the render
+ * split into separately launchable pieces (pipelined schedules).  The workspace layout is private to the library. */
+int ias_voice_control_ws(const float* params01, void* workspace, long long workspace_bytes, int B, int T, int Tc,
+                         int control_rate, void* stream);
+
 /* Same as ias_voice_control plus the intermediates dbg [B,10,Tc]: rows 0-5 the envelopes,
  * 6-7 the LFO phases, 8-9 the LFO outputs. */
 int ias_voice_control_debug(const float* params01, float* ctrl, void* vconst, float* env, float* dbg, int B,
@@ -59,7 +65,7 @@ int ias_voice_stage(int stage, const float* noise, float* audio, void* workspace
                     int B, int T, int Tc, int sample_rate, void* stream);
 
 /* status[0] (device) = 0 if the last render's tile chain completed, 1 if a workgroup's bounded wait for
- * its predecessors expired (the audio of that call is then invalid). */
+ * its predecessors expired (that tile's audio is then NaN: an expired wait never continues with partial sums). */
 int ias_voice_read_status(const void* workspace, unsigned* status, int B, int T, int Tc, void* stream);
 
 /* Copy the B row peaks (max |x| before normalisation) of the last render out of the workspace. */

@@ -29,6 +29,7 @@ SYMBOLS = {
     "ias_stream_copy": (_I, [_P, _P, _LL, _P]),
     "ias_voice_workspace_bytes": (_LL, [_I, _I, _I]),
     "ias_voice_control": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "ias_voice_control_ws": (_I, [_P, _P, _LL, _I, _I, _I, _I, _P]),
     "ias_voice_control_debug": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ias_voice_render": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _P]),
     "ias_voice_stage": (_I, [_I, _P, _P, _P, _LL, _I, _I, _I, _I, _P]),

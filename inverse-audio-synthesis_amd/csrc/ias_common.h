@@ -20,6 +20,8 @@
 #define IAS_ERR_WORKSPACE (-4)  // workspace too small
 
 #define IAS_NPARAMS 78
+// torchsynth LFO shape-mix exponent: LFO.__init__'s default `exponent = tensor(e)`, i.e. the fp32 0x402DF854
+#define IAS_LFO_EXPONENT_F 2.7182817459106445f
 #define IAS_NCTRL 5             // mod-matrix outputs: vco1 pitch, vco1 amp, vco2 pitch, vco2 amp, noise amp
 
 // Per-voice scalars produced by the control-rate kernel, consumed at audio rate.

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
   double mode[2][5], msum[2];
   for (int m = 0; m < 2; ++m) {
     msum[m] = 0.0;
-    for (int s = 0; s < 5; ++s) { const double p = s_v[lfo_base[m] + 3 + s]; mode[m][s] = p * p; msum[m] += mode[m][s]; }
+    for (int s = 0; s < 5; ++s) { mode[m][s] = pow(s_v[lfo_base[m] + 3 + s], (double)IAS_LFO_EXPONENT_F); msum[m] += mode[m][s]; }
     for (int s = 0; s < 5; ++s) mode[m][s] /= msum[m];
   }
   double w[5][4];
@@ -239,8 +239,10 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
     double gm[5], dot = 0.0;
     for (int s = 0; s < 5; ++s) { gm[s] = cg_block_sum(gmode[m][s], s_red, tid); dot += gm[s] * mode[m][s]; }
     if (tid == 0)
-      for (int s = 0; s < 5; ++s)   // mode = p^2 / sum p^2
-        s_gv[lfo_base[m] + 3 + s] += (gm[s] - dot) / msum[m] * 2.0 * s_v[lfo_base[m] + 3 + s];
+      for (int s = 0; s < 5; ++s) {   // mode = p^e / sum p^e;  d p^e / dp = e p^(e-1)
+        const double p = s_v[lfo_base[m] + 3 + s], ex = (double)IAS_LFO_EXPONENT_F;
+        s_gv[lfo_base[m] + 3 + s] += (gm[s] - dot) / msum[m] * ex * pow(p, ex - 1.0);
+      }
   }
 
   // ---- LFO phase gradient: reverse cumulative sum, then frequency / depth / rate envelope

@@ -322,8 +322,13 @@ __global__ __launch_bounds__(AUDIO_THREADS) void voice_audio_kernel(
     }
     a1 = wave_sum(a1); a2 = wave_sum(a2);
     if (lane == 0) {
+      // an expired wait never continues with partial carries: the tile's phases (hence its audio) become NaN,
+      // and the status word says why
+      if (timeout) {
+        a1 = a2 = __longlong_as_double(0x7ff8000000000000ll);
+        __hip_atomic_store((gu32*)ticket_status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       s_carry[0] = a1; s_carry[1] = a2;
-      if (timeout) __hip_atomic_store((gu32*)ticket_status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();
@@ -483,6 +488,20 @@ static int voice_control_launch(const float* params01, float* ctrl, void* vconst
 extern "C" int ias_voice_control(const float* params01, float* ctrl, void* vconst, float* env, int B, int Tc,
                                  int control_rate, void* stream_) {
   return voice_control_launch(params01, ctrl, vconst, env, nullptr, B, Tc, control_rate, stream_);
+}
+
+// The same pass into the ctrl / vconst / env regions of an ias_voice_render workspace (the layout stays private to
+// this file: callers that split the render into control + stages never compute offsets themselves).
+extern "C" int ias_voice_control_ws(const float* params01, void* workspace, long long workspace_bytes, int B, int T,
+                                    int Tc, int control_rate, void* stream_) {
+  if (!workspace) return IAS_ERR_ARG;
+  int rc = voice_check_dims(B, T, Tc);
+  if (rc) return rc;
+  const VoiceWs w = voice_ws_layout(B, T, Tc);
+  if ((size_t)workspace_bytes < w.total) return IAS_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  return voice_control_launch(params01, (float*)(ws + w.off_ctrl), ws + w.off_vconst, (float*)(ws + w.off_env), nullptr,
+                              B, Tc, control_rate, stream_);
 }
 
 // Same, plus the control-rate intermediates dbg [B][10][Tc] (6 envelopes, 2 LFO phases, 2 LFO outputs).

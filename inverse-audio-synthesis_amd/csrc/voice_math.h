@@ -226,9 +226,10 @@ IAS_HD float ias_dot4_cr(float w0, float w1, float w2, float w3, float s0, float
   return (float)o;
 }
 
+// torchsynth LFO: mode = pow(p, exponent) / sum with the LFO.__init__ default exponent (IAS_LFO_EXPONENT_F)
 IAS_HD void ias_lfo_mode(const float* p5, float* mode) {
   float m[5];
-  for (int k = 0; k < 5; ++k) m[k] = ias_mul(p5[k], p5[k]);  // pow(x, 2) correctly rounded
+  for (int k = 0; k < 5; ++k) m[k] = ias_pow_cr(p5[k], IAS_LFO_EXPONENT_F);
   const float s = (float)((double)m[0] + (double)m[1] + (double)m[2] + (double)m[3] + (double)m[4]);
   for (int k = 0; k < 5; ++k) mode[k] = ias_div(m[k], s);
 }

@@ -52,8 +52,17 @@ class GradBucketer:
     """Bucketed, backward-overlapped gradient averaging for ``module`` (replicas only: no SyncBN,
     matching the reference's plain DDP)."""
 
-    def __init__(self, module, bucket_bytes=128 << 20):
+    def __init__(self, module, bucket_bytes=128 << 20, always_reduce=False):
+        """``always_reduce``: issue the collectives on a one-rank group as well (exercises the RCCL path on a
+        single GPU; tests)."""
         self.world = world_size()
+        self.collective = dist.is_available() and dist.is_initialized() and (self.world > 1 or always_reduce)
+        if self.collective:
+            # replicas start from rank 0's parameters AND buffers (BatchNorm running statistics), as torch DDP /
+            # Lightning's strategy "ddp" do at construction (/root/reference/conf/config.yaml:8 -> pretrain.py:97-99)
+            with torch.no_grad():
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t, 0)
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.buckets = []      # (flat buffer, [params])
         self._pending = {}     # bucket index -> grads still to arrive this step
@@ -101,12 +110,12 @@ class GradBucketer:
             view.copy_(p.grad)
             p.grad = view
         self._pending[bi] -= 1
-        if self._pending[bi] == 0 and self.world > 1:
+        if self._pending[bi] == 0 and self.collective:
             self._work.append(dist.all_reduce(flat, async_op=True))
 
     def finish(self):
         """Wait for the outstanding all-reduces and turn sums into means."""
-        if self.world == 1:
+        if not self.collective:
             return
         # parameters that received no gradient this step still have to take part in the collective
         for bi, (flat, _plist) in enumerate(self.buckets):

@@ -37,11 +37,12 @@ class LARS(torch.optim.Optimizer):
                 p_norm = torch._foreach_norm(ps)
                 g_norm = torch._foreach_norm(gs)
                 pn, gn = torch.stack(p_norm), torch.stack(g_norm)
-                ratio = torch.where((pn != 0) & (gn != 0),
-                                    pn / (gn + pn * wd + group["eps"]) * group["trust_coefficient"],
+                # flash's LARS applies BOTH the weight decay and the trust ratio only where p_norm != 0 and g_norm != 0
+                on = (pn != 0) & (gn != 0)
+                ratio = torch.where(on, pn / (gn + pn * wd + group["eps"]) * group["trust_coefficient"],
                                     torch.ones_like(pn))
-                upd = torch._foreach_add(gs, ps, alpha=wd)
-                torch._foreach_mul_(upd, list(ratio.unbind(0)))
+                upd = torch._foreach_mul(gs, list(ratio.unbind(0)))
+                torch._foreach_add_(upd, torch._foreach_mul(ps, list((ratio * wd * on).unbind(0))))
             else:
                 upd = [g.clone() for g in gs]
             if mom != 0:

@@ -15,16 +15,37 @@ import torch
 from . import dist as ias_dist
 
 
-def split_indices(num_batches, ntest_batches, seed, count, part, rank=0, world=1):
-    """``count`` batch indices of split ``part`` in {"train","val","test"}: a seeded draw from the
-    index universe (train = [0, 0.9n), val = [0.9n, n - ntest), test = the last ntest)."""
+def _feistel_perm(i, m, seed):
+    """Index i of a seeded permutation of range(m), in O(1) memory: a 4-round Feistel network on the next even
+    number of bits, cycle-walked back into [0, m).  Draws are therefore WITHOUT replacement, like the reference's
+    ``random_split`` permutation (/root/reference/runsetup.py:28-44), without materialising 50 M indices."""
+    bits = max(2, (int(m - 1).bit_length() + 1) // 2 * 2)
+    half, mask = bits // 2, (1 << (bits // 2)) - 1
+    x = int(i)
+    while True:
+        l, r = x >> half, x & mask
+        for rnd in range(4):
+            f = ((r * 0x9E3779B1 + (int(seed) + 1) * 0x85EBCA77 + rnd * 0xC2B2AE3D) >> 7) & mask
+            l, r = r, l ^ f
+        x = (l << half) | r
+        if x < m:
+            return x
+
+
+def split_sizes(num_batches, ntest_batches):
     n = int(num_batches)
     lo_val = int(0.9 * (n - ntest_batches))
-    ranges = {"train": (0, lo_val), "val": (lo_val, n - ntest_batches), "test": (n - ntest_batches, n)}
-    lo, hi = ranges[part]
-    g = torch.Generator().manual_seed(int(seed) + {"train": 0, "val": 1, "test": 2}[part])
-    idx = torch.randint(lo, hi, (count * world,), generator=g)
-    return idx[rank::world].tolist()
+    return {"train": (0, lo_val), "val": (lo_val, n - ntest_batches), "test": (n - ntest_batches, n)}
+
+
+def split_indices(num_batches, ntest_batches, seed, count, part, rank=0, world=1, start=0):
+    """``count`` batch indices (per rank) of split ``part`` in {"train","val","test"}: consecutive entries of a seeded
+    permutation of that split's slice of the index universe (train = [0, 0.9n), val = [0.9n, n - ntest), test = the
+    last ntest), rank-strided; no index repeats until the split is exhausted."""
+    lo, hi = split_sizes(num_batches, ntest_batches)[part]
+    m = hi - lo
+    sd = int(seed) * 3 + {"train": 0, "val": 1, "test": 2}[part]
+    return [lo + _feistel_perm((start + k * world + rank) % m, m, sd) for k in range(count)]
 
 
 class Trainer:
@@ -32,7 +53,8 @@ class Trainer:
         self.cfg, self.module, self.stage = cfg, module, stage
         self.rank, self.local_rank, self.world = ias_dist.init_from_env()
         self.device = device or torch.device("cuda", self.local_rank)
-        torch.manual_seed(cfg.seed)
+        # (the entry points seed BEFORE building the module, as runsetup.py:22 does; GradBucketer then broadcasts
+        # rank 0's parameters and buffers, as Lightning's DDP does, so replicas start identical by construction)
         self.module.to(self.device)
         opt = module.configure_optimizers()
         if isinstance(opt, dict):
@@ -61,22 +83,36 @@ class Trainer:
         os.makedirs(self.out_dir, exist_ok=True)
         path = os.path.join(self.out_dir, name)
         torch.save({"state_dict": self.module.state_dict(), "optimizer": self.optimizer.state_dict(),
-                    "scheduler": self.scheduler.state_dict() if self.scheduler else None}, path)
+                    "scheduler": self.scheduler.state_dict() if self.scheduler else None,
+                    "step": getattr(self, "_step", 0)}, path)
         return path
 
-    def load_checkpoint(self, path):
-        ck = torch.load(path, map_location=self.device)
-        self.module.load_state_dict(ck["state_dict"])
+    def load_checkpoint(self, path, strict=True):
+        """Resume: module, optimizer and scheduler state (so a resumed LARS run does not restart its warm-up)."""
+        ck = torch.load(path, map_location=self.device, weights_only=False)
+        self.module.load_state_dict(ck["state_dict"], strict=strict)
+        if ck.get("optimizer") is not None:
+            self.optimizer.load_state_dict(ck["optimizer"])
+        if self.scheduler is not None and ck.get("scheduler") is not None:
+            self.scheduler.load_state_dict(ck["scheduler"])
+        self.start_step = int(ck.get("step", 0))
         return ck
 
     def fit(self, max_steps=None):
         cfg, st = self.cfg, self.cfg[self.stage]
-        steps = max_steps or cfg.trainer.max_steps or st.limit_train_batches
-        assert steps, "set trainer.max_steps or <stage>.limit_train_batches"
-        idx = split_indices(cfg.num_batches, cfg.ntest_batches, cfg.seed, steps, "train", self.rank, self.world)
+        lo, hi = split_sizes(cfg.num_batches, cfg.ntest_batches)["train"]
+        # null / null = one epoch over the train split (what the reference's max_epochs=1 means), shared by the ranks
+        steps = max_steps or cfg.trainer.max_steps or st.limit_train_batches or (hi - lo) // self.world
+        start = getattr(self, "start_step", 0)
+        idx = split_indices(cfg.num_batches, cfg.ntest_batches, cfg.seed, steps, "train", self.rank, self.world,
+                            start=start * self.world) if steps <= 1 << 20 else None
+        val_every, val_count = st.get("val_check_interval"), st.get("limit_val_batches")
         self.module.train()
         t0 = time.perf_counter()
-        for step, batch in enumerate(idx):
+        for step in range(steps):
+            batch = idx[step] if idx is not None else split_indices(
+                cfg.num_batches, cfg.ntest_batches, cfg.seed, 1, "train", self.rank, self.world,
+                start=(start + step) * self.world)[0]
             self.bucketer.begin_step()
             loss = self.module.training_step(batch, step)
             loss.backward()
@@ -84,11 +120,19 @@ class Trainer:
             self.optimizer.step()
             if self.scheduler is not None:
                 self.scheduler.step()
+            self._step = start + step + 1
             if step % int(cfg.trainer.log_every) == 0 or step == steps - 1:
                 self._log(step, {"elapsed_s": round(time.perf_counter() - t0, 3)})
             every = st.get("checkpoint_every_nbatches")
             if every and (step + 1) % int(every) == 0:
                 self.save_checkpoint(f"{self.stage}-step{step + 1:06d}.ckpt")
+            if val_every and val_count and (step + 1) % int(val_every) == 0 and hasattr(self.module, "validation_step"):
+                val = self.evaluate("val", count=int(val_count))   # Lightning's val_check_interval
+                keys = val[0].keys() if val else []
+                self.history.append({"step": step, **{k: sum(v[k] for v in val) / len(val) for k in keys}})
+                if self.rank == 0:
+                    print(json.dumps(self.history[-1]), flush=True)
+                self.module.train()
         self.save_checkpoint(f"{self.stage}-last.ckpt")
         return self.history
 
@@ -102,3 +146,15 @@ class Trainer:
             getattr(self.module, step_fn)(batch, i)
             out.append({k: float(ias_dist.all_reduce_mean(v)) for k, v in self.module.logged.items()})
         return out
+
+
+def load_reference_state_dict(module, state_dict):
+    """Load a state_dict shaped like the reference's Lightning ``vicreg.ckpt`` (/root/reference/downstream.py:29) into
+    this build's ``VicregAudioParams``.  The reference's checkpoint also holds the torchvision classifier head
+    (``*.classifier.*``; this build keeps only ``.features``, the part audioembed.py:61 uses) and torchsynth's
+    per-module ``voice.*`` parameter tensors (the Voice here registers no parameters: it is re-seeded per batch);
+    those are dropped.  Anything else that does not line up is reported.  -> (missing, unexpected, dropped)"""
+    dropped = [k for k in state_dict if ".classifier." in k or k.startswith("voice.") or ".voice." in k]
+    kept = {k: v for k, v in state_dict.items() if k not in set(dropped)}
+    res = module.load_state_dict(kept, strict=False)
+    return list(res.missing_keys), list(res.unexpected_keys), dropped

@@ -86,7 +86,9 @@ class VICReg(nn.Module):
 
     def loss(self, x, y):
         assert x.shape[1] == self.embeddim
-        if self.gather_distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # "always": gather on a one-rank group too (runs the RCCL branch on a single GPU; tests and bench)
+        if self.gather_distributed and dist.is_available() and dist.is_initialized() and \
+                (dist.get_world_size() > 1 or self.gather_distributed == "always"):
             x = torch.cat(FullGatherLayer.apply(x), dim=0)
             y = torch.cat(FullGatherLayer.apply(y), dim=0)
         v = self.cfg.vicreg

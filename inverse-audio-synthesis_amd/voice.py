@@ -13,6 +13,7 @@ Reference call sites (the classes themselves live in the absent third-party
 The render itself is the HIP path (csrc/voice_kernels.hip); parameter sampling stays on
 the host with torch's CPU generator so that seeds mean the same thing as in the oracle.
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -20,6 +21,8 @@ import torch.nn as nn
 
 from . import _lib
 from . import voice_spec as S
+
+_CHECK_STATUS = os.environ.get("IAS_CHECK_STATUS", "0") not in ("", "0")
 
 
 class SynthConfig:
@@ -170,6 +173,7 @@ class Voice(nn.Module):
                                   self._workspace.numel(), c.batch_size, c.buffer_size, c.control_buffer_size,
                                   c.sample_rate, c.control_rate, 1 if normalize else 0, _lib.stream())
         _lib.check(st, "ias_voice_render")
+        self._check_chain(self._workspace)
         return audio
 
     def new_workspace(self, device=None):
@@ -182,15 +186,9 @@ class Voice(nn.Module):
         """Control-rate pass only (78 params -> control signals + per-voice constants) into ``workspace``."""
         c = self.synthconfig
         p = (self.params01 if params01 is None else params01).detach().to(torch.float32).contiguous()
-        lib = _lib.load()
-        # workspace layout: ctrl, vconst (64 B per voice), env (csrc/voice_kernels.hip voice_ws_layout)
-        a256 = lambda n: (n + 255) // 256 * 256
-        ctrl_bytes = a256(4 * c.batch_size * 5 * c.control_buffer_size)
-        env_off = ctrl_bytes + a256(64 * c.batch_size)
-        st = lib.ias_voice_control(_lib.ptr(p), _lib.ptr(workspace), _lib.ptr(workspace[ctrl_bytes:]),
-                                   _lib.ptr(workspace[env_off:]), c.batch_size, c.control_buffer_size, c.control_rate,
-                                   _lib.stream())
-        _lib.check(st, "ias_voice_control")
+        st = _lib.load().ias_voice_control_ws(_lib.ptr(p), _lib.ptr(workspace), workspace.numel(), c.batch_size,
+                                              c.buffer_size, c.control_buffer_size, c.control_rate, _lib.stream())
+        _lib.check(st, "ias_voice_control_ws")
 
     def render_audio(self, workspace, out=None, on_stage=None, normalize=True):
         """Audio-rate pass (+ normalise) from a workspace ``render_control`` has filled -> audio [B,T]."""
@@ -208,6 +206,7 @@ class Voice(nn.Module):
                                      c.batch_size, c.buffer_size, c.control_buffer_size, c.sample_rate, _lib.stream())
             _lib.check(st, f"ias_voice_stage({name})")
             hook(name, "end")
+        self._check_chain(workspace)
         return audio
 
     def render_staged(self, params01=None, on_stage=None, out=None):
@@ -231,14 +230,24 @@ class Voice(nn.Module):
                                                     c.control_buffer_size, _lib.stream()), "ias_voice_read_peaks")
         return pk
 
-    def chain_status(self):
-        """0 if the last render's cross-tile scan completed; 1 if a bounded wait expired (tests)."""
+    def chain_status(self, workspace=None):
+        """0 if the last render into ``workspace`` (default: the module's own) completed its cross-tile scan; 1 if a
+        bounded wait for a predecessor tile expired.  Synchronises (reads one word back)."""
         c = self.synthconfig
-        st = torch.zeros(1, dtype=torch.int32, device=self._workspace.device)
-        _lib.check(_lib.load().ias_voice_read_status(_lib.ptr(self._workspace), _lib.ptr(st), c.batch_size,
+        ws = self._workspace if workspace is None else workspace
+        st = torch.zeros(1, dtype=torch.int32, device=ws.device)
+        _lib.check(_lib.load().ias_voice_read_status(_lib.ptr(ws), _lib.ptr(st), c.batch_size,
                                                      c.buffer_size, c.control_buffer_size, _lib.stream()),
                    "ias_voice_read_status")
         return int(st.item())
+
+    def _check_chain(self, workspace):
+        """An expired wait is never silent: the kernel turns that tile's audio into NaN (so any loss computed from it
+        is NaN), and with IAS_CHECK_STATUS=1 every render also reads the status word back and raises (this
+        synchronises, so it is opt-in and skipped while a hipGraph is being captured)."""
+        if _CHECK_STATUS and not torch.cuda.is_current_stream_capturing() and self.chain_status(workspace) != 0:
+            raise RuntimeError("voice render: a tile's bounded wait for its predecessors expired "
+                               "(ias_voice_read_status != 0); the audio of that tile is NaN")
 
     def control_debug(self, params01=None):
         """Control-rate intermediates [B,10,Tc] (envelopes, LFO phases, LFO outputs) for tests."""

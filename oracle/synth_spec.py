@@ -76,6 +76,6 @@ INDEX = {(m, n): i for i, (m, n, *_r) in enumerate(PARAMS)}
 # Constants of the signal graph.
 CONTROL_RATE = 441
 EPS = 1e-6
-LFO_EXPONENT = 2.0
+LFO_EXPONENT = 2.7182817459106445  # torchsynth LFO default exponent tensor(e), as the fp32 it is stored in
 NOISE_SEED = 13
 REPRODUCIBLE_SUBBATCH = 32

@@ -13,6 +13,8 @@ def app(overrides=None):
     from inverse_audio_synthesis_amd.harness import VicregAudioParams
     from inverse_audio_synthesis_amd.trainer import Trainer
     cfg = load_config(os.path.join(ROOT, "conf"), "config", overrides if overrides is not None else sys.argv[1:])
+    import torch
+    torch.manual_seed(int(cfg.seed))     # seed_everything(42) BEFORE the model is built (runsetup.py:22 -> pretrain.py:60)
     model = VicregAudioParams(cfg)
     trainer = Trainer(cfg, model, stage="vicreg")
     if trainer.rank == 0:

@@ -65,3 +65,58 @@ def test_lars_matches_single_tensor_formula():
             ref[i] = w - 0.5 * bufs[i]
         for p, w in zip(ps, ref):
             assert torch.allclose(p.detach(), w, atol=1e-6)
+
+
+def test_lars_skips_weight_decay_when_a_norm_is_zero():
+    """flash's LARS adds weight decay only where p_norm != 0 and g_norm != 0: a parameter whose gradient is exactly
+    zero must not move (plain `g + wd p` would shrink it)."""
+    p = torch.nn.Parameter(torch.ones(3))
+    q = torch.nn.Parameter(torch.zeros(3))
+    opt = LARS([p, q], lr=1.0, weight_decay=0.1)
+    p.grad = torch.zeros(3)
+    q.grad = torch.ones(3)
+    opt.step()
+    assert torch.equal(p.detach(), torch.ones(3))          # g_norm == 0: no decay, no update
+    assert torch.allclose(q.detach(), -torch.ones(3))      # p_norm == 0: plain gradient step, ratio 1
+
+
+def test_split_indices_draw_without_replacement():
+    from inverse_audio_synthesis_amd.trainer import split_indices, split_sizes
+    n, nt = 1000, 10
+    sz = split_sizes(n, nt)
+    tr = split_indices(n, nt, 42, sz["train"][1] - sz["train"][0], "train")
+    assert sorted(tr) == list(range(*sz["train"])), "one epoch visits every train index exactly once"
+    va = split_indices(n, nt, 42, 50, "val")
+    te = split_indices(n, nt, 42, nt, "test")
+    assert len(set(va)) == 50 and all(sz["val"][0] <= i < sz["val"][1] for i in va)
+    assert sorted(te) == list(range(n - nt, n))
+    # rank-strided: two ranks see disjoint indices, together the one-rank sequence
+    r0 = split_indices(n, nt, 42, 20, "train", 0, 2)
+    r1 = split_indices(n, nt, 42, 20, "train", 1, 2)
+    assert not set(r0) & set(r1) and sorted(r0 + r1) == sorted(tr[:40])
+    assert split_indices(n, nt, 43, 20, "train") != tr[:20]
+    # the full-size universe is addressed lazily
+    big = split_indices(50_000_000, 1, 42, 5, "train")
+    assert len(set(big)) == 5 and all(0 <= i < 45_000_000 for i in big)
+
+
+def test_reference_shaped_checkpoint_loads():
+    """A state_dict shaped like the reference's Lightning vicreg.ckpt (with torchvision classifier keys and
+    torchsynth voice.* parameter tensors) loads into VicregAudioParams; only the documented extras are dropped."""
+    import warnings
+    from inverse_audio_synthesis_amd.harness import VicregAudioParams
+    from inverse_audio_synthesis_amd.trainer import load_reference_state_dict
+    cfg = load_config(os.path.join(ROOT, "conf"), "config", ["vicreg=fast", "dim=32", "embeddim=64",
+                                                             "vicreg.batch_size=2", "vicreg.mlp=48-48-%d"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = VicregAudioParams(cfg)
+    sd = {k: torch.randn_like(v) if v.is_floating_point() else v.clone() for k, v in m.state_dict().items()}
+    sd["vision_model.classifier.0.weight"] = torch.zeros(1024, 576)
+    sd["audio_repr.vision_model.classifier.3.bias"] = torch.zeros(1000)
+    sd["voice.adsr_1.torchparameters.attack"] = torch.zeros(2)
+    sd["voice.noise.noise"] = torch.zeros(2, 8)
+    missing, unexpected, dropped = load_reference_state_dict(m, sd)
+    assert missing == [] and unexpected == [] and len(dropped) == 4
+    k = "vicreg.projector.0.weight"
+    assert torch.equal(m.state_dict()[k], sd[k])

@@ -123,3 +123,50 @@ def test_low_pitch_square_shaper_accuracy(lib, dev):
     ref = so.render_from_params01(cfg, p, so.make_noise(cfg), "cr")
     got = v.render(p.to(dev)).cpu()
     assert (got - ref).abs().max().item() <= AUDIO_TOL
+
+
+def _distance_stats(a, ref):
+    """per-voice relative L2 (max, median), max |delta|, fraction of samples with |delta| > 1e-4"""
+    d = (a.double() - ref.double())
+    rel = d.norm(dim=1) / ref.double().norm(dim=1).clamp_min(1e-30)
+    return dict(rel_l2_max=rel.max().item(), rel_l2_median=rel.median().item(), max_abs=d.abs().max().item(),
+                frac_gt_1e4=(d.abs() > 1e-4).double().mean().item())
+
+
+# Documented bounds on the distance to the reference's own op sequence (oracle math "torch": fp32 torch CPU ops as
+# torchsynth issues them).  The reference is only reproducible to this level across libm / BLAS builds: one ulp in an
+# fp32 exp2 / pow upstream of the phase accumulates over 176400 samples (DESIGN.md section 2.1).  Measured values are
+# written to gpurun_out/parity_vs_torch.json and quoted in DESIGN.md.
+TORCH_REL_L2_MAX, TORCH_REL_L2_MEDIAN, TORCH_MAX_ABS, TORCH_FRAC = 6e-3, 3e-4, 6e-2, 6e-2
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_headline_size_distance_to_reference_op_sequence(lib, dev, seed):
+    """B=128 x 4 s @ 44.1 kHz (BASELINE configs[1]): the HIP render against the oracle's "torch" mode -- the op
+    sequence the reference CPU path issues -- and, on the same inputs, "cr" against "torch": the HIP path is no
+    farther from the reference's arithmetic than a second correctly-rounded CPU evaluation of it is."""
+    import json
+    import os
+    B = 128
+    v = _voice(dev, B, 44100, 4.0)
+    audio, params, _ = v(seed)
+    assert v.chain_status() == 0
+    cfg = so.VoiceConfig(batch_size=B)
+    noise = so.make_noise(cfg)
+    ref_t = so.render_from_params01(cfg, params.cpu(), noise, "torch")
+    ref_c = so.render_from_params01(cfg, params.cpu(), noise, "cr")
+    a = audio.cpu()
+    hip_t, cr_t, hip_c = _distance_stats(a, ref_t), _distance_stats(ref_c, ref_t), _distance_stats(a, ref_c)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, f"parity_vs_torch_seed{seed}.json"), "w") as f:
+        json.dump({"B": B, "seed": seed, "hip_vs_torch": hip_t, "cr_vs_torch": cr_t, "hip_vs_cr": hip_c}, f)
+    print(f"[parity B=128 seed={seed}] hip-vs-torch {hip_t}  cr-vs-torch {cr_t}  hip-vs-cr {hip_c}")
+    # the asserted contract with the HIP path's own arithmetic definition ("cr"): north_star's 1e-4
+    assert hip_c["max_abs"] <= AUDIO_TOL and hip_c["rel_l2_max"] <= AUDIO_TOL
+    # distance to the reference op sequence: inside the documented libm-to-libm spread ...
+    assert hip_t["rel_l2_max"] <= TORCH_REL_L2_MAX and hip_t["rel_l2_median"] <= TORCH_REL_L2_MEDIAN
+    assert hip_t["max_abs"] <= TORCH_MAX_ABS and hip_t["frac_gt_1e4"] <= TORCH_FRAC
+    # ... and no larger than the distance of the correctly-rounded CPU evaluation to it
+    for k in hip_t:
+        assert hip_t[k] <= cr_t[k] * 1.02 + 1e-6, (k, hip_t[k], cr_t[k])

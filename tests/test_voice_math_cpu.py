@@ -73,6 +73,22 @@ def test_torch_vs_cr_math_spread_is_documented():
     assert rel < 5e-2
 
 
+def test_torch_vs_cr_spread_at_full_length():
+    """4 s @ 44.1 kHz, 16 voices: the spread between the reference op sequence evaluated with torch's fp32 CPU ops
+    and with correctly rounded ops -- the bound the GPU parity test (tests/test_voice_gpu.py) asserts for the HIP
+    render against "torch" is this spread, not 1e-4."""
+    cfg = so.VoiceConfig(batch_size=16)
+    noise = so.make_noise(cfg)
+    p01 = so.sample_params01(cfg, 0)
+    a = so.render_from_params01(cfg, p01, noise, "torch")
+    b = so.render_from_params01(cfg, p01, noise, "cr")
+    d = (a - b).double()
+    rel = d.norm(dim=1) / b.double().norm(dim=1)
+    assert rel.max().item() <= 6e-3 and rel.median().item() <= 3e-4
+    assert d.abs().max().item() <= 6e-2
+    assert (d.abs() > 1e-4).double().mean().item() <= 6e-2
+
+
 def test_fast_formulations_are_bit_identical(emul):
     """The cheaper device formulations (fp64-reciprocal divisions, degree-10 exp2 polynomial) give the
     same fp32 bits as the specification ones, for the sample rates the configs use."""
