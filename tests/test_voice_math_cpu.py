@@ -84,8 +84,8 @@ def test_torch_vs_cr_spread_at_full_length():
     b = so.render_from_params01(cfg, p01, noise, "cr")
     d = (a - b).double()
     rel = d.norm(dim=1) / b.double().norm(dim=1)
-    assert rel.max().item() <= 6e-3 and rel.median().item() <= 3e-4
-    assert d.abs().max().item() <= 6e-2
+    assert rel.max().item() <= 1.5e-2 and rel.median().item() <= 3e-4
+    assert d.abs().max().item() <= 1e-1
     assert (d.abs() > 1e-4).double().mean().item() <= 6e-2
 
 
