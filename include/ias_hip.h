@@ -52,17 +52,19 @@ int ias_voice_control_debug(const float* params01, float* ctrl, void* vconst, fl
                             int Tc, int control_rate, void* stream);
 
 /* Voice.output(): params01 [B,78], noise [B,T] (the fixed Noise(seed=13) buffer) -> audio [B,T].
- * normalize != 0 applies torchsynth's normalize_if_clipping (row / max(|row|) when the max > 1). */
+ * normalize != 0 applies torchsynth's normalize_if_clipping (row / max(|row|) when the max > 1).
+ * math_mode 0: the tested arithmetic contract (oracle math "cr": every fp32 operation of the phase path correctly
+ * rounded); 1: the pitch exp2 is the hardware's fp32 v_exp_f32 (<= 1 ulp, the reference's own precision) -- kept
+ * for the A/B measurement in DESIGN.md, not covered by the bit-exactness tests. */
 int ias_voice_render(const float* params01, const float* noise, float* audio, void* workspace,
                      long long workspace_bytes, int B, int T, int Tc, int sample_rate, int control_rate,
-                     int normalize, void* stream);
+                     int normalize, int math_mode, void* stream);
 
-/* One stage of ias_voice_render on a workspace ias_voice_control(params01, ws.ctrl, ws.vconst) has
- * filled (ias_voice_render = control + stage 0 [+ stage 1]): 0 the single-pass audio-rate kernel
- * (phase increments, chained fp64 scan across tiles, oscillators, mixer -> unnormalised audio and row
- * peaks), 1 normalize_if_clipping in place. */
-int ias_voice_stage(int stage, const float* noise, float* audio, void* workspace, long long workspace_bytes,
-                    int B, int T, int Tc, int sample_rate, void* stream);
+/* One stage of ias_voice_render on a workspace ias_voice_control_ws has filled (ias_voice_render = control +
+ * stage 0 [+ stage 1]): 0 the single-pass audio-rate kernel (phase increments, chained fp64 scan across tiles,
+ * oscillators, mixer -> unnormalised audio and row peaks), 1 normalize_if_clipping in place. */
+int ias_voice_stage(int stage, int math_mode, const float* noise, float* audio, void* workspace,
+                    long long workspace_bytes, int B, int T, int Tc, int sample_rate, void* stream);
 
 /* status[0] (device) = 0 if the last render's tile chain completed, 1 if a workgroup's bounded wait for
  * its predecessors expired (that tile's audio is then NaN: an expired wait never continues with partial sums). */

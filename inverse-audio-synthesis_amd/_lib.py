@@ -31,8 +31,8 @@ SYMBOLS = {
     "ias_voice_control": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ias_voice_control_ws": (_I, [_P, _P, _LL, _I, _I, _I, _I, _P]),
     "ias_voice_control_debug": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "ias_voice_render": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _P]),
-    "ias_voice_stage": (_I, [_I, _P, _P, _P, _LL, _I, _I, _I, _I, _P]),
+    "ias_voice_render": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ias_voice_stage": (_I, [_I, _I, _P, _P, _P, _LL, _I, _I, _I, _I, _P]),
     "ias_voice_read_status": (_I, [_P, _P, _I, _I, _I, _P]),
     "ias_voice_read_peaks": (_I, [_P, _P, _I, _I, _I, _P]),
     "ias_voice_grad_tiles": (_I, [_I]),

@@ -16,6 +16,8 @@
 //
 // HBM traffic per audio sample: noise 4 B read + 4 B write (pass 1), 4 B read + 4 B write
 // (normalise).  Control-rate traffic is < 0.1 %.
+#include <cstdio>
+#include <cstdlib>
 #include "voice_math.h"
 #include "wave_ops.h"
 #include "voice_table.h"
@@ -26,11 +28,6 @@
 #define AUDIO_WAVES (AUDIO_THREADS / 64)
 #define VOICE_SPT 16                          // samples per thread (8 and 12 measured slower: per-tile latencies)
 #define VOICE_TILE (AUDIO_THREADS * VOICE_SPT)  // 4096 samples per workgroup
-#ifndef VOICE_RUN
-#define VOICE_RUN 4                            // consecutive samples of a lane within one chunk (one wave scan per chunk);
-                                              // 8 halves the scans but costs a wave of occupancy (110 VGPRs): same time
-#endif
-#define VOICE_CHUNKS (VOICE_SPT / VOICE_RUN)
 
 __constant__ IasParamRange c_param_table[IAS_NPARAMS] = IAS_PARAM_TABLE_INIT;
 
@@ -178,228 +175,462 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_modmix_kernel(
 #define VOICE_MAXCTRL 320  // control points staged per tile (covers sample rates down to ~6 kHz)
 #define VOICE_SPIN_LIMIT (1u << 24)
 #define VOICE_READY_BIT 0x8000000000000000ull
+#ifndef VOICE_MIN_WAVES
+#define VOICE_MIN_WAVES 3    // waves per SIMD the audio kernel is compiled for (<= 168 VGPRs: two tiles' increments)
+#endif
+#ifndef VOICE_GROUP
+#define VOICE_GROUP 4        // samples the compiler may interleave (a scheduling barrier after each group)
+#endif
+#define VOICE_NCOUNTERS 8   // ticket counters (one 128-byte line each): counter c hands out the tiles of the voices b % 8 == c
+#define VOICE_SYNC_HEAD_BYTES ((VOICE_NCOUNTERS + 1) * 128)   // counters, then the line of the status word
+#define VOICE_MATH_CR 0     // pitch exp2 correctly rounded (oracle math "cr"): the default and the tested contract
+#define VOICE_TAB_DOUBLES ((IAS_EXP2_TAB_LEN + 1) / 2 * 2)   // table padded to 16 bytes
+#define VOICE_MATH_HW 1     // pitch exp2 = v_exp_f32 (the reference's own precision: fp32 exp2, <= 1 ulp); A/B only
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 
-// Single pass over the row with a chained scan across tiles ("decoupled look-back"):
-//   ticket  -> (tile, voice), tile-major; tickets are handed out in launch order, so every predecessor tile of
-//              the same voice has already started when a workgroup begins (no dependence on dispatch
-//              order or placement: a workgroup only ever waits for workgroups with smaller tickets,
-//              and those publish before they wait).
-//   phase A -> the tile's 2 x 4096 phase increments (kept in registers) and their fp64 sums.  Sums of
-//              fp32 increments below 2^19 are exact in fp64, so the order of summation is irrelevant
-//              and the result is bit-identical to the sequential double accumulation of the oracle.
+__device__ const double g_exp2_tab[IAS_EXP2_TAB_LEN] = IAS_EXP2_TAB_INIT;
+
+#ifdef VOICE_STAMPS
+// Diagnostic build only (scripts/diag): per-tile s_memtime stamps of wave 0 / wave 3, written to a buffer of their own.
+__device__ unsigned long long* g_voice_stamps = nullptr;
+extern "C" int ias_voice_debug_set_stamps(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_voice_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}
+#define VSTAMP(slot) do { if (g_voice_stamps && have_cur && lane == 0) { unsigned long long* sp_ = g_voice_stamps + ((size_t)(cur.b * ntiles + cur.tile) * 4 + wave) * 12; sp_[slot] = __builtin_amdgcn_s_memtime(); if ((slot) == 0) sp_[10] = __builtin_amdgcn_s_memrealtime(); if ((slot) == 6) sp_[11] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define VSTAMP(slot) do {} while (0)
+#endif
+
+// a / (2 pi) in revolutions as fp + t: fp = fract(fl(a * c_hi)) exactly, t = the exact rounding residual of that
+// product + a * c_lo (c_hi + c_lo = 1 / (2 pi) to 2^-52 relative) -- the fp64 product of the first version in five
+// fp32 instructions; |error| < 1e-9 revolutions for |a| <= 1e6 rad.
+__device__ __forceinline__ void voice_rev_split(float a, float& fp, float& t) {
+  const float c_hi = 0.15915493667125702f, c_lo = 6.4206382432985265e-09f;
+  const float p = a * c_hi;
+  const float e = fmaf(a, c_hi, -p);
+  fp = __builtin_amdgcn_fractf(p);
+  t = fmaf(a, c_lo, e);
+}
+__device__ __forceinline__ float voice_cos(float a) {
+  float fp, t;
+  voice_rev_split(a, fp, t);
+  return __builtin_amdgcn_cosf(fp + t);
+}
+// sin and cos of the square-saw VCO's phase.  The shaper multiplies sin by up to ~2500 before tanh, so sin needs
+// RELATIVE accuracy at its zero crossings: reduce to r2 in [-1/4, 1/4] around the nearest crossing (fp - q/2 is exact,
+// the residual t is added last), sin(2 pi r) = (-1)^q sin(2 pi r2), q = rint(2 r) in {0, 1, 2}.
+// -> sin(2 pi r2), cos(2 pi r2) and flip = (q == 1): the true values are both negated when flip is set (the caller
+// folds the sign into its products: two selects instead of a sign factor and two multiplies).
+__device__ __forceinline__ void voice_sincos(float a, float& s, float& c, bool& flip) {
+  float fp, t;
+  voice_rev_split(a, fp, t);
+  const float r = fp + t;
+  const float q = __builtin_rintf(r + r);
+  const float r2 = fmaf(q, -0.5f, fp) + t;
+  flip = (q == 1.0f);
+  s = __builtin_amdgcn_sinf(r2);
+  c = __builtin_amdgcn_cosf(r2);
+}
+// |tanh(z)| = (1 - e^{-2|z|}) / (1 + e^{-2|z|})   (v_exp_f32 + v_rcp_f32; max abs error 1.3e-7)
+__device__ __forceinline__ float voice_tanh_abs(float z) {
+  const float t = __builtin_amdgcn_exp2f(-2.885390081777927f * fabsf(z));
+  return (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+}
+
+typedef __attribute__((address_space(3))) void voice_lds_void;
+typedef const __attribute__((address_space(3))) char voice_lds_cchar;       // 32-bit LDS addresses: one v_mad / shift-add
+typedef float voice_f2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) voice_f2 voice_lds_cfloat2;
+typedef const __attribute__((address_space(3))) double voice_lds_cdouble;
+
+// ias_exp2_cr_tab (voice_math.h) with the table addressed as LDS bytes: tab_biased = LDS address of IAS_EXP2_TAB[0]
+// minus 8 * (0x4B400000 + IAS_EXP2_TAB_MIN), so that the entry of u = 1.5 * 2^23 + m is at tab_biased + 8 * bits(u).
+__device__ __forceinline__ float voice_exp2_cr_lds(float t, unsigned tab_biased) {
+  const float u = fmaf(t, 256.0f, 12582912.0f);
+  const float mf = u - 12582912.0f;
+  const float r = fmaf(mf, -0.00390625f, t);
+  const double tv = *(voice_lds_cdouble*)(uintptr_t)(tab_biased + ((unsigned)__float_as_uint(u) << 3));
+  const double rd = (double)r;
+  double p = IAS_EXP2_C4;
+  p = fma(p, rd, IAS_EXP2_C3);
+  p = fma(p, rd, IAS_EXP2_C2);
+  p = fma(p, rd, IAS_EXP2_C1);
+  p = fma(p, rd, 1.0);
+  return (float)(p * tv);
+}
+typedef const __attribute__((address_space(1))) void voice_glb_void;
+// Phase increment of one VCO sample, fl(fl(2 pi hz) / sr) with hz = fl(440 fl(2^fl((c - 69) / 12))): bit-identical to
+// ias_vco_inc (MATH_CR).  FMA_DIV: the sample rate is one ias_div_fma is verified for (sr_f = the rate, sr_r = fl32 of
+// its reciprocal), otherwise the fp64 reciprocal product is used.
+template <int MATH, bool FMA_DIV>
+__device__ __forceinline__ float voice_inc(float f0, float depth, float pm, unsigned tab_biased, double inv_sample_rate,
+                                           float sr_f, float sr_r) {
+  float c = f0 + depth * pm;
+  c = fminf(fmaxf(c, 0.0f), 127.0f);
+  const float t = ias_div_fma(c - 69.0f, 12.0f, 1.0f / 12.0f);
+  const float e = (MATH == VOICE_MATH_CR) ? voice_exp2_cr_lds(t, tab_biased) : __builtin_amdgcn_exp2f(t);
+  const float w = (float)IAS_TWO_PI_D * (440.0f * e);
+  return FMA_DIV ? ias_div_fma(w, sr_f, sr_r) : ias_div_by_recip(w, inv_sample_rate);
+}
+
+// Single pass over the row with a chained scan across tiles ("decoupled look-back"), persistent workgroups:
+//   ticket  -> (tile, voice), tile-major; a workgroup keeps taking tickets until they run out.  Tickets are handed
+//              out in order, so every predecessor tile of the same voice has been taken by a running workgroup
+//              when a workgroup starts on its own (no dependence on dispatch order or placement: a workgroup only
+//              ever waits for smaller tickets, and those publish before they wait).
+//   layout  -> a lane owns 16 CONSECUTIVE samples of the tile (lane order = time order), so the tile-local prefix
+//              of a sample is (wave scan of the lane totals) + a running sum inside the lane: two wave scans per
+//              tile and VCO instead of one per 4-sample chunk, and no array of partial sums.
+//   phase A -> the lane's 2 x 16 phase increments (registers) and their fp64 totals; wave scan; wave totals to LDS.
+//              Sums of fp32 increments below 2^19 are exact in fp64, so the order of summation is irrelevant and
+//              the result is bit-identical to the sequential double accumulation of the oracle.
 //   publish -> one 8-byte write-through store per VCO: the sum's bits with the sign bit as READY flag
 //              (sums are >= 0).  The datum is its own flag (MI355X guide, Guideline 16 form R2).
 //   wait    -> wave 0 polls the predecessors' words with relaxed agent-scope loads (L1 bypass),
-//              bounded spins, and adds them up: the tile's carry-in.
-//   phase B -> fp64 scan with the carry, round to fp32, + phi, oscillators, VCAs, mixer, row peak.
-__global__ __launch_bounds__(AUDIO_THREADS) void voice_audio_kernel(
+//              bounded spins, and adds them up: the tile's carry-in.  An expired wait turns the carry into NaN.
+//   phase B -> running fp64 phase per lane, round to fp32, + phi, oscillators, VCAs, mixer, row peak.
+// The pitch exp2 reads a 2^(i/256) table (fp64, 21.7 KB) that each workgroup copies to LDS once.
+#define VOICE_CTRL_ROW (IAS_NCTRL * 8)    // bytes of one control point in LDS: five (c[i], c[i+1]) pairs, interleaved
+
+// Tickets.  One counter word serves ~88 returning atomics per microsecond (MI355X guide, "dequeue"): the 5632 tiles of a
+// B = 128 render would keep a single counter busy for 64 us, and a 1024-workgroup start for 12 us.  The tiles are
+// therefore handed out by VOICE_NCOUNTERS counters: counter c owns the voices b with b % NC == c, its n-th ticket is
+// tile n / nv_c of voice (n % nv_c) * NC + c -- tile-major per counter, so a tile's predecessors (same voice, smaller
+// tiles) are always smaller tickets OF THE SAME COUNTER, i.e. already taken by a running workgroup when it is taken.
+// A workgroup starts at counter blockIdx % NC and moves on when a counter is exhausted.  -> (c << 24) | n, or -1.
+__device__ __forceinline__ int voice_take_ticket(unsigned int* counters, int& c, int& tried, int ntiles, int nvoices) {
+  while (tried < VOICE_NCOUNTERS) {
+    const int nv_c = (nvoices - c + VOICE_NCOUNTERS - 1) / VOICE_NCOUNTERS;
+    const unsigned n = __hip_atomic_fetch_add((gu32*)(counters + c * 32), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)n < nv_c * ntiles) return (c << 24) | (int)n;
+    c = (c + 1) % VOICE_NCOUNTERS;
+    ++tried;
+  }
+  return -1;
+}
+// One tile = 4096 consecutive samples of one voice; all fields are workgroup-uniform.
+struct VoiceTile {
+  int tile, b, j_tile, c_lo, ncp;
+  bool fast;   // a full tile of a row whose length is a multiple of 4 samples (LDS-DMA / whole-KB path)
+};
+__device__ __forceinline__ VoiceTile voice_tile_of(int ticket, int nvoices, int T, int Tc, float scale) {
+  VoiceTile t;
+  const int c = ticket >> 24, n = ticket & 0xffffff;
+  const int nv_c = (nvoices - c + VOICE_NCOUNTERS - 1) / VOICE_NCOUNTERS;
+  t.tile = n / nv_c;
+  t.b = (n - t.tile * nv_c) * VOICE_NCOUNTERS + c;
+  t.j_tile = t.tile * VOICE_TILE;
+  const int j_last = min(t.j_tile + VOICE_TILE, T) - 1;
+  int i0, i1; float w0, w1;
+  ias_interp_pos(t.j_tile, scale, Tc, i0, i1, w0, w1);
+  t.c_lo = i0;
+  ias_interp_pos(j_last, scale, Tc, i0, i1, w0, w1);
+  t.ncp = i1 - t.c_lo + 1;                       // host guarantees ncp <= maxctrl
+  t.fast = (t.j_tile + VOICE_TILE <= T) && (T & 3) == 0;
+  return t;
+}
+// The control points a tile interpolates between -> LDS rows [ncp][IAS_NCTRL] of (c[i], c[min(i + 1, Tc - 1)]) pairs:
+// one ds_read_b64 at an immediate offset from the point's address fetches both ends of a lerp.
+__device__ __forceinline__ void voice_stage_ctrl(char* dst, const float* __restrict__ ctrl, const VoiceTile& t, int Tc) {
+  const float* cb = ctrl + (size_t)t.b * IAS_NCTRL * Tc;
+  for (int i = threadIdx.x; i < IAS_NCTRL * t.ncp; i += AUDIO_THREADS) {
+    const int k = i / t.ncp, c = i - k * t.ncp;
+    const float* crow = cb + k * Tc;
+    reinterpret_cast<float2*>(dst)[c * IAS_NCTRL + k] = make_float2(crow[t.c_lo + c], crow[min(t.c_lo + c + 1, Tc - 1)]);
+  }
+}
+
+// ---- phase A of a tile: the lane's 2 x 16 phase increments (registers), their fp64 totals, the wave scan of the
+// totals (exclusive lane prefix ex1 / ex2) and the wave totals -> wsum[vco][wave].  A lane owns 16 CONSECUTIVE
+// samples (lane order = time order): two wave scans per tile and VCO, no array of partial sums.  Sums of fp32
+// increments below 2^19 are exact in fp64, so any summation order gives the bits of the oracle's sequential
+// double accumulation.
+template <int MATH, bool FMA_DIV, bool FAST>
+__device__ __forceinline__ void voice_phase_a(const char* s_ctrl, const double* s_tab_, const IasVoiceConst& vc,
+                                              const VoiceTile& t, int T, double inv_sample_rate, float sr_f, float sr_r,
+                                              float scale, float (&inc1)[VOICE_SPT], float (&inc2)[VOICE_SPT],
+                                              double& ex1, double& ex2, double (*wsum)[AUDIO_WAVES]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j0 = t.j_tile + tid * VOICE_SPT;             // the lane's first sample
+  const float jf0 = (float)j0;
+  // 32-bit LDS addresses: control rows indexed by the absolute control index, exp2 table by the bits of 1.5 * 2^23 + m
+  const unsigned ctrl_biased = (unsigned)(uintptr_t)(voice_lds_cchar*)s_ctrl - (unsigned)(t.c_lo * VOICE_CTRL_ROW);
+  const unsigned s_tab = (unsigned)(uintptr_t)(voice_lds_cchar*)s_tab_ - (0x4B400000u + (unsigned)IAS_EXP2_TAB_MIN) * 8u;
+  double tot1 = 0.0, tot2 = 0.0;
+#pragma unroll
+  for (int e = 0; e < VOICE_SPT; ++e) {
+    // interpolation position (ias_interp_pos_fast): k = trunc(real) (real >= 0), w1 = real - k = fract(real), exactly
+    const float real = scale * (jf0 + (float)e);
+    const float w1 = __builtin_amdgcn_fractf(real), w0 = 1.0f - w1;
+    voice_lds_cchar* cp = (voice_lds_cchar*)(uintptr_t)((unsigned)__umul24((unsigned)(int)real, VOICE_CTRL_ROW) + ctrl_biased);
+    const voice_f2 q1 = *(voice_lds_cfloat2*)cp, q2 = *(voice_lds_cfloat2*)(cp + 16);
+    const float pm1 = w0 * q1.x + w1 * q1.y, pm2 = w0 * q2.x + w1 * q2.y;
+    float a = voice_inc<MATH, FMA_DIV>(vc.f0_1, vc.depth_1, pm1, s_tab, inv_sample_rate, sr_f, sr_r);
+    float d = voice_inc<MATH, FMA_DIV>(vc.f0_2, vc.depth_2, pm2, s_tab, inv_sample_rate, sr_f, sr_r);
+    if (!FAST && j0 + e >= T) { a = 0.0f; d = 0.0f; }
+    inc1[e] = a; inc2[e] = d;
+    tot1 += (double)a; tot2 += (double)d;
+    // bounds the scheduler's interleaving of the 16 samples (it otherwise keeps all of them in flight)
+    if ((e & (VOICE_GROUP - 1)) == VOICE_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+  }
+  const double in1 = wave_incl_scan(tot1, lane), in2 = wave_incl_scan(tot2, lane);
+  if (lane == 63) { wsum[0][wave] = in1; wsum[1][wave] = in2; }
+  ex1 = in1 - tot1; ex2 = in2 - tot2;   // exact
+}
+
+// ---- phase B of a tile: running fp64 phase per lane (carry-in + earlier waves + ex + the lane's own increments), round
+// to fp32, + phi, oscillators, VCAs, mixer, row peak.  FAST tiles: the noise was brought into the wave's 4 KB LDS block
+// by LDS-DMA and the audio leaves through the same block, so every global access is a whole 1 KB per wave-instruction
+// although a lane owns 16 consecutive samples.  Block layout: the lane's 16 samples are its own 64 bytes, the four
+// 16-byte granules XOR-permuted by (lane >> 2) & 3 -- conflict-free for the lane-consecutive ds_read/write_b128 and
+// lane-linear (the DMA's destination order) once the SOURCE granule of DMA lane i is i ^ (i >> 4).
+template <bool FAST>
+__device__ __forceinline__ void voice_phase_b(const char* s_ctrl, float* s_stage, const IasVoiceConst& vc, const VoiceTile& t,
+                                              const float* __restrict__ nrow, float* __restrict__ arow, int T, float scale,
+                                              const float (&inc1)[VOICE_SPT], const float (&inc2)[VOICE_SPT], double ex1,
+                                              double ex2, const double* s_carry, const double (*wsum)[AUDIO_WAVES],
+                                              float& pk) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j0 = t.j_tile + tid * VOICE_SPT;
+  float jf0 = (float)j0;
+  asm volatile("" : "+v"(jf0));   // the interpolation positions are recomputed: kept from phase A they cost 32+ VGPRs
+  float* stage = s_stage + wave_u * (64 * VOICE_SPT);   // this wave's 4 KB block
+  const int j_wave = t.j_tile + wave_u * (64 * VOICE_SPT);
+  const int perm = (lane >> 2) & 3;
+  const unsigned ctrl_biased = (unsigned)(uintptr_t)(voice_lds_cchar*)s_ctrl - (unsigned)(t.c_lo * VOICE_CTRL_ROW);
+
+  double run1 = s_carry[0] + ex1, run2 = s_carry[1] + ex2;   // all exact
+  for (int w = 0; w < wave_u; ++w) { run1 += wsum[0][w]; run2 += wsum[1][w]; }
+  float o[4], nz[4];
+  float4 nz_next = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_noise4 = [&](int jq) -> float4 {   // plain path only
+    return make_float4(jq < T ? nrow[jq] : 0.0f, jq + 1 < T ? nrow[jq + 1] : 0.0f, jq + 2 < T ? nrow[jq + 2] : 0.0f,
+                       jq + 3 < T ? nrow[jq + 3] : 0.0f);
+  };
+  if (!FAST) nz_next = load_noise4(j0);
+#pragma unroll
+  for (int e = 0; e < VOICE_SPT; ++e) {
+    if ((e & 3) == 0) {
+      if (FAST) {
+        const float4 v = *reinterpret_cast<const float4*>(stage + lane * VOICE_SPT + 4 * ((e >> 2) ^ perm));
+        nz[0] = v.x; nz[1] = v.y; nz[2] = v.z; nz[3] = v.w;
+      } else {
+        nz[0] = nz_next.x; nz[1] = nz_next.y; nz[2] = nz_next.z; nz[3] = nz_next.w;
+        if (e + 4 < VOICE_SPT) nz_next = load_noise4(j0 + e + 4);
+      }
+    }
+    const float real = scale * (jf0 + (float)e);
+    const float w1 = __builtin_amdgcn_fractf(real), w0 = 1.0f - w1;
+    voice_lds_cchar* cp = (voice_lds_cchar*)(uintptr_t)((unsigned)__umul24((unsigned)(int)real, VOICE_CTRL_ROW) + ctrl_biased);
+    const voice_f2 qa = *(voice_lds_cfloat2*)(cp + 8), qb = *(voice_lds_cfloat2*)(cp + 24), qn = *(voice_lds_cfloat2*)(cp + 32);
+    const float amp1 = w0 * qa.x + w1 * qa.y, amp2 = w0 * qb.x + w1 * qb.y, ampn = w0 * qn.x + w1 * qn.y;
+    run1 += (double)inc1[e]; run2 += (double)inc2[e];
+    const float arg1 = (float)run1 + vc.phi_1, arg2 = (float)run2 + vc.phi_2;
+    float s2, c2;
+    bool flip;
+    voice_sincos(arg2, s2, c2, flip);    // sin = (flip ? -s2 : s2), cos = (flip ? -c2 : c2)
+    const float v1 = voice_cos(arg1) * amp1;
+    // square = tanh(k sin / 2) is odd in sin: magnitude from |s2|, sign = sign(s2) ^ flip (signs commute with the
+    // correctly rounded multiplications that follow)
+    const float sqm = __builtin_copysignf(voice_tanh_abs((vc.kpart * s2) * 0.5f), s2);
+    const float sc = vc.shape * c2;
+    const float v2 = ((vc.shape_gain * (flip ? -sqm : sqm)) * (1.0f + (flip ? -sc : sc))) * amp2;
+    float om = vc.lvl0 * v1;
+    om = om + vc.lvl1 * v2;
+    om = om + vc.lvl2 * (nz[e & 3] * ampn);
+    if (FAST || j0 + e < T) pk = fmaxf(pk, fabsf(om));
+    o[e & 3] = om;
+    if ((e & 3) == 3) {
+      if (FAST) {
+        *reinterpret_cast<float4*>(stage + lane * VOICE_SPT + 4 * ((e >> 2) ^ perm)) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        const int jq = j0 + e - 3;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) if (jq + x < T) arow[jq + x] = o[x];
+      }
+      if ((e & (VOICE_GROUP - 1)) == VOICE_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (FAST) {
+    // the wave's 4 KB leave as four whole 1 KB stores (LDS operations of one wave execute in order: no barrier)
+    const int dst = 4 * (lane ^ (lane >> 4));
+#pragma unroll
+    for (int q = 0; q < VOICE_SPT / 4; ++q)
+      *reinterpret_cast<float4*>(arow + j_wave + q * 256 + dst) = *reinterpret_cast<const float4*>(stage + q * 256 + lane * 4);
+  }
+}
+
+// Single pass over every row with a chained scan across tiles ("decoupled look-back"), persistent workgroups, two tiles
+// in flight per workgroup:
+//   ticket  -> (tile, voice), tile-major; a workgroup keeps taking tickets until they run out.  Tickets are handed out
+//              in order and a workgroup only ever WAITS for smaller tickets, whose holders have either published or are
+//              computing their phase A without waiting for anybody -- no dependence on dispatch order or placement.
+//   loop    -> phase A of the NEXT tile (increments, sums; needs nothing from other workgroups), publish its sums, then
+//              look-back + phase B of the CURRENT tile.  A tile's sums are thus published one phase B (~10 us of wave
+//              time) before its own audio is due, and the words a tile polls were requested before phase A of the next
+//              one: the look-back round trip and the predecessors' publish delay are off the critical path (with one
+//              tile in flight the waves spent 18 % of a tile waiting for them).
+//   publish -> one 8-byte write-through store per VCO: the sum's bits with the sign bit as READY flag (sums are >= 0).
+//              The datum is its own flag (MI355X guide, Guideline 16 form R2).
+//   wait    -> wave 0 polls the predecessors' words with relaxed agent-scope loads (L1 bypass), bounded spins, and adds
+//              them up: the tile's carry-in.  An expired wait turns the carry (hence the tile's audio) into NaN.
+// The pitch exp2 reads a 2^(i/256) table (fp64, 21.7 KB) that each workgroup copies to LDS once.
+template <int MATH, bool FMA_DIV>
+__global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) void voice_audio_kernel(
     const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst,
     const float* __restrict__ noise, float* __restrict__ audio, unsigned long long* agg /* [B][ntiles][2] */,
-    unsigned int* ticket_status /* [0] ticket counter, [1] spin-timeout flag */,
-    unsigned* __restrict__ rowpeak, int T, int Tc, int ntiles, double inv_sample_rate, float sr_f, float sr_r,
-    float scale, int maxctrl) {
-  // control points as (c[i], c[i+1]) pairs: one ds_read_b64 fetches both ends of a lerp, and the clamp of
-  // the upper index at the end of the buffer is folded into the table
-  // dynamic LDS: s_inc [2][VOICE_SPT][AUDIO_THREADS] floats (the tile's phase increments wait here between
-  // phase A and phase B instead of in 32 VGPRs) | s_ctrl [IAS_NCTRL][maxctrl] float2
-  extern __shared__ __attribute__((aligned(16))) float dyn_smem[];
-  float* s_inc = dyn_smem;
-  float2* s_ctrl = reinterpret_cast<float2*>(dyn_smem + 2 * VOICE_SPT * AUDIO_THREADS);
-  __shared__ double s_wsum[2][AUDIO_WAVES];
+    unsigned int* ticket_status /* VOICE_NCOUNTERS ticket counters (32 words apart), then the spin-timeout flag */,
+    unsigned* __restrict__ rowpeak, int T, int Tc, int ntiles, int nvoices, double inv_sample_rate, float sr_f,
+    float sr_r, float scale, int maxctrl) {
+  // dynamic LDS: exp2 table | per-wave noise / audio blocks [AUDIO_WAVES][1024] floats | two control stages
+  extern __shared__ __attribute__((aligned(16))) double dyn_smem_d[];
+  double* s_tab = dyn_smem_d;
+  float* s_stage = reinterpret_cast<float*>(dyn_smem_d + VOICE_TAB_DOUBLES);
+  char* s_ctrl0 = reinterpret_cast<char*>(s_stage + VOICE_TILE);
+  const int ctrl_bytes = maxctrl * VOICE_CTRL_ROW;
+  __shared__ double s_wsum[2][2][AUDIO_WAVES];   // [slot][vco][wave]
   __shared__ double s_carry[2];
   __shared__ float s_max[AUDIO_WAVES];
   __shared__ unsigned s_ticket;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_ticket = __hip_atomic_fetch_add((gu32*)ticket_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int my_counter = blockIdx.x % VOICE_NCOUNTERS, counters_tried = 0;   // used by thread 0 only
+  if (tid == 0) s_ticket = (unsigned)voice_take_ticket(ticket_status, my_counter, counters_tried, ntiles, nvoices);
+  if (MATH == VOICE_MATH_CR)
+    for (int i = tid; i < IAS_EXP2_TAB_LEN; i += AUDIO_THREADS) s_tab[i] = g_exp2_tab[i];
   __syncthreads();
-  const int ticket = (int)s_ticket;
-  // tile-major order: the predecessors of (tile, b) are the tickets (tile', b), tile' < tile, i.e. at least
-  // B tickets older -- they have normally published long before this workgroup polls.  (Row-major order,
-  // where the predecessor is the previous ticket, spent 42 % of the wave time in the look-back wait.)
-  const int nvoices = gridDim.x / ntiles;
-  const int tile = ticket / nvoices, b = ticket - tile * nvoices;
-  const int j_tile = tile * VOICE_TILE;
-  const int j_last = min(j_tile + VOICE_TILE, T) - 1;
+  int t_next = __builtin_amdgcn_readfirstlane((int)s_ticket);
 
-  // stage the control points this tile interpolates between
-  int c_lo, c_hi;
-  {
-    int i0, i1; float w0, w1;
-    ias_interp_pos(j_tile, scale, Tc, i0, i1, w0, w1);
-    c_lo = i0;
-    ias_interp_pos(j_last, scale, Tc, i0, i1, w0, w1);
-    c_hi = i1;
-  }
-  const int ncp = c_hi - c_lo + 1;  // host guarantees ncp <= VOICE_MAXCTRL
-  const float* cb = ctrl + (size_t)b * IAS_NCTRL * Tc;
-  for (int i = tid; i < IAS_NCTRL * ncp; i += AUDIO_THREADS) {
-    const int k = i / ncp, c = i - k * ncp;
-    const float* row = cb + k * Tc;
-    s_ctrl[k * maxctrl + c] = make_float2(row[c_lo + c], row[min(c_lo + c + 1, Tc - 1)]);
-  }
-  const IasVoiceConst vc = vconst[b];
-  __syncthreads();
-  // early look-back: the predecessors' words are requested here, after the staging barrier (tile-major
-  // tickets make the predecessors ~3 us older: by now they have normally published) and examined only
-  // after phase A, which hides the round trip
-  gu64* row = (gu64*)(agg + ((size_t)b * ntiles) * 2);
-  unsigned long long early1 = VOICE_READY_BIT, early2 = VOICE_READY_BIT;
-  if (wave == 0 && lane < tile) {
-    early1 = __hip_atomic_load(row + lane * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    early2 = __hip_atomic_load(row + lane * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-
-
-  const int j_wave = j_tile + wave * (64 * VOICE_SPT);
-  const float* nrow = noise + (size_t)b * T;
-  const bool vec_ok = (T & 3) == 0;
-
-  // phase A: increments (kept in registers) and per-wave totals
-  double tot1 = 0.0, tot2 = 0.0;
-  // (branch-free: samples past the end of the row are computed for the clamped index and masked,
-  // so the four samples of a lane form straight-line code the compiler can pack two by two)
+  VoiceTile cur = {}, next = {};
+  bool have_cur = false;
+  int slot = 0;                                 // s_wsum / control stage of the CURRENT tile
+  float incC1[VOICE_SPT], incC2[VOICE_SPT];     // the current tile's increments (phase B), the next tile's (phase A)
+  float incN1[VOICE_SPT], incN2[VOICE_SPT];
+  double exC1 = 0.0, exC2 = 0.0, exN1 = 0.0, exN2 = 0.0;
 #pragma unroll
-  for (int c = 0; c < VOICE_CHUNKS; ++c) {
+  for (int e = 0; e < VOICE_SPT; ++e) { incC1[e] = incC2[e] = 0.0f; }
+
+  for (;;) {
+    const bool have_next = t_next >= 0;
+    if (!have_cur && !have_next) break;
+    gu64* row = (gu64*)(agg + ((size_t)cur.b * ntiles) * 2);
+    VSTAMP(0);
+    unsigned long long early1 = VOICE_READY_BIT, early2 = VOICE_READY_BIT;
+    if (have_cur) {
+      // the current tile's look-back words and noise are requested now and examined after phase A of the next tile
+      if (wave == 0 && lane < cur.tile) {
+        early1 = __hip_atomic_load(row + lane * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        early2 = __hip_atomic_load(row + lane * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (cur.fast) {
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const float* nsrc = noise + (size_t)cur.b * T + cur.j_tile + wave_u * (64 * VOICE_SPT) + 4 * (lane ^ (lane >> 4));
 #pragma unroll
-    for (int h = 0; h < VOICE_RUN / 2; ++h) {   // two samples at a time (packed fp32)
-      const int j = j_wave + c * (64 * VOICE_RUN) + lane * VOICE_RUN + 2 * h;
-      int k[2]; ias_f2 w0, w1;
-      ias_interp_pair(min(j, T - 1), min(j + 1, T - 1), scale, k, w0, w1);
-      const int i0 = k[0] - c_lo, i1 = k[1] - c_lo;
-      const ias_f2 pm1 = ias_lerp_pair(s_ctrl[i0], s_ctrl[i1], w0, w1);
-      const ias_f2 pm2 = ias_lerp_pair(s_ctrl[2 * maxctrl + i0], s_ctrl[2 * maxctrl + i1], w0, w1);
-      ias_f2 a = ias_vco_inc_pair(vc.f0_1, vc.depth_1, pm1, inv_sample_rate, sr_f, sr_r);
-      ias_f2 d = ias_vco_inc_pair(vc.f0_2, vc.depth_2, pm2, inv_sample_rate, sr_f, sr_r);
-      if (j >= T) { a.x = 0.0f; d.x = 0.0f; }
-      if (j + 1 >= T) { a.y = 0.0f; d.y = 0.0f; }
-      const int e0 = c * VOICE_RUN + 2 * h;
-      s_inc[e0 * AUDIO_THREADS + tid] = a.x;
-      s_inc[(e0 + 1) * AUDIO_THREADS + tid] = a.y;
-      s_inc[(VOICE_SPT + e0) * AUDIO_THREADS + tid] = d.x;
-      s_inc[(VOICE_SPT + e0 + 1) * AUDIO_THREADS + tid] = d.y;
-      tot1 += (double)a.x; tot1 += (double)a.y;
-      tot2 += (double)d.x; tot2 += (double)d.y;
+        for (int q = 0; q < VOICE_SPT / 4; ++q)
+          __builtin_amdgcn_global_load_lds((voice_glb_void*)(nsrc + q * 256),
+                                           (voice_lds_void*)(s_stage + wave_u * (64 * VOICE_SPT) + q * 256), 16, 0, 0);
+      }
     }
-  }
-  tot1 = wave_sum(tot1); tot2 = wave_sum(tot2);
-  if (lane == 0) { s_wsum[0][wave] = tot1; s_wsum[1][wave] = tot2; }
-  __syncthreads();
-
-  // publish this tile's sums, then collect the predecessors' (wave 0)
-  if (wave == 0) {
-    if (lane < 2) {
+    if (have_next) {
+      next = voice_tile_of(t_next, nvoices, T, Tc, scale);
+      voice_stage_ctrl(s_ctrl0 + (slot ^ 1) * ctrl_bytes, ctrl, next, Tc);
+    }
+    __syncthreads();   // (1) the next tile's control points are staged; everybody has read s_ticket
+    VSTAMP(1);
+    if (have_next) {
+      // the ticket after next: in flight during phase A, read after barrier (3)
+      if (tid == 0) s_ticket = (unsigned)voice_take_ticket(ticket_status, my_counter, counters_tried, ntiles, nvoices);
+      const IasVoiceConst vcn = vconst[next.b];
+      if (next.fast)
+        voice_phase_a<MATH, FMA_DIV, true>(s_ctrl0 + (slot ^ 1) * ctrl_bytes, s_tab, vcn, next, T, inv_sample_rate, sr_f, sr_r,
+                                           scale, incN1, incN2, exN1, exN2, s_wsum[slot ^ 1]);
+#ifndef VOICE_ANALYZE_FULL_ONLY
+      else
+        voice_phase_a<MATH, FMA_DIV, false>(s_ctrl0 + (slot ^ 1) * ctrl_bytes, s_tab, vcn, next, T, inv_sample_rate, sr_f, sr_r,
+                                            scale, incN1, incN2, exN1, exN2, s_wsum[slot ^ 1]);
+#endif
+    }
+    VSTAMP(2);
+    // ---- the current tile's carry-in: its predecessors' sums (wave 0)
+    if (have_cur && wave == 0) {
+      double a1 = 0.0, a2 = 0.0;
+      bool timeout = false;
+      for (int t0 = 0; t0 < cur.tile; t0 += 64) {
+        const int t = t0 + lane;
+        unsigned long long x1 = VOICE_READY_BIT, x2 = VOICE_READY_BIT;   // lanes without a predecessor: ready
+        if (t0 == 0) { x1 = early1; x2 = early2; }
+        else if (t < cur.tile) { x1 = 0; x2 = 0; }
+        unsigned spins = 0;
+        bool ok = (x1 & x2 & VOICE_READY_BIT) != 0;
+        while (!__all(ok)) {                        // wave-uniform loop condition
+          if (++spins > VOICE_SPIN_LIMIT) { timeout = true; break; }
+          if (!ok) {
+            x1 = __hip_atomic_load(row + t * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x2 = __hip_atomic_load(row + t * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = (x1 & x2 & VOICE_READY_BIT) != 0;
+          }
+          if (!__all(ok)) __builtin_amdgcn_s_sleep(2);
+        }
+        if (t < cur.tile) {
+          a1 += __longlong_as_double((long long)(x1 & ~VOICE_READY_BIT));
+          a2 += __longlong_as_double((long long)(x2 & ~VOICE_READY_BIT));
+        }
+      }
+      a1 = wave_sum(a1); a2 = wave_sum(a2);
+      if (lane == 0) {
+        // an expired wait never continues with partial carries: the tile's phases (hence its audio) become NaN,
+        // and the status word says why
+        if (timeout) {
+          a1 = a2 = __longlong_as_double(0x7ff8000000000000ll);
+          __hip_atomic_store((gu32*)ticket_status + VOICE_NCOUNTERS * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_carry[0] = a1; s_carry[1] = a2;
+      }
+    }
+    VSTAMP(3);
+    __syncthreads();   // (2) the next tile's wave sums, the current tile's carry, the noise blocks
+    VSTAMP(4);
+    if (have_next && wave == 0 && lane < 2) {
+      // publish the next tile's sums: from here on nobody waits for this workgroup on its account
       double a = 0.0;
-      for (int w = 0; w < AUDIO_WAVES; ++w) a += s_wsum[lane][w];
-      __hip_atomic_store(row + tile * 2 + lane, (unsigned long long)__double_as_longlong(a) | VOICE_READY_BIT,
+      for (int w = 0; w < AUDIO_WAVES; ++w) a += s_wsum[slot ^ 1][lane][w];
+      gu64* nrow_agg = (gu64*)(agg + ((size_t)next.b * ntiles) * 2);
+      __hip_atomic_store(nrow_agg + next.tile * 2 + lane, (unsigned long long)__double_as_longlong(a) | VOICE_READY_BIT,
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    double a1 = 0.0, a2 = 0.0;
-    bool timeout = false;
-    for (int t0 = 0; t0 < tile; t0 += 64) {
-      const int t = t0 + lane;
-      unsigned long long x1 = VOICE_READY_BIT, x2 = VOICE_READY_BIT;   // lanes without a predecessor: ready
-      if (t0 == 0) { x1 = early1; x2 = early2; }
-      else if (t < tile) { x1 = 0; x2 = 0; }
-      unsigned spins = 0;
-      bool ok = (x1 & x2 & VOICE_READY_BIT) != 0;
-      while (!__all(ok)) {                        // wave-uniform loop condition
-        if (++spins > VOICE_SPIN_LIMIT) { timeout = true; break; }
-        if (!ok) {
-          x1 = __hip_atomic_load(row + t * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          x2 = __hip_atomic_load(row + t * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = (x1 & x2 & VOICE_READY_BIT) != 0;
-        }
-        if (!__all(ok)) __builtin_amdgcn_s_sleep(2);
-      }
-      if (t < tile) {
-        a1 += __longlong_as_double((long long)(x1 & ~VOICE_READY_BIT));
-        a2 += __longlong_as_double((long long)(x2 & ~VOICE_READY_BIT));
-      }
+    if (have_cur) {
+      const IasVoiceConst vc = vconst[cur.b];
+      float pk = 0.0f;
+      if (cur.fast)
+        voice_phase_b<true>(s_ctrl0 + slot * ctrl_bytes, s_stage, vc, cur, noise + (size_t)cur.b * T, audio + (size_t)cur.b * T,
+                            T, scale, incC1, incC2, exC1, exC2, s_carry, s_wsum[slot], pk);
+#ifndef VOICE_ANALYZE_FULL_ONLY
+      else
+        voice_phase_b<false>(s_ctrl0 + slot * ctrl_bytes, s_stage, vc, cur, noise + (size_t)cur.b * T, audio + (size_t)cur.b * T,
+                             T, scale, incC1, incC2, exC1, exC2, s_carry, s_wsum[slot], pk);
+#endif
+      pk = wave_max(pk);
+      if (lane == 0) s_max[wave] = pk;
     }
-    a1 = wave_sum(a1); a2 = wave_sum(a2);
-    if (lane == 0) {
-      // an expired wait never continues with partial carries: the tile's phases (hence its audio) become NaN,
-      // and the status word says why
-      if (timeout) {
-        a1 = a2 = __longlong_as_double(0x7ff8000000000000ll);
-        __hip_atomic_store((gu32*)ticket_status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      s_carry[0] = a1; s_carry[1] = a2;
+    VSTAMP(5);
+    __syncthreads();   // (3) the current tile is done with its control stage, wave sums, carry; s_max and s_ticket are set
+    VSTAMP(6);
+    if (have_cur && tid == 0) {
+      float m = s_max[0];
+      for (int w = 1; w < AUDIO_WAVES; ++w) m = fmaxf(m, s_max[w]);
+      atomicMax(rowpeak + cur.b, __float_as_uint(m));  // m >= 0: uint order == float order
     }
-  }
-  __syncthreads();
-
-  // phase B: scan + oscillators
-  double run1 = s_carry[0], run2 = s_carry[1];
-  for (int w = 0; w < wave; ++w) { run1 += s_wsum[0][w]; run2 += s_wsum[1][w]; }
-  float pk = 0.0f;
-  float* arow = audio + (size_t)b * T;
+    // the next tile becomes the current one
+    cur = next;
+    have_cur = have_next;
+    slot ^= 1;
 #pragma unroll
-  for (int c = 0; c < VOICE_CHUNKS; ++c) {
-    constexpr int RN = VOICE_RUN;
-    const int j0 = j_wave + c * (64 * RN) + lane * RN;
-    double l1[RN], l2[RN];
-    l1[0] = (double)s_inc[(c * RN) * AUDIO_THREADS + tid];
-    l2[0] = (double)s_inc[(VOICE_SPT + c * RN) * AUDIO_THREADS + tid];
-#pragma unroll
-    for (int e = 1; e < RN; ++e) {
-      l1[e] = l1[e - 1] + (double)s_inc[(c * RN + e) * AUDIO_THREADS + tid];
-      l2[e] = l2[e - 1] + (double)s_inc[(VOICE_SPT + c * RN + e) * AUDIO_THREADS + tid];
-    }
-    const double in1 = wave_incl_scan(l1[RN - 1], lane), in2 = wave_incl_scan(l2[RN - 1], lane);
-    const double base1 = run1 + (in1 - l1[RN - 1]), base2 = run2 + (in2 - l2[RN - 1]);
-    run1 += __shfl(in1, 63, 64); run2 += __shfl(in2, 63, 64);
-
-    float nz[RN];
-#pragma unroll
-    for (int e = 0; e < RN; ++e) nz[e] = 0.f;
-    if (vec_ok && j0 + RN - 1 < T) {
-#pragma unroll
-      for (int q = 0; q < RN / 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(nrow + j0 + 4 * q);
-        nz[4 * q] = v.x; nz[4 * q + 1] = v.y; nz[4 * q + 2] = v.z; nz[4 * q + 3] = v.w;
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < RN; ++e) if (j0 + e < T) nz[e] = nrow[j0 + e];
-    }
-    float o[RN];
-#pragma unroll
-    for (int h = 0; h < RN / 2; ++h) {   // two samples at a time (packed fp32)
-      const int j = j0 + 2 * h;
-      int k[2]; ias_f2 w0, w1;
-      ias_interp_pair(min(j, T - 1), min(j + 1, T - 1), scale, k, w0, w1);
-      const int i0 = k[0] - c_lo, i1 = k[1] - c_lo;
-      const ias_f2 amp1 = ias_lerp_pair(s_ctrl[maxctrl + i0], s_ctrl[maxctrl + i1], w0, w1);
-      const ias_f2 amp2 = ias_lerp_pair(s_ctrl[3 * maxctrl + i0], s_ctrl[3 * maxctrl + i1], w0, w1);
-      const ias_f2 ampn = ias_lerp_pair(s_ctrl[4 * maxctrl + i0], s_ctrl[4 * maxctrl + i1], w0, w1);
-      const ias_f2 a1 = (ias_f2){(float)(base1 + l1[2 * h]), (float)(base1 + l1[2 * h + 1])} + vc.phi_1;
-      const ias_f2 a2 = (ias_f2){(float)(base2 + l2[2 * h]), (float)(base2 + l2[2 * h + 1])} + vc.phi_2;
-      const ias_f2 om = ias_mix_pair_dev(a1, a2, amp1, amp2, ampn, (ias_f2){nz[2 * h], nz[2 * h + 1]}, vc);
-      o[2 * h] = om.x; o[2 * h + 1] = om.y;
-      if (j < T) pk = fmaxf(pk, fabsf(om.x));
-      if (j + 1 < T) pk = fmaxf(pk, fabsf(om.y));
-    }
-    if (vec_ok && j0 + RN - 1 < T) {
-#pragma unroll
-      for (int q = 0; q < RN / 4; ++q)
-        *reinterpret_cast<float4*>(arow + j0 + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < RN; ++e) if (j0 + e < T) arow[j0 + e] = o[e];
-    }
-  }
-  pk = wave_max(pk);
-  if (lane == 0) s_max[wave] = pk;
-  __syncthreads();
-  if (tid == 0) {
-    float m = s_max[0];
-    for (int w = 1; w < AUDIO_WAVES; ++w) m = fmaxf(m, s_max[w]);
-    atomicMax(rowpeak + b, __float_as_uint(m));  // m >= 0: uint order == float order
+    for (int e = 0; e < VOICE_SPT; ++e) { incC1[e] = incN1[e]; incC2[e] = incN2[e]; }
+    exC1 = exN1; exC2 = exN2;
+    t_next = have_next ? __builtin_amdgcn_readfirstlane((int)s_ticket) : -1;
   }
 }
 
@@ -439,9 +670,9 @@ static VoiceWs voice_ws_layout(int B, int T, int Tc) {
   w.off_vconst = o;  o = align_up(o + sizeof(IasVoiceConst) * (size_t)B, 256);
   w.off_env = o;     o = align_up(o + sizeof(float) * (size_t)B * 8 * Tc, 256);
   // words zeroed before every launch, in one block of their own (multiple of 16 bytes):
-  // [ticket, timeout flag, pad, pad][agg: B*ntiles*2 u64][row peaks: B u32]
+  // [ticket counters: one 128-byte line each][status word line][agg: B*ntiles*2 u64][row peaks: B u32]
   w.off_sync = o;
-  w.off_agg = o + 16;
+  w.off_agg = o + VOICE_SYNC_HEAD_BYTES;
   w.off_peak = w.off_agg + sizeof(unsigned long long) * (size_t)B * 2 * w.ntiles;
   w.sync_bytes = align_up(w.off_peak + sizeof(unsigned) * (size_t)B - w.off_sync, 16);
   o = align_up(w.off_sync + w.sync_bytes, 256);
@@ -463,7 +694,7 @@ static int voice_check_dims(int B, int T, int Tc) {
   if (B <= 0 || T <= 1 || Tc <= 1 || B > 65535) return IAS_ERR_ARG;
   // control points touched by one tile must fit the LDS stage
   const double span = (double)VOICE_TILE * (double)(Tc - 1) / (double)(T - 1);
-  if (span + 6.0 > (double)VOICE_MAXCTRL) return IAS_ERR_UNSUPPORTED;   // keeps the LDS image under ~45 KB
+  if (span + 6.0 > (double)VOICE_MAXCTRL) return IAS_ERR_UNSUPPORTED;   // keeps the LDS image under ~35 KB
   return IAS_OK;
 }
 
@@ -511,47 +742,81 @@ extern "C" int ias_voice_control_debug(const float* params01, float* ctrl, void*
   return voice_control_launch(params01, ctrl, vconst, env, dbg, B, Tc, control_rate, stream_);
 }
 
-// One stage of the render on an already-filled workspace (ias_voice_control must have run into it):
+// Persistent grid of the audio-rate kernel: resident workgroups per CU (occupancy query, cached) x CUs.
+template <int MATH, bool FMA_DIV>
+static int voice_audio_grid(size_t lds, int total_tiles) {
+  static int cached_lds = -1, cached_grid = 0;
+  if (cached_lds != (int)lds) {
+    int dev = 0, ncu = 256, per_cu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, voice_audio_kernel<MATH, FMA_DIV>, AUDIO_THREADS, lds) != hipSuccess ||
+        per_cu < 1)
+      per_cu = 2;
+    cached_grid = per_cu * ncu;
+    cached_lds = (int)lds;
+    if (getenv("IAS_DEBUG")) fprintf(stderr, "[ias] voice_audio_kernel: %d workgroups/CU x %d CUs, %zu B LDS\n", per_cu, ncu, lds);
+  }
+  return cached_grid < total_tiles ? cached_grid : total_tiles;
+}
+
+template <int MATH, bool FMA_DIV>
+static void voice_audio_launch(hipStream_t stream, const VoiceWs& w, char* ws, const float* noise, float* audio, int B,
+                               int T, int Tc, int sample_rate) {
+  const float scale = (float)(Tc - 1) / (float)(T - 1);
+  const float sr_f = (float)sample_rate;
+  const int maxctrl = voice_maxctrl(T, Tc);
+  const size_t lds = sizeof(double) * VOICE_TAB_DOUBLES + sizeof(float) * VOICE_TILE + 2 * sizeof(float2) * IAS_NCTRL * (size_t)maxctrl;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)voice_audio_kernel<MATH, FMA_DIV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int grid = voice_audio_grid<MATH, FMA_DIV>(lds, w.ntiles * B);
+  hipLaunchKernelGGL((voice_audio_kernel<MATH, FMA_DIV>), dim3(grid), dim3(AUDIO_THREADS), lds, stream,
+                     (const float*)(ws + w.off_ctrl), (const IasVoiceConst*)(ws + w.off_vconst), noise, audio,
+                     (unsigned long long*)(ws + w.off_agg), (unsigned int*)(ws + w.off_sync),
+                     (unsigned*)(ws + w.off_peak), T, Tc, w.ntiles, B, 1.0 / (double)sample_rate, sr_f,
+                     1.0f / sr_f, scale, maxctrl);
+}
+
+// One stage of the render on an already-filled workspace (ias_voice_control_ws must have run into it):
 //   stage 0: single-pass audio-rate kernel: phase increments, chained fp64 scan across tiles,
 //            oscillators + mixer -> unnormalised audio, row peaks (voice_audio_kernel)
 //   stage 1: normalize_if_clipping in place (voice_normalize_kernel)
-extern "C" int ias_voice_stage(int stage, const float* noise, float* audio, void* workspace,
+// math_mode: 0 = the tested contract (oracle math "cr"); 1 = hardware fp32 exp2 on the pitch path (A/B only).
+extern "C" int ias_voice_stage(int stage, int math_mode, const float* noise, float* audio, void* workspace,
                                long long workspace_bytes, int B, int T, int Tc, int sample_rate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!noise || !audio || !workspace || sample_rate <= 0 || stage < 0 || stage > 1) return IAS_ERR_ARG;
+  if (!noise || !audio || !workspace || sample_rate <= 0 || stage < 0 || stage > 1 || math_mode < 0 || math_mode > 1)
+    return IAS_ERR_ARG;
   int rc = voice_check_dims(B, T, Tc);
   if (rc) return rc;
   const VoiceWs w = voice_ws_layout(B, T, Tc);
   if ((size_t)workspace_bytes < w.total) return IAS_ERR_WORKSPACE;
   char* ws = (char*)workspace;
-  const float* ctrl = (const float*)(ws + w.off_ctrl);
-  const IasVoiceConst* vconst = (const IasVoiceConst*)(ws + w.off_vconst);
-  unsigned* peak = (unsigned*)(ws + w.off_peak);
   if (stage == 0) {
     // ticket, timeout flag, tile aggregates and row peaks are re-zeroed on every call
     if (hipMemsetAsync(ws + w.off_sync, 0, w.sync_bytes, stream) != hipSuccess) return IAS_ERR_LAUNCH;
-    const float scale = (float)(Tc - 1) / (float)(T - 1);
-    const float sr_f = ias_div_fma_rate_ok(sample_rate) ? (float)sample_rate : 0.0f;   // 0: fp64 reciprocal path
-    const int maxctrl = voice_maxctrl(T, Tc);
-    const size_t lds = sizeof(float) * 2 * VOICE_SPT * AUDIO_THREADS + sizeof(float2) * IAS_NCTRL * (size_t)maxctrl;
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)voice_audio_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(voice_audio_kernel, dim3(w.ntiles * B), dim3(AUDIO_THREADS), lds, stream, ctrl, vconst, noise,
-                       audio, (unsigned long long*)(ws + w.off_agg), (unsigned int*)(ws + w.off_sync), peak, T, Tc,
-                       w.ntiles, 1.0 / (double)sample_rate, sr_f, sr_f > 0.0f ? 1.0f / sr_f : 0.0f, scale, maxctrl);
+    const bool fma_div = ias_div_fma_rate_ok(sample_rate) != 0;   // else: fp64 reciprocal path of the increment
+    if (math_mode == VOICE_MATH_CR) {
+      if (fma_div) voice_audio_launch<VOICE_MATH_CR, true>(stream, w, ws, noise, audio, B, T, Tc, sample_rate);
+      else voice_audio_launch<VOICE_MATH_CR, false>(stream, w, ws, noise, audio, B, T, Tc, sample_rate);
+    } else {
+      if (fma_div) voice_audio_launch<VOICE_MATH_HW, true>(stream, w, ws, noise, audio, B, T, Tc, sample_rate);
+      else voice_audio_launch<VOICE_MATH_HW, false>(stream, w, ws, noise, audio, B, T, Tc, sample_rate);
+    }
   } else {
     const int nvec = T / 4;
     int gx = (nvec + 255) / 256;
     if (gx > 64) gx = 64;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(voice_normalize_kernel, dim3(gx, B), dim3(256), 0, stream, audio, peak, T, nvec);
+    hipLaunchKernelGGL(voice_normalize_kernel, dim3(gx, B), dim3(256), 0, stream, audio, (unsigned*)(ws + w.off_peak), T,
+                       nvec);
   }
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
 extern "C" int ias_voice_render(const float* params01, const float* noise, float* audio, void* workspace,
                                 long long workspace_bytes, int B, int T, int Tc, int sample_rate,
-                                int control_rate, int normalize, void* stream_) {
+                                int control_rate, int normalize, int math_mode, void* stream_) {
   if (!params01 || !noise || !audio || !workspace || sample_rate <= 0 || control_rate <= 0) return IAS_ERR_ARG;
   int rc = voice_check_dims(B, T, Tc);
   if (rc) return rc;
@@ -561,7 +826,7 @@ extern "C" int ias_voice_render(const float* params01, const float* noise, float
   rc = ias_voice_control(params01, (float*)(ws + w.off_ctrl), ws + w.off_vconst, (float*)(ws + w.off_env), B, Tc,
                          control_rate, stream_);
   for (int stage = 0; stage < (normalize ? 2 : 1) && rc == IAS_OK; ++stage)
-    rc = ias_voice_stage(stage, noise, audio, workspace, workspace_bytes, B, T, Tc, sample_rate, stream_);
+    rc = ias_voice_stage(stage, math_mode, noise, audio, workspace, workspace_bytes, B, T, Tc, sample_rate, stream_);
   return rc;
 }
 
@@ -569,7 +834,7 @@ extern "C" int ias_voice_render(const float* params01, const float* noise, float
 extern "C" int ias_voice_read_status(const void* workspace, unsigned* status_dev, int B, int T, int Tc, void* stream_) {
   if (!workspace || !status_dev) return IAS_ERR_ARG;
   const VoiceWs w = voice_ws_layout(B, T, Tc);
-  if (hipMemcpyAsync(status_dev, (const char*)workspace + w.off_sync + 4, sizeof(unsigned), hipMemcpyDeviceToDevice,
+  if (hipMemcpyAsync(status_dev, (const char*)workspace + w.off_sync + VOICE_NCOUNTERS * 128, sizeof(unsigned), hipMemcpyDeviceToDevice,
                      (hipStream_t)stream_) != hipSuccess)
     return IAS_ERR_LAUNCH;
   return IAS_OK;

@@ -12,6 +12,7 @@
 // /root/reference/audio_to_params.py:215,240-257.
 #pragma once
 #include "ias_common.h"
+#include "voice_exp2_table.h"
 #if !defined(__HIPCC__)
 #include <algorithm>
 using std::min;
@@ -86,6 +87,29 @@ IAS_HD float ias_exp2_cr_fast(float t) {
   p = fma(p, f, 0.69314718055994995);
   p = fma(p, f, 1.0);
   return (float)ldexp(p, (int)n);
+}
+
+// Same value as ias_exp2_cr for t in [(IAS_EXP2_TAB_MIN + 1) / 256, (IAS_EXP2_TAB_MIN + LEN - 2) / 256] (the pitch path:
+// t = (midi - 69) / 12, midi in [0, 127]): m = rint(256 t) by the 1.5 * 2^23 trick (the fma is exact up to the one
+// rounding to an integer, ties to even as rintf), r = t - m / 256 exact in fp32 with |r| <= 1/512,
+// 2^t = T[m] * (1 + r (c1 + r (c2 + r (c3 + r c4)))) in fp64 (Taylor truncation 4e-17, total error <= ~3.5e-16 before
+// the single rounding to fp32), T = IAS_EXP2_TAB (fp64, correctly rounded; in LDS on the device).
+// 6 fp64 operations instead of the 11 + ldexp + int conversion of ias_exp2_cr_fast.  (The render kernel runs the same
+// arithmetic with the table in LDS: voice_exp2_cr_lds in voice_kernels.hip.)
+IAS_HD float ias_exp2_cr_tab(float t, const double* tab) {
+  const float u = fmaf(t, 256.0f, 12582912.0f);
+  const float mf = u - 12582912.0f;
+  const float r = fmaf(mf, -0.00390625f, t);
+  union { float f; int32_t i; } b;
+  b.f = u;
+  const double tv = tab[b.i - (0x4B400000 + IAS_EXP2_TAB_MIN)];
+  const double rd = (double)r;
+  double p = IAS_EXP2_C4;
+  p = fma(p, rd, IAS_EXP2_C3);
+  p = fma(p, rd, IAS_EXP2_C2);
+  p = fma(p, rd, IAS_EXP2_C1);
+  p = fma(p, rd, 1.0);
+  return (float)(p * tv);
 }
 
 // fl32(a / d) for a divisor d whose odd part is small (12, audio sample rates): the fp64 product

@@ -92,6 +92,8 @@ class Voice(nn.Module):
         self.register_buffer("params01", torch.full((c.batch_size, S.NPARAMS), 0.5), persistent=False)
         self._frozen = set()
         self._workspace = None
+        # 0: the tested arithmetic contract (oracle "cr"); 1: hardware fp32 exp2 on the pitch path (A/B measurement)
+        self.math_mode = 0
         for mod, _plist in S.MODULES:
             object.__setattr__(self, "_view_" + mod, _ModuleView(self, mod))
 
@@ -171,7 +173,7 @@ class Voice(nn.Module):
         audio = torch.empty((c.batch_size, c.buffer_size), dtype=torch.float32, device=p.device)
         st = lib.ias_voice_render(_lib.ptr(p), _lib.ptr(self.noise), _lib.ptr(audio), _lib.ptr(self._workspace),
                                   self._workspace.numel(), c.batch_size, c.buffer_size, c.control_buffer_size,
-                                  c.sample_rate, c.control_rate, 1 if normalize else 0, _lib.stream())
+                                  c.sample_rate, c.control_rate, 1 if normalize else 0, self.math_mode, _lib.stream())
         _lib.check(st, "ias_voice_render")
         self._check_chain(self._workspace)
         return audio
@@ -202,7 +204,8 @@ class Voice(nn.Module):
         hook = on_stage or (lambda name, phase: None)
         for stage, name in enumerate(("oscillators", "normalize")[: 2 if normalize else 1]):
             hook(name, "begin")
-            st = lib.ias_voice_stage(stage, _lib.ptr(self.noise), _lib.ptr(audio), _lib.ptr(workspace), workspace.numel(),
+            st = lib.ias_voice_stage(stage, self.math_mode, _lib.ptr(self.noise), _lib.ptr(audio), _lib.ptr(workspace),
+                                     workspace.numel(),
                                      c.batch_size, c.buffer_size, c.control_buffer_size, c.sample_rate, _lib.stream())
             _lib.check(st, f"ias_voice_stage({name})")
             hook(name, "end")

@@ -93,6 +93,14 @@ extern "C" long long emul_check_fast_paths(const float* pm, long long n, float f
     if (a != b) ++bad;
     const float t = pm[i] * 10.0f - 5.0f;
     if (ias_exp2_cr(t) != ias_exp2_cr_fast(t)) ++bad;
+    // table form of the render kernel, over the whole pitch range t = (c - 69) / 12, c in [0, 127]
+    static const double tab[IAS_EXP2_TAB_LEN] = IAS_EXP2_TAB_INIT;
+    const float tp = ias_div(ias_sub(pm[i] * 127.0f, 69.0f), 12.0f);
+    if (ias_exp2_cr(tp) != ias_exp2_cr_tab(tp, tab)) ++bad;
+    if (i < 128) {   // the range ends exactly
+      const float te = ias_div(ias_sub(i < 64 ? 0.0f : 127.0f, 69.0f), 12.0f);
+      if (ias_exp2_cr(te) != ias_exp2_cr_tab(te, tab)) ++bad;
+    }
     const float w = pm[i] * 7000.0f;
     if (ias_div(w, sr) != ias_div_by_recip(w, inv_sr)) ++bad;
     if (ias_div(t, 12.0f) != ias_div_by_recip(t, 1.0 / 12.0)) ++bad;

@@ -91,7 +91,7 @@ def test_bad_arguments_fail_loudly(lib, dev):
     with pytest.raises(RuntimeError):
         v.render(torch.rand(4, 78))  # CPU tensor: no CPU fallback
     from inverse_audio_synthesis_amd import _lib
-    assert lib.ias_voice_render(None, None, None, None, 0, 4, 16000, 441, 16000, 441, 1, None) == -1
+    assert lib.ias_voice_render(None, None, None, None, 0, 4, 16000, 441, 16000, 441, 1, 0, None) == -1
 
 
 def test_tile_chain_completes_and_debug_rows(lib, dev):
