@@ -181,7 +181,9 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_modmix_kernel(
 #ifndef VOICE_GROUP
 #define VOICE_GROUP 4        // samples the compiler may interleave (a scheduling barrier after each group)
 #endif
+#ifndef VOICE_NCOUNTERS
 #define VOICE_NCOUNTERS 8   // ticket counters (one 128-byte line each): counter c hands out the tiles of the voices b % 8 == c
+#endif
 #define VOICE_SYNC_HEAD_BYTES ((VOICE_NCOUNTERS + 1) * 128)   // counters, then the line of the status word
 #define VOICE_MATH_CR 0     // pitch exp2 correctly rounded (oracle math "cr"): the default and the tested contract
 #define VOICE_TAB_DOUBLES ((IAS_EXP2_TAB_LEN + 1) / 2 * 2)   // table padded to 16 bytes
@@ -463,21 +465,37 @@ __device__ __forceinline__ void voice_phase_b(const char* s_ctrl, float* s_stage
   }
 }
 
-// Single pass over every row with a chained scan across tiles ("decoupled look-back"), persistent workgroups, two tiles
-// in flight per workgroup:
-//   ticket  -> (tile, voice), tile-major; a workgroup keeps taking tickets until they run out.  Tickets are handed out
-//              in order and a workgroup only ever WAITS for smaller tickets, whose holders have either published or are
-//              computing their phase A without waiting for anybody -- no dependence on dispatch order or placement.
+// element i (< IAS_NCTRL * ncp) of a tile's control stage: signal k = i / ncp, point c = i % ncp
+__device__ __forceinline__ float2 voice_ctrl_elem(const float* __restrict__ ctrl, const VoiceTile& t, int Tc, int i) {
+  const int k = i / t.ncp, c = i - k * t.ncp;
+  const float* crow = ctrl + ((size_t)t.b * IAS_NCTRL + k) * Tc;
+  return make_float2(crow[t.c_lo + c], crow[min(t.c_lo + c + 1, Tc - 1)]);
+}
+__device__ __forceinline__ void voice_ctrl_put(char* dst, const VoiceTile& t, int i, float2 v) {
+  const int k = i / t.ncp, c = i - k * t.ncp;
+  reinterpret_cast<float2*>(dst)[c * IAS_NCTRL + k] = v;
+}
+
+// Single pass over every row with a chained scan across tiles ("decoupled look-back"), persistent workgroups, three
+// tiles in flight per workgroup (AFTER: ticket + control points being fetched; NEXT: phase A; CURRENT: phase B):
+//   ticket  -> (tile, voice), tile-major per counter; a workgroup keeps taking tickets until they run out.  Tickets are
+//              handed out in order and a workgroup only ever WAITS for smaller tickets, whose holders have either
+//              published or are computing their phase A without waiting for anybody -- no dependence on dispatch order
+//              or placement.
 //   loop    -> phase A of the NEXT tile (increments, sums; needs nothing from other workgroups), publish its sums, then
 //              look-back + phase B of the CURRENT tile.  A tile's sums are thus published one phase B (~10 us of wave
 //              time) before its own audio is due, and the words a tile polls were requested before phase A of the next
 //              one: the look-back round trip and the predecessors' publish delay are off the critical path (with one
-//              tile in flight the waves spent 18 % of a tile waiting for them).
+//              tile in flight the waves spent 18 % of a tile waiting for them).  The ticket after next is requested
+//              before phase A and read after it; its control points are fetched during phase B.
 //   publish -> one 8-byte write-through store per VCO: the sum's bits with the sign bit as READY flag (sums are >= 0).
 //              The datum is its own flag (MI355X guide, Guideline 16 form R2).
-//   wait    -> wave 0 polls the predecessors' words with relaxed agent-scope loads (L1 bypass), bounded spins, and adds
-//              them up: the tile's carry-in.  An expired wait turns the carry (hence the tile's audio) into NaN.
+//   wait    -> one wave polls the predecessors' words with relaxed agent-scope loads (L1 bypass), bounded spins, and
+//              adds them up: the tile's carry-in.  An expired wait turns the carry (hence the tile's audio) into NaN.
+//   roles   -> wave 0 takes tickets, wave 3 looks back, wave 2 publishes: no wave carries all the serial work.
 // The pitch exp2 reads a 2^(i/256) table (fp64, 21.7 KB) that each workgroup copies to LDS once.
+#define VOICE_WAVE_LOOKBACK (AUDIO_WAVES - 1)
+#define VOICE_WAVE_PUBLISH (AUDIO_WAVES - 2)
 template <int MATH, bool FMA_DIV>
 __global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) void voice_audio_kernel(
     const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst,
@@ -494,18 +512,24 @@ __global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) void voice_audio_ke
   __shared__ double s_wsum[2][2][AUDIO_WAVES];   // [slot][vco][wave]
   __shared__ double s_carry[2];
   __shared__ float s_max[AUDIO_WAVES];
-  __shared__ unsigned s_ticket;
+  __shared__ int s_ticket;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int my_counter = blockIdx.x % VOICE_NCOUNTERS, counters_tried = 0;   // used by thread 0 only
-  if (tid == 0) s_ticket = (unsigned)voice_take_ticket(ticket_status, my_counter, counters_tried, ntiles, nvoices);
+  if (tid == 0) s_ticket = voice_take_ticket(ticket_status, my_counter, counters_tried, ntiles, nvoices);
   if (MATH == VOICE_MATH_CR)
     for (int i = tid; i < IAS_EXP2_TAB_LEN; i += AUDIO_THREADS) s_tab[i] = g_exp2_tab[i];
   __syncthreads();
-  int t_next = __builtin_amdgcn_readfirstlane((int)s_ticket);
 
   VoiceTile cur = {}, next = {};
   bool have_cur = false;
+  // the first tile: ticket and control points fetched here, synchronously
+  bool have_next = __builtin_amdgcn_readfirstlane(s_ticket) >= 0;
+  float2 pre = make_float2(0.f, 0.f);           // this thread's element of the control stage of `next`
+  if (have_next) {
+    next = voice_tile_of(__builtin_amdgcn_readfirstlane(s_ticket), nvoices, T, Tc, scale);
+    if (tid < IAS_NCTRL * next.ncp) pre = voice_ctrl_elem(ctrl, next, Tc, tid);
+  }
   int slot = 0;                                 // s_wsum / control stage of the CURRENT tile
   float incC1[VOICE_SPT], incC2[VOICE_SPT];     // the current tile's increments (phase B), the next tile's (phase A)
   float incN1[VOICE_SPT], incN2[VOICE_SPT];
@@ -513,15 +537,13 @@ __global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) void voice_audio_ke
 #pragma unroll
   for (int e = 0; e < VOICE_SPT; ++e) { incC1[e] = incC2[e] = 0.0f; }
 
-  for (;;) {
-    const bool have_next = t_next >= 0;
-    if (!have_cur && !have_next) break;
+  while (have_cur || have_next) {
     gu64* row = (gu64*)(agg + ((size_t)cur.b * ntiles) * 2);
     VSTAMP(0);
     unsigned long long early1 = VOICE_READY_BIT, early2 = VOICE_READY_BIT;
     if (have_cur) {
       // the current tile's look-back words and noise are requested now and examined after phase A of the next tile
-      if (wave == 0 && lane < cur.tile) {
+      if (wave == VOICE_WAVE_LOOKBACK && lane < cur.tile) {
         early1 = __hip_atomic_load(row + lane * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         early2 = __hip_atomic_load(row + lane * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -535,16 +557,28 @@ __global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) void voice_audio_ke
       }
     }
     if (have_next) {
-      next = voice_tile_of(t_next, nvoices, T, Tc, scale);
-      voice_stage_ctrl(s_ctrl0 + (slot ^ 1) * ctrl_bytes, ctrl, next, Tc);
+      // the next tile's control points (fetched during the previous phase B) -> LDS
+      char* dst = s_ctrl0 + (slot ^ 1) * ctrl_bytes;
+      if (tid < IAS_NCTRL * next.ncp) voice_ctrl_put(dst, next, tid, pre);
+      for (int i = tid + AUDIO_THREADS; i < IAS_NCTRL * next.ncp; i += AUDIO_THREADS)   // windows wider than 51 points
+        voice_ctrl_put(dst, next, i, voice_ctrl_elem(ctrl, next, Tc, i));
     }
-    __syncthreads();   // (1) the next tile's control points are staged; everybody has read s_ticket
+    __syncthreads();   // (1) the next tile's control points are staged
     VSTAMP(1);
+    unsigned after_raw = 0;
+    int after_c = 0;
     if (have_next) {
-      // the ticket after next: in flight during phase A, read after barrier (3)
-      if (tid == 0) s_ticket = (unsigned)voice_take_ticket(ticket_status, my_counter, counters_tried, ntiles, nvoices);
+      // the ticket after next: requested now, resolved after phase A
+      if (tid == 0) {
+        after_c = my_counter;
+        after_raw = __hip_atomic_fetch_add((gu32*)(ticket_status + after_c * 32), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       const IasVoiceConst vcn = vconst[next.b];
+#ifdef VOICE_SKIP_A
+      if (false)
+#else
       if (next.fast)
+#endif
         voice_phase_a<MATH, FMA_DIV, true>(s_ctrl0 + (slot ^ 1) * ctrl_bytes, s_tab, vcn, next, T, inv_sample_rate, sr_f, sr_r,
                                            scale, incN1, incN2, exN1, exN2, s_wsum[slot ^ 1]);
 #ifndef VOICE_ANALYZE_FULL_ONLY
@@ -552,10 +586,22 @@ __global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) void voice_audio_ke
         voice_phase_a<MATH, FMA_DIV, false>(s_ctrl0 + (slot ^ 1) * ctrl_bytes, s_tab, vcn, next, T, inv_sample_rate, sr_f, sr_r,
                                             scale, incN1, incN2, exN1, exN2, s_wsum[slot ^ 1]);
 #endif
+      if (tid == 0) {
+        const int nv_c = (nvoices - after_c + VOICE_NCOUNTERS - 1) / VOICE_NCOUNTERS;
+        int tk = (after_c << 24) | (int)after_raw;
+        if ((int)after_raw >= nv_c * ntiles) {      // that counter is exhausted: try the others (end of the launch only)
+          my_counter = (my_counter + 1) % VOICE_NCOUNTERS;
+          ++counters_tried;
+          tk = voice_take_ticket(ticket_status, my_counter, counters_tried, ntiles, nvoices);
+        }
+        s_ticket = tk;
+      }
+    } else if (tid == 0) {
+      s_ticket = -1;
     }
     VSTAMP(2);
-    // ---- the current tile's carry-in: its predecessors' sums (wave 0)
-    if (have_cur && wave == 0) {
+    // ---- the current tile's carry-in: its predecessors' sums
+    if (have_cur && wave == VOICE_WAVE_LOOKBACK) {
       double a1 = 0.0, a2 = 0.0;
       bool timeout = false;
       for (int t0 = 0; t0 < cur.tile; t0 += 64) {
@@ -591,9 +637,9 @@ __global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) void voice_audio_ke
       }
     }
     VSTAMP(3);
-    __syncthreads();   // (2) the next tile's wave sums, the current tile's carry, the noise blocks
+    __syncthreads();   // (2) the next tile's wave sums, the current tile's carry, the noise blocks, the ticket after next
     VSTAMP(4);
-    if (have_next && wave == 0 && lane < 2) {
+    if (have_next && wave == VOICE_WAVE_PUBLISH && lane < 2) {
       // publish the next tile's sums: from here on nobody waits for this workgroup on its account
       double a = 0.0;
       for (int w = 0; w < AUDIO_WAVES; ++w) a += s_wsum[slot ^ 1][lane][w];
@@ -601,10 +647,22 @@ __global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) void voice_audio_ke
       __hip_atomic_store(nrow_agg + next.tile * 2 + lane, (unsigned long long)__double_as_longlong(a) | VOICE_READY_BIT,
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // the tile after next: its control points are requested now and land during phase B
+    const int t_after = __builtin_amdgcn_readfirstlane(s_ticket);
+    const bool have_after = t_after >= 0;
+    VoiceTile after = {};
+    if (have_after) {
+      after = voice_tile_of(t_after, nvoices, T, Tc, scale);
+      if (tid < IAS_NCTRL * after.ncp) pre = voice_ctrl_elem(ctrl, after, Tc, tid);
+    }
     if (have_cur) {
       const IasVoiceConst vc = vconst[cur.b];
       float pk = 0.0f;
+#ifdef VOICE_SKIP_B
+      if (false)
+#else
       if (cur.fast)
+#endif
         voice_phase_b<true>(s_ctrl0 + slot * ctrl_bytes, s_stage, vc, cur, noise + (size_t)cur.b * T, audio + (size_t)cur.b * T,
                             T, scale, incC1, incC2, exC1, exC2, s_carry, s_wsum[slot], pk);
 #ifndef VOICE_ANALYZE_FULL_ONLY
@@ -616,21 +674,22 @@ __global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) void voice_audio_ke
       if (lane == 0) s_max[wave] = pk;
     }
     VSTAMP(5);
-    __syncthreads();   // (3) the current tile is done with its control stage, wave sums, carry; s_max and s_ticket are set
+    __syncthreads();   // (3) the current tile is done with its control stage, wave sums and carry; s_max is set
     VSTAMP(6);
     if (have_cur && tid == 0) {
       float m = s_max[0];
       for (int w = 1; w < AUDIO_WAVES; ++w) m = fmaxf(m, s_max[w]);
       atomicMax(rowpeak + cur.b, __float_as_uint(m));  // m >= 0: uint order == float order
     }
-    // the next tile becomes the current one
+    // rotate: next -> current, after -> next
     cur = next;
     have_cur = have_next;
+    next = after;
+    have_next = have_after;
     slot ^= 1;
 #pragma unroll
     for (int e = 0; e < VOICE_SPT; ++e) { incC1[e] = incN1[e]; incC2[e] = incN2[e]; }
     exC1 = exN1; exC2 = exN2;
-    t_next = have_next ? __builtin_amdgcn_readfirstlane((int)s_ticket) : -1;
   }
 }
 
