@@ -189,7 +189,9 @@ def main():
             main.wait_event(ctrl_done)
             if pipelined and i + 1 < k:
                 ctrl_done_next = issue_control(i + 1)
-            audio = voice.render_audio(workspaces[buf], out=audio_bufs[buf], on_stage=hook)
+            # normalize_if_clipping is folded into the two consumers (row peaks read in place from the workspace)
+            audio = voice.render_audio(workspaces[buf], out=audio_bufs[buf], on_stage=hook, normalize=False)
+            peaks = voice.peaks_view(workspaces[buf])
             ws_free[buf] = main.record_event()
             if not (pipelined and i + 1 < k) and i + 1 < k:
                 ctrl_done_next = issue_control(i + 1)
@@ -199,10 +201,10 @@ def main():
             side_a.wait_event(rendered)
             side_b.wait_event(rendered)
             with torch.cuda.stream(side_a):
-                z = gram(audio.unsqueeze(1))
+                z = gram.analysis(audio.unsqueeze(1), rowpeak=peaks)
                 ea = side_a.record_event()
             with torch.cuda.stream(side_b):
-                loss = mel_l1(audio, target_mel=target_mel)
+                loss = mel_l1(audio, target_mel=target_mel, rowpeak=peaks)
                 eb = side_b.record_event()
             consumed[buf] = (ea, eb)
             if not pipelined:

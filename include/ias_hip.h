@@ -70,6 +70,11 @@ int ias_voice_stage(int stage, int math_mode, const float* noise, float* audio, 
  * its predecessors expired (that tile's audio is then NaN: an expired wait never continues with partial sums). */
 int ias_voice_read_status(const void* workspace, unsigned* status, int B, int T, int Tc, void* stream);
 
+/* Byte offset inside the workspace of the B row peaks (fp32, max |x| of the un-normalised mix) of the last render.
+ * ias_pqmf_analysis / ias_stft take that address as `rowpeak` to fold normalize_if_clipping into their own pass
+ * (render with normalize = 0): the normalised audio is then never written or re-read. */
+long long ias_voice_peaks_offset(int B, int T, int Tc);
+
 /* Copy the B row peaks (max |x| before normalisation) of the last render out of the workspace. */
 int ias_voice_read_peaks(const void* workspace, float* peaks, int B, int T, int Tc, void* stream);
 
@@ -110,9 +115,11 @@ int ias_pqmf_pack_taps(const float* H, float* packed, int N, int K, void* stream
  * packed: the ias_pqmf_pack_taps table of H, or NULL (generic one-lane-per-output kernel, same sums in the same
  * order, 10-100x slower).
  * mean/stdv [N] (both or neither, may be NULL): fused (z - mean[k]) / stdv[k] of
- * AudioEmbedding._preprocess (reference audioembed.py:41,49). */
+ * AudioEmbedding._preprocess (reference audioembed.py:41,49).
+ * rowpeak [B] (may be NULL): row peaks of x; the result is the analysis of x[b] / rowpeak[b] where rowpeak[b] > 1
+ * (torchsynth normalize_if_clipping folded in, see ias_voice_peaks_offset). */
 int ias_pqmf_analysis(const float* x, const float* H, const float* packed, float* z, const float* mean,
-                      const float* stdv, int B, int T, int N, int K, void* stream);
+                      const float* stdv, const float* rowpeak, int B, int T, int N, int K, void* stream);
 
 /* synthesis: z [B,N,L], G [N,K] (= buffer G[1,N,K]) -> out [B, L*N] (= [B,1,L*N])   (pqmf.py:52-55). */
 /* packed: ias_pqmf_pack_synth_taps table of G (ias_pqmf_synth_taps_len floats; wide kernel for N <= 64, K <= 255),
@@ -144,11 +151,13 @@ int ias_stft_build_tables(int n_fft, const float* window_host, float* out_host);
  * mel_w [mel_nnz]); with NULL mel_* n_out must be n_fft/2+1.
  * out [B,F,n_out] (frames-major) or NULL; target [B,F,n_out] + partials required when
  * loss_mode is 1 (sum |v-t|) or 2 (MR-STFT sums {(t-v)^2, t^2, |log v - log t|}).
+ * rowpeak [B] or NULL: row peaks of audio; the spectrum is that of audio[b] / rowpeak[b] where rowpeak[b] > 1
+ * (normalize_if_clipping folded in: |X|^2 scales by 1 / peak^2).
  * n_fft in {512, 1024, 2048}. */
 int ias_stft(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
              const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
-             double* partials, int B, int T, int n_fft, int hop, int n_out, int value_mode, int loss_mode,
-             float eps, void* stream);
+             double* partials, const float* rowpeak, int B, int T, int n_fft, int hop, int n_out, int value_mode,
+             int loss_mode, float eps, void* stream);
 
 /* Backward of the spectral losses w.r.t. the audio (the reference's mel-L1 loop
  * audio_to_params.py:150-153 is commented out and would have used torchaudio's differentiable modules, its MR-STFT

@@ -34,6 +34,7 @@ SYMBOLS = {
     "ias_voice_render": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ias_voice_stage": (_I, [_I, _I, _P, _P, _P, _LL, _I, _I, _I, _I, _P]),
     "ias_voice_read_status": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ias_voice_peaks_offset": (_LL, [_I, _I, _I]),
     "ias_voice_read_peaks": (_I, [_P, _P, _I, _I, _I, _P]),
     "ias_voice_grad_tiles": (_I, [_I]),
     "ias_voice_grad_nscalars": (_I, []),
@@ -43,7 +44,7 @@ SYMBOLS = {
     "ias_pqmf_out_len": (_I, [_I, _I, _I]),
     "ias_pqmf_packed_taps_len": (_I, [_I, _I]),
     "ias_pqmf_pack_taps": (_I, [_P, _P, _I, _I, _P]),
-    "ias_pqmf_analysis": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_pqmf_analysis": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_pqmf_synth_taps_len": (_I, [_I, _I]),
     "ias_pqmf_pack_synth_taps": (_I, [_P, _P, _I, _I, _P]),
     "ias_pqmf_synthesis": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -51,7 +52,7 @@ SYMBOLS = {
     "ias_stft_partials_count": (_LL, [_I, _I, _I, _I]),
     "ias_stft_tables_len": (_I, [_I]),
     "ias_stft_build_tables": (_I, [_I, _P, _P]),
-    "ias_stft": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "ias_stft": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "ias_stft_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I,
                                    ctypes.c_float, ctypes.c_float, _P]),
     "ias_reduce_partials": (_I, [_P, _LL, _P, _c.c_double, _P, _P]),

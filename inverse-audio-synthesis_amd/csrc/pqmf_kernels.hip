@@ -101,11 +101,20 @@ struct PqmfStage {
 // Workgroups are persistent: each walks tiles t = blockIdx.x, + gridDim.x, ... of the (batch row, 1024-frame tile)
 // list and loads the next tile's samples into registers before it computes the current one, so the ~3000-cycle
 // global-load latency overlaps the FMAs instead of preceding them.
+// Row scale of torchsynth's normalize_if_clipping folded into the analysis (the filterbank is linear): rowpeak[b] =
+// max |x[b, :]| as ias_voice_render leaves it in its workspace; the output is that of the row divided by its peak when
+// the peak exceeds 1.  Saves the separate in-place pass over the audio (8 B per sample of HBM traffic for clipping rows).
+__device__ __forceinline__ float pqmf_row_scale(const float* __restrict__ rowpeak, int b) {
+  if (rowpeak == nullptr) return 1.0f;
+  const float pk = rowpeak[b];
+  return pk > 1.0f ? 1.0f / pk : 1.0f;
+}
+
 template <int N, int K>
 __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_fast_kernel(
     const float* __restrict__ x, const float* __restrict__ Pt, float* __restrict__ z,
-    const float* __restrict__ mean, const float* __restrict__ stdv, int T, int L, int pad, int tiles_x,
-    int ntiles) {
+    const float* __restrict__ mean, const float* __restrict__ stdv, const float* __restrict__ rowpeak, int T, int L,
+    int pad, int tiles_x, int ntiles) {
   using C = PqmfFast<N, K>;
   constexpr int FT = C::FT, Q = C::Q, U = C::U, COLS = C::COLS, ROW = C::ROW, NST = C::NST;
   constexpr int NH = U * N * N / 2;
@@ -212,9 +221,11 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_fast_kernel(
     sa.template fma<Q % U>(acc);   // tail steps (the table is zero past K)
 
     const int f0 = f_tile + wave * 256 + 2 * lane;
+    const float rsc = pqmf_row_scale(rowpeak, b);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       f32x2 o[2] = {acc[k][0], acc[k][1]};
+      if (rowpeak != nullptr) { o[0] = o[0] * rsc; o[1] = o[1] * rsc; }
       if (mean != nullptr) {
         const float m = mean[k], sd = stdv[k];
 #pragma unroll
@@ -246,8 +257,8 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_fast_kernel(
 template <int NPAD>
 __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_wide_kernel(
     const float* __restrict__ x, const float* __restrict__ Pt, float* __restrict__ z,
-    const float* __restrict__ mean, const float* __restrict__ stdv, int T, int L, int N, int K, int pad,
-    int rs /* LDS row stride (odd) */) {
+    const float* __restrict__ mean, const float* __restrict__ stdv, const float* __restrict__ rowpeak, int T, int L,
+    int N, int K, int pad, int rs /* LDS row stride (odd) */) {
   constexpr int HB = NPAD / 2;
   extern __shared__ __attribute__((aligned(16))) float s_rows[];   // [N][rs]
   const int tid = threadIdx.x, b = blockIdx.y;
@@ -282,11 +293,12 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_wide_kernel(
   }
   const int f = f0 + fl;
   if (f >= L) return;
+  const float rsc = pqmf_row_scale(rowpeak, b);
 #pragma unroll
   for (int k = 0; k < HB; ++k) {
     const int band = half * HB + k;
     if (band < N) {
-      float o = acc[k];
+      float o = acc[k] * rsc;
       if (mean != nullptr) o = (o - mean[band]) / stdv[band];
       z[((size_t)b * N + band) * L + f] = o;
     }
@@ -309,7 +321,8 @@ static int pqmf_wide_npad(int N, int K) {
 // Generic analysis (any N, K): one lane per output element.
 __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_generic_kernel(
     const float* __restrict__ x, const float* __restrict__ H, float* __restrict__ z,
-    const float* __restrict__ mean, const float* __restrict__ stdv, int T, int L, int N, int K, int pad) {
+    const float* __restrict__ mean, const float* __restrict__ stdv, const float* __restrict__ rowpeak, int T, int L,
+    int N, int K, int pad) {
   const int f = blockIdx.x * PQ_THREADS + threadIdx.x;
   const int k = blockIdx.y, b = blockIdx.z;
   if (f >= L) return;
@@ -321,6 +334,7 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_generic_kernel(
     const long long i = s + j;
     if (i >= 0 && i < T) acc = fmaf(xr[i], h[j], acc);
   }
+  acc *= pqmf_row_scale(rowpeak, b);
   if (mean != nullptr) acc = (acc - mean[k]) / stdv[k];
   z[((size_t)b * N + k) * L + f] = acc;
 }
@@ -490,8 +504,10 @@ extern "C" int ias_pqmf_out_len(int T, int N, int K) {
 // AudioEmbedding._preprocess normalisation.
 // packed: ias_pqmf_pack_taps table of H (fast kernel for N = 3, 4 with K = 63; wide kernel for other N <= 64);
 // NULL, or an (N, K) for which ias_pqmf_packed_taps_len is 0, runs the generic one-lane-per-output kernel.
+// rowpeak: optional [B] row peaks max |x| (ias_voice_render's workspace, ias_voice_peaks_offset): the analysis of the
+// row normalised as torchsynth's normalize_if_clipping would, without the normalised audio ever being written.
 extern "C" int ias_pqmf_analysis(const float* x, const float* H, const float* packed, float* z, const float* mean,
-                                 const float* stdv, int B, int T, int N, int K, void* stream_) {
+                                 const float* stdv, const float* rowpeak, int B, int T, int N, int K, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !H || !z || B <= 0 || B > 65535 || N <= 0 || N > 65535 || K <= 0 || (K & 1) == 0) return IAS_ERR_ARG;
   if ((mean == nullptr) != (stdv == nullptr)) return IAS_ERR_ARG;
@@ -507,10 +523,10 @@ extern "C" int ias_pqmf_analysis(const float* x, const float* H, const float* pa
     const int grid = (int)(ntiles < pqmf_resident_blocks() ? ntiles : pqmf_resident_blocks());
     if (N == 3)
       hipLaunchKernelGGL((pqmf_analysis_fast_kernel<3, 63>), dim3(grid), dim3(PQ_THREADS), 0, stream, x, packed, z,
-                         mean, stdv, T, L, pad, tiles_x, (int)ntiles);
+                         mean, stdv, rowpeak, T, L, pad, tiles_x, (int)ntiles);
     else
       hipLaunchKernelGGL((pqmf_analysis_fast_kernel<4, 63>), dim3(grid), dim3(PQ_THREADS), 0, stream, x, packed, z,
-                         mean, stdv, T, L, pad, tiles_x, (int)ntiles);
+                         mean, stdv, rowpeak, T, L, pad, tiles_x, (int)ntiles);
   } else if (packed && !((N == 3 || N == 4) && K == 63) /* those tables have the fast kernel's layout */ &&
              pqmf_wide_npad(N, K) && (long long)L * N + 2 * K < 0x7fffffffLL) {
     const int npad = pqmf_wide_npad(N, K);
@@ -519,8 +535,8 @@ extern "C" int ias_pqmf_analysis(const float* x, const float* H, const float* pa
     const size_t lds = sizeof(float) * (size_t)N * rs;
     const dim3 grid((L + PQW_FRAMES - 1) / PQW_FRAMES, B), block(PQ_THREADS);
 #define IAS_PQW_LAUNCH(NP)                                                                                      \
-    hipLaunchKernelGGL((pqmf_analysis_wide_kernel<NP>), grid, block, lds, stream, x, packed, z, mean, stdv, T, L, N, \
-                       K, pad, rs)
+    hipLaunchKernelGGL((pqmf_analysis_wide_kernel<NP>), grid, block, lds, stream, x, packed, z, mean, stdv, rowpeak, T, \
+                       L, N, K, pad, rs)
     if (npad == 8) IAS_PQW_LAUNCH(8);
     else if (npad == 16) IAS_PQW_LAUNCH(16);
     else if (npad == 32) IAS_PQW_LAUNCH(32);
@@ -528,7 +544,7 @@ extern "C" int ias_pqmf_analysis(const float* x, const float* H, const float* pa
 #undef IAS_PQW_LAUNCH
   } else {
     hipLaunchKernelGGL(pqmf_analysis_generic_kernel, dim3((L + PQ_THREADS - 1) / PQ_THREADS, N, B),
-                       dim3(PQ_THREADS), 0, stream, x, H, z, mean, stdv, T, L, N, K, pad);
+                       dim3(PQ_THREADS), 0, stream, x, H, z, mean, stdv, rowpeak, T, L, N, K, pad);
   }
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }

@@ -94,6 +94,7 @@ struct SpecArgs {
   float* out;              // [B,F,n_out] or null
   const float* target;     // [B,F,n_out] or null
   double* partials;        // [gridDim.x*gridDim.y][3] or null
+  const float* rowpeak;    // [B] or null: row peaks; the spectrum is that of row / peak when peak > 1 (|X|^2 scales by 1/peak^2)
   int T, F, hop, n_out, mel_nnz;
   int groups;              // frame groups (of SP_FPB frames) each workgroup walks through
   int value_mode;          // 1: |X|, 2: |X|^2, 3: sqrt(max(|X|^2, eps))
@@ -149,6 +150,9 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
   const int b = blockIdx.y;
   const float* arow = a.audio + (size_t)b * a.T;
   const bool mel = a.mel_start != nullptr;
+  // normalize_if_clipping folded in: |FFT(x / peak)|^2 = |FFT(x)|^2 / peak^2
+  float pscale = 1.0f;
+  if (a.rowpeak != nullptr) { const float pkv = a.rowpeak[b]; if (pkv > 1.0f) { const float r = 1.0f / pkv; pscale = r * r; } }
 
   if (mel) {
     for (int i = tid; i < a.mel_nnz; i += SP_THREADS) s_melw[i] = a.mel_w[i];
@@ -276,6 +280,7 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
         const cpx xk = cadd(ze, t);                     // X[k]
         const cpx xq = cmk(ze.x - t.x, -(ze.y - t.y));  // X[N2-k] = conj(ze - t)
         float vk = xk.x * xk.x + xk.y * xk.y, vn = xq.x * xq.x + xq.y * xq.y;
+        if (a.rowpeak != nullptr) { vk *= pscale; vn *= pscale; }
         if (a.value_mode == 1) { vk = sqrtf(vk); vn = sqrtf(vn); }
         else if (a.value_mode == 3) { vk = sqrtf(fmaxf(vk, a.eps)); vn = sqrtf(fmaxf(vn, a.eps)); }
         pk[i] = vk; pn[i] = vn;
@@ -497,10 +502,12 @@ extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float*
 //   out      [B,F,n_out] or NULL : the spectrogram (frames-major layout)
 //   target   [B,F,n_out] or NULL : with loss_mode 1 (sum |v-t|) or 2 (MR-STFT sums)
 //   partials [ias_stft_partials_count][3] doubles, required when loss_mode != 0
+//   rowpeak  [B] or NULL : row peaks max |audio| (ias_voice_render's workspace): the spectrum of the row normalised as
+//                          torchsynth's normalize_if_clipping would, without the normalised audio ever being written
 extern "C" int ias_stft(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
                         const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
-                        double* partials, int B, int T, int n_fft, int hop, int n_out, int value_mode,
-                        int loss_mode, float eps, void* stream_) {
+                        double* partials, const float* rowpeak, int B, int T, int n_fft, int hop, int n_out,
+                        int value_mode, int loss_mode, float eps, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!audio || !tables || B <= 0 || B > 65535 || n_out <= 0) return IAS_ERR_ARG;
   if (value_mode < 1 || value_mode > 3 || loss_mode < 0 || loss_mode > 2) return IAS_ERR_ARG;
@@ -516,7 +523,7 @@ extern "C" int ias_stft(const float* audio, const float* tables, const int* mel_
   SpecArgs a;
   a.audio = audio; a.tables = tables;
   a.mel_start = mel_start; a.mel_count = mel_count; a.mel_woff = mel_woff; a.mel_w = mel_w;
-  a.out = out; a.target = target; a.partials = partials;
+  a.out = out; a.target = target; a.partials = partials; a.rowpeak = rowpeak;
   a.T = T; a.F = F; a.hop = hop; a.n_out = n_out; a.mel_nnz = mel ? mel_nnz : 0;
   a.value_mode = value_mode; a.loss_mode = loss_mode; a.eps = eps;
 

@@ -899,6 +899,13 @@ extern "C" int ias_voice_read_status(const void* workspace, unsigned* status_dev
   return IAS_OK;
 }
 
+// Byte offset of the row peaks [B] (fp32 bit patterns of max |x| before normalisation) inside the workspace: consumers
+// that fold the normalisation in (ias_pqmf_analysis / ias_stft `rowpeak`) read them in place.
+extern "C" long long ias_voice_peaks_offset(int B, int T, int Tc) {
+  if (B <= 0 || T <= 0 || Tc <= 1) return IAS_ERR_ARG;
+  return (long long)voice_ws_layout(B, T, Tc).off_peak;
+}
+
 // Row peaks (|x| max before normalisation) of the last render, for tests/diagnostics.
 extern "C" int ias_voice_read_peaks(const void* workspace, float* peaks_dev, int B, int T, int Tc, void* stream_) {
   if (!workspace || !peaks_dev) return IAS_ERR_ARG;

@@ -72,31 +72,34 @@ class _AnalysisFn(torch.autograd.Function):
         return g_x.reshape(ctx.shape), None, None, None
 
 
-def pqmf_analysis(x, H, mean=None, std=None):
+def pqmf_analysis(x, H, mean=None, std=None, rowpeak=None):
     """x [B,1,T] or [B,T] fp32 on a ROCm device, H [N,1,K] -> z [B,N,L].
 
     ``mean``/``std`` ([N] device tensors) fuse the per-band normalisation of
     /root/reference/audioembed.py:49 into the store.  Differentiable with respect to ``x`` (not H).
+    ``rowpeak`` [B]: row peaks of an un-normalised render (``Voice.peaks_view``): the analysis of x / peak where
+    peak > 1 (torchsynth normalize_if_clipping folded in; forward only).
     """
     if torch.is_grad_enabled() and x.requires_grad:
+        assert rowpeak is None, "the folded normalisation is a forward-only path"
         return _AnalysisFn.apply(x, H, mean, std)
-    return _analysis_nograd(x, H, mean, std)
+    return _analysis_nograd(x, H, mean, std, rowpeak)
 
 
-def _analysis_nograd(x, H, mean=None, std=None):
+def _analysis_nograd(x, H, mean=None, std=None, rowpeak=None):
     lib = _lib.load()
     if x.dim() == 3:
         assert x.shape[1] == 1, "PQMF analysis takes one input channel"
     x2 = x.reshape(x.shape[0], -1).contiguous()
     Hc = H.reshape(H.shape[0], -1).contiguous()
-    _lib.require_f32(x2, Hc, mean, std)
+    _lib.require_f32(x2, Hc, mean, std, rowpeak)
     B, T = x2.shape
     N, K = Hc.shape
     L = lib.ias_pqmf_out_len(T, N, K)
     _lib.check(min(L, 0), "ias_pqmf_out_len")
     z = torch.empty((B, N, L), dtype=torch.float32, device=x2.device)
     st = lib.ias_pqmf_analysis(_lib.ptr(x2), _lib.ptr(Hc), _lib.ptr(_packed_taps(H, Hc, N, K)), _lib.ptr(z),
-                               _lib.ptr(mean), _lib.ptr(std), B, T, N, K, _lib.stream())
+                               _lib.ptr(mean), _lib.ptr(std), _lib.ptr(rowpeak), B, T, N, K, _lib.stream())
     _lib.check(st, "ias_pqmf_analysis")
     return z
 
@@ -151,8 +154,8 @@ class PQMF(torch.nn.Module):
     def forward(self, x):
         return self.analysis(x)
 
-    def analysis(self, x):
-        return pqmf_analysis(x, self.H)
+    def analysis(self, x, rowpeak=None):
+        return pqmf_analysis(x, self.H, rowpeak=rowpeak)
 
     def synthesis(self, x):
         return pqmf_synthesis(x, self.G)

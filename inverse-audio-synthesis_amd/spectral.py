@@ -96,14 +96,15 @@ class STFTPlan(nn.Module):
         _lib.check(min(F, 0), "ias_stft_num_frames (need T > n_fft/2 for reflect padding)")
         return F
 
-    def _call(self, audio, out, target, partials, value_mode, loss_mode, eps):
+    def _call(self, audio, out, target, partials, value_mode, loss_mode, eps, rowpeak=None):
         lib = _lib.load()
         B, T = audio.shape
         mel = self.n_mels is not None
         st = lib.ias_stft(_lib.ptr(audio), _lib.ptr(self.tables),
                           _lib.ptr(self.mel_start) if mel else None, _lib.ptr(self.mel_count) if mel else None,
                           _lib.ptr(self.mel_woff) if mel else None, _lib.ptr(self.mel_w) if mel else None,
-                          int(self.mel_w.numel()) if mel else 0, _lib.ptr(out), _lib.ptr(target), _lib.ptr(partials), B, T, self.n_fft, self.hop_length,
+                          int(self.mel_w.numel()) if mel else 0, _lib.ptr(out), _lib.ptr(target), _lib.ptr(partials),
+                          _lib.ptr(rowpeak), B, T, self.n_fft, self.hop_length,
                           self.n_out, value_mode, loss_mode, float(eps), _lib.stream())
         _lib.check(st, "ias_stft")
 
@@ -115,14 +116,15 @@ class STFTPlan(nn.Module):
         _lib.require_f32(a)
         return a
 
-    def values(self, audio, value_mode=VALUE_POWER, eps=0.0):
-        """-> [B, frames, n_out] (frames-major) spectrogram values."""
+    def values(self, audio, value_mode=VALUE_POWER, eps=0.0, rowpeak=None):
+        """-> [B, frames, n_out] (frames-major) spectrogram values.  ``rowpeak`` [B]: the row peaks of an
+        un-normalised render (``Voice.peaks_view``): values of audio / peak where peak > 1, audio left as it is."""
         a = self._audio2d(audio)
         out = torch.empty((a.shape[0], self.num_frames(a.shape[1]), self.n_out), dtype=torch.float32, device=a.device)
-        self._call(a, out, None, None, value_mode, LOSS_NONE, eps)
+        self._call(a, out, None, None, value_mode, LOSS_NONE, eps, rowpeak)
         return out
 
-    def loss_sums(self, audio, target_values, value_mode, loss_mode, eps=0.0, mean_scale=None):
+    def loss_sums(self, audio, target_values, value_mode, loss_mode, eps=0.0, mean_scale=None, rowpeak=None):
         """Fused STFT + comparison with cached target values -> 3 fp64 sums on the device
         (with ``mean_scale``: -> the fp32 scalar sums[0] * mean_scale, computed by the same kernel)."""
         a = self._audio2d(audio)
@@ -131,7 +133,7 @@ class STFTPlan(nn.Module):
         assert target_values.shape == (a.shape[0], F, self.n_out) and target_values.is_contiguous()
         n = lib.ias_stft_partials_count(a.shape[0], a.shape[1], self.n_fft, self.hop_length)
         partials = torch.empty((n, 3), dtype=torch.float64, device=a.device)
-        self._call(a, None, target_values, partials, value_mode, loss_mode, eps)
+        self._call(a, None, target_values, partials, value_mode, loss_mode, eps, rowpeak)
         sums = torch.empty(3, dtype=torch.float64, device=a.device)
         mean = torch.empty((), dtype=torch.float32, device=a.device) if mean_scale is not None else None
         _lib.check(lib.ias_reduce_partials(_lib.ptr(partials), n, _lib.ptr(sums),
@@ -172,11 +174,13 @@ class _L1LossFn(torch.autograd.Function):
         return g_audio.reshape(ctx.shape), None, None, None
 
 
-def _l1_loss(plan, audio, target_values, value_mode):
+def _l1_loss(plan, audio, target_values, value_mode, rowpeak=None):
     if torch.is_grad_enabled() and audio.requires_grad:
         assert value_mode in (VALUE_POWER, VALUE_MAG)
+        assert rowpeak is None, "the folded normalisation is a forward-only path"
         return _L1LossFn.apply(audio, plan, target_values, value_mode)
-    return plan.loss_sums(audio, target_values, value_mode, LOSS_L1, mean_scale=1.0 / target_values.numel())
+    return plan.loss_sums(audio, target_values, value_mode, LOSS_L1, mean_scale=1.0 / target_values.numel(),
+                          rowpeak=rowpeak)
 
 
 class MelSpectrogram(nn.Module):
@@ -214,10 +218,12 @@ class MelSpectrogramL1(nn.Module):
         """Cacheable frames-major mel of the target audio."""
         return self.mel.frames_major(target_audio)
 
-    def forward(self, audio, target_audio=None, target_mel=None):
+    def forward(self, audio, target_audio=None, target_mel=None, rowpeak=None):
+        """``rowpeak``: row peaks of an un-normalised render; the loss is that of the normalised audio
+        (torchsynth normalize_if_clipping folded into the STFT pass)."""
         if target_mel is None:
             target_mel = self.target(target_audio)
-        return _l1_loss(self.mel.plan, audio, target_mel.detach(), self.mel.value_mode)
+        return _l1_loss(self.mel.plan, audio, target_mel.detach(), self.mel.value_mode, rowpeak)
 
 
 class STFTL1(nn.Module):

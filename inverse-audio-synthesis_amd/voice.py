@@ -225,6 +225,15 @@ class Voice(nn.Module):
         hook("control", "end")
         return self.render_audio(self._workspace, out=out, on_stage=on_stage)
 
+    def peaks_view(self, workspace=None):
+        """The row peaks [B] (fp32, max |mix| before normalisation) of the last render INSIDE its workspace, as a
+        tensor view (no copy): the ``rowpeak`` argument of ``PQMF.analysis`` / ``MelSpectrogramL1`` when the render was
+        issued with ``normalize=False`` and the normalisation is folded into the consumers."""
+        c = self.synthconfig
+        ws = self._workspace if workspace is None else workspace
+        off = int(_lib.load().ias_voice_peaks_offset(c.batch_size, c.buffer_size, c.control_buffer_size))
+        return ws[off:off + 4 * c.batch_size].view(torch.float32)
+
     def read_peaks(self):
         """Row peaks max|mix| [B] of the last render (before normalisation)."""
         c = self.synthconfig

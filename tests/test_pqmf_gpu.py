@@ -110,7 +110,7 @@ def test_packed_taps_follow_filter_updates(lib, dev):
     z2 = torch.empty_like(z1)
     Hc = m.H.reshape(3, 63).contiguous()
     x2 = x.reshape(2, -1)
-    st = lib.ias_pqmf_analysis(_lib.ptr(x2), _lib.ptr(Hc), None, _lib.ptr(z2), None, None, 2, 9000, 3, 63,
+    st = lib.ias_pqmf_analysis(_lib.ptr(x2), _lib.ptr(Hc), None, _lib.ptr(z2), None, None, None, 2, 9000, 3, 63,
                                _lib.stream())
     assert st == 0
     np.testing.assert_allclose(z2.cpu().numpy(), z1.cpu().numpy(), atol=1e-6)

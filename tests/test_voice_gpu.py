@@ -170,3 +170,36 @@ def test_headline_size_distance_to_reference_op_sequence(lib, dev, seed):
     # ... and no larger than the distance of the correctly-rounded CPU evaluation to it
     for k in hip_t:
         assert hip_t[k] <= cr_t[k] * 1.02 + 1e-6, (k, hip_t[k], cr_t[k])
+
+
+def test_normalisation_folded_into_the_consumers(lib, dev):
+    """render(normalize=False) + rowpeak on the consumers == normalised render + plain consumers: the fused step
+    never writes the normalised audio (torchsynth normalize_if_clipping folded into the PQMF / STFT passes)."""
+    from inverse_audio_synthesis_amd.pqmf import PQMF
+    from inverse_audio_synthesis_amd.spectral import MelSpectrogramL1
+    from oracle import pqmf_oracle as po
+    B = 16
+    v = _voice(dev, B, 44100, 4.0)
+    v.randomize(2)                                   # seed 2 has clipping voices
+    ws = v.new_workspace(dev)
+    v.render_control(ws)
+    raw = v.render_audio(ws, normalize=False)
+    peaks = v.peaks_view(ws)
+    assert torch.equal(peaks, raw.abs().max(dim=1)[0]) and (peaks > 1).any() and (peaks <= 1).any()
+    norm = v.render()                                # normalised, the reference semantics
+    for N in (3, 64):
+        gram = PQMF(N=N).to(dev)
+        z_fold = gram.analysis(raw.unsqueeze(1), rowpeak=peaks)
+        z_ref = gram(norm.unsqueeze(1))
+        assert (z_fold - z_ref).abs().max().item() <= 2e-6 * max(1.0, z_ref.abs().max().item())
+    # against the CPU oracle on the normalised audio as well
+    zo = po.analysis(norm[:2].cpu().unsqueeze(1), PQMF(N=3).H, 3, 62)
+    assert (PQMF(N=3).to(dev).analysis(raw[:2].unsqueeze(1), rowpeak=peaks[:2].contiguous()).cpu() - zo).abs().max().item() <= 2e-5
+    mel = MelSpectrogramL1(sample_rate=44100).to(dev)
+    tgt = mel.target(v.render(torch.rand(B, 78, generator=torch.Generator().manual_seed(5)).to(dev))).clone()
+    l_fold = mel(raw, target_mel=tgt, rowpeak=peaks).item()
+    l_ref = mel(norm, target_mel=tgt).item()
+    assert abs(l_fold - l_ref) <= 1e-5 * abs(l_ref)
+    m_fold = mel.mel.plan.values(raw, rowpeak=peaks)
+    m_ref = mel.mel.plan.values(norm)
+    assert ((m_fold - m_ref).abs() <= 1e-5 * m_ref.abs() + 1e-6).all()
