@@ -36,7 +36,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 128; gradstep: 64)")
+    ap.add_argument("--workload", default="synth", choices=["synth", "vicreg", "gradstep"],
+                    help="synth: the headline (BASELINE configs[1]: render + PQMF(3) + mel-L1, forward); "
+                         "vicreg: VICReg.loss forward + backward on [B, 8192] embeddings (configs[2]; with N > 1 ranks "
+                         "the FullGatherLayer all-gather / reduce-scatter and the global-batch loss of configs[3]); "
+                         "gradstep: configs[4] per GPU: render + 64-band PQMF + 3-resolution MR-STFT loss, forward + backward")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish a step's PQMF / spectral loss before the next step's render starts")
@@ -112,6 +117,175 @@ def cpu_baseline(cpu_batch):
     }
 
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
+
+
+def timed_regions(one_region_fn, args, world, dev):
+    """R timed regions of exactly K steps each (barrier + synchronize on both sides, max over ranks); -> sorted list."""
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def one():
+        sync_all()
+        t0 = time.perf_counter()
+        one_region_fn()
+        sync_all()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        return el
+
+    first = one()
+    replays = args.replays if args.replays > 0 else max(20, min(2000, int(0.25 / max(first, 1e-6)) + 1))
+    if world > 1:
+        r = torch.tensor([replays], dtype=torch.int64, device=dev)
+        dist.broadcast(r, 0)
+        replays = int(r.item())
+    return sorted(one() for _ in range(replays))
+
+
+def vicreg_cpu_baseline(B, D):
+    """oracle/vicreg_oracle.py (the reference's op sequence, vicreg.py:35-58) forward + autograd backward on the host."""
+    from oracle import vicreg_oracle as vo
+    cores = os.cpu_count() or 1
+    threads = min(cores, 32)
+    torch.set_num_threads(threads)
+    x = torch.randn(B, D, generator=torch.Generator().manual_seed(0)).requires_grad_()
+    y = torch.randn(B, D, generator=torch.Generator().manual_seed(1)).requires_grad_()
+
+    def step():
+        x.grad = y.grad = None
+        vo.loss(x, y, B, D)[0].backward()
+
+    step()
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        reps += 1
+        el = time.perf_counter() - t0
+        if (el > 8.0 and reps >= 3) or el > 40.0:
+            break
+    return {"value": round(B * reps / el, 2), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} passes of VICReg.loss forward + backward on x, y [{B}, {D}] (oracle, torch CPU ops, {el:.1f} s)"}
+
+
+def run_vicreg(args, rank, world, dev):
+    """BASELINE configs[2] / [3]: the projector loss on [B, 8192] embeddings, forward + backward.  N = 1: the local
+    loss.  N > 1: x and y all-gathered over RCCL (FullGatherLayer), the loss on the global batch with denominator
+    B_global - 1, gradients reduce-scattered back -- one real exchange step per direction."""
+    from inverse_audio_synthesis_amd import _lib
+    from inverse_audio_synthesis_amd.vicreg import FullGatherLayer, vicreg_loss
+    lib = _lib.load()
+    B, D = args.batch or BATCH, 8192
+    x = torch.randn(B, D, generator=torch.Generator().manual_seed(2 * rank)).to(dev).requires_grad_()
+    y = torch.randn(B, D, generator=torch.Generator().manual_seed(2 * rank + 1)).to(dev).requires_grad_()
+    gather = world > 1
+    state = {}
+
+    def step():
+        if gather:
+            xy = torch.cat(FullGatherLayer.apply(torch.cat([x, y], dim=1)), dim=0)     # ONE collective for both branches
+            xa, ya = xy[:, :D], xy[:, D:]
+        else:
+            xa, ya = x, y
+        out = vicreg_loss(xa.contiguous(), ya.contiguous(), B * world, 25.0, 25.0, 1.0)
+        gx, gy = torch.autograd.grad(out[0], (x, y))          # backward of the loss (and of the gather)
+        state["out"] = tuple(v.detach() for v in out)
+        state["grads"] = (gx, gy)
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    launch, graph = "eager", None
+    if not gather and not args.no_graph:
+        try:
+            state.clear()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(args.steps):
+                    step()
+            graph.replay()
+            torch.cuda.synchronize()
+            launch = "hipgraph"
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly\n")
+            graph = None
+            torch.cuda.synchronize()
+
+    def region():
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(args.steps):
+                step()
+
+    regions = timed_regions(region, args, world, dev)
+    elapsed = regions[len(regions) // 2]
+    out = [float(v) for v in state["out"]]
+
+    # ---- the Gram kernel alone (stage 1 of ias_vicreg_stage on a filled workspace), HIP events around K launches
+    Bg = B * world
+    xg = torch.randn(Bg, D, generator=torch.Generator().manual_seed(100)).to(dev)
+    yg = torch.randn(Bg, D, generator=torch.Generator().manual_seed(101)).to(dev)
+    need = int(lib.ias_vicreg_workspace_bytes(Bg, D))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    o4 = torch.empty(4, dtype=torch.float32, device=dev)
+
+    def stage(k):
+        _lib.check(lib.ias_vicreg_stage(k, _lib.ptr(xg), _lib.ptr(yg), _lib.ptr(o4), _lib.ptr(ws), need, Bg, D, Bg, 25.0, 25.0,
+                                        1.0, _lib.stream()), "ias_vicreg_stage")
+
+    stage(-1)
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        for _ in range(args.steps):
+            stage(1)
+    g2.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(5):
+        e0.record(); g2.replay(); e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / args.steps)
+    gram_ms = best
+    kpad = (Bg + 63) // 64 * 64
+    kpad = 128 if kpad == 64 else kpad
+    ntile = (D + 127) // 128
+    executed = 2.0 * (ntile * (ntile + 1) // 2) * 2.0 * 128 * 128 * kpad      # both branches, upper-triangular tiles
+    nominal = 2.0 * 2.0 * Bg * D * D                                          # 2 B D^2 per branch (vicreg.py:47-48)
+    achieved = executed / (gram_ms * 1e-3) / 1e12
+    result = {
+        "metric": "VICReg.loss forward+backward, embeddings [B, 8192] per GPU (BASELINE configs[2]; N>1: configs[3] with "
+                  "the FullGatherLayer all-gather / reduce-scatter over RCCL)",
+        "value": round(world * B * args.steps / elapsed, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "ms_per_step_min": round(regions[0] / args.steps * 1e3, 4), "timed_regions": len(regions),
+        "timed_region_s": round(elapsed, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 MFMA Gram (fp32 centring and accumulation), fp32 elsewhere", "data": "synthetic",
+        "config": {"workload": f"VICReg.loss fwd+bwd, x, y = randn({B}, {D}) per rank, global batch {Bg}",
+                   "batch_per_gpu": B, "embeddim": D, "launch": launch, "gather": gather,
+                   "collective": "all_gather_into_tensor fwd + reduce_scatter_tensor bwd (RCCL)" if gather else None,
+                   "rccl_world_size": dist.get_world_size() if gather else 1,
+                   "loss": out[0], "repr_loss": out[1], "std_loss": out[2], "cov_loss": out[3]},
+        "roofline": {"kernel": "vicreg_gram_strip_kernel" if kpad == 128 else "vicreg_gram_kernel (x2 branches)",
+                     "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                     "avg_launch_ms": round(gram_ms, 4), "flops_executed": executed, "flops_nominal_2BD2_per_branch_x2": nominal,
+                     "frac_nominal": round(nominal / (gram_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "measured": "HIP events around K back-to-back launches of stage 1 (the Gram) on the global batch"},
+    }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = vicreg_cpu_baseline(B, D)
+    return result
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -134,7 +308,16 @@ def main():
     from inverse_audio_synthesis_amd.voice import SynthConfig, Voice
     _lib.load()
 
-    B = args.batch
+    if args.workload == "vicreg":
+        result = run_vicreg(args, rank, world, dev)
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    B = args.batch or BATCH
     cfg = SynthConfig(batch_size=B, sample_rate=SAMPLE_RATE, buffer_size_seconds=SECONDS, reproducible=False)
     T = cfg.buffer_size
     voice = Voice(cfg).to(dev)

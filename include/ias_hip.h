@@ -191,6 +191,19 @@ long long ias_vicreg_colstats_offset(int B, int D);
 int ias_vicreg_loss(const float* x, const float* y, float* out, void* workspace, long long workspace_bytes,
                     int B, int D, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff, void* stream);
 
+/* Backward of ias_vicreg_loss (the reference gets it from autograd through vicreg.py:35-58): gcoef [4] device floats,
+ * the cotangents of (loss, repr_loss, std_loss, cov_loss) -> gx, gy [B,D] fp32.  Same workspace as the forward call,
+ * untouched in between (it holds the column statistics and the centred bf16 copies); D % 8 == 0.  Closed form with
+ * the B x B Gram (never a D x D matrix); both matrix products on the bf16 matrix cores, fp32 accumulate. */
+int ias_vicreg_backward(const float* x, const float* y, const float* gcoef, float* gx, float* gy, void* workspace,
+                        long long workspace_bytes, int B, int D, int cfg_batch, float sim_coeff, float std_coeff,
+                        float cov_coeff, void* stream);
+
+/* One stage of ias_vicreg_loss on the same workspace: 0 column pass, 1 the Gram kernel(s) on the matrix cores,
+ * 2 the final reduction (stage < 0: all of them = ias_vicreg_loss).  Lets a caller time the Gram alone. */
+int ias_vicreg_stage(int stage, const float* x, const float* y, float* out, void* workspace, long long workspace_bytes,
+                     int B, int D, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,8 @@ SYMBOLS = {
     "ias_vicreg_workspace_bytes": (_LL, [_I, _I]),
     "ias_vicreg_colstats_offset": (_LL, [_I, _I]),
     "ias_vicreg_loss": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
+    "ias_vicreg_backward": (_I, [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
+    "ias_vicreg_stage": (_I, [_I, _P, _P, _P, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
 }
 
 _lib = None

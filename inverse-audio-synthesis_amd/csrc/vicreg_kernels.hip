@@ -39,7 +39,8 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
     const float* __restrict__ x, const float* __restrict__ y, unsigned short* __restrict__ Xt_x,
     unsigned short* __restrict__ Xt_y, float* __restrict__ colstats, double* __restrict__ msepart,
-    double* __restrict__ hingepart, int B, int D, int Kpad) {
+    double* __restrict__ hingepart, unsigned short* __restrict__ Xc_x, unsigned short* __restrict__ Xc_y, int B, int D,
+    int Kpad) {
   __shared__ float s_red[4][VC_THREADS / 64][VC_COLS];
   __shared__ float s_mean[2][VC_COLS];
   __shared__ unsigned short s_tile[2][VC_COLS][64 + 2];
@@ -89,8 +90,11 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
         qx = fmaf(cx, cx, qx);
         qy = fmaf(cy, cy, qy);
       }
-      s_tile[0][lane][r] = f2bf(cx);
-      s_tile[1][lane][r] = f2bf(cy);
+      const unsigned short bx = f2bf(cx), by = f2bf(cy);
+      s_tile[0][lane][r] = bx;
+      s_tile[1][lane][r] = by;
+      // the same values batch-major, Xc[Kpad][D] (zero rows beyond B): the backward's B x B Gram contracts over D
+      if (jok) { Xc_x[(size_t)b * D + j] = bx; Xc_y[(size_t)b * D + j] = by; }
     }
     __syncthreads();
     // write out: 64 columns x 64 k as 128-byte rows; thread -> (column c = tid/4, 16 k values)
@@ -378,11 +382,10 @@ __global__ __launch_bounds__(256) void vicreg_finish_kernel(const double* __rest
 
 // ------------------------------------------------------------------------ C ABI
 static inline size_t vc_align(size_t x) { return (x + 255) / 256 * 256; }
-struct VicregWs { size_t xt_x, xt_y, colstats, mse, hinge, gram_x, gram_y, total; int Kpad, ntile, ngram, nmse; };
+struct VicregWs { size_t xt_x, xt_y, colstats, mse, hinge, gram_x, gram_y, xc_x, xc_y, bgram, total; int Kpad, ntile, ngram, nmse; };
 static VicregWs vicreg_ws(int B, int D) {
   VicregWs w;
-  w.Kpad = (B + GK - 1) / GK * GK;
-  if (w.Kpad == 64) w.Kpad = 128;   // the strip kernel's depth (zero padded)
+  w.Kpad = (B + GT - 1) / GT * GT;   // multiple of 128: the strip kernel's depth, the backward's batch tiles (zero padded)
   w.ntile = (D + GT - 1) / GT;
   w.ngram = w.ntile * (w.ntile + 1) / 2;
   w.nmse = (D + VC_COLS - 1) / VC_COLS;
@@ -394,6 +397,10 @@ static VicregWs vicreg_ws(int B, int D) {
   w.hinge = o;    o = vc_align(o + sizeof(double) * w.nmse);
   w.gram_x = o;   o = vc_align(o + sizeof(double) * w.ngram);
   w.gram_y = o;   o = vc_align(o + sizeof(double) * w.ngram);
+  // backward: centred bf16 copies batch-major [Kpad][D], and the two B x B Grams [2][Kpad][Kpad] fp32
+  w.xc_x = o;     o = vc_align(o + sizeof(unsigned short) * (size_t)D * w.Kpad);
+  w.xc_y = o;     o = vc_align(o + sizeof(unsigned short) * (size_t)D * w.Kpad);
+  w.bgram = o;    o = vc_align(o + sizeof(float) * 2 * (size_t)w.Kpad * w.Kpad);
   w.total = o;
   return w;
 }
@@ -406,11 +413,14 @@ extern "C" long long ias_vicreg_workspace_bytes(int B, int D) {
 // x, y [B,D] fp32 -> out[4] = (loss, repr_loss, std_loss, cov_loss).  cfg_batch = the configured batch
 // size whose (cfg_batch - 1) divides the covariance (vicreg.py:47-48).  After the call the workspace
 // holds colstats [4][D] (mean_x, mean_y, centred sum of squares x / y) at ias_vicreg_colstats_offset().
-extern "C" int ias_vicreg_loss(const float* x, const float* y, float* out, void* workspace, long long workspace_bytes,
-                               int B, int D, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff,
-                               void* stream_) {
+// stage < 0: the whole loss; 0: column pass (means, centred bf16 transposes, MSE / hinge partials); 1: the Gram
+// kernel(s) on the matrix cores; 2: the final reduction.  Stages run on a workspace the earlier stages have filled
+// (bench.py times stage 1 alone with HIP events for the MFMA roofline).
+extern "C" int ias_vicreg_stage(int stage, const float* x, const float* y, float* out, void* workspace,
+                                long long workspace_bytes, int B, int D, int cfg_batch, float sim_coeff, float std_coeff,
+                                float cov_coeff, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!x || !y || !out || !workspace || B < 2 || D < 1 || cfg_batch < 2) return IAS_ERR_ARG;
+  if (!x || !y || !out || !workspace || B < 2 || D < 1 || cfg_batch < 2 || stage > 2) return IAS_ERR_ARG;
   const VicregWs w = vicreg_ws(B, D);
   if ((size_t)workspace_bytes < w.total) return IAS_ERR_WORKSPACE;
   char* ws = (char*)workspace;
@@ -421,22 +431,247 @@ extern "C" int ias_vicreg_loss(const float* x, const float* y, float* out, void*
   double* hinge = (double*)(ws + w.hinge);
   double* gram_x = (double*)(ws + w.gram_x);
   double* gram_y = (double*)(ws + w.gram_y);
-  hipLaunchKernelGGL(vicreg_colstats_kernel, dim3(w.nmse), dim3(VC_THREADS), 0, stream, x, y, xt_x, xt_y, colstats,
-                     mse, hinge, B, D, w.Kpad);
+  if (stage < 0 || stage == 0)
+    hipLaunchKernelGGL(vicreg_colstats_kernel, dim3(w.nmse), dim3(VC_THREADS), 0, stream, x, y, xt_x, xt_y, colstats,
+                       mse, hinge, (unsigned short*)(ws + w.xc_x), (unsigned short*)(ws + w.xc_y), B, D, w.Kpad);
   int ngram = w.ngram;
+  int nitems = 0;
   if (w.Kpad == 128) {
     // strip kernel: items (ti, group of GS column tiles), both branches in one launch
-    int nitems = 0;
     for (int ti = 0; ti < w.ntile; ++ti) nitems += (w.ntile - ti + GS - 1) / GS;
-    hipLaunchKernelGGL(vicreg_gram_strip_kernel, dim3(2 * nitems), dim3(256), 0, stream, xt_x, xt_y, gram_x, gram_y, D,
-                       w.ntile, nitems);
     ngram = nitems;
-  } else {
-    hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_x, gram_x, D, w.Kpad, w.ntile);
-    hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_y, gram_y, D, w.Kpad, w.ntile);
   }
-  hipLaunchKernelGGL(vicreg_finish_kernel, dim3(1), dim3(256), 0, stream, hinge, mse, w.nmse, gram_x, gram_y,
-                     ngram, B, D, cfg_batch, sim_coeff, std_coeff, cov_coeff, out);
+  if (stage < 0 || stage == 1) {
+    if (w.Kpad == 128) {
+      hipLaunchKernelGGL(vicreg_gram_strip_kernel, dim3(2 * nitems), dim3(256), 0, stream, xt_x, xt_y, gram_x, gram_y, D,
+                         w.ntile, nitems);
+    } else {
+      hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_x, gram_x, D, w.Kpad, w.ntile);
+      hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_y, gram_y, D, w.Kpad, w.ntile);
+    }
+  }
+  if (stage < 0 || stage == 2)
+    hipLaunchKernelGGL(vicreg_finish_kernel, dim3(1), dim3(256), 0, stream, hinge, mse, w.nmse, gram_x, gram_y,
+                       ngram, B, D, cfg_batch, sim_coeff, std_coeff, cov_coeff, out);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+extern "C" int ias_vicreg_loss(const float* x, const float* y, float* out, void* workspace, long long workspace_bytes,
+                               int B, int D, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff,
+                               void* stream_) {
+  return ias_vicreg_stage(-1, x, y, out, workspace, workspace_bytes, B, D, cfg_batch, sim_coeff, std_coeff, cov_coeff,
+                          stream_);
+}
+
+
+// ------------------------------------------------------------------------ backward
+// d loss / d x, d loss / d y of vicreg.py:35-58 in closed form, never forming a D x D matrix.  With vc = v - mean_b(v)
+// (v = x or y), m2_j = sum_b vc_bj^2, s_j = sqrt(m2_j / (B - 1) + 1e-4), G = vc vc^T (B x B), and the incoming
+// cotangents folded into a = g_loss sim + g_repr, b = g_loss std + g_std, c = g_loss cov + g_cov:
+//   grad_v = +-a 2 (x - y) / (B D)  -  b [s_j < 1] vc / (2 D (B - 1) s_j)  +  c kappa (G vc - vc m2_j),
+//   kappa = 4 / ((cfg_batch - 1)^2 D)          (the centring adjoint vanishes: every column of the sum is zero-mean)
+// Kernels: vicreg_bgram_kernel  G = Xc Xc^T on the matrix cores (bf16 in, fp32 accumulate), split over D, fp32 atomics;
+//          vicreg_grad_kernel   G vc as a second bf16 MFMA product (A = G cast to bf16, B = Xt) for x and y at once,
+//                               epilogue adds the elementwise terms from x, y and the column statistics, writes gx, gy.
+#define BG_SPLIT_K 512    // features per vicreg_bgram_kernel workgroup
+
+__global__ __launch_bounds__(256) void vicreg_bgram_kernel(const unsigned short* __restrict__ Xc_x,
+                                                           const unsigned short* __restrict__ Xc_y, float* __restrict__ G,
+                                                           int D, int Kpad, int ntile) {
+  __shared__ __attribute__((aligned(16))) unsigned short s_a[GT][GLD];
+  __shared__ __attribute__((aligned(16))) unsigned short s_b[GT][GLD];
+  int t = blockIdx.x, ti = 0;
+  {
+    int rowlen = ntile;
+    while (t >= rowlen) { t -= rowlen; --rowlen; ++ti; }
+  }
+  const int tj = ti + t;
+  const int branch = blockIdx.z;
+  const unsigned short* Xc = branch ? Xc_y : Xc_x;
+  float* Gb = G + (size_t)branch * Kpad * Kpad;
+  const int kbeg = blockIdx.y * BG_SPLIT_K, kend = min(kbeg + BG_SPLIT_K, D);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int row0 = ti * GT, col0 = tj * GT;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (tid >> 3) + 32 * i, ch = tid & 7;
+      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+      if (k0 + ch * 8 + 8 <= D) {     // D % 8 == 0 is checked on the host
+        va = *reinterpret_cast<const uint4*>(Xc + (size_t)(row0 + rr) * D + k0 + ch * 8);
+        vb = *reinterpret_cast<const uint4*>(Xc + (size_t)(col0 + rr) * D + k0 + ch * 8);
+      }
+      *reinterpret_cast<uint4*>(&s_a[rr][ch * 8]) = va;
+      *reinterpret_cast<uint4*>(&s_b[rr][ch * 8]) = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < GK / 16; ++ks) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        fa[m] = *reinterpret_cast<const bf16x8*>(&s_a[wr * 64 + m * 32 + r][ks * 16 + h * 8]);
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        fb[n] = *reinterpret_cast<const bf16x8*>(&s_b[wc * 64 + n * 32 + r][ks * 16 + h * 8]);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // accumulate the partial tile (and its mirror image for tiles above the diagonal)
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = row0 + wr * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int col = col0 + wc * 64 + n * 32 + r;
+        atomicAdd(Gb + (size_t)row * Kpad + col, acc[m][n][e]);
+        if (ti != tj) atomicAdd(Gb + (size_t)col * Kpad + row, acc[m][n][e]);
+      }
+}
+
+// One 128 (batch rows) x 128 (features) tile of gx and gy per workgroup.
+__global__ __launch_bounds__(256) void vicreg_grad_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const unsigned short* __restrict__ Xt_x,
+    const unsigned short* __restrict__ Xt_y, const float* __restrict__ G, const float* __restrict__ colstats,
+    const float* __restrict__ gcoef /* g_loss, g_repr, g_std, g_cov */, float* __restrict__ gx, float* __restrict__ gy,
+    int B, int D, int Kpad, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff) {
+  __shared__ __attribute__((aligned(16))) unsigned short s_a[2][GT][GLD];   // G rows (bf16), per branch
+  __shared__ __attribute__((aligned(16))) unsigned short s_b[2][GT][GLD];   // Xt rows (features), per branch
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int col0 = blockIdx.x * GT, row0 = blockIdx.y * GT;
+  const float gl = gcoef[0];
+  const float ca = gl * sim_coeff + gcoef[1], cb = gl * std_coeff + gcoef[2], cc = gl * cov_coeff + gcoef[3];
+  const float kappa = 4.0f / ((float)(cfg_batch - 1) * (float)(cfg_batch - 1) * (float)D);
+
+  f32x16 acc[2][2][2];   // [branch][m][n]
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][m][n][e] = 0.f;
+
+  for (int k0 = 0; k0 < Kpad; k0 += GK) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float* Gb = G + (size_t)q * Kpad * Kpad;
+      const unsigned short* Xt = q ? Xt_y : Xt_x;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rr = (tid >> 3) + 32 * i, ch = tid & 7;
+        // A: G[row0 + rr][k0 + 8 ch ..] fp32 -> bf16
+        const float4 g0 = *reinterpret_cast<const float4*>(Gb + (size_t)(row0 + rr) * Kpad + k0 + ch * 8);
+        const float4 g1 = *reinterpret_cast<const float4*>(Gb + (size_t)(row0 + rr) * Kpad + k0 + ch * 8 + 4);
+        // the diagonal of G is 10-100x its off-diagonal entries and would carry its bf16 rounding (2^-9) straight
+        // into the dominant term G_bb vc_bj: it is left out of the matrix product and added in fp32 by the epilogue
+        float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const int dd = (row0 + rr) - (k0 + ch * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (i == dd) gv[i] = 0.0f;
+        uint4 va;
+        va.x = (unsigned)f2bf(gv[0]) | ((unsigned)f2bf(gv[1]) << 16);
+        va.y = (unsigned)f2bf(gv[2]) | ((unsigned)f2bf(gv[3]) << 16);
+        va.z = (unsigned)f2bf(gv[4]) | ((unsigned)f2bf(gv[5]) << 16);
+        va.w = (unsigned)f2bf(gv[6]) | ((unsigned)f2bf(gv[7]) << 16);
+        *reinterpret_cast<uint4*>(&s_a[q][rr][ch * 8]) = va;
+        uint4 vb = make_uint4(0, 0, 0, 0);
+        if (col0 + rr < D) vb = *reinterpret_cast<const uint4*>(Xt + (size_t)(col0 + rr) * Kpad + k0 + ch * 8);
+        *reinterpret_cast<uint4*>(&s_b[q][rr][ch * 8]) = vb;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int ks = 0; ks < GK / 16; ++ks) {
+        bf16x8 fa[2], fb[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          fa[m] = *reinterpret_cast<const bf16x8*>(&s_a[q][wr * 64 + m * 32 + r][ks * 16 + h * 8]);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          fb[n] = *reinterpret_cast<const bf16x8*>(&s_b[q][wc * 64 + n * 32 + r][ks * 16 + h * 8]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[q][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[q][m][n], 0, 0, 0);
+      }
+    __syncthreads();
+  }
+
+  // epilogue: elementwise terms.  C layout of a 32 x 32 block: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+  const float inv_bm1 = 1.0f / (float)(B - 1);
+  const float repr_k = ca * 2.0f / ((float)B * (float)D);
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int j = col0 + wc * 64 + n * 32 + r;
+    if (j >= D) continue;
+    const float mx = colstats[j], my = colstats[(size_t)D + j];
+    const float m2x = colstats[2 * (size_t)D + j], m2y = colstats[3 * (size_t)D + j];
+    const float sx = sqrtf(m2x * inv_bm1 + 0.0001f), sy = sqrtf(m2y * inv_bm1 + 0.0001f);
+    // coefficient of vc: variance hinge (active where s < 1) and the diagonal part of the covariance term
+    const float ax = (sx < 1.0f ? -cb / (2.0f * (float)D * (float)(B - 1) * sx) : 0.0f) - cc * kappa * m2x;
+    const float ay = (sy < 1.0f ? -cb / (2.0f * (float)D * (float)(B - 1) * sy) : 0.0f) - cc * kappa * m2y;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int b = row0 + wr * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (b >= B) continue;
+        const size_t idx = (size_t)b * D + j;
+        const float xv = x[idx], yv = y[idx];
+        const float dr = repr_k * (xv - yv);
+        const float gbx = G[(size_t)b * Kpad + b], gby = G[(size_t)Kpad * Kpad + (size_t)b * Kpad + b];   // G_bb, fp32
+        const float vx = xv - mx, vy = yv - my;
+        gx[idx] = dr + ax * vx + cc * kappa * (acc[0][m][n][e] + gbx * vx);
+        gy[idx] = -dr + ay * vy + cc * kappa * (acc[1][m][n][e] + gby * vy);
+      }
+  }
+}
+
+// Backward of ias_vicreg_loss on the SAME workspace (it must still hold the forward's column statistics and centred
+// bf16 copies): gcoef [4] device floats = the cotangents of (loss, repr_loss, std_loss, cov_loss) -> gx, gy [B,D] fp32.
+extern "C" int ias_vicreg_backward(const float* x, const float* y, const float* gcoef, float* gx, float* gy, void* workspace,
+                                   long long workspace_bytes, int B, int D, int cfg_batch, float sim_coeff, float std_coeff,
+                                   float cov_coeff, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !y || !gcoef || !gx || !gy || !workspace || B < 2 || D < 8 || (D & 7) || cfg_batch < 2) return IAS_ERR_ARG;
+  const VicregWs w = vicreg_ws(B, D);
+  if ((size_t)workspace_bytes < w.total) return IAS_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  float* G = (float*)(ws + w.bgram);
+  if (hipMemsetAsync(G, 0, sizeof(float) * 2 * (size_t)w.Kpad * w.Kpad, stream) != hipSuccess) return IAS_ERR_LAUNCH;
+  const int bt = w.Kpad / GT;                       // Kpad is a multiple of 128 whenever it exceeds 64... see below
+  if (w.Kpad % GT) return IAS_ERR_UNSUPPORTED;
+  const int npair = bt * (bt + 1) / 2, nsplit = (D + BG_SPLIT_K - 1) / BG_SPLIT_K;
+  hipLaunchKernelGGL(vicreg_bgram_kernel, dim3(npair, nsplit, 2), dim3(256), 0, stream, (const unsigned short*)(ws + w.xc_x),
+                     (const unsigned short*)(ws + w.xc_y), G, D, w.Kpad, bt);
+  hipLaunchKernelGGL(vicreg_grad_kernel, dim3((D + GT - 1) / GT, bt), dim3(256), 0, stream, x, y,
+                     (const unsigned short*)(ws + w.xt_x), (const unsigned short*)(ws + w.xt_y), G,
+                     (const float*)(ws + w.colstats), gcoef, gx, gy, B, D, w.Kpad, cfg_batch, sim_coeff, std_coeff, cov_coeff);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 

@@ -7,9 +7,9 @@ Same public names and contracts: ``VICReg(cfg, backbone_audio, backbone_param)``
 imported -- here it works, over RCCL), ``exclude_bias_and_norm`` (:98-99).
 
 The loss forward is the HIP path (csrc/vicreg_kernels.hip: fp32 column statistics, bf16 MFMA Gram with
-fp32 accumulation, fused off-diagonal square-sum).  The backward is closed-form fp32 on the device and
-uses the B x B Gram identity  d cov_loss / d xc = 4/((Bc-1)^2 D) * ((xc xc^T) xc - xc diag(xc^T xc)),
-so no D x D matrix is ever materialised in either direction.
+fp32 accumulation, fused off-diagonal square-sum).  The backward is HIP as well (ias_vicreg_backward): closed form
+with the B x B Gram identity  d cov_loss / d xc = 4/((Bc-1)^2 D) * ((xc xc^T) xc - xc diag(xc^T xc)) -- both
+products on the matrix cores, one elementwise epilogue -- so no D x D matrix is ever materialised in either direction.
 """
 import torch
 import torch.distributed as dist
@@ -34,32 +34,45 @@ class _VICRegLossFn(torch.autograd.Function):
         st = lib.ias_vicreg_loss(_lib.ptr(xc), _lib.ptr(yc), _lib.ptr(out), _lib.ptr(ws), ws.numel(), B, D,
                                  int(cfg_batch), float(sim_coeff), float(std_coeff), float(cov_coeff), _lib.stream())
         _lib.check(st, "ias_vicreg_loss")
-        ctx.save_for_backward(xc, yc)
+        ctx.save_for_backward(xc, yc, ws)     # the workspace keeps the column statistics / centred bf16 copies
         ctx.consts = (int(cfg_batch), float(sim_coeff), float(std_coeff), float(cov_coeff))
         return out[0], out[1], out[2], out[3]
 
     @staticmethod
     def backward(ctx, g_loss, g_repr, g_std, g_cov):
-        x, y = ctx.saved_tensors
+        x, y, ws = ctx.saved_tensors
         cfg_batch, sim, std, cov = ctx.consts
         B, D = x.shape
-        a = g_loss * sim + g_repr
-        b = g_loss * std + g_std
-        c = g_loss * cov + g_cov
-        d_repr = (x - y) * (2.0 / (B * D))
-
-        def branch(v):
-            vc = v - v.mean(dim=0)
-            m2 = (vc * vc).sum(dim=0)
-            s = torch.sqrt(m2 / (B - 1) + 0.0001)
-            d_std = -(s < 1).to(v.dtype) / (2.0 * D * (B - 1) * s) * vc
-            gram = vc @ vc.T
-            d_cov = (gram @ vc - vc * m2) * (4.0 / ((cfg_batch - 1) ** 2 * D))
-            return b * d_std + c * d_cov
-
-        gx = a * d_repr + branch(x)
-        gy = -a * d_repr + branch(y)
+        lib = _lib.load()
+        gcoef = torch.stack([g.to(torch.float32).reshape(()) for g in (g_loss, g_repr, g_std, g_cov)])
+        if D % 8 != 0:
+            return _vicreg_backward_torch(x, y, gcoef, cfg_batch, sim, std, cov) + (None, None, None, None)
+        gx, gy = torch.empty_like(x), torch.empty_like(y)
+        st = lib.ias_vicreg_backward(_lib.ptr(x), _lib.ptr(y), _lib.ptr(gcoef), _lib.ptr(gx), _lib.ptr(gy), _lib.ptr(ws),
+                                     ws.numel(), B, D, cfg_batch, sim, std, cov, _lib.stream())
+        _lib.check(st, "ias_vicreg_backward")
         return gx, gy, None, None, None, None
+
+
+def _vicreg_backward_torch(x, y, gcoef, cfg_batch, sim, std, cov):
+    """The same closed form as plain fp32 device ops (embedding widths that are not a multiple of 8; also the
+    definition the HIP backward is tested against besides autograd through the oracle)."""
+    B, D = x.shape
+    a = gcoef[0] * sim + gcoef[1]
+    b = gcoef[0] * std + gcoef[2]
+    c = gcoef[0] * cov + gcoef[3]
+    d_repr = (x - y) * (2.0 / (B * D))
+
+    def branch(v):
+        vc = v - v.mean(dim=0)
+        m2 = (vc * vc).sum(dim=0)
+        s = torch.sqrt(m2 / (B - 1) + 0.0001)
+        d_std = -(s < 1).to(v.dtype) / (2.0 * D * (B - 1) * s) * vc
+        gram = vc @ vc.T
+        d_cov = (gram @ vc - vc * m2) * (4.0 / ((cfg_batch - 1) ** 2 * D))
+        return b * d_std + c * d_cov
+
+    return a * d_repr + branch(x), -a * d_repr + branch(y)
 
 
 def vicreg_loss(x, y, cfg_batch_size, sim_coeff=25.0, std_coeff=25.0, cov_coeff=1.0):

@@ -2,7 +2,9 @@
 
 Tolerances: repr/std losses are fp32 reductions (1e-5 rel).  cov_loss comes from a bf16 MFMA Gram with
 fp32 accumulation (north_star names bf16; it states no bar): measured error is ~1e-4 relative, asserted
-at 2e-3.  The backward is fp32 closed form: compared with autograd through the oracle at 1e-4."""
+at 2e-3.  The backward is the HIP closed form with both products on the bf16 matrix cores (fp32 accumulate): compared
+with autograd through the oracle, asserted at 2e-3 of the largest gradient element (measured values are printed), and
+with the same closed form evaluated in fp32 torch ops."""
 import os
 import types
 
@@ -47,9 +49,12 @@ def test_loss_ragged_shapes(lib, dev, B, D):
     assert abs(out[0] - ref[0]) <= COV_RTOL * abs(ref[0])
 
 
-def test_backward_matches_autograd_of_oracle(lib, dev):
+GRAD_RTOL = 2e-3   # of the largest gradient element (bf16 operands, fp32 accumulation)
+
+
+@pytest.mark.parametrize("B,D,cfgB", [(32, 256, 48), (128, 1024, 128), (200, 512, 200), (17, 136, 17)])
+def test_backward_matches_autograd_of_oracle(lib, dev, B, D, cfgB):
     from inverse_audio_synthesis_amd.vicreg import vicreg_loss
-    B, D, cfgB = 32, 256, 48
     x0, y0 = randn((B, D), 5) * 0.8, randn((B, D), 6) * 1.1 + 0.3   # std < 1 and > 1 columns both occur
     xr, yr = x0.clone().requires_grad_(), y0.clone().requires_grad_()
     ref = vo.loss(xr, yr, cfgB, D)
@@ -58,7 +63,34 @@ def test_backward_matches_autograd_of_oracle(lib, dev):
     out = vicreg_loss(xg, yg, cfgB)
     (out[0] + 0.5 * out[1] - 2.0 * out[2] + 3.0 * out[3]).backward()
     for got, want in ((xg.grad.cpu(), xr.grad), (yg.grad.cpu(), yr.grad)):
-        assert (got - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+        err = (got - want).abs().max().item() / want.abs().max().item()
+        print(f"[vicreg backward B={B} D={D}] max|err|/max|g| = {err:.2e}")
+        assert err <= GRAD_RTOL
+
+
+def test_backward_full_size_vs_fp32_closed_form(lib, dev):
+    """BASELINE configs[2] / [3] shapes (128 and 1024 x 8192): the HIP backward against the same closed form in fp32
+    device ops (the round-1 backward, itself 1e-4 from autograd through the oracle), and, for B = 128, against
+    autograd through the CPU oracle."""
+    from inverse_audio_synthesis_amd.vicreg import vicreg_loss, _vicreg_backward_torch
+    for B in (128, 1024):
+        g = torch.Generator(device="cpu").manual_seed(B)
+        x0 = torch.randn((B, 8192), generator=g) * 0.9
+        y0 = torch.randn((B, 8192), generator=g) * 1.1 + 0.2
+        xg, yg = x0.to(dev).requires_grad_(), y0.to(dev).requires_grad_()
+        out = vicreg_loss(xg, yg, B)
+        out[0].backward()
+        gcoef = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev)
+        rx, ry = _vicreg_backward_torch(xg.detach(), yg.detach(), gcoef, B, 25.0, 25.0, 1.0)
+        for got, want in ((xg.grad, rx), (yg.grad, ry)):
+            err = (got - want).abs().max().item() / want.abs().max().item()
+            print(f"[vicreg backward B={B} D=8192 vs fp32 closed form] max|err|/max|g| = {err:.2e}")
+            assert err <= GRAD_RTOL
+        if B == 128:
+            xr, yr = x0.clone().requires_grad_(), y0.clone().requires_grad_()
+            vo.loss(xr, yr, B, 8192)[0].backward()
+            for got, want in ((xg.grad.cpu(), xr.grad), (yg.grad.cpu(), yr.grad)):
+                assert (got - want).abs().max().item() <= GRAD_RTOL * want.abs().max().item()
 
 
 def test_module_api_and_offdiagonal(lib, dev, golden_dir):
