@@ -286,6 +286,96 @@ def run_vicreg(args, rank, world, dev):
     return result
 
 
+def run_gradstep(args, rank, world, dev):
+    """BASELINE configs[4], one GPU's share (global batch 512 / 8): params -> Voice render -> {3-resolution MR-STFT loss,
+    64-band PQMF sub-band L1} -> gradient w.r.t. the 78 normalised parameters, all HIP (render and its backward,
+    spectral_kernels / spectral_grad_kernels, wide PQMF analysis and its adjoint).  Batch-split, no data-path collective."""
+    from inverse_audio_synthesis_amd.pqmf import PQMF
+    from inverse_audio_synthesis_amd.spectral import MultiResolutionSTFTLoss, SubbandL1
+    from inverse_audio_synthesis_amd.voice import SynthConfig, Voice
+    B = args.batch or 64
+    cfg = SynthConfig(batch_size=B, sample_rate=SAMPLE_RATE, buffer_size_seconds=SECONDS, reproducible=False)
+    T = cfg.buffer_size
+    voice = Voice(cfg).to(dev)
+    gram = PQMF(N=64).to(dev)
+    mr = MultiResolutionSTFTLoss().to(dev)
+    sub = SubbandL1(gram)
+    params = torch.rand(B, 78, generator=torch.Generator().manual_seed(1000 + rank)).to(dev).requires_grad_(True)
+    tgt = voice.render(torch.rand(B, 78, generator=torch.Generator().manual_seed(2000 + rank)).to(dev)).clone()
+    tb, tm = sub.target(tgt), mr.target(tgt)
+    state = {}
+
+    def step(ev=None):
+        if ev: ev[0].record()
+        a = voice.render(params)
+        if ev: ev[1].record()
+        loss = mr(a, targets=tm) + sub(a, target_bands=tb)
+        if ev: ev[2].record()
+        (g,) = torch.autograd.grad(loss, params)
+        if ev: ev[3].record()
+        state["loss"], state["g"] = loss.detach(), g
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    launch, graph = "eager", None
+    if not args.no_graph:
+        try:
+            state.clear()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(args.steps):
+                    step()
+            graph.replay()
+            torch.cuda.synchronize()
+            launch = "hipgraph"
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly\n")
+            graph = None
+            torch.cuda.synchronize()
+            step()
+
+    def region():
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(args.steps):
+                step()
+
+    regions = timed_regions(region, args, world, dev)
+    elapsed = regions[len(regions) // 2]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    step(ev)
+    torch.cuda.synchronize()
+    phases = [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
+    gnorm = float(state["g"].norm())
+    # algorithmic HBM bytes of the step per audio sample (SURVEY.md 8d): render 8 (noise in, audio out); PQMF analysis
+    # 8 (4 in + 4 out); each STFT resolution 4 in + 4 (n_fft/2+1)/hop target read; backward: the cotangent of the audio
+    # written and read once per loss (4 x 4 x 2), the render backward reads noise + cotangent (8)
+    bins = sum((n // 2 + 1) / h for n, h in ((1024, 120), (2048, 240), (512, 50)))
+    bytes_per_sample = 8 + 8 + 3 * 4 + 4 * bins + 32 + 8
+    algo = bytes_per_sample * B * T
+    ms = elapsed / args.steps * 1e3
+    return {
+        "metric": "audio-seconds rendered+lossed+differentiated/sec, BASELINE configs[4] per-GPU share: 64-band PQMF + "
+                  "3-resolution STFT loss, forward + backward to the 78 parameters",
+        "value": round(world * B * SECONDS * args.steps / elapsed, 1), "unit": "audio-s/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+        "ms_per_step_min": round(regions[0] / args.steps * 1e3, 4), "timed_regions": len(regions),
+        "timed_region_s": round(elapsed, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[4] share: grad step, batch {B} x {SECONDS:g} s @ {SAMPLE_RATE} Hz per GPU, "
+                               "PQMF(64) sub-band L1 + MR-STFT (1024/2048/512)", "batch_per_gpu": B, "launch": launch,
+                   "loss": float(state["loss"]), "grad_norm": gnorm,
+                   "phase_ms_eager": {"render_forward": round(phases[0], 4), "losses_forward": round(phases[1], 4),
+                                      "backward": round(phases[2], 4)}},
+        "roofline": {"kernel": "whole gradient step (no single dominant kernel: ~20 launches)", "bound": "hbm",
+                     "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_step": int(algo), "bytes_per_sample": round(bytes_per_sample, 1)},
+    }
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -308,8 +398,8 @@ def main():
     from inverse_audio_synthesis_amd.voice import SynthConfig, Voice
     _lib.load()
 
-    if args.workload == "vicreg":
-        result = run_vicreg(args, rank, world, dev)
+    if args.workload in ("vicreg", "gradstep"):
+        result = (run_vicreg if args.workload == "vicreg" else run_gradstep)(args, rank, world, dev)
         if rank == 0:
             print(json.dumps(result), flush=True)
         if world > 1:

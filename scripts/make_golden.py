@@ -134,6 +134,30 @@ def main():
     pp = {"seed": np.array(104), "shape": np.array(img.shape), "sub": img.flatten()[::89].numpy(),
           "checks": checks(img)}
     np.savez_compressed(os.path.join(OUT, "audioembed_preprocess.npz"), **pp)
+    # (8) AudioRepresentationToParams (audio_to_params.py:16-53), eval() forward from a seeded state_dict.  The module
+    # audio_to_params.py itself cannot be imported here (its top-level imports need flash / lightning / torchsynth /
+    # wandb: ModuleNotFoundError), so only that class definition is taken from the reference file (parsed, compiled
+    # and executed in a namespace that provides torch.nn) -- the reference's own code computes the vectors.
+    import ast
+    tree = ast.parse(open(os.path.join(REF, "audio_to_params.py")).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "AudioRepresentationToParams"]
+    ns = {"nn": torch.nn, "Tensor": torch.Tensor, "torch": torch}
+    exec(compile(ast.Module(body=cls, type_ignores=[]), "audio_to_params.py", "exec"), ns)
+    ar = {}
+    for norm in ("nn.BatchNorm1d", "nn.Identity"):
+        torch.manual_seed(11)
+        m = ns["AudioRepresentationToParams"](nparams=78, dim=40, hidden_norm=norm, dropout=0.1)
+        tag = "a2p_bn" if "Batch" in norm else "a2p_id"
+        if "Batch" in norm:     # non-trivial running statistics
+            m.train()
+            for i in range(3):
+                m(randn((16, 40), 20 + i) * (1.0 + 0.5 * i))
+        m.eval()
+        for k, v in m.state_dict().items():
+            ar[f"{tag}." + k] = v.numpy()
+        xin = randn((6, 40), 12)
+        ar[f"{tag}_in"], ar[f"{tag}_out"] = xin.numpy(), m(xin).detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "audio_repr_to_params.npz"), **ar)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
