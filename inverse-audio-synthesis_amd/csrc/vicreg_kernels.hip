@@ -349,6 +349,311 @@ __global__ __launch_bounds__(256, 2) void vicreg_gram_strip_kernel(const unsigne
   if (tid == 0) (branch ? part_y : part_x)[item] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
 }
 
+
+// ---- Gram for a contraction depth of 128 (batch <= 128, BASELINE configs[2]) -----------------------------------
+// At K = 128 a 128 x 128 tile is only 32 MFMAs per wave: what bounds the kernel is the panel traffic L2 -> LDS
+// (~30 B/clk per CU at best), not the matrix cores.  So a workgroup keeps a PAIR of row panels (256 rows x K = 128) in
+// registers as A fragments (128 VGPRs per lane) and streams the column panels past them: one 32 KB panel fetched feeds
+// 64 MFMAs per wave (two tiles), 16 B/clk at full matrix rate.  The panels come in by LDS-DMA (no VGPR staging) into a
+// ring of four 32 KB slots, requested three steps ahead; one raw s_barrier per step.  LDS image of a panel:
+// [128 rows][16 granules of 16 B], granule g of row r at slot g ^ (r & 15) -- conflict-free for the fragment reads
+// (16 consecutive rows, same granule) and lane-linear for the DMA once the SOURCE address is permuted the same way.
+// Tiles below the diagonal of a pair (2p+1, 2p) are computed and given weight 0 (1.5 % of the work).
+#define GP_RING 4
+#define GP_PANEL_BYTES (GT * 128 * 2)
+
+typedef __attribute__((address_space(3))) void gram_lds_void;
+typedef const __attribute__((address_space(1))) void gram_glb_void;
+
+// A step = one column panel tj streamed past the row-panel pair p of one branch, tj = 2p .. ntile-1.  A work item is a
+// run of at most GP_CH consecutive steps of ONE pair: (branch, p, chunk), enumerated branch-major, p-major.  One
+// workgroup per item (235 - 260 items at D = 8192: one resident round of one 128 KB-LDS workgroup per CU).
+#define GP_CH 10
+__device__ __forceinline__ void gp_item(int item, int ntile, int& p, int& c) {
+  p = 0;
+  for (;;) {
+    const int nc = (ntile - 2 * p + GP_CH - 1) / GP_CH;
+    if (item < nc) break;
+    item -= nc; ++p;
+  }
+  c = item;
+}
+static int gp_nitems(int ntile) {
+  int n = 0;
+  for (int p = 0; 2 * p < ntile; ++p) n += (ntile - 2 * p + GP_CH - 1) / GP_CH;
+  return n;
+}
+
+__device__ __forceinline__ void gp_lds_read_b128(bf16x8& dst, unsigned lds_addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_addr) : "memory");
+}
+// the wait that makes two asm-loaded fragments usable: they pass through it, so no consumer can be scheduled above it
+__device__ __forceinline__ void gp_lds_wait(bf16x8& a, bf16x8& b) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory");
+}
+
+#ifdef GP_STAMPS
+// Diagnostic build only (scripts/diag): s_memtime stamps of wave 0 of every workgroup, into a buffer of their own.
+__device__ unsigned long long* g_gp_stamps = nullptr;
+extern "C" int ias_vicreg_debug_set_stamps(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gp_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}
+#define GPSTAMP(i) do { if (g_gp_stamps && (threadIdx.x & 63) == 0) g_gp_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 32 + (i)] = __builtin_amdgcn_s_memtime(); if (g_gp_stamps && (threadIdx.x & 63) == 0 && (i) == 0) g_gp_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 32 + 31] = __builtin_amdgcn_s_getreg(6 << 11 | 4 << 6 | 4); } while (0)
+#else
+#define GPSTAMP(i) do {} while (0)
+#endif
+
+#define GP_THREADS 512      // 8 waves, two per SIMD: one wave's square-sum epilogue runs beside its partner's MFMAs
+__global__ __launch_bounds__(GP_THREADS, 2) void vicreg_gram_pair_kernel(const unsigned short* __restrict__ Xt_x,
+                                                                         const unsigned short* __restrict__ Xt_y,
+                                                                         double* __restrict__ part_x,
+                                                                         double* __restrict__ part_y, int D, int ntile,
+                                                                         int nitems) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_ring[];   // GP_RING x 32 KB
+  __shared__ double s_part[GP_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;       // wave tile: rows wr*64 .. +63 of the 256-row pair, columns wc*64 .. +63
+  const int r = lane & 31, h = lane >> 5;
+  // XCD-aware placement (speed only): consecutive block indices are dealt round-robin over the 8 XCDs, each with its own
+  // 4 MB L2.  Blocks with (blockIdx % 8) < 4 work on branch x, the others on branch y, so that an XCD's L2 has to hold
+  // only ONE of the two 2 MB matrices -- with both in every L2 a third of the panel requests missed it and the ring
+  // filled at the Infinity-Cache rate (measured: 1750 of every 3650 cycles per step spent waiting for the panel).
+  const int xslot = blockIdx.x & 7, branch = xslot >> 2;
+  const int item = (blockIdx.x >> 3) * 4 + (xslot & 3);
+  if (item >= nitems) return;
+  const unsigned short* Xt = branch ? Xt_y : Xt_x;
+  int p, c;
+  gp_item(item, ntile, p, c);
+  const int tj0 = 2 * p + c * GP_CH, nsteps = min(GP_CH, ntile - tj0);
+  const bool ragged = (D % GT) != 0;
+
+  // panel tj -> ring slot: 4 LDS-DMA instructions per wave (1 KB = 4 rows each); rows beyond D repeat row D - 1
+  // (as columns they are masked in the epilogue, as rows of A they are zeroed below)
+  auto request_piece = [&](int tj, int slot_i, int i) {
+    unsigned char* slot = s_ring + slot_i * GP_PANEL_BYTES;
+    const int row = wave * 16 + i * 4 + (lane >> 4);          // row of the panel this lane's 16 bytes belong to
+    const int g = (lane & 15) ^ (row & 15);                    // source granule for LDS slot (lane & 15)
+    int grow = tj * GT + row;
+    grow = grow < D ? grow : D - 1;
+    __builtin_amdgcn_global_load_lds((gram_glb_void*)(Xt + (size_t)grow * 128 + g * 8),
+                                     (gram_lds_void*)(slot + (wave * 16 + i * 4) * 256), 16, 0, 0);
+  };
+  auto request = [&](int tj, int slot_i) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) request_piece(tj, slot_i, i);
+  };
+
+  GPSTAMP(0);
+  // ---- the pair's own two panels -> ring slots 0, 1 -> A fragments in registers (they are never re-fetched per wave
+  // from global memory: 64 KB per workgroup instead of 16 KB x 8 waves x 2)
+  request(2 * p, 0);
+  request(min(2 * p + 1, ntile - 1), 1);
+  // the first two column panels go to slots 2 and 3 at once (step s uses slot (s + 2) % GP_RING): their latency runs
+  // beside the A setup instead of after it
+  int requested = 0;
+#ifndef GP_NO_LOAD
+  for (; requested < min(nsteps, 2); ++requested) request(tj0 + requested, (requested + 2) % GP_RING);
+#else
+  requested = min(nsteps, 2);
+#endif
+  if (requested == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (requested == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  bf16x8 fa[2][8];             // rows wr*64 + m*32 + r of the pair (panel q = wr >> 1), [m block][k step]
+  {
+    const int q = wr >> 1;
+    const unsigned char* slot = s_ring + q * GP_PANEL_BYTES;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int prow = (wr & 1) * 64 + m * 32 + r;               // row inside the panel
+      const bool ok = (2 * p + q < ntile) && ((2 * p + q) * GT + prow < D);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(slot + prow * 256 + (((ks * 2 + h) ^ (prow & 15)) << 4));
+        if (!ok) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = 0;
+        }
+        fa[m][ks] = v;
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();        // every wave has its fragments: the slots can be reused
+
+  GPSTAMP(1);
+  // ---- stream the column panels: requested GP_RING - 1 steps ahead, one barrier per step
+  const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)s_ring;
+#ifndef GP_NO_LOAD
+  if (requested < nsteps) { request(tj0 + requested, (requested + 2) % GP_RING); ++requested; }   // slot 0 is free now
+#else
+  if (requested < nsteps) ++requested;
+#endif
+  float tot = 0.f;
+  const int ti = 2 * p + (wr >> 1);    // the row panel this wave's rows belong to
+  const int rbase = (wr & 1) * 64;     // first row of this wave inside its row panel
+
+  // The square-sum epilogue of step s runs INSIDE the MFMA stream of step s + 1 (two accumulator sets, ping-pong): eight
+  // FMAs behind each group of four MFMAs, which the matrix pipe hides.  The per-step barrier starts both waves of a SIMD
+  // on their MFMAs together, so without this the pipe idles while both run their epilogues.
+  //   plain   : sum of squares of the previous tile's 64 values per lane (done inside the MFMA stream)
+  //   finish  : what is left for the previous tile after the stream: weights, the diagonal of a diagonal tile
+  //             (one element per lane and diagonal block), or the fully masked form for the last panel of a ragged D
+  auto finish_prev = [&](const f32x16 (&accP)[2][2], float ssP, int tjP) {
+    if (!(ti < ntile && tjP >= ti)) return;      // no such row panel / mirror image of a tile counted elsewhere
+    float ss = ssP;
+    if (ragged && tjP == ntile - 1) {
+      ss = 0.f;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int col = wc * 64 + n * 32 + r;
+          const bool col_ok = tjP * GT + col < D;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = rbase + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float v = accP[m][n][e];
+            if (col_ok && !(ti == tjP && row == col)) ss = fmaf(v, v, ss);
+          }
+        }
+    } else if (ti == tjP) {
+      // element (row, col) of block (m, n) lies on the diagonal iff rbase + m*32 + rowin == wc*64 + n*32 + r
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int rowin = wc * 64 + n * 32 + r - rbase - m * 32;   // row inside the 32 x 32 block, if in [0, 32)
+          const int t = rowin - 4 * h;                                // = (e & 3) + 8 (e >> 2) for the lane's element e
+          if (rowin >= 0 && rowin < 32 && t >= 0 && (t & 4) == 0) {
+            const int esel = (t & 3) + 4 * (t >> 3);
+            float v = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v = (e == esel) ? accP[m][n][e] : v;
+            ss = fmaf(-v, v, ss);
+          }
+        }
+    }
+    tot += (ti == tjP) ? ss : 2.0f * ss;
+  };
+
+  // one step: MFMAs of panel s into accC, plain square sums of accP (the previous step) in their shadow
+  auto step = [&](int s, f32x16 (&accC)[2][2], const f32x16 (&accP)[2][2], bool haveP) {
+    // this wave's loads of panel s have landed once at most the loads of the later panels requested so far are
+    // outstanding (vector memory operations retire in order); the barrier extends that to every wave's part and frees
+    // the slot of panel s - 1
+    const int later = requested - 1 - s;
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    GPSTAMP(2 + 2 * s);
+    // the next panel's four 1 KB pieces are issued one at a time between the groups of MFMAs below (as a burst right
+    // after the barrier, the 32 DMA instructions of the eight waves queue up in front of the matrix work)
+    const bool req = requested < nsteps;
+    const int req_tj = tj0 + requested, req_slot = (requested + 2) % GP_RING;
+    if (req) ++requested;
+
+    // B fragments by inline-asm ds_read_b128: through the compiler's own LDS loads every step would first drain ALL
+    // outstanding LDS-DMA (it cannot tell the slot being read from the slots being filled and inserts vmcnt(0)), which
+    // serialises the ring.  The reads of k step ks + 1 are issued before the MFMAs of step ks and waited for after them.
+    const unsigned slot_a = ring_lds + (unsigned)(((s + 2) % GP_RING) * GP_PANEL_BYTES);
+    bf16x8 fb[2][2];    // [ks & 1][n]
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int brow = wc * 64 + n * 32 + r;
+      gp_lds_read_b128(fb[0][n], slot_a + (unsigned)(brow * 256 + ((h ^ (brow & 15)) << 4)));
+    }
+    gp_lds_wait(fb[0][0], fb[0][1]);
+    float ssP = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks + 1 < 8) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int brow = wc * 64 + n * 32 + r;
+          gp_lds_read_b128(fb[(ks + 1) & 1][n], slot_a + (unsigned)(brow * 256 + ((((ks + 1) * 2 + h) ^ (brow & 15)) << 4)));
+        }
+      }
+#ifndef GP_NO_LOAD
+      if (req && (ks & 1) == 0) request_piece(req_tj, req_slot, ks >> 1);
+#endif
+      __builtin_amdgcn_sched_barrier(0);   // keep this k step's MFMAs between the issue of the next reads and their wait
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+#ifdef GP_NO_MFMA
+          accC[m][n][ks] = (float)fb[ks & 1][n][0] + (float)fa[m][ks][1];
+#else
+          if (ks == 0) {
+            f32x16 z;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] = 0.f;
+            accC[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][ks], fb[ks & 1][n], z, 0, 0, 0);
+          } else {
+            accC[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][ks], fb[ks & 1][n], accC[m][n], 0, 0, 0);
+          }
+#endif
+        }
+      // eight of the previous tile's 64 squares: block (ks >> 1), elements 8 (ks & 1) .. + 7
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = accP[(ks >> 2) & 1][(ks >> 1) & 1][8 * (ks & 1) + e];
+        ssP = fmaf(v, v, ssP);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < 8) gp_lds_wait(fb[(ks + 1) & 1][0], fb[(ks + 1) & 1][1]);
+    }
+    GPSTAMP(3 + 2 * s);
+    if (haveP) finish_prev(accP, ssP, tj0 + s - 1);
+  };
+
+  f32x16 acc0[2][2], acc1[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc0[m][n][e] = 0.f; acc1[m][n][e] = 0.f; }
+  int s = 0;
+  for (; s + 1 < nsteps; s += 2) {
+    step(s, acc0, acc1, s > 0);
+    step(s + 1, acc1, acc0, true);
+  }
+  if (s < nsteps) {
+    step(s, acc0, acc1, s > 0);
+    // the last tile's squares, not hidden behind anything
+    float ss = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ss = fmaf(acc0[m][n][e], acc0[m][n][e], ss);
+    finish_prev(acc0, ss, tj0 + nsteps - 1);
+  } else {
+    float ss = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ss = fmaf(acc1[m][n][e], acc1[m][n][e], ss);
+    finish_prev(acc1, ss, tj0 + nsteps - 1);
+  }
+  GPSTAMP(30);
+  for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
+  if (lane == 0) s_part[wave] = (double)tot;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < GP_THREADS / 64; ++w) t += s_part[w];
+    (branch ? part_y : part_x)[item] = t;
+  }
+}
+
 // out[0..3] = loss, repr_loss, std_loss, cov_loss (fp32)
 __global__ __launch_bounds__(256) void vicreg_finish_kernel(const double* __restrict__ hingepart,
                                                             const double* __restrict__ msepart, int nmse,
@@ -437,14 +742,15 @@ extern "C" int ias_vicreg_stage(int stage, const float* x, const float* y, float
   int ngram = w.ngram;
   int nitems = 0;
   if (w.Kpad == 128) {
-    // strip kernel: items (ti, group of GS column tiles), both branches in one launch
-    for (int ti = 0; ti < w.ntile; ++ti) nitems += (w.ntile - ti + GS - 1) / GS;
+    nitems = gp_nitems(w.ntile);       // pair kernel: one workgroup per (branch, row-panel pair, run of column panels)
     ngram = nitems;
   }
   if (stage < 0 || stage == 1) {
     if (w.Kpad == 128) {
-      hipLaunchKernelGGL(vicreg_gram_strip_kernel, dim3(2 * nitems), dim3(256), 0, stream, xt_x, xt_y, gram_x, gram_y, D,
-                         w.ntile, nitems);
+      const size_t lds = (size_t)GP_RING * GP_PANEL_BYTES;
+      (void)hipFuncSetAttribute((const void*)vicreg_gram_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(vicreg_gram_pair_kernel, dim3(8 * ((nitems + 3) / 4)), dim3(GP_THREADS), lds, stream, xt_x, xt_y,
+                         gram_x, gram_y, D, w.ntile, nitems);
     } else {
       hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_x, gram_x, D, w.Kpad, w.ntile);
       hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_y, gram_y, D, w.Kpad, w.ntile);
