@@ -140,14 +140,20 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
   }
 }
 
-// One upper-triangular 128x128 tile of C = Xt Xt^T per workgroup; partial[tile] = sum of squares of
-// the tile's off-diagonal elements (x2 for tiles above the diagonal).
-__global__ __launch_bounds__(256) void vicreg_gram_kernel(const unsigned short* __restrict__ Xt,
-                                                          double* __restrict__ partials, int D, int Kpad,
-                                                          int ntile) {
-  __shared__ __attribute__((aligned(16))) unsigned short s_a[GT][GLD];
-  __shared__ __attribute__((aligned(16))) unsigned short s_b[GT][GLD];
+// One upper-triangular 128x128 tile of C = Xt Xt^T per workgroup and branch (blockIdx.y); partial[tile] = sum of
+// squares of the tile's off-diagonal elements (x2 for tiles above the diagonal).  Any contraction depth (batch > 128:
+// BASELINE configs[3], global batch 1024).  The k loop is double-buffered: the next 64-deep chunk of both panels is
+// fetched into registers while the matrix cores work on the current one and written to the other LDS buffer afterwards
+// (one barrier per chunk).
+__global__ __launch_bounds__(256, 2) void vicreg_gram_kernel(const unsigned short* __restrict__ Xt_x,
+                                                             const unsigned short* __restrict__ Xt_y,
+                                                             double* __restrict__ part_x, double* __restrict__ part_y,
+                                                             int D, int Kpad, int ntile) {
+  __shared__ __attribute__((aligned(16))) unsigned short s_a[2][GT][GLD];
+  __shared__ __attribute__((aligned(16))) unsigned short s_b[2][GT][GLD];
   __shared__ double s_part[4];
+  const unsigned short* Xt = blockIdx.y ? Xt_y : Xt_x;
+  double* partials = blockIdx.y ? part_y : part_x;
   // linear upper-triangular index -> (ti, tj), ti <= tj
   int t = blockIdx.x, ti = 0;
   {
@@ -168,34 +174,50 @@ __global__ __launch_bounds__(256) void vicreg_gram_kernel(const unsigned short* 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
 
-  for (int k0 = 0; k0 < Kpad; k0 += GK) {
-    // stage A (rows row0..+127) and B (rows col0..+127): 128 rows x 128 B each, 16 B per thread x 4
+  // one 64-deep chunk of A (rows row0..+127) and B (rows col0..+127): 128 rows x 128 B each, 16 B per thread x 4
+  uint4 sta[4], stb[4];
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rr = (tid >> 3) + 32 * i, ch = tid & 7;
-      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
-      if (row0 + rr < D) va = *reinterpret_cast<const uint4*>(Xt + (size_t)(row0 + rr) * Kpad + k0 + ch * 8);
-      if (col0 + rr < D) vb = *reinterpret_cast<const uint4*>(Xt + (size_t)(col0 + rr) * Kpad + k0 + ch * 8);
-      *reinterpret_cast<uint4*>(&s_a[rr][ch * 8]) = va;
-      *reinterpret_cast<uint4*>(&s_b[rr][ch * 8]) = vb;
+      sta[i] = make_uint4(0, 0, 0, 0); stb[i] = make_uint4(0, 0, 0, 0);
+      if (row0 + rr < D) sta[i] = *reinterpret_cast<const uint4*>(Xt + (size_t)(row0 + rr) * Kpad + k0 + ch * 8);
+      if (col0 + rr < D) stb[i] = *reinterpret_cast<const uint4*>(Xt + (size_t)(col0 + rr) * Kpad + k0 + ch * 8);
     }
-    __syncthreads();
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (tid >> 3) + 32 * i, ch = tid & 7;
+      *reinterpret_cast<uint4*>(&s_a[buf][rr][ch * 8]) = sta[i];
+      *reinterpret_cast<uint4*>(&s_b[buf][rr][ch * 8]) = stb[i];
+    }
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < Kpad; k0 += GK) {
+    const bool more = k0 + GK < Kpad;
+    if (more) fetch(k0 + GK);              // in flight while the matrix cores work on this chunk
 #pragma unroll
     for (int ks = 0; ks < GK / 16; ++ks) {
       bf16x8 fa[2], fb[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
-        fa[m] = *reinterpret_cast<const bf16x8*>(&s_a[wr * 64 + m * 32 + r][ks * 16 + h * 8]);
+        fa[m] = *reinterpret_cast<const bf16x8*>(&s_a[buf][wr * 64 + m * 32 + r][ks * 16 + h * 8]);
 #pragma unroll
       for (int n = 0; n < 2; ++n)
-        fb[n] = *reinterpret_cast<const bf16x8*>(&s_b[wc * 64 + n * 32 + r][ks * 16 + h * 8]);
+        fb[n] = *reinterpret_cast<const bf16x8*>(&s_b[buf][wc * 64 + n * 32 + r][ks * 16 + h * 8]);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
     }
+    if (more) commit(buf ^ 1);             // the other buffer: nobody reads it during this chunk
     __syncthreads();
+    buf ^= 1;
   }
 
   // epilogue: sum of squares; C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -224,131 +246,6 @@ __global__ __launch_bounds__(256) void vicreg_gram_kernel(const unsigned short* 
     partials[blockIdx.x] = diag_tile ? tot : 2.0 * tot;
   }
 }
-
-// Fast path for Kpad == 128 (batch <= 128: the whole contraction depth fits one pass).  One workgroup walks
-// through up to GS column tiles of one row strip: the strip's A fragments (its 128 rows x K = 128) are loaded
-// once into registers (64 VGPRs per lane), the 128 x 128 B panels stream through a double-buffered LDS
-// image whose next tile is fetched (global -> registers) while the current one feeds the matrix cores and
-// is written to LDS afterwards.  Both branches (x and y) are one launch.
-#define GS 4               // column tiles per workgroup
-#define GBLD (128 + 8)     // LDS row stride in bf16 (272 B)
-
-__device__ __forceinline__ void strip_item(int item, int ntile, int& ti, int& g) {
-  // items enumerate (ti, g) with g < ceil((ntile - ti) / GS), row-major
-  ti = 0;
-  for (;;) {
-    const int ng = (ntile - ti + GS - 1) / GS;
-    if (item < ng) break;
-    item -= ng; ++ti;
-  }
-  g = item;
-}
-
-__global__ __launch_bounds__(256, 2) void vicreg_gram_strip_kernel(const unsigned short* __restrict__ Xt_x,
-                                                                    const unsigned short* __restrict__ Xt_y,
-                                                                    double* __restrict__ part_x,
-                                                                    double* __restrict__ part_y, int D, int ntile,
-                                                                    int nitems) {
-  __shared__ __attribute__((aligned(16))) unsigned short s_b[2][GT][GBLD];
-  __shared__ double s_part[4];
-  const int branch = blockIdx.x / nitems, item = blockIdx.x - branch * nitems;
-  const unsigned short* Xt = branch ? Xt_y : Xt_x;
-  int ti, g;
-  strip_item(item, ntile, ti, g);
-  const int tj0 = ti + g * GS, tj1 = min(tj0 + GS, ntile);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int r = lane & 31, h = lane >> 5;
-  const int row0 = ti * GT;
-
-  // A fragments of this wave's 64 rows, all 8 k-steps (K = 128)
-  bf16x8 fa[2][8];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int row = row0 + wr * 64 + m * 32 + r;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (row < D) v = *reinterpret_cast<const uint4*>(Xt + (size_t)row * 128 + ks * 16 + h * 8);
-      fa[m][ks] = __builtin_bit_cast(bf16x8, v);
-    }
-  }
-
-  // stage loads of one B tile: 128 rows x 256 B = 2048 x 16 B, 8 per thread
-  uint4 stage[8];
-  auto fetch = [&](int tj) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + 256 * i, rr = idx >> 4, ch = idx & 15;
-      const int row = tj * GT + rr;
-      stage[i] = make_uint4(0, 0, 0, 0);
-      if (row < D) stage[i] = *reinterpret_cast<const uint4*>(Xt + (size_t)row * 128 + ch * 8);
-    }
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + 256 * i, rr = idx >> 4, ch = idx & 15;
-      *reinterpret_cast<uint4*>(&s_b[buf][rr][ch * 8]) = stage[i];
-    }
-  };
-
-  fetch(tj0);
-  commit(0);
-  __syncthreads();
-  float s_off = 0.f, s_dia = 0.f;
-  int buf = 0;
-  for (int tj = tj0; tj < tj1; ++tj) {
-    const bool more = tj + 1 < tj1;
-    if (more) fetch(tj + 1);            // in flight while the matrix cores work on this tile
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      bf16x8 fb[2];
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-        fb[n] = *reinterpret_cast<const bf16x8*>(&s_b[buf][wc * 64 + n * 32 + r][ks * 16 + h * 8]);
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][ks], fb[n], acc[m][n], 0, 0, 0);
-    }
-    const bool diag_tile = (ti == tj);
-    float s = 0.f;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = acc[m][n][e];
-          if (diag_tile) {
-            const int row = wr * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const int col = wc * 64 + n * 32 + r;
-            if (row != col) s = fmaf(v, v, s);
-          } else {
-            s = fmaf(v, v, s);
-          }
-        }
-    if (diag_tile) s_dia += s; else s_off += s;
-    if (more) commit(buf ^ 1);          // other buffer: nobody reads it during this tile
-    __syncthreads();
-    buf ^= 1;
-  }
-  float tot = s_dia + 2.0f * s_off;
-  for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
-  if (lane == 0) s_part[wave] = (double)tot;
-  __syncthreads();
-  if (tid == 0) (branch ? part_y : part_x)[item] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-}
-
 
 // ---- Gram for a contraction depth of 128 (batch <= 128, BASELINE configs[2]) -----------------------------------
 // At K = 128 a 128 x 128 tile is only 32 MFMAs per wave: what bounds the kernel is the panel traffic L2 -> LDS
@@ -687,10 +584,10 @@ __global__ __launch_bounds__(256) void vicreg_finish_kernel(const double* __rest
 
 // ------------------------------------------------------------------------ C ABI
 static inline size_t vc_align(size_t x) { return (x + 255) / 256 * 256; }
-struct VicregWs { size_t xt_x, xt_y, colstats, mse, hinge, gram_x, gram_y, xc_x, xc_y, bgram, total; int Kpad, ntile, ngram, nmse; };
+struct VicregWs { size_t xt_x, xt_y, colstats, mse, hinge, gram_x, gram_y, xc_x, xc_y, bgram, bgram16, gdiag, total; int Kpad, ntile, ngram, nmse; };
 static VicregWs vicreg_ws(int B, int D) {
   VicregWs w;
-  w.Kpad = (B + GT - 1) / GT * GT;   // multiple of 128: the strip kernel's depth, the backward's batch tiles (zero padded)
+  w.Kpad = (B + GT - 1) / GT * GT;   // multiple of 128: the pair kernel's depth, the backward's batch tiles (zero padded)
   w.ntile = (D + GT - 1) / GT;
   w.ngram = w.ntile * (w.ntile + 1) / 2;
   w.nmse = (D + VC_COLS - 1) / VC_COLS;
@@ -706,6 +603,8 @@ static VicregWs vicreg_ws(int B, int D) {
   w.xc_x = o;     o = vc_align(o + sizeof(unsigned short) * (size_t)D * w.Kpad);
   w.xc_y = o;     o = vc_align(o + sizeof(unsigned short) * (size_t)D * w.Kpad);
   w.bgram = o;    o = vc_align(o + sizeof(float) * 2 * (size_t)w.Kpad * w.Kpad);
+  w.bgram16 = o;  o = vc_align(o + sizeof(unsigned short) * 2 * (size_t)w.Kpad * w.Kpad);
+  w.gdiag = o;    o = vc_align(o + sizeof(float) * 2 * (size_t)w.Kpad);
   w.total = o;
   return w;
 }
@@ -752,8 +651,8 @@ extern "C" int ias_vicreg_stage(int stage, const float* x, const float* y, float
       hipLaunchKernelGGL(vicreg_gram_pair_kernel, dim3(8 * ((nitems + 3) / 4)), dim3(GP_THREADS), lds, stream, xt_x, xt_y,
                          gram_x, gram_y, D, w.ntile, nitems);
     } else {
-      hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_x, gram_x, D, w.Kpad, w.ntile);
-      hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram), dim3(256), 0, stream, xt_y, gram_y, D, w.Kpad, w.ntile);
+      hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram, 2), dim3(256), 0, stream, xt_x, xt_y, gram_x, gram_y, D, w.Kpad,
+                         w.ntile);
     }
   }
   if (stage < 0 || stage == 2)
@@ -779,11 +678,10 @@ extern "C" int ias_vicreg_loss(const float* x, const float* y, float* out, void*
 // Kernels: vicreg_bgram_kernel  G = Xc Xc^T on the matrix cores (bf16 in, fp32 accumulate), split over D, fp32 atomics;
 //          vicreg_grad_kernel   G vc as a second bf16 MFMA product (A = G cast to bf16, B = Xt) for x and y at once,
 //                               epilogue adds the elementwise terms from x, y and the column statistics, writes gx, gy.
-#define BG_SPLIT_K 512    // features per vicreg_bgram_kernel workgroup
 
 __global__ __launch_bounds__(256) void vicreg_bgram_kernel(const unsigned short* __restrict__ Xc_x,
                                                            const unsigned short* __restrict__ Xc_y, float* __restrict__ G,
-                                                           int D, int Kpad, int ntile) {
+                                                           int D, int Kpad, int ntile, int ksplit /* features per workgroup */) {
   __shared__ __attribute__((aligned(16))) unsigned short s_a[GT][GLD];
   __shared__ __attribute__((aligned(16))) unsigned short s_b[GT][GLD];
   int t = blockIdx.x, ti = 0;
@@ -795,7 +693,7 @@ __global__ __launch_bounds__(256) void vicreg_bgram_kernel(const unsigned short*
   const int branch = blockIdx.z;
   const unsigned short* Xc = branch ? Xc_y : Xc_x;
   float* Gb = G + (size_t)branch * Kpad * Kpad;
-  const int kbeg = blockIdx.y * BG_SPLIT_K, kend = min(kbeg + BG_SPLIT_K, D);
+  const int kbeg = blockIdx.y * ksplit, kend = min(kbeg + ksplit, D);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int r = lane & 31, h = lane >> 5;
@@ -853,10 +751,26 @@ __global__ __launch_bounds__(256) void vicreg_bgram_kernel(const unsigned short*
       }
 }
 
+// G (fp32, both branches) -> bf16 with the diagonal taken out (it stays in fp32: gdiag[branch][b] = G_bb).  The diagonal
+// of G is 10-100x its off-diagonal entries and would carry its bf16 rounding (2^-9) straight into the dominant term
+// G_bb vc_bj of the gradient; the epilogue of vicreg_grad_kernel adds that term in fp32 instead.
+__global__ __launch_bounds__(256) void vicreg_gconv_kernel(const float* __restrict__ G, unsigned short* __restrict__ Gb,
+                                                           float* __restrict__ gdiag, int Kpad) {
+  const size_t n = (size_t)2 * Kpad * Kpad;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t q = i / ((size_t)Kpad * Kpad), rem = i - q * (size_t)Kpad * Kpad;
+    const int row = (int)(rem / Kpad), col = (int)(rem - (size_t)row * Kpad);
+    const float v = G[i];
+    if (row == col) gdiag[q * Kpad + row] = v;
+    Gb[i] = f2bf(row == col ? 0.0f : v);
+  }
+}
+
 // One 128 (batch rows) x 128 (features) tile of gx and gy per workgroup.
 __global__ __launch_bounds__(256) void vicreg_grad_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const unsigned short* __restrict__ Xt_x,
-    const unsigned short* __restrict__ Xt_y, const float* __restrict__ G, const float* __restrict__ colstats,
+    const unsigned short* __restrict__ Xt_y, const unsigned short* __restrict__ Gb, const float* __restrict__ gdiag,
+    const float* __restrict__ colstats,
     const float* __restrict__ gcoef /* g_loss, g_repr, g_std, g_cov */, float* __restrict__ gx, float* __restrict__ gy,
     int B, int D, int Kpad, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff) {
   __shared__ __attribute__((aligned(16))) unsigned short s_a[2][GT][GLD];   // G rows (bf16), per branch
@@ -882,26 +796,13 @@ __global__ __launch_bounds__(256) void vicreg_grad_kernel(
   for (int k0 = 0; k0 < Kpad; k0 += GK) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const float* Gb = G + (size_t)q * Kpad * Kpad;
+      const unsigned short* Gq = Gb + (size_t)q * Kpad * Kpad;
       const unsigned short* Xt = q ? Xt_y : Xt_x;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rr = (tid >> 3) + 32 * i, ch = tid & 7;
-        // A: G[row0 + rr][k0 + 8 ch ..] fp32 -> bf16
-        const float4 g0 = *reinterpret_cast<const float4*>(Gb + (size_t)(row0 + rr) * Kpad + k0 + ch * 8);
-        const float4 g1 = *reinterpret_cast<const float4*>(Gb + (size_t)(row0 + rr) * Kpad + k0 + ch * 8 + 4);
-        // the diagonal of G is 10-100x its off-diagonal entries and would carry its bf16 rounding (2^-9) straight
-        // into the dominant term G_bb vc_bj: it is left out of the matrix product and added in fp32 by the epilogue
-        float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        const int dd = (row0 + rr) - (k0 + ch * 8);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) if (i == dd) gv[i] = 0.0f;
-        uint4 va;
-        va.x = (unsigned)f2bf(gv[0]) | ((unsigned)f2bf(gv[1]) << 16);
-        va.y = (unsigned)f2bf(gv[2]) | ((unsigned)f2bf(gv[3]) << 16);
-        va.z = (unsigned)f2bf(gv[4]) | ((unsigned)f2bf(gv[5]) << 16);
-        va.w = (unsigned)f2bf(gv[6]) | ((unsigned)f2bf(gv[7]) << 16);
-        *reinterpret_cast<uint4*>(&s_a[q][rr][ch * 8]) = va;
+        *reinterpret_cast<uint4*>(&s_a[q][rr][ch * 8]) =
+            *reinterpret_cast<const uint4*>(Gq + (size_t)(row0 + rr) * Kpad + k0 + ch * 8);
         uint4 vb = make_uint4(0, 0, 0, 0);
         if (col0 + rr < D) vb = *reinterpret_cast<const uint4*>(Xt + (size_t)(col0 + rr) * Kpad + k0 + ch * 8);
         *reinterpret_cast<uint4*>(&s_b[q][rr][ch * 8]) = vb;
@@ -950,7 +851,7 @@ __global__ __launch_bounds__(256) void vicreg_grad_kernel(
         const size_t idx = (size_t)b * D + j;
         const float xv = x[idx], yv = y[idx];
         const float dr = repr_k * (xv - yv);
-        const float gbx = G[(size_t)b * Kpad + b], gby = G[(size_t)Kpad * Kpad + (size_t)b * Kpad + b];   // G_bb, fp32
+        const float gbx = gdiag[b], gby = gdiag[Kpad + b];   // G_bb, fp32
         const float vx = xv - mx, vy = yv - my;
         gx[idx] = dr + ax * vx + cc * kappa * (acc[0][m][n][e] + gbx * vx);
         gy[idx] = -dr + ay * vy + cc * kappa * (acc[1][m][n][e] + gby * vy);
@@ -972,11 +873,23 @@ extern "C" int ias_vicreg_backward(const float* x, const float* y, const float* 
   if (hipMemsetAsync(G, 0, sizeof(float) * 2 * (size_t)w.Kpad * w.Kpad, stream) != hipSuccess) return IAS_ERR_LAUNCH;
   const int bt = w.Kpad / GT;                       // Kpad is a multiple of 128 whenever it exceeds 64... see below
   if (w.Kpad % GT) return IAS_ERR_UNSUPPORTED;
-  const int npair = bt * (bt + 1) / 2, nsplit = (D + BG_SPLIT_K - 1) / BG_SPLIT_K;
+  // split the contraction over D so that about two rounds of workgroups are in flight (every workgroup ends with
+  // 128 x 128 fp32 atomics, twice for tiles above the diagonal: fewer, longer workgroups for large batches)
+  const int npair = bt * (bt + 1) / 2;
+  int nsplit = 512 / (2 * npair);
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > D / 256) nsplit = D / 256 > 0 ? D / 256 : 1;
+  const int ksplit = ((D + nsplit - 1) / nsplit + GK - 1) / GK * GK;
+  nsplit = (D + ksplit - 1) / ksplit;
   hipLaunchKernelGGL(vicreg_bgram_kernel, dim3(npair, nsplit, 2), dim3(256), 0, stream, (const unsigned short*)(ws + w.xc_x),
-                     (const unsigned short*)(ws + w.xc_y), G, D, w.Kpad, bt);
+                     (const unsigned short*)(ws + w.xc_y), G, D, w.Kpad, bt, ksplit);
+  unsigned short* Gb = (unsigned short*)(ws + w.bgram16);
+  float* gdiag = (float*)(ws + w.gdiag);
+  int cgrid = (int)((2 * (size_t)w.Kpad * w.Kpad + 255) / 256);
+  if (cgrid > 2048) cgrid = 2048;
+  hipLaunchKernelGGL(vicreg_gconv_kernel, dim3(cgrid), dim3(256), 0, stream, G, Gb, gdiag, w.Kpad);
   hipLaunchKernelGGL(vicreg_grad_kernel, dim3((D + GT - 1) / GT, bt), dim3(256), 0, stream, x, y,
-                     (const unsigned short*)(ws + w.xt_x), (const unsigned short*)(ws + w.xt_y), G,
+                     (const unsigned short*)(ws + w.xt_x), (const unsigned short*)(ws + w.xt_y), Gb, gdiag,
                      (const float*)(ws + w.colstats), gcoef, gx, gy, B, D, w.Kpad, cfg_batch, sim_coeff, std_coeff, cov_coeff);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
