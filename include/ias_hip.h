@@ -204,6 +204,21 @@ int ias_vicreg_backward(const float* x, const float* y, const float* gcoef, floa
 int ias_vicreg_stage(int stage, const float* x, const float* y, float* out, void* workspace, long long workspace_bytes,
                      int B, int D, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff, void* stream);
 
+/* ---- AudioEmbedding trunk: the depthwise convolutions and the stem of torchvision's mobilenet_v3_small.features
+ * (reference vicreg_audio_params.py:52-54, audioembed.py:61), NCHW fp32, padding (K-1)/2, no bias.
+ * K in {3, 5}, stride S in {1, 2}; B * C <= 65535.  ias_conv_out_size: output extent of one spatial dimension. */
+int ias_conv_out_size(int n, int K, int S);
+int ias_dwconv_forward(const float* x, const float* w, float* out, int B, int C, int H, int W, int K, int S, void* stream);
+int ias_dwconv_backward_data(const float* g, const float* w, float* gx, int B, int C, int H, int W, int K, int S,
+                             void* stream);
+long long ias_dwconv_weight_scratch(int B, int C, int K);     /* floats */
+int ias_dwconv_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int C, int H, int W,
+                               int K, int S, void* stream);
+/* Conv2d(3, 16, 3, stride 2, padding 1, bias=False): x [B,3,H,W], w [16,3,3,3] -> out [B,16,Ho,Wo]; weight gradient. */
+int ias_stem_forward(const float* x, const float* w, float* out, int B, int H, int W, void* stream);
+long long ias_stem_weight_scratch(int B);                     /* floats */
+int ias_stem_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,14 @@ SYMBOLS = {
     "ias_vicreg_loss": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
     "ias_vicreg_backward": (_I, [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
     "ias_vicreg_stage": (_I, [_I, _P, _P, _P, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
+    "ias_conv_out_size": (_I, [_I, _I, _I]),
+    "ias_dwconv_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ias_dwconv_backward_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ias_dwconv_weight_scratch": (_LL, [_I, _I, _I]),
+    "ias_dwconv_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ias_stem_forward": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ias_stem_weight_scratch": (_LL, [_I]),
+    "ias_stem_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
 }
 
 _lib = None

@@ -26,6 +26,22 @@ class ChannelNormalize(nn.Module):
         return (x - self.mean.view(1, -1, 1, 1)) / self.std.view(1, -1, 1, 1)
 
 
+def conv2x2_nhwc(x, weight, bias):
+    """``nn.Conv2d(kernel_size=2)`` (stride 1, no padding) on a channels-last activation x [B,H,W,Cin] with the module's
+    own parameters (weight [Cout,Cin,2,2], bias [Cout]) -> [B,H-1,W-1,Cout], as ONE gather + ONE dense GEMM:
+    out[(b,i,j), :] = patches[(b,i,j), (di,dj,c)] @ W[(di,dj,c), :].  The seven layers of AudioEmbedding's head
+    (/root/reference/audioembed.py:15-33,62-68) are 1024 -> 1024 convolutions on 8x8 ... 2x2 maps: as nn.Conv2d on
+    MIOpen they ran as naive fallbacks plus one im2col + one small GEMM PER SAMPLE (4096 Im2d2Col launches per step at
+    batch 128); as a GEMM [B Ho Wo, 4 Cin] x [4 Cin, Cout] they are seven rocBLAS / hipBLASLt calls.  fp32 throughout,
+    differentiable through plain autograd (two more GEMMs per layer in backward)."""
+    B, H, W, C = x.shape
+    patches = x.unfold(1, 2, 1).unfold(2, 2, 1)                       # [B,H-1,W-1,C,2,2] view
+    patches = patches.permute(0, 1, 2, 4, 5, 3).reshape(B * (H - 1) * (W - 1), 4 * C)   # the one gather (copy)
+    w2 = weight.permute(0, 2, 3, 1).reshape(weight.shape[0], 4 * C)   # [Cout, (di,dj,c)]
+    out = torch.nn.functional.linear(patches, w2, bias)
+    return out.view(B, H - 1, W - 1, weight.shape[0])
+
+
 class AudioEmbedding(nn.Module):
     def __init__(self, gram, vision_model, img_preprocess, dim):
         super().__init__()
@@ -45,6 +61,12 @@ class AudioEmbedding(nn.Module):
 
     def forward(self, audio):
         t = self.vision_model.features(self._preprocess(audio))
+        if t.is_cuda and all(getattr(self, f"conv{i}").kernel_size == (2, 2) for i in range(1, 8)):
+            t = t.permute(0, 2, 3, 1)                 # channels-last once; the head stays channels-last
+            for i in range(7, 0, -1):
+                c = getattr(self, f"conv{i}")
+                t = conv2x2_nhwc(t, c.weight, c.bias)
+            return t.reshape(-1, self.dim)            # [B,1,1,dim]
         for i in range(7, 0, -1):
             t = getattr(self, f"conv{i}")(t)
         return t.view(-1, self.dim)

@@ -9,7 +9,126 @@ random-initialised; ``pretrained=True`` only warns.  Convolutions run on MIOpen 
 """
 import warnings
 
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+
+class PointwiseConv2d(nn.Conv2d):
+    """A 1x1 convolution (same parameters and state_dict keys as nn.Conv2d).  On a ROCm device it is what it is -- ONE
+    strided-batched GEMM  y[b] = W [Cout,Cin] x[b] [Cin, H W]  on rocBLAS / hipBLASLt, layout unchanged (NCHW in, NCHW
+    out) -- instead of MIOpen's fp32 fallback, which ran it as an im2col plus a small GEMM PER SAMPLE (3 x 1024 launches
+    per training step at batch 128 for the MobileNet body).  The depthwise convolutions stay on MIOpen in NCHW (its
+    channels-last depthwise weight-gradient took 13 ms per layer).  Elsewhere this is the plain nn.Conv2d."""
+
+    def forward(self, x):
+        if x.is_cuda and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.groups == 1 and \
+                x.dim() == 4 and x.is_contiguous():
+            B, C, H, W = x.shape
+            y = torch.matmul(self.weight.view(self.out_channels, C), x.view(B, C, H * W))
+            if self.bias is not None:
+                y = y + self.bias.view(1, -1, 1)
+            return y.view(B, self.out_channels, H, W)
+        return super().forward(x)
+
+
+class _DepthwiseFn(torch.autograd.Function):
+    """csrc/conv_kernels.hip: depthwise conv forward, input gradient, weight gradient (deterministic reduction)."""
+
+    @staticmethod
+    def forward(ctx, x, w, K, S):
+        from . import _lib
+        lib = _lib.load()
+        x, w = x.contiguous(), w.contiguous()
+        _lib.require_f32(x, w)
+        B, C, H, W = x.shape
+        Ho, Wo = lib.ias_conv_out_size(H, K, S), lib.ias_conv_out_size(W, K, S)
+        out = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        _lib.check(lib.ias_dwconv_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), B, C, H, W, K, S, _lib.stream()),
+                   "ias_dwconv_forward")
+        ctx.save_for_backward(x, w)
+        ctx.ks = (K, S)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        K, S = ctx.ks
+        B, C, H, W = x.shape
+        g = g.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _lib.check(lib.ias_dwconv_backward_data(_lib.ptr(g), _lib.ptr(w), _lib.ptr(gx), B, C, H, W, K, S, _lib.stream()),
+                       "ias_dwconv_backward_data")
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            scratch = torch.empty(int(lib.ias_dwconv_weight_scratch(B, C, K)), dtype=torch.float32, device=x.device)
+            _lib.check(lib.ias_dwconv_backward_weight(_lib.ptr(x), _lib.ptr(g), _lib.ptr(gw), _lib.ptr(scratch), B, C, H, W, K,
+                                                      S, _lib.stream()), "ias_dwconv_backward_weight")
+        return gx, gw, None, None
+
+
+class DepthwiseConv2d(nn.Conv2d):
+    """Depthwise convolution (groups = channels; same parameters / state_dict keys as nn.Conv2d).  On a ROCm device, for
+    the shapes of MobileNetV3 (3x3 / 5x5, stride 1 / 2, padding (k-1)/2, no bias), it runs the stencil kernels of
+    csrc/conv_kernels.hip instead of MIOpen's fp32 fallbacks (naive_conv_*, 0.85 ms Winograd calls on 15 x 16 maps);
+    elsewhere it is the plain nn.Conv2d."""
+
+    def forward(self, x):
+        k, s = self.kernel_size[0], self.stride[0]
+        if x.is_cuda and x.dtype == torch.float32 and self.groups == self.in_channels == self.out_channels and \
+                self.bias is None and self.kernel_size in ((3, 3), (5, 5)) and self.stride in ((1, 1), (2, 2)) and \
+                self.padding == ((k - 1) // 2, (k - 1) // 2) and self.dilation == (1, 1) and \
+                x.shape[0] * x.shape[1] <= 65535:
+            return _DepthwiseFn.apply(x, self.weight, k, s)
+        return super().forward(x)
+
+
+class _StemFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        from . import _lib
+        lib = _lib.load()
+        x, w = x.contiguous(), w.contiguous()
+        _lib.require_f32(x, w)
+        B, _c, H, W = x.shape
+        Ho, Wo = lib.ias_conv_out_size(H, 3, 2), lib.ias_conv_out_size(W, 3, 2)
+        out = torch.empty((B, 16, Ho, Wo), dtype=torch.float32, device=x.device)
+        _lib.check(lib.ias_stem_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), B, H, W, _lib.stream()), "ias_stem_forward")
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        B, _c, H, W = x.shape
+        g = g.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:   # the image never requires grad in this model; kept correct through torch
+            gx = torch.nn.grad.conv2d_input(x.shape, w, g, stride=2, padding=1)
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            scratch = torch.empty(int(lib.ias_stem_weight_scratch(B)), dtype=torch.float32, device=x.device)
+            _lib.check(lib.ias_stem_backward_weight(_lib.ptr(x), _lib.ptr(g), _lib.ptr(gw), _lib.ptr(scratch), B, H, W,
+                                                    _lib.stream()), "ias_stem_backward_weight")
+        return gx, gw
+
+
+class StemConv2d(nn.Conv2d):
+    """The 3 -> 16, 3x3, stride-2 stem (same parameters as nn.Conv2d): a direct HIP kernel on a ROCm device -- MIOpen ran
+    it as an im2col plus a GEMM per sample -- the plain nn.Conv2d elsewhere."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and (self.in_channels, self.out_channels) == (3, 16) and \
+                self.kernel_size == (3, 3) and self.stride == (2, 2) and self.padding == (1, 1) and self.bias is None and \
+                self.groups == 1 and x.shape[0] <= 65535:
+            return _StemFn.apply(x, self.weight)
+        return super().forward(x)
 
 
 def _divisible(v, d=8):
@@ -19,7 +138,9 @@ def _divisible(v, d=8):
 
 class ConvBNAct(nn.Sequential):
     def __init__(self, cin, cout, k=3, stride=1, groups=1, act=None):
-        layers = [nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False),
+        conv = PointwiseConv2d if (k == 1 and groups == 1) else (DepthwiseConv2d if groups == cin == cout else
+                                                                 (StemConv2d if (cin, cout, k, stride) == (3, 16, 3, 2) else nn.Conv2d))
+        layers = [conv(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False),
                   nn.BatchNorm2d(cout, eps=0.001, momentum=0.01)]
         if act is not None:
             layers.append(act(inplace=True))
@@ -30,8 +151,8 @@ class SqueezeExcitation(nn.Module):
     def __init__(self, channels, squeeze):
         super().__init__()
         self.avgpool = nn.AdaptiveAvgPool2d(1)
-        self.fc1 = nn.Conv2d(channels, squeeze, 1)
-        self.fc2 = nn.Conv2d(squeeze, channels, 1)
+        self.fc1 = PointwiseConv2d(channels, squeeze, 1)
+        self.fc2 = PointwiseConv2d(squeeze, channels, 1)
         self.activation = nn.ReLU()
         self.scale_activation = nn.Hardsigmoid()
 

@@ -1,0 +1,74 @@
+"""The trunk's convolution kernels (csrc/conv_kernels.hip) and GEMM forms against torch's own Conv2d on the same
+device (the reference takes these layers from torchvision's mobilenet_v3_small, vicreg_audio_params.py:52-54): forward,
+input gradient, weight gradient; and the whole AudioEmbedding trunk against the same modules run as plain nn.Conv2d."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import randn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("C,K,S,H,W", [(16, 3, 2, 120, 123), (88, 3, 1, 30, 31), (96, 5, 2, 30, 31), (240, 5, 1, 15, 16),
+                                       (576, 5, 1, 8, 8), (7, 3, 1, 5, 4), (5, 5, 2, 9, 2)])
+def test_depthwise_conv_matches_torch(lib, dev, C, K, S, H, W):
+    from inverse_audio_synthesis_amd.vision import DepthwiseConv2d
+    B = 6
+    m = DepthwiseConv2d(C, C, K, S, (K - 1) // 2, groups=C, bias=False).to(dev)
+    x = randn((B, C, H, W), 1).to(dev).requires_grad_(True)
+    y = m(x)
+    ref = F.conv2d(x, m.weight, None, S, (K - 1) // 2, 1, C)
+    assert y.shape == ref.shape and (y - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    g = randn(tuple(ref.shape), 2).to(dev)
+    gx, gw = torch.autograd.grad(y, (x, m.weight), g)
+    rx, rw = torch.autograd.grad(ref, (x, m.weight), g)
+    assert (gx - rx).abs().max().item() <= 1e-5 * max(1.0, rx.abs().max().item())
+    assert (gw - rw).abs().max().item() <= 2e-4 * max(1.0, rw.abs().max().item())
+    gw2 = torch.autograd.grad(m(x), m.weight, g)[0]
+    assert torch.equal(gw, gw2), "the weight gradient is reduced in a fixed order"
+
+
+def test_stem_conv_matches_torch(lib, dev):
+    from inverse_audio_synthesis_amd.vision import StemConv2d
+    m = StemConv2d(3, 16, 3, 2, 1, bias=False).to(dev)
+    for shape in ((4, 3, 240, 245), (3, 3, 17, 10)):
+        x = randn(shape, 3).to(dev)
+        y = m(x)
+        ref = F.conv2d(x, m.weight, None, 2, 1)
+        assert y.shape == ref.shape and (y - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+        g = randn(tuple(ref.shape), 4).to(dev)
+        gw = torch.autograd.grad(y, m.weight, g)[0]
+        rw = torch.autograd.grad(ref, m.weight, g)[0]
+        assert (gw - rw).abs().max().item() <= 2e-4 * max(1.0, rw.abs().max().item())
+
+
+def test_trunk_matches_plain_conv2d_modules(lib, dev):
+    """AudioEmbedding (fused PQMF epilogue, HIP stem / depthwise kernels, 1x1 and 2x2 convolutions as GEMMs) against the
+    same parameters evaluated with torch's own conv2d everywhere: forward and parameter gradients (eval mode)."""
+    from inverse_audio_synthesis_amd.audioembed import AudioEmbedding, ChannelNormalize
+    from inverse_audio_synthesis_amd.pqmf import PQMF
+    from inverse_audio_synthesis_amd.vision import mobilenet_v3_small
+    torch.manual_seed(0)
+    net = AudioEmbedding(PQMF(N=3), mobilenet_v3_small(), ChannelNormalize(), dim=32).to(dev).eval()
+    audio = (randn((2, 1, 176400), 5) * 0.3).to(dev)
+    out = net(audio)
+    w = randn(tuple(out.shape), 6).to(dev)
+    params = [p for p in net.parameters() if p.requires_grad]
+    grads = torch.autograd.grad((out * w).sum(), params)
+
+    def plain_forward(m, x):      # every conv through F.conv2d
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Conv2d):
+                mod.forward = (lambda self: lambda t: F.conv2d(t, self.weight, self.bias, self.stride, self.padding,
+                                                               self.dilation, self.groups))(mod)
+        t = m.vision_model.features(m._preprocess(x))
+        for i in range(7, 0, -1):
+            t = getattr(m, f"conv{i}")(t)
+        return t.view(-1, m.dim)
+
+    ref = plain_forward(net, audio)
+    assert (out - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    rgrads = torch.autograd.grad((ref * w).sum(), params)
+    for a, b in zip(grads, rgrads):
+        assert (a - b).abs().max().item() <= 2e-3 * max(1e-3, b.abs().max().item())
