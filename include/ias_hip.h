@@ -206,7 +206,7 @@ int ias_vicreg_stage(int stage, const float* x, const float* y, float* out, void
 
 /* ---- AudioEmbedding trunk: the depthwise convolutions and the stem of torchvision's mobilenet_v3_small.features
  * (reference vicreg_audio_params.py:52-54, audioembed.py:61), NCHW fp32, padding (K-1)/2, no bias.
- * K in {3, 5}, stride S in {1, 2}; B * C <= 65535.  ias_conv_out_size: output extent of one spatial dimension. */
+ * K in {3, 5}, stride S in {1, 2}.  ias_conv_out_size: output extent of one spatial dimension. */
 int ias_conv_out_size(int n, int K, int S);
 int ias_dwconv_forward(const float* x, const float* w, float* out, int B, int C, int H, int W, int K, int S, void* stream);
 int ias_dwconv_backward_data(const float* g, const float* w, float* gx, int B, int C, int H, int W, int K, int S,

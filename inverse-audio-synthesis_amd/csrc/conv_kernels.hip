@@ -17,13 +17,13 @@ __global__ __launch_bounds__(CV_THREADS) void dwconv_fwd_kernel(const float* __r
                                                                 float* __restrict__ out, int C, int H, int W, int Ho,
                                                                 int Wo) {
   constexpr int P = (K - 1) / 2;
-  const int plane = blockIdx.y, c = plane % C;
+  const int plane = blockIdx.x, c = plane % C;
   float wt[K * K];
 #pragma unroll
   for (int i = 0; i < K * K; ++i) wt[i] = w[c * K * K + i];
   const float* xp = x + (size_t)plane * H * W;
   float* op = out + (size_t)plane * Ho * Wo;
-  for (int o = blockIdx.x * CV_THREADS + threadIdx.x; o < Ho * Wo; o += gridDim.x * CV_THREADS) {
+  for (int o = blockIdx.y * CV_THREADS + threadIdx.x; o < Ho * Wo; o += gridDim.y * CV_THREADS) {
     const int ho = o / Wo, wo = o - ho * Wo;
     float acc = 0.0f;
 #pragma unroll
@@ -46,13 +46,13 @@ __global__ __launch_bounds__(CV_THREADS) void dwconv_bwd_data_kernel(const float
                                                                      float* __restrict__ gx, int C, int H, int W, int Ho,
                                                                      int Wo) {
   constexpr int P = (K - 1) / 2;
-  const int plane = blockIdx.y, c = plane % C;
+  const int plane = blockIdx.x, c = plane % C;
   float wt[K * K];
 #pragma unroll
   for (int i = 0; i < K * K; ++i) wt[i] = w[c * K * K + i];
   const float* gp = g + (size_t)plane * Ho * Wo;
   float* xp = gx + (size_t)plane * H * W;
-  for (int i = blockIdx.x * CV_THREADS + threadIdx.x; i < H * W; i += gridDim.x * CV_THREADS) {
+  for (int i = blockIdx.y * CV_THREADS + threadIdx.x; i < H * W; i += gridDim.y * CV_THREADS) {
     const int hi = i / W, wi = i - hi * W;
     float acc = 0.0f;
 #pragma unroll
@@ -224,7 +224,7 @@ static int cv_grid_x(int n) {
   } while (0)
 
 static int cv_check(const void* a, const void* b, const void* c, int B, int C, int H, int W, int K, int S) {
-  if (!a || !b || !c || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (long long)B * C > 0x7fffffffLL || B * C > 65535 * 1024) return IAS_ERR_ARG;
+  if (!a || !b || !c || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (long long)B * C > 0x7fffffffLL) return IAS_ERR_ARG;
   if (!((K == 3 || K == 5) && (S == 1 || S == 2))) return IAS_ERR_UNSUPPORTED;
   return IAS_OK;
 }
@@ -236,9 +236,8 @@ extern "C" int ias_dwconv_forward(const float* x, const float* w, float* out, in
                                   void* stream_) {
   int rc = cv_check(x, w, out, B, C, H, W, K, S);
   if (rc) return rc;
-  if (B * C > 65535) return IAS_ERR_UNSUPPORTED;
   const int Ho = ias_conv_out_size(H, K, S), Wo = ias_conv_out_size(W, K, S);
-  const dim3 grid(cv_grid_x(Ho * Wo), B * C), block(CV_THREADS);
+  const dim3 grid(B * C, cv_grid_x(Ho * Wo)), block(CV_THREADS);
   CV_DISPATCH(dwconv_fwd_kernel, grid, block, 0, (hipStream_t)stream_, x, w, out, C, H, W, Ho, Wo);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
@@ -248,9 +247,8 @@ extern "C" int ias_dwconv_backward_data(const float* g, const float* w, float* g
                                         void* stream_) {
   int rc = cv_check(g, w, gx, B, C, H, W, K, S);
   if (rc) return rc;
-  if (B * C > 65535) return IAS_ERR_UNSUPPORTED;
   const int Ho = ias_conv_out_size(H, K, S), Wo = ias_conv_out_size(W, K, S);
-  const dim3 grid(cv_grid_x(H * W), B * C), block(CV_THREADS);
+  const dim3 grid(B * C, cv_grid_x(H * W)), block(CV_THREADS);
   CV_DISPATCH(dwconv_bwd_data_kernel, grid, block, 0, (hipStream_t)stream_, g, w, gx, C, H, W, Ho, Wo);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }

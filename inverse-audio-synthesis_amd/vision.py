@@ -81,8 +81,7 @@ class DepthwiseConv2d(nn.Conv2d):
         k, s = self.kernel_size[0], self.stride[0]
         if x.is_cuda and x.dtype == torch.float32 and self.groups == self.in_channels == self.out_channels and \
                 self.bias is None and self.kernel_size in ((3, 3), (5, 5)) and self.stride in ((1, 1), (2, 2)) and \
-                self.padding == ((k - 1) // 2, (k - 1) // 2) and self.dilation == (1, 1) and \
-                x.shape[0] * x.shape[1] <= 65535:
+                self.padding == ((k - 1) // 2, (k - 1) // 2) and self.dilation == (1, 1):
             return _DepthwiseFn.apply(x, self.weight, k, s)
         return super().forward(x)
 
