@@ -11,6 +11,7 @@
 // Algorithmic HBM bytes: 4 B in + 4 B out per audio sample.
 #include "ias_common.h"
 #include <cstdint>
+#include <cstdlib>
 
 #define PQ_THREADS 256
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -108,6 +109,12 @@ __device__ __forceinline__ float pqmf_row_scale(const float* __restrict__ rowpea
   if (rowpeak == nullptr) return 1.0f;
   const float pk = rowpeak[b];
   return pk > 1.0f ? 1.0f / pk : 1.0f;
+}
+// The fused epilogue of every analysis kernel, spelled out so that all of them round alike whatever the compiler's
+// contraction choices: band value = acc * rsc, normalised value = (acc * rsc - m) / sd with the product and the
+// subtraction in one fma (rsc == 1: exactly (acc - m) / sd).
+__device__ __forceinline__ float pqmf_finish(float acc, float rsc, bool norm, float m, float sd) {
+  return norm ? __fdiv_rn(fmaf(acc, rsc, -m), sd) : __fmul_rn(acc, rsc);
 }
 
 template <int N, int K>
@@ -224,12 +231,15 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_fast_kernel(
     const float rsc = pqmf_row_scale(rowpeak, b);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      f32x2 o[2] = {acc[k][0], acc[k][1]};
-      if (rowpeak != nullptr) { o[0] = o[0] * rsc; o[1] = o[1] * rsc; }
-      if (mean != nullptr) {
-        const float m = mean[k], sd = stdv[k];
+      f32x2 o[2];
+      {
+        const bool nrm = mean != nullptr;
+        const float m = nrm ? mean[k] : 0.0f, sd = nrm ? stdv[k] : 1.0f;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) { o[r].x = (o[r].x - m) / sd; o[r].y = (o[r].y - m) / sd; }
+        for (int r = 0; r < 2; ++r) {
+          o[r].x = pqmf_finish(acc[k][r].x, rsc, nrm, m, sd);
+          o[r].y = pqmf_finish(acc[k][r].y, rsc, nrm, m, sd);
+        }
       }
       float* zr = z + ((size_t)b * N + k) * L;
 #pragma unroll
@@ -244,6 +254,512 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_fast_kernel(
       }
     }
     __syncthreads();   // every wave is done reading the rows before the next tile overwrites them
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Analysis on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, bit-for-bit the tap-ordered fmaf chain the
+// VALU kernels compute, on a pipe nothing else in the step uses).
+//
+// The filterbank is a GEMM z[f][k] = sum_j x[N f + j - pad] H[k][j] with only N output columns, far too few for a
+// 16-wide tile when N = 3.  S consecutive frames are therefore folded into one "super-frame" row: column (k, s)
+// of row F is band k of frame S F + s, its taps shifted by N s samples,
+//     Hs[(k, s)][i] = H[k][i - N s]   (0 <= i - N s < K, zero elsewhere),   i < KP = K + N (S - 1),
+// so that every row reads ONE contiguous run x[N S F - pad + i] and each A value feeds N S columns.  N = 3: S = 5,
+// 15 of 16 columns live, KP = 75 -> 19 k-steps of 4 (78 % of the issued FMAs are real ones); N = 4: S = 4, 16 columns,
+// 19 k-steps; N = 64: S = 1, four column tiles, 16 k-steps.  The zero taps add exact zeros (x finite), so the sum of
+// each column is the same chain fma(x_62, h_62, ... fma(x_0, h_0, 0)) as the polyphase kernel's.
+//
+// Operands (guide section 3, FP32-input MFMA): lane l = (r = l & 15, kq = l >> 4) gives A[row r][k = kq] =
+// x_lds[RS (16 rt + r) + 4 kk + kq] (one ds_read_b32 per k-step and row tile, immediate offsets) and B[k = kq][col r] =
+// Hs[col][4 kk + kq] (KQ x CT registers loaded once per workgroup).  D: col = l & 15, row = 4 (l >> 4) + reg.
+// A wave keeps RT row tiles in flight (independent accumulators cover the 40-cycle dependent-MFMA latency).  Results
+// go through a wave-private LDS block so that the stores are 16-byte runs along the frame axis.
+// Staging: 16-byte global loads from the 16-byte aligned address at or below the tile's first sample, one tile ahead
+// in registers; the residual shift (0..3 samples) is added to the A read address.
+typedef float pq_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned pq_u32x4 __attribute__((ext_vector_type(4)));
+#ifdef PQM_STAMPS   /* diagnostics: s_memtime of workgroup 0's waves at five points of its first tiles, written over z */
+#define PQM_STAMP(i)                                                                                         \
+  do {                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (blockIdx.x == 0 && lane == 0 && stamp_n < 6)                                                         \
+      reinterpret_cast<unsigned long long*>(z)[(wave * 6 + stamp_n) * 5 + (i)] = __builtin_readcyclecounter(); \
+    if ((i) == 4) ++stamp_n;                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  } while (0)
+#else
+#define PQM_STAMP(i)
+#endif
+
+template <int N, int K, int S, int RT, int PSH>
+struct PqmfMfma {
+  static_assert(RT % 2 == 0, "row tiles are processed in pairs");
+  static constexpr int NC = N * S;                      // live columns
+  static constexpr int CT = (NC + 15) / 16;             // column tiles
+  static constexpr int KP = K + N * (S - 1);            // taps of a super-frame row
+  static constexpr int KQ = (KP + 3) / 4;               // k-steps
+  static constexpr int RS = N * S;                      // samples between super-frames
+  static constexpr int WF = RT * 16 * S;                // frames per wave
+  static constexpr int FT = (PQ_THREADS / 64) * WF;     // frames per workgroup tile
+  static constexpr int SPAN = (N * FT + 4 * KQ - N + 3 + 3) / 4 * 4;   // staged samples (every word an A read can touch)
+  static constexpr int NV4 = SPAN / 4;
+  static constexpr int NIT = (NV4 + PQ_THREADS - 1) / PQ_THREADS;
+  // LDS position of staged sample j: 4 pad words per 2^PSH samples when the row stride is a multiple of 16 words
+  // (N S = 16: rows 4 apart share a bank; N = 64: all 16 rows do)
+  __host__ __device__ static constexpr int pos(int j) { return PSH ? j + 4 * (j >> PSH) : j; }
+  static constexpr int IN_WORDS = pos(SPAN) + 4;
+  static constexpr int OROW = WF + 4;                   // wave-private output block [N][OROW]
+  static constexpr int OUT_WORDS = (PQ_THREADS / 64) * N * OROW;
+  static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(IN_WORDS + OUT_WORDS);
+};
+
+template <int N, int K, int S, int RT, int PSH>
+__global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ H, float* __restrict__ z, const float* __restrict__ mean,
+    const float* __restrict__ stdv, const float* __restrict__ rowpeak, int T, int L, int pad, int tiles_x, int ntiles,
+    int zvec /* z rows are 16-byte aligned (z aligned and L % 4 == 0) */) {
+  using C = PqmfMfma<N, K, S, RT, PSH>;
+  constexpr int CT = C::CT, KQ = C::KQ, RS = C::RS, WF = C::WF, FT = C::FT, NV4 = C::NV4, NIT = C::NIT, OROW = C::OROW;
+  extern __shared__ __attribute__((aligned(16))) float s_pm[];
+  float* s_in = s_pm;
+  float* s_out = s_pm + C::IN_WORDS;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, kq = lane >> 4;
+
+  float bf[CT][KQ];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int col = 16 * ct + r, band = col / S, j0 = kq - N * (col - band * S);
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) {
+      const int j = j0 + 4 * kk;
+      bf[ct][kk] = (col < C::NC && j >= 0 && j < K) ? H[band * K + j] : 0.0f;
+    }
+  }
+
+  // band constants of the fused normalisation: loaded once (a vector load in the tile loop would make its wait drain
+  // the next tile's prefetch, which is queued ahead of it)
+  float nm[CT], nsd[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int col = 16 * ct + r, band = min(col, C::NC - 1) / S;
+    nm[ct] = mean != nullptr ? mean[band] : 0.0f;
+    nsd[ct] = mean != nullptr ? stdv[band] : 1.0f;
+  }
+
+  pq_f32x4 e[NIT];
+  auto load_tile = [&](int t) {
+    const int b = t / tiles_x;
+    const int a0 = ((t - b * tiles_x) * FT * N - pad) & ~3;
+    const float* xr = x + (size_t)b * T;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int g = a0 + 4 * min(tid + it * PQ_THREADS, NV4 - 1);
+#ifdef PQM_NO_LOAD   /* diagnostics */
+      e[it] = (pq_f32x4){(float)g, 1.0f, 2.0f, (float)tid};
+#else
+      e[it] = *reinterpret_cast<const pq_f32x4*>(xr + min(max(g, 0), T - 4));
+#endif
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+#ifdef PQM_STAMPS
+  int stamp_n = 0;
+#endif
+  load_tile(t);
+  for (; t < ntiles; t += gridDim.x) {
+    const int b = t / tiles_x;
+    const int f_tile = (t - b * tiles_x) * FT;
+    const int g_tile = f_tile * N - pad;
+    const int a0 = g_tile & ~3, sh = g_tile - a0;
+    // groups of four are wholly inside or wholly outside the row (T % 4 == 0): zero padding of the convolution
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int j4 = tid + it * PQ_THREADS;
+      const int g = a0 + 4 * j4;
+      if (g < 0 || g >= T) e[it] = (pq_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+      if (j4 < NV4) *reinterpret_cast<pq_f32x4*>(s_in + C::pos(4 * j4)) = e[it];
+    }
+    __syncthreads();
+    PQM_STAMP(0);
+    load_tile(min(t + (int)gridDim.x, ntiles - 1));   // the last round reloads a tile nobody will use
+
+    pq_f32x4 acc[RT][CT];
+    int ab[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      ab[rt] = sh + RS * (16 * (wave * RT + rt) + r) + kq;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (pq_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    // Row tiles are taken in pairs (two independent accumulation chains).  The A values of pair p + 1 are read, one
+    // k-step per k-step, while pair p feeds the matrix core: every ds_read is a whole pair (2 KQ MFMAs, > 1000 cycles)
+    // ahead of its use.  Left to itself the compiler places each read two or three MFMAs ahead of its use, less than
+    // the LDS latency, and the MFMA stream of a wave runs at half rate (measured: 4800 instead of 2432 cycles a tile).
+    float av[2][2][KQ];
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) {
+      av[0][0][kk] = s_in[C::pos(ab[0] + 4 * kk)];
+      av[0][1][kk] = s_in[C::pos(ab[1] + 4 * kk)];
+    }
+#pragma unroll
+    for (int p = 0; p < RT / 2; ++p) {
+#pragma unroll
+      for (int kk = 0; kk < KQ; ++kk) {
+        if (p + 1 < RT / 2) {
+          av[(p + 1) & 1][0][kk] = s_in[C::pos(ab[2 * p + 2] + 4 * kk)];
+          av[(p + 1) & 1][1][kk] = s_in[C::pos(ab[2 * p + 3] + 4 * kk)];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+#ifdef PQM_NO_MFMA   /* diagnostics: everything but the matrix instructions */
+            acc[2 * p + h][ct][kk & 3] += av[p & 1][h][kk] * bf[ct][kk];
+#else
+            acc[2 * p + h][ct] =
+                __builtin_amdgcn_mfma_f32_16x16x4f32(av[p & 1][h][kk], bf[ct][kk], acc[2 * p + h][ct], 0, 0, 0);
+#endif
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    PQM_STAMP(1);
+    float* so = s_out + wave * (N * OROW);
+    const float rsc = pqmf_row_scale(rowpeak, b);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int col = 16 * ct + r;
+      if (col < C::NC) {
+        const int band = col / S, s = col - band * S;
+        const float m = nm[ct], sd = nsd[ct];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float o = pqmf_finish(acc[rt][ct][q], rsc, mean != nullptr, m, sd);
+            so[band * OROW + S * (16 * rt + 4 * kq + q) + s] = o;
+          }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    PQM_STAMP(2);
+    constexpr int W4 = WF / 4;
+    const int fw = f_tile + wave * WF;
+    for (int i = lane; i < N * W4; i += 64) {
+      const int band = i / W4, f = fw + 4 * (i - band * W4);
+      const pq_f32x4 v = *reinterpret_cast<const pq_f32x4*>(so + band * OROW + (f - fw));
+      float* zr = z + ((size_t)b * N + band) * L;
+#ifdef PQM_NO_STORE    /* diagnostics */
+      if (v[0] == 123.456f) zr[f] = v[1];
+#else
+      if (zvec && f + 3 < L) {
+        *reinterpret_cast<pq_f32x4*>(zr + f) = v;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (f + q < L) zr[f + q] = v[q];
+      }
+#endif
+    }
+    PQM_STAMP(3);
+    __syncthreads();   // every wave is done with the staged samples (and its output block) before the next tile
+    PQM_STAMP(4);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-pipelined form of the MFMA analysis for the folded cases (N S <= 16, one column tile: N = 3, 4).
+//
+// The workgroup-tiled kernel above alternates phases -- stage, barrier, MFMA, epilogue, store, barrier -- and all waves
+// of a SIMD end up in the same phase (they start together and share the matrix core fairly), so the matrix core idles
+// while they stage or store: 46 % busy at N = 3 (SQ_VALU_MFMA_BUSY_CYCLES), stamps: 3500 cycles of MFMA issue against
+// 3000-6000 of epilogue / store / staging per tile.  Here every wave is its own pipeline and there is no workgroup
+// barrier.  A wave tile is four row tiles (64 S frames) taken as two pairs; while pair p feeds the matrix core
+// (2 KQ MFMAs, about 1200 cycles) the same wave's instruction stream carries, between the MFMAs,
+//   * the A reads of the NEXT pair (a full pair ahead of their use),
+//   * the epilogue of the PREVIOUS pair: accumulators -> wave-private LDS block -> 16-byte global stores,
+//   * phase 0: staging of the next tile (registers -> the other LDS input buffer),
+//     phase 1: the global loads of the tile after that (in flight for a whole tile).
+// LDS traffic of one wave executes in order, so the write -> read hand-overs inside the wave need a compiler fence
+// but no s_waitcnt; the only waits are on data the MFMAs or stores consume.
+// s_waitcnt vmcnt(allow) that the uses of v cannot be scheduled above (allow is a constant once the caller is unrolled)
+__device__ __forceinline__ void pq_vm_wait(pq_f32x4& v, int allow) {
+  switch (allow) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" : "+v"(v)::"memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" : "+v"(v)::"memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" : "+v"(v)::"memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" : "+v"(v)::"memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" : "+v"(v)::"memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" : "+v"(v)::"memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" : "+v"(v)::"memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" : "+v"(v)::"memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory"); break;
+  }
+}
+
+template <int N, int K, int S, int PSH>
+struct PqmfPipe {
+  static constexpr int NC = N * S;
+  static_assert(NC <= 16, "one column tile");
+  static constexpr int KP = K + N * (S - 1), KQ = (KP + 3) / 4;
+  static constexpr int RS = N * S;
+  static constexpr int PF = 32 * S;                     // frames of a pair of row tiles
+  static constexpr int WF = 2 * PF;                     // frames of a wave tile
+  static constexpr int SPAN = (RS * 63 + 4 * KQ + 3 + 3) / 4 * 4;   // staged samples: shift + 64 rows + KQ k-steps
+  static constexpr int NV4 = SPAN / 4, NIT = (NV4 + 63) / 64;
+  __host__ __device__ static constexpr int pos(int j) { return PSH ? j + 4 * (j >> PSH) : j; }
+  static constexpr int INW = (pos(SPAN) + 4 + 3) / 4 * 4;
+  static constexpr int OROW = PF + 4;
+  static constexpr int WAVEW = (2 * INW + N * OROW + 20 * S + 3) / 4 * 4;   // two input buffers, the output block and
+                                                                         // the dump area of one wave
+  static constexpr int W4 = PF / 4;                     // 16-byte pieces per band and pair
+  static constexpr int NIO = (N * W4 + 63) / 64;
+  static constexpr int NEV = 8;                         // accumulator values per lane and pair
+  static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(PQ_THREADS / 64) * WAVEW;
+  static_assert(10 + NIT <= KQ - 4 && NEV + 1 <= 9, "slot plan of the phase loop");
+};
+
+template <int N, int K, int S, int PSH, bool NORM>
+__global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_pipe_kernel(
+    const float* __restrict__ x, const float* __restrict__ H, float* __restrict__ z, const float* __restrict__ mean,
+    const float* __restrict__ stdv, const float* __restrict__ rowpeak, int T, int L, int pad, int tiles_x, int ntiles,
+    int zvec /* always 1 here: z rows 16-byte aligned, L % 4 == 0 (the host sends other shapes to the tiled kernel) */) {
+  using C = PqmfPipe<N, K, S, PSH>;
+  constexpr int KQ = C::KQ, RS = C::RS, PF = C::PF, WF = C::WF, NV4 = C::NV4, NIT = C::NIT, OROW = C::OROW;
+  constexpr int NIO = C::NIO, W4 = C::W4, INW = C::INW;
+  extern __shared__ __attribute__((aligned(16))) float s_pm[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, kq = lane >> 4;
+  float* const s_in = s_pm + wave * C::WAVEW;           // [2][INW]
+  float* const so = s_in + 2 * INW;                     // [N][OROW]
+
+  const int band = min(r, C::NC - 1) / S, sfr = min(r, C::NC - 1) - band * S;
+  const bool live = r < C::NC;
+  float bf[KQ];
+#pragma unroll
+  for (int kk = 0; kk < KQ; ++kk) {
+    const int j = 4 * kk + kq - N * sfr;
+    bf[kk] = (live && j >= 0 && j < K) ? H[band * K + j] : 0.0f;
+  }
+  float nm = 0.0f, nsd = 1.0f;
+  if (NORM) { nm = mean[band]; nsd = stdv[band]; }
+  // where accumulator value (h, q) goes: ew + S (16 h + q); the lanes of the unused columns write a dump area instead
+  // (branch-free: the epilogue stays in the MFMA stream's basic block)
+  const int ew = live ? band * OROW + S * (4 * kq) + sfr : N * OROW;
+  int io_lds[NIO], io_glb[NIO], io_f[NIO];   // the 16-byte pieces of the output block this lane stores
+#pragma unroll
+  for (int i = 0; i < NIO; ++i) {
+    const int idx = lane + 64 * i, bnd = idx / W4, f4 = idx - bnd * W4;
+    io_lds[i] = idx < N * W4 ? bnd * OROW + 4 * f4 : -1;
+    io_glb[i] = bnd * L + 4 * f4;
+    io_f[i] = 4 * f4;
+  }
+
+  const int stride = gridDim.x * (PQ_THREADS / 64);
+  int t = blockIdx.x * (PQ_THREADS / 64) + wave;
+  if (t >= ntiles) return;                              // no workgroup barrier anywhere: waves leave on their own
+  // z as a raw buffer (byte offsets, range-checked by the hardware); the host keeps it below 2^31 - 16 bytes
+  const __amdgpu_buffer_rsrc_t zres =
+      __builtin_amdgcn_make_buffer_rsrc(z, 0, (int)((long long)(ntiles / tiles_x) * N * L * 4), 0x00020000);
+
+  // The tile loads are inline asm, outside the compiler's vmcnt bookkeeping, and waited for by hand (pq_vm_wait).  Left
+  // to the compiler, the staging wait in the loop becomes vmcnt(3..0): at the loop header it merges the entry path with
+  // the back edge and assumes nothing younger than the loads is in the queue, so the wave waits for the two stores of
+  // phase 1 (issued after the loads) to COMPLETE before it stages -- measured: 47 instead of 29 us.
+  // Queue when piece `it` is staged (phase 0, slots 10..): [rowpeak] L0 .. L(NIT-1) S x NIO, nothing younger: the wait is
+  // vmcnt(NIT - 1 - it + NIO).  The prologue issues NIO dropped stores after its loads so that the first tile sees the
+  // same queue.
+  pq_f32x4 e[NIT];
+  float pk_next = 1.0f;
+  auto load_tile = [&](int tt) {
+    const int b = tt / tiles_x;
+    const int a0 = ((tt - b * tiles_x) * WF * N - pad) & ~3;
+    const float* xr = x + (size_t)b * T;
+    if (rowpeak != nullptr) pk_next = rowpeak[b];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int g = a0 + 4 * min(lane + it * 64, NV4 - 1);
+      const float* src = xr + min(max(g, 0), T - 4);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(e[it]) : "v"(src) : "memory");
+    }
+  };
+  // groups of four samples are wholly inside or wholly outside the row (T % 4 == 0): zero padding of the convolution
+  auto stage_piece = [&](int it, int a0, float* buf, int allow) {
+    pq_vm_wait(e[it], allow);
+    const int j4 = lane + it * 64;
+    const int g = a0 + 4 * j4;
+    pq_f32x4 v = e[it];
+    if (g < 0 || g >= T) v = (pq_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    if (j4 < NV4) *reinterpret_cast<pq_f32x4*>(buf + C::pos(4 * j4)) = v;
+  };
+  auto tile_a0 = [&](int tt) { const int b = tt / tiles_x; return ((tt - b * tiles_x) * WF * N - pad) & ~3; };
+  auto tile_sh = [&](int tt) { const int b = tt / tiles_x; return ((tt - b * tiles_x) * WF * N - pad) & 3; };
+
+  // prologue: first tile staged, second tile in registers, A values of the first pair read
+  load_tile(t);
+  {
+    const int a0 = tile_a0(t);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) stage_piece(it, a0, s_in, 0);
+  }
+  float pk_cur = pk_next;
+  load_tile(min(t + stride, ntiles - 1));
+  // NIO stores the hardware drops (offset past the end): the queue shape stage_piece's wait counts on (see load_tile)
+#pragma unroll
+  for (int i = 0; i < NIO; ++i)
+    __builtin_amdgcn_raw_buffer_store_b128((pq_u32x4){0u, 0u, 0u, 0u}, zres, 0x7ffffff0 - 16 * i, 0, 0);   // (distinct:
+                                                                      // identical stores would be merged into one)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float av[2][2][KQ];
+  {
+    const int ab = tile_sh(t) + RS * r + kq;
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) {
+      av[0][0][kk] = s_in[C::pos(ab + 4 * kk)];
+      av[0][1][kk] = s_in[C::pos(ab + RS * 16 + 4 * kk)];
+    }
+  }
+
+  pq_f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (pq_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#ifdef PQP_NO_EPI
+  float sink = 0.0f;
+#endif
+  int cur = 0;
+  // the pair whose epilogue phase 0 carries: pair 1 of the previous tile (none yet: pL = 0 masks its stores)
+  int pb = 0, pf = 0, pL = 0;
+  float prsc = 1.0f;
+
+  for (; t < ntiles; t += stride) {
+    const int b = t / tiles_x;
+    const int f_tile = (t - b * tiles_x) * WF;
+    const int sh = tile_sh(t);
+    const int tn = min(t + stride, ntiles - 1);
+    const int a0n = tile_a0(tn), shn = tile_sh(tn);
+    const float rsc = pk_cur > 1.0f ? 1.0f / pk_cur : 1.0f;
+    const float pk_tn = pk_next;                        // peak of tile tn; phase 1 reloads pk_next for the tile after
+    float* const bufc = s_in + cur * INW;
+    float* const bufn = s_in + (cur ^ 1) * INW;
+
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+      // A values to read in this phase: pair 1 of this tile (phase 0) / pair 0 of the next tile (phase 1)
+      const float* abuf = P == 0 ? bufc : bufn;
+      const int ab = (P == 0 ? sh + RS * 32 : shn) + RS * r + kq;
+      // epilogue carried by this phase: pair 1 of the previous tile (phase 0) / pair 0 of this tile (phase 1)
+      const int eb = P == 0 ? pb : b, ef = P == 0 ? pf : f_tile, eL = P == 0 ? pL : L;
+      const float ersc = P == 0 ? prsc : rsc;
+      pq_f32x4 ov[NIO];
+#pragma unroll
+      for (int kk = 0; kk < KQ; ++kk) {
+#ifndef PQP_NO_AREAD
+        av[P ^ 1][0][kk] = abuf[C::pos(ab + 4 * kk)];
+        av[P ^ 1][1][kk] = abuf[C::pos(ab + RS * 16 + 4 * kk)];
+#endif
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const pq_f32x4 cin = kk == 0 ? (pq_f32x4){0.0f, 0.0f, 0.0f, 0.0f} : acc[2 * P + h];
+          acc[2 * P + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[P][h][kk], bf[kk], cin, 0, 0, 0);
+        }
+#ifdef PQP_NO_EPI   /* diagnostics: the accumulators stay live through one value per phase */
+        if (kk == 1) sink += acc[2 * (P ^ 1)][0] + acc[2 * (P ^ 1) + 1][3];
+#endif
+#ifdef PQP_NO_AREAD
+        if (kk == 0) {
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) asm volatile("" : "+v"(av[P ^ 1][0][q]), "+v"(av[P ^ 1][1][q]));
+        }
+#endif
+#ifndef PQP_NO_EPI
+        if (kk >= 1 && kk <= 8) {                         // one accumulator value of the other pair -> LDS block
+          const int j = kk - 1, h = j >> 2, q = j & 3;
+          const float o = pqmf_finish(acc[2 * (P ^ 1) + h][q], ersc, NORM, nm, nsd);
+#ifdef PQP_NO_LDSW
+          asm volatile("" ::"v"(o));
+#else
+          so[ew + S * (16 * h + q)] = o;
+#endif
+        }
+        if (kk == 9) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int i = 0; i < NIO; ++i)
+            ov[i] = *reinterpret_cast<const pq_f32x4*>(so + max(io_lds[i], 0));
+        }
+#endif
+#ifndef PQP_NO_STAGE
+        // staging ahead of the stores: its vmcnt wait then covers the loads (issued a phase ago) and nothing younger
+        if (P == 0 && kk >= 10 && kk < 10 + NIT) stage_piece(kk - 10, a0n, bufn, NIT - 1 - (kk - 10) + NIO);
+#endif
+#ifndef PQP_NO_EPI
+        if (kk == KQ - 4) {
+          // Buffer stores: a piece outside the row (L % 4 == 0: wholly inside or wholly outside) gets an offset past
+          // the end of the buffer and the hardware drops it.  No exec-masked branch: with one, the compiler cannot count
+          // the stores in vmcnt and the staging wait of the next phase falls back to waiting for them to COMPLETE.
+          const int zoff = (eb * N * L + ef) * 4;
+#pragma unroll
+          for (int i = 0; i < NIO; ++i) {
+            const bool ok = io_lds[i] >= 0 && ef + io_f[i] < eL;
+#ifdef PQP_NO_GSTORE
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pq_u32x4, ov[i]), zres,
+                                                   ok && ov[i][0] == 123.456f ? zoff + 4 * io_glb[i] : 0x7ffffff0, 0, 0);
+#else
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pq_u32x4, ov[i]), zres,
+                                                   ok ? zoff + 4 * io_glb[i] : 0x7ffffff0, 0, 0);
+#endif
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the block is free for the next pair's values
+          __builtin_amdgcn_wave_barrier();
+        }
+#endif
+#ifndef PQP_NO_STAGE
+        if (P == 1 && kk == 0) load_tile(min(t + 2 * stride, ntiles - 1));
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (P == 0) {   // the staged tile is visible to the A reads of phase 1
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    pb = b; pf = f_tile + PF; pL = L; prsc = rsc;
+    pk_cur = pk_tn;
+    cur ^= 1;
+  }
+
+#ifdef PQP_NO_EPI
+  if (sink == 123.456f) z[lane] = sink;
+#endif
+  // drain: pair 1 of the last tile
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int h = j >> 2, q = j & 3;
+    const float o = pqmf_finish(acc[2 + h][q], prsc, NORM, nm, nsd);
+    so[ew + S * (16 * h + q)] = o;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float* zt = z + (size_t)pb * N * L + pf;
+#pragma unroll
+  for (int i = 0; i < NIO; ++i) {
+    if (io_lds[i] < 0) continue;
+    const pq_f32x4 v = *reinterpret_cast<const pq_f32x4*>(so + io_lds[i]);
+    const int f = pf + io_f[i];
+    if (f < pL) *reinterpret_cast<pq_f32x4*>(zt + io_glb[i]) = v;
   }
 }
 
@@ -298,8 +814,8 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_wide_kernel(
   for (int k = 0; k < HB; ++k) {
     const int band = half * HB + k;
     if (band < N) {
-      float o = acc[k] * rsc;
-      if (mean != nullptr) o = (o - mean[band]) / stdv[band];
+      const bool nrm = mean != nullptr;
+      const float o = pqmf_finish(acc[k], rsc, nrm, nrm ? mean[band] : 0.0f, nrm ? stdv[band] : 1.0f);
       z[((size_t)b * N + band) * L + f] = o;
     }
   }
@@ -334,9 +850,9 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_generic_kernel(
     const long long i = s + j;
     if (i >= 0 && i < T) acc = fmaf(xr[i], h[j], acc);
   }
-  acc *= pqmf_row_scale(rowpeak, b);
-  if (mean != nullptr) acc = (acc - mean[k]) / stdv[k];
-  z[((size_t)b * N + k) * L + f] = acc;
+  const bool nrm = mean != nullptr;
+  z[((size_t)b * N + k) * L + f] =
+      pqmf_finish(acc, pqmf_row_scale(rowpeak, b), nrm, nrm ? mean[k] : 0.0f, nrm ? stdv[k] : 1.0f);
 }
 
 // Synthesis in polyphase form (the zero-stuffed [B,N,L*N] tensor is never built):
@@ -515,7 +1031,56 @@ extern "C" int ias_pqmf_analysis(const float* x, const float* H, const float* pa
   const int L = ias_pqmf_out_len(T, N, K);
   if (L <= 0) return IAS_ERR_ARG;
   if (packed && ((uintptr_t)packed & 7)) return IAS_ERR_ARG;
-  if (packed && (N == 3 || N == 4) && K == 63 && T >= N && (long long)L * N + 2 * K < 0x7fffffffLL) {
+  static const bool force_valu = getenv("IAS_PQMF_VALU") != nullptr;   // diagnostics: the pre-MFMA kernels
+  if (!force_valu && K == 63 && (N == 3 || N == 64) && T >= 4 && (T & 3) == 0 && ((uintptr_t)x & 15) == 0 &&
+      (long long)L * N + 4 * K < 0x7fffffffLL) {
+    const int zvec = ((uintptr_t)z & 15) == 0 && (L & 3) == 0;
+#define IAS_PQM_LAUNCH(NN, SS, RTT, PSHH, PERCU)                                                                  \
+    do {                                                                                                          \
+      using C = PqmfMfma<NN, 63, SS, RTT, PSHH>;                                                                  \
+      auto kern = pqmf_analysis_mfma_kernel<NN, 63, SS, RTT, PSHH>;                                               \
+      static bool attr_set = false;                                                                               \
+      if (!attr_set) {                                                                                            \
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,                    \
+                                (int)C::LDS_BYTES) != hipSuccess) return IAS_ERR_LAUNCH;                          \
+        attr_set = true;                                                                                          \
+      }                                                                                                           \
+      const int tiles_x = (L + C::FT - 1) / C::FT;                                                                \
+      const long long ntiles = (long long)tiles_x * B;                                                            \
+      if (ntiles > 0x7fffffffLL) return IAS_ERR_ARG;                                                              \
+      const long long res = (long long)pqmf_resident_blocks() / 4 * PERCU;                                        \
+      const int grid = (int)(ntiles < res ? ntiles : res);                                                        \
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(PQ_THREADS), C::LDS_BYTES, stream, x, H, z, mean, stdv, rowpeak, T, \
+                         L, pad, tiles_x, (int)ntiles, zvec);                                                     \
+    } while (0)
+    static const int percu = getenv("IAS_PQM_PERCU") ? atoi(getenv("IAS_PQM_PERCU")) : 0;
+    static const bool tiled = getenv("IAS_PQM_TILED") != nullptr;   // diagnostics: workgroup-tiled kernel for N = 3, 4 too
+#define IAS_PQP_LAUNCH(NN, SS, PSHH, NORMM, PERCU)                                                                \
+    do {                                                                                                          \
+      using C = PqmfPipe<NN, 63, SS, PSHH>;                                                                       \
+      auto kern = pqmf_analysis_pipe_kernel<NN, 63, SS, PSHH, NORMM>;                                             \
+      static bool attr_set = false;                                                                               \
+      if (!attr_set) {                                                                                            \
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,                    \
+                                (int)C::LDS_BYTES) != hipSuccess) return IAS_ERR_LAUNCH;                          \
+        attr_set = true;                                                                                          \
+      }                                                                                                           \
+      const int tiles_x = (L + C::WF - 1) / C::WF;                                                                \
+      const long long ntiles = (long long)tiles_x * B;              /* wave tiles */                              \
+      if (ntiles > 0x7fffffffLL) return IAS_ERR_ARG;                                                              \
+      const long long wgs = (ntiles + PQ_THREADS / 64 - 1) / (PQ_THREADS / 64);                                   \
+      const long long res = (long long)pqmf_resident_blocks() / 4 * PERCU;                                        \
+      const int grid = (int)(wgs < res ? wgs : res);                                                              \
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(PQ_THREADS), C::LDS_BYTES, stream, x, H, z, mean, stdv, rowpeak, T, \
+                         L, pad, tiles_x, (int)ntiles, zvec);                                                     \
+    } while (0)
+    if (N == 3 && !tiled && zvec && (long long)B * N * L * 4 < 0x7fffff00LL) {
+      if (mean) IAS_PQP_LAUNCH(3, 5, 0, true, (percu ? percu : 3)); else IAS_PQP_LAUNCH(3, 5, 0, false, (percu ? percu : 3));
+    } else if (N == 3) IAS_PQM_LAUNCH(3, 5, 4, 0, (percu ? percu : 3));
+    else IAS_PQM_LAUNCH(64, 1, 2, 6, (percu ? percu : 2));
+#undef IAS_PQP_LAUNCH
+#undef IAS_PQM_LAUNCH
+  } else if (packed && (N == 3 || N == 4) && K == 63 && T >= N && (long long)L * N + 2 * K < 0x7fffffffLL) {
     constexpr int FT = PqmfFast<3, 63>::FT;
     const int tiles_x = (L + FT - 1) / FT;
     const long long ntiles = (long long)tiles_x * B;

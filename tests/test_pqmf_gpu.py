@@ -154,3 +154,36 @@ def test_synthesis_vs_oracle(lib, dev, N, taps, L):
     got = m.synthesis(z.to(dev)).cpu()
     assert got.shape == ref.shape
     np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=1e-4 * max(1.0, float(ref.abs().max())))
+
+
+@pytest.mark.parametrize("N,B,T", [(3, 5, 176400), (3, 2, 4100), (4, 3, 20004), (64, 2, 176400), (64, 3, 8192)])
+def test_matrix_core_path_is_bit_identical_to_the_vector_kernels(lib, dev, N, B, T):
+    """The fp32 MFMA analysis (16-byte aligned rows, T % 4 == 0) and the VALU kernels (taken for any other alignment)
+    evaluate the same tap-ordered fmaf chain per output: the results must agree bit for bit, with and without the
+    fused band normalisation and row scale.  A misaligned view of the same samples selects the VALU kernels."""
+    from inverse_audio_synthesis_amd import _lib
+    m = _mod(dev, N)
+    Hc = m.H.reshape(N, 63).contiguous()
+    packed = torch.empty(lib.ias_pqmf_packed_taps_len(N, 63), device=dev)
+    assert lib.ias_pqmf_pack_taps(_lib.ptr(Hc), _lib.ptr(packed), N, 63, _lib.stream()) == 0
+    x = randn((B, T), 4000 + N).to(dev)
+    x[0, :40] = 0.0
+    x[-1, -100:] *= 1e-30                              # subnormal products
+    xa = x.contiguous()
+    xm = torch.empty(B * T + 1, device=dev)[1:]
+    xm.copy_(x.flatten())
+    assert _lib.ptr(xa).value % 16 == 0 and _lib.ptr(xm).value % 16 != 0
+    L = lib.ias_pqmf_out_len(T, N, 63)
+    mean = torch.linspace(-0.1, 0.1, N, device=dev)
+    std = torch.linspace(0.5, 1.5, N, device=dev)
+    peak = torch.linspace(0.5, 3.0, B, device=dev)
+    for fused in (False, True):
+        za = torch.full((B, N, L), 7.0, device=dev)
+        zm = torch.full((B, N, L), 9.0, device=dev)
+        args = (_lib.ptr(mean), _lib.ptr(std), _lib.ptr(peak)) if fused else (None, None, None)
+        assert lib.ias_pqmf_analysis(_lib.ptr(xa), _lib.ptr(Hc), _lib.ptr(packed), _lib.ptr(za), *args, B, T, N, 63,
+                                     _lib.stream()) == 0
+        assert lib.ias_pqmf_analysis(_lib.ptr(xm), _lib.ptr(Hc), _lib.ptr(packed), _lib.ptr(zm), *args, B, T, N, 63,
+                                     _lib.stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(za, zm), f"max diff {(za - zm).abs().max().item():.3e}"
