@@ -279,18 +279,6 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_fast_kernel(
 // in registers; the residual shift (0..3 samples) is added to the A read address.
 typedef float pq_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned pq_u32x4 __attribute__((ext_vector_type(4)));
-#ifdef PQM_STAMPS   /* diagnostics: s_memtime of workgroup 0's waves at five points of its first tiles, written over z */
-#define PQM_STAMP(i)                                                                                         \
-  do {                                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if (blockIdx.x == 0 && lane == 0 && stamp_n < 6)                                                         \
-      reinterpret_cast<unsigned long long*>(z)[(wave * 6 + stamp_n) * 5 + (i)] = __builtin_readcyclecounter(); \
-    if ((i) == 4) ++stamp_n;                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-  } while (0)
-#else
-#define PQM_STAMP(i)
-#endif
 
 template <int N, int K, int S, int RT, int PSH>
 struct PqmfMfma {
@@ -357,19 +345,12 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_mfma_kernel(
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int g = a0 + 4 * min(tid + it * PQ_THREADS, NV4 - 1);
-#ifdef PQM_NO_LOAD   /* diagnostics */
-      e[it] = (pq_f32x4){(float)g, 1.0f, 2.0f, (float)tid};
-#else
       e[it] = *reinterpret_cast<const pq_f32x4*>(xr + min(max(g, 0), T - 4));
-#endif
     }
   };
 
   int t = blockIdx.x;
   if (t >= ntiles) return;
-#ifdef PQM_STAMPS
-  int stamp_n = 0;
-#endif
   load_tile(t);
   for (; t < ntiles; t += gridDim.x) {
     const int b = t / tiles_x;
@@ -385,7 +366,6 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_mfma_kernel(
       if (j4 < NV4) *reinterpret_cast<pq_f32x4*>(s_in + C::pos(4 * j4)) = e[it];
     }
     __syncthreads();
-    PQM_STAMP(0);
     load_tile(min(t + (int)gridDim.x, ntiles - 1));   // the last round reloads a tile nobody will use
 
     pq_f32x4 acc[RT][CT];
@@ -418,18 +398,12 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_mfma_kernel(
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
-#ifdef PQM_NO_MFMA   /* diagnostics: everything but the matrix instructions */
-            acc[2 * p + h][ct][kk & 3] += av[p & 1][h][kk] * bf[ct][kk];
-#else
             acc[2 * p + h][ct] =
                 __builtin_amdgcn_mfma_f32_16x16x4f32(av[p & 1][h][kk], bf[ct][kk], acc[2 * p + h][ct], 0, 0, 0);
-#endif
           }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-
-    PQM_STAMP(1);
     float* so = s_out + wave * (N * OROW);
     const float rsc = pqmf_row_scale(rowpeak, b);
 #pragma unroll
@@ -449,16 +423,12 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_mfma_kernel(
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    PQM_STAMP(2);
     constexpr int W4 = WF / 4;
     const int fw = f_tile + wave * WF;
     for (int i = lane; i < N * W4; i += 64) {
       const int band = i / W4, f = fw + 4 * (i - band * W4);
       const pq_f32x4 v = *reinterpret_cast<const pq_f32x4*>(so + band * OROW + (f - fw));
       float* zr = z + ((size_t)b * N + band) * L;
-#ifdef PQM_NO_STORE    /* diagnostics */
-      if (v[0] == 123.456f) zr[f] = v[1];
-#else
       if (zvec && f + 3 < L) {
         *reinterpret_cast<pq_f32x4*>(zr + f) = v;
       } else {
@@ -466,11 +436,8 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_mfma_kernel(
         for (int q = 0; q < 4; ++q)
           if (f + q < L) zr[f + q] = v[q];
       }
-#endif
     }
-    PQM_STAMP(3);
     __syncthreads();   // every wave is done with the staged samples (and its output block) before the next tile
-    PQM_STAMP(4);
   }
 }
 
@@ -505,6 +472,17 @@ __device__ __forceinline__ void pq_vm_wait(pq_f32x4& v, int allow) {
   }
 }
 
+__device__ __forceinline__ void pq_vm_wait1(float& v, int allow) {
+  switch (allow) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" : "+v"(v)::"memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" : "+v"(v)::"memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" : "+v"(v)::"memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" : "+v"(v)::"memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory"); break;
+  }
+}
+
 template <int N, int K, int S, int PSH>
 struct PqmfPipe {
   static constexpr int NC = N * S;
@@ -524,7 +502,7 @@ struct PqmfPipe {
   static constexpr int NIO = (N * W4 + 63) / 64;
   static constexpr int NEV = 8;                         // accumulator values per lane and pair
   static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(PQ_THREADS / 64) * WAVEW;
-  static_assert(10 + NIT <= KQ - 4 && NEV + 1 <= 9, "slot plan of the phase loop");
+  static_assert(10 + NIT <= KQ - 4 && NEV + 1 <= 9 && NIT - 1 + NIO + 1 <= 8 && NIO <= 4, "slot plan of the phase loop");
 };
 
 template <int N, int K, int S, int PSH, bool NORM>
@@ -536,7 +514,7 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_pipe_kernel(
   constexpr int KQ = C::KQ, RS = C::RS, PF = C::PF, WF = C::WF, NV4 = C::NV4, NIT = C::NIT, OROW = C::OROW;
   constexpr int NIO = C::NIO, W4 = C::W4, INW = C::INW;
   extern __shared__ __attribute__((aligned(16))) float s_pm[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int r = lane & 15, kq = lane >> 4;
   float* const s_in = s_pm + wave * C::WAVEW;           // [2][INW]
   float* const so = s_in + 2 * INW;                     // [N][OROW]
@@ -563,55 +541,61 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_pipe_kernel(
     io_f[i] = 4 * f4;
   }
 
+  // Tile bookkeeping is wave-uniform and kept in SGPRs: (row b, tile tx of the row) advance by the grid stride
+  // without a division per tile.
   const int stride = gridDim.x * (PQ_THREADS / 64);
+  const int stride_b = stride / tiles_x, stride_x = stride - stride_b * tiles_x;
   int t = blockIdx.x * (PQ_THREADS / 64) + wave;
   if (t >= ntiles) return;                              // no workgroup barrier anywhere: waves leave on their own
-  // z as a raw buffer (byte offsets, range-checked by the hardware); the host keeps it below 2^31 - 16 bytes
+  struct Tile { int b, tx; };
+  auto advance = [&](Tile c) {
+    c.b += stride_b; c.tx += stride_x;
+    if (c.tx >= tiles_x) { c.tx -= tiles_x; ++c.b; }
+    return c;
+  };
+  auto tile_g0 = [&](Tile c) { return c.tx * (WF * N) - pad; };   // first sample of the tile (may be negative)
+  // z as a raw buffer (byte offsets, range-checked by the hardware); the host keeps it below 2^31 - 256 bytes
   const __amdgpu_buffer_rsrc_t zres =
       __builtin_amdgcn_make_buffer_rsrc(z, 0, (int)((long long)(ntiles / tiles_x) * N * L * 4), 0x00020000);
 
-  // The tile loads are inline asm, outside the compiler's vmcnt bookkeeping, and waited for by hand (pq_vm_wait).  Left
-  // to the compiler, the staging wait in the loop becomes vmcnt(3..0): at the loop header it merges the entry path with
-  // the back edge and assumes nothing younger than the loads is in the queue, so the wave waits for the two stores of
-  // phase 1 (issued after the loads) to COMPLETE before it stages -- measured: 47 instead of 29 us.
-  // Queue when piece `it` is staged (phase 0, slots 10..): [rowpeak] L0 .. L(NIT-1) S x NIO, nothing younger: the wait is
-  // vmcnt(NIT - 1 - it + NIO).  The prologue issues NIO dropped stores after its loads so that the first tile sees the
-  // same queue.
+  // Tile loads: buffer loads over the ROW (base x + b T, T * 4 bytes), so the zero padding of the convolution is the
+  // hardware's range check (an offset below 0 or past the row returns 0) and there is no clamping or masking on the
+  // VALU.  They are inline asm, outside the compiler's vmcnt bookkeeping, and waited for by hand (pq_vm_wait): left to
+  // the compiler, the staging wait in the loop becomes vmcnt(3..0) -- at the loop header it merges the entry path with
+  // the back edge and assumes nothing younger than the loads is in the queue -- and the wave waits for the stores of
+  // phase 1 (issued after the loads) to COMPLETE before it stages.
+  // Queue when piece `it` is staged (phase 0, slots 10..): L0 .. L(NIT-1) (phase 1 slot 0), S x NIO (phase 1), PK (the row
+  // peak of this tile, phase 0 slot 0), nothing younger: the wait is vmcnt(NIT - 1 - it + NIO + 1).  The prologue issues NIO
+  // dropped stores after its loads so that the first tile sees the same queue.  The peak is waited for in slot 16 behind
+  // the NIO stores of phase 0: vmcnt(NIO).  Nothing in flight is carried in a register across the loop's back edge
+  // except e[], which the loop only ever touches through the asm statements (no copies).
   pq_f32x4 e[NIT];
-  float pk_next = 1.0f;
-  auto load_tile = [&](int tt) {
-    const int b = tt / tiles_x;
-    const int a0 = ((tt - b * tiles_x) * WF * N - pad) & ~3;
-    const float* xr = x + (size_t)b * T;
-    if (rowpeak != nullptr) pk_next = rowpeak[b];
+  float pk = 1.0f;
+  const int lane16 = lane * 16;
+  auto load_tile = [&](Tile c) {
+    const float* xr = x + (size_t)c.b * T;
+    const pq_u32x4 rs = {(unsigned)(uintptr_t)xr, (unsigned)((uintptr_t)xr >> 32), (unsigned)T * 4u, 0x00020000u};
+    const int voff = lane16 + 4 * (tile_g0(c) & ~3);
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int g = a0 + 4 * min(lane + it * 64, NV4 - 1);
-      const float* src = xr + min(max(g, 0), T - 4);
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(e[it]) : "v"(src) : "memory");
-    }
+    for (int it = 0; it < NIT; ++it)
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3"
+                   : "=v"(e[it]) : "v"(voff), "s"(rs), "n"(1024 * it) : "memory");
   };
-  // groups of four samples are wholly inside or wholly outside the row (T % 4 == 0): zero padding of the convolution
-  auto stage_piece = [&](int it, int a0, float* buf, int allow) {
+  auto stage_piece = [&](int it, float* buf, int allow) {
     pq_vm_wait(e[it], allow);
     const int j4 = lane + it * 64;
-    const int g = a0 + 4 * j4;
-    pq_f32x4 v = e[it];
-    if (g < 0 || g >= T) v = (pq_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    if (j4 < NV4) *reinterpret_cast<pq_f32x4*>(buf + C::pos(4 * j4)) = v;
+    if (NV4 % 64 == 0 || j4 < NV4) *reinterpret_cast<pq_f32x4*>(buf + C::pos(4 * j4)) = e[it];
   };
-  auto tile_a0 = [&](int tt) { const int b = tt / tiles_x; return ((tt - b * tiles_x) * WF * N - pad) & ~3; };
-  auto tile_sh = [&](int tt) { const int b = tt / tiles_x; return ((tt - b * tiles_x) * WF * N - pad) & 3; };
 
   // prologue: first tile staged, second tile in registers, A values of the first pair read
-  load_tile(t);
-  {
-    const int a0 = tile_a0(t);
+  Tile cur;
+  cur.b = t / tiles_x;
+  cur.tx = t - cur.b * tiles_x;
+  load_tile(cur);
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) stage_piece(it, a0, s_in, 0);
-  }
-  float pk_cur = pk_next;
-  load_tile(min(t + stride, ntiles - 1));
+  for (int it = 0; it < NIT; ++it) stage_piece(it, s_in, 0);
+  Tile nxt = t + stride < ntiles ? advance(cur) : cur;
+  load_tile(nxt);
   // NIO stores the hardware drops (offset past the end): the queue shape stage_piece's wait counts on (see load_tile)
 #pragma unroll
   for (int i = 0; i < NIO; ++i)
@@ -620,8 +604,9 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_pipe_kernel(
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   float av[2][2][KQ];
+  const int abl = RS * r + kq;                          // lane part of an A read index
   {
-    const int ab = tile_sh(t) + RS * r + kq;
+    const int ab = (tile_g0(cur) & 3) + abl;
 #pragma unroll
     for (int kk = 0; kk < KQ; ++kk) {
       av[0][0][kk] = s_in[C::pos(ab + 4 * kk)];
@@ -632,63 +617,42 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_pipe_kernel(
   pq_f32x4 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = (pq_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-#ifdef PQP_NO_EPI
-  float sink = 0.0f;
-#endif
-  int cur = 0;
+  int cbuf = 0;
   // the pair whose epilogue phase 0 carries: pair 1 of the previous tile (none yet: pL = 0 masks its stores)
   int pb = 0, pf = 0, pL = 0;
   float prsc = 1.0f;
 
   for (; t < ntiles; t += stride) {
-    const int b = t / tiles_x;
-    const int f_tile = (t - b * tiles_x) * WF;
-    const int sh = tile_sh(t);
-    const int tn = min(t + stride, ntiles - 1);
-    const int a0n = tile_a0(tn), shn = tile_sh(tn);
-    const float rsc = pk_cur > 1.0f ? 1.0f / pk_cur : 1.0f;
-    const float pk_tn = pk_next;                        // peak of tile tn; phase 1 reloads pk_next for the tile after
-    float* const bufc = s_in + cur * INW;
-    float* const bufn = s_in + (cur ^ 1) * INW;
+    const int b = cur.b;
+    const int f_tile = cur.tx * WF;
+    const int sh = tile_g0(cur) & 3, shn = tile_g0(nxt) & 3;
+    const Tile nx2 = t + 2 * stride < ntiles ? advance(nxt) : nxt;
+    float rsc = 1.0f;                                   // row scale of this tile: known from slot 16 of phase 0 on
+    float* const bufc = s_in + cbuf * INW;
+    float* const bufn = s_in + (cbuf ^ 1) * INW;
 
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
       // A values to read in this phase: pair 1 of this tile (phase 0) / pair 0 of the next tile (phase 1)
       const float* abuf = P == 0 ? bufc : bufn;
-      const int ab = (P == 0 ? sh + RS * 32 : shn) + RS * r + kq;
+      const int ab = (P == 0 ? sh + RS * 32 : shn) + abl;
       // epilogue carried by this phase: pair 1 of the previous tile (phase 0) / pair 0 of this tile (phase 1)
       const int eb = P == 0 ? pb : b, ef = P == 0 ? pf : f_tile, eL = P == 0 ? pL : L;
       const float ersc = P == 0 ? prsc : rsc;
       pq_f32x4 ov[NIO];
 #pragma unroll
       for (int kk = 0; kk < KQ; ++kk) {
-#ifndef PQP_NO_AREAD
         av[P ^ 1][0][kk] = abuf[C::pos(ab + 4 * kk)];
         av[P ^ 1][1][kk] = abuf[C::pos(ab + RS * 16 + 4 * kk)];
-#endif
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const pq_f32x4 cin = kk == 0 ? (pq_f32x4){0.0f, 0.0f, 0.0f, 0.0f} : acc[2 * P + h];
           acc[2 * P + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[P][h][kk], bf[kk], cin, 0, 0, 0);
         }
-#ifdef PQP_NO_EPI   /* diagnostics: the accumulators stay live through one value per phase */
-        if (kk == 1) sink += acc[2 * (P ^ 1)][0] + acc[2 * (P ^ 1) + 1][3];
-#endif
-#ifdef PQP_NO_AREAD
-        if (kk == 0) {
-#pragma unroll
-          for (int q = 0; q < KQ; ++q) asm volatile("" : "+v"(av[P ^ 1][0][q]), "+v"(av[P ^ 1][1][q]));
-        }
-#endif
-#ifndef PQP_NO_EPI
         if (kk >= 1 && kk <= 8) {                         // one accumulator value of the other pair -> LDS block
           const int j = kk - 1, h = j >> 2, q = j & 3;
           const float o = pqmf_finish(acc[2 * (P ^ 1) + h][q], ersc, NORM, nm, nsd);
-#ifdef PQP_NO_LDSW
-          asm volatile("" ::"v"(o));
-#else
           so[ew + S * (16 * h + q)] = o;
-#endif
         }
         if (kk == 9) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -698,12 +662,12 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_pipe_kernel(
           for (int i = 0; i < NIO; ++i)
             ov[i] = *reinterpret_cast<const pq_f32x4*>(so + max(io_lds[i], 0));
         }
-#endif
-#ifndef PQP_NO_STAGE
         // staging ahead of the stores: its vmcnt wait then covers the loads (issued a phase ago) and nothing younger
-        if (P == 0 && kk >= 10 && kk < 10 + NIT) stage_piece(kk - 10, a0n, bufn, NIT - 1 - (kk - 10) + NIO);
-#endif
-#ifndef PQP_NO_EPI
+        if (P == 0 && kk == 0) {   // (always issued, from a dummy address without row peaks: the queue shape is fixed)
+          const float* pp = rowpeak != nullptr ? rowpeak + b : x;
+          asm volatile("global_load_dword %0, %1, %2" : "=v"(pk) : "v"(0), "s"(pp) : "memory");
+        }
+        if (P == 0 && kk >= 10 && kk < 10 + NIT) stage_piece(kk - 10, bufn, NIT - 1 - (kk - 10) + NIO + 1);
         if (kk == KQ - 4) {
           // Buffer stores: a piece outside the row (L % 4 == 0: wholly inside or wholly outside) gets an offset past
           // the end of the buffer and the hardware drops it.  No exec-masked branch: with one, the compiler cannot count
@@ -712,21 +676,17 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_pipe_kernel(
 #pragma unroll
           for (int i = 0; i < NIO; ++i) {
             const bool ok = io_lds[i] >= 0 && ef + io_f[i] < eL;
-#ifdef PQP_NO_GSTORE
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pq_u32x4, ov[i]), zres,
-                                                   ok && ov[i][0] == 123.456f ? zoff + 4 * io_glb[i] : 0x7ffffff0, 0, 0);
-#else
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pq_u32x4, ov[i]), zres,
                                                    ok ? zoff + 4 * io_glb[i] : 0x7ffffff0, 0, 0);
-#endif
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the block is free for the next pair's values
           __builtin_amdgcn_wave_barrier();
         }
-#endif
-#ifndef PQP_NO_STAGE
-        if (P == 1 && kk == 0) load_tile(min(t + 2 * stride, ntiles - 1));
-#endif
+        if (P == 0 && kk == KQ - 3) {
+          pq_vm_wait1(pk, NIO);
+          rsc = (rowpeak != nullptr && pk > 1.0f) ? 1.0f / pk : 1.0f;
+        }
+        if (P == 1 && kk == 0) load_tile(nx2);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (P == 0) {   // the staged tile is visible to the A reads of phase 1
@@ -736,13 +696,15 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_pipe_kernel(
       }
     }
     pb = b; pf = f_tile + PF; pL = L; prsc = rsc;
-    pk_cur = pk_tn;
-    cur ^= 1;
+    cbuf ^= 1;
+    cur = nxt; nxt = nx2;
   }
 
-#ifdef PQP_NO_EPI
-  if (sink == 123.456f) z[lane] = sink;
-#endif
+  // The loads the last phase 1 issued are still in flight and nobody consumes them.  They must have landed before the
+  // compiler may reuse their registers (it does not know they are pending: a late arrival would overwrite whatever
+  // lives there by then, e.g. a store address of the drain below).
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) pq_vm_wait(e[it], 0);
   // drain: pair 1 of the last tile
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
