@@ -112,8 +112,11 @@ int ias_pqmf_packed_taps_len(int N, int K);
 int ias_pqmf_pack_taps(const float* H, float* packed, int N, int K, void* stream);
 
 /* analysis: x [B,T] (= [B,1,T]), H [N,K] (= buffer H[N,1,K]) -> z [B,N,L]   (pqmf.py:49-50).
- * packed: the ias_pqmf_pack_taps table of H, or NULL (generic one-lane-per-output kernel, same sums in the same
- * order, 10-100x slower).
+ * K = 63 with N = 3 or 64, x 16-byte aligned and T % 4 == 0: the filterbank runs on the fp32 matrix cores
+ * (v_mfma_f32_16x16x4_f32, exact fp32; N = 3 with z 16-byte aligned and L % 4 == 0: the wave-pipelined kernel) and
+ * `packed` is not read.  Otherwise: packed = the ias_pqmf_pack_taps table of H (fast / wide VALU kernels), or NULL
+ * (generic one-lane-per-output kernel, 10-100x slower).  Every path evaluates the same tap-ordered fmaf chain per
+ * output: results are bit-identical across them.
  * mean/stdv [N] (both or neither, may be NULL): fused (z - mean[k]) / stdv[k] of
  * AudioEmbedding._preprocess (reference audioembed.py:41,49).
  * rowpeak [B] (may be NULL): row peaks of x; the result is the analysis of x[b] / rowpeak[b] where rowpeak[b] > 1
