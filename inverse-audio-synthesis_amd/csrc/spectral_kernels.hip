@@ -14,15 +14,24 @@
 // overlap, so the second touch of a sample is served by L1/L2 and every audio sample comes from HBM
 // ~once: algorithmic bytes = 4 B in per sample + 4*bins/hop B out (or the same to read a cached target).
 #include "ias_common.h"
+#include <cstdlib>
 
-#define SP_THREADS 256
-#define SP_WAVES 4
-#define SP_FPB_MAX 8   // frames per workgroup (8, or 4 when the staged span would not fit LDS)
+// Waves per workgroup.  The per-lane tables (14.8 KB at n_fft 1024) are one LDS copy per workgroup and a wave's FFT
+// scratch is 4.6 KB: with 4 waves a workgroup needs 36 KB and a CU holds 4 of them = 4 waves per SIMD; with 10 waves it
+// needs 66 KB and a CU holds 2 = 5 waves per SIMD (the kernel is bound by the latency of its LDS round trips, five per
+// frame, not by a unit: VALU and LDS are each ~50 % busy).  n_fft 1024 (<= 96 VGPRs) takes the 10-wave form.
+#define SP_WAVES_MAX 10
+static int stft_waves(int n_fft) { (void)n_fft; return getenv("IAS_STFT_WAVES10") && n_fft == 1024 ? 10 : 4; }
 
 // Complex numbers as 2-wide vectors: complex add/sub are one packed op and a complex multiply is pk_mul +
 // pk_fma (a packed fp32 op costs the SIMD 4 clocks, two plain ones 2 + 2: the same arithmetic time, fewer
 // instructions to issue).  8-byte aligned: LDS accesses are ds_*_b64.
 typedef float cpx __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// floats of the re-packed mel weight table in LDS (every filter padded to a multiple of four taps), rounded to 16 bytes
+__host__ __device__ static inline int mel_padded_words(int mel_nnz, int n_out) {
+  return n_out > 0 ? ((mel_nnz + 3 * n_out + 3) & ~3) : 0;
+}
 __device__ __forceinline__ cpx cmk(float x, float y) { return (cpx){x, y}; }
 __device__ __forceinline__ cpx cadd(cpx a, cpx b) { return a + b; }
 __device__ __forceinline__ cpx csub(cpx a, cpx b) { return a - b; }
@@ -96,18 +105,26 @@ struct SpecArgs {
   double* partials;        // [gridDim.x*gridDim.y][3] or null
   const float* rowpeak;    // [B] or null: row peaks; the spectrum is that of row / peak when peak > 1 (|X|^2 scales by 1/peak^2)
   int T, F, hop, n_out, mel_nnz;
-  int groups;              // frame groups (of SP_FPB frames) each workgroup walks through
+  int groups;              // consecutive frames of a row each workgroup walks through
   int value_mode;          // 1: |X|, 2: |X|^2, 3: sqrt(max(|X|^2, eps))
   int loss_mode;           // 0: none, 1: sum |v - t|, 2: MR-STFT sums {(t-v)^2, t^2, |log v - log t|}
   float eps;
 };
 
-// LDS traffic inside one wave only needs ordering, not a workgroup barrier: the waves of a workgroup
-// work on different frames with private scratch.  Only LDS (lgkm) is waited for: global loads of the
-// next frame stay in flight across these points.
+// LDS traffic inside one wave only needs ORDERING, not a workgroup barrier and not a wait: the waves of a workgroup
+// work on different frames with private scratch, and the LDS instructions of one wave execute in program order
+// (LLVM's AMDGPU memory model puts no s_waitcnt on a wavefront-scope fence for that reason).  So a hand-over between
+// lanes of the wave is a compiler-level fence; the s_waitcnt lgkmcnt(0) that used to sit here drained the wave's LDS
+// queue eight times per frame.  The compiler still waits, with exact counts, where a loaded VALUE is consumed.
 __device__ __forceinline__ void wave_lds_sync() {
+#ifdef IAS_STFT_DRAIN_SYNC   /* diagnostics: the round-1 form */
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 
 // Loads the 2R samples of frame f that lane `lane` owns in pass 1 (points 64*n1 + lane, n1 < R).
@@ -133,18 +150,22 @@ __device__ __forceinline__ void load_frame(const float* __restrict__ arow, int T
 
 // One wave per frame, no staging: every wave reads its frame straight from global memory (frames
 // overlap, so the second touch of a sample is an L1/L2 hit), prefetching the next frame while it
-// transforms the current one.  A workgroup (4 waves) walks through a.groups * SP_FPB consecutive frames
+// transforms the current one.  A workgroup (SP_WAVES waves) walks through a.groups consecutive frames
 // of one row, wave w taking frames w, w+4, ...; LDS holds only the per-wave FFT scratch and the mel
 // tables, and there is no workgroup barrier in the frame loop.
-template <int LOG2N, int SP_FPB>
-__global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
+template <int LOG2N, int SP_WAVES, bool LOSS2 /* a.loss_mode == 2: its two extra accumulators cost registers */>
+__global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES == 10 ? 5 : 1) void stft_kernel(const SpecArgs a) {
+  constexpr int SP_THREADS = 64 * SP_WAVES;
   constexpr int NFFT = 1 << LOG2N, N2 = NFFT / 2, R = N2 / 64, NPAIR = 8 * R, NP_IT = (NPAIR + 63) / 64;
   constexpr int SCR = NPAIR * 9;          // padded [k1*8+c][9] complex scratch, reused in place by every pass
   constexpr int NUNP = (N2 / 2) / 64 + 1; // unpack iterations per lane
   extern __shared__ __attribute__((aligned(16))) float smem[];
   cpx* s_scr = reinterpret_cast<cpx*>(smem);                           // SP_WAVES * SCR
-  float* s_melw = reinterpret_cast<float*>(s_scr + SP_WAVES * SCR);   // a.mel_nnz (mel mode)
-  int* s_meli = reinterpret_cast<int*>(s_melw + ((a.mel_nnz + 3) & ~3));  // [3][n_out]: start, count, woff
+  // mel weights, re-packed per filter to a multiple of four taps (zero padded) at 16-byte aligned offsets, so that a
+  // trip of the filter loop reads its four weights as ONE ds_read_b128 and needs no per-tap predicate
+  float* s_melw = reinterpret_cast<float*>(s_scr + SP_WAVES * SCR);   // <= a.mel_nnz + 3 n_out floats (mel mode)
+  const int melw_words = mel_padded_words(a.mel_nnz, a.mel_start != nullptr ? a.n_out : 0);
+  int* s_meli = reinterpret_cast<int*>(s_melw + melw_words);   // [3][n_out]: start, padded count, padded offset
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
@@ -155,11 +176,21 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
   if (a.rowpeak != nullptr) { const float pkv = a.rowpeak[b]; if (pkv > 1.0f) { const float r = 1.0f / pkv; pscale = r * r; } }
 
   if (mel) {
-    for (int i = tid; i < a.mel_nnz; i += SP_THREADS) s_melw[i] = a.mel_w[i];
+    for (int i = tid; i < melw_words; i += SP_THREADS) s_melw[i] = 0.0f;
     for (int i = tid; i < a.n_out; i += SP_THREADS) {
       s_meli[i] = a.mel_start[i];
-      s_meli[a.n_out + i] = a.mel_count[i];
-      s_meli[2 * a.n_out + i] = a.mel_woff[i];
+      s_meli[a.n_out + i] = (a.mel_count[i] + 3) & ~3;
+    }
+    __syncthreads();
+    for (int i = tid; i < a.n_out; i += SP_THREADS) {
+      int off = 0;                                   // padded offset: sum of the padded counts before filter i
+      for (int m = 0; m < i; ++m) off += s_meli[a.n_out + m];
+      s_meli[2 * a.n_out + i] = off;
+    }
+    __syncthreads();
+    for (int i = tid; i < a.n_out; i += SP_THREADS) {
+      const int n = a.mel_count[i], src = a.mel_woff[i], dst = s_meli[2 * a.n_out + i];
+      for (int j = 0; j < n; ++j) s_melw[dst + j] = a.mel_w[src + j];
     }
   }
 
@@ -184,20 +215,23 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
 
   cpx* sA = s_scr + wave * SCR;
   float l0 = 0.f, l1 = 0.f, l2 = 0.f;
-  // filter descriptors of this lane's first two outputs (all of them when n_out <= 128): frame-invariant
-  int h_sa = 0, h_na = 0, h_wa = 0, h_sb = 0, h_nb = 0, h_wb = 0;
+  // wave-wide longest filter of each output group of the first 128 outputs (wave-uniform, frame-invariant).  The
+  // per-lane filter descriptors themselves are re-read from LDS every frame: holding them cost six VGPRs, which at 10
+  // waves per workgroup is the difference between 5 waves per SIMD and spilling.
+  int h_nmaxa = 0, h_nmaxb = 0;
   if (mel) {
-    if (lane < a.n_out) { h_sa = s_meli[lane]; h_na = s_meli[a.n_out + lane]; h_wa = s_meli[2 * a.n_out + lane]; }
-    if (lane + 64 < a.n_out) { h_sb = s_meli[lane + 64]; h_nb = s_meli[a.n_out + lane + 64]; h_wb = s_meli[2 * a.n_out + lane + 64]; }
+    if (lane < a.n_out) h_nmaxa = s_meli[a.n_out + lane];
+    if (lane + 64 < a.n_out) h_nmaxb = s_meli[a.n_out + lane + 64];
   }
-  int h_nmaxa = h_na, h_nmaxb = h_nb;   // wave-wide longest filter of each output group (uniform)
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
     h_nmaxa = max(h_nmaxa, __shfl_xor(h_nmaxa, d, 64));
     h_nmaxb = max(h_nmaxb, __shfl_xor(h_nmaxb, d, 64));
   }
-  const int f_begin = blockIdx.x * a.groups * SP_FPB;
-  const int f_end = min(f_begin + a.groups * SP_FPB, a.F);
+  h_nmaxa = __builtin_amdgcn_readfirstlane(h_nmaxa);
+  h_nmaxb = __builtin_amdgcn_readfirstlane(h_nmaxb);
+  const int f_begin = blockIdx.x * a.groups;
+  const int f_end = min(f_begin + a.groups, a.F);
 
   float xc[2 * R], xn[2 * R];
   int f = f_begin + wave;
@@ -304,11 +338,8 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
         const bool oka = ma < a.n_out, okb = mb < a.n_out;
         float va = 0.f, vb = 0.f;
         if (mel) {
-          int sa = h_sa, na = h_na, sb = h_sb, nb = h_nb, woa = h_wa, wob = h_wb;
-          if (m0 != 0) {   // outputs beyond the first 128: descriptors from LDS
-            sa = oka ? s_meli[ma] : 0; na = oka ? s_meli[a.n_out + ma] : 0; woa = oka ? s_meli[2 * a.n_out + ma] : 0;
-            sb = okb ? s_meli[mb] : 0; nb = okb ? s_meli[a.n_out + mb] : 0; wob = okb ? s_meli[2 * a.n_out + mb] : 0;
-          }
+          const int sa = oka ? s_meli[ma] : 0, na = oka ? s_meli[a.n_out + ma] : 0, woa = oka ? s_meli[2 * a.n_out + ma] : 0;
+          const int sb = okb ? s_meli[mb] : 0, nb = okb ? s_meli[a.n_out + mb] : 0, wob = okb ? s_meli[2 * a.n_out + mb] : 0;
           const float* wa = s_melw + woa;
           const float* wb = s_melw + wob;
           // the two outputs of a lane run as two loops with their own wave-wide trip counts: with mel filters the
@@ -324,25 +355,28 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
               nmaxb = max(nmaxb, __shfl_xor(nmaxb, d, 64));
             }
           }
+          // (na, nb, nmaxa, nmaxb are multiples of four; a lane whose filter has ended re-reads its first trip and
+          //  keeps its sum; the zero padding multiplies power values of neighbouring bins, which are finite.)
+          // Measured alternatives that were slower: one merged loop advancing both chains with the next trip's reads
+          // issued ahead (94.7 vs 84.9 us: the short chain then re-reads for the long chain's trips and the LDS is the
+          // co-bottleneck), 10 waves per workgroup at 5 waves per SIMD (98.9 us).
           for (int j = 0; j < nmaxa; j += 4) {
-            float pa[4], ca[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const bool ia = j + e < na;
-              pa[e] = P[ia ? sa + j + e : 0]; ca[e] = ia ? wa[j + e] : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) va = fmaf(ca[e], pa[e], va);
+            const bool on = j < na;
+            const int jj = on ? j : 0;
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wa + jj);
+            const float* pp = P + sa + jj;
+            const float p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+            const float t = fmaf(w[3], p3, fmaf(w[2], p2, fmaf(w[1], p1, fmaf(w[0], p0, va))));
+            va = on ? t : va;
           }
           for (int j = 0; j < nmaxb; j += 4) {
-            float pb[4], cb[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const bool ib = j + e < nb;
-              pb[e] = P[ib ? sb + j + e : 0]; cb[e] = ib ? wb[j + e] : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) vb = fmaf(cb[e], pb[e], vb);
+            const bool on = j < nb;
+            const int jj = on ? j : 0;
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wb + jj);
+            const float* pp = P + sb + jj;
+            const float p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+            const float t = fmaf(w[3], p3, fmaf(w[2], p2, fmaf(w[1], p1, fmaf(w[0], p0, vb))));
+            vb = on ? t : vb;
           }
         } else {
           va = oka ? P[ma] : 0.f;
@@ -360,7 +394,7 @@ __global__ __launch_bounds__(SP_THREADS) void stft_kernel(const SpecArgs a) {
         if (a.loss_mode == 1) {
           if (oka) l0 += fabsf(va - ta);
           if (okb) l0 += fabsf(vb - tb);
-        } else if (a.loss_mode == 2) {
+        } else if (LOSS2) {
           if (oka) { const float d = ta - va; l0 = fmaf(d, d, l0); l1 = fmaf(ta, ta, l1); l2 += fabsf(logf(va) - logf(ta)); }
           if (okb) { const float d = tb - vb; l0 = fmaf(d, d, l0); l1 = fmaf(tb, tb, l1); l2 += fabsf(logf(vb) - logf(tb)); }
         }
@@ -413,36 +447,30 @@ extern "C" int ias_stft_num_frames(int T, int n_fft, int hop) {
   return 1 + T / hop;   // center=True: 1 + (T + 2*(n_fft/2) - n_fft) / hop
 }
 
-static size_t stft_lds_bytes(int n_fft, int hop, int fpb, int mel_nnz, int n_out) {
+static size_t stft_lds_bytes(int n_fft, int mel_nnz, int n_out) {
   const int R = n_fft / 128, scr = 8 * R * 9;
-  (void)hop; (void)fpb;
   const int np_it = (8 * R + 63) / 64, nunp = (n_fft / 4) / 64 + 1;
   const int ntab = 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp);
-  return sizeof(cpx) * SP_WAVES * scr + sizeof(float) * ((mel_nnz + 3) & ~3) + sizeof(int) * 3 * (mel_nnz ? n_out : 0) +
-         sizeof(float) * ntab + 8;
+  return sizeof(cpx) * stft_waves(n_fft) * scr + sizeof(float) * mel_padded_words(mel_nnz, mel_nnz ? n_out : 0) +
+         sizeof(int) * 3 * (mel_nnz ? n_out : 0) + sizeof(float) * ntab + 8;
 }
-static int stft_fpb(int n_fft, int hop) {
-  (void)n_fft; (void)hop;
-  return SP_FPB_MAX;   // frames per group; nothing is staged any more, so the span never limits it
-}
-// Frame groups per workgroup: the per-lane tables are loaded once per workgroup, so a workgroup walks
-// through several groups; sized so that B * gridDim.x is about one resident round (4 workgroups per CU).
-static int stft_groups(int B, int F, int fpb) {
-  const int total = (F + fpb - 1) / fpb;
-  // ~2048 workgroups in all: two rounds of the 4-5 that fit a CU; measured 3 % faster than one round of 1024 both
-  // alone and beside the render / PQMF kernels of the pipelined step
-  int per_row = 2048 / B;
+// Consecutive frames of a row per workgroup (the per-lane tables are loaded once per workgroup).  10-wave form: ONE
+// resident round (2 workgroups per CU x 256 CUs) so that every wave gets the same 8-9 frames; 4-wave form: ~2048
+// workgroups, two rounds of the 4 that fit a CU (measured 3 % faster than one round there).
+static int stft_groups(int B, int F, int n_fft) {
+  const int waves = stft_waves(n_fft);
+  int per_row = (waves == 10 ? 512 : 2048) / B;
   if (per_row < 1) per_row = 1;
-  int g = (total + per_row - 1) / per_row;
-  if (g < 1) g = 1;
-  if (g > 16) g = 16;
+  int g = (F + per_row - 1) / per_row;
+  const int gmin = 2 * waves, gmax = 32 * waves;
+  if (g < gmin) g = gmin;
+  if (g > gmax) g = gmax;
   return g;
 }
 static int stft_grid_x(int B, int F, int n_fft, int hop) {
-  const int fpb = stft_fpb(n_fft, hop);
-  const int total = (F + fpb - 1) / fpb;
-  const int g = stft_groups(B, F, fpb);
-  return (total + g - 1) / g;
+  (void)hop;
+  const int g = stft_groups(B, F, n_fft);
+  return (F + g - 1) / g;
 }
 
 extern "C" long long ias_stft_partials_count(int B, int T, int n_fft, int hop) {
@@ -527,23 +555,22 @@ extern "C" int ias_stft(const float* audio, const float* tables, const int* mel_
   a.T = T; a.F = F; a.hop = hop; a.n_out = n_out; a.mel_nnz = mel ? mel_nnz : 0;
   a.value_mode = value_mode; a.loss_mode = loss_mode; a.eps = eps;
 
-  const int fpb = stft_fpb(n_fft, hop);
-  a.groups = stft_groups(B, F, fpb);
-  const size_t lds = stft_lds_bytes(n_fft, hop, fpb, a.mel_nnz, n_out);
+  a.groups = stft_groups(B, F, n_fft);
+  const size_t lds = stft_lds_bytes(n_fft, a.mel_nnz, n_out);
   if (lds > 150 * 1024) return IAS_ERR_UNSUPPORTED;
-  const dim3 grid(stft_grid_x(B, F, n_fft, hop), B), block(SP_THREADS);
-#define IAS_STFT_LAUNCH(LOG2N, FPB)                                                                              \
-  do {                                                                                                           \
-    if (lds > 64 * 1024)                                                                                         \
-      (void)hipFuncSetAttribute((const void*)stft_kernel<LOG2N, FPB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds);                                                                       \
-    hipLaunchKernelGGL((stft_kernel<LOG2N, FPB>), grid, block, lds, stream, a);                                  \
+  const dim3 grid(stft_grid_x(B, F, n_fft, hop), B), block(64 * stft_waves(n_fft));
+#define IAS_STFT_LAUNCH(LOG2N, WAVES)                                                                              \
+  do {                                                                                                             \
+    if (lds > 64 * 1024)                                                                                           \
+      (void)hipFuncSetAttribute(loss_mode == 2 ? (const void*)stft_kernel<LOG2N, WAVES, true>                     \
+                                               : (const void*)stft_kernel<LOG2N, WAVES, false>,                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+    if (loss_mode == 2) hipLaunchKernelGGL((stft_kernel<LOG2N, WAVES, true>), grid, block, lds, stream, a);        \
+    else hipLaunchKernelGGL((stft_kernel<LOG2N, WAVES, false>), grid, block, lds, stream, a);                      \
   } while (0)
-  if (fpb == 8) {
-    if (n_fft == 512) IAS_STFT_LAUNCH(9, 8); else if (n_fft == 1024) IAS_STFT_LAUNCH(10, 8); else IAS_STFT_LAUNCH(11, 8);
-  } else {
-    if (n_fft == 512) IAS_STFT_LAUNCH(9, 4); else if (n_fft == 1024) IAS_STFT_LAUNCH(10, 4); else IAS_STFT_LAUNCH(11, 4);
-  }
+  if (n_fft == 512) IAS_STFT_LAUNCH(9, 4);
+  else if (n_fft == 1024) { if (stft_waves(n_fft) == 10) IAS_STFT_LAUNCH(10, 10); else IAS_STFT_LAUNCH(10, 4); }
+  else IAS_STFT_LAUNCH(11, 4);
 #undef IAS_STFT_LAUNCH
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
