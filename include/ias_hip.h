@@ -222,6 +222,17 @@ int ias_stem_forward(const float* x, const float* w, float* out, int B, int H, i
 long long ias_stem_weight_scratch(int B);                     /* floats */
 int ias_stem_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int H, int W, void* stream);
 
+/* ---- LARS optimizer step (momentum 0) as three multi-tensor launches: replaces flash.core.optimizers.LARS.step as
+ * configured at vicreg_audio_params.py:134-151.
+ * tensors [n][3] int64 (device): parameter pointer, gradient pointer, element count (fp32, contiguous);
+ * chunks [nchunks][2] int32 (device): tensor index, chunk index within the tensor, chunks of ias_lars_chunk_elems()
+ * elements; first_chunk [n+1] int32 (device): prefix of the chunk counts; partials [nchunks][2] doubles and coef [n][2]
+ * floats: scratch; hyper [4] floats (device): lr, weight_decay, trust_coefficient, eps.  skip_norms != 0: coef is taken
+ * as given (weight_decay == 0: the caller sets (1, 0) per tensor). */
+int ias_lars_chunk_elems(void);
+int ias_lars_step(const long long* tensors, const int* chunks, const int* first_chunk, double* partials, float* coef,
+                  const float* hyper, int ntensors, int nchunks, int skip_norms, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,8 @@ SYMBOLS = {
     "ias_stem_forward": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ias_stem_weight_scratch": (_LL, [_I]),
     "ias_stem_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "ias_lars_chunk_elems": (_I, []),
+    "ias_lars_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
 }
 
 _lib = None

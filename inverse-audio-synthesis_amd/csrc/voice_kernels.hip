@@ -812,6 +812,10 @@ static int voice_audio_grid(size_t lds, int total_tiles) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, voice_audio_kernel<MATH, FMA_DIV>, AUDIO_THREADS, lds) != hipSuccess ||
         per_cu < 1)
       per_cu = 2;
+    if (const char* e = getenv("IAS_VOICE_PERCU")) {   // diagnostics: fewer resident workgroups (room for neighbours)
+      const int v = atoi(e);
+      if (v >= 1 && v < per_cu) per_cu = v;
+    }
     cached_grid = per_cu * ncu;
     cached_lds = (int)lds;
     if (getenv("IAS_DEBUG")) fprintf(stderr, "[ias] voice_audio_kernel: %d workgroups/CU x %d CUs, %zu B LDS\n", per_cu, ncu, lds);

@@ -5,8 +5,9 @@ lr = batch_size / 256 * base_lr)`` and ``pl_bolts LinearWarmupCosineAnnealingLR(
 warmup_epochs, max_epochs, warmup_start_lr, eta_min)`` stepped every optimizer step (:154-165).
 Neither package is in this image; both are restated from their published definitions (LARS: You et
 al. 2017 as implemented by lightning-flash/bolts: trust ratio on parameters with weight decay, then
-plain momentum-SGD; default momentum 0, trust_coefficient 1e-3, eps 1e-8).  The update is issued as
-multi-tensor (``torch._foreach``) ops: a handful of launches per step instead of ~6 per parameter.
+plain momentum-SGD; default momentum 0, trust_coefficient 1e-3, eps 1e-8).  On a ROCm device with momentum 0 (the
+reference's configuration) the whole step is three HIP launches (``ias_lars_step``: norm partials, per-tensor
+coefficients, update; csrc/optim_kernels.hip); otherwise multi-tensor ``torch._foreach`` ops.
 """
 import math
 
@@ -27,12 +28,15 @@ class LARS(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
             gs = [p.grad for p in ps]
             wd, lr, mom = group["weight_decay"], group["lr"], group["momentum"]
+            if mom == 0 and self._hip_ok(ps, gs):
+                self._hip_step(gi, group, ps, gs)
+                continue
             if wd != 0:
                 p_norm = torch._foreach_norm(ps)
                 g_norm = torch._foreach_norm(gs)
@@ -57,6 +61,50 @@ class LARS(torch.optim.Optimizer):
                 upd = torch._foreach_add(upd, bufs, alpha=mom) if group["nesterov"] else bufs
             torch._foreach_add_(ps, upd, alpha=-lr)
         return loss
+
+
+    # ------------------------------------------------------------------ fused HIP path (momentum 0)
+    @staticmethod
+    def _hip_ok(ps, gs):
+        return all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous() and
+                   g.dtype == torch.float32 and g.device == p.device for p, g in zip(ps, gs)) and \
+            len({p.device for p in ps}) == 1
+
+    def _hip_step(self, gi, group, ps, gs):
+        from . import _lib
+        lib = _lib.load()
+        dev = ps[0].device
+        cache = self.__dict__.setdefault("_hip_tables", {})
+        key = tuple((p.data_ptr(), g.data_ptr(), p.numel()) for p, g in zip(ps, gs))
+        ent = cache.get(gi)
+        if ent is None or ent["key"] != key:
+            chunk = lib.ias_lars_chunk_elems()
+            tensors, chunks, first = [], [], [0]
+            for t, (pp, gp, n) in enumerate(key):
+                tensors.append((pp, gp, n))
+                nc = (n + chunk - 1) // chunk
+                chunks.extend((t, c) for c in range(nc))
+                first.append(first[-1] + nc)
+            ent = dict(key=key, n=len(key), nchunks=len(chunks),
+                       tensors=torch.tensor(tensors, dtype=torch.int64).to(dev),
+                       chunks=torch.tensor(chunks, dtype=torch.int32).to(dev),
+                       first=torch.tensor(first, dtype=torch.int32).to(dev),
+                       partials=torch.empty(2 * len(chunks), dtype=torch.float64, device=dev),
+                       coef=torch.empty(2 * len(key), dtype=torch.float32, device=dev),
+                       hyper_host=torch.empty(4, dtype=torch.float32).pin_memory(),
+                       hyper=torch.empty(4, dtype=torch.float32, device=dev), hyper_vals=None)
+            cache[gi] = ent
+        vals = (float(group["lr"]), float(group["weight_decay"]), float(group["trust_coefficient"]), float(group["eps"]))
+        if ent["hyper_vals"] != vals:
+            ent["hyper_host"].copy_(torch.tensor(vals, dtype=torch.float32))
+            ent["hyper"].copy_(ent["hyper_host"], non_blocking=True)
+            ent["hyper_vals"] = vals
+        skip = group["weight_decay"] == 0
+        if skip:
+            ent["coef"].view(-1, 2).copy_(torch.tensor([1.0, 0.0], device=dev))
+        _lib.check(lib.ias_lars_step(_lib.ptr(ent["tensors"]), _lib.ptr(ent["chunks"]), _lib.ptr(ent["first"]),
+                                     _lib.ptr(ent["partials"]), _lib.ptr(ent["coef"]), _lib.ptr(ent["hyper"]),
+                                     ent["n"], ent["nchunks"], int(skip), _lib.stream()), "ias_lars_step")
 
 
 class LinearWarmupCosineAnnealingLR:

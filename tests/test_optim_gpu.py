@@ -1,0 +1,56 @@
+"""Fused HIP LARS step (ias_lars_step) against the multi-tensor torch formulation of the same update on CPU copies
+(tests/test_config_optim_cpu.py pins that one against the single-tensor formula of flash's LARS)."""
+import pytest
+import torch
+
+from inverse_audio_synthesis_amd.optim import LARS
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(257, 129), (8192,), (3,), (70000,), (64, 1025), (5,), (1,)]
+    ps = [torch.randn(s, generator=g) * (0.5 + i) for i, s in enumerate(shapes)]
+    ps[5].zero_()                                   # a parameter that is exactly zero: ratio 1, no decay
+    return [torch.nn.Parameter(p.clone().to(dev)) for p in ps]
+
+
+@pytest.mark.parametrize("wd", [1e-2, 0.0])
+def test_fused_lars_matches_foreach_formulation(lib, dev, wd):
+    hip, ref = _params(dev, 3), _params(torch.device("cpu"), 3)
+    o_hip = LARS(hip, lr=0.3, weight_decay=wd)
+    o_ref = LARS(ref, lr=0.3, weight_decay=wd)
+    for step in range(3):
+        for i, (a, b) in enumerate(zip(hip, ref)):
+            g = torch.randn(b.shape, generator=torch.Generator().manual_seed(100 * step + i))
+            if i == 2:
+                g.zero_()                           # a gradient that is exactly zero: that parameter must not move
+            b.grad = g
+            a.grad = g.to(dev)
+        if step == 2:                               # the scheduler changed the learning rate
+            o_hip.param_groups[0]["lr"] = o_ref.param_groups[0]["lr"] = 0.05
+        o_hip.step()
+        o_ref.step()
+        assert "_hip_tables" in o_hip.__dict__ and "_hip_tables" not in o_ref.__dict__
+        for i, (a, b) in enumerate(zip(hip, ref)):
+            tol = 2e-6 * max(1.0, float(b.detach().abs().max()))
+            assert (a.detach().cpu() - b.detach()).abs().max().item() <= tol, (step, i)
+    assert torch.equal(hip[2].detach().cpu(), _params(torch.device("cpu"), 3)[2].detach()) or wd == 0.0
+
+
+def test_fused_lars_is_deterministic_and_handles_unaligned_views(lib, dev):
+    base = torch.randn(100001, generator=torch.Generator().manual_seed(0)).to(dev)
+    outs = []
+    for _ in range(2):
+        buf = base.clone()
+        p = torch.nn.Parameter(buf[1:70002])       # 4-byte aligned only
+        q = torch.nn.Parameter(buf[70004:])
+        o = LARS([p, q], lr=0.1, weight_decay=1e-3)
+        p.grad = torch.ones_like(p) * 0.25
+        q.grad = torch.linspace(-1, 1, q.numel(), device=dev)
+        o.step()
+        torch.cuda.synchronize()
+        outs.append(buf.clone())
+        assert buf[0] == base[0] and torch.equal(buf[70002:70004], base[70002:70004])   # nothing written outside
+    assert torch.equal(outs[0], outs[1])
