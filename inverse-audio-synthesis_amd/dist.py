@@ -67,6 +67,10 @@ class GradBucketer:
         self.buckets = []      # (flat buffer, [params])
         self._pending = {}     # bucket index -> grads still to arrive this step
         self._work = []
+        if not self.collective:
+            # one replica: nothing to reduce, so no flat buckets and no hooks -- begin_step() drops the gradients and
+            # autograd hands each parameter its gradient tensor directly (no per-parameter accumulate / copy launches)
+            return
         # reverse registration order ~ the order gradients become ready in backward
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
@@ -78,10 +82,13 @@ class GradBucketer:
             cur_bytes += nbytes
         if cur:
             self._seal(cur)
-        self._bucket_of = {}
+        self._bucket_of, self._offset_of = {}, {}
         for bi, (_flat, plist) in enumerate(self.buckets):
+            off = 0
             for p in plist:
                 self._bucket_of[p] = bi
+                self._offset_of[p] = off          # (looked up by identity: list.index would compare tensors by value)
+                off += p.numel()
                 p.register_post_accumulate_grad_hook(self._on_grad)
         self.begin_step()
 
@@ -96,6 +103,10 @@ class GradBucketer:
     def begin_step(self):
         """Zero the flat gradient buffers (call instead of optimizer.zero_grad())."""
         self._work = []
+        if not self.collective:
+            for p in self.params:
+                p.grad = None
+            return
         for bi, (flat, plist) in enumerate(self.buckets):
             flat.zero_()
             self._pending[bi] = len(plist)
@@ -105,7 +116,7 @@ class GradBucketer:
         flat, plist = self.buckets[bi]
         if p.grad.data_ptr() < flat.data_ptr() or p.grad.data_ptr() >= flat.data_ptr() + flat.numel() * flat.element_size():
             # autograd replaced the view (first backward): copy into the bucket and re-point
-            off = sum(q.numel() for q in plist[:plist.index(p)])
+            off = self._offset_of[p]
             view = flat[off:off + p.numel()].view_as(p)
             view.copy_(p.grad)
             p.grad = view

@@ -57,7 +57,9 @@ class VicregAudioParams(nn.Module):
 
     def _step(self, name, batch, batch_idx=None):
         with torch.no_grad():
-            audio, params, _is_train = self.voice(_batch_num(batch))
+            # batch None: the parameters already stored in the voice (Trainer's captured step samples them on the host,
+            # outside the graph, with voice.randomize(batch))
+            audio, params, _is_train = self.voice(None if batch is None else _batch_num(batch))
         x, y = self.forward(audio, params)
         loss, repr_loss, std_loss, cov_loss = self.vicreg.loss(x, y)
         self.logged = {f"vicreg/{name}/loss": loss.detach(), f"vicreg/{name}/repr_loss": repr_loss.detach(),

@@ -65,6 +65,23 @@ class LARS(torch.optim.Optimizer):
 
     # ------------------------------------------------------------------ fused HIP path (momentum 0)
     @staticmethod
+    def _sync_group_hyper(group, ent):
+        vals = (float(group["lr"]), float(group["weight_decay"]), float(group["trust_coefficient"]), float(group["eps"]))
+        if ent["hyper_vals"] != vals:
+            ent["hyper_host"].copy_(torch.tensor(vals, dtype=torch.float32))
+            ent["hyper"].copy_(ent["hyper_host"], non_blocking=True)
+            ent["hyper_vals"] = vals
+
+    def sync_hyper(self):
+        """Push lr / weight decay / trust coefficient / eps of every group to the device scalars the fused step reads.
+        ``step()`` does this itself; a step replayed from a captured hipGraph cannot (the Python around the launches
+        does not run again), so the replaying loop calls this after the scheduler has moved the learning rate."""
+        for gi, group in enumerate(self.param_groups):
+            ent = self.__dict__.get("_hip_tables", {}).get(gi)
+            if ent is not None:
+                self._sync_group_hyper(group, ent)
+
+    @staticmethod
     def _hip_ok(ps, gs):
         return all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous() and
                    g.dtype == torch.float32 and g.device == p.device for p, g in zip(ps, gs)) and \
@@ -85,23 +102,27 @@ class LARS(torch.optim.Optimizer):
                 nc = (n + chunk - 1) // chunk
                 chunks.extend((t, c) for c in range(nc))
                 first.append(first[-1] + nc)
-            ent = dict(key=key, n=len(key), nchunks=len(chunks),
-                       tensors=torch.tensor(tensors, dtype=torch.int64).to(dev),
-                       chunks=torch.tensor(chunks, dtype=torch.int32).to(dev),
-                       first=torch.tensor(first, dtype=torch.int32).to(dev),
+            def up(values, dtype):
+                # pinned staging + asynchronous copy: also legal while a hipGraph is being captured (the gradients of
+                # a captured step live in the graph's private pool, so the tables are rebuilt during capture)
+                host = torch.tensor(values, dtype=dtype).pin_memory()
+                return host, torch.empty(host.shape, dtype=dtype, device=dev).copy_(host, non_blocking=True)
+            t_host, t_dev = up(tensors, torch.int64)
+            c_host, c_dev = up(chunks, torch.int32)
+            f_host, f_dev = up(first, torch.int32)
+            ent = dict(key=key, n=len(key), nchunks=len(chunks), hosts=(t_host, c_host, f_host),
+                       tensors=t_dev, chunks=c_dev, first=f_dev,
                        partials=torch.empty(2 * len(chunks), dtype=torch.float64, device=dev),
                        coef=torch.empty(2 * len(key), dtype=torch.float32, device=dev),
                        hyper_host=torch.empty(4, dtype=torch.float32).pin_memory(),
                        hyper=torch.empty(4, dtype=torch.float32, device=dev), hyper_vals=None)
             cache[gi] = ent
-        vals = (float(group["lr"]), float(group["weight_decay"]), float(group["trust_coefficient"]), float(group["eps"]))
-        if ent["hyper_vals"] != vals:
-            ent["hyper_host"].copy_(torch.tensor(vals, dtype=torch.float32))
-            ent["hyper"].copy_(ent["hyper_host"], non_blocking=True)
-            ent["hyper_vals"] = vals
+        self._sync_group_hyper(group, ent)
         skip = group["weight_decay"] == 0
         if skip:
-            ent["coef"].view(-1, 2).copy_(torch.tensor([1.0, 0.0], device=dev))
+            c2 = ent["coef"].view(-1, 2)
+            c2[:, 0].fill_(1.0)
+            c2[:, 1].fill_(0.0)
         _lib.check(lib.ias_lars_step(_lib.ptr(ent["tensors"]), _lib.ptr(ent["chunks"]), _lib.ptr(ent["first"]),
                                      _lib.ptr(ent["partials"]), _lib.ptr(ent["coef"]), _lib.ptr(ent["hyper"]),
                                      ent["n"], ent["nchunks"], int(skip), _lib.stream()), "ias_lars_step")

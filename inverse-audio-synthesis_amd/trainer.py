@@ -98,6 +98,40 @@ class Trainer:
         self.start_step = int(ck.get("step", 0))
         return ck
 
+    # ---- whole-step hipGraph (trainer.cuda_graph) --------------------------------------------------------------
+    def _use_graph(self):
+        return bool(self.cfg.trainer.get("cuda_graph")) and self.world == 1 and self.stage == "vicreg" and \
+            self.device.type == "cuda" and hasattr(self.module, "voice")
+
+    def _graph_step(self, batch, step, warmup=3):
+        """One training step as a replay of ONE captured hipGraph: render + PQMF + trunk + projector + loss + backward +
+        LARS are ~1500 launches per step and the eager loop is bound by issuing them (36 ms wall for 22 ms of kernels at
+        batch 128).  Host work stays outside the graph: the synth parameters of the batch are sampled on the CPU and
+        copied into the voice's parameter buffer, the scheduler's learning rate is pushed to the device scalar the fused
+        LARS step reads.  The first ``warmup`` steps run eagerly (library handles, MIOpen find, allocator), the next one
+        is captured (and executed by its first replay)."""
+        m, opt = self.module, self.optimizer
+        m.voice.randomize(int(batch))
+        if hasattr(opt, "sync_hyper"):
+            opt.sync_hyper()
+        g = getattr(self, "_graph", None)
+        if g is None:
+            n = getattr(self, "_graph_warm", 0)
+            if n < warmup:
+                self._graph_warm = n + 1
+                self.bucketer.begin_step()
+                m.training_step(None, step).backward()
+                opt.step()
+                return
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.bucketer.begin_step()            # zero the flat gradient buffers (static addresses) in the graph
+                m.training_step(None, step).backward()
+                opt.step()
+            self._graph = g
+        g.replay()
+
     def fit(self, max_steps=None):
         cfg, st = self.cfg, self.cfg[self.stage]
         lo, hi = split_sizes(cfg.num_batches, cfg.ntest_batches)["train"]
@@ -113,11 +147,14 @@ class Trainer:
             batch = idx[step] if idx is not None else split_indices(
                 cfg.num_batches, cfg.ntest_batches, cfg.seed, 1, "train", self.rank, self.world,
                 start=(start + step) * self.world)[0]
-            self.bucketer.begin_step()
-            loss = self.module.training_step(batch, step)
-            loss.backward()
-            self.bucketer.finish()
-            self.optimizer.step()
+            if self._use_graph():
+                self._graph_step(batch, step)
+            else:
+                self.bucketer.begin_step()
+                loss = self.module.training_step(batch, step)
+                loss.backward()
+                self.bucketer.finish()
+                self.optimizer.step()
             if self.scheduler is not None:
                 self.scheduler.step()
             self._step = start + step + 1

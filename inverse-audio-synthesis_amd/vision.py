@@ -18,14 +18,17 @@ class PointwiseConv2d(nn.Conv2d):
     """A 1x1 convolution (same parameters and state_dict keys as nn.Conv2d).  On a ROCm device it is what it is -- ONE
     strided-batched GEMM  y[b] = W [Cout,Cin] x[b] [Cin, H W]  on rocBLAS / hipBLASLt, layout unchanged (NCHW in, NCHW
     out) -- instead of MIOpen's fp32 fallback, which ran it as an im2col plus a small GEMM PER SAMPLE (3 x 1024 launches
-    per training step at batch 128 for the MobileNet body).  The depthwise convolutions stay on MIOpen in NCHW (its
-    channels-last depthwise weight-gradient took 13 ms per layer).  Elsewhere this is the plain nn.Conv2d."""
+    per training step at batch 128 for the MobileNet body).  Elsewhere this is the plain nn.Conv2d."""
 
     def forward(self, x):
         if x.is_cuda and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.groups == 1 and \
                 x.dim() == 4 and x.is_contiguous():
             B, C, H, W = x.shape
-            y = torch.matmul(self.weight.view(self.out_channels, C), x.view(B, C, H * W))
+            # bmm with the weight expanded along the batch (stride 0), not torch.matmul(W, x): matmul folds the batch into
+            # the rows of a transposed COPY of x (and of the result, and again in backward) -- 106 copy launches and
+            # 2.3 ms of a pretraining step at batch 128.  Autograd of this form is two more bmm's and one sum over the
+            # batch for the weight gradient, all on the operands where they lie.
+            y = torch.bmm(self.weight.view(1, self.out_channels, C).expand(B, -1, -1), x.view(B, C, H * W))
             if self.bias is not None:
                 y = y + self.bias.view(1, -1, 1)
             return y.view(B, self.out_channels, H, W)

@@ -5,6 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/kstats_pt_$tag
 mkdir -p $O
 python3 $R/scripts/diag/time_pretrain_step.py > $O/time.log 2>&1
+GRAPH=1 python3 $R/scripts/diag/time_pretrain_step.py > $O/time_graph.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/prof -o out --output-format csv -- python3 $R/scripts/diag/time_pretrain_step.py > $O/prof.log 2>&1
 python3 - <<PY
@@ -15,7 +16,8 @@ for f in glob.glob("$O/prof/**/out_kernel_stats.csv", recursive=True):
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(open("$O/time.log").read().strip().splitlines()[-1])
-print(f"total kernel time {tot/1e6:.1f} ms over 8 steps (3 warm-up + 5 timed)")
+print(open("$O/time_graph.log").read().strip().splitlines()[-1])
+print(f"total kernel time {tot/1e6:.1f} ms over 10 steps (5 warm-up + 5 timed)")
 for r in rows[:28]:
     print(f"{float(r['TotalDurationNs'])/tot*100:5.1f}%  calls {r['Calls']:>6s}  avg {float(r['AverageNs'])/1e3:9.1f} us  {r['Name'][:110]}")
 PY

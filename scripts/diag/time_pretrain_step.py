@@ -1,27 +1,36 @@
-"""One VICReg pretraining step (BASELINE config #3: B=128, 4 s @ 44.1 kHz, dim 1024, embeddim 8192) -- stage times."""
+"""One VICReg pretraining step (BASELINE config #3: B=128, 4 s @ 44.1 kHz, dim 1024, embeddim 8192) -- wall time per step,
+eager (default) or as the Trainer's captured hipGraph (GRAPH=1)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from inverse_audio_synthesis_amd.config import load_config
 from inverse_audio_synthesis_amd.harness import VicregAudioParams
+from inverse_audio_synthesis_amd.trainer import Trainer
 
 dev = torch.device("cuda:0")
 B = int(os.environ.get("B", 128))
-cfg = load_config(os.path.join(ROOT, "conf"), "config", [f"vicreg.batch_size={B}"])
-model = VicregAudioParams(cfg).to(dev).train()
-opt = model.configure_optimizers()
-opt = opt["optimizer"] if isinstance(opt, dict) else opt
+graph = bool(int(os.environ.get("GRAPH", "0")))
+torch.manual_seed(42)
+cfg = load_config(os.path.join(ROOT, "conf"), "config", [f"vicreg.batch_size={B}", f"trainer.cuda_graph={'true' if graph else 'false'}"])
+model = VicregAudioParams(cfg)
+tr = Trainer(cfg, model, stage="vicreg", device=dev)
+model.train()
+opt = tr.optimizer
 def step(i):
-    loss = model.training_step(i)
-    opt.zero_grad(set_to_none=True)
-    loss.backward()
-    opt.step()
-    return loss
-for i in range(3): step(i)
+    if graph:
+        tr._graph_step(i, i)
+    else:
+        tr.bucketer.begin_step()
+        model.training_step(i).backward()
+        opt.step()
+for i in range(5): step(i)          # (graph mode: 3 eager warm-up steps, capture, first replays)
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+n = int(os.environ.get("STEPS", 5))
 ev[0].record()
-for i in range(5): loss = step(10 + i)
+for i in range(n): step(10 + i)
 ev[1].record(); torch.cuda.synchronize()
-print(f"VICReg pretraining step B={B}: {ev[0].elapsed_time(ev[1]) / 5:.2f} ms/step (render + PQMF + MobileNetV3 trunk + projector + loss + backward + LARS), loss {loss.item():.4f}")
+loss = model.logged["vicreg/train/loss"]
+print(f"VICReg pretraining step B={B} ({'hipGraph replay' if graph else 'eager'}): {ev[0].elapsed_time(ev[1]) / n:.2f} ms/step "
+      f"(render + PQMF + MobileNetV3 trunk + projector + loss + backward + LARS), loss {loss.item():.4f}")

@@ -117,3 +117,23 @@ def test_retrieval_finds_the_same_voice(lib, dev):
     dist, idx = nearest(embed_audio(m, audio), bank, k=2)
     assert idx[:, 0].tolist() == [4, 5, 6, 7]
     assert dist[:, 0].max().item() <= 1e-3 * max(dist[:, 1].min().item(), 1e-6) + 1e-4
+
+
+def test_captured_step_reproduces_the_eager_loop(lib, dev, tmp_path):
+    """trainer.cuda_graph=true replays render + forward + backward + LARS of a step as one hipGraph; host work (parameter
+    sampling, scheduler) stays outside.  Eight steps of the same small run must give the eager loop's losses, learning
+    rates and final weights up to the run-to-run noise of the VICReg backward's fp32 atomics."""
+    import pretrain
+    args = SMALL + ["trainer.max_steps=8", "param_embed.dropout=0.0"]
+    h_e = pretrain.app(args + [f"trainer.out_dir={tmp_path / 'eager'}"])
+    h_g = pretrain.app(args + ["trainer.cuda_graph=true", f"trainer.out_dir={tmp_path / 'graph'}"])
+    assert len(h_e) == len(h_g) == 8
+    for a, b in zip(h_e, h_g):
+        assert a["lr"] == b["lr"]
+        assert abs(a["vicreg/train/loss"] - b["vicreg/train/loss"]) <= 2e-3 * abs(a["vicreg/train/loss"]), (a, b)
+    assert h_e[0]["vicreg/train/loss"] != h_e[-1]["vicreg/train/loss"]          # the run did train
+    se = torch.load(tmp_path / "eager" / "vicreg-last.ckpt", map_location="cpu")["state_dict"]
+    sg = torch.load(tmp_path / "graph" / "vicreg-last.ckpt", map_location="cpu")["state_dict"]
+    for k in ("audio_repr.conv7.weight", "vicreg.projector.0.weight", "vision_model.features.0.1.running_mean"):
+        d = (se[k] - sg[k]).abs().max().item()
+        assert d <= 2e-3 * max(1.0, se[k].abs().max().item()), (k, d)
