@@ -222,6 +222,19 @@ int ias_stem_forward(const float* x, const float* w, float* out, int B, int H, i
 long long ias_stem_weight_scratch(int B);                     /* floats */
 int ias_stem_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int H, int W, void* stream);
 
+/* ---- Training-mode BatchNorm2d with the following activation fused (act 0 none, 1 ReLU, 2 Hardswish): replaces the
+ * nn.BatchNorm2d + activation pairs of torchvision's mobilenet_v3_small.features (audioembed.py:61) and their autograd.
+ * x, y, dy, dx [B,C,HW] fp32 contiguous (NCHW); weight / bias / running_mean / running_var [C] or NULL; save_mean,
+ * save_invstd [C]; scratch: ias_bn_scratch_doubles(B, C) doubles; sums: [C][2] floats.  Running statistics are updated
+ * as torch does (momentum, unbiased variance). */
+long long ias_bn_scratch_doubles(int B, int C);
+int ias_bn_act_forward(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
+                       float* y, float* save_mean, float* save_invstd, double* scratch, int B, int C, int HW, float eps,
+                       float momentum, int act, void* stream);
+int ias_bn_act_backward(const float* x, const float* dy, const float* weight, const float* bias, const float* save_mean,
+                        const float* save_invstd, float* dx, float* gw, float* gb, double* scratch, float* sums, int B,
+                        int C, int HW, int act, void* stream);
+
 /* ---- LARS optimizer step (momentum 0) as three multi-tensor launches: replaces flash.core.optimizers.LARS.step as
  * configured at vicreg_audio_params.py:134-151.
  * tensors [n][3] int64 (device): parameter pointer, gradient pointer, element count (fp32, contiguous);

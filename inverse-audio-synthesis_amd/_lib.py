@@ -69,6 +69,9 @@ SYMBOLS = {
     "ias_stem_forward": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ias_stem_weight_scratch": (_LL, [_I]),
     "ias_stem_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "ias_bn_scratch_doubles": (_LL, [_I, _I]),
+    "ias_bn_act_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P]),
+    "ias_bn_act_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_lars_chunk_elems": (_I, []),
     "ias_lars_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
 }

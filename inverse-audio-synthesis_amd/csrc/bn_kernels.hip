@@ -1,0 +1,238 @@
+// Training-mode BatchNorm2d with the following activation fused in (MI355X / gfx950), NCHW fp32.
+//
+// Replaces nn.BatchNorm2d + nn.ReLU / nn.Hardswish of torchvision's MobileNetV3 blocks as AudioEmbedding runs them
+// (/root/reference/audioembed.py:61 -> vision_model.features, /root/reference/vicreg_audio_params.py:52-54) and their
+// autograd.  On MIOpen the two large-map layers alone took 0.8 ms forward and 0.77 ms backward each at batch 128
+// ([128,16,120,123]); the activation and its backward were separate elementwise passes.  Here:
+//   forward : per-channel shifted sums (partials + fixed-order finalize, running statistics updated as torch does),
+//             then ONE pass y = act(w (x - mean) invstd + b);
+//   backward: ONE reduction pass over (x, dy) that recomputes the pre-activation value z, applies act'(z) and sums
+//             dz and dz * xhat per channel, a finalize (dw, db), and ONE pass dx = w invstd (dz - mean(dz) - xhat mean(dz xhat)).
+// Nothing but mean / invstd is saved between forward and backward.  All sums in a fixed order (deterministic).
+#include "ias_common.h"
+#include <cstdint>
+
+#define BN_THREADS 256
+#define BN_ACT_NONE 0
+#define BN_ACT_RELU 1
+#define BN_ACT_HARDSWISH 2
+
+__device__ __forceinline__ float bn_act(float z, int act) {
+  if (act == BN_ACT_RELU) return fmaxf(z, 0.0f);
+  if (act == BN_ACT_HARDSWISH) return z * fminf(fmaxf(z + 3.0f, 0.0f), 6.0f) / 6.0f;
+  return z;
+}
+// d act / dz with torch's conventions at the kinks (threshold_backward: z > 0; hardswish_backward: z < -3 -> 0,
+// z <= 3 -> z / 3 + 0.5, else 1)
+__device__ __forceinline__ float bn_act_grad(float z, int act) {
+  if (act == BN_ACT_RELU) return z > 0.0f ? 1.0f : 0.0f;
+  if (act == BN_ACT_HARDSWISH) return z < -3.0f ? 0.0f : (z <= 3.0f ? z / 3.0f + 0.5f : 1.0f);
+  return 1.0f;
+}
+
+__device__ __forceinline__ void bn_block_reduce2(double& a, double& b) {
+  __shared__ double s_a[BN_THREADS], s_b[BN_THREADS];
+  const int tid = threadIdx.x;
+  s_a[tid] = a; s_b[tid] = b;
+  __syncthreads();
+#pragma unroll
+  for (int d = BN_THREADS / 2; d > 0; d >>= 1) {
+    if (tid < d) { s_a[tid] += s_a[tid + d]; s_b[tid] += s_b[tid + d]; }
+    __syncthreads();
+  }
+  a = s_a[0]; b = s_b[0];
+}
+
+// Workgroup (c, s) sums over the batches b = s, s + S, ... of channel c.  MODE 0: sum (x - K), sum (x - K)^2 with the
+// shift K = x[0, c, 0] (no cancellation for channels with a large mean).  MODE 1: sum dz, sum dz xhat.
+template <int MODE>
+__global__ __launch_bounds__(BN_THREADS) void bn_partials_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd,
+                                                                  const float* __restrict__ weight,
+                                                                  const float* __restrict__ bias, double* __restrict__ partials,
+                                                                  int B, int C, int HW, int act) {
+  const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y, tid = threadIdx.x;
+  float p0 = 0.0f, p1 = 0.0f;
+  float k = 0.0f, m = 0.0f, is = 1.0f, w = 1.0f, bb = 0.0f;
+  if (MODE == 0) k = x[(size_t)c * HW];
+  else { m = mean[c]; is = invstd[c]; w = weight ? weight[c] : 1.0f; bb = bias ? bias[c] : 0.0f; }
+  const bool vec = (HW & 3) == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0;
+  for (int b = s; b < B; b += S) {
+    const size_t base = ((size_t)b * C + c) * HW;
+    auto one = [&](float xv, float gv) {
+      if (MODE == 0) { const float d = xv - k; p0 += d; p1 = fmaf(d, d, p1); }
+      else {
+        const float xh = (xv - m) * is;
+        const float dz = gv * bn_act_grad(fmaf(w, xh, bb), act);
+        p0 += dz; p1 = fmaf(dz, xh, p1);
+      }
+    };
+    if (vec) {
+      const float4* x4 = reinterpret_cast<const float4*>(x + base);
+      const float4* g4 = MODE == 1 ? reinterpret_cast<const float4*>(dy + base) : nullptr;
+      for (int i = tid; i < (HW >> 2); i += BN_THREADS) {
+        const float4 a = x4[i];
+        float4 g = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == 1) g = g4[i];
+        one(a.x, g.x); one(a.y, g.y); one(a.z, g.z); one(a.w, g.w);
+      }
+    } else {
+      for (int i = tid; i < HW; i += BN_THREADS) one(x[base + i], MODE == 1 ? dy[base + i] : 0.0f);
+    }
+  }
+  double d0 = (double)p0, d1 = (double)p1;
+  bn_block_reduce2(d0, d1);
+  if (tid == 0) { partials[((size_t)c * S + s) * 2] = d0; partials[((size_t)c * S + s) * 2 + 1] = d1; }
+}
+
+// mean, biased variance -> save_mean, save_invstd, running statistics (momentum m: r = (1 - m) r + m stat, unbiased
+// variance in the running one, as torch.nn.BatchNorm2d)
+__global__ void bn_finalize_stats_kernel(const float* __restrict__ x, const double* __restrict__ partials,
+                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var, int C, int S,
+                                         int HW, double n, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < S; ++s) { s1 += partials[((size_t)c * S + s) * 2]; s2 += partials[((size_t)c * S + s) * 2 + 1]; }
+  const double k = (double)x[(size_t)c * HW];
+  const double dm = s1 / n;
+  double var = s2 / n - dm * dm;
+  if (var < 0.0) var = 0.0;
+  const double mean = k + dm;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+  if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * (n > 1.0 ? n / (n - 1.0) : 1.0));
+}
+
+__global__ void bn_finalize_grads_kernel(const double* __restrict__ partials, float* __restrict__ gw, float* __restrict__ gb,
+                                         float* __restrict__ sums, int C, int S) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < S; ++s) { s1 += partials[((size_t)c * S + s) * 2]; s2 += partials[((size_t)c * S + s) * 2 + 1]; }
+  if (gb) gb[c] = (float)s1;
+  if (gw) gw[c] = (float)s2;
+  sums[2 * c] = (float)s1; sums[2 * c + 1] = (float)s2;
+}
+
+// One elementwise pass over planes (b, c): MODE 0 y = act(w xhat + b); MODE 1 dx = w invstd (dz - sum_dz / n - xhat sum_dzxh / n)
+template <int MODE, int VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ weight, const float* __restrict__ bias,
+                                                               const float* __restrict__ sums, float* __restrict__ out, int C,
+                                                               int HW, long long total_vec, float inv_n, int act) {
+  typedef float vt __attribute__((ext_vector_type(VEC)));
+  const int hwv = HW / VEC;
+  for (long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x; i < total_vec; i += (long long)gridDim.x * BN_THREADS) {
+    const int c = (int)((i / hwv) % C);
+    const float m = mean[c], is = invstd[c], w = weight ? weight[c] : 1.0f, bb = bias ? bias[c] : 0.0f;
+    const vt xv = reinterpret_cast<const vt*>(x)[i];
+    vt o;
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = bn_act(fmaf(w, (xv[e] - m) * is, bb), act);
+    } else {
+      const vt gv = reinterpret_cast<const vt*>(dy)[i];
+      const float a = sums[2 * c] * inv_n, b2 = sums[2 * c + 1] * inv_n, ws = w * is;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float xh = (xv[e] - m) * is;
+        const float dz = gv[e] * bn_act_grad(fmaf(w, xh, bb), act);
+        o[e] = ws * (dz - a - xh * b2);
+      }
+    }
+    reinterpret_cast<vt*>(out)[i] = o;
+  }
+}
+// (float1 as a 1-wide ext vector is not subscriptable on every compiler version: scalar specialisation)
+template <int MODE>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_scalar_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                      const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                      const float* __restrict__ sums, float* __restrict__ out, int C,
+                                                                      int HW, long long total, float inv_n, int act) {
+  for (long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * BN_THREADS) {
+    const int c = (int)((i / HW) % C);
+    const float m = mean[c], is = invstd[c], w = weight ? weight[c] : 1.0f, bb = bias ? bias[c] : 0.0f;
+    const float xh = (x[i] - m) * is;
+    if (MODE == 0) out[i] = bn_act(fmaf(w, xh, bb), act);
+    else {
+      const float dz = dy[i] * bn_act_grad(fmaf(w, xh, bb), act);
+      out[i] = w * is * (dz - sums[2 * c] * inv_n - xh * sums[2 * c + 1] * inv_n);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------ C ABI
+static int bn_split(int B, int C) {
+  int s = (2048 + C - 1) / C;
+  if (s < 1) s = 1;
+  if (s > B) s = B;
+  if (s > 64) s = 64;
+  return s;
+}
+// doubles of scratch the forward / backward need (partials [C][split][2])
+extern "C" long long ias_bn_scratch_doubles(int B, int C) {
+  if (B <= 0 || C <= 0) return IAS_ERR_ARG;
+  return (long long)C * bn_split(B, C) * 2;
+}
+
+template <int MODE>
+static void bn_launch_apply(hipStream_t stream, const float* x, const float* dy, const float* mean, const float* invstd,
+                            const float* weight, const float* bias, const float* sums, float* out, int B, int C, int HW,
+                            int act) {
+  const long long total = (long long)B * C * HW;
+  const float inv_n = 1.0f / (float)((long long)B * HW);
+  const bool a16 = ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy) & 15) == 0);
+  const int vec = (a16 && (HW & 3) == 0) ? 4 : ((a16 && (HW & 1) == 0) ? 2 : 1);
+  const long long tv = total / vec;
+  long long blocks = (tv + BN_THREADS - 1) / BN_THREADS;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (vec == 4)
+    hipLaunchKernelGGL((bn_apply_kernel<MODE, 4>), dim3((unsigned)blocks), dim3(BN_THREADS), 0, stream, x, dy, mean, invstd,
+                       weight, bias, sums, out, C, HW, tv, inv_n, act);
+  else if (vec == 2)
+    hipLaunchKernelGGL((bn_apply_kernel<MODE, 2>), dim3((unsigned)blocks), dim3(BN_THREADS), 0, stream, x, dy, mean, invstd,
+                       weight, bias, sums, out, C, HW, tv, inv_n, act);
+  else
+    hipLaunchKernelGGL((bn_apply_scalar_kernel<MODE>), dim3((unsigned)blocks), dim3(BN_THREADS), 0, stream, x, dy, mean,
+                       invstd, weight, bias, sums, out, C, HW, tv, inv_n, act);
+}
+
+// y = act(BatchNorm_train(x)); x, y [B,C,HW] fp32 contiguous; weight / bias [C] or NULL; running_mean / running_var [C]
+// or NULL (updated in place with `momentum`); save_mean / save_invstd [C] out; act 0 none, 1 ReLU, 2 Hardswish.
+extern "C" int ias_bn_act_forward(const float* x, const float* weight, const float* bias, float* running_mean,
+                                  float* running_var, float* y, float* save_mean, float* save_invstd, double* scratch,
+                                  int B, int C, int HW, float eps, float momentum, int act, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !y || !save_mean || !save_invstd || !scratch || B <= 0 || C <= 0 || C > 65535 || HW <= 0 || act < 0 || act > 2)
+    return IAS_ERR_ARG;
+  const int S = bn_split(B, C);
+  hipLaunchKernelGGL((bn_partials_kernel<0>), dim3(C, S), dim3(BN_THREADS), 0, stream, x, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, scratch, B, C,
+                     HW, act);
+  hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, x, scratch, save_mean, save_invstd,
+                     running_mean, running_var, C, S, HW, (double)B * HW, eps, momentum);
+  bn_launch_apply<0>(stream, x, nullptr, save_mean, save_invstd, weight, bias, nullptr, y, B, C, HW, act);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+// Backward of ias_bn_act_forward: dy [B,C,HW] -> dx [B,C,HW], gw / gb [C] (either may be NULL); sums [C][2] floats scratch.
+extern "C" int ias_bn_act_backward(const float* x, const float* dy, const float* weight, const float* bias,
+                                   const float* save_mean, const float* save_invstd, float* dx, float* gw, float* gb,
+                                   double* scratch, float* sums, int B, int C, int HW, int act, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !dy || !dx || !save_mean || !save_invstd || !scratch || !sums || B <= 0 || C <= 0 || C > 65535 || HW <= 0 ||
+      act < 0 || act > 2)
+    return IAS_ERR_ARG;
+  const int S = bn_split(B, C);
+  hipLaunchKernelGGL((bn_partials_kernel<1>), dim3(C, S), dim3(BN_THREADS), 0, stream, x, dy, save_mean, save_invstd, weight,
+                     bias, scratch, B, C, HW, act);
+  hipLaunchKernelGGL(bn_finalize_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch, gw, gb, sums, C, S);
+  bn_launch_apply<1>(stream, x, dy, save_mean, save_invstd, weight, bias, sums, dx, B, C, HW, act);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}

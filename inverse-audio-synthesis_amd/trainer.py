@@ -101,7 +101,8 @@ class Trainer:
     # ---- whole-step hipGraph (trainer.cuda_graph) --------------------------------------------------------------
     def _use_graph(self):
         return bool(self.cfg.trainer.get("cuda_graph")) and self.world == 1 and self.stage == "vicreg" and \
-            self.device.type == "cuda" and hasattr(self.module, "voice")
+            self.device.type == "cuda" and hasattr(self.module, "voice") and not getattr(self, "_graph_failed", False) \
+            and not os.environ.get("IAS_CHECK_STATUS")
 
     def _graph_step(self, batch, step, warmup=3):
         """One training step as a replay of ONE captured hipGraph: render + PQMF + trunk + projector + loss + backward +
@@ -125,10 +126,20 @@ class Trainer:
                 return
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.bucketer.begin_step()            # zero the flat gradient buffers (static addresses) in the graph
+            try:
+                with torch.cuda.graph(g):
+                    self.bucketer.begin_step()        # drop the gradients: the step's own live in the graph's pool
+                    m.training_step(None, step).backward()
+                    opt.step()
+            except Exception as ex:                   # something in the step cannot be captured: stay eager
+                import warnings
+                warnings.warn(f"trainer.cuda_graph: capture failed ({type(ex).__name__}: {ex}); running eagerly")
+                self._graph_failed = True
+                torch.cuda.synchronize(self.device)
+                self.bucketer.begin_step()
                 m.training_step(None, step).backward()
                 opt.step()
+                return
             self._graph = g
         g.replay()
 

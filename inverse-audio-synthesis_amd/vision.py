@@ -133,6 +133,75 @@ class StemConv2d(nn.Conv2d):
         return super().forward(x)
 
 
+class _BNActFn(torch.autograd.Function):
+    """Training-mode batch norm + activation as the HIP kernels of csrc/bn_kernels.hip (ias_bn_act_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act):
+        from . import _lib
+        lib = _lib.load()
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * C)
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        scratch = torch.empty(int(lib.ias_bn_scratch_doubles(B, C)), dtype=torch.float64, device=x.device)
+        _lib.check(lib.ias_bn_act_forward(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(running_mean),
+                                          _lib.ptr(running_var), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(invstd),
+                                          _lib.ptr(scratch), B, C, HW, float(eps), float(momentum), int(act),
+                                          _lib.stream()), "ias_bn_act_forward")
+        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        ctx.act = int(act)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.load()
+        x, weight, bias, mean, invstd = ctx.saved_tensors
+        g = g.contiguous()
+        B, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * C)
+        dx = torch.empty_like(x)
+        gw = torch.empty_like(weight) if weight is not None else None
+        gb = torch.empty_like(bias) if bias is not None else None
+        scratch = torch.empty(int(lib.ias_bn_scratch_doubles(B, C)), dtype=torch.float64, device=x.device)
+        sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        _lib.check(lib.ias_bn_act_backward(_lib.ptr(x), _lib.ptr(g), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(mean),
+                                           _lib.ptr(invstd), _lib.ptr(dx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(scratch),
+                                           _lib.ptr(sums), B, C, HW, ctx.act, _lib.stream()), "ias_bn_act_backward")
+        return dx, gw, gb, None, None, None, None, None
+
+
+_ACT_CODE = {None: 0, nn.ReLU: 1, nn.Hardswish: 2}
+
+
+class BatchNormAct2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters, buffers and state_dict keys) that also applies the activation that follows it in
+    torchvision's ConvNormActivation (``act``: None, nn.ReLU or nn.Hardswish).  Training on a ROCm device: one fused HIP
+    forward and one fused HIP backward (csrc/bn_kernels.hip); evaluation, CPU tensors and exotic settings: the torch ops."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, act=None):
+        super().__init__(num_features, eps=eps, momentum=momentum)
+        assert act in _ACT_CODE
+        self.act_code = _ACT_CODE[act]
+
+    def forward(self, x):
+        if self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and self.track_running_stats and \
+                self.momentum is not None and self.affine:
+            if self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            return _BNActFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                  self.momentum, self.act_code)
+        y = super().forward(x)
+        if self.act_code == 1:
+            return F.relu(y)
+        if self.act_code == 2:
+            return F.hardswish(y)
+        return y
+
+
 def _divisible(v, d=8):
     new = max(d, int(v + d / 2) // d * d)
     return new + d if new < 0.9 * v else new
@@ -142,10 +211,10 @@ class ConvBNAct(nn.Sequential):
     def __init__(self, cin, cout, k=3, stride=1, groups=1, act=None):
         conv = PointwiseConv2d if (k == 1 and groups == 1) else (DepthwiseConv2d if groups == cin == cout else
                                                                  (StemConv2d if (cin, cout, k, stride) == (3, 16, 3, 2) else nn.Conv2d))
+        # torchvision's layout is [conv, norm, activation]; the activation has no parameters, so folding it into the
+        # norm module (index 1) leaves every state_dict key where it was
         layers = [conv(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False),
-                  nn.BatchNorm2d(cout, eps=0.001, momentum=0.01)]
-        if act is not None:
-            layers.append(act(inplace=True))
+                  BatchNormAct2d(cout, eps=0.001, momentum=0.01, act=act)]
         super().__init__(*layers)
 
 

@@ -72,3 +72,43 @@ def test_trunk_matches_plain_conv2d_modules(lib, dev):
     rgrads = torch.autograd.grad((ref * w).sum(), params)
     for a, b in zip(grads, rgrads):
         assert (a - b).abs().max().item() <= 2e-3 * max(1e-3, b.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 120, 123), (4, 24, 30, 31), (3, 5, 7, 9), (16, 576, 8, 8), (2, 3, 1, 1)])
+@pytest.mark.parametrize("act", [None, torch.nn.ReLU, torch.nn.Hardswish])
+def test_fused_batchnorm_activation_matches_torch(lib, dev, shape, act):
+    """BatchNormAct2d (ias_bn_act_forward / _backward) against nn.BatchNorm2d + activation in fp64 on the same data:
+    output, running statistics after two steps, gradients w.r.t. input, weight and bias."""
+    from inverse_audio_synthesis_amd.vision import BatchNormAct2d
+    C = shape[1]
+    g = torch.Generator().manual_seed(7)
+    fused = BatchNormAct2d(C, eps=0.001, momentum=0.01, act=act).to(dev).train()
+    ref = torch.nn.BatchNorm2d(C, eps=0.001, momentum=0.01).double().train()
+    with torch.no_grad():
+        w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+        fused.weight.copy_(w); fused.bias.copy_(b); ref.weight.copy_(w.double()); ref.bias.copy_(b.double())
+    actf = (lambda t: t) if act is None else act()
+    for step in range(2):
+        x = torch.randn(shape, generator=g) * 2.0 + torch.linspace(-5, 50, C).view(1, C, 1, 1)   # large channel means
+        up = torch.randn(shape, generator=g)
+        xf = x.to(dev).requires_grad_(True)
+        xr = x.double().requires_grad_(True)
+        yf = fused(xf)
+        yr = actf(ref(xr))
+        yf.backward(up.to(dev))
+        yr.backward(up.double())
+        assert (yf.detach().cpu().double() - yr.detach()).abs().max().item() <= 2e-5 * max(1.0, yr.abs().max().item())
+        sc = max(1.0, xr.grad.abs().max().item())
+        assert (xf.grad.cpu().double() - xr.grad).abs().max().item() <= 5e-5 * sc, "dx"
+        for name in ("weight", "bias"):
+            gf, gr = getattr(fused, name).grad.cpu().double(), getattr(ref, name).grad
+            assert (gf - gr).abs().max().item() <= 1e-4 * max(1.0, gr.abs().max().item()), name
+        fused.zero_grad(); ref.zero_grad()
+    assert (fused.running_mean.cpu().double() - ref.running_mean).abs().max().item() <= 1e-5 * 50
+    assert (fused.running_var.cpu().double() - ref.running_var).abs().max().item() <= 1e-5 * max(1.0, ref.running_var.max().item())
+    assert int(fused.num_batches_tracked) == 2
+    fused.eval()
+    xe = torch.randn(shape, generator=g)
+    ye = fused(xe.to(dev)).cpu().double()
+    ref.eval()
+    assert (ye - actf(ref(xe.double()))).abs().max().item() <= 1e-4
