@@ -5,40 +5,11 @@
 // convolutions (3x3 / 5x5, stride 1 / 2) and the 3 -> 16 stem of that network run through MIOpen's fp32 fallbacks:
 // naive_conv_* kernels, Winograd kernels of 0.85 ms for a 15 x 16 map, and an im2col + GEMM PER SAMPLE for the stem
 // (measured 10 of the 40 ms of a batch-128 pretraining step).  They are memory-bound stencils; these kernels do them
-// at stencil cost: one lane per output element, the k x k taps of the lane's channel in SGPRs (a workgroup stays
-// inside one (b, c) plane), the weight gradient as per-workgroup partial sums reduced in a fixed order (deterministic).
+// at stencil cost (LDS-tiled, see dw_tile_kernel), the weight gradient as per-plane partial sums reduced in a fixed
+// order (deterministic).
 #include "ias_common.h"
 
 #define CV_THREADS 256
-
-// out[b,c,ho,wo] = sum_{kh,kw} w[c,kh,kw] x[b,c,ho*S+kh-P,wo*S+kw-P]       (groups = C, zero padding P = (K-1)/2)
-template <int K, int S>
-__global__ __launch_bounds__(CV_THREADS) void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                float* __restrict__ out, int C, int H, int W, int Ho,
-                                                                int Wo) {
-  constexpr int P = (K - 1) / 2;
-  const int plane = blockIdx.x, c = plane % C;
-  float wt[K * K];
-#pragma unroll
-  for (int i = 0; i < K * K; ++i) wt[i] = w[c * K * K + i];
-  const float* xp = x + (size_t)plane * H * W;
-  float* op = out + (size_t)plane * Ho * Wo;
-  for (int o = blockIdx.y * CV_THREADS + threadIdx.x; o < Ho * Wo; o += gridDim.y * CV_THREADS) {
-    const int ho = o / Wo, wo = o - ho * Wo;
-    float acc = 0.0f;
-#pragma unroll
-    for (int kh = 0; kh < K; ++kh) {
-      const int hi = ho * S + kh - P;
-      if (hi < 0 || hi >= H) continue;
-#pragma unroll
-      for (int kw = 0; kw < K; ++kw) {
-        const int wi = wo * S + kw - P;
-        if (wi >= 0 && wi < W) acc = fmaf(wt[kh * K + kw], xp[hi * W + wi], acc);
-      }
-    }
-    op[o] = acc;
-  }
-}
 
 // gx[b,c,hi,wi] = sum_{kh,kw : (hi+P-kh) % S == 0, ...} w[c,kh,kw] g[b,c,(hi+P-kh)/S,(wi+P-kw)/S]
 template <int K, int S>
@@ -73,61 +44,153 @@ __global__ __launch_bounds__(CV_THREADS) void dwconv_bwd_data_kernel(const float
   }
 }
 
-// partial[chunk][c][kh*K+kw] = sum over the chunk's batch rows and all (ho,wo) of g[b,c,ho,wo] x[b,c,ho*S+kh-P,wo*S+kw-P]
-// grid (C, nchunk); the chunk's planes are walked by the whole workgroup, a lane keeps its K*K sums in registers.
-template <int K, int S>
-__global__ __launch_bounds__(CV_THREADS) void dwconv_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                                       float* __restrict__ partial, int B, int C, int H,
-                                                                       int W, int Ho, int Wo, int rows_per_chunk) {
-  constexpr int P = (K - 1) / 2;
-  __shared__ float s_red[CV_THREADS / 64][K * K];
-  const int c = blockIdx.x, chunk = blockIdx.y;
-  const int b0 = chunk * rows_per_chunk, b1 = min(b0 + rows_per_chunk, B);
-  float acc[K * K];
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-tiled depthwise forward / stride-1 input gradient / weight gradient.  The first version of these kernels read
+// every tap from global memory: 25 L1 hits per output at k = 5, and the L1 (64 B/clk/CU) bounded them (67 us for a
+// [128,240,15,16] layer whose HBM traffic is 10 us; the stride-2 input gradient below still has that form).  Here a
+// workgroup stages its input planes (zero-padded halo included) in LDS once; a thread owns FOUR consecutive outputs of
+// a row and reads the 3 S + K inputs they share as two or three ds_read_b128 per kernel row (40 B of LDS per output
+// instead of 100 B of L1), with no bounds checks in the inner loops.  Small planes share a workgroup (pp planes,
+// 256 / pp threads each, pp a power of two); large planes are walked in row tiles.
+// MODE 0: out = conv(x, w) (flip != 0: taps reversed -- the stride-1 input gradient is this with x = g).
+// MODE 1: partial[plane][K K] = sum over the plane of g * window(x); the per-thread sums meet in LDS and are added in
+//         a fixed order (deterministic); a second launch adds the planes of a channel.
+template <int K, int S, int MODE>
+__global__ __launch_bounds__(CV_THREADS) void dw_tile_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ g, float* __restrict__ out, int C,
+                                                             int H, int W, int Ho, int Wo, int planes, int pp,
+                                                             int rows_out, int Wp, int flip) {
+  constexpr int P = (K - 1) / 2, KK = K * K, NSEG4 = (3 * S + K + 3) / 4;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float s_dw[];
+  const int rows_in = (rows_out - 1) * S + K;
+  float* s_x = s_dw;                                   // [pp][rows_in][Wp]
+  float* s_w = s_dw + pp * rows_in * Wp;               // MODE 0: [pp][KK] taps; MODE 1: [CV_THREADS][KK] partial sums
+  const int tid = threadIdx.x;
+  const int p0 = blockIdx.x * pp, npl = min(pp, planes - p0);
+  const int tpp = CV_THREADS / pp, slot = tid / tpp, tl = tid - slot * tpp;   // this thread's plane and rank in it
+  const int quads = (Wo + 3) >> 2;
+  if (MODE == 0) {
+    for (int i = tid; i < npl * KK; i += CV_THREADS) {
+      const int pl = i / KK, t = i - pl * KK;
+      s_w[i] = w[((p0 + pl) % C) * KK + (flip ? KK - 1 - t : t)];
+    }
+  }
+  float aw[MODE == 1 ? KK : 1];
 #pragma unroll
-  for (int i = 0; i < K * K; ++i) acc[i] = 0.0f;
-  const int n = Ho * Wo;
-  for (int b = b0; b < b1; ++b) {
-    const float* xp = x + ((size_t)b * C + c) * H * W;
-    const float* gp = g + ((size_t)b * C + c) * n;
-    for (int o = threadIdx.x; o < n; o += CV_THREADS) {
-      const int ho = o / Wo, wo = o - ho * Wo;
-      const float gv = gp[o];
+  for (int i = 0; i < (MODE == 1 ? KK : 1); ++i) aw[i] = 0.0f;
+
+  for (int r0 = 0; r0 < Ho; r0 += rows_out) {
+    const int nr = min(rows_out, Ho - r0);
+    __syncthreads();                                   // the previous tile has been consumed
+    // staging: 32 lanes walk a row (one index division per row, none per element), 8 rows at a time
+    for (int pr = tid >> 5; pr < npl * rows_in; pr += CV_THREADS / 32) {
+      const int pl = pr / rows_in, r = pr - pl * rows_in;
+      const int hi = r0 * S - P + r;
+      const bool rok = hi >= 0 && hi < H;
+      const float* xr = x + ((size_t)(p0 + pl) * H + (rok ? hi : 0)) * W;
+      float* sr = s_x + pr * Wp;
+      for (int col = tid & 31; col < Wp; col += 32) {
+        const int wi = col - P;
+        sr[col] = (rok && wi >= 0 && wi < W) ? xr[wi] : 0.0f;
+      }
+    }
+    __syncthreads();
+    if (slot < npl) {
+      const size_t obase = (size_t)(p0 + slot) * Ho * Wo;
+      for (int item = tl; item < nr * quads; item += tpp) {
+        const int r = item / quads, q = item - r * quads;
+        const float* row0 = s_x + (slot * rows_in + r * S) * Wp + q * 4 * S;
+        const int o = (r0 + r) * Wo + q * 4;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (MODE == 1) {
 #pragma unroll
-      for (int kh = 0; kh < K; ++kh) {
-        const int hi = ho * S + kh - P;
-        if (hi < 0 || hi >= H) continue;
+          for (int j = 0; j < 4; ++j) gv[j] = (q * 4 + j < Wo) ? g[obase + o + j] : 0.0f;
+        }
 #pragma unroll
-        for (int kw = 0; kw < K; ++kw) {
-          const int wi = wo * S + kw - P;
-          if (wi >= 0 && wi < W) acc[kh * K + kw] = fmaf(gv, xp[hi * W + wi], acc[kh * K + kw]);
+        for (int kh = 0; kh < K; ++kh) {
+          float seg[4 * NSEG4];
+#pragma unroll
+          for (int v = 0; v < NSEG4; ++v) {
+            const f4 t = *reinterpret_cast<const f4*>(row0 + kh * Wp + 4 * v);
+            seg[4 * v] = t[0]; seg[4 * v + 1] = t[1]; seg[4 * v + 2] = t[2]; seg[4 * v + 3] = t[3];
+          }
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            if (MODE == 0) {
+              const float wt = s_w[slot * KK + kh * K + kw];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[j] = fmaf(wt, seg[j * S + kw], acc[j]);
+            } else {
+              float t = aw[kh * K + kw];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) t = fmaf(gv[j], seg[j * S + kw], t);
+              aw[kh * K + kw] = t;
+            }
+          }
+        }
+        if (MODE == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < Wo) out[obase + o + j] = acc[j];
         }
       }
     }
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (MODE == 1) {
+    __syncthreads();
 #pragma unroll
-  for (int i = 0; i < K * K; ++i) {
-    float v = acc[i];
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    if (lane == 0) s_red[wave][i] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < K * K) {
-    float v = 0.0f;
-    for (int wv = 0; wv < CV_THREADS / 64; ++wv) v += s_red[wv][threadIdx.x];
-    partial[((size_t)chunk * C + c) * K * K + threadIdx.x] = v;
+    for (int i = 0; i < KK; ++i) s_w[tid * KK + i] = aw[i];
+    __syncthreads();
+    for (int i = tid; i < npl * KK; i += CV_THREADS) {
+      const int pl = i / KK, t = i - pl * KK;
+      float v = 0.0f;
+      for (int j = 0; j < tpp; ++j) v += s_w[(pl * tpp + j) * KK + t];
+      out[(size_t)(p0 + pl) * KK + t] = v;
+    }
   }
 }
 
-// out[i] = sum_chunk partial[chunk][i]   (fixed order)
+struct DwTile { int pp, rows_out, Wp; size_t lds; };
+static DwTile dw_tile_geometry(int H, int W, int Ho, int Wo, int K, int S, int mode) {
+  (void)H;
+  const int P = (K - 1) / 2, quads = (Wo + 3) / 4, nseg4 = (3 * S + K + 3) / 4;
+  int Wp = W + 2 * P;
+  const int need = (quads - 1) * 4 * S + 4 * nseg4;
+  if (Wp < need) Wp = need;
+  Wp = (Wp + 3) & ~3;
+  const int budget = 8192;                              // floats of staged input per workgroup (32 KB)
+  DwTile t;
+  const int rows_full = (Ho - 1) * S + K;
+  if (rows_full * Wp <= budget) {
+    t.rows_out = Ho;
+    int pp = 1;
+    while (pp * 2 <= 64 && pp * 2 * rows_full * Wp <= budget && pp * 2 * Ho * quads <= CV_THREADS) pp *= 2;
+    t.pp = pp;
+  } else {
+    int rin = budget / Wp;
+    int ro = (rin - K) / S + 1;
+    if (ro < 1) ro = 1;
+    t.rows_out = ro;
+    t.pp = 1;
+  }
+  t.Wp = Wp;
+  const int rows_in = (t.rows_out - 1) * S + K;
+  t.lds = sizeof(float) * ((size_t)t.pp * rows_in * Wp + (mode == 1 ? (size_t)CV_THREADS * K * K : (size_t)t.pp * K * K));
+  return t;
+}
+
+// out[i] = sum_chunk partial[chunk][i]: one wave per output, lane l adds chunks l, l + 64, ... and the lanes meet in a
+// butterfly (a fixed order: deterministic)
 __global__ __launch_bounds__(CV_THREADS) void conv_reduce_partials_kernel(const float* __restrict__ partial,
                                                                           float* __restrict__ out, int n, int nchunk) {
-  const int i = blockIdx.x * CV_THREADS + threadIdx.x;
+  const int i = blockIdx.x * (CV_THREADS / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   float v = 0.0f;
-  for (int k = 0; k < nchunk; ++k) v += partial[(size_t)k * n + i];
-  out[i] = v;
+  for (int k = lane; k < nchunk; k += 64) v += partial[(size_t)k * n + i];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  if (lane == 0) out[i] = v;
 }
 
 // ---- stem: Conv2d(CIN, COUT, 3, stride 2, padding 1, bias=False), CIN = 3, COUT = 16 -----------------------------
@@ -232,13 +295,24 @@ static int cv_check(const void* a, const void* b, const void* c, int B, int C, i
 extern "C" int ias_conv_out_size(int n, int K, int S) { return (n + 2 * ((K - 1) / 2) - K) / S + 1; }
 
 // Depthwise Conv2d(C, C, K, stride S, padding (K-1)/2, groups=C, bias=False) forward: x [B,C,H,W], w [C,1,K,K] -> out
+#define DW_TILE_DISPATCH(MODE, ...)                                                                       \
+  do {                                                                                                   \
+    if (K == 3 && S == 1) hipLaunchKernelGGL((dw_tile_kernel<3, 1, MODE>), __VA_ARGS__);                 \
+    else if (K == 3 && S == 2) hipLaunchKernelGGL((dw_tile_kernel<3, 2, MODE>), __VA_ARGS__);            \
+    else if (K == 5 && S == 1) hipLaunchKernelGGL((dw_tile_kernel<5, 1, MODE>), __VA_ARGS__);            \
+    else if (K == 5 && S == 2) hipLaunchKernelGGL((dw_tile_kernel<5, 2, MODE>), __VA_ARGS__);            \
+    else return IAS_ERR_UNSUPPORTED;                                                                     \
+  } while (0)
+
 extern "C" int ias_dwconv_forward(const float* x, const float* w, float* out, int B, int C, int H, int W, int K, int S,
                                   void* stream_) {
   int rc = cv_check(x, w, out, B, C, H, W, K, S);
   if (rc) return rc;
   const int Ho = ias_conv_out_size(H, K, S), Wo = ias_conv_out_size(W, K, S);
-  const dim3 grid(B * C, cv_grid_x(Ho * Wo)), block(CV_THREADS);
-  CV_DISPATCH(dwconv_fwd_kernel, grid, block, 0, (hipStream_t)stream_, x, w, out, C, H, W, Ho, Wo);
+  const DwTile t = dw_tile_geometry(H, W, Ho, Wo, K, S, 0);
+  const int planes = B * C;
+  DW_TILE_DISPATCH(0, dim3((planes + t.pp - 1) / t.pp), dim3(CV_THREADS), t.lds, (hipStream_t)stream_, x, w,
+                   (const float*)nullptr, out, C, H, W, Ho, Wo, planes, t.pp, t.rows_out, t.Wp, 0);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
@@ -248,16 +322,22 @@ extern "C" int ias_dwconv_backward_data(const float* g, const float* w, float* g
   int rc = cv_check(g, w, gx, B, C, H, W, K, S);
   if (rc) return rc;
   const int Ho = ias_conv_out_size(H, K, S), Wo = ias_conv_out_size(W, K, S);
-  const dim3 grid(B * C, cv_grid_x(H * W)), block(CV_THREADS);
-  CV_DISPATCH(dwconv_bwd_data_kernel, grid, block, 0, (hipStream_t)stream_, g, w, gx, C, H, W, Ho, Wo);
+  if (S == 1) {   // Ho = H, Wo = W: the same convolution of g with the taps reversed
+    const DwTile t = dw_tile_geometry(Ho, Wo, H, W, K, 1, 0);
+    const int planes = B * C;
+    DW_TILE_DISPATCH(0, dim3((planes + t.pp - 1) / t.pp), dim3(CV_THREADS), t.lds, (hipStream_t)stream_, g, w,
+                     (const float*)nullptr, gx, C, Ho, Wo, H, W, planes, t.pp, t.rows_out, t.Wp, 1);
+  } else {
+    const dim3 grid(B * C, cv_grid_x(H * W)), block(CV_THREADS);
+    CV_DISPATCH(dwconv_bwd_data_kernel, grid, block, 0, (hipStream_t)stream_, g, w, gx, C, H, W, Ho, Wo);
+  }
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
-// floats of scratch for ias_dwconv_backward_weight
+// floats of scratch for ias_dwconv_backward_weight: one K x K partial per (b, c) plane
 extern "C" long long ias_dwconv_weight_scratch(int B, int C, int K) {
   if (B <= 0 || C <= 0 || K <= 0) return IAS_ERR_ARG;
-  int nchunk = B < 32 ? B : 32;
-  return (long long)nchunk * C * K * K;
+  return (long long)B * C * K * K;
 }
 
 // its gradient w.r.t. the weights: x [B,C,H,W], g [B,C,Ho,Wo] -> gw [C,1,K,K]; scratch: ias_dwconv_weight_scratch floats
@@ -265,16 +345,15 @@ extern "C" int ias_dwconv_backward_weight(const float* x, const float* g, float*
                                           int W, int K, int S, void* stream_) {
   int rc = cv_check(x, g, gw, B, C, H, W, K, S);
   if (rc) return rc;
-  if (!scratch || C > 65535) return IAS_ERR_ARG;
+  if (!scratch) return IAS_ERR_ARG;
   const int Ho = ias_conv_out_size(H, K, S), Wo = ias_conv_out_size(W, K, S);
-  int nchunk = B < 32 ? B : 32;
-  const int rows = (B + nchunk - 1) / nchunk;
-  nchunk = (B + rows - 1) / rows;
-  const dim3 grid(C, nchunk), block(CV_THREADS);
-  CV_DISPATCH(dwconv_bwd_weight_kernel, grid, block, 0, (hipStream_t)stream_, x, g, scratch, B, C, H, W, Ho, Wo, rows);
-  const int n = C * K * K;
-  hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((n + CV_THREADS - 1) / CV_THREADS), dim3(CV_THREADS), 0,
-                     (hipStream_t)stream_, scratch, gw, n, nchunk);
+  const DwTile t = dw_tile_geometry(H, W, Ho, Wo, K, S, 1);
+  const int planes = B * C;
+  DW_TILE_DISPATCH(1, dim3((planes + t.pp - 1) / t.pp), dim3(CV_THREADS), t.lds, (hipStream_t)stream_, x,
+                   (const float*)nullptr, g, scratch, C, H, W, Ho, Wo, planes, t.pp, t.rows_out, t.Wp, 0);
+  const int n = C * K * K;   // scratch is [b][c][K K]: the planes of a channel are n floats apart
+  hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((n + 3) / 4), dim3(CV_THREADS), 0, (hipStream_t)stream_, scratch, gw,
+                     n, B);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
@@ -297,7 +376,7 @@ extern "C" int ias_stem_backward_weight(const float* x, const float* g, float* g
   const int Ho = ias_conv_out_size(H, 3, 2), Wo = ias_conv_out_size(W, 3, 2);
   hipLaunchKernelGGL((stem_bwd_weight_kernel<3, 16>), dim3(STEM_CHUNKS_X, B), dim3(CV_THREADS), 0, (hipStream_t)stream_, x, g,
                      scratch, H, W, Ho, Wo, STEM_CHUNKS_X);
-  hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((432 + CV_THREADS - 1) / CV_THREADS), dim3(CV_THREADS), 0,
-                     (hipStream_t)stream_, scratch, gw, 432, B * STEM_CHUNKS_X);
+  hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((432 + 3) / 4), dim3(CV_THREADS), 0, (hipStream_t)stream_, scratch, gw,
+                     432, B * STEM_CHUNKS_X);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
