@@ -420,6 +420,222 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES == 10 ? 5 : 1) void stft_ke
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the linear-bin losses, frame part, on the same wave-per-frame FFT core (round 2).
+//
+// d loss / d x_f for  loss_mode 1: scale * sum |V - t|  and  loss_mode 2: one MR-STFT resolution (cotangent
+// gO = coef[0] (V - t) + coef[1] sign(V - t) / V), V = |X|^2 (power 2) or sqrt(|X|^2) (power 1; loss_mode 2 clamps at
+// eps), linear bins (n_out = N/2 + 1).  The first version (csrc/spectral_grad_kernels.hip: one workgroup per frame
+// pair, Stockham radix-4 with a workgroup barrier per stage) was 51 % of the configs[4] gradient step.  Here a wave
+// owns a frame end to end:
+//   forward   the stft_kernel passes (window, packed real FFT of N/2 complex points), unpack to X[k], X[N/2-k] in registers
+//   adjoint   G[k] = 2 gP[k] X[k] per bin, in registers (a lane owns bins k and N/2 - k)
+//   inverse   y[n] = Re sum_{k<=N/2} G[k] e^{+2 pi i k n / N} as ONE N/2-point complex inverse FFT:
+//             with a[k] = G[k], a[0] = G[0] + G[N/2];  b[k] = G[k] e^{+2 pi i k / N}, b[0] = G[0] - G[N/2]:
+//             y[2m] + i y[2m+1] = IDFT(Zin)[m],  Zin[k] = (a[k] + conj a[N/2-k]) / 2 + i (b[k] + conj b[N/2-k]) / 2;
+//             the inverse transform is the same three passes on conj(Zin), conjugated again at the end
+//   output    frame_grad[f][n] = window[n] y[n]  (the overlap-add stays in stft_grad_ola_kernel)
+extern "C" int ias_stft_num_frames(int T, int n_fft, int hop);
+struct SgwArgs {
+  const float* audio; const float* tables; const float* target; const double* coef; float* frame_grad;
+  int T, F, hop, groups, power2, loss_mode;
+  float scale, eps;
+};
+
+template <int LOG2N>
+__global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
+  constexpr int SP_WAVES = 4, SP_THREADS = 256;
+  constexpr int NFFT = 1 << LOG2N, N2 = NFFT / 2, R = N2 / 64, NPAIR = 8 * R, NP_IT = (NPAIR + 63) / 64;
+  constexpr int SCR = NPAIR * 9, NUNP = (N2 / 2) / 64 + 1, NB = N2 + 1;
+  constexpr int NTAB = 64 * (2 * R + 2 * R + 16 * NP_IT + 2 * NUNP);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  cpx* s_scr = reinterpret_cast<cpx*>(smem);
+  cpx* s_tab = s_scr + SP_WAVES * SCR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
+  const float* arow = a.audio + (size_t)b * a.T;
+  for (int i = tid; i < NTAB / 2; i += SP_THREADS) {
+    const int pp = i >> 6, l = i & 63;
+    s_tab[i] = cmk(a.tables[64 * (2 * pp) + l], a.tables[64 * (2 * pp + 1) + l]);
+  }
+  const cpx* t_win = s_tab + lane;
+  const cpx* t_tw1 = t_win + 64 * R;
+  const cpx* t_tw2 = t_tw1 + 64 * R;
+  const cpx* t_twu = t_tw2 + 64 * 8 * NP_IT;
+  __syncthreads();
+  cpx* sA = s_scr + wave * SCR;
+  float c0 = 0.0f, c1 = 0.0f;
+  if (a.loss_mode == 2) { c0 = (float)a.coef[0]; c1 = (float)a.coef[1]; }
+
+  // the three passes of stft_kernel: v = the lane's R points (64 n1 + lane) -> DFT in natural order, sA[k + (k >> 3)]
+  auto fft = [&](cpx (&v)[R]) {
+    dftR<R>(v);
+    {
+      const int c = lane & 7, aa = lane >> 3;
+#pragma unroll
+      for (int k1 = 0; k1 < R; ++k1) sA[(k1 * 8 + c) * 9 + aa] = cmul(v[k1], t_tw1[64 * k1]);
+    }
+    wave_lds_sync();
+    cpx u[NP_IT][8];
+#pragma unroll
+    for (int i = 0; i < NP_IT; ++i) {
+      const int p = lane + 64 * i;
+      if (p < NPAIR) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u[i][q] = sA[p * 9 + q];
+      }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NP_IT; ++i) {
+      const int p = lane + 64 * i;
+      if (p < NPAIR) {
+        const int k1 = p >> 3, c = p & 7;
+        dft8(u[i]);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) sA[(k1 * 8 + d) * 9 + c] = cmul(u[i][d], t_tw2[64 * (8 * i + d)]);
+      }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NP_IT; ++i) {
+      const int p = lane + 64 * i;
+      if (p < NPAIR) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u[i][q] = sA[p * 9 + q];
+      }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NP_IT; ++i) {
+      const int p = lane + 64 * i;
+      if (p < NPAIR) {
+        const int k1 = p >> 3, d = p & 7;
+        dft8(u[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int k = k1 + R * d + 8 * R * e; sA[k + (k >> 3)] = u[i][e]; }
+      }
+    }
+    wave_lds_sync();
+  };
+  // d loss / d |X|^2 of one bin from its value and target
+  auto bin_grad = [&](float p, float t) {
+    float v = p;
+    if (!a.power2) v = sqrtf(a.loss_mode == 2 ? fmaxf(p, a.eps) : p);
+    const float d = v - t;
+    const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+    const float gv = a.loss_mode == 2 ? c0 * d + c1 * sg / v : sg * a.scale;
+    if (a.power2) return gv;
+    const bool live = a.loss_mode == 2 ? v > sqrtf(a.eps) : v > 0.0f;   // a clamped (or zero) bin passes nothing
+    return live ? gv / (2.0f * v) : 0.0f;
+  };
+
+  const int f_begin = blockIdx.x * a.groups;
+  const int f_end = min(f_begin + a.groups, a.F);
+  float xc[2 * R];
+  for (int f = f_begin + wave; f < f_end; f += SP_WAVES) {
+    load_frame<R, N2>(arow, a.T, a.hop, f, lane, xc);
+    cpx v[R];
+#pragma unroll
+    for (int n1 = 0; n1 < R; ++n1) v[n1] = cmk(xc[2 * n1], xc[2 * n1 + 1]) * t_win[64 * n1];
+    fft(v);
+    // unpack + adjoint per bin pair (k, N2 - k), k = lane + 64 i <= N2 / 2; the inverse input in registers
+    cpx zk_in[NUNP], zn_in[NUNP];
+    const float* trow = a.target + ((size_t)b * a.F + f) * NB;
+#pragma unroll
+    for (int i = 0; i < NUNP; ++i) {
+      const int k = lane + 64 * i;
+      zk_in[i] = zn_in[i] = cmk(0.0f, 0.0f);
+      if (k <= N2 / 2) {
+        const int kn = (N2 - k) & (N2 - 1);
+        const cpx zk = sA[k + (k >> 3)], zn = sA[kn + (kn >> 3)];
+        const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        const cpx w = t_twu[64 * i];                      // W_N^k = e^{-2 pi i k / N}
+        const cpx t = cmul(w, zo);
+        const cpx xk = cadd(ze, t);                       // X[k]
+        const cpx xq = cmk(ze.x - t.x, -(ze.y - t.y));    // X[N2 - k]
+        const float gk = 2.0f * bin_grad(xk.x * xk.x + xk.y * xk.y, trow[k]);
+        const float gq = 2.0f * bin_grad(xq.x * xq.x + xq.y * xq.y, trow[N2 - k]);
+        const cpx ck = xk * gk, cq = xq * gq;             // G[k], G[N2 - k]
+        if (k == 0) {
+          // edge bins (real X): a[0] = G[0] + G[N2], b[0] = G[0] - G[N2]; Zin[0] = a[0] + i b[0]
+          zk_in[i] = cmk(ck.x + cq.x, ck.x - cq.x);
+          zn_in[i] = zk_in[i];
+        } else {
+          const cpx wc = cmk(w.x, -w.y);                  // e^{+2 pi i k / N}
+          const cpx bk = cmul(ck, wc);                    // b[k]
+          const cpx bn = cmul(cq, cmk(-w.x, -w.y));       // b[N2 - k] = G[N2 - k] (-W^k)
+          // Zin[k] = (a[k] + conj a[kn]) / 2 + i (b[k] + conj b[kn]) / 2, and the same with k <-> kn
+          const cpx ak = cmk(0.5f * (ck.x + cq.x), 0.5f * (ck.y - cq.y)), an = cmk(ak.x, -ak.y);
+          const cpx sk = cmk(0.5f * (bk.x + bn.x), 0.5f * (bk.y - bn.y)), sn = cmk(sk.x, -sk.y);
+          zk_in[i] = cmk(ak.x - sk.y, ak.y + sk.x);
+          zn_in[i] = cmk(an.x - sn.y, an.y + sn.x);
+        }
+      }
+    }
+    wave_lds_sync();                                      // every Z read is done
+    // conj(Zin) in natural order (padded like Z), then the lane's R points of it
+#pragma unroll
+    for (int i = 0; i < NUNP; ++i) {
+      const int k = lane + 64 * i;
+      if (k <= N2 / 2) {
+        const int kn = (N2 - k) & (N2 - 1);
+        sA[k + (k >> 3)] = cmk(zk_in[i].x, -zk_in[i].y);
+        if (kn != k) sA[kn + (kn >> 3)] = cmk(zn_in[i].x, -zn_in[i].y);
+      }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int n1 = 0; n1 < R; ++n1) { const int p = 64 * n1 + lane; v[n1] = sA[p + (p >> 3)]; }
+    wave_lds_sync();
+    fft(v);
+    // z[m] = conj(out[m]) = y[2m] + i y[2m+1];  frame_grad = window * y
+    float* out = a.frame_grad + ((size_t)b * a.F + f) * NFFT;
+#pragma unroll
+    for (int n1 = 0; n1 < R; ++n1) {
+      const int m = 64 * n1 + lane;
+      const cpx o = sA[m + (m >> 3)];
+      const cpx w2 = t_win[64 * n1];
+      *reinterpret_cast<cpx*>(out + 2 * m) = cmk(w2.x * o.x, -w2.y * o.y);
+    }
+    wave_lds_sync();
+  }
+}
+
+// frame_grad [B,F,n_fft] <- d loss / d (windowed frames) for the linear-bin losses (see stft_grad_wave_kernel);
+// tables: ias_stft_build_tables of the plan's window; target [B,F,n_fft/2+1]; coef: device doubles [2] (loss_mode 2).
+extern "C" int ias_stft_grad_frames(const float* audio, const float* tables, const float* target, const double* coef,
+                                    float* frame_grad, int B, int T, int n_fft, int hop, int power, int loss_mode,
+                                    float scale, float eps, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!audio || !tables || !target || !frame_grad || B <= 0 || B > 65535 || hop <= 0) return IAS_ERR_ARG;
+  if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return IAS_ERR_UNSUPPORTED;
+  if ((power != 1 && power != 2) || (loss_mode != 1 && loss_mode != 2) || (loss_mode == 2 && !coef)) return IAS_ERR_ARG;
+  const int F = ias_stft_num_frames(T, n_fft, hop);
+  if (F < 0 || F > 2147483647 / n_fft) return IAS_ERR_ARG;
+  SgwArgs a;
+  a.audio = audio; a.tables = tables; a.target = target; a.coef = coef; a.frame_grad = frame_grad;
+  a.T = T; a.F = F; a.hop = hop; a.power2 = power == 2; a.loss_mode = loss_mode; a.scale = scale; a.eps = eps;
+  int per_row = 2048 / B;
+  if (per_row < 1) per_row = 1;
+  int g = (F + per_row - 1) / per_row;
+  if (g < 8) g = 8;
+  a.groups = g;
+  const int R = n_fft / 128, scr = 8 * R * 9, np_it = (8 * R + 63) / 64, nunp = (n_fft / 4) / 64 + 1;
+  const size_t lds = sizeof(cpx) * 4 * scr + sizeof(float) * 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp) + 16;
+  const dim3 grid((F + g - 1) / g, B), block(256);
+#define IAS_SGW_LAUNCH(LOG2N)                                                                                     \
+  do {                                                                                                             \
+    if (lds > 64 * 1024)                                                                                           \
+      (void)hipFuncSetAttribute((const void*)stft_grad_wave_kernel<LOG2N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                         \
+    hipLaunchKernelGGL((stft_grad_wave_kernel<LOG2N>), grid, block, lds, stream, a);                               \
+  } while (0)
+  if (n_fft == 512) IAS_SGW_LAUNCH(9); else if (n_fft == 1024) IAS_SGW_LAUNCH(10); else IAS_SGW_LAUNCH(11);
+#undef IAS_SGW_LAUNCH
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
 // sums[0..2] = sum over n partial triples (fixed order: deterministic); optionally
 // mean_out[0] = (float)(sums[0] * scale)  (the L1 mean, without further elementwise launches)
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __restrict__ partials, long long n,

@@ -164,7 +164,7 @@ class _L1LossFn(torch.autograd.Function):
         g_audio = torch.empty_like(a)
         gl = g_loss.to(torch.float32).reshape(1).contiguous()
         st = lib.ias_stft_loss_backward(
-            _lib.ptr(a), _lib.ptr(plan.window), _lib.ptr(plan.mel_start) if mel else None,
+            _lib.ptr(a), _lib.ptr(plan.window), _lib.ptr(plan.tables), _lib.ptr(plan.mel_start) if mel else None,
             _lib.ptr(plan.mel_count) if mel else None, _lib.ptr(plan.mel_woff) if mel else None,
             _lib.ptr(plan.mel_w) if mel else None, int(plan.mel_w.numel()) if mel else 0, _lib.ptr(target), _lib.ptr(gl),
             None, _lib.ptr(frame_grad),
@@ -301,7 +301,8 @@ class _MRSTFTFn(torch.autograd.Function):
             coef = torch.stack([c0, g64 / (nres * tgt.numel())]).contiguous()
             frame_grad = torch.empty((B, plan.num_frames(T), plan.n_fft), dtype=torch.float32, device=a.device)
             g_audio = torch.empty_like(a)
-            st = lib.ias_stft_loss_backward(_lib.ptr(a), _lib.ptr(plan.window), None, None, None, None, 0, _lib.ptr(tgt),
+            st = lib.ias_stft_loss_backward(_lib.ptr(a), _lib.ptr(plan.window), _lib.ptr(plan.tables), None, None, None,
+                                            None, 0, _lib.ptr(tgt),
                                             None, _lib.ptr(coef), _lib.ptr(frame_grad), _lib.ptr(g_audio), B, T,
                                             plan.n_fft, plan.hop_length, plan.n_out, 1, LOSS_MRSTFT, 0.0,
                                             float(module.eps), _lib.stream())

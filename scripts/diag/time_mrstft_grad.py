@@ -1,0 +1,28 @@
+"""MR-STFT loss forward + backward at configs[4]'s shape (B=64 x 176400): wave-per-frame backward vs the round-1 kernel
+(IAS_STFT_GRAD_V1=1) -- developer tool."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from inverse_audio_synthesis_amd.spectral import MultiResolutionSTFTLoss
+
+dev = torch.device("cuda:0")
+B = int(os.environ.get("B", 64))
+g = torch.Generator().manual_seed(0)
+a = (torch.randn(B, 176400, generator=g) * 0.1).to(dev).requires_grad_(True)
+t = (torch.randn(B, 176400, generator=g) * 0.1).to(dev)
+mr = MultiResolutionSTFTLoss().to(dev)
+tm = mr.target(t)
+def step():
+    a.grad = None
+    loss = mr(a, targets=tm)
+    loss.backward()
+    return loss
+for _ in range(3): loss = step()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+n = 10
+e0.record()
+for _ in range(n): loss = step()
+e1.record(); torch.cuda.synchronize()
+print(f"MR-STFT fwd+bwd B={B}: {e0.elapsed_time(e1) / n:.3f} ms  loss {loss.item():.6f}  |grad| {a.grad.norm().item():.6e}  "
+      f"[{'v1' if os.environ.get('IAS_STFT_GRAD_V1') else 'wave'}]")
