@@ -170,18 +170,18 @@ int ias_stft(const float* audio, const float* tables, const int* mel_start, cons
  *                coef[0] (V - target) + coef[1] sign(V - target) / V with coef a device double[2].
  * window [n_fft] on the device; mel_* as for ias_stft (NULL = linear bins, n_out = n_fft/2+1); target [B,F,n_out]
  * frames-major; power 1 or 2; g_loss a device scalar (NULL = 1); frame_grad [B,F,n_fft] fp32 scratch.
- * tables: the plan's ias_stft_build_tables block (device) or NULL.  With tables and linear bins the frame part runs on
- * the forward's wave-per-frame FFT core (ias_stft_grad_frames); otherwise (mel, or tables == NULL) the workgroup-per-
- * frame-pair kernel of round 1. */
+ * tables: the plan's ias_stft_build_tables block (device) or NULL.  With tables the frame part runs on the forward's
+ * wave-per-frame FFT core (ias_stft_grad_frames); with NULL the workgroup-per-frame-pair kernel of round 1. */
 int ias_stft_loss_backward(const float* audio, const float* window, const float* tables, const int* mel_start,
                            const int* mel_count, const int* mel_woff, const float* mel_w, int mel_nnz,
                            const float* target, const float* g_loss, const double* coef, float* frame_grad,
                            float* g_audio, int B, int T, int n_fft, int hop, int n_out, int power, int loss_mode,
                            float scale, float eps, void* stream);
-/* The frame part alone, linear bins (n_out = n_fft/2 + 1): frame_grad [B,F,n_fft] = window * d loss / d frame. */
-int ias_stft_grad_frames(const float* audio, const float* tables, const float* target, const double* coef,
-                         float* frame_grad, int B, int T, int n_fft, int hop, int power, int loss_mode, float scale,
-                         float eps, void* stream);
+/* The frame part alone: frame_grad [B,F,n_fft] = window * d loss / d frame (mel_* NULL: linear bins). */
+int ias_stft_grad_frames(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
+                         const int* mel_woff, const float* mel_w, int mel_nnz, int n_out, const float* target,
+                         const double* coef, float* frame_grad, int B, int T, int n_fft, int hop, int power,
+                         int loss_mode, float scale, float eps, void* stream);
 
 /* sums[3] (doubles) = column sums of partials [n][3], fixed order (deterministic); when mean_out is not
  * NULL also mean_out[0] = (float)(sums[0] * scale). */

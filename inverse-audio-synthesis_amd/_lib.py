@@ -55,7 +55,8 @@ SYMBOLS = {
     "ias_stft": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "ias_stft_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I,
                                    ctypes.c_float, ctypes.c_float, _P]),
-    "ias_stft_grad_frames": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P]),
+    "ias_stft_grad_frames": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, ctypes.c_float,
+                                 ctypes.c_float, _P]),
     "ias_reduce_partials": (_I, [_P, _LL, _P, _c.c_double, _P, _P]),
     "ias_vicreg_workspace_bytes": (_LL, [_I, _I]),
     "ias_vicreg_colstats_offset": (_LL, [_I, _I]),

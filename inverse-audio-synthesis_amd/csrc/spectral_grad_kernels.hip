@@ -266,9 +266,10 @@ __global__ __launch_bounds__(SG_THREADS) void stft_grad_ola_kernel(const float* 
 //   audio [B,T]; window [n_fft] (device); mel_* : the forward's CSR filterbank (NULL = linear bins, n_out = n_fft/2+1);
 //   target [B,F,n_out] frames-major (what ias_stft wrote for the target); power: 1 (magnitude) or 2 (power);
 //   frame_grad [B,F,n_fft] fp32 scratch; g_audio [B,T] out.  F = ias_stft_num_frames(T, n_fft, hop).
-extern "C" int ias_stft_grad_frames(const float* audio, const float* tables, const float* target, const double* coef,
-                                    float* frame_grad, int B, int T, int n_fft, int hop, int power, int loss_mode,
-                                    float scale, float eps, void* stream);   // csrc/spectral_kernels.hip
+extern "C" int ias_stft_grad_frames(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
+                                    const int* mel_woff, const float* mel_w, int mel_nnz, int n_out, const float* target,
+                                    const double* coef, float* frame_grad, int B, int T, int n_fft, int hop, int power,
+                                    int loss_mode, float scale, float eps, void* stream);   // csrc/spectral_kernels.hip
 
 extern "C" int ias_stft_loss_backward(const float* audio, const float* window, const float* tables, const int* mel_start,
                                       const int* mel_count, const int* mel_woff, const float* mel_w, int mel_nnz,
@@ -288,10 +289,10 @@ extern "C" int ias_stft_loss_backward(const float* audio, const float* window, c
   if (n_out <= 0 || n_out > n_fft / 2 + 1) return IAS_ERR_ARG;
   const int F = 1 + T / hop;
   if (F > 2147483647 / n_fft) return IAS_ERR_UNSUPPORTED;
-  if (tables != nullptr && !mel && getenv("IAS_STFT_GRAD_V1") == nullptr) {
-    // linear bins: the frame part on the forward's wave-per-frame FFT core, then the same overlap-add
-    const int rc = ias_stft_grad_frames(audio, tables, target, coef, frame_grad, B, T, n_fft, hop, power, loss_mode,
-                                        scale, eps, stream_);
+  if (tables != nullptr && getenv("IAS_STFT_GRAD_V1") == nullptr) {
+    // the frame part on the forward's wave-per-frame FFT core, then the same overlap-add
+    const int rc = ias_stft_grad_frames(audio, tables, mel_start, mel_count, mel_woff, mel_w, mel ? mel_nnz : 0, n_out,
+                                        target, coef, frame_grad, B, T, n_fft, hop, power, loss_mode, scale, eps, stream_);
     if (rc != IAS_OK) return rc;
     hipLaunchKernelGGL(stft_grad_ola_kernel, dim3((T + SG_THREADS - 1) / SG_THREADS, B), dim3(SG_THREADS), 0, stream,
                        frame_grad, g_loss, g_audio, T, F, n_fft, hop);

@@ -438,11 +438,15 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES == 10 ? 5 : 1) void stft_ke
 extern "C" int ias_stft_num_frames(int T, int n_fft, int hop);
 struct SgwArgs {
   const float* audio; const float* tables; const float* target; const double* coef; float* frame_grad;
-  int T, F, hop, groups, power2, loss_mode;
+  const int* mel_start; const int* mel_count; const int* mel_woff; const float* mel_w;   // MEL: the forward's CSR filters
+  int T, F, hop, groups, power2, loss_mode, n_out, mel_nnz;
   float scale, eps;
 };
 
-template <int LOG2N>
+// MEL: the loss is taken on O = melW^T V (loss_mode 1 only).  V goes to LDS, a lane computes two outputs with the
+// forward's padded filter loops, their cotangents are scattered back to the bins with LDS float atomics (a bin lies under
+// at most two triangular filters: the sum of two terms does not depend on their order), then the bins continue as above.
+template <int LOG2N, bool MEL>
 __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
   constexpr int SP_WAVES = 4, SP_THREADS = 256;
   constexpr int NFFT = 1 << LOG2N, N2 = NFFT / 2, R = N2 / 64, NPAIR = 8 * R, NP_IT = (NPAIR + 63) / 64;
@@ -456,6 +460,31 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
   for (int i = tid; i < NTAB / 2; i += SP_THREADS) {
     const int pp = i >> 6, l = i & 63;
     s_tab[i] = cmk(a.tables[64 * (2 * pp) + l], a.tables[64 * (2 * pp + 1) + l]);
+  }
+  // MEL: padded weights + descriptors (as in stft_kernel), then per wave the output cotangents and the bin cotangents
+  float* s_melw = reinterpret_cast<float*>(s_tab + NTAB / 2);
+  const int melw_words = MEL ? mel_padded_words(a.mel_nnz, a.n_out) : 0;
+  int* s_meli = reinterpret_cast<int*>(s_melw + melw_words);            // [3][n_out]: start, padded count, padded offset
+  const int so_words = MEL ? ((a.n_out + 3) & ~3) : 0;
+  float* s_go = reinterpret_cast<float*>(s_meli + (MEL ? ((3 * a.n_out + 3) & ~3) : 0)) + wave * (so_words + NB + 7);
+  float* s_gv = s_go + so_words;                                        // [NB + 4] (+ slack for the zero padding)
+  if (MEL) {
+    for (int i = tid; i < melw_words; i += SP_THREADS) s_melw[i] = 0.0f;
+    for (int i = tid; i < a.n_out; i += SP_THREADS) {
+      s_meli[i] = a.mel_start[i];
+      s_meli[a.n_out + i] = (a.mel_count[i] + 3) & ~3;
+    }
+    __syncthreads();
+    for (int i = tid; i < a.n_out; i += SP_THREADS) {
+      int off = 0;
+      for (int m = 0; m < i; ++m) off += s_meli[a.n_out + m];
+      s_meli[2 * a.n_out + i] = off;
+    }
+    __syncthreads();
+    for (int i = tid; i < a.n_out; i += SP_THREADS) {
+      const int n = a.mel_count[i], src = a.mel_woff[i], dst = s_meli[2 * a.n_out + i];
+      for (int j = 0; j < n; ++j) s_melw[dst + j] = a.mel_w[src + j];
+    }
   }
   const cpx* t_win = s_tab + lane;
   const cpx* t_tw1 = t_win + 64 * R;
@@ -517,13 +546,14 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
     }
     wave_lds_sync();
   };
-  // d loss / d |X|^2 of one bin from its value and target
-  auto bin_grad = [&](float p, float t) {
-    float v = p;
-    if (!a.power2) v = sqrtf(a.loss_mode == 2 ? fmaxf(p, a.eps) : p);
+  // value V of a bin from its power; d loss / d V from value and target (linear bins); d loss / d |X|^2 from d loss / d V
+  auto bin_value = [&](float p) { return a.power2 ? p : sqrtf(a.loss_mode == 2 ? fmaxf(p, a.eps) : p); };
+  auto value_grad = [&](float v, float t) {
     const float d = v - t;
     const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-    const float gv = a.loss_mode == 2 ? c0 * d + c1 * sg / v : sg * a.scale;
+    return a.loss_mode == 2 ? c0 * d + c1 * sg / v : sg * a.scale;
+  };
+  auto power_grad = [&](float gv, float v) {
     if (a.power2) return gv;
     const bool live = a.loss_mode == 2 ? v > sqrtf(a.eps) : v > 0.0f;   // a clamped (or zero) bin passes nothing
     return live ? gv / (2.0f * v) : 0.0f;
@@ -538,25 +568,82 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
 #pragma unroll
     for (int n1 = 0; n1 < R; ++n1) v[n1] = cmk(xc[2 * n1], xc[2 * n1 + 1]) * t_win[64 * n1];
     fft(v);
-    // unpack + adjoint per bin pair (k, N2 - k), k = lane + 64 i <= N2 / 2; the inverse input in registers
-    cpx zk_in[NUNP], zn_in[NUNP];
-    const float* trow = a.target + ((size_t)b * a.F + f) * NB;
+    // unpack per bin pair (k, N2 - k), k = lane + 64 i <= N2 / 2: X and V of both bins in registers
+    cpx xk_[NUNP], xq_[NUNP];
+    float vk_[NUNP], vq_[NUNP], gk_[NUNP], gq_[NUNP];
+    const float* trow = a.target + ((size_t)b * a.F + f) * (MEL ? a.n_out : NB);
 #pragma unroll
     for (int i = 0; i < NUNP; ++i) {
       const int k = lane + 64 * i;
-      zk_in[i] = zn_in[i] = cmk(0.0f, 0.0f);
+      xk_[i] = xq_[i] = cmk(0.0f, 0.0f);
+      vk_[i] = vq_[i] = gk_[i] = gq_[i] = 0.0f;
       if (k <= N2 / 2) {
         const int kn = (N2 - k) & (N2 - 1);
         const cpx zk = sA[k + (k >> 3)], zn = sA[kn + (kn >> 3)];
         const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
         const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        const cpx t = cmul(t_twu[64 * i], zo);            // W_N^k Zo[k]
+        xk_[i] = cadd(ze, t);                             // X[k]
+        xq_[i] = cmk(ze.x - t.x, -(ze.y - t.y));          // X[N2 - k]
+        vk_[i] = bin_value(xk_[i].x * xk_[i].x + xk_[i].y * xk_[i].y);
+        vq_[i] = bin_value(xq_[i].x * xq_[i].x + xq_[i].y * xq_[i].y);
+        if (!MEL) { gk_[i] = value_grad(vk_[i], trow[k]); gq_[i] = value_grad(vq_[i], trow[N2 - k]); }
+      }
+    }
+    if (MEL) {
+      wave_lds_sync();                                    // every Z read is done: V overwrites the scratch
+      float* P = reinterpret_cast<float*>(sA);
+#pragma unroll
+      for (int i = 0; i < NUNP; ++i) {
+        const int k = lane + 64 * i;
+        if (k <= N2 / 2) { P[k] = vk_[i]; P[N2 - k] = vq_[i]; }
+      }
+      for (int i = lane; i < NB + 4; i += 64) s_gv[i] = 0.0f;
+      wave_lds_sync();
+      for (int m0 = 0; m0 < a.n_out; m0 += 64) {
+        const int m = m0 + lane;
+        if (m < a.n_out) {
+          const int s0 = s_meli[m], n4 = s_meli[a.n_out + m];
+          const float* w = s_melw + s_meli[2 * a.n_out + m];
+          float o = 0.0f;
+          for (int j = 0; j < n4; j += 4) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + j);
+            const float* pp = P + s0 + j;
+            o = fmaf(wv[3], pp[3], fmaf(wv[2], pp[2], fmaf(wv[1], pp[1], fmaf(wv[0], pp[0], o))));
+          }
+          s_go[m] = value_grad(o, trow[m]);
+        }
+      }
+      wave_lds_sync();
+      for (int m0 = 0; m0 < a.n_out; m0 += 64) {
+        const int m = m0 + lane;
+        if (m < a.n_out) {
+          const int s0 = s_meli[m], n4 = s_meli[a.n_out + m];
+          const float* w = s_melw + s_meli[2 * a.n_out + m];
+          const float go = s_go[m];
+          for (int j = 0; j < n4; ++j) {
+            const float wj = w[j];
+            if (wj != 0.0f) atomicAdd(&s_gv[s0 + j], wj * go);
+          }
+        }
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int i = 0; i < NUNP; ++i) {
+        const int k = lane + 64 * i;
+        if (k <= N2 / 2) { gk_[i] = s_gv[k]; gq_[i] = s_gv[N2 - k]; }
+      }
+    }
+    // adjoint per bin pair; the inverse input in registers
+    cpx zk_in[NUNP], zn_in[NUNP];
+#pragma unroll
+    for (int i = 0; i < NUNP; ++i) {
+      const int k = lane + 64 * i;
+      zk_in[i] = zn_in[i] = cmk(0.0f, 0.0f);
+      if (k <= N2 / 2) {
         const cpx w = t_twu[64 * i];                      // W_N^k = e^{-2 pi i k / N}
-        const cpx t = cmul(w, zo);
-        const cpx xk = cadd(ze, t);                       // X[k]
-        const cpx xq = cmk(ze.x - t.x, -(ze.y - t.y));    // X[N2 - k]
-        const float gk = 2.0f * bin_grad(xk.x * xk.x + xk.y * xk.y, trow[k]);
-        const float gq = 2.0f * bin_grad(xq.x * xq.x + xq.y * xq.y, trow[N2 - k]);
-        const cpx ck = xk * gk, cq = xq * gq;             // G[k], G[N2 - k]
+        const cpx ck = xk_[i] * (2.0f * power_grad(gk_[i], vk_[i]));   // G[k]
+        const cpx cq = xq_[i] * (2.0f * power_grad(gq_[i], vq_[i]));   // G[N2 - k]
         if (k == 0) {
           // edge bins (real X): a[0] = G[0] + G[N2], b[0] = G[0] - G[N2]; Zin[0] = a[0] + i b[0]
           zk_in[i] = cmk(ck.x + cq.x, ck.x - cq.x);
@@ -602,36 +689,48 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
   }
 }
 
-// frame_grad [B,F,n_fft] <- d loss / d (windowed frames) for the linear-bin losses (see stft_grad_wave_kernel);
-// tables: ias_stft_build_tables of the plan's window; target [B,F,n_fft/2+1]; coef: device doubles [2] (loss_mode 2).
-extern "C" int ias_stft_grad_frames(const float* audio, const float* tables, const float* target, const double* coef,
-                                    float* frame_grad, int B, int T, int n_fft, int hop, int power, int loss_mode,
-                                    float scale, float eps, void* stream_) {
+// frame_grad [B,F,n_fft] <- d loss / d (windowed frames) (see stft_grad_wave_kernel); tables: ias_stft_build_tables of
+// the plan's window; mel_*: the forward's CSR filterbank or NULL (linear bins, n_out = n_fft/2+1); target [B,F,n_out];
+// coef: device doubles [2] (loss_mode 2, linear bins only).
+extern "C" int ias_stft_grad_frames(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
+                                    const int* mel_woff, const float* mel_w, int mel_nnz, int n_out, const float* target,
+                                    const double* coef, float* frame_grad, int B, int T, int n_fft, int hop, int power,
+                                    int loss_mode, float scale, float eps, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!audio || !tables || !target || !frame_grad || B <= 0 || B > 65535 || hop <= 0) return IAS_ERR_ARG;
   if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return IAS_ERR_UNSUPPORTED;
   if ((power != 1 && power != 2) || (loss_mode != 1 && loss_mode != 2) || (loss_mode == 2 && !coef)) return IAS_ERR_ARG;
+  const bool mel = mel_start != nullptr;
+  if (mel && (!mel_count || !mel_woff || !mel_w || mel_nnz <= 0 || n_out <= 0 || loss_mode != 1)) return IAS_ERR_ARG;
+  if (!mel && n_out != n_fft / 2 + 1) return IAS_ERR_ARG;
   const int F = ias_stft_num_frames(T, n_fft, hop);
   if (F < 0 || F > 2147483647 / n_fft) return IAS_ERR_ARG;
   SgwArgs a;
   a.audio = audio; a.tables = tables; a.target = target; a.coef = coef; a.frame_grad = frame_grad;
   a.T = T; a.F = F; a.hop = hop; a.power2 = power == 2; a.loss_mode = loss_mode; a.scale = scale; a.eps = eps;
+  a.mel_start = mel_start; a.mel_count = mel_count; a.mel_woff = mel_woff; a.mel_w = mel_w;
+  a.n_out = n_out; a.mel_nnz = mel ? mel_nnz : 0;
   int per_row = 2048 / B;
   if (per_row < 1) per_row = 1;
   int g = (F + per_row - 1) / per_row;
   if (g < 8) g = 8;
   a.groups = g;
   const int R = n_fft / 128, scr = 8 * R * 9, np_it = (8 * R + 63) / 64, nunp = (n_fft / 4) / 64 + 1;
-  const size_t lds = sizeof(cpx) * 4 * scr + sizeof(float) * 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp) + 16;
+  size_t lds = sizeof(cpx) * 4 * scr + sizeof(float) * 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp) + 16;
+  if (mel)
+    lds += sizeof(float) * (mel_padded_words(mel_nnz, n_out) + ((3 * n_out + 3) & ~3) +
+                            4 * (((n_out + 3) & ~3) + n_fft / 2 + 1 + 7));
+  if (lds > 150 * 1024) return IAS_ERR_UNSUPPORTED;
   const dim3 grid((F + g - 1) / g, B), block(256);
-#define IAS_SGW_LAUNCH(LOG2N)                                                                                     \
+#define IAS_SGW_LAUNCH(LOG2N, MEL)                                                                                \
   do {                                                                                                             \
     if (lds > 64 * 1024)                                                                                           \
-      (void)hipFuncSetAttribute((const void*)stft_grad_wave_kernel<LOG2N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds);                                                                         \
-    hipLaunchKernelGGL((stft_grad_wave_kernel<LOG2N>), grid, block, lds, stream, a);                               \
+      (void)hipFuncSetAttribute((const void*)stft_grad_wave_kernel<LOG2N, MEL>,                                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+    hipLaunchKernelGGL((stft_grad_wave_kernel<LOG2N, MEL>), grid, block, lds, stream, a);                          \
   } while (0)
-  if (n_fft == 512) IAS_SGW_LAUNCH(9); else if (n_fft == 1024) IAS_SGW_LAUNCH(10); else IAS_SGW_LAUNCH(11);
+  if (mel) { if (n_fft == 512) IAS_SGW_LAUNCH(9, true); else if (n_fft == 1024) IAS_SGW_LAUNCH(10, true); else IAS_SGW_LAUNCH(11, true); }
+  else { if (n_fft == 512) IAS_SGW_LAUNCH(9, false); else if (n_fft == 1024) IAS_SGW_LAUNCH(10, false); else IAS_SGW_LAUNCH(11, false); }
 #undef IAS_SGW_LAUNCH
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }

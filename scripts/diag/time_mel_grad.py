@@ -1,0 +1,27 @@
+"""mel-L1 loss forward + backward at B=128 x 176400 -- developer tool (IAS_STFT_GRAD_V1=1: the round-1 backward kernel)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from inverse_audio_synthesis_amd.spectral import MelSpectrogramL1
+
+dev = torch.device("cuda:0")
+B = int(os.environ.get("B", 128))
+g = torch.Generator().manual_seed(0)
+a = (torch.randn(B, 176400, generator=g) * 0.1).to(dev).requires_grad_(True)
+t = (torch.randn(B, 176400, generator=g) * 0.1).to(dev)
+mel = MelSpectrogramL1().to(dev)
+tm = mel.target(t).clone()
+def step():
+    a.grad = None
+    loss = mel(a, target_mel=tm)
+    loss.backward()
+    return loss
+for _ in range(3): loss = step()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+n = 10
+e0.record()
+for _ in range(n): loss = step()
+e1.record(); torch.cuda.synchronize()
+print(f"mel-L1 fwd+bwd B={B}: {e0.elapsed_time(e1) / n:.3f} ms  loss {loss.item():.6f}  |grad| {a.grad.norm().item():.6e}  "
+      f"[{'v1' if os.environ.get('IAS_STFT_GRAD_V1') else 'wave'}]")
