@@ -156,7 +156,10 @@ def test_synthesis_vs_oracle(lib, dev, N, taps, L):
     np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=1e-4 * max(1.0, float(ref.abs().max())))
 
 
-@pytest.mark.parametrize("N,B,T", [(3, 5, 176400), (3, 2, 4100), (4, 3, 20004), (64, 2, 176400), (64, 3, 8192)])
+# (3, *, T) with T % 4 == 0 and L % 4 == 0 (L = (T - 1) // 3 + 1): the wave-pipelined kernel, down to a single, mostly
+# empty wave tile (T = 12: L = 4) and with more rows than resident waves' first tiles; other N = 3 shapes: the tiled kernel
+@pytest.mark.parametrize("N,B,T", [(3, 5, 176400), (3, 2, 4100), (4, 3, 20004), (64, 2, 176400), (64, 3, 8192),
+                                   (3, 3, 12), (3, 2, 1020), (3, 1, 96000), (3, 130, 3840), (3, 7, 960 * 3 + 12)])
 def test_matrix_core_path_is_bit_identical_to_the_vector_kernels(lib, dev, N, B, T):
     """The fp32 MFMA analysis (16-byte aligned rows, T % 4 == 0) and the VALU kernels (taken for any other alignment)
     evaluate the same tap-ordered fmaf chain per output: the results must agree bit for bit, with and without the
