@@ -472,12 +472,23 @@ def main():
             rendered = ws_free[buf]
             side_a.wait_event(rendered)
             side_b.wait_event(rendered)
-            with torch.cuda.stream(side_a):
-                z = gram.analysis(audio.unsqueeze(1), rowpeak=peaks)
-                ea = side_a.record_event()
-            with torch.cuda.stream(side_b):
-                loss = mel_l1(audio, target_mel=target_mel, rowpeak=peaks)
-                eb = side_b.record_event()
+            order = os.environ.get("IAS_BENCH_CONSUMERS", "parallel")   # diagnostics: how the two consumers are issued
+            if order == "parallel":
+                with torch.cuda.stream(side_a):
+                    z = gram.analysis(audio.unsqueeze(1), rowpeak=peaks)
+                    ea = side_a.record_event()
+                with torch.cuda.stream(side_b):
+                    loss = mel_l1(audio, target_mel=target_mel, rowpeak=peaks)
+                    eb = side_b.record_event()
+            else:
+                with torch.cuda.stream(side_a):
+                    if order == "pqmf_first":
+                        z = gram.analysis(audio.unsqueeze(1), rowpeak=peaks)
+                        loss = mel_l1(audio, target_mel=target_mel, rowpeak=peaks)
+                    else:
+                        loss = mel_l1(audio, target_mel=target_mel, rowpeak=peaks)
+                        z = gram.analysis(audio.unsqueeze(1), rowpeak=peaks)
+                    ea = eb = side_a.record_event()
             consumed[buf] = (ea, eb)
             if not pipelined:
                 main.wait_event(ea)
