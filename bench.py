@@ -45,7 +45,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish a step's PQMF / spectral loss before the next step's render starts")
-    ap.add_argument("--buffers", type=int, default=2, help="audio buffers / workspaces in flight (pipeline depth)")
+    ap.add_argument("--buffers", type=int, default=3, help="audio buffers / workspaces in flight (pipeline depth)")
+    ap.add_argument("--no-defer-consumers", action="store_true",
+                    help="issue a step's PQMF / STFT right after its render instead of after the next render "
+                         "(the round-1 issue order; see run_steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32, help="voices in the CPU baseline sample")
     ap.add_argument("--replays", type=int, default=0,
@@ -436,6 +439,8 @@ def main():
     workspaces = [voice.new_workspace(dev) for _ in range(nbuf)]
     last = {}
 
+    defer = not args.no_defer_consumers
+
     def run_steps(k, pipelined=True):
         main = torch.cuda.current_stream()
         consumed = [None] * nbuf
@@ -452,24 +457,9 @@ def main():
                 voice.render_control(workspaces[buf])
                 return side_c.record_event()
 
-        ctrl_done = issue_control(0)
-        for i in range(k):
-            buf = i % nbuf
-            if consumed[buf] is not None:          # buffer free again: both readers of step i-nbuf are done
-                for e in consumed[buf]:
-                    main.wait_event(e)
-            main.wait_event(ctrl_done)
-            if pipelined and i + 1 < k:
-                ctrl_done_next = issue_control(i + 1)
-            # normalize_if_clipping is folded into the two consumers (row peaks read in place from the workspace)
-            audio = voice.render_audio(workspaces[buf], out=audio_bufs[buf], on_stage=hook, normalize=False)
-            peaks = voice.peaks_view(workspaces[buf])
-            ws_free[buf] = main.record_event()
-            if not (pipelined and i + 1 < k) and i + 1 < k:
-                ctrl_done_next = issue_control(i + 1)
-            if i + 1 < k:
-                ctrl_done = ctrl_done_next
-            rendered = ws_free[buf]
+        pending = [None]
+
+        def issue_consumers(audio, peaks, rendered, buf):
             side_a.wait_event(rendered)
             side_b.wait_event(rendered)
             order = os.environ.get("IAS_BENCH_CONSUMERS", "parallel")   # diagnostics: how the two consumers are issued
@@ -490,10 +480,46 @@ def main():
                         z = gram.analysis(audio.unsqueeze(1), rowpeak=peaks)
                     ea = eb = side_a.record_event()
             consumed[buf] = (ea, eb)
-            if not pipelined:
-                main.wait_event(ea)
-                main.wait_event(eb)
             last["z"], last["loss"] = z, loss
+
+        # control passes run `depth` steps ahead of their render
+        # (two steps of lead, legal with three workspaces, measured slower: 0.232 vs 0.211 ms -- the capture order of the
+        # extra successor changes the executor's queue assignment again)
+        depth = 1
+        ctrl_events = {j: issue_control(j) for j in range(min(depth, k))}
+        for i in range(k):
+            buf = i % nbuf
+            if consumed[buf] is not None:          # buffer free again: both readers of step i-nbuf are done
+                for e in consumed[buf]:
+                    main.wait_event(e)
+            main.wait_event(ctrl_events.pop(i))
+            early_ctrl = pipelined and not defer   # (with deferred consumers the render is issued first: see below)
+            if early_ctrl and i + depth < k:
+                ctrl_events[i + depth] = issue_control(i + depth)
+            # normalize_if_clipping is folded into the two consumers (row peaks read in place from the workspace)
+            audio = voice.render_audio(workspaces[buf], out=audio_bufs[buf], on_stage=hook, normalize=False)
+            peaks = voice.peaks_view(workspaces[buf])
+            ws_free[buf] = main.record_event()
+            if not early_ctrl and i + depth < k:
+                ctrl_events[i + depth] = issue_control(i + depth)
+            step_out = (audio, peaks, ws_free[buf], buf)
+            if defer and pipelined:
+                # Issue order = capture order.  The graph executor keeps the FIRST successor of a node on that node's
+                # hardware queue: with the consumers issued right after their render, the PQMF took the render's queue
+                # and the next render waited behind it (rocprofv3 trace: render(i) -> pqmf(i) -> render(i+1) on one queue,
+                # a 56 us bubble per step).  Issuing the consumers of step i-1 after render(i) makes the next render the
+                # first successor; the dependencies are unchanged.
+                if pending[0] is not None:
+                    issue_consumers(*pending[0])
+                pending[0] = step_out
+            else:
+                issue_consumers(*step_out)
+                if not pipelined:
+                    for e in consumed[buf]:
+                        main.wait_event(e)
+        if pending[0] is not None:
+            issue_consumers(*pending[0])
+            pending[0] = None
         main.wait_stream(side_a)
         main.wait_stream(side_b)
         main.wait_stream(side_c)
