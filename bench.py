@@ -493,7 +493,7 @@ def main():
                 for e in consumed[buf]:
                     main.wait_event(e)
             main.wait_event(ctrl_events.pop(i))
-            early_ctrl = pipelined and not defer   # (with deferred consumers the render is issued first: see below)
+            early_ctrl = pipelined    # the control pass of the next step is issued ahead of this step's render
             if early_ctrl and i + depth < k:
                 ctrl_events[i + depth] = issue_control(i + depth)
             # normalize_if_clipping is folded into the two consumers (row peaks read in place from the workspace)
