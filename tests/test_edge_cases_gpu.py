@@ -115,13 +115,13 @@ def test_c_abi_rejects_bad_arguments(lib, dev):
     assert lib.ias_voice_control_backward(None, p(z), p(zd), p(z), 1, 441, 441, None) == ARG
     assert lib.ias_voice_control_backward(p(z), p(z), p(zd), p(z), 1, 441, 440, None) == UNSUP     # kernel is built for 441
     assert lib.ias_voice_control_backward(p(z), p(z), p(zd), p(z), 1, 100000, 441, None) == UNSUP  # does not fit LDS
-    assert lib.ias_stft_loss_backward(p(z), p(z), None, None, None, None, 0, p(z), None, None, p(z), p(z), 1, 4000, 1000,
+    assert lib.ias_stft_loss_backward(p(z), p(z), None, None, None, None, None, 0, p(z), None, None, p(z), p(z), 1, 4000, 1000,
                                       256, 501, 2, 1, 1.0, 0.0, None) == UNSUP   # n_fft not 512 / 1024 / 2048
-    assert lib.ias_stft_loss_backward(p(z), p(z), None, None, None, None, 0, p(z), None, None, p(z), p(z), 1, 400, 1024,
+    assert lib.ias_stft_loss_backward(p(z), p(z), None, None, None, None, None, 0, p(z), None, None, p(z), p(z), 1, 400, 1024,
                                       256, 513, 2, 1, 1.0, 0.0, None) == ARG     # T <= n_fft / 2: reflect padding impossible
-    assert lib.ias_stft_loss_backward(p(z), p(z), None, None, None, None, 0, p(z), None, None, p(z), p(z), 1, 4000, 1024,
+    assert lib.ias_stft_loss_backward(p(z), p(z), None, None, None, None, None, 0, p(z), None, None, p(z), p(z), 1, 4000, 1024,
                                       256, 128, 2, 1, 1.0, 0.0, None) == ARG     # linear bins need n_out = n_fft / 2 + 1
-    assert lib.ias_stft_loss_backward(p(z), p(z), None, None, None, None, 0, p(z), None, None, p(z), p(z), 1, 4000, 1024,
+    assert lib.ias_stft_loss_backward(p(z), p(z), None, None, None, None, None, 0, p(z), None, None, p(z), p(z), 1, 4000, 1024,
                                       256, 513, 1, 2, 1.0, 1e-8, None) == ARG    # MR-STFT mode needs its coefficients
     assert lib.ias_pqmf_pack_taps(p(z), p(z), 200, 63, None) == ARG                  # no packed layout for N > 64
     assert lib.ias_pqmf_packed_taps_len(200, 63) == 0 and lib.ias_pqmf_packed_taps_len(3, 63) > 0
