@@ -137,3 +137,22 @@ def test_captured_step_reproduces_the_eager_loop(lib, dev, tmp_path):
     for k in ("audio_repr.conv7.weight", "vicreg.projector.0.weight", "vision_model.features.0.1.running_mean"):
         d = (se[k] - sg[k]).abs().max().item()
         assert d <= 2e-3 * max(1.0, se[k].abs().max().item()), (k, d)
+
+
+def test_pretrain_full_size_steps(lib, dev, tmp_path):
+    """BASELINE configs[2] shape end to end through the entry point: batch 128 x 4 s @ 44.1 kHz, dim 1024, embeddim 8192,
+    MobileNetV3 trunk, LARS, the step captured as one hipGraph after three eager steps.  Six steps: finite, changing
+    losses, the learning-rate warm-up of the scheduler, a checkpoint with the reference's key layout."""
+    import pretrain
+    hist = pretrain.app(["vicreg.batch_size=128", "trainer.max_steps=6", "trainer.log_every=1",
+                         "vicreg.checkpoint_every_nbatches=null", f"trainer.out_dir={tmp_path}"])
+    assert len(hist) == 6
+    losses = [h["vicreg/train/loss"] for h in hist]
+    assert all(math.isfinite(v) for v in losses) and len(set(losses)) == 6
+    lrs = [h["lr"] for h in hist]
+    assert all(b > a for a, b in zip(lrs, lrs[1:]))                      # linear warm-up
+    ck = torch.load(tmp_path / "vicreg-last.ckpt", map_location="cpu")
+    sd = ck["state_dict"]
+    assert sd["vicreg.projector.0.weight"].shape == (8192, 1024) and sd["audio_repr.conv1.weight"].shape == (1024, 1024, 2, 2)
+    assert sd["vision_model.features.1.block.0.1.running_mean"].abs().sum() > 0   # BatchNorm statistics were updated
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
