@@ -61,6 +61,11 @@ class VicregAudioParams(nn.Module):
             # outside the graph, with voice.randomize(batch))
             audio, params, _is_train = self.voice(None if batch is None else _batch_num(batch))
         x, y = self.forward(audio, params)
+        if self.training and audio.is_cuda:
+            if getattr(self, "_bump_bn", None) is None:
+                from .vision import defer_bn_counters
+                self._bump_bn = defer_bn_counters(self.vision_model)
+            self._bump_bn()
         loss, repr_loss, std_loss, cov_loss = self.vicreg.loss(x, y)
         self.logged = {f"vicreg/{name}/loss": loss.detach(), f"vicreg/{name}/repr_loss": repr_loss.detach(),
                        f"vicreg/{name}/std_loss": std_loss.detach(), f"vicreg/{name}/cov_loss": cov_loss.detach()}

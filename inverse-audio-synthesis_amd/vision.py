@@ -190,8 +190,8 @@ class BatchNormAct2d(nn.BatchNorm2d):
     def forward(self, x):
         if self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and self.track_running_stats and \
                 self.momentum is not None and self.affine:
-            if self.num_batches_tracked is not None:
-                self.num_batches_tracked.add_(1)
+            if self.num_batches_tracked is not None and not getattr(self, "counter_deferred", False):
+                self.num_batches_tracked.add_(1)     # (deferred: one multi-tensor add for all layers, see defer_bn_counters)
             return _BNActFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                   self.momentum, self.act_code)
         y = super().forward(x)
@@ -200,6 +200,21 @@ class BatchNormAct2d(nn.BatchNorm2d):
         if self.act_code == 2:
             return F.hardswish(y)
         return y
+
+
+def defer_bn_counters(module):
+    """The 34 BatchNormAct2d layers of the trunk each bump their ``num_batches_tracked`` with a one-element launch per
+    step.  After this call they leave it to the returned function, which adds 1 to all of them in ONE multi-tensor launch
+    (call it once per training forward)."""
+    bns = [m for m in module.modules() if isinstance(m, BatchNormAct2d) and m.num_batches_tracked is not None]
+    for m in bns:
+        m.counter_deferred = True
+    counters = [m.num_batches_tracked for m in bns]
+
+    def bump():
+        if counters:
+            torch._foreach_add_(counters, 1)
+    return bump
 
 
 def _divisible(v, d=8):
