@@ -8,7 +8,7 @@ from inverse_audio_synthesis_amd.config import load_config
 from inverse_audio_synthesis_amd.harness import VicregAudioParams
 
 dev = torch.device("cuda:0")
-cfg = load_config(os.path.join(ROOT, "conf"), "config", ["vicreg.batch_size=128"])
+cfg = load_config(os.path.join(ROOT, "conf"), "config", ["vicreg.batch_size=128", "trainer.cuda_graph=false"])
 model = VicregAudioParams(cfg).to(dev).train()
 opt = model.configure_optimizers()
 opt = opt["optimizer"] if isinstance(opt, dict) else opt

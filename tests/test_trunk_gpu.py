@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("C,K,S,H,W", [(16, 3, 2, 120, 123), (88, 3, 1, 30, 31), (96, 5, 2, 30, 31), (240, 5, 1, 15, 16),
-                                       (576, 5, 1, 8, 8), (7, 3, 1, 5, 4), (5, 5, 2, 9, 2), (576, 5, 1, 8, 7)])
+                                       (576, 5, 1, 8, 8), (7, 3, 1, 5, 4), (5, 5, 2, 9, 2), (576, 5, 1, 8, 7),
+                                       (4, 5, 1, 100, 90), (3, 3, 1, 130, 7), (2, 5, 2, 64, 201)])   # row-tiled planes
 def test_depthwise_conv_matches_torch(lib, dev, C, K, S, H, W):
     from inverse_audio_synthesis_amd.vision import DepthwiseConv2d
     B = 128 if (H, W) == (8, 7) else 6          # 128 x 576 planes: more than one grid dimension's 65535
