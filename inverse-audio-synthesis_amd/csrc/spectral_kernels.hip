@@ -769,12 +769,14 @@ static size_t stft_lds_bytes(int n_fft, int mel_nnz, int n_out) {
   return sizeof(cpx) * stft_waves(n_fft) * scr + sizeof(float) * mel_padded_words(mel_nnz, mel_nnz ? n_out : 0) +
          sizeof(int) * 3 * (mel_nnz ? n_out : 0) + sizeof(float) * ntab + 8;
 }
-// Consecutive frames of a row per workgroup (the per-lane tables are loaded once per workgroup).  10-wave form: ONE
-// resident round (2 workgroups per CU x 256 CUs) so that every wave gets the same 8-9 frames; 4-wave form: ~2048
-// workgroups, two rounds of the 4 that fit a CU (measured 3 % faster than one round there).
+// Consecutive frames of a row per workgroup (the per-lane tables and the re-packed mel weights are set up once per
+// workgroup).  ONE resident round: 4-wave form ~1024 workgroups (4 per CU x 256 CUs), 10-wave form 512.  Round 1 ran two
+// rounds (2048 workgroups, 3 % faster then); with the heavier per-workgroup set-up of this round one round is faster both
+// alone (85.1 -> 78.9 us) and in the pipelined step (0.2085 -> 0.1983 ms, scripts/diag/run_bench_stftwgs.sh).
 static int stft_groups(int B, int F, int n_fft) {
   const int waves = stft_waves(n_fft);
-  int per_row = (waves == 10 ? 512 : 2048) / B;
+  static const int wgs_env = getenv("IAS_STFT_WGS") ? atoi(getenv("IAS_STFT_WGS")) : 0;   // diagnostics
+  int per_row = (wgs_env > 0 ? wgs_env : (waves == 10 ? 512 : 1024)) / B;
   if (per_row < 1) per_row = 1;
   int g = (F + per_row - 1) / per_row;
   const int gmin = 2 * waves, gmax = 32 * waves;
