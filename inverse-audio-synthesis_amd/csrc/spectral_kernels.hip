@@ -21,7 +21,10 @@
 // needs 66 KB and a CU holds 2 = 5 waves per SIMD (the kernel is bound by the latency of its LDS round trips, five per
 // frame, not by a unit: VALU and LDS are each ~50 % busy).  n_fft 1024 (<= 96 VGPRs) takes the 10-wave form.
 #define SP_WAVES_MAX 10
-static int stft_waves(int n_fft) { (void)n_fft; return getenv("IAS_STFT_WAVES10") && n_fft == 1024 ? 10 : 4; }
+static int stft_waves(int n_fft) {
+  static const int env = getenv("IAS_STFT_WAVES") ? atoi(getenv("IAS_STFT_WAVES")) : 0;   // diagnostics: 8 or 10
+  return (n_fft == 1024 && (env == 8 || env == 10)) ? env : 4;
+}
 
 // Complex numbers as 2-wide vectors: complex add/sub are one packed op and a complex multiply is pk_mul +
 // pk_fma (a packed fp32 op costs the SIMD 4 clocks, two plain ones 2 + 2: the same arithmetic time, fewer
@@ -776,7 +779,7 @@ static size_t stft_lds_bytes(int n_fft, int mel_nnz, int n_out) {
 static int stft_groups(int B, int F, int n_fft) {
   const int waves = stft_waves(n_fft);
   static const int wgs_env = getenv("IAS_STFT_WGS") ? atoi(getenv("IAS_STFT_WGS")) : 0;   // diagnostics
-  int per_row = (wgs_env > 0 ? wgs_env : (waves == 10 ? 512 : 1024)) / B;
+  int per_row = (wgs_env > 0 ? wgs_env : (waves == 10 ? 512 : (waves == 8 ? 512 : 1024))) / B;
   if (per_row < 1) per_row = 1;
   int g = (F + per_row - 1) / per_row;
   const int gmin = 2 * waves, gmax = 32 * waves;
@@ -886,7 +889,9 @@ extern "C" int ias_stft(const float* audio, const float* tables, const int* mel_
     else hipLaunchKernelGGL((stft_kernel<LOG2N, WAVES, false>), grid, block, lds, stream, a);                      \
   } while (0)
   if (n_fft == 512) IAS_STFT_LAUNCH(9, 4);
-  else if (n_fft == 1024) { if (stft_waves(n_fft) == 10) IAS_STFT_LAUNCH(10, 10); else IAS_STFT_LAUNCH(10, 4); }
+  else if (n_fft == 1024) {
+    if (stft_waves(n_fft) == 10) IAS_STFT_LAUNCH(10, 10); else if (stft_waves(n_fft) == 8) IAS_STFT_LAUNCH(10, 8); else IAS_STFT_LAUNCH(10, 4);
+  }
   else IAS_STFT_LAUNCH(11, 4);
 #undef IAS_STFT_LAUNCH
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
