@@ -124,9 +124,13 @@ class STFTPlan(nn.Module):
         self._call(a, out, None, None, value_mode, LOSS_NONE, eps, rowpeak)
         return out
 
-    def loss_sums(self, audio, target_values, value_mode, loss_mode, eps=0.0, mean_scale=None, rowpeak=None):
+    def loss_sums(self, audio, target_values, value_mode, loss_mode, eps=0.0, mean_scale=None, rowpeak=None,
+                  reduce_stream=None):
         """Fused STFT + comparison with cached target values -> 3 fp64 sums on the device
-        (with ``mean_scale``: -> the fp32 scalar sums[0] * mean_scale, computed by the same kernel)."""
+        (with ``mean_scale``: -> the fp32 scalar sums[0] * mean_scale, computed by the reduction launch).
+        ``reduce_stream``: issue the small fixed-order reduction of the per-workgroup partials on that stream (it waits
+        for the STFT kernel through an event) instead of behind the STFT on the current one; the result then belongs to
+        ``reduce_stream`` (pipelines whose STFT queue is the critical path: bench.py)."""
         a = self._audio2d(audio)
         lib = _lib.load()
         F = self.num_frames(a.shape[1])
@@ -136,9 +140,21 @@ class STFTPlan(nn.Module):
         self._call(a, None, target_values, partials, value_mode, loss_mode, eps, rowpeak)
         sums = torch.empty(3, dtype=torch.float64, device=a.device)
         mean = torch.empty((), dtype=torch.float32, device=a.device) if mean_scale is not None else None
-        _lib.check(lib.ias_reduce_partials(_lib.ptr(partials), n, _lib.ptr(sums),
-                                           float(mean_scale) if mean_scale is not None else 0.0,
-                                           _lib.ptr(mean), _lib.stream()), "ias_reduce_partials")
+
+        def reduce():
+            _lib.check(lib.ias_reduce_partials(_lib.ptr(partials), n, _lib.ptr(sums),
+                                               float(mean_scale) if mean_scale is not None else 0.0,
+                                               _lib.ptr(mean), _lib.stream()), "ias_reduce_partials")
+        if reduce_stream is None:
+            reduce()
+        else:
+            done = torch.cuda.current_stream().record_event()
+            with torch.cuda.stream(reduce_stream):
+                reduce_stream.wait_event(done)
+                for t in (partials, sums, mean, target_values):
+                    if t is not None:
+                        t.record_stream(reduce_stream)
+                reduce()
         return sums if mean is None else mean
 
 
@@ -174,13 +190,13 @@ class _L1LossFn(torch.autograd.Function):
         return g_audio.reshape(ctx.shape), None, None, None
 
 
-def _l1_loss(plan, audio, target_values, value_mode, rowpeak=None):
+def _l1_loss(plan, audio, target_values, value_mode, rowpeak=None, reduce_stream=None):
     if torch.is_grad_enabled() and audio.requires_grad:
         assert value_mode in (VALUE_POWER, VALUE_MAG)
         assert rowpeak is None, "the folded normalisation is a forward-only path"
         return _L1LossFn.apply(audio, plan, target_values, value_mode)
     return plan.loss_sums(audio, target_values, value_mode, LOSS_L1, mean_scale=1.0 / target_values.numel(),
-                          rowpeak=rowpeak)
+                          rowpeak=rowpeak, reduce_stream=reduce_stream)
 
 
 class MelSpectrogram(nn.Module):
@@ -218,12 +234,13 @@ class MelSpectrogramL1(nn.Module):
         """Cacheable frames-major mel of the target audio."""
         return self.mel.frames_major(target_audio)
 
-    def forward(self, audio, target_audio=None, target_mel=None, rowpeak=None):
+    def forward(self, audio, target_audio=None, target_mel=None, rowpeak=None, reduce_stream=None):
         """``rowpeak``: row peaks of an un-normalised render; the loss is that of the normalised audio
-        (torchsynth normalize_if_clipping folded into the STFT pass)."""
+        (torchsynth normalize_if_clipping folded into the STFT pass).  ``reduce_stream``: see ``STFTPlan.loss_sums``
+        (forward-only path)."""
         if target_mel is None:
             target_mel = self.target(target_audio)
-        return _l1_loss(self.mel.plan, audio, target_mel.detach(), self.mel.value_mode, rowpeak)
+        return _l1_loss(self.mel.plan, audio, target_mel.detach(), self.mel.value_mode, rowpeak, reduce_stream)
 
 
 class STFTL1(nn.Module):
