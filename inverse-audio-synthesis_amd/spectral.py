@@ -265,6 +265,7 @@ class MultiResolutionSTFTLoss(nn.Module):
                  eps=1e-8):
         super().__init__()
         self.eps = eps
+        self.parallel = True      # the resolutions on side streams (False: one after the other on the caller's stream)
         self.plans = nn.ModuleList([STFTPlan(n, w, h) for n, h, w in zip(fft_sizes, hop_sizes, win_lengths)])
 
     def target(self, y):
@@ -280,10 +281,32 @@ class MultiResolutionSTFTLoss(nn.Module):
             return _MRSTFTFn.apply(x, self, *targets)
         return self._forward(x, targets)[0]
 
+    def _streams(self, device):
+        """One side stream per resolution (created once per device).  The kernels of the three resolutions are latency
+        bound at low occupancy and independent of each other: issued on three streams they overlap (forward and backward
+        of the configs[4] loss).  The results are joined on the caller's stream in a fixed order."""
+        pool = self.__dict__.setdefault("_side_streams", {})
+        if device not in pool:
+            pool[device] = [torch.cuda.Stream(device) for _ in self.plans]
+        return pool[device]
+
     def _forward(self, x, targets):
+        cur = torch.cuda.current_stream(x.device) if x.is_cuda else None
+        streams = self._streams(x.device) if (x.is_cuda and self.parallel) else None
+        sums = []
+        for k, (plan, tgt) in enumerate(zip(self.plans, targets)):
+            if streams is None:
+                sums.append(plan.loss_sums(x, tgt, VALUE_MAG_CLAMPED, LOSS_MRSTFT, self.eps))
+            else:
+                streams[k].wait_stream(cur)
+                with torch.cuda.stream(streams[k]):
+                    s = plan.loss_sums(x, tgt, VALUE_MAG_CLAMPED, LOSS_MRSTFT, self.eps)
+                    s.record_stream(cur)
+                    sums.append(s)
         total, saved = None, []
-        for plan, tgt in zip(self.plans, targets):
-            s = plan.loss_sums(x, tgt, VALUE_MAG_CLAMPED, LOSS_MRSTFT, self.eps)
+        for k, (tgt, s) in enumerate(zip(targets, sums)):
+            if streams is not None:
+                cur.wait_stream(streams[k])
             term = torch.sqrt(s[0]) / torch.sqrt(s[1]) + s[2] / tgt.numel()
             total = term if total is None else total + term
             saved.append((tgt, s))
@@ -308,24 +331,42 @@ class _MRSTFTFn(torch.autograd.Function):
         lib = _lib.load()
         B, T = a.shape
         nres = len(module.plans)
-        g_total = torch.zeros_like(a)
         g64 = g_loss.to(torch.float64).reshape(())
+        cur = torch.cuda.current_stream(a.device)
+        streams = module._streams(a.device) if module.parallel else None
+        grads = []
         for i, plan in enumerate(module.plans):
             tgt, s = rest[2 * i], rest[2 * i + 1]
-            # d (sqrt(l0) / sqrt(l1)) / dV = (V - T) / (sqrt(l0) sqrt(l1));  d (l2 / count) / dV = sign(V - T) / (V count)
-            den = torch.sqrt(s[0]) * torch.sqrt(s[1])
-            c0 = torch.where(den > 0, g64 / (nres * den), torch.zeros_like(den))
-            coef = torch.stack([c0, g64 / (nres * tgt.numel())]).contiguous()
-            frame_grad = torch.empty((B, plan.num_frames(T), plan.n_fft), dtype=torch.float32, device=a.device)
-            g_audio = torch.empty_like(a)
-            st = lib.ias_stft_loss_backward(_lib.ptr(a), _lib.ptr(plan.window), _lib.ptr(plan.tables), None, None, None,
-                                            None, 0, _lib.ptr(tgt),
-                                            None, _lib.ptr(coef), _lib.ptr(frame_grad), _lib.ptr(g_audio), B, T,
-                                            plan.n_fft, plan.hop_length, plan.n_out, 1, LOSS_MRSTFT, 0.0,
-                                            float(module.eps), _lib.stream())
-            _lib.check(st, "ias_stft_loss_backward")
-            g_total += g_audio
+            if streams is not None:
+                streams[i].wait_stream(cur)
+            with torch.cuda.stream(streams[i] if streams is not None else cur):
+                grads.append(_mrstft_plan_backward(lib, plan, a, tgt, s, g64, nres, float(module.eps), cur))
+        g_total = None
+        for i, g_audio in enumerate(grads):      # joined in a fixed order
+            if streams is not None:
+                cur.wait_stream(streams[i])
+            g_total = g_audio if g_total is None else g_total + g_audio
         return (g_total.reshape(ctx.shape), None) + (None,) * len(module.plans)
+
+
+def _mrstft_plan_backward(lib, plan, a, tgt, s, g64, nres, eps, consumer_stream):
+    """One resolution's d loss / d audio (on the current stream; the result is handed to ``consumer_stream``)."""
+    B, T = a.shape
+    here = torch.cuda.current_stream(a.device)
+    g64.record_stream(here)
+    # d (sqrt(l0) / sqrt(l1)) / dV = (V - T) / (sqrt(l0) sqrt(l1));  d (l2 / count) / dV = sign(V - T) / (V count)
+    den = torch.sqrt(s[0]) * torch.sqrt(s[1])
+    c0 = torch.where(den > 0, g64 / (nres * den), torch.zeros_like(den))
+    coef = torch.stack([c0, g64 / (nres * tgt.numel())]).contiguous()
+    frame_grad = torch.empty((B, plan.num_frames(T), plan.n_fft), dtype=torch.float32, device=a.device)
+    g_audio = torch.empty_like(a)
+    st = lib.ias_stft_loss_backward(_lib.ptr(a), _lib.ptr(plan.window), _lib.ptr(plan.tables), None, None, None,
+                                    None, 0, _lib.ptr(tgt), None, _lib.ptr(coef), _lib.ptr(frame_grad),
+                                    _lib.ptr(g_audio), B, T, plan.n_fft, plan.hop_length, plan.n_out, 1, LOSS_MRSTFT,
+                                    0.0, eps, _lib.stream())
+    _lib.check(st, "ias_stft_loss_backward")
+    g_audio.record_stream(consumer_stream)
+    return g_audio
 
 
 class SubbandL1(nn.Module):
