@@ -56,6 +56,9 @@ def parse():
     return ap.parse_args()
 
 
+COLL_DEV = None   # device of the timing collectives' tensors (set in main)
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (one per GPU, RCCL
     rendezvous on 127.0.0.1) BEFORE this process touches the GPU, wait for them, return the worst exit code."""
@@ -138,7 +141,7 @@ def timed_regions(one_region_fn, args, world, dev):
         sync_all()
         el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device=COLL_DEV)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = t.item()
         return el
@@ -146,7 +149,7 @@ def timed_regions(one_region_fn, args, world, dev):
     first = one()
     replays = args.replays if args.replays > 0 else max(20, min(2000, int(0.25 / max(first, 1e-6)) + 1))
     if world > 1:
-        r = torch.tensor([replays], dtype=torch.int64, device=dev)
+        r = torch.tensor([replays], dtype=torch.int64, device=COLL_DEV)
         dist.broadcast(r, 0)
         replays = int(r.item())
     return sorted(one() for _ in range(replays))
@@ -385,14 +388,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # IAS_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (the ranks share
+    # the visible devices round-robin and the timing collectives run on CPU tensors); the real runs use RCCL.
+    backend = os.environ.get("IAS_BENCH_BACKEND", "nccl")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    dev = torch.device("cuda", local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))   # host-side setup only; no oversubscription
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    global COLL_DEV
+    COLL_DEV = dev if backend == "nccl" else torch.device("cpu")
 
     from inverse_audio_synthesis_amd import _lib
     from inverse_audio_synthesis_amd.pqmf import PQMF
@@ -565,7 +576,7 @@ def main():
         sync_all()
         el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device=COLL_DEV)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = t.item()
         return el
@@ -573,7 +584,7 @@ def main():
     first = one_region()
     replays = args.replays if args.replays > 0 else max(20, min(2000, int(0.25 / max(first, 1e-6)) + 1))
     if world > 1:   # every rank must time the same number of regions
-        r = torch.tensor([replays], dtype=torch.int64, device=dev)
+        r = torch.tensor([replays], dtype=torch.int64, device=COLL_DEV)
         dist.broadcast(r, 0)
         replays = int(r.item())
     regions = sorted(one_region() for _ in range(replays))
