@@ -440,10 +440,10 @@ def main():
             e.record()
             ev[phase].append(e)
 
-    # Dataflow of one step: control-rate pass -> audio-rate render -> audio -> {PQMF, spectral loss}.  The two consumers depend only on the
-    # audio, so they run on two side HIP streams; with double-buffered audio the NEXT step's render (VALU
-    # bound) starts while this step's PQMF / STFT (LDS / latency bound) are still running.  All K steps and
-    # their cross-stream dependencies are captured once into one hipGraph and replayed.
+    # Dataflow of one step: control-rate pass -> audio-rate render -> audio -> {PQMF, spectral loss}.  The two consumers
+    # depend only on the audio, so they run on two side HIP streams (the control pass on a third); with several audio
+    # buffers and workspaces in flight the NEXT steps' renders run beside this step's PQMF / STFT.  All K steps and their
+    # cross-stream dependencies are captured once into one hipGraph and replayed (issue order matters: see run_steps).
     side_a, side_b, side_c = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
     nbuf = max(2, args.buffers)
     audio_bufs = [torch.empty((B, T), dtype=torch.float32, device=dev) for _ in range(nbuf)]
