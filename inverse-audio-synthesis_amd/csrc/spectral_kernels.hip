@@ -713,7 +713,8 @@ extern "C" int ias_stft_grad_frames(const float* audio, const float* tables, con
   a.T = T; a.F = F; a.hop = hop; a.power2 = power == 2; a.loss_mode = loss_mode; a.scale = scale; a.eps = eps;
   a.mel_start = mel_start; a.mel_count = mel_count; a.mel_woff = mel_woff; a.mel_w = mel_w;
   a.n_out = n_out; a.mel_nnz = mel ? mel_nnz : 0;
-  int per_row = 2048 / B;
+  static const int wgs_env = getenv("IAS_STFT_GRAD_WGS") ? atoi(getenv("IAS_STFT_GRAD_WGS")) : 0;   // diagnostics
+  int per_row = (wgs_env > 0 ? wgs_env : 1024) / B;   // one resident round (measured: 2.36 -> 2.29 ms for the MR-STFT loss)
   if (per_row < 1) per_row = 1;
   int g = (F + per_row - 1) / per_row;
   if (g < 8) g = 8;
