@@ -11,6 +11,7 @@
 // Nothing but mean / invstd is saved between forward and backward.  All sums in a fixed order (deterministic).
 #include "ias_common.h"
 #include <cstdint>
+#include <cstdlib>
 
 #define BN_THREADS 256
 #define BN_ACT_NONE 0
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_scalar_kernel(const float
 
 // ------------------------------------------------------------------------ C ABI
 static int bn_split(int B, int C) {
-  int s = (2048 + C - 1) / C;
+  static const int target = getenv("IAS_BN_WGS") ? atoi(getenv("IAS_BN_WGS")) : 2048;   // (diagnostics knob)
+  int s = (target + C - 1) / C;
   if (s < 1) s = 1;
   if (s > B) s = B;
   if (s > 64) s = 64;
