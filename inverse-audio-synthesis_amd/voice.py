@@ -78,7 +78,9 @@ def sample_params01(batch_size, batch_idx):
         drawn = torch.rand((batch_size, S.NPARAMS), generator=g)
     inv = torch.empty(S.NPARAMS, dtype=torch.long)
     inv[torch.tensor(order)] = torch.arange(S.NPARAMS)
-    return drawn[:, inv].contiguous()
+    # index_select, not drawn[:, inv]: advanced indexing of this 128 x 78 tensor goes through the intra-op thread pool and
+    # took 30-50 ms on the host (8 us this way) -- it was what bounded a replayed pretraining step
+    return drawn.index_select(1, inv)
 
 
 class Voice(nn.Module):
