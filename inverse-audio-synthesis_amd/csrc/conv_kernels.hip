@@ -151,6 +151,64 @@ __global__ __launch_bounds__(CV_THREADS) void dw_tile_kernel(const float* __rest
   }
 }
 
+// Stride-2 input gradient, LDS-tiled: a workgroup stages pp cotangent planes [Ho][Wo] with a one-element zero halo; a
+// thread owns the 2 x 2 block of gx at (2a + i, 2b + j), whose taps (kh of the parity of i + P, likewise kw) all fall on
+// the 3 x 3 cotangents around (a, b).  The taps are added in the order of dwconv_bwd_data_kernel (kh, then kw,
+// ascending), so the two kernels give the same bits.
+template <int K>
+__global__ __launch_bounds__(CV_THREADS) void dw_tile_bwd_s2_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                                    float* __restrict__ gx, int C, int H, int W, int Ho,
+                                                                    int Wo, int planes, int pp) {
+  constexpr int P = (K - 1) / 2, KK = K * K;
+  extern __shared__ __attribute__((aligned(16))) float s_dw[];
+  const int Wp = Wo + 2, rows = Ho + 2;
+  float* s_g = s_dw;                                   // [pp][Ho + 2][Wo + 2]
+  float* s_w = s_dw + pp * rows * Wp;                  // [pp][KK]
+  const int tid = threadIdx.x;
+  const int p0 = blockIdx.x * pp, npl = min(pp, planes - p0);
+  const int tpp = CV_THREADS / pp, slot = tid / tpp, tl = tid - slot * tpp;
+  for (int i = tid; i < npl * KK; i += CV_THREADS) s_w[i] = w[((p0 + i / KK) % C) * KK + i % KK];
+  for (int pr = tid >> 5; pr < npl * rows; pr += CV_THREADS / 32) {
+    const int pl = pr / rows, r = pr - pl * rows, ho = r - 1;
+    const bool rok = ho >= 0 && ho < Ho;
+    const float* gr = g + ((size_t)(p0 + pl) * Ho + (rok ? ho : 0)) * Wo;
+    float* sr = s_g + pr * Wp;
+    for (int col = tid & 31; col < Wp; col += 32) sr[col] = (rok && col >= 1 && col <= Wo) ? gr[col - 1] : 0.0f;
+  }
+  __syncthreads();
+  if (slot >= npl) return;
+  float* xp = gx + (size_t)(p0 + slot) * H * W;
+  const float* sp = s_g + slot * rows * Wp;
+  const float* wp = s_w + slot * KK;
+  for (int item = tl; item < Ho * Wo; item += tpp) {
+    const int a = item / Wo, b = item - a * Wo;
+    float G[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) G[r][c] = sp[(a + r) * Wp + b + c];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (2 * a + i >= H) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (2 * b + j >= W) continue;
+        float acc = 0.0f;
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+          if ((i + P - kh) & 1) continue;
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            if ((j + P - kw) & 1) continue;
+            acc = fmaf(wp[kh * K + kw], G[(i + P - kh) / 2 + 1][(j + P - kw) / 2 + 1], acc);
+          }
+        }
+        xp[(size_t)(2 * a + i) * W + 2 * b + j] = acc;
+      }
+    }
+  }
+}
+
 struct DwTile { int pp, rows_out, Wp; size_t lds; };
 static DwTile dw_tile_geometry(int H, int W, int Ho, int Wo, int K, int S, int mode) {
   (void)H;
@@ -327,7 +385,15 @@ extern "C" int ias_dwconv_backward_data(const float* g, const float* w, float* g
     const int planes = B * C;
     DW_TILE_DISPATCH(0, dim3((planes + t.pp - 1) / t.pp), dim3(CV_THREADS), t.lds, (hipStream_t)stream_, g, w,
                      (const float*)nullptr, gx, C, Ho, Wo, H, W, planes, t.pp, t.rows_out, t.Wp, 1);
-  } else {
+  } else if ((size_t)(Ho + 2) * (Wo + 2) <= 12288 && !getenv("IAS_DW_S2_DIRECT")) {
+    const int planes = B * C, plane_lds = (Ho + 2) * (Wo + 2);
+    int pp = 1;
+    while (pp * 2 <= 64 && pp * 2 * plane_lds <= 8192 && pp * 2 * Ho * Wo <= CV_THREADS) pp *= 2;
+    const size_t lds = sizeof(float) * ((size_t)pp * plane_lds + (size_t)pp * K * K);
+    const dim3 grid((planes + pp - 1) / pp), block(CV_THREADS);
+    if (K == 3) hipLaunchKernelGGL((dw_tile_bwd_s2_kernel<3>), grid, block, lds, (hipStream_t)stream_, g, w, gx, C, H, W, Ho, Wo, planes, pp);
+    else hipLaunchKernelGGL((dw_tile_bwd_s2_kernel<5>), grid, block, lds, (hipStream_t)stream_, g, w, gx, C, H, W, Ho, Wo, planes, pp);
+  } else {      // a plane too large for LDS: taps from global memory
     const dim3 grid(B * C, cv_grid_x(H * W)), block(CV_THREADS);
     CV_DISPATCH(dwconv_bwd_data_kernel, grid, block, 0, (hipStream_t)stream_, g, w, gx, C, H, W, Ho, Wo);
   }

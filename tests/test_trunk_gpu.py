@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("C,K,S,H,W", [(16, 3, 2, 120, 123), (88, 3, 1, 30, 31), (96, 5, 2, 30, 31), (240, 5, 1, 15, 16),
                                        (576, 5, 1, 8, 8), (7, 3, 1, 5, 4), (5, 5, 2, 9, 2), (576, 5, 1, 8, 7),
-                                       (4, 5, 1, 100, 90), (3, 3, 1, 130, 7), (2, 5, 2, 64, 201)])   # row-tiled planes
+                                       (4, 5, 1, 100, 90), (3, 3, 1, 130, 7), (2, 5, 2, 64, 201),    # row-tiled planes
+                                       (72, 3, 2, 60, 62), (288, 5, 2, 15, 16), (3, 3, 2, 7, 1), (2, 3, 2, 300, 200)])
 def test_depthwise_conv_matches_torch(lib, dev, C, K, S, H, W):
     from inverse_audio_synthesis_amd.vision import DepthwiseConv2d
     B = 128 if (H, W) == (8, 7) else 6          # 128 x 576 planes: more than one grid dimension's 65535
@@ -28,6 +29,14 @@ def test_depthwise_conv_matches_torch(lib, dev, C, K, S, H, W):
     assert (gw - rw).abs().max().item() <= 2e-4 * max(1.0, rw.abs().max().item())
     gw2 = torch.autograd.grad(m(x), m.weight, g)[0]
     assert torch.equal(gw, gw2), "the weight gradient is reduced in a fixed order"
+    if S == 2:      # the LDS-tiled input gradient adds its taps in the order of the direct kernel
+        import os
+        os.environ["IAS_DW_S2_DIRECT"] = "1"
+        try:
+            gx_direct = torch.autograd.grad(m(x), x, g)[0]
+        finally:
+            del os.environ["IAS_DW_S2_DIRECT"]
+        assert torch.equal(gx, gx_direct)
 
 
 def test_stem_conv_matches_torch(lib, dev):
