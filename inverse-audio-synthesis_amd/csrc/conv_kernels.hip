@@ -47,7 +47,7 @@ __global__ __launch_bounds__(CV_THREADS) void dwconv_bwd_data_kernel(const float
 // ---------------------------------------------------------------------------------------------------------------
 // LDS-tiled depthwise forward / stride-1 input gradient / weight gradient.  The first version of these kernels read
 // every tap from global memory: 25 L1 hits per output at k = 5, and the L1 (64 B/clk/CU) bounded them (67 us for a
-// [128,240,15,16] layer whose HBM traffic is 10 us; the stride-2 input gradient below still has that form).  Here a
+// [128,240,15,16] layer whose HBM traffic is 10 us; dwconv_bwd_data_kernel above still has that form).  Here a
 // workgroup stages its input planes (zero-padded halo included) in LDS once; a thread owns FOUR consecutive outputs of
 // a row and reads the 3 S + K inputs they share as two or three ds_read_b128 per kernel row (40 B of LDS per output
 // instead of 100 B of L1), with no bounds checks in the inner loops.  Small planes share a workgroup (pp planes,
@@ -329,6 +329,119 @@ __global__ __launch_bounds__(CV_THREADS) void stem_bwd_weight_kernel(const float
   if (t1 < NW) pp[t1] = acc1;
 }
 
+// The same weight gradient on the matrix cores: gw[co][tap] = sum over positions of g[co][pos] * xcol[tap][pos] is a
+// 16 x 27 x (B Ho Wo) GEMM.  One wave per (sample, chunk of output rows); per 64 output positions of a row it issues
+// 16 k-steps of v_mfma_f32_16x16x4_f32 for each of the two tap tiles (taps 0..15, 16..26): lane (m, q) supplies
+// g[co = m] and the tap-m / tap-(m+16) input of one position per k-step, each read straight from global memory (the
+// four q of a load instruction read neighbouring positions, so an instruction touches ~16-32 cache lines, not 64; the
+// stride-2 input reads hit the L1 4.5 times per element).  The 389 us of
+// the LDS version (bound by its 4 LDS reads per 2 FMAs) become ~40 us.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(CV_THREADS) void stem_bwd_weight_mfma_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                          float* __restrict__ partial, int B, int H, int W,
+                                                                          int Ho, int Wo, int chunks, int rows_per_chunk) {
+  static_assert(COUT == 16 && CIN * 9 <= 32, "one 16-row tile of output channels, two 16-column tiles of taps");
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  constexpr int NT = CIN * 9;
+  const int wave = blockIdx.x * (CV_THREADS / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wave >= B * chunks) return;
+  const int b = wave / chunks, chunk = wave - b * chunks;
+  const int m = lane & 15, q = lane >> 4;
+  const int t1 = m + 16;
+  const bool t1ok = t1 < NT;
+  const int ci0 = m / 9, kh0 = (m % 9) / 3, kw0 = m % 3;
+  const int ci1 = t1ok ? t1 / 9 : 0, kh1 = t1ok ? (t1 % 9) / 3 : 0, kw1 = t1ok ? t1 % 3 : 0;
+  const float* xb0 = x + ((size_t)b * CIN + ci0) * H * W;
+  const float* xb1 = x + ((size_t)b * CIN + ci1) * H * W;
+  const float* gb = g + ((size_t)b * COUT + m) * Ho * Wo;
+  v4f acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int ho_end = min(Ho, (chunk + 1) * rows_per_chunk);
+  for (int ho = chunk * rows_per_chunk; ho < ho_end; ++ho) {
+    const int hi0 = 2 * ho + kh0 - 1, hi1 = 2 * ho + kh1 - 1;
+    const bool r0 = hi0 >= 0 && hi0 < H, r1 = t1ok && hi1 >= 0 && hi1 < H;
+    const float* xr0 = xb0 + (size_t)(r0 ? hi0 : 0) * W;
+    const float* xr1 = xb1 + (size_t)(r1 ? hi1 : 0) * W;
+    const float* gr = gb + (size_t)ho * Wo;
+    for (int w0 = 0; w0 < Wo; w0 += 64) {
+      float a[16], b0[16], b1[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {   // k-slot (q, s) <-> position 16 (s / 4) + 4 q + s % 4: the four q of a load are neighbours
+        const int wo = w0 + 16 * (s >> 2) + 4 * q + (s & 3), c0 = 2 * wo + kw0 - 1, c1 = 2 * wo + kw1 - 1;
+        a[s] = wo < Wo ? gr[wo] : 0.0f;
+        b0[s] = (r0 && c0 >= 0 && c0 < W) ? xr0[c0] : 0.0f;
+        b1[s] = (r1 && c1 >= 0 && c1 < W) ? xr1[c1] : 0.0f;
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b0[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[s], acc1, 0, 0, 0);
+      }
+    }
+  }
+  float* pp = partial + (size_t)wave * (COUT * NT);     // D[co = 4 q + reg][tap = m (+16)]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    pp[(4 * q + r) * NT + m] = acc0[r];
+    if (t1ok) pp[(4 * q + r) * NT + t1] = acc1[r];
+  }
+}
+
+// The stem forward on the matrix cores: out[co][pos] = sum_tap w[co][tap] xcol[tap][pos] with M = 16 output channels,
+// K = 27 taps (7 k-steps of 4, the last tap slot zero), N = 16 positions per tile.  One wave per output row (b, ho);
+// lane (n, q) keeps its 7 weights w[co = n][tap = 4 ks + q] in registers and reads the tap's input of position
+// wo0 + n from global memory (stride-2 reads, 108 B of L1 per position); D gives it out[co = 4 q + r][wo0 + n].
+// The VALU version spent 432 broadcast LDS reads + 432 FMAs per position (144 us at B = 128; HBM floor 26 us).
+template <int CIN, int COUT>
+__global__ __launch_bounds__(CV_THREADS) void stem_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                   float* __restrict__ out, int rows, int H, int W, int Ho,
+                                                                   int Wo) {
+  static_assert(COUT == 16 && CIN * 9 <= 28, "one 16-row tile of output channels, 7 k-steps of taps");
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  constexpr int NT = CIN * 9, KS = 7;
+  const int row = blockIdx.x * (CV_THREADS / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int b = row / Ho, ho = row - b * Ho;
+  const int n = lane & 15, q = lane >> 4;
+  float aw[KS];
+  int off[KS], kwm1[KS];
+  bool ok[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int tap = 4 * ks + q;
+    const bool tv = tap < NT;
+    const int ci = tv ? tap / 9 : 0, kh = tv ? (tap % 9) / 3 : 0, kw = tv ? tap % 3 : 0;
+    const int hi = 2 * ho + kh - 1;
+    aw[ks] = tv ? w[n * NT + tap] : 0.0f;
+    ok[ks] = tv && hi >= 0 && hi < H;
+    off[ks] = ok[ks] ? (ci * H + hi) * W : 0;
+    kwm1[ks] = kw - 1;
+  }
+  const float* xb = x + (size_t)b * CIN * H * W;
+  float* ob = out + ((size_t)b * COUT * Ho + ho) * Wo;
+  for (int wo0 = 0; wo0 < Wo; wo0 += 32) {
+    const int wa = wo0 + n, wb = wo0 + 16 + n;
+    v4f acc_a = {0.0f, 0.0f, 0.0f, 0.0f}, acc_b = {0.0f, 0.0f, 0.0f, 0.0f};
+    float va[KS], vb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int ca = 2 * wa + kwm1[ks], cb = 2 * wb + kwm1[ks];
+      va[ks] = (ok[ks] && ca >= 0 && ca < W) ? xb[off[ks] + ca] : 0.0f;
+      vb[ks] = (ok[ks] && cb >= 0 && cb < W) ? xb[off[ks] + cb] : 0.0f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[ks], va[ks], acc_a, 0, 0, 0);
+      acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[ks], vb[ks], acc_b, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* oc = ob + (size_t)(4 * q + r) * Ho * Wo;
+      if (wa < Wo) oc[wa] = acc_a[r];
+      if (wb < Wo) oc[wb] = acc_b[r];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------ C ABI
 static int cv_grid_x(int n) {
   int g = (n + CV_THREADS - 1) / CV_THREADS;
@@ -427,12 +540,18 @@ extern "C" int ias_dwconv_backward_weight(const float* x, const float* g, float*
 extern "C" int ias_stem_forward(const float* x, const float* w, float* out, int B, int H, int W, void* stream_) {
   if (!x || !w || !out || B <= 0 || B > 65535 || H <= 0 || W <= 0) return IAS_ERR_ARG;
   const int Ho = ias_conv_out_size(H, 3, 2), Wo = ias_conv_out_size(W, 3, 2);
-  hipLaunchKernelGGL((stem_fwd_kernel<3, 16>), dim3(cv_grid_x(Ho * Wo), B), dim3(CV_THREADS), 0, (hipStream_t)stream_, x, w,
-                     out, H, W, Ho, Wo);
+  if (getenv("IAS_STEM_VALU") || (long long)3 * H * W > 0x7fffffffLL) {
+    hipLaunchKernelGGL((stem_fwd_kernel<3, 16>), dim3(cv_grid_x(Ho * Wo), B), dim3(CV_THREADS), 0, (hipStream_t)stream_, x, w,
+                       out, H, W, Ho, Wo);
+  } else {
+    const int rows = B * Ho;
+    hipLaunchKernelGGL((stem_fwd_mfma_kernel<3, 16>), dim3((rows + CV_THREADS / 64 - 1) / (CV_THREADS / 64)),
+                       dim3(CV_THREADS), 0, (hipStream_t)stream_, x, w, out, rows, H, W, Ho, Wo);
+  }
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
-#define STEM_CHUNKS_X 8
+#define STEM_CHUNKS_X 32
 extern "C" long long ias_stem_weight_scratch(int B) { return B <= 0 ? IAS_ERR_ARG : (long long)B * STEM_CHUNKS_X * 432; }
 
 // its weight gradient: x [B,3,H,W], g [B,16,Ho,Wo] -> gw [16,3,3,3]; scratch: ias_stem_weight_scratch(B) floats
@@ -440,8 +559,15 @@ extern "C" int ias_stem_backward_weight(const float* x, const float* g, float* g
                                         void* stream_) {
   if (!x || !g || !gw || !scratch || B <= 0 || B > 65535 || H <= 0 || W <= 0) return IAS_ERR_ARG;
   const int Ho = ias_conv_out_size(H, 3, 2), Wo = ias_conv_out_size(W, 3, 2);
-  hipLaunchKernelGGL((stem_bwd_weight_kernel<3, 16>), dim3(STEM_CHUNKS_X, B), dim3(CV_THREADS), 0, (hipStream_t)stream_, x, g,
-                     scratch, H, W, Ho, Wo, STEM_CHUNKS_X);
+  if (getenv("IAS_STEM_GW_LDS")) {   // the VALU / LDS form (diagnostics)
+    hipLaunchKernelGGL((stem_bwd_weight_kernel<3, 16>), dim3(STEM_CHUNKS_X, B), dim3(CV_THREADS), 0, (hipStream_t)stream_, x,
+                       g, scratch, H, W, Ho, Wo, STEM_CHUNKS_X);
+  } else {
+    const int waves = B * STEM_CHUNKS_X, rows_per_chunk = (Ho + STEM_CHUNKS_X - 1) / STEM_CHUNKS_X;
+    hipLaunchKernelGGL((stem_bwd_weight_mfma_kernel<3, 16>), dim3((waves + CV_THREADS / 64 - 1) / (CV_THREADS / 64)),
+                       dim3(CV_THREADS), 0, (hipStream_t)stream_, x, g, scratch, B, H, W, Ho, Wo, STEM_CHUNKS_X,
+                       rows_per_chunk);
+  }
   hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((432 + 3) / 4), dim3(CV_THREADS), 0, (hipStream_t)stream_, scratch, gw,
                      432, B * STEM_CHUNKS_X);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
