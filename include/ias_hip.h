@@ -226,6 +226,11 @@ long long ias_dwconv_weight_scratch(int B, int C, int K);     /* floats */
 int ias_dwconv_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int C, int H, int W,
                                int K, int S, void* stream);
 /* Conv2d(3, 16, 3, stride 2, padding 1, bias=False): x [B,3,H,W], w [16,3,3,3] -> out [B,16,Ho,Wo]; weight gradient. */
+/* head Conv2d(C, Cout, kernel_size=2) of AudioEmbedding (/root/reference/audioembed.py:15-33, 62-68) as one GEMM on
+ * channels-last maps: patches [B (H-1) (W-1)][4 C] (columns ordered (c, di, dj), i.e. weight.view(Cout, 4 C) is the
+ * GEMM's other operand) from x [B,H,W,C], and the adjoint gp -> gx [B,H,W,C].  patches 16-byte aligned. */
+int ias_conv2x2_patches(const float* x, float* patches, int B, int H, int W, int C, void* stream);
+int ias_conv2x2_patches_backward(const float* gp, float* gx, int B, int H, int W, int C, void* stream);
 int ias_stem_forward(const float* x, const float* w, float* out, int B, int H, int W, void* stream);
 long long ias_stem_weight_scratch(int B);                     /* floats */
 int ias_stem_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int H, int W, void* stream);

@@ -26,20 +26,58 @@ class ChannelNormalize(nn.Module):
         return (x - self.mean.view(1, -1, 1, 1)) / self.std.view(1, -1, 1, 1)
 
 
+class _Conv2x2Fn(torch.autograd.Function):
+    """out[(b,i,j), :] = patches[(b,i,j), (c,di,dj)] @ weight.view(Cout, 4 Cin)^T + bias, patches gathered by
+    ``ias_conv2x2_patches`` (csrc/conv_kernels.hip); backward: two GEMMs, the patch adjoint in one kernel, the weight
+    gradient directly in the weight's layout."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import _lib
+        lib = _lib.load()
+        x, weight = x.contiguous(), weight.contiguous()
+        _lib.require_f32(x, weight)
+        B, H, W, C = x.shape
+        Cout = weight.shape[0]
+        patches = torch.empty((B * (H - 1) * (W - 1), 4 * C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.ias_conv2x2_patches(_lib.ptr(x), _lib.ptr(patches), B, H, W, C, _lib.stream()), "ias_conv2x2_patches")
+        w2 = weight.view(Cout, 4 * C)
+        out = torch.addmm(bias, patches, w2.t()) if bias is not None else torch.mm(patches, w2.t())
+        ctx.save_for_backward(patches, weight)
+        ctx.shape = (B, H, W, C)
+        ctx.has_bias = bias is not None
+        return out.view(B, H - 1, W - 1, Cout)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.load()
+        patches, weight = ctx.saved_tensors
+        B, H, W, C = ctx.shape
+        Cout = weight.shape[0]
+        g2 = g.reshape(-1, Cout)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gp = torch.mm(g2, weight.view(Cout, 4 * C))
+            gx = torch.empty((B, H, W, C), dtype=torch.float32, device=g.device)
+            _lib.check(lib.ias_conv2x2_patches_backward(_lib.ptr(gp), _lib.ptr(gx), B, H, W, C, _lib.stream()),
+                       "ias_conv2x2_patches_backward")
+        if ctx.needs_input_grad[1]:
+            gw = torch.mm(g2.t(), patches).view_as(weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return gx, gw, gb
+
+
 def conv2x2_nhwc(x, weight, bias):
     """``nn.Conv2d(kernel_size=2)`` (stride 1, no padding) on a channels-last activation x [B,H,W,Cin] with the module's
-    own parameters (weight [Cout,Cin,2,2], bias [Cout]) -> [B,H-1,W-1,Cout], as ONE gather + ONE dense GEMM:
-    out[(b,i,j), :] = patches[(b,i,j), (di,dj,c)] @ W[(di,dj,c), :].  The seven layers of AudioEmbedding's head
-    (/root/reference/audioembed.py:15-33,62-68) are 1024 -> 1024 convolutions on 8x8 ... 2x2 maps: as nn.Conv2d on
-    MIOpen they ran as naive fallbacks plus one im2col + one small GEMM PER SAMPLE (4096 Im2d2Col launches per step at
-    batch 128); as a GEMM [B Ho Wo, 4 Cin] x [4 Cin, Cout] they are seven rocBLAS / hipBLASLt calls.  fp32 throughout,
-    differentiable through plain autograd (two more GEMMs per layer in backward)."""
-    B, H, W, C = x.shape
-    patches = x.unfold(1, 2, 1).unfold(2, 2, 1)                       # [B,H-1,W-1,C,2,2] view
-    patches = patches.permute(0, 1, 2, 4, 5, 3).reshape(B * (H - 1) * (W - 1), 4 * C)   # the one gather (copy)
-    w2 = weight.permute(0, 2, 3, 1).reshape(weight.shape[0], 4 * C)   # [Cout, (di,dj,c)]
-    out = torch.nn.functional.linear(patches, w2, bias)
-    return out.view(B, H - 1, W - 1, weight.shape[0])
+    own parameters (weight [Cout,Cin,2,2], bias [Cout]) -> [B,H-1,W-1,Cout], as ONE gather + ONE dense GEMM.  The seven
+    layers of AudioEmbedding's head (/root/reference/audioembed.py:15-33,62-68) are 1024 -> 1024 convolutions on
+    8x8 ... 2x2 maps: as nn.Conv2d on MIOpen they ran as naive fallbacks plus one im2col + one small GEMM PER SAMPLE
+    (4096 Im2d2Col launches per step at batch 128); as a GEMM [B Ho Wo, 4 Cin] x [4 Cin, Cout] they are seven rocBLAS /
+    hipBLASLt calls.  fp32 throughout.  The patch columns are ordered (c, di, dj) -- the weight's own memory order -- so
+    neither the weight nor its gradient is ever permuted."""
+    return _Conv2x2Fn.apply(x, weight, bias)
 
 
 class AudioEmbedding(nn.Module):

@@ -572,3 +572,70 @@ extern "C" int ias_stem_backward_weight(const float* x, const float* g, float* g
                      432, B * STEM_CHUNKS_X);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
+
+// ---- head: Conv2d(C, Cout, kernel 2) on channels-last maps as one GEMM (audioembed.py: conv7 .. conv1) -------------
+// patches[(b,i,j)][(c,di,dj)] = x[b, i+di, j+dj, c], x [B,H,W,C] channels-last: the column order is the weight's own
+// [Cout][(c,di,dj)] layout, so the GEMMs use weight.view(Cout, 4 C) and give the weight gradient in place (no permuted
+// copies of a 16 MB weight per layer and step).  A thread reads its channel at the four pixels (lanes along c:
+// coalesced) and writes one 16-byte group.
+__global__ __launch_bounds__(CV_THREADS) void conv2x2_patches_kernel(const float* __restrict__ x, float* __restrict__ patches,
+                                                                     int H, int W, int C, long long total) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int Ho = H - 1, Wo = W - 1;
+  for (long long i = (long long)blockIdx.x * CV_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * CV_THREADS) {
+    const int c = (int)(i % C);
+    const long long r = i / C;
+    const int j = (int)(r % Wo), ii = (int)((r / Wo) % Ho);
+    const long long b = r / ((long long)Wo * Ho);
+    const float* xp = x + ((b * H + ii) * W + j) * C + c;
+    f4 v;
+    v[0] = xp[0]; v[1] = xp[C]; v[2] = xp[(size_t)W * C]; v[3] = xp[(size_t)W * C + C];
+    *reinterpret_cast<f4*>(patches + i * 4) = v;
+  }
+}
+
+// its adjoint: gx[b,h,w,c] = sum over the (up to four) patches that contain the pixel
+__global__ __launch_bounds__(CV_THREADS) void conv2x2_patches_bwd_kernel(const float* __restrict__ gp, float* __restrict__ gx,
+                                                                         int H, int W, int C, long long total) {
+  const int Ho = H - 1, Wo = W - 1;
+  for (long long i = (long long)blockIdx.x * CV_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * CV_THREADS) {
+    const int c = (int)(i % C);
+    const long long px = i / C;
+    const int w = (int)(px % W), h = (int)((px / W) % H);
+    const long long b = px / ((long long)W * H);
+    float acc = 0.0f;
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) {
+        const int pi = h - di, pj = w - dj;
+        if (pi >= 0 && pi < Ho && pj >= 0 && pj < Wo)
+          acc += gp[(((b * Ho + pi) * Wo + pj) * C + c) * 4 + 2 * di + dj];
+      }
+    gx[i] = acc;
+  }
+}
+
+static int conv2x2_grid(long long total) {
+  long long g = (total + CV_THREADS - 1) / CV_THREADS;
+  return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+// x [B,H,W,C] channels-last -> patches [B (H-1) (W-1)][4 C], columns (c, di, dj); H, W >= 2
+extern "C" int ias_conv2x2_patches(const float* x, float* patches, int B, int H, int W, int C, void* stream_) {
+  if (!x || !patches || B <= 0 || H < 2 || W < 2 || C <= 0) return IAS_ERR_ARG;
+  if (((uintptr_t)patches & 15) != 0) return IAS_ERR_ARG;
+  const long long total = (long long)B * (H - 1) * (W - 1) * C;
+  hipLaunchKernelGGL(conv2x2_patches_kernel, dim3(conv2x2_grid(total)), dim3(CV_THREADS), 0, (hipStream_t)stream_, x, patches, H,
+                     W, C, total);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+// gp [B (H-1) (W-1)][4 C] -> gx [B,H,W,C]
+extern "C" int ias_conv2x2_patches_backward(const float* gp, float* gx, int B, int H, int W, int C, void* stream_) {
+  if (!gp || !gx || B <= 0 || H < 2 || W < 2 || C <= 0) return IAS_ERR_ARG;
+  const long long total = (long long)B * H * W * C;
+  hipLaunchKernelGGL(conv2x2_patches_bwd_kernel, dim3(conv2x2_grid(total)), dim3(CV_THREADS), 0, (hipStream_t)stream_, gp, gx,
+                     H, W, C, total);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}

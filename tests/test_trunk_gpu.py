@@ -122,3 +122,21 @@ def test_fused_batchnorm_activation_matches_torch(lib, dev, shape, act):
     ye = fused(xe.to(dev)).cpu().double()
     ref.eval()
     assert (ye - actf(ref(xe.double()))).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("B,H,W,C,Cout", [(3, 8, 8, 64, 32), (2, 2, 2, 8, 8), (5, 3, 6, 12, 20), (128, 8, 8, 576, 16)])
+def test_head_conv2x2_matches_torch(lib, dev, B, H, W, C, Cout):
+    """conv2x2_nhwc (ias_conv2x2_patches + GEMM) against F.conv2d with the same weight / bias: output, input gradient,
+    weight and bias gradients."""
+    from inverse_audio_synthesis_amd.audioembed import conv2x2_nhwc
+    x = randn((B, H, W, C), 11).to(dev).requires_grad_(True)
+    w = (randn((Cout, C, 2, 2), 12) * 0.1).to(dev).requires_grad_(True)
+    b = randn((Cout,), 13).to(dev).requires_grad_(True)
+    y = conv2x2_nhwc(x, w, b)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b).permute(0, 2, 3, 1)
+    assert y.shape == ref.shape and (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    g = randn(tuple(ref.shape), 14).to(dev)
+    got = torch.autograd.grad(y, (x, w, b), g)
+    want = torch.autograd.grad(ref, (x, w, b), g)
+    for a, r, name in zip(got, want, ("gx", "gw", "gb")):
+        assert (a - r).abs().max().item() <= 1e-4 * max(1.0, r.abs().max().item()), name
