@@ -226,6 +226,15 @@ long long ias_dwconv_weight_scratch(int B, int C, int K);     /* floats */
 int ias_dwconv_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int C, int H, int W,
                                int K, int S, void* stream);
 /* Conv2d(3, 16, 3, stride 2, padding 1, bias=False): x [B,3,H,W], w [16,3,3,3] -> out [B,16,Ho,Wo]; weight gradient. */
+/* squeeze-and-excitation blocks of the trunk (torchvision SqueezeExcitation; /root/reference/vicreg_audio_params.py:52-54):
+ * per-plane reductions and the per-plane scale over a [planes][hw] activation (planes = B C).
+ *   ias_se_plane_reduce: out[p] = scale * sum_i a[p][i]          (b == NULL: the average pool with scale = 1/hw)
+ *                        out[p] = scale * sum_i a[p][i] b[p][i]   (the gradient of the per-plane scale)
+ *   ias_se_scale:        y[p][i] = x[p][i] * s[p] + (add ? add[p] * add_scale : 0) */
+int ias_se_plane_reduce(const float* a, const float* b, float* out, long long planes, int hw, float scale, void* stream);
+int ias_se_scale(const float* x, const float* s, const float* add, float* y, long long planes, int hw, float add_scale,
+                 void* stream);
+
 /* head Conv2d(C, Cout, kernel_size=2) of AudioEmbedding (/root/reference/audioembed.py:15-33, 62-68) as one GEMM on
  * channels-last maps: patches [B (H-1) (W-1)][4 C] (columns ordered (c, di, dj), i.e. weight.view(Cout, 4 C) is the
  * GEMM's other operand) from x [B,H,W,C], and the adjoint gp -> gx [B,H,W,C].  patches 16-byte aligned. */

@@ -233,6 +233,56 @@ class ConvBNAct(nn.Sequential):
         super().__init__(*layers)
 
 
+class _SEFn(torch.autograd.Function):
+    """y = x * hardsigmoid(fc2(relu(fc1(mean_hw x)))) with the passes over x in csrc/se_kernels.hip (pool, scale, and in
+    backward the per-plane <gy, x> and gx = gy s + gpool / HW in one pass each) and the two 1x1 convolutions as GEMMs on
+    [B, C]."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        from . import _lib
+        lib = _lib.load()
+        x = x.contiguous()
+        _lib.require_f32(x, w1, b1, w2, b2)
+        B, C, H, W = x.shape
+        hw = H * W
+        w1m, w2m = w1.view(w1.shape[0], C), w2.view(C, w1.shape[0])
+        pooled = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.ias_se_plane_reduce(_lib.ptr(x), None, _lib.ptr(pooled), B * C, hw, 1.0 / hw, _lib.stream()),
+                   "ias_se_plane_reduce")
+        h = torch.relu_(torch.addmm(b1, pooled, w1m.t()))
+        z = torch.addmm(b2, h, w2m.t())
+        s = F.hardsigmoid(z)
+        y = torch.empty_like(x)
+        _lib.check(lib.ias_se_scale(_lib.ptr(x), _lib.ptr(s), None, _lib.ptr(y), B * C, hw, 0.0, _lib.stream()), "ias_se_scale")
+        ctx.save_for_backward(x, pooled, h, z, s, w1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _lib
+        lib = _lib.load()
+        x, pooled, h, z, s, w1, w2 = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, C, H, W = x.shape
+        hw = H * W
+        w1m, w2m = w1.view(w1.shape[0], C), w2.view(C, w1.shape[0])
+        gs = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.ias_se_plane_reduce(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(gs), B * C, hw, 1.0, _lib.stream()),
+                   "ias_se_plane_reduce")
+        gz = torch.ops.aten.hardsigmoid_backward(gs, z)
+        gw2 = torch.mm(gz.t(), h)
+        gb2 = gz.sum(0)
+        gh = torch.ops.aten.threshold_backward(torch.mm(gz, w2m), h, 0.0)
+        gw1 = torch.mm(gh.t(), pooled)
+        gb1 = gh.sum(0)
+        gp = torch.mm(gh, w1m)
+        gx = torch.empty_like(x)
+        _lib.check(lib.ias_se_scale(_lib.ptr(gy), _lib.ptr(s), _lib.ptr(gp), _lib.ptr(gx), B * C, hw, 1.0 / hw, _lib.stream()),
+                   "ias_se_scale")
+        return gx, gw1.view_as(w1), gb1, gw2.view_as(w2), gb2
+
+
 class SqueezeExcitation(nn.Module):
     def __init__(self, channels, squeeze):
         super().__init__()
@@ -243,6 +293,8 @@ class SqueezeExcitation(nn.Module):
         self.scale_activation = nn.Hardsigmoid()
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
+            return _SEFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
         s = self.scale_activation(self.fc2(self.activation(self.fc1(self.avgpool(x)))))
         return s * x
 
