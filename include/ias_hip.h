@@ -226,6 +226,18 @@ long long ias_dwconv_weight_scratch(int B, int C, int K);     /* floats */
 int ias_dwconv_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int C, int H, int W,
                                int K, int S, void* stream);
 /* Conv2d(3, 16, 3, stride 2, padding 1, bias=False): x [B,3,H,W], w [16,3,3,3] -> out [B,16,Ho,Wo]; weight gradient. */
+/* 1x1 convolutions (nn.Conv2d(Cin, Cout, 1, bias=False)) of torchvision's mobilenet_v3_small.features as run at
+ * /root/reference/audioembed.py:61, NCHW fp32, on fp32 MFMA: x [B,Cin,HW], w [Cout,Cin], y / g [B,Cout,HW].
+ * ias_pwconv_supported(Cin, Cout) = 1 for the shapes taken (channel counts multiples of 4, 16-padded Cout * Cin and
+ * 16-padded Cin * Cout <= 16384, Cin <= 240); the other entry points return IAS_ERR_UNSUPPORTED otherwise.
+ * The weight gradient is reduced in a fixed order (deterministic); scratch: ias_pwconv_weight_scratch floats. */
+int ias_pwconv_supported(int Cin, int Cout);
+int ias_pwconv_forward(const float* x, const float* w, float* y, int B, int Cin, int Cout, int HW, void* stream);
+int ias_pwconv_backward_data(const float* g, const float* w, float* gx, int B, int Cin, int Cout, int HW, void* stream);
+long long ias_pwconv_weight_scratch(int B, int Cin, int Cout, int HW);
+int ias_pwconv_backward_weight(const float* g, const float* x, float* gw, float* scratch, int B, int Cin, int Cout, int HW,
+                               void* stream);
+
 /* squeeze-and-excitation blocks of the trunk (torchvision SqueezeExcitation; /root/reference/vicreg_audio_params.py:52-54):
  * per-plane reductions and the per-plane scale over a [planes][hw] activation (planes = B C).
  *   ias_se_plane_reduce: out[p] = scale * sum_i a[p][i]          (b == NULL: the average pool with scale = 1/hw)

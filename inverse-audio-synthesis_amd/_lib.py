@@ -68,6 +68,11 @@ SYMBOLS = {
     "ias_dwconv_backward_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ias_dwconv_weight_scratch": (_LL, [_I, _I, _I]),
     "ias_dwconv_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ias_pwconv_supported": (_I, [_I, _I]),
+    "ias_pwconv_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_pwconv_backward_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_pwconv_weight_scratch": (_LL, [_I, _I, _I, _I]),
+    "ias_pwconv_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_se_plane_reduce": (_I, [_P, _P, _P, _LL, _I, _F, _P]),
     "ias_se_scale": (_I, [_P, _P, _P, _P, _LL, _I, _F, _P]),
     "ias_conv2x2_patches": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -14,6 +14,61 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+_PW_SUPPORTED = {}
+
+
+def _pw_mfma(cin, cout):
+    """Whether csrc/pointwise_kernels.hip takes this 1x1 convolution (ias_pwconv_supported); IAS_PW_BMM=1 keeps the
+    batched-GEMM form everywhere (diagnostics)."""
+    import os
+    if os.environ.get("IAS_PW_BMM"):
+        return False
+    key = (cin, cout)
+    if key not in _PW_SUPPORTED:
+        from . import _lib
+        _PW_SUPPORTED[key] = bool(_lib.load().ias_pwconv_supported(cin, cout))
+    return _PW_SUPPORTED[key]
+
+
+class _PointwiseFn(torch.autograd.Function):
+    """csrc/pointwise_kernels.hip: a thin 1x1 convolution (no bias) on fp32 MFMA -- forward, input gradient, weight
+    gradient (deterministic reduction)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        from . import _lib
+        lib = _lib.load()
+        x, w = x.contiguous(), w.contiguous()
+        _lib.require_f32(x, w)
+        B, C, H, W = x.shape
+        Cout = w.shape[0]
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+        _lib.check(lib.ias_pwconv_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), B, C, Cout, H * W, _lib.stream()),
+                   "ias_pwconv_forward")
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        B, C, H, W = x.shape
+        Cout = w.shape[0]
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _lib.check(lib.ias_pwconv_backward_data(_lib.ptr(g), _lib.ptr(w), _lib.ptr(gx), B, C, Cout, H * W, _lib.stream()),
+                       "ias_pwconv_backward_data")
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            scratch = torch.empty(int(lib.ias_pwconv_weight_scratch(B, C, Cout, H * W)), dtype=torch.float32, device=x.device)
+            _lib.check(lib.ias_pwconv_backward_weight(_lib.ptr(g), _lib.ptr(x), _lib.ptr(gw), _lib.ptr(scratch), B, C, Cout,
+                                                      H * W, _lib.stream()), "ias_pwconv_backward_weight")
+        return gx, gw
+
+
 class PointwiseConv2d(nn.Conv2d):
     """A 1x1 convolution (same parameters and state_dict keys as nn.Conv2d).  On a ROCm device it is what it is -- ONE
     strided-batched GEMM  y[b] = W [Cout,Cin] x[b] [Cin, H W]  on rocBLAS / hipBLASLt, layout unchanged (NCHW in, NCHW
@@ -24,6 +79,8 @@ class PointwiseConv2d(nn.Conv2d):
         if x.is_cuda and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.groups == 1 and \
                 x.dim() == 4 and x.is_contiguous():
             B, C, H, W = x.shape
+            if self.bias is None and x.dtype == torch.float32 and _pw_mfma(C, self.out_channels):
+                return _PointwiseFn.apply(x, self.weight)      # the thin layers: weight in LDS, fp32 MFMA
             # bmm with the weight expanded along the batch (stride 0), not torch.matmul(W, x): matmul folds the batch into
             # the rows of a transposed COPY of x (and of the result, and again in backward) -- 106 copy launches and
             # 2.3 ms of a pretraining step at batch 128.  Autograd of this form is two more bmm's and one sum over the

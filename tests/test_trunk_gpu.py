@@ -168,3 +168,26 @@ def test_squeeze_excitation_matches_torch(lib, dev, B, C, Cs, H, W):
     assert (y.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
     for a, r, name in zip(got, want, ("gx", "gw1", "gb1", "gw2", "gb2")):
         assert (a.double() - r).abs().max().item() <= 1e-4 * max(1.0, r.abs().max().item()), name
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(3, 16, 16, 60, 62), (2, 16, 72, 60, 62), (4, 72, 24, 30, 31), (4, 24, 88, 30, 31),
+                                            (5, 240, 40, 15, 16), (5, 40, 240, 15, 16), (3, 48, 288, 15, 16), (2, 288, 96, 8, 8),
+                                            (7, 8, 12, 3, 3), (2, 96, 576, 8, 8), (130, 24, 96, 5, 7)])
+def test_pointwise_conv_matches_torch(lib, dev, B, Cin, Cout, H, W):
+    """PointwiseConv2d (csrc/pointwise_kernels.hip where ias_pwconv_supported, the batched GEMM otherwise) against
+    F.conv2d in fp64: output, input gradient, weight gradient; the weight gradient twice (fixed-order reduction)."""
+    from inverse_audio_synthesis_amd.vision import PointwiseConv2d
+    m = PointwiseConv2d(Cin, Cout, 1, bias=False).to(dev)
+    x = randn((B, Cin, H, W), 31).to(dev).requires_grad_(True)
+    g = randn((B, Cout, H, W), 32).to(dev)
+    y = m(x)
+    gx, gw = torch.autograd.grad(y, (x, m.weight), g)
+    xd, wd = x.detach().double().requires_grad_(True), m.weight.detach().double().requires_grad_(True)
+    ref = F.conv2d(xd, wd)
+    rx, rw = torch.autograd.grad(ref, (xd, wd), g.double())
+    assert (y.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    assert (gx.double() - rx).abs().max().item() <= 1e-5 * max(1.0, rx.abs().max().item())
+    assert (gw.double() - rw).abs().max().item() <= 1e-4 * max(1.0, rw.abs().max().item())
+    gw2 = torch.autograd.grad(m(x), m.weight, g)[0]
+    if lib.ias_pwconv_supported(Cin, Cout):
+        assert torch.equal(gw, gw2)
