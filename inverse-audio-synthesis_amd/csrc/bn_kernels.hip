@@ -59,27 +59,33 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partials_kernel(const float* __
   if (MODE == 0) k = x[(size_t)c * HW];
   else { m = mean[c]; is = invstd[c]; w = weight ? weight[c] : 1.0f; bb = bias ? bias[c] : 0.0f; }
   const bool vec = (HW & 3) == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0;
-  for (int b = s; b < B; b += S) {
+  // small planes share the workgroup: lpp lanes per plane (a power of two >= the plane's vector count, at most the
+  // workgroup), BN_THREADS / lpp planes per pass -- a [*,576,8,8] layer has 16 vectors per plane
+  const int nv = vec ? (HW >> 2) : HW;
+  int lpp = BN_THREADS;
+  while (lpp > 16 && (lpp >> 1) >= nv) lpp >>= 1;
+  const int ppi = BN_THREADS / lpp, pl = tid / lpp, li = tid - pl * lpp;
+  auto one = [&](float xv, float gv) {
+    if (MODE == 0) { const float d = xv - k; p0 += d; p1 = fmaf(d, d, p1); }
+    else {
+      const float xh = (xv - m) * is;
+      const float dz = gv * bn_act_grad(fmaf(w, xh, bb), act);
+      p0 += dz; p1 = fmaf(dz, xh, p1);
+    }
+  };
+  for (int b = s + pl * S; b < B; b += S * ppi) {
     const size_t base = ((size_t)b * C + c) * HW;
-    auto one = [&](float xv, float gv) {
-      if (MODE == 0) { const float d = xv - k; p0 += d; p1 = fmaf(d, d, p1); }
-      else {
-        const float xh = (xv - m) * is;
-        const float dz = gv * bn_act_grad(fmaf(w, xh, bb), act);
-        p0 += dz; p1 = fmaf(dz, xh, p1);
-      }
-    };
     if (vec) {
       const float4* x4 = reinterpret_cast<const float4*>(x + base);
       const float4* g4 = MODE == 1 ? reinterpret_cast<const float4*>(dy + base) : nullptr;
-      for (int i = tid; i < (HW >> 2); i += BN_THREADS) {
+      for (int i = li; i < nv; i += lpp) {
         const float4 a = x4[i];
         float4 g = {0.f, 0.f, 0.f, 0.f};
         if (MODE == 1) g = g4[i];
         one(a.x, g.x); one(a.y, g.y); one(a.z, g.z); one(a.w, g.w);
       }
     } else {
-      for (int i = tid; i < HW; i += BN_THREADS) one(x[base + i], MODE == 1 ? dy[base + i] : 0.0f);
+      for (int i = li; i < HW; i += lpp) one(x[base + i], MODE == 1 ? dy[base + i] : 0.0f);
     }
   }
   double d0 = (double)p0, d1 = (double)p1;
