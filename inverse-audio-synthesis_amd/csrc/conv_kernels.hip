@@ -83,16 +83,31 @@ __global__ __launch_bounds__(CV_THREADS) void dw_tile_kernel(const float* __rest
   for (int r0 = 0; r0 < Ho; r0 += rows_out) {
     const int nr = min(rows_out, Ho - r0);
     __syncthreads();                                   // the previous tile has been consumed
-    // staging: 32 lanes walk a row (one index division per row, none per element), 8 rows at a time
-    for (int pr = tid >> 5; pr < npl * rows_in; pr += CV_THREADS / 32) {
-      const int pl = pr / rows_in, r = pr - pl * rows_in;
-      const int hi = r0 * S - P + r;
-      const bool rok = hi >= 0 && hi < H;
-      const float* xr = x + ((size_t)(p0 + pl) * H + (rok ? hi : 0)) * W;
-      float* sr = s_x + pr * Wp;
-      for (int col = tid & 31; col < Wp; col += 32) {
-        const int wi = col - P;
-        sr[col] = (rok && wi >= 0 && wi < W) ? xr[wi] : 0.0f;
+    // staging: the tile as one flat index space, four loads in flight per thread (walking it row by row, one load
+    // per thread and pass, left the workgroup waiting out ten memory latencies on a 15 x 16 plane)
+    // Wide rows keep the row walk (32 lanes per row: several loads per lane and row, no index division per element).
+    if (Wp <= 48) {
+      const int stage_n = npl * rows_in * Wp;
+#pragma unroll 4
+      for (int idx = tid; idx < stage_n; idx += CV_THREADS) {
+        const int pr = idx / Wp, col = idx - pr * Wp;
+        const int pl = pr / rows_in, r = pr - pl * rows_in;
+        const int hi = r0 * S - P + r, wi = col - P;
+        const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+        s_x[idx] = ok ? x[((size_t)(p0 + pl) * H + hi) * W + wi] : 0.0f;
+      }
+    } else {
+      for (int pr = tid >> 5; pr < npl * rows_in; pr += CV_THREADS / 32) {
+        const int pl = pr / rows_in, r = pr - pl * rows_in;
+        const int hi = r0 * S - P + r;
+        const bool rok = hi >= 0 && hi < H;
+        const float* xr = x + ((size_t)(p0 + pl) * H + (rok ? hi : 0)) * W;
+        float* sr = s_x + pr * Wp;
+#pragma unroll 4
+        for (int col = tid & 31; col < Wp; col += 32) {
+          const int wi = col - P;
+          sr[col] = (rok && wi >= 0 && wi < W) ? xr[wi] : 0.0f;
+        }
       }
     }
     __syncthreads();
@@ -168,12 +183,13 @@ __global__ __launch_bounds__(CV_THREADS) void dw_tile_bwd_s2_kernel(const float*
   const int p0 = blockIdx.x * pp, npl = min(pp, planes - p0);
   const int tpp = CV_THREADS / pp, slot = tid / tpp, tl = tid - slot * tpp;
   for (int i = tid; i < npl * KK; i += CV_THREADS) s_w[i] = w[((p0 + i / KK) % C) * KK + i % KK];
-  for (int pr = tid >> 5; pr < npl * rows; pr += CV_THREADS / 32) {
-    const int pl = pr / rows, r = pr - pl * rows, ho = r - 1;
-    const bool rok = ho >= 0 && ho < Ho;
-    const float* gr = g + ((size_t)(p0 + pl) * Ho + (rok ? ho : 0)) * Wo;
-    float* sr = s_g + pr * Wp;
-    for (int col = tid & 31; col < Wp; col += 32) sr[col] = (rok && col >= 1 && col <= Wo) ? gr[col - 1] : 0.0f;
+  const int stage_n = npl * rows * Wp;
+#pragma unroll 4
+  for (int idx = tid; idx < stage_n; idx += CV_THREADS) {
+    const int pr = idx / Wp, col = idx - pr * Wp;
+    const int pl = pr / rows, ho = pr - pl * rows - 1;
+    const bool ok = ho >= 0 && ho < Ho && col >= 1 && col <= Wo;
+    s_g[idx] = ok ? g[((size_t)(p0 + pl) * Ho + ho) * Wo + col - 1] : 0.0f;
   }
   __syncthreads();
   if (slot >= npl) return;
