@@ -103,7 +103,6 @@ __global__ __launch_bounds__(CV_THREADS) void dw_tile_kernel(const float* __rest
         const bool rok = hi >= 0 && hi < H;
         const float* xr = x + ((size_t)(p0 + pl) * H + (rok ? hi : 0)) * W;
         float* sr = s_x + pr * Wp;
-#pragma unroll 4
         for (int col = tid & 31; col < Wp; col += 32) {
           const int wi = col - P;
           sr[col] = (rok && wi >= 0 && wi < W) ? xr[wi] : 0.0f;
