@@ -647,7 +647,9 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("voice_audio_kernel", {}).get("hbm_bytes_per_launch")
+            table = json.load(open(tpath))      # keys are rocprofv3 kernel names: "void voice_audio_kernel<0, true>"
+            hits = [v for k, v in table.items() if "voice_audio_kernel" in k and isinstance(v, dict)]
+            traffic = hits[0].get("hbm_bytes_per_launch") if hits else None
         except Exception:  # noqa: BLE001
             traffic = None
 
