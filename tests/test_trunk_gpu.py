@@ -172,7 +172,8 @@ def test_squeeze_excitation_matches_torch(lib, dev, B, C, Cs, H, W):
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(3, 16, 16, 60, 62), (2, 16, 72, 60, 62), (4, 72, 24, 30, 31), (4, 24, 88, 30, 31),
                                             (5, 240, 40, 15, 16), (5, 40, 240, 15, 16), (3, 48, 288, 15, 16), (2, 288, 96, 8, 8),
-                                            (7, 8, 12, 3, 3), (2, 96, 576, 8, 8), (130, 24, 96, 5, 7)])
+                                            (7, 8, 12, 3, 3), (2, 96, 576, 8, 8), (130, 24, 96, 5, 7), (3, 576, 96, 8, 8),
+                                            (2, 1028, 16, 4, 4), (2, 6, 10, 4, 4)])     # the last two: batched-GEMM form
 def test_pointwise_conv_matches_torch(lib, dev, B, Cin, Cout, H, W):
     """PointwiseConv2d (csrc/pointwise_kernels.hip where ias_pwconv_supported, the batched GEMM otherwise) against
     F.conv2d in fp64: output, input gradient, weight gradient; the weight gradient twice (fixed-order reduction)."""
