@@ -93,9 +93,7 @@ class VICReg(nn.Module):
         self.gather_distributed = gather_distributed
 
     def forward(self, audio, params):
-        x = self.projector(self.backbone_audio(audio))
-        y = self.projector(self.backbone_param(params))
-        return x, y
+        return project_pair(self.projector, self.backbone_audio(audio), self.backbone_param(params))
 
     def loss(self, x, y):
         assert x.shape[1] == self.embeddim
@@ -115,6 +113,25 @@ def Projector(cfg, reprdim):
         layers += [nn.Linear(fan_in, fan_out), nn.BatchNorm1d(fan_out), nn.ReLU(True)]
     layers.append(nn.Linear(widths[-2], widths[-1], bias=False))
     return nn.Sequential(*layers)
+
+
+def project_pair(projector, a, b):
+    """``projector(a), projector(b)`` (reference vicreg.py:27-30: the shared projector applied to both branches) with
+    every Linear run ONCE on the concatenated rows and every BatchNorm1d on each branch alone, in the order a, b -- the
+    same statistics, running-stat updates and outputs as two calls.  At embeddim 8192 the two calls cost two weight
+    gradients per layer (each a 268 MB write) plus the add that accumulates them; the pair form costs one."""
+    mods = list(projector) if isinstance(projector, nn.Sequential) else None
+    if mods is None or a.shape != b.shape or a.dim() != 2 or not all(
+            isinstance(m, (nn.Linear, nn.modules.batchnorm._BatchNorm, nn.ReLU)) for m in mods):
+        return projector(a), projector(b)
+    n = a.shape[0]
+    t = torch.cat([a, b], 0)
+    for m in mods:
+        if isinstance(m, nn.modules.batchnorm._BatchNorm):
+            t = torch.cat([m(t[:n]), m(t[n:])], 0)
+        else:
+            t = m(t)
+    return t[:n], t[n:]
 
 
 def off_diagonal(x):
