@@ -246,6 +246,14 @@ int ias_pwconv_backward_weight(const float* g, const float* x, float* gw, float*
 int ias_se_plane_reduce(const float* a, const float* b, float* out, long long planes, int hw, float scale, void* stream);
 int ias_se_scale(const float* x, const float* s, const float* add, float* y, long long planes, int hw, float add_scale,
                  void* stream);
+/* the block's two 1x1 convolutions on the pooled [B,C]: h = relu(pooled w1^T + b1) [B,Cs], z = h w2^T + b2 [B,C],
+ * s = hardsigmoid(z); w1 [Cs,C], w2 [C,Cs]; b1 / b2 may be NULL.  Backward from gs = dL/ds: gp = dL/dpooled and the four
+ * parameter gradients (gb1 / gb2 may be NULL); gz [B,C], gh [B,Cs] are scratch.  Sums in a fixed order. */
+int ias_se_mlp_forward(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* h,
+                       float* z, float* s, int B, int C, int Cs, void* stream);
+int ias_se_mlp_backward(const float* gs, const float* z, const float* h, const float* pooled, const float* w1,
+                        const float* w2, float* gz, float* gh, float* gp, float* gw1, float* gb1, float* gw2, float* gb2,
+                        int B, int C, int Cs, void* stream);
 
 /* head Conv2d(C, Cout, kernel_size=2) of AudioEmbedding (/root/reference/audioembed.py:15-33, 62-68) as one GEMM on
  * channels-last maps: patches [B (H-1) (W-1)][4 C] (columns ordered (c, di, dj), i.e. weight.view(Cout, 4 C) is the

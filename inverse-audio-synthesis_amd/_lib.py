@@ -75,6 +75,8 @@ SYMBOLS = {
     "ias_pwconv_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_se_plane_reduce": (_I, [_P, _P, _P, _LL, _I, _F, _P]),
     "ias_se_scale": (_I, [_P, _P, _P, _P, _LL, _I, _F, _P]),
+    "ias_se_mlp_forward": (_I, [_P] * 8 + [_I, _I, _I, _P]),
+    "ias_se_mlp_backward": (_I, [_P] * 13 + [_I, _I, _I, _P]),
     "ias_conv2x2_patches": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ias_conv2x2_patches_backward": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ias_stem_forward": (_I, [_P, _P, _P, _I, _I, _I, _P]),

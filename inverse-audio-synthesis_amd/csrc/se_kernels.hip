@@ -98,3 +98,159 @@ extern "C" int ias_se_scale(const float* x, const float* s, const float* add, fl
   else hipLaunchKernelGGL((se_scale_kernel<1>), dim3((unsigned)g), dim3(SE_THREADS), 0, st, x, s, add, y, total, hw, add_scale);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
+
+// ---- the block's two 1x1 convolutions on [B, C]: fc1 (C -> Cs) + ReLU, fc2 (Cs -> C) + Hardsigmoid ----------------
+// At batch 128 these are GEMMs of 10 MFLOP; as rocBLAS calls they cost 15-50 us each (six per block and step, 0.8 ms
+// of a training step).  Here one workgroup per sample runs both layers out of LDS (forward), or the three
+// matrix-vector products of their backward; the four parameter gradients, sums over the batch of outer products, are
+// small LDS-tiled products.  All sums in a fixed order.
+#define SEM_THREADS 256
+
+// acc + sum_i row[i] v[i] with four running sums (row in global memory, v in LDS), n % 4 == 0 and row 16-byte aligned
+// for the vector form
+__device__ __forceinline__ float sem_dot(const float* __restrict__ row, const float* __restrict__ v, int n, float acc, bool vec) {
+  float a0 = acc, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  if (vec) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* r4 = reinterpret_cast<const f4*>(row);
+    for (int i = 0; i < (n >> 2); ++i) {
+      const f4 w = r4[i];
+      a0 = fmaf(w[0], v[4 * i], a0); a1 = fmaf(w[1], v[4 * i + 1], a1);
+      a2 = fmaf(w[2], v[4 * i + 2], a2); a3 = fmaf(w[3], v[4 * i + 3], a3);
+    }
+  } else {
+    for (int i = 0; i < n; ++i) a0 = fmaf(row[i], v[i], a0);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+__global__ __launch_bounds__(SEM_THREADS) void se_mlp_forward_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                                     const float* __restrict__ b1, const float* __restrict__ w2,
+                                                                     const float* __restrict__ b2, float* __restrict__ h,
+                                                                     float* __restrict__ z, float* __restrict__ s, int C, int Cs,
+                                                                     int vec1, int vec2) {
+  extern __shared__ __attribute__((aligned(16))) float sem_lds[];
+  float* s_p = sem_lds;            // [C]
+  float* s_h = sem_lds + C;        // [Cs]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < C; i += SEM_THREADS) s_p[i] = pooled[(size_t)b * C + i];
+  __syncthreads();
+  for (int o = tid; o < Cs; o += SEM_THREADS) {
+    const float v = fmaxf(sem_dot(w1 + (size_t)o * C, s_p, C, b1 ? b1[o] : 0.0f, vec1 != 0), 0.0f);
+    s_h[o] = v;
+    h[(size_t)b * Cs + o] = v;
+  }
+  __syncthreads();
+  for (int o = tid; o < C; o += SEM_THREADS) {
+    const float v = sem_dot(w2 + (size_t)o * Cs, s_h, Cs, b2 ? b2[o] : 0.0f, vec2 != 0);
+    z[(size_t)b * C + o] = v;
+    s[(size_t)b * C + o] = fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f;
+  }
+}
+
+// per sample: gz = gs * hardsigmoid'(z); gh = relu'(h) * W2^T gz; gp = W1^T gh   (lanes along the output index: the
+// rows of W2 / W1 are read coalesced, the vector operand is broadcast from LDS)
+__global__ __launch_bounds__(SEM_THREADS) void se_mlp_backward_sample_kernel(const float* __restrict__ gs, const float* __restrict__ z,
+                                                                             const float* __restrict__ h, const float* __restrict__ w1,
+                                                                             const float* __restrict__ w2, float* __restrict__ gz,
+                                                                             float* __restrict__ gh, float* __restrict__ gp, int C,
+                                                                             int Cs) {
+  extern __shared__ __attribute__((aligned(16))) float sem_lds[];
+  float* s_gz = sem_lds;           // [C]
+  float* s_gh = sem_lds + C;       // [Cs]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < C; c += SEM_THREADS) {
+    const float zz = z[(size_t)b * C + c];
+    const float g = (zz > -3.0f && zz < 3.0f) ? gs[(size_t)b * C + c] * (1.0f / 6.0f) : 0.0f;
+    s_gz[c] = g;
+    gz[(size_t)b * C + c] = g;
+  }
+  __syncthreads();
+  for (int j = tid; j < Cs; j += SEM_THREADS) {
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int c = 0;
+    for (; c + 3 < C; c += 4) {
+      a0 = fmaf(s_gz[c], w2[(size_t)c * Cs + j], a0); a1 = fmaf(s_gz[c + 1], w2[(size_t)(c + 1) * Cs + j], a1);
+      a2 = fmaf(s_gz[c + 2], w2[(size_t)(c + 2) * Cs + j], a2); a3 = fmaf(s_gz[c + 3], w2[(size_t)(c + 3) * Cs + j], a3);
+    }
+    for (; c < C; ++c) a0 = fmaf(s_gz[c], w2[(size_t)c * Cs + j], a0);
+    const float g = h[(size_t)b * Cs + j] > 0.0f ? (a0 + a1) + (a2 + a3) : 0.0f;
+    s_gh[j] = g;
+    gh[(size_t)b * Cs + j] = g;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += SEM_THREADS) {
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int j = 0;
+    for (; j + 3 < Cs; j += 4) {
+      a0 = fmaf(s_gh[j], w1[(size_t)j * C + c], a0); a1 = fmaf(s_gh[j + 1], w1[(size_t)(j + 1) * C + c], a1);
+      a2 = fmaf(s_gh[j + 2], w1[(size_t)(j + 2) * C + c], a2); a3 = fmaf(s_gh[j + 3], w1[(size_t)(j + 3) * C + c], a3);
+    }
+    for (; j < Cs; ++j) a0 = fmaf(s_gh[j], w1[(size_t)j * C + c], a0);
+    gp[(size_t)b * C + c] = (a0 + a1) + (a2 + a3);
+  }
+}
+
+// out[r][q] = sum_b a[b][r] m[b][q] (a [B,R], m [B,Q]), colsum[r] = sum_b a[b][r]: 32 x 32 output tiles, the batch in
+// LDS slices of 32, a thread owns a 2 x 2 block
+__global__ __launch_bounds__(SEM_THREADS) void se_outer_sum_kernel(const float* __restrict__ a, const float* __restrict__ m,
+                                                                   float* __restrict__ out, float* __restrict__ colsum, int B,
+                                                                   int R, int Q) {
+  __shared__ float s_a[32][33], s_m[32][33];
+  const int r0 = blockIdx.x * 32, q0 = blockIdx.y * 32, tid = threadIdx.x;
+  const int tr = tid >> 4, tq = tid & 15;
+  float acc[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, cs[2] = {0.0f, 0.0f};
+  for (int b0 = 0; b0 < B; b0 += 32) {
+    __syncthreads();
+    for (int i = tid; i < 1024; i += SEM_THREADS) {
+      const int bb = i >> 5, x = i & 31;
+      s_a[bb][x] = (b0 + bb < B && r0 + x < R) ? a[(size_t)(b0 + bb) * R + r0 + x] : 0.0f;
+      s_m[bb][x] = (b0 + bb < B && q0 + x < Q) ? m[(size_t)(b0 + bb) * Q + q0 + x] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int bb = 0; bb < 32; ++bb) {
+      const float a0 = s_a[bb][2 * tr], a1 = s_a[bb][2 * tr + 1], m0 = s_m[bb][2 * tq], m1 = s_m[bb][2 * tq + 1];
+      acc[0][0] = fmaf(a0, m0, acc[0][0]); acc[0][1] = fmaf(a0, m1, acc[0][1]);
+      acc[1][0] = fmaf(a1, m0, acc[1][0]); acc[1][1] = fmaf(a1, m1, acc[1][1]);
+      cs[0] += a0; cs[1] += a1;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = r0 + 2 * tr + i;
+    if (r >= R) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q = q0 + 2 * tq + j;
+      if (q < Q) out[(size_t)r * Q + q] = acc[i][j];
+    }
+    if (colsum && blockIdx.y == 0 && tq == 0) colsum[r] = cs[i];
+  }
+}
+
+// h = relu(pooled W1^T + b1) [B,Cs], z = h W2^T + b2 [B,C], s = hardsigmoid(z); pooled [B,C], w1 [Cs,C], w2 [C,Cs]
+extern "C" int ias_se_mlp_forward(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
+                                  float* h, float* z, float* s, int B, int C, int Cs, void* stream_) {
+  if (!pooled || !w1 || !w2 || !h || !z || !s || B <= 0 || C <= 0 || Cs <= 0 || C + Cs > 12288) return IAS_ERR_ARG;
+  const int vec1 = ((C & 3) == 0 && se_aligned16(w1)) ? 1 : 0, vec2 = ((Cs & 3) == 0 && se_aligned16(w2)) ? 1 : 0;
+  hipLaunchKernelGGL(se_mlp_forward_kernel, dim3(B), dim3(SEM_THREADS), sizeof(float) * (size_t)(C + Cs), (hipStream_t)stream_,
+                     pooled, w1, b1, w2, b2, h, z, s, C, Cs, vec1, vec2);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+// its backward from gs = d loss / d s: gp = d loss / d pooled [B,C], gw1 [Cs,C], gb1 [Cs], gw2 [C,Cs], gb2 [C];
+// gz [B,C] and gh [B,Cs] are caller-owned scratch
+extern "C" int ias_se_mlp_backward(const float* gs, const float* z, const float* h, const float* pooled, const float* w1,
+                                   const float* w2, float* gz, float* gh, float* gp, float* gw1, float* gb1, float* gw2,
+                                   float* gb2, int B, int C, int Cs, void* stream_) {
+  if (!gs || !z || !h || !pooled || !w1 || !w2 || !gz || !gh || !gp || !gw1 || !gw2 || B <= 0 || C <= 0 || Cs <= 0 ||
+      C + Cs > 12288)
+    return IAS_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream_;
+  hipLaunchKernelGGL(se_mlp_backward_sample_kernel, dim3(B), dim3(SEM_THREADS), sizeof(float) * (size_t)(C + Cs), st, gs, z, h,
+                     w1, w2, gz, gh, gp, C, Cs);
+  hipLaunchKernelGGL(se_outer_sum_kernel, dim3((C + 31) / 32, (Cs + 31) / 32), dim3(SEM_THREADS), 0, st, gz, h, gw2, gb2, B, C, Cs);
+  hipLaunchKernelGGL(se_outer_sum_kernel, dim3((Cs + 31) / 32, (C + 31) / 32), dim3(SEM_THREADS), 0, st, gh, pooled, gw1, gb1, B, Cs, C);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}

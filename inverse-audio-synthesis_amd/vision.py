@@ -291,9 +291,9 @@ class ConvBNAct(nn.Sequential):
 
 
 class _SEFn(torch.autograd.Function):
-    """y = x * hardsigmoid(fc2(relu(fc1(mean_hw x)))) with the passes over x in csrc/se_kernels.hip (pool, scale, and in
-    backward the per-plane <gy, x> and gx = gy s + gpool / HW in one pass each) and the two 1x1 convolutions as GEMMs on
-    [B, C]."""
+    """y = x * hardsigmoid(fc2(relu(fc1(mean_hw x)))), all of it in csrc/se_kernels.hip: the passes over x (pool, scale,
+    and in backward the per-plane <gy, x> and gx = gy s + gpool / HW, one pass each) and the two 1x1 convolutions on
+    [B, C] with their backward (one workgroup per sample; parameter gradients as small tiled products over the batch)."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
@@ -303,13 +303,15 @@ class _SEFn(torch.autograd.Function):
         _lib.require_f32(x, w1, b1, w2, b2)
         B, C, H, W = x.shape
         hw = H * W
-        w1m, w2m = w1.view(w1.shape[0], C), w2.view(C, w1.shape[0])
+        Cs = w1.shape[0]
+        w1, w2 = w1.contiguous(), w2.contiguous()
         pooled = torch.empty((B, C), dtype=torch.float32, device=x.device)
         _lib.check(lib.ias_se_plane_reduce(_lib.ptr(x), None, _lib.ptr(pooled), B * C, hw, 1.0 / hw, _lib.stream()),
                    "ias_se_plane_reduce")
-        h = torch.relu_(torch.addmm(b1, pooled, w1m.t()))
-        z = torch.addmm(b2, h, w2m.t())
-        s = F.hardsigmoid(z)
+        h = torch.empty((B, Cs), dtype=torch.float32, device=x.device)
+        z, s = torch.empty_like(pooled), torch.empty_like(pooled)
+        _lib.check(lib.ias_se_mlp_forward(_lib.ptr(pooled), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(h),
+                                          _lib.ptr(z), _lib.ptr(s), B, C, Cs, _lib.stream()), "ias_se_mlp_forward")
         y = torch.empty_like(x)
         _lib.check(lib.ias_se_scale(_lib.ptr(x), _lib.ptr(s), None, _lib.ptr(y), B * C, hw, 0.0, _lib.stream()), "ias_se_scale")
         ctx.save_for_backward(x, pooled, h, z, s, w1, w2)
@@ -323,21 +325,22 @@ class _SEFn(torch.autograd.Function):
         gy = gy.contiguous()
         B, C, H, W = x.shape
         hw = H * W
-        w1m, w2m = w1.view(w1.shape[0], C), w2.view(C, w1.shape[0])
+        Cs = w1.shape[0]
         gs = torch.empty((B, C), dtype=torch.float32, device=x.device)
         _lib.check(lib.ias_se_plane_reduce(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(gs), B * C, hw, 1.0, _lib.stream()),
                    "ias_se_plane_reduce")
-        gz = torch.ops.aten.hardsigmoid_backward(gs, z)
-        gw2 = torch.mm(gz.t(), h)
-        gb2 = gz.sum(0)
-        gh = torch.ops.aten.threshold_backward(torch.mm(gz, w2m), h, 0.0)
-        gw1 = torch.mm(gh.t(), pooled)
-        gb1 = gh.sum(0)
-        gp = torch.mm(gh, w1m)
+        gz, gp = torch.empty_like(gs), torch.empty_like(gs)
+        gh = torch.empty((B, Cs), dtype=torch.float32, device=x.device)
+        gw1, gw2 = torch.empty_like(w1), torch.empty_like(w2)
+        gb1 = torch.empty(Cs, dtype=torch.float32, device=x.device)
+        gb2 = torch.empty(C, dtype=torch.float32, device=x.device)
+        _lib.check(lib.ias_se_mlp_backward(_lib.ptr(gs), _lib.ptr(z), _lib.ptr(h), _lib.ptr(pooled), _lib.ptr(w1), _lib.ptr(w2),
+                                           _lib.ptr(gz), _lib.ptr(gh), _lib.ptr(gp), _lib.ptr(gw1), _lib.ptr(gb1), _lib.ptr(gw2),
+                                           _lib.ptr(gb2), B, C, Cs, _lib.stream()), "ias_se_mlp_backward")
         gx = torch.empty_like(x)
         _lib.check(lib.ias_se_scale(_lib.ptr(gy), _lib.ptr(s), _lib.ptr(gp), _lib.ptr(gx), B * C, hw, 1.0 / hw, _lib.stream()),
                    "ias_se_scale")
-        return gx, gw1.view_as(w1), gb1, gw2.view_as(w2), gb2
+        return gx, gw1, gb1, gw2, gb2
 
 
 class SqueezeExcitation(nn.Module):
