@@ -37,5 +37,5 @@ for e in prof.key_averages(group_by_input_shape=True):
     if dt > 0 and e.key.startswith("aten::"):
         rows.append((dt, e.count, e.key, str(e.input_shapes)[:110]))
 rows.sort(reverse=True)
-for dt, cnt, key, shp in rows[:45]:
+for dt, cnt, key, shp in rows[:int(os.environ.get('ROWS', 45))]:
     print(f"{dt:9.1f} us  x{cnt:<3d} {key:32s} {shp}")
