@@ -20,6 +20,10 @@ def timed(name, fn, n=20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     print(f"{name:40s} {e0.elapsed_time(e1) / n * 1e3:8.1f} us")
-timed("mel-L1 vs cached target (loss mode)", lambda: mel(a, target_mel=tm))
-timed("mel spectrogram out (128 mels)", lambda: mel.mel.plan.values(a, VALUE_POWER))
-timed("power spectrogram out (513 bins)", lambda: raw.values(a, VALUE_POWER))
+parts = os.environ.get("PARTS", "loss,mel,raw").split(",")      # PARTS=raw: one variant only (for per-variant PMC runs)
+if "loss" in parts:
+    timed("mel-L1 vs cached target (loss mode)", lambda: mel(a, target_mel=tm))
+if "mel" in parts:
+    timed("mel spectrogram out (128 mels)", lambda: mel.mel.plan.values(a, VALUE_POWER))
+if "raw" in parts:
+    timed("power spectrogram out (513 bins)", lambda: raw.values(a, VALUE_POWER))
