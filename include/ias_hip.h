@@ -148,8 +148,17 @@ long long ias_stft_partials_count(int B, int T, int n_fft, int hop);
 int ias_stft_tables_len(int n_fft);
 int ias_stft_build_tables(int n_fft, const float* window_host, float* out_host);
 
+/* HOST helpers of the matrix-core STFT kernel (v_mfma_f32_16x16x4_f32; csrc/stft_mfma_kernels.hip): length (floats)
+ * and contents of its constant block: per-lane window, DFT-matrix operands and twiddles, and -- when the host copies
+ * of the packed mel filterbank (mel_start / mel_count / mel_woff [n_out], mel_w) are given -- the filterbank re-cut
+ * into banded 16-output tiles in A-operand order with a per-wave tile list.  NULL mel_* = linear bins. */
+long long ias_stft_mtables_len(int n_fft, const int* mel_start_host, const int* mel_count_host, int n_out);
+int ias_stft_build_mtables(int n_fft, const float* window_host, const int* mel_start_host, const int* mel_count_host,
+                           const int* mel_woff_host, const float* mel_w_host, int n_out, float* out_host);
+
 /* Framed STFT of audio [B,T] (center=True, reflect padding, one-sided); tables = device copy of the
- * ias_stft_build_tables block.  Per-bin value by value_mode: 1 |X|, 2 |X|^2, 3 sqrt(max(|X|^2, eps)).
+ * ias_stft_build_tables block, mtables = device copy of the ias_stft_build_mtables block (built with the same
+ * filterbank as mel_*; required for the sizes the matrix-core kernel serves: n_fft 1024).  Per-bin value by value_mode: 1 |X|, 2 |X|^2, 3 sqrt(max(|X|^2, eps)).
  * Optional mel projection as packed triangular filters (mel_start/mel_count/mel_woff [n_out],
  * mel_w [mel_nnz]); with NULL mel_* n_out must be n_fft/2+1.
  * out [B,F,n_out] (frames-major) or NULL; target [B,F,n_out] + partials required when
@@ -157,8 +166,8 @@ int ias_stft_build_tables(int n_fft, const float* window_host, float* out_host);
  * rowpeak [B] or NULL: row peaks of audio; the spectrum is that of audio[b] / rowpeak[b] where rowpeak[b] > 1
  * (normalize_if_clipping folded in: |X|^2 scales by 1 / peak^2).
  * n_fft in {512, 1024, 2048}. */
-int ias_stft(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
-             const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
+int ias_stft(const float* audio, const float* tables, const float* mtables, const int* mel_start,
+             const int* mel_count, const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
              double* partials, const float* rowpeak, int B, int T, int n_fft, int hop, int n_out, int value_mode,
              int loss_mode, float eps, void* stream);
 

@@ -794,9 +794,17 @@ static int stft_grid_x(int B, int F, int n_fft, int hop) {
   return (F + g - 1) / g;
 }
 
+// the matrix-core form (csrc/stft_mfma_kernels.hip)
+bool ias_sm_enabled(int n_fft);
+int ias_sm_grid(long long nframes);
+int ias_sm_launch(const float* audio, const float* mtab, bool mel, float* out, const float* target, double* partials,
+                  const float* rowpeak, int B, int T, int F, int n_fft, int hop, int n_out, int value_mode, int loss_mode,
+                  float eps, hipStream_t stream);
+
 extern "C" long long ias_stft_partials_count(int B, int T, int n_fft, int hop) {
   const int F = ias_stft_num_frames(T, n_fft, hop);
   if (F < 0 || B <= 0) return IAS_ERR_ARG;
+  if (ias_sm_enabled(n_fft)) return ias_sm_grid((long long)B * F);
   return (long long)B * stft_grid_x(B, F, n_fft, hop);
 }
 
@@ -844,8 +852,9 @@ extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float*
   return IAS_OK;
 }
 
-// Framed STFT of audio [B,T] (center=True, reflect pad); window and twiddles come as the device copy of
-// the ias_stft_build_tables block.  Per-bin value by value_mode (1 |X|, 2 |X|^2, 3 sqrt(max(|X|^2, eps))),
+// Framed STFT of audio [B,T] (center=True, reflect pad); window and twiddles come as the device copies of
+// the ias_stft_build_tables block (VALU kernel) and the ias_stft_build_mtables block (matrix-core kernel, which
+// takes its mel filterbank from that block too).  Per-bin value by value_mode (1 |X|, 2 |X|^2, 3 sqrt(max(|X|^2, eps))),
 // optional mel projection given as packed filters (mel_start/count/woff [n_out], mel_w [mel_nnz]);
 // n_out = n_mels, or n_fft/2+1 when mel_* are NULL.
 //   out      [B,F,n_out] or NULL : the spectrogram (frames-major layout)
@@ -853,7 +862,7 @@ extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float*
 //   partials [ias_stft_partials_count][3] doubles, required when loss_mode != 0
 //   rowpeak  [B] or NULL : row peaks max |audio| (ias_voice_render's workspace): the spectrum of the row normalised as
 //                          torchsynth's normalize_if_clipping would, without the normalised audio ever being written
-extern "C" int ias_stft(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
+extern "C" int ias_stft(const float* audio, const float* tables, const float* mtables, const int* mel_start, const int* mel_count,
                         const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
                         double* partials, const float* rowpeak, int B, int T, int n_fft, int hop, int n_out,
                         int value_mode, int loss_mode, float eps, void* stream_) {
@@ -868,6 +877,11 @@ extern "C" int ias_stft(const float* audio, const float* tables, const int* mel_
   const int F = ias_stft_num_frames(T, n_fft, hop);
   if (F < 0) return IAS_ERR_ARG;
   if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return IAS_ERR_UNSUPPORTED;
+  if (ias_sm_enabled(n_fft)) {
+    if (!mtables) return IAS_ERR_ARG;
+    return ias_sm_launch(audio, mtables, mel, out, target, partials, rowpeak, B, T, F, n_fft, hop, n_out, value_mode,
+                         loss_mode, eps, stream);
+  }
 
   SpecArgs a;
   a.audio = audio; a.tables = tables;

@@ -90,6 +90,18 @@ class STFTPlan(nn.Module):
             self.n_out = n_mels
         else:
             self.n_out = n_fft // 2 + 1
+        # constant block of the matrix-core kernel (per-lane DFT operands / twiddles, mel filterbank as banded tiles)
+        if n_mels is not None:
+            mel_host = [self.mel_start, self.mel_count, self.mel_woff, self.mel_w]
+            mel_args = [ctypes.c_void_p(t.data_ptr()) for t in mel_host] + [n_mels]
+        else:
+            mel_args = [None, None, None, None, 0]
+        n_mtab = lib.ias_stft_mtables_len(n_fft, mel_args[0], mel_args[1], mel_args[4])
+        _lib.check(min(n_mtab, 0), "ias_stft_mtables_len")
+        mtables = torch.empty(n_mtab, dtype=torch.float32)
+        _lib.check(lib.ias_stft_build_mtables(n_fft, ctypes.c_void_p(wc.data_ptr()), *mel_args,
+                                              ctypes.c_void_p(mtables.data_ptr())), "ias_stft_build_mtables")
+        self.register_buffer("mtables", mtables, persistent=False)
 
     def num_frames(self, T):
         F = _lib.load().ias_stft_num_frames(T, self.n_fft, self.hop_length)
@@ -100,7 +112,7 @@ class STFTPlan(nn.Module):
         lib = _lib.load()
         B, T = audio.shape
         mel = self.n_mels is not None
-        st = lib.ias_stft(_lib.ptr(audio), _lib.ptr(self.tables),
+        st = lib.ias_stft(_lib.ptr(audio), _lib.ptr(self.tables), _lib.ptr(self.mtables),
                           _lib.ptr(self.mel_start) if mel else None, _lib.ptr(self.mel_count) if mel else None,
                           _lib.ptr(self.mel_woff) if mel else None, _lib.ptr(self.mel_w) if mel else None,
                           int(self.mel_w.numel()) if mel else 0, _lib.ptr(out), _lib.ptr(target), _lib.ptr(partials),

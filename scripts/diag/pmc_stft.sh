@@ -1,5 +1,6 @@
 #!/bin/bash
-# SQ counters of the PQMF analysis kernel alone (scripts/diag/time_stft_parts.py).  usage: bash scripts/diag/pmc_pqmf.sh <tag> [ENV=.. ...]
+# SQ counters of the STFT kernel alone (scripts/diag/time_stft_parts.py; PARTS=loss|mel|raw selects one variant).
+# usage: bash scripts/diag/pmc_stft.sh <tag> [ENV=.. ...]
 tag=${1:-x}; shift
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmcs_$tag
@@ -20,7 +21,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$O/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0][:60]
-        if "stft_kernel" in k:
+        if "stft_kernel" in k or "stft_mfma_kernel" in k:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(agg):
     print(k)

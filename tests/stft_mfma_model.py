@@ -1,0 +1,180 @@
+"""Lane-level numpy model of csrc/stft_mfma_kernels.hip (test infrastructure, never imported by the product).
+
+It executes the kernel's data flow with 64 "lanes" and an emulated v_mfma_f32_16x16x4_f32 on the constant block that
+``ias_stft_build_mtables`` (the product's host-side C builder) produces, so the CPU suite pins the builder and the index
+algebra of the kernel (operand lane maps, permuted k-order of the chained MFMAs, twiddles, Hermitian unpack, banded mel
+tiles) against ``numpy.fft.rfft`` without a GPU.
+"""
+import ctypes
+
+import numpy as np
+
+LANES = np.arange(64)
+LO, G = LANES & 15, LANES >> 4
+
+
+def mfma16x16x4(a, b, c):
+    """a, b: [64] operands (A[l&15][l>>4], B[l>>4][l&15]); c: [64,4] (col l&15, row 4 (l>>4) + reg) -> d [64,4]"""
+    A = np.zeros((16, 4), np.float64)
+    B = np.zeros((4, 16), np.float64)
+    A[LO, G] = a
+    B[G, LO] = b
+    D = A @ B
+    d = c.copy()
+    for r in range(4):
+        d[:, r] += D[4 * G + r, LO]
+    return d
+
+
+def layout(n_fft):
+    N2 = n_fft // 2
+    Q = N2 // 16
+    L = dict(n_fft=n_fft, N2=N2, Q=Q, NT=Q // 16, NB=Q // 8, VPL=Q // 2, NPAIR_IT=N2 // 128)
+    e = 0
+    for name, n in (("win", L["VPL"]), ("b1", 8), ("tw1", L["NT"] * 8), ("a2", 4), ("tw2", (L["NB"] - 1) * 4),
+                    ("unp", L["NPAIR_IT"] * 2)):
+        L["e_" + name] = e
+        e += n
+    L["n_entries"] = e
+    bins = N2 + 1
+    L["pstr"] = ((bins - 8 + 63) // 64) * 64 + 8
+    L["off_desc"] = 64 * e
+    L["off_mela"] = L["off_desc"] + 4 * (1 + 4 * 16)
+    return L
+
+
+def build_mtables(lib, n_fft, window, mel=None):
+    """mel: None or (start, count, woff, w, n_out) numpy arrays (int32 / float32)"""
+    window = np.ascontiguousarray(window, np.float32)
+    P = ctypes.c_void_p
+    if mel is None:
+        args = (None, None, None, None, 0)
+    else:
+        s, c, o, w, n_out = mel
+        args = (P(s.ctypes.data), P(c.ctypes.data), P(o.ctypes.data), P(w.ctypes.data), int(n_out))
+    n = lib.ias_stft_mtables_len(n_fft, args[0], args[1], args[4])
+    assert n > 0, n
+    out = np.zeros(n, np.float32)
+    st = lib.ias_stft_build_mtables(n_fft, P(window.ctypes.data), args[0], args[1], args[2], args[3], args[4],
+                                    P(out.ctypes.data))
+    assert st == 0, st
+    return out
+
+
+def n2_of(Q, t, row):
+    if Q == 16:
+        return row
+    h, e = t >> 1, t & 1
+    return 2 * (row + 16 * h) + e
+
+
+def frame_power(tab, n_fft, frame):
+    """frame: [n_fft] float samples (un-windowed) -> power [n_fft/2 + 1], through the kernel's lane-level data flow"""
+    L = layout(n_fft)
+    Q, N2, NT, NB = L["Q"], L["N2"], L["NT"], L["NB"]
+    E = lambda e: tab[64 * e:64 * e + 64].astype(np.float64)
+    # loads, in load order, windowed
+    xv = np.zeros((64, L["VPL"]))
+    for v in range(L["VPL"]):
+        if Q == 16:
+            s, c = v >> 1, v & 1
+            sample = 2 * Q * (4 * s + G) + 2 * LO + c
+        else:
+            nh = Q // 32
+            s, h, e4 = v // (4 * nh), (v // 4) % nh, v & 3
+            sample = 2 * Q * (4 * s + G) + 64 * h + 4 * LO + e4
+        xv[:, v] = frame[sample] * E(L["e_win"] + v)
+
+    def a_elem(s, t, c):    # A value of lane (i, kq) for tile t, k-step (c, s)
+        if Q == 16:
+            return xv[:, 2 * s + c]
+        nh = Q // 32
+        h, e = t >> 1, t & 1
+        return xv[:, (s * nh + h) * 4 + 2 * e + c]
+
+    cosb = [E(L["e_b1"] + s) for s in range(4)]
+    sinb = [E(L["e_b1"] + 4 + s) for s in range(4)]
+    acc1 = np.zeros((NT, 2, 64, 4))
+    for t in range(NT):
+        for s in range(4):
+            acc1[t, 0] = mfma16x16x4(a_elem(s, t, 0), cosb[s], acc1[t, 0])
+            acc1[t, 0] = mfma16x16x4(a_elem(s, t, 1), sinb[s], acc1[t, 0])
+            acc1[t, 1] = mfma16x16x4(a_elem(s, t, 0), -sinb[s], acc1[t, 1])
+            acc1[t, 1] = mfma16x16x4(a_elem(s, t, 1), cosb[s], acc1[t, 1])
+    # twiddle 1
+    sp = np.zeros((NT, 2, 64, 4))
+    for t in range(NT):
+        for r in range(4):
+            c, s_ = E(L["e_tw1"] + 2 * (4 * t + r)), E(L["e_tw1"] + 2 * (4 * t + r) + 1)
+            sr, si = acc1[t, 0][:, r], acc1[t, 1][:, r]
+            sp[t, 0][:, r] = sr * c + si * s_
+            sp[t, 1][:, r] = si * c - sr * s_
+    # stage 2a
+    a2 = [[E(L["e_a2"] + 2 * c + x) for x in range(2)] for c in range(2)]
+    acc2 = np.zeros((NB, 64, 4))
+    for b in range(NB):
+        for c in range(2):
+            for x in range(2):
+                if Q == 16:
+                    t, r = 0, 2 * x + b
+                elif Q == 32:
+                    t, r = b & 1, 2 * x + (b >> 1)
+                else:
+                    t, r = 2 * x + (b & 1), b >> 1
+                acc2[b] = mfma16x16x4(a2[c][x], sp[t, c][:, r], acc2[b])
+    # twiddle 2 + radix NB;  acc2[b][:, 2 kl + c']
+    Z = np.zeros(N2, np.complex128)
+    for kl in range(2):
+        tv = []
+        for b in range(NB):
+            tr, ti = acc2[b][:, 2 * kl], acc2[b][:, 2 * kl + 1]
+            if b > 0:
+                c, s_ = E(L["e_tw2"] + 2 * (2 * (b - 1) + kl)), E(L["e_tw2"] + 2 * (2 * (b - 1) + kl) + 1)
+                tr, ti = tr * c + ti * s_, ti * c - tr * s_
+            tv.append(tr + 1j * ti)
+        tv = np.stack(tv)                                   # [NB, 64]
+        W = np.exp(-2j * np.pi * np.outer(np.arange(NB), np.arange(NB)) / NB)
+        Y = W @ tv                                          # [kb, 64]
+        for kb in range(NB):
+            Z[LO + 16 * ((2 * G + kl) + 8 * kb)] = Y[kb]
+    # unpack
+    P = np.zeros(N2 + 1)
+    for i in range(L["NPAIR_IT"]):
+        k = 1 + LANES + 64 * i
+        zk, zn = Z[k], Z[N2 - k]
+        wr, wi = E(L["e_unp"] + 2 * i), E(L["e_unp"] + 2 * i + 1)
+        a, b = zk.real + zn.real, zk.imag - zn.imag
+        d, s_ = zk.real - zn.real, zk.imag + zn.imag
+        tx = wr * s_ + wi * d
+        ty = wi * s_ - wr * d
+        P[k] = 0.25 * ((a + tx) ** 2 + (b + ty) ** 2)
+        P[N2 - k] = 0.25 * ((a - tx) ** 2 + (b - ty) ** 2)
+    P[0] = (Z[0].real + Z[0].imag) ** 2
+    P[N2] = (Z[0].real - Z[0].imag) ** 2
+    return P
+
+
+def mel_project(tab, n_fft, n_out, Pslots):
+    """Pslots: [16, bins] power values of 16 frames -> [16, n_out] through the tiled descriptors / A table"""
+    L = layout(n_fft)
+    pstr = L["pstr"]
+    sP = np.zeros((16, pstr))
+    sP[:, :Pslots.shape[1]] = Pslots
+    desc = tab[L["off_desc"]:L["off_mela"]].view(np.int32)
+    A = tab[L["off_mela"]:].astype(np.float64)
+    out = np.zeros((16, 16 * ((n_out + 15) // 16)))
+    seen = set()
+    for w in range(4):
+        dw = desc[w * 65:(w + 1) * 65]
+        for n in range(dw[0]):
+            t, kb, nblk, aoff = dw[1 + 4 * n:5 + 4 * n]
+            assert t not in seen
+            seen.add(int(t))
+            acc = np.zeros((64, 4))
+            for q in range(nblk):
+                bq = np.stack([sP[LO, kb + 16 * q + 4 * G + s] for s in range(4)], 1)   # the b128 read of lane (g, j)
+                for s in range(4):
+                    acc = mfma16x16x4(A[256 * (aoff + q) + 64 * s:256 * (aoff + q) + 64 * s + 64], bq[:, s], acc)
+            for r in range(4):
+                out[LO, 16 * t + 4 * G + r] = acc[:, r]
+    return out[:, :n_out], seen

@@ -1,0 +1,58 @@
+"""Host logic of the matrix-core STFT kernel: the product's constant-block builder (``ias_stft_build_mtables``) run
+through a lane-level numpy model of the kernel's data flow (tests/stft_mfma_model.py) against numpy.fft — the index
+algebra of the chained MFMAs is pinned without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+import stft_mfma_model as M
+from inverse_audio_synthesis_amd import _lib
+from inverse_audio_synthesis_amd.spectral import melscale_fbanks
+
+
+def _csr(fb):
+    start, count, woff, w = [], [], [], []
+    for m in range(fb.shape[1]):
+        nz = np.nonzero(fb[:, m])[0]
+        if len(nz) == 0:
+            start.append(0); count.append(0); woff.append(len(w))
+            continue
+        s, e = int(nz[0]), int(nz[-1]) + 1
+        start.append(s); count.append(e - s); woff.append(len(w))
+        w.extend(fb[s:e, m].tolist())
+    return (np.array(start, np.int32), np.array(count, np.int32), np.array(woff, np.int32),
+            np.array(w if w else [0.0], np.float32), fb.shape[1])
+
+
+@pytest.mark.parametrize("n_fft", [512, 1024, 2048])
+def test_lane_model_on_the_built_tables_matches_rfft(n_fft):
+    lib = _lib.load()
+    rng = np.random.default_rng(n_fft)
+    win = torch.hann_window(n_fft).numpy()
+    tab = M.build_mtables(lib, n_fft, win)
+    for trial in range(2):
+        x = rng.standard_normal(n_fft)
+        if trial == 1:
+            x = np.cos(2 * np.pi * 37.25 * np.arange(n_fft) / n_fft) + 0.3     # leakage + DC
+        P = M.frame_power(tab, n_fft, x)
+        ref = np.abs(np.fft.rfft(x * win)) ** 2
+        assert np.abs(P - ref).max() <= 2e-6 * ref.max()
+
+
+@pytest.mark.parametrize("n_fft,n_mels,sr", [(1024, 128, 44100), (512, 40, 16000), (2048, 100, 44100), (1024, 23, 16000)])
+def test_mel_tiles_cover_the_filterbank(n_fft, n_mels, sr):
+    lib = _lib.load()
+    fb = melscale_fbanks(n_fft // 2 + 1, 0.0, sr / 2, n_mels, sr).numpy()
+    tab = M.build_mtables(lib, n_fft, torch.hann_window(n_fft).numpy(), _csr(fb))
+    Ps = np.random.default_rng(1).random((16, n_fft // 2 + 1))
+    out, seen = M.mel_project(tab, n_fft, n_mels, Ps)
+    ref = Ps @ fb
+    assert np.abs(out - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1.0)
+    # every tile that has a non-zero filter is in exactly one wave's list
+    live = {t for t in range((n_mels + 15) // 16) if np.any(fb[:, 16 * t:16 * t + 16])}
+    assert seen == live
+
+
+def test_unsupported_sizes_are_refused():
+    lib = _lib.load()
+    assert lib.ias_stft_mtables_len(768, None, None, 0) == -2
