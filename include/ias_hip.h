@@ -139,8 +139,9 @@ int ias_pqmf_synthesis(const float* z, const float* G, const float* packed, floa
 /* Frames of a center=True STFT: 1 + T / hop (needs T > n_fft/2 for reflect padding). */
 int ias_stft_num_frames(int T, int n_fft, int hop);
 
-/* Number of [3]-double partial records ias_stft writes when loss_mode != 0. */
-long long ias_stft_partials_count(int B, int T, int n_fft, int hop);
+/* Number of [3]-double partial records ias_stft writes when loss_mode != 0; have_mtables != 0: the call will be given
+ * an ias_stft_build_mtables block (the matrix-core kernel writes one record per 16-frame group and wave). */
+long long ias_stft_partials_count(int B, int T, int n_fft, int hop, int have_mtables);
 
 /* HOST helpers: length (floats) and contents of the lane-major window/twiddle table block the kernel
  * keeps in registers.  window_host [n_fft] = the analysis window zero-padded and centred to n_fft
@@ -158,7 +159,9 @@ int ias_stft_build_mtables(int n_fft, const float* window_host, const int* mel_s
 
 /* Framed STFT of audio [B,T] (center=True, reflect padding, one-sided); tables = device copy of the
  * ias_stft_build_tables block, mtables = device copy of the ias_stft_build_mtables block (built with the same
- * filterbank as mel_*; required for the sizes the matrix-core kernel serves: n_fft 1024).  Per-bin value by value_mode: 1 |X|, 2 |X|^2, 3 sqrt(max(|X|^2, eps)).
+ * filterbank as mel_*; NULL: the VALU kernel; the matrix-core kernel serves n_fft 1024).  ticket [2] ints or NULL: the
+ * matrix-core kernel's work counter, zero before the first launch (the kernel re-arms it on exit); launches that may
+ * run concurrently need counters of their own; NULL = static round-robin assignment of the frame groups.  Per-bin value by value_mode: 1 |X|, 2 |X|^2, 3 sqrt(max(|X|^2, eps)).
  * Optional mel projection as packed triangular filters (mel_start/mel_count/mel_woff [n_out],
  * mel_w [mel_nnz]); with NULL mel_* n_out must be n_fft/2+1.
  * out [B,F,n_out] (frames-major) or NULL; target [B,F,n_out] + partials required when
@@ -168,8 +171,8 @@ int ias_stft_build_mtables(int n_fft, const float* window_host, const int* mel_s
  * n_fft in {512, 1024, 2048}. */
 int ias_stft(const float* audio, const float* tables, const float* mtables, const int* mel_start,
              const int* mel_count, const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
-             double* partials, const float* rowpeak, int B, int T, int n_fft, int hop, int n_out, int value_mode,
-             int loss_mode, float eps, void* stream);
+             double* partials, const float* rowpeak, int* ticket, int B, int T, int n_fft, int hop, int n_out,
+             int value_mode, int loss_mode, float eps, void* stream);
 
 /* Backward of the spectral losses w.r.t. the audio (the reference's mel-L1 loop
  * audio_to_params.py:150-153 is commented out and would have used torchaudio's differentiable modules, its MR-STFT

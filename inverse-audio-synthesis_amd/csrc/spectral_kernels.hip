@@ -795,16 +795,18 @@ static int stft_grid_x(int B, int F, int n_fft, int hop) {
 }
 
 // the matrix-core form (csrc/stft_mfma_kernels.hip)
-bool ias_sm_enabled(int n_fft);
-int ias_sm_grid(long long nframes);
+bool ias_sm_enabled(int n_fft, bool have_mtables);
+long long ias_sm_partials(long long nframes);
 int ias_sm_launch(const float* audio, const float* mtab, bool mel, float* out, const float* target, double* partials,
-                  const float* rowpeak, int B, int T, int F, int n_fft, int hop, int n_out, int value_mode, int loss_mode,
-                  float eps, hipStream_t stream);
+                  const float* rowpeak, int* ticket, int B, int T, int F, int n_fft, int hop, int n_out, int value_mode,
+                  int loss_mode, float eps, hipStream_t stream);
 
-extern "C" long long ias_stft_partials_count(int B, int T, int n_fft, int hop) {
+// have_mtables: the ias_stft call will be given an ias_stft_build_mtables block (the matrix-core kernel writes one
+// record per 16-frame group and wave, the VALU kernel one per workgroup)
+extern "C" long long ias_stft_partials_count(int B, int T, int n_fft, int hop, int have_mtables) {
   const int F = ias_stft_num_frames(T, n_fft, hop);
   if (F < 0 || B <= 0) return IAS_ERR_ARG;
-  if (ias_sm_enabled(n_fft)) return ias_sm_grid((long long)B * F);
+  if (ias_sm_enabled(n_fft, have_mtables != 0)) return ias_sm_partials((long long)B * F);
   return (long long)B * stft_grid_x(B, F, n_fft, hop);
 }
 
@@ -864,7 +866,7 @@ extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float*
 //                          torchsynth's normalize_if_clipping would, without the normalised audio ever being written
 extern "C" int ias_stft(const float* audio, const float* tables, const float* mtables, const int* mel_start, const int* mel_count,
                         const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
-                        double* partials, const float* rowpeak, int B, int T, int n_fft, int hop, int n_out,
+                        double* partials, const float* rowpeak, int* ticket, int B, int T, int n_fft, int hop, int n_out,
                         int value_mode, int loss_mode, float eps, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!audio || !tables || B <= 0 || B > 65535 || n_out <= 0) return IAS_ERR_ARG;
@@ -877,11 +879,9 @@ extern "C" int ias_stft(const float* audio, const float* tables, const float* mt
   const int F = ias_stft_num_frames(T, n_fft, hop);
   if (F < 0) return IAS_ERR_ARG;
   if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return IAS_ERR_UNSUPPORTED;
-  if (ias_sm_enabled(n_fft)) {
-    if (!mtables) return IAS_ERR_ARG;
-    return ias_sm_launch(audio, mtables, mel, out, target, partials, rowpeak, B, T, F, n_fft, hop, n_out, value_mode,
-                         loss_mode, eps, stream);
-  }
+  if (ias_sm_enabled(n_fft, mtables != nullptr))
+    return ias_sm_launch(audio, mtables, mel, out, target, partials, rowpeak, ticket, B, T, F, n_fft, hop, n_out,
+                         value_mode, loss_mode, eps, stream);
 
   SpecArgs a;
   a.audio = audio; a.tables = tables;

@@ -13,7 +13,11 @@
 #pragma once
 
 #define IAS_SM_MAX_TILES 16   // mel tiles of 16 outputs: n_out <= 256
-#define IAS_SM_WAVES 4
+#define IAS_SM_REG_BLOCKS 12  // mel blocks whose weights a wave holds in registers at a time (one pass of its mel loop)
+#define IAS_SM_MAX_BLOCKS 60  // 16-bin k-blocks of the mel tiles one wave may be given
+#define IAS_SM_DESC_W (4 + 2 * IAS_SM_MAX_BLOCKS)   // descriptor ints per wave: nblk, first A block, first tile, passes (max over the waves of ceil(nblk / IAS_SM_REG_BLOCKS)), then per block (power offset, tile | first << 8 | last << 9 | row quarters (rows 4q .. 4q+3) << 10 | next tile << 16)
+#define IAS_SM_WAVES 4        // waves per workgroup; a group of 16 frames = IAS_SM_FPW frames per wave
+#define IAS_SM_FPW (16 / IAS_SM_WAVES)
 
 struct IasSmLayout {
   int n_fft, N2, Q, NT, NB, VPL, NPAIR_IT;
@@ -32,7 +36,7 @@ IAS_SM_HD IasSmLayout ias_sm_layout(int n_fft) {
   IasSmLayout L{};
   L.n_fft = n_fft; L.N2 = n_fft / 2; L.Q = L.N2 / 16; L.NT = L.Q / 16; L.NB = L.Q / 8;
   L.VPL = L.Q / 2;                 // samples per lane and frame
-  L.NPAIR_IT = L.N2 / 128;         // bin pairs (k, N2 - k), k = 1 + lane + 64 i, per lane
+  L.NPAIR_IT = L.N2 / 128;         // = NB: bin pairs (k, N2 - k) per lane, k = the lane's own lower-half bins
   int e = 0;
   L.e_win = e; e += L.VPL;         // window of the lane's samples, in load order
   L.e_b1 = e;  e += 8;             // stage-1 B operand: cos[4], sin[4]
@@ -45,7 +49,7 @@ IAS_SM_HD IasSmLayout ias_sm_layout(int n_fft) {
   const int bins = L.N2 + 1;
   L.pstr = ((bins - 8 + 63) / 64) * 64 + 8;
   L.off_desc = 64 * L.n_entries;
-  L.off_mela = L.off_desc + IAS_SM_WAVES * (1 + 4 * IAS_SM_MAX_TILES);
+  L.off_mela = L.off_desc + IAS_SM_WAVES * IAS_SM_DESC_W;
   return L;
 }
 

@@ -97,11 +97,25 @@ class STFTPlan(nn.Module):
         else:
             mel_args = [None, None, None, None, 0]
         n_mtab = lib.ias_stft_mtables_len(n_fft, mel_args[0], mel_args[1], mel_args[4])
-        _lib.check(min(n_mtab, 0), "ias_stft_mtables_len")
-        mtables = torch.empty(n_mtab, dtype=torch.float32)
-        _lib.check(lib.ias_stft_build_mtables(n_fft, ctypes.c_void_p(wc.data_ptr()), *mel_args,
-                                              ctypes.c_void_p(mtables.data_ptr())), "ias_stft_build_mtables")
-        self.register_buffer("mtables", mtables, persistent=False)
+        if n_mtab == -2:
+            # a filterbank whose bands do not fit the matrix-core kernel's tiles: the VALU kernel serves the plan
+            self.mtables = None
+        else:
+            _lib.check(min(n_mtab, 0), "ias_stft_mtables_len")
+            mtables = torch.empty(n_mtab, dtype=torch.float32)
+            _lib.check(lib.ias_stft_build_mtables(n_fft, ctypes.c_void_p(wc.data_ptr()), *mel_args,
+                                                  ctypes.c_void_p(mtables.data_ptr())), "ias_stft_build_mtables")
+            self.register_buffer("mtables", mtables, persistent=False)
+        self._tickets = {}
+
+    def _ticket(self, device):
+        """The matrix-core kernel's work counter (two ints, zero between launches: the kernel re-arms it), one per
+        stream: launches on different streams may overlap."""
+        key = (device, torch.cuda.current_stream().cuda_stream)
+        t = self._tickets.get(key)
+        if t is None:
+            t = self._tickets[key] = torch.zeros(2, dtype=torch.int32, device=device)
+        return t
 
     def num_frames(self, T):
         F = _lib.load().ias_stft_num_frames(T, self.n_fft, self.hop_length)
@@ -116,7 +130,7 @@ class STFTPlan(nn.Module):
                           _lib.ptr(self.mel_start) if mel else None, _lib.ptr(self.mel_count) if mel else None,
                           _lib.ptr(self.mel_woff) if mel else None, _lib.ptr(self.mel_w) if mel else None,
                           int(self.mel_w.numel()) if mel else 0, _lib.ptr(out), _lib.ptr(target), _lib.ptr(partials),
-                          _lib.ptr(rowpeak), B, T, self.n_fft, self.hop_length,
+                          _lib.ptr(rowpeak), _lib.ptr(self._ticket(audio.device)), B, T, self.n_fft, self.hop_length,
                           self.n_out, value_mode, loss_mode, float(eps), _lib.stream())
         _lib.check(st, "ias_stft")
 
@@ -147,7 +161,8 @@ class STFTPlan(nn.Module):
         lib = _lib.load()
         F = self.num_frames(a.shape[1])
         assert target_values.shape == (a.shape[0], F, self.n_out) and target_values.is_contiguous()
-        n = lib.ias_stft_partials_count(a.shape[0], a.shape[1], self.n_fft, self.hop_length)
+        n = lib.ias_stft_partials_count(a.shape[0], a.shape[1], self.n_fft, self.hop_length,
+                                        0 if self.mtables is None else 1)
         partials = torch.empty((n, 3), dtype=torch.float64, device=a.device)
         self._call(a, None, target_values, partials, value_mode, loss_mode, eps, rowpeak)
         sums = torch.empty(3, dtype=torch.float64, device=a.device)

@@ -39,7 +39,7 @@ def layout(n_fft):
     bins = N2 + 1
     L["pstr"] = ((bins - 8 + 63) // 64) * 64 + 8
     L["off_desc"] = 64 * e
-    L["off_mela"] = L["off_desc"] + 4 * (1 + 4 * 16)
+    L["off_mela"] = L["off_desc"] + 4 * (4 + 2 * 60)
     return L
 
 
@@ -137,20 +137,21 @@ def frame_power(tab, n_fft, frame):
         Y = W @ tv                                          # [kb, 64]
         for kb in range(NB):
             Z[LO + 16 * ((2 * G + kl) + 8 * kb)] = Y[kb]
-    # unpack
+    # unpack: a lane pairs its own lower-half bins k = k1 + 16 (2 G + kl) + 128 kb (kb < NB/2) with Z[N2 - k]
     P = np.zeros(N2 + 1)
-    for i in range(L["NPAIR_IT"]):
-        k = 1 + LANES + 64 * i
-        zk, zn = Z[k], Z[N2 - k]
-        wr, wi = E(L["e_unp"] + 2 * i), E(L["e_unp"] + 2 * i + 1)
-        a, b = zk.real + zn.real, zk.imag - zn.imag
-        d, s_ = zk.real - zn.real, zk.imag + zn.imag
-        tx = wr * s_ + wi * d
-        ty = wi * s_ - wr * d
-        P[k] = 0.25 * ((a + tx) ** 2 + (b + ty) ** 2)
-        P[N2 - k] = 0.25 * ((a - tx) ** 2 + (b - ty) ** 2)
-    P[0] = (Z[0].real + Z[0].imag) ** 2
-    P[N2] = (Z[0].real - Z[0].imag) ** 2
+    for kl in range(2):
+        for kb in range(NB // 2):
+            k = LO + 16 * (2 * G + kl) + 128 * kb
+            zk, zn = Z[k], Z[(N2 - k) % N2]
+            e = L["e_unp"] + 2 * (kl * (NB // 2) + kb)
+            wr, wi = E(e), E(e + 1)
+            a, b = zk.real + zn.real, zk.imag - zn.imag
+            d, s_ = zk.real - zn.real, zk.imag + zn.imag
+            tx = wr * s_ + wi * d
+            ty = wi * s_ - wr * d
+            P[k] = 0.25 * ((a + tx) ** 2 + (b + ty) ** 2)
+            P[N2 - k] = 0.25 * ((a - tx) ** 2 + (b - ty) ** 2)
+    P[N2 // 2] = abs(Z[N2 // 2]) ** 2
     return P
 
 
@@ -164,17 +165,35 @@ def mel_project(tab, n_fft, n_out, Pslots):
     A = tab[L["off_mela"]:].astype(np.float64)
     out = np.zeros((16, 16 * ((n_out + 15) // 16)))
     seen = set()
+    DW = 4 + 2 * 60
     for w in range(4):
-        dw = desc[w * 65:(w + 1) * 65]
-        for n in range(dw[0]):
-            t, kb, nblk, aoff = dw[1 + 4 * n:5 + 4 * n]
-            assert t not in seen
-            seen.add(int(t))
-            acc = np.zeros((64, 4))
-            for q in range(nblk):
-                bq = np.stack([sP[LO, kb + 16 * q + 4 * G + s] for s in range(4)], 1)   # the b128 read of lane (g, j)
-                for s in range(4):
-                    acc = mfma16x16x4(A[256 * (aoff + q) + 64 * s:256 * (aoff + q) + 64 * s + 64], bq[:, s], acc)
-            for r in range(4):
-                out[LO, 16 * t + 4 * G + r] = acc[:, r]
+        dw = desc[w * DW:(w + 1) * DW]
+        nblk, ablk = int(dw[0]), int(dw[1])
+        acc = None
+        firsts = []
+        for b in range(nblk):
+            poff, flags = int(dw[4 + 2 * b]), int(dw[5 + 2 * b])
+            t = flags & 255
+            if flags & 0x100:
+                key = (t, (flags >> 10) & 15)
+                assert key not in seen and acc is None
+                seen.add(key)
+                firsts.append(b)
+                acc = np.zeros((64, 4))
+            bq = np.stack([sP[LO, poff + 4 * G + s] for s in range(4)], 1)   # the 16-byte read of lane (g, j)
+            for s in range(4):
+                acc = mfma16x16x4(A[256 * (ablk + b) + 64 * s:256 * (ablk + b) + 64 * s + 64], bq[:, s], acc)
+            if flags & 0x200:
+                emit = ((flags >> (10 + G)) & 1).astype(bool)   # row quarter G (rows 4 G + r) belongs to the (sub)tile
+                for r in range(4):
+                    out[LO[emit], 16 * t + 4 * G[emit] + r] = acc[emit, r]
+                acc = None
+        assert acc is None
+        # "next tile" links: the first tile in dw[2], then bits 16.. of every block of the tile before
+        tiles_w = [int(dw[5 + 2 * b]) & 255 for b in firsts]
+        assert int(dw[3]) == max(1, max(-(-int(desc[v * DW]) // 12) for v in range(4)))    # passes of 12 register blocks
+        if tiles_w:
+            assert int(dw[2]) == tiles_w[0]
+            for i, b in enumerate(firsts):
+                assert (int(dw[5 + 2 * b]) >> 16) & 255 == (tiles_w[i + 1] if i + 1 < len(tiles_w) else 255)
     return out[:, :n_out], seen
