@@ -737,9 +737,14 @@ int ias_sm_grid(long long nframes) {
 }
 // loss partial records: one per (16-frame group, wave)
 long long ias_sm_partials(long long nframes) { return ((nframes + 15) / 16) * IAS_SM_WAVES; }
+// Opt-in (IAS_STFT_MFMA=1): measured on MI355X, v_mfma_f32_16x16x4_f32 does not run beside vector instructions -- not
+// from another wave of the SIMD and not from its own wave (scripts/diag/mfma_valu_overlap.hip, mfma_valu_inwave.hip:
+// an MFMA stream and an FMA stream on one SIMD take the SUM of their times) -- so the 4x larger multiply count of a
+// DFT-as-GEMM is paid in full on the vector ALU and this kernel (85-90 us at the headline size) loses to the radix-8
+// FFT kernel (csrc/spectral_kernels.hip).  Kept as the measured record of that experiment and for its tests.
 bool ias_sm_enabled(int n_fft, bool have_mtables) {
-  static const int valu = getenv("IAS_STFT_VALU") ? atoi(getenv("IAS_STFT_VALU")) : 0;   // diagnostics: the VALU kernel
-  return !valu && have_mtables && n_fft == 1024;
+  static const int on = getenv("IAS_STFT_MFMA") ? atoi(getenv("IAS_STFT_MFMA")) : 0;
+  return on && have_mtables && n_fft == 1024;
 }
 
 #ifdef IAS_SM_STAMPS
