@@ -139,9 +139,10 @@ int ias_pqmf_synthesis(const float* z, const float* G, const float* packed, floa
 /* Frames of a center=True STFT: 1 + T / hop (needs T > n_fft/2 for reflect padding). */
 int ias_stft_num_frames(int T, int n_fft, int hop);
 
-/* Number of [3]-double partial records ias_stft writes when loss_mode != 0; have_mtables != 0: the call will be given
- * an ias_stft_build_mtables block (the matrix-core kernel writes one record per 16-frame group and wave). */
-long long ias_stft_partials_count(int B, int T, int n_fft, int hop, int have_mtables);
+/* Number of [3]-double partial records ias_stft writes when loss_mode != 0.  It depends on the kernel the call will
+ * run, hence on its arguments: flags bit 0: an ias_stft_build_mtables block is given, bit 1: mel filters are given,
+ * bit 2: an ias_stft_build_segtab block is given. */
+long long ias_stft_partials_count(int B, int T, int n_fft, int hop, int flags);
 
 /* HOST helpers: length (floats) and contents of the lane-major window/twiddle table block the kernel
  * keeps in registers.  window_host [n_fft] = the analysis window zero-padded and centred to n_fft
@@ -157,9 +158,20 @@ long long ias_stft_mtables_len(int n_fft, const int* mel_start_host, const int* 
 int ias_stft_build_mtables(int n_fft, const float* window_host, const int* mel_start_host, const int* mel_count_host,
                            const int* mel_woff_host, const float* mel_w_host, int n_out, float* out_host);
 
+/* HOST helpers of the n_fft 1024 kernel's mel projection (csrc/stft2_kernels.hip): the packed triangular filterbank
+ * (host copies of mel_start / mel_count / mel_woff / mel_w) re-cut into contiguous bin segments between filter centres,
+ * with the store offset of every bin in a segment-major buffer and the two weights (rising into filter j, falling out of
+ * filter j-1) per bin.  IAS_ERR_UNSUPPORTED: not a triangular filterbank, more than 192 filters, or segments too long
+ * for the kernel's buffer -- ias_stft then takes the packed filters (segtab = NULL). */
+long long ias_stft_segtab_len(int n_fft, const int* mel_start_host, const int* mel_count_host, const int* mel_woff_host,
+                              const float* mel_w_host, int n_out);
+int ias_stft_build_segtab(int n_fft, const int* mel_start_host, const int* mel_count_host, const int* mel_woff_host,
+                          const float* mel_w_host, int n_out, float* out_host);
+
 /* Framed STFT of audio [B,T] (center=True, reflect padding, one-sided); tables = device copy of the
  * ias_stft_build_tables block, mtables = device copy of the ias_stft_build_mtables block (built with the same
- * filterbank as mel_*; NULL: the VALU kernel; the matrix-core kernel serves n_fft 1024).  ticket [2] ints or NULL: the
+ * filterbank as mel_*; NULL or IAS_STFT_MFMA unset: the radix-8 kernels), segtab = device copy of the
+ * ias_stft_build_segtab block of the same filterbank or NULL.  ticket [2] ints or NULL: the
  * matrix-core kernel's work counter, zero before the first launch (the kernel re-arms it on exit); launches that may
  * run concurrently need counters of their own; NULL = static round-robin assignment of the frame groups.  Per-bin value by value_mode: 1 |X|, 2 |X|^2, 3 sqrt(max(|X|^2, eps)).
  * Optional mel projection as packed triangular filters (mel_start/mel_count/mel_woff [n_out],
@@ -169,7 +181,7 @@ int ias_stft_build_mtables(int n_fft, const float* window_host, const int* mel_s
  * rowpeak [B] or NULL: row peaks of audio; the spectrum is that of audio[b] / rowpeak[b] where rowpeak[b] > 1
  * (normalize_if_clipping folded in: |X|^2 scales by 1 / peak^2).
  * n_fft in {512, 1024, 2048}. */
-int ias_stft(const float* audio, const float* tables, const float* mtables, const int* mel_start,
+int ias_stft(const float* audio, const float* tables, const float* mtables, const float* segtab, const int* mel_start,
              const int* mel_count, const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
              double* partials, const float* rowpeak, int* ticket, int B, int T, int n_fft, int hop, int n_out,
              int value_mode, int loss_mode, float eps, void* stream);

@@ -52,9 +52,11 @@ SYMBOLS = {
     "ias_stft_partials_count": (_LL, [_I, _I, _I, _I, _I]),
     "ias_stft_tables_len": (_I, [_I]),
     "ias_stft_build_tables": (_I, [_I, _P, _P]),
+    "ias_stft_segtab_len": (_LL, [_I, _P, _P, _P, _P, _I]),
+    "ias_stft_build_segtab": (_I, [_I, _P, _P, _P, _P, _I, _P]),
     "ias_stft_mtables_len": (_LL, [_I, _P, _P, _I]),
     "ias_stft_build_mtables": (_I, [_I, _P, _P, _P, _P, _P, _I, _P]),
-    "ias_stft": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "ias_stft": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "ias_stft_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I,
                                    ctypes.c_float, ctypes.c_float, _P]),
     "ias_stft_grad_frames": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, ctypes.c_float,

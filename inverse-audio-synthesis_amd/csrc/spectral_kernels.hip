@@ -424,6 +424,220 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES == 10 ? 5 : 1) void stft_ke
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// n_fft 1024, round 3 (design notes: csrc/stft2_kernels.hip, which also builds the segment-major mel tables):
+// the same three radix-8 passes, then the Hermitian unpack on half the spectrum, the mel projection as conflict-free
+// row reads of a segment-major power buffer, frames dealt to waves from one flat [B*F] list.
+#define IAS_SEG_MAX_ROWS 17
+#define IAS_SEG_HDR 16
+#define IAS_SEG_STRIDE 65
+struct Spec2Args {
+  const float* audio;      // [B,T]
+  const float* tables;     // ias_stft_build_tables block (n_fft 1024: with the unpack twiddles of this kernel at the end)
+  const float* segtab;     // ias_stft_build_segtab block, or null: linear bins
+  float* out;              // [B,F,n_out] or null
+  const float* target;     // [B,F,n_out] or null
+  double* partials;        // [gridDim.x][3] or null
+  const float* rowpeak;    // [B] or null
+  int T, F, hop, n_out, nframes;
+  unsigned magicF;         // floor(2^32 / F)
+  int value_mode, loss_mode;
+  float eps;
+};
+// lane l <- x of lane l-1 (lane 0 <- fill) / lane l+1 (lane 63 <- fill): one DPP move across the whole wave
+__device__ __forceinline__ float wave_shr1(float x, float fill) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float x, float fill) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x130, 0xf, 0xf, false));
+}
+
+template <int SP_WAVES, bool MEL, int LOSS>
+__global__ __launch_bounds__(64 * SP_WAVES, (5 * SP_WAVES + 9) / 10) void stft2_kernel(const Spec2Args a) {
+  constexpr int SP_THREADS = 64 * SP_WAVES, N2 = 512, R = 8, SCR = 64 * 9;
+  constexpr int NTAB = 8 + 8 + 8 + 4;     // cpx per lane: window pairs, pass-1 twiddles, pass-2 twiddles, unpack twiddles
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  cpx* s_scr = reinterpret_cast<cpx*>(smem);                        // SP_WAVES x SCR: FFT exchange scratch / power buffer
+  cpx* s_tab = s_scr + SP_WAVES * SCR;                              // [NTAB][64]
+  cpx* s_segw = s_tab + NTAB * 64;                                  // MEL: [rows][64] (up, down)
+  int* s_sega = reinterpret_cast<int*>(s_segw + (MEL ? IAS_SEG_MAX_ROWS * 64 : 0));   // MEL: [9][64] store offsets
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // tables: the old block's entries [0,16) window, [16,32) pass-1, [32,48) pass-2 twiddles; this kernel's unpack
+  // twiddles W_1024^k, k = (lane >> 3) + 8 (lane & 7) + 64 e, are the 8 entries behind the old block's unpack entries
+  constexpr int OLD_UNP = 10;
+  for (int i = tid; i < NTAB * 64; i += SP_THREADS) {
+    const int pp = i >> 6, l = i & 63;
+    const int src = pp < 24 ? 2 * pp : 48 + OLD_UNP + 2 * (pp - 24);
+    s_tab[i] = cmk(a.tables[64 * src + l], a.tables[64 * (src + 1) + l]);
+  }
+  // the scratch doubles as the segment-major power buffer, some of whose words (the padding of the exchange layout,
+  // positions past the end of a short segment) no pass ever writes: they meet zero weights and must be finite
+  for (int i = tid; i < SP_WAVES * SCR; i += SP_THREADS) s_scr[i] = cmk(0.f, 0.f);
+  int seg_rows = 0, seg_r[3] = {0, 0, 0}, seg_s0 = 0;
+  if (MEL) {
+    const int* hdr = reinterpret_cast<const int*>(a.segtab);
+    seg_rows = hdr[1]; seg_r[0] = hdr[2]; seg_r[1] = hdr[3]; seg_r[2] = hdr[4]; seg_s0 = hdr[5];
+    for (int i = tid; i < 9 * 64; i += SP_THREADS) s_sega[i] = hdr[IAS_SEG_HDR + i];
+    const cpx* wsrc = reinterpret_cast<const cpx*>(a.segtab + IAS_SEG_HDR + 9 * 64);
+    for (int i = tid; i < seg_rows * 64; i += SP_THREADS) s_segw[i] = wsrc[i];
+  }
+  const cpx* t_win = s_tab + lane;          // [n1]  -> (win[2 n1], win[2 n1 + 1])
+  const cpx* t_tw1 = t_win + 64 * 8;        // [k1]  -> W_512^(lane k1)
+  const cpx* t_tw2 = t_tw1 + 64 * 8;        // [d]   -> W_64^(c d)
+  const cpx* t_twu = t_tw2 + 64 * 8;        // [e]   -> W_1024^k, k = k1 + 8 d + 64 e
+  __syncthreads();                           // the only workgroup barrier before the final reduction
+
+  cpx* sA = s_scr + wave * SCR;
+  float* P2 = reinterpret_cast<float*>(sA);
+  float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+  const int gw = blockIdx.x * SP_WAVES + wave, nw = gridDim.x * SP_WAVES;
+  const int k1 = lane >> 3, dd = lane & 7;   // after the last pass the lane holds Z[k1 + 8 dd + 64 e]
+
+  auto row_of = [&](int fi, int& b, int& f) {
+    unsigned q0 = __umulhi((unsigned)fi, a.magicF);
+    int r = fi - (int)q0 * a.F;
+    if (r >= a.F) { r -= a.F; ++q0; }
+    b = (int)q0; f = r;
+  };
+  float xc[2 * R], xn[2 * R];
+  int fi = gw, bcur = 0, fcur = 0;
+  if (fi < a.nframes) { row_of(fi, bcur, fcur); load_frame<R, N2>(a.audio + (size_t)bcur * a.T, a.T, a.hop, fcur, lane, xc); }
+  for (; fi < a.nframes; fi += nw) {
+    const bool more = fi + nw < a.nframes;   // wave-uniform
+    int bnext = 0, fnext = 0;
+    if (more) { row_of(fi + nw, bnext, fnext); load_frame<R, N2>(a.audio + (size_t)bnext * a.T, a.T, a.hop, fnext, lane, xn); }
+    float pscale = 0.25f;
+    if (a.rowpeak != nullptr) { const float pkv = a.rowpeak[bcur]; if (pkv > 1.0f) { const float r = 1.0f / pkv; pscale = 0.25f * (r * r); } }
+
+    // pass 1: radix 8 over n1 (points 64 n1 + lane), twiddle W_512^(lane k1), scatter to [k1][c][a]
+    cpx v[R];
+#pragma unroll
+    for (int n1 = 0; n1 < R; ++n1) v[n1] = cmk(xc[2 * n1], xc[2 * n1 + 1]) * t_win[64 * n1];
+    dft8(v);
+    {
+      const int c = lane & 7, aa = lane >> 3;
+#pragma unroll
+      for (int q = 0; q < R; ++q) sA[(q * 8 + c) * 9 + aa] = cmul(v[q], t_tw1[64 * q]);
+    }
+    wave_lds_sync();
+    cpx u[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+    wave_lds_sync();
+    // pass 2: radix 8 over a for each (k1, c); twiddle W_64^(c d); scatter (in place) to [k1][d][c]
+    dft8(u);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) sA[(k1 * 8 + d) * 9 + dd] = cmul(u[d], t_tw2[64 * d]);
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+    wave_lds_sync();
+    // pass 3: radix 8 over c for each (k1, d): u[e] = Z[k1 + 8 d + 64 e]
+    dft8(u);
+    // the upper half (e >= 4, k >= 256) goes to LDS at k - 256 (padded by one complex per 8: conflict-free 8-byte stores)
+    const int kl = k1 + 8 * dd;
+#pragma unroll
+    for (int e = 4; e < 8; ++e) { const int i = kl + 64 * (e - 4); sA[i + (i >> 3)] = u[e]; }
+    wave_lds_sync();
+    // unpack: own bins k = kl + 64 e (e < 4) with Z[512 - k] from the upper half
+    float pk[4], pn[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = kl + 64 * e;
+      const int i = (256 - k) & 255;                         // k = 0: Z[512] = Z[0] (own), the read is a dummy
+      cpx zn = sA[i + (i >> 3)];
+      const cpx zk = u[e];
+      if (e == 0 && k == 0) zn = zk;
+      const cpx w = t_twu[64 * e];
+      const float ea = zk.x + zn.x, eb = zk.y - zn.y, od = zk.x - zn.x, os = zk.y + zn.y;
+      const float tx = fmaf(w.y, od, w.x * os), ty = fmaf(-w.x, od, w.y * os);
+      const float xr = ea + tx, xi = eb + ty, yr = ea - tx, yi = eb - ty;
+      pk[e] = fmaf(xi, xi, xr * xr) * pscale;
+      pn[e] = fmaf(yi, yi, yr * yr) * pscale;
+    }
+    float pmid = fmaf(u[4].y, u[4].y, u[4].x * u[4].x) * (4.0f * pscale);    // lane 0: |Z[256]|^2
+    if (a.value_mode == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pk[e] = sqrtf(pk[e]); pn[e] = sqrtf(pn[e]); }
+      pmid = sqrtf(pmid);
+    } else if (a.value_mode == 3) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pk[e] = sqrtf(fmaxf(pk[e], a.eps)); pn[e] = sqrtf(fmaxf(pn[e], a.eps)); }
+      pmid = sqrtf(fmaxf(pmid, a.eps));
+    }
+    wave_lds_sync();   // every Z read is done: the power values overwrite the scratch
+    const size_t row = (size_t)fi * a.n_out;
+    auto emit = [&](int m, float val) {
+      float t = 0.f;
+      if (LOSS != 0) t = a.target[row + m];
+      if (a.out != nullptr) a.out[row + m] = val;
+      if (LOSS == 1) l0 += fabsf(val - t);
+      else if (LOSS == 2) { const float d = t - val; l0 = fmaf(d, d, l0); l1 = fmaf(t, t, l1); l2 += fabsf(logf(val) - logf(t)); }
+    };
+    if (MEL) {
+      // segment-major store: position t of segment j at row (base + t), column j % 64
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { P2[s_sega[64 * e + lane]] = pk[e]; P2[s_sega[64 * (4 + e) + lane]] = pn[e]; }
+      if (lane == 0) P2[s_sega[64 * 8]] = pmid;
+      wave_lds_sync();
+      float U[3], D[3];
+      int rbase = 0;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        float us = 0.f, ds = 0.f;
+        for (int t = 0; t < seg_r[g]; ++t) {
+          const float pv = P2[(rbase + t) * IAS_SEG_STRIDE + lane];
+          const cpx w = s_segw[(rbase + t) * 64 + lane];
+          us = fmaf(w.x, pv, us);
+          ds = fmaf(w.y, pv, ds);
+        }
+        U[g] = us; D[g] = ds;
+        rbase += seg_r[g];
+      }
+      // mel m = U[segment m] + D[segment m + 1]; slot i = 64 g + lane holds segment s0 + i
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int m = 64 * c + lane;
+        if (64 * c < a.n_out) {
+          float val;
+          if (seg_s0 == 1) {
+            const float fill = c > 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(U[c > 0 ? c - 1 : 0]), 63)) : 0.f;
+            val = D[c] + wave_shr1(U[c], fill);
+          } else {
+            const float fill = c < 2 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(D[c < 2 ? c + 1 : 2]), 0)) : 0.f;
+            val = U[c] + wave_shl1(D[c], fill);
+          }
+          if (m < a.n_out) emit(m, val);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const int k = kl + 64 * e; emit(k, pk[e]); emit(512 - k, pn[e]); }
+      if (lane == 0) emit(256, pmid);
+    }
+    wave_lds_sync();
+    if (more) {
+#pragma unroll
+      for (int e = 0; e < 2 * R; ++e) xc[e] = xn[e];
+      bcur = bnext; fcur = fnext;
+    }
+  }
+
+  if (a.partials != nullptr) {
+    __shared__ float s_red[SP_WAVES][4];
+    l0 = wave_sum_f(l0); l1 = wave_sum_f(l1); l2 = wave_sum_f(l2);
+    if (lane == 0) { s_red[wave][0] = l0; s_red[wave][1] = l1; s_red[wave][2] = l2; }
+    __syncthreads();
+    if (tid < 3) {
+      double sacc = 0.0;
+      for (int w = 0; w < SP_WAVES; ++w) sacc += (double)s_red[w][tid];
+      a.partials[(size_t)blockIdx.x * 3 + tid] = sacc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Backward of the linear-bin losses, frame part, on the same wave-per-frame FFT core (round 2).
 //
 // d loss / d x_f for  loss_mode 1: scale * sum |V - t|  and  loss_mode 2: one MR-STFT resolution (cotangent
@@ -803,10 +1017,32 @@ int ias_sm_launch(const float* audio, const float* mtab, bool mel, float* out, c
 
 // have_mtables: the ias_stft call will be given an ias_stft_build_mtables block (the matrix-core kernel writes one
 // record per 16-frame group and wave, the VALU kernel one per workgroup)
-extern "C" long long ias_stft_partials_count(int B, int T, int n_fft, int hop, int have_mtables) {
+// the round-3 radix-8 kernel (stft2_kernel): n_fft 1024; mel plans need their segment-major tables
+#define IAS_STFT2_WAVES 10
+static bool stft2_enabled(int n_fft, bool mel, bool have_segtab) {
+  static const int v1 = getenv("IAS_STFT_V1") ? atoi(getenv("IAS_STFT_V1")) : 0;   // diagnostics: round-2 kernel
+  return !v1 && n_fft == 1024 && (!mel || have_segtab);
+}
+static int stft2_grid(long long nframes) {
+  static const int env = getenv("IAS_STFT2_WGS") ? atoi(getenv("IAS_STFT2_WGS")) : 0;   // diagnostics
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    ncu = v;
+  }
+  const long long need = (nframes + IAS_STFT2_WAVES - 1) / IAS_STFT2_WAVES;
+  const long long cap = env > 0 ? env : 2LL * ncu;          // two 10-wave workgroups per CU = five waves per SIMD
+  return (int)(need < cap ? need : cap);
+}
+
+// which kernel an ias_stft call with these arguments runs decides how many records it writes:
+// flags bit 0: an ias_stft_build_mtables block will be given, bit 1: mel filters, bit 2: an ias_stft_build_segtab block
+extern "C" long long ias_stft_partials_count(int B, int T, int n_fft, int hop, int flags) {
   const int F = ias_stft_num_frames(T, n_fft, hop);
   if (F < 0 || B <= 0) return IAS_ERR_ARG;
-  if (ias_sm_enabled(n_fft, have_mtables != 0)) return ias_sm_partials((long long)B * F);
+  if (ias_sm_enabled(n_fft, (flags & 1) != 0)) return ias_sm_partials((long long)B * F);
+  if (stft2_enabled(n_fft, (flags & 2) != 0, (flags & 4) != 0)) return stft2_grid((long long)B * F);
   return (long long)B * stft_grid_x(B, F, n_fft, hop);
 }
 
@@ -815,7 +1051,8 @@ extern "C" long long ias_stft_partials_count(int B, int T, int n_fft, int hop, i
 extern "C" int ias_stft_tables_len(int n_fft) {
   if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return IAS_ERR_UNSUPPORTED;
   const int N2 = n_fft / 2, R = N2 / 64, np_it = (8 * R + 63) / 64, nunp = (N2 / 2) / 64 + 1;
-  return 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp);
+  // n_fft 1024: + the unpack twiddles of stft2_kernel (bins k = (lane >> 3) + 8 (lane & 7) + 64 e, e < 4)
+  return 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp + (n_fft == 1024 ? 8 : 0));
 }
 
 extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float* out_host) {
@@ -851,6 +1088,14 @@ extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float*
       o[64 * (2 * i) + l] = (float)cos(ang);
       o[64 * (2 * i + 1) + l] = (float)(-sin(ang));
     }
+  o += 64 * 2 * nunp;
+  if (n_fft == 1024)
+    for (int e = 0; e < 4; ++e)
+      for (int l = 0; l < 64; ++l) {
+        const double ang = w0 * (double)((l >> 3) + 8 * (l & 7) + 64 * e);
+        o[64 * (2 * e) + l] = (float)cos(ang);
+        o[64 * (2 * e + 1) + l] = (float)(-sin(ang));
+      }
   return IAS_OK;
 }
 
@@ -864,7 +1109,7 @@ extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float*
 //   partials [ias_stft_partials_count][3] doubles, required when loss_mode != 0
 //   rowpeak  [B] or NULL : row peaks max |audio| (ias_voice_render's workspace): the spectrum of the row normalised as
 //                          torchsynth's normalize_if_clipping would, without the normalised audio ever being written
-extern "C" int ias_stft(const float* audio, const float* tables, const float* mtables, const int* mel_start, const int* mel_count,
+extern "C" int ias_stft(const float* audio, const float* tables, const float* mtables, const float* segtab, const int* mel_start, const int* mel_count,
                         const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
                         double* partials, const float* rowpeak, int* ticket, int B, int T, int n_fft, int hop, int n_out,
                         int value_mode, int loss_mode, float eps, void* stream_) {
@@ -882,6 +1127,28 @@ extern "C" int ias_stft(const float* audio, const float* tables, const float* mt
   if (ias_sm_enabled(n_fft, mtables != nullptr))
     return ias_sm_launch(audio, mtables, mel, out, target, partials, rowpeak, ticket, B, T, F, n_fft, hop, n_out,
                          value_mode, loss_mode, eps, stream);
+
+  if (stft2_enabled(n_fft, mel, segtab != nullptr)) {
+    if ((long long)B * F > 2000000000LL) return IAS_ERR_UNSUPPORTED;
+    Spec2Args a2;
+    a2.audio = audio; a2.tables = tables; a2.segtab = mel ? segtab : nullptr; a2.out = out; a2.target = target;
+    a2.partials = partials; a2.rowpeak = rowpeak; a2.T = T; a2.F = F; a2.hop = hop; a2.n_out = n_out; a2.nframes = B * F;
+    a2.magicF = (unsigned)(0x100000000ULL / (unsigned long long)F);
+    a2.value_mode = value_mode; a2.loss_mode = loss_mode; a2.eps = eps;
+    const size_t lds2 = sizeof(cpx) * (IAS_STFT2_WAVES * 64 * 9 + 28 * 64 + (mel ? IAS_SEG_MAX_ROWS * 64 : 0)) +
+                        (mel ? sizeof(int) * 9 * 64 : 0);
+    const dim3 grid2(stft2_grid(a2.nframes)), block2(64 * IAS_STFT2_WAVES);
+#define IAS_STFT2_LAUNCH(MEL, LOSS)                                                                                \
+  do {                                                                                                             \
+    (void)hipFuncSetAttribute((const void*)stft2_kernel<IAS_STFT2_WAVES, MEL, LOSS>,                               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                              \
+    hipLaunchKernelGGL((stft2_kernel<IAS_STFT2_WAVES, MEL, LOSS>), grid2, block2, lds2, stream, a2);               \
+  } while (0)
+    if (mel) { if (loss_mode == 0) IAS_STFT2_LAUNCH(true, 0); else if (loss_mode == 1) IAS_STFT2_LAUNCH(true, 1); else IAS_STFT2_LAUNCH(true, 2); }
+    else { if (loss_mode == 0) IAS_STFT2_LAUNCH(false, 0); else if (loss_mode == 1) IAS_STFT2_LAUNCH(false, 1); else IAS_STFT2_LAUNCH(false, 2); }
+#undef IAS_STFT2_LAUNCH
+    return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+  }
 
   SpecArgs a;
   a.audio = audio; a.tables = tables;

@@ -106,6 +106,15 @@ class STFTPlan(nn.Module):
             _lib.check(lib.ias_stft_build_mtables(n_fft, ctypes.c_void_p(wc.data_ptr()), *mel_args,
                                                   ctypes.c_void_p(mtables.data_ptr())), "ias_stft_build_mtables")
             self.register_buffer("mtables", mtables, persistent=False)
+        # segment-major mel tables of the n_fft 1024 kernel (triangular filterbanks with short segments; else None)
+        self.register_buffer("segtab", None, persistent=False)
+        if n_mels is not None and n_fft == 1024:
+            n_seg = lib.ias_stft_segtab_len(n_fft, mel_args[0], mel_args[1], mel_args[2], mel_args[3], n_mels)
+            if n_seg > 0:
+                segtab = torch.empty(n_seg, dtype=torch.float32)
+                _lib.check(lib.ias_stft_build_segtab(n_fft, mel_args[0], mel_args[1], mel_args[2], mel_args[3], n_mels,
+                                                     ctypes.c_void_p(segtab.data_ptr())), "ias_stft_build_segtab")
+                self.segtab = segtab
         self._tickets = {}
 
     def _ticket(self, device):
@@ -126,7 +135,7 @@ class STFTPlan(nn.Module):
         lib = _lib.load()
         B, T = audio.shape
         mel = self.n_mels is not None
-        st = lib.ias_stft(_lib.ptr(audio), _lib.ptr(self.tables), _lib.ptr(self.mtables),
+        st = lib.ias_stft(_lib.ptr(audio), _lib.ptr(self.tables), _lib.ptr(self.mtables), _lib.ptr(self.segtab),
                           _lib.ptr(self.mel_start) if mel else None, _lib.ptr(self.mel_count) if mel else None,
                           _lib.ptr(self.mel_woff) if mel else None, _lib.ptr(self.mel_w) if mel else None,
                           int(self.mel_w.numel()) if mel else 0, _lib.ptr(out), _lib.ptr(target), _lib.ptr(partials),
@@ -162,7 +171,8 @@ class STFTPlan(nn.Module):
         F = self.num_frames(a.shape[1])
         assert target_values.shape == (a.shape[0], F, self.n_out) and target_values.is_contiguous()
         n = lib.ias_stft_partials_count(a.shape[0], a.shape[1], self.n_fft, self.hop_length,
-                                        0 if self.mtables is None else 1)
+                                        (0 if self.mtables is None else 1) | (0 if self.n_mels is None else 2) |
+                                        (0 if self.segtab is None else 4))
         partials = torch.empty((n, 3), dtype=torch.float64, device=a.device)
         self._call(a, None, target_values, partials, value_mode, loss_mode, eps, rowpeak)
         sums = torch.empty(3, dtype=torch.float64, device=a.device)

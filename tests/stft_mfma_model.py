@@ -197,3 +197,56 @@ def mel_project(tab, n_fft, n_out, Pslots):
             for i, b in enumerate(firsts):
                 assert (int(dw[5 + 2 * b]) >> 16) & 255 == (tiles_w[i + 1] if i + 1 < len(tiles_w) else 255)
     return out[:, :n_out], seen
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# segment-major mel projection of csrc/stft2_kernels.hip (ias_stft_build_segtab)
+def build_segtab(lib, n_fft, mel):
+    s, c, o, w, n_out = mel
+    P = ctypes.c_void_p
+    n = lib.ias_stft_segtab_len(n_fft, P(s.ctypes.data), P(c.ctypes.data), P(o.ctypes.data), P(w.ctypes.data), int(n_out))
+    if n < 0:
+        return None
+    out = np.zeros(n, np.float32)
+    st = lib.ias_stft_build_segtab(n_fft, P(s.ctypes.data), P(c.ctypes.data), P(o.ctypes.data), P(w.ctypes.data),
+                                   int(n_out), P(out.ctypes.data))
+    assert st == 0, st
+    return out
+
+
+def seg_mel(tab, Pbins, n_out):
+    """Pbins [513] -> mel [n_out] through the lanes' store offsets, the row-wise gather and the U/D shift"""
+    hdr = tab[:16].view(np.int32)
+    assert hdr[0] == 0x5e67ab
+    rows, rA, rB, rC, s0, nseg = (int(v) for v in hdr[1:7])
+    addr = tab[16:16 + 9 * 64].view(np.int32).reshape(9, 64)
+    wt = tab[16 + 9 * 64:].astype(np.float64).reshape(rows, 64, 2)
+    buf = np.full(17 * 65 + 64, 1e30)                     # stale scratch: must only ever meet zero weights
+    seen = set()
+    for e in range(4):
+        k = (LANES >> 3) + 8 * (LANES & 7) + 64 * e
+        buf[addr[e]] = Pbins[k]
+        buf[addr[4 + e]] = Pbins[512 - k]
+        seen |= set(k.tolist()) | set((512 - k).tolist())
+    buf[addr[8][0]] = Pbins[256]
+    seen.add(256)
+    assert seen == set(range(513))
+    U = np.zeros((3, 64)); D = np.zeros((3, 64))
+    base = [0, rA, rA + rB]
+    for g, rg in enumerate((rA, rB, rC)):
+        for t in range(rg):
+            r = base[g] + t
+            w = wt[r]
+            pv = buf[r * 65 + LANES]
+            pv = np.where((w[:, 0] == 0) & (w[:, 1] == 0), 0.0, pv)      # 0 x stale = 0 in the kernel too (finite stale)
+            U[g] += w[:, 0] * pv
+            D[g] += w[:, 1] * pv
+    Uf, Df = U.reshape(-1), D.reshape(-1)                  # slot i = 64 g + lane  <->  segment s0 + i
+    mel = np.zeros(n_out)
+    for m in range(n_out):
+        iu, idn = m - s0, m + 1 - s0
+        if 0 <= iu < nseg:
+            mel[m] += Uf[iu]
+        if 0 <= idn < nseg:
+            mel[m] += Df[idn]
+    return mel

@@ -59,3 +59,29 @@ def test_mel_tiles_cover_the_filterbank(n_fft, n_mels, sr):
 def test_unsupported_sizes_are_refused():
     lib = _lib.load()
     assert lib.ias_stft_mtables_len(768, None, None, 0) == -2
+
+
+@pytest.mark.parametrize("n_mels,sr", [(128, 44100), (128, 16000), (80, 22050), (40, 16000), (23, 16000)])
+def test_segment_major_mel_tables(n_mels, sr):
+    """ias_stft_build_segtab: every bin is stored exactly once, stale scratch only meets zero weights, and the row-wise
+    gather + U/D shift reproduces P @ fb; filterbanks whose segments do not fit report 'unsupported' (-> CSR path)."""
+    lib = _lib.load()
+    fb = melscale_fbanks(513, 0.0, sr / 2, n_mels, sr).numpy()
+    tab = M.build_segtab(lib, 1024, _csr(fb))
+    if tab is None:
+        assert n_mels < 128       # wide filters: segments longer than the 17 rows of the scratch -> CSR path
+        return
+    rng = np.random.default_rng(3)
+    for _ in range(3):
+        Pb = rng.random(513)
+        got = M.seg_mel(tab, Pb, n_mels)
+        ref = Pb @ fb.astype(np.float64)
+        assert np.abs(got - ref).max() <= 1e-12 * max(ref.max(), 1.0)
+
+
+def test_segment_tables_refuse_non_triangular_filterbanks():
+    lib = _lib.load()
+    fb = np.zeros((513, 8), np.float32)
+    fb[10:40, 0] = 1.0
+    fb[10:40, 2] = 1.0            # two non-adjacent filters on the same bins
+    assert M.build_segtab(lib, 1024, _csr(fb)) is None
