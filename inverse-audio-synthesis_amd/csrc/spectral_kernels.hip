@@ -452,7 +452,7 @@ __device__ __forceinline__ float wave_shl1(float x, float fill) {
 }
 
 template <int SP_WAVES, bool MEL, int LOSS>
-__global__ __launch_bounds__(64 * SP_WAVES, (5 * SP_WAVES + 9) / 10) void stft2_kernel(const Spec2Args a) {
+__global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES >= 8 ? SP_WAVES / 2 : (3 * SP_WAVES + 3) / 4) void stft2_kernel(const Spec2Args a) {
   constexpr int SP_THREADS = 64 * SP_WAVES, N2 = 512, R = 8, SCR = 64 * 9;
   constexpr int NTAB = 8 + 8 + 8 + 4;     // cpx per lane: window pairs, pass-1 twiddles, pass-2 twiddles, unpack twiddles
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -509,6 +509,13 @@ __global__ __launch_bounds__(64 * SP_WAVES, (5 * SP_WAVES + 9) / 10) void stft2_
     if (more) { row_of(fi + nw, bnext, fnext); load_frame<R, N2>(a.audio + (size_t)bnext * a.T, a.T, a.hop, fnext, lane, xn); }
     float pscale = 0.25f;
     if (a.rowpeak != nullptr) { const float pkv = a.rowpeak[bcur]; if (pkv > 1.0f) { const float r = 1.0f / pkv; pscale = 0.25f * (r * r); } }
+    const size_t row = (size_t)fi * a.n_out;
+    // MEL: the frame's target row is requested now and consumed after the transform
+    float tgt_m[3] = {0.f, 0.f, 0.f};
+    if (MEL && LOSS != 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) if (64 * c + lane < a.n_out) tgt_m[c] = a.target[row + 64 * c + lane];
+    }
 
     // pass 1: radix 8 over n1 (points 64 n1 + lane), twiddle W_512^(lane k1), scatter to [k1][c][a]
     cpx v[R];
@@ -567,7 +574,11 @@ __global__ __launch_bounds__(64 * SP_WAVES, (5 * SP_WAVES + 9) / 10) void stft2_
       pmid = sqrtf(fmaxf(pmid, a.eps));
     }
     wave_lds_sync();   // every Z read is done: the power values overwrite the scratch
-    const size_t row = (size_t)fi * a.n_out;
+    auto emit_t = [&](int m, float val, float t) {
+      if (a.out != nullptr) a.out[row + m] = val;
+      if (LOSS == 1) l0 += fabsf(val - t);
+      else if (LOSS == 2) { const float d = t - val; l0 = fmaf(d, d, l0); l1 = fmaf(t, t, l1); l2 += fabsf(logf(val) - logf(t)); }
+    };
     auto emit = [&](int m, float val) {
       float t = 0.f;
       if (LOSS != 0) t = a.target[row + m];
@@ -608,7 +619,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, (5 * SP_WAVES + 9) / 10) void stft2_
             const float fill = c < 2 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(D[c < 2 ? c + 1 : 2]), 0)) : 0.f;
             val = U[c] + wave_shl1(D[c], fill);
           }
-          if (m < a.n_out) emit(m, val);
+          if (m < a.n_out) emit_t(m, val, tgt_m[c]);
         }
       }
     } else {
@@ -1018,7 +1029,10 @@ int ias_sm_launch(const float* audio, const float* mtab, bool mel, float* out, c
 // have_mtables: the ias_stft call will be given an ias_stft_build_mtables block (the matrix-core kernel writes one
 // record per 16-frame group and wave, the VALU kernel one per workgroup)
 // the round-3 radix-8 kernel (stft2_kernel): n_fft 1024; mel plans need their segment-major tables
-#define IAS_STFT2_WAVES 10
+static int stft2_waves() {
+  static const int env = getenv("IAS_STFT2_WAVES") ? atoi(getenv("IAS_STFT2_WAVES")) : 0;   // diagnostics: 4, 5, 8 or 10
+  return (env == 4 || env == 5 || env == 8 || env == 10) ? env : 8;
+}
 static bool stft2_enabled(int n_fft, bool mel, bool have_segtab) {
   static const int v1 = getenv("IAS_STFT_V1") ? atoi(getenv("IAS_STFT_V1")) : 0;   // diagnostics: round-2 kernel
   return !v1 && n_fft == 1024 && (!mel || have_segtab);
@@ -1031,8 +1045,10 @@ static int stft2_grid(long long nframes) {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
     ncu = v;
   }
-  const long long need = (nframes + IAS_STFT2_WAVES - 1) / IAS_STFT2_WAVES;
-  const long long cap = env > 0 ? env : 2LL * ncu;          // two 10-wave workgroups per CU = five waves per SIMD
+  const int waves = stft2_waves();
+  const long long need = (nframes + waves - 1) / waves;
+  // workgroups per CU by LDS (scratch 4.5 KB per wave + 25 KB of tables per workgroup): 10 waves: 2, 8: 2, 5: 3, 4: 3
+  const long long cap = env > 0 ? env : (waves >= 8 ? 2LL : 3LL) * ncu;
   return (int)(need < cap ? need : cap);
 }
 
@@ -1135,18 +1151,27 @@ extern "C" int ias_stft(const float* audio, const float* tables, const float* mt
     a2.partials = partials; a2.rowpeak = rowpeak; a2.T = T; a2.F = F; a2.hop = hop; a2.n_out = n_out; a2.nframes = B * F;
     a2.magicF = (unsigned)(0x100000000ULL / (unsigned long long)F);
     a2.value_mode = value_mode; a2.loss_mode = loss_mode; a2.eps = eps;
-    const size_t lds2 = sizeof(cpx) * (IAS_STFT2_WAVES * 64 * 9 + 28 * 64 + (mel ? IAS_SEG_MAX_ROWS * 64 : 0)) +
+    const int waves2 = stft2_waves();
+    const size_t lds2 = sizeof(cpx) * (waves2 * 64 * 9 + 28 * 64 + (mel ? IAS_SEG_MAX_ROWS * 64 : 0)) +
                         (mel ? sizeof(int) * 9 * 64 : 0);
-    const dim3 grid2(stft2_grid(a2.nframes)), block2(64 * IAS_STFT2_WAVES);
+    const dim3 grid2(stft2_grid(a2.nframes)), block2(64 * waves2);
+#define IAS_STFT2_LAUNCHW(W, MEL, LOSS)                                                                            \
+  do {                                                                                                             \
+    (void)hipFuncSetAttribute((const void*)stft2_kernel<W, MEL, LOSS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds2);                                                                          \
+    hipLaunchKernelGGL((stft2_kernel<W, MEL, LOSS>), grid2, block2, lds2, stream, a2);                             \
+  } while (0)
 #define IAS_STFT2_LAUNCH(MEL, LOSS)                                                                                \
   do {                                                                                                             \
-    (void)hipFuncSetAttribute((const void*)stft2_kernel<IAS_STFT2_WAVES, MEL, LOSS>,                               \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                              \
-    hipLaunchKernelGGL((stft2_kernel<IAS_STFT2_WAVES, MEL, LOSS>), grid2, block2, lds2, stream, a2);               \
+    if (waves2 == 4) IAS_STFT2_LAUNCHW(4, MEL, LOSS);                                                              \
+    else if (waves2 == 5) IAS_STFT2_LAUNCHW(5, MEL, LOSS);                                                         \
+    else if (waves2 == 8) IAS_STFT2_LAUNCHW(8, MEL, LOSS);                                                         \
+    else IAS_STFT2_LAUNCHW(10, MEL, LOSS);                                                                         \
   } while (0)
     if (mel) { if (loss_mode == 0) IAS_STFT2_LAUNCH(true, 0); else if (loss_mode == 1) IAS_STFT2_LAUNCH(true, 1); else IAS_STFT2_LAUNCH(true, 2); }
     else { if (loss_mode == 0) IAS_STFT2_LAUNCH(false, 0); else if (loss_mode == 1) IAS_STFT2_LAUNCH(false, 1); else IAS_STFT2_LAUNCH(false, 2); }
 #undef IAS_STFT2_LAUNCH
+#undef IAS_STFT2_LAUNCHW
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   }
 

@@ -21,7 +21,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$O/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0][:60]
-        if "stft_kernel" in k or "stft_mfma_kernel" in k:
+        if "stft_kernel" in k or "stft_mfma_kernel" in k or "stft2_kernel" in k:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(agg):
     print(k)
