@@ -50,6 +50,7 @@ def parse():
                     help="issue a step's PQMF / STFT right after its render instead of after the next render "
                          "(the round-1 issue order; see run_steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the short vicreg / gradstep legs behind the headline")
     ap.add_argument("--cpu-batch", type=int, default=32, help="voices in the CPU baseline sample")
     ap.add_argument("--replays", type=int, default=0,
                     help="timed regions of K steps each (0: as many as give >= 0.25 s of timed work, at least 20)")
@@ -291,6 +292,33 @@ def run_vicreg(args, rank, world, dev):
     return result
 
 
+def secondary_legs(args, dev):
+    """Short runs of the other workloads (bench.py --workload vicreg / gradstep) so that ONE default invocation carries
+    a driver-timed MFMA number and a configs[4] number: -> {"vicreg128": {...}, "vicreg1024": {...}, "gradstep": {...}}"""
+    import copy
+    legs = {}
+    for name, wl, batch, steps in (("vicreg128", "vicreg", 128, 20), ("vicreg1024", "vicreg", 1024, 10),
+                                   ("gradstep", "gradstep", 64, 5)):
+        a2 = copy.copy(args)
+        a2.workload, a2.batch, a2.steps, a2.warmup, a2.replays, a2.no_cpu_baseline = wl, batch, steps, 2, 10, True
+        t0 = time.perf_counter()
+        try:
+            r = (run_vicreg if wl == "vicreg" else run_gradstep)(a2, 0, 1, dev)
+            leg = {"ms_per_step": r["ms_per_step"], "ms_per_step_min": r["ms_per_step_min"], "steps": steps,
+                   "timed_regions": r["timed_regions"], "value": r["value"], "unit": r["unit"],
+                   "workload": r["config"]["workload"], "launch": r["config"]["launch"]}
+            rf = r["roofline"]
+            leg["roofline"] = {k: rf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
+                                                  "frac_nominal", "flops_executed", "algorithmic_bytes_per_step") if k in rf}
+        except Exception as e:  # noqa: BLE001 -- a failing leg must not take the headline line down
+            leg = {"error": f"{type(e).__name__}: {e}"}
+        leg["wall_s"] = round(time.perf_counter() - t0, 2)
+        legs[name] = leg
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return legs
+
+
 def run_gradstep(args, rank, world, dev):
     """BASELINE configs[4], one GPU's share (global batch 512 / 8): params -> Voice render -> {3-resolution MR-STFT loss,
     64-band PQMF sub-band L1} -> gradient w.r.t. the 78 normalised parameters, all HIP (render and its backward,
@@ -432,7 +460,20 @@ def main():
     voice.set_parameters01(params)
 
     ev = {"begin": [], "end": []}
+    cev = {"pqmf": [], "stft": []}      # (begin, end) HIP events on the consumers' own streams (in-step durations)
     instrument = {"on": False}
+
+    def bracket(name):
+        """with bracket("pqmf"): ... -- HIP events on the CURRENT stream around the launches inside (eager passes only)"""
+        class _B:
+            def __enter__(self_):
+                if instrument["on"]:
+                    self_.e0 = torch.cuda.Event(enable_timing=True); self_.e0.record()
+            def __exit__(self_, *exc):
+                if instrument["on"]:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                    cev[name].append((self_.e0, e1))
+        return _B()
 
     def hook(name, phase):
         if instrument["on"] and name == "oscillators":
@@ -477,12 +518,14 @@ def main():
             order = os.environ.get("IAS_BENCH_CONSUMERS", "parallel")   # diagnostics: how the two consumers are issued
             if order == "parallel":
                 with torch.cuda.stream(side_a):
-                    z = gram.analysis(audio.unsqueeze(1), rowpeak=peaks)
+                    with bracket("pqmf"):
+                        z = gram.analysis(audio.unsqueeze(1), rowpeak=peaks)
                     ea = side_a.record_event()
                 with torch.cuda.stream(side_b):
                     # the STFT queue bounds the step: the 6 us reduction of its partials goes to the control stream
-                    loss = mel_l1(audio, target_mel=target_mel, rowpeak=peaks,
-                                  reduce_stream=side_c if reduce_aside else None)
+                    with bracket("stft"):
+                        loss = mel_l1(audio, target_mel=target_mel, rowpeak=peaks,
+                                      reduce_stream=side_c if reduce_aside else None)
                     eb = side_b.record_event()
             else:
                 with torch.cuda.stream(side_a):
@@ -605,6 +648,7 @@ def main():
     # The bracket holds the kernel and the 90 KB memset of its ticket / aggregate words.
     def timed_pass(pipe):
         ev["begin"].clear(); ev["end"].clear()
+        cev["pqmf"].clear(); cev["stft"].clear()
         instrument["on"] = True
         torch.cuda.synchronize()
         run_steps(args.steps, pipe)
@@ -614,6 +658,32 @@ def main():
         return sum(ms) / len(ms)
 
     osc_ms_overlapped = timed_pass(pipelined)
+    instep_ms = {"render": osc_ms_overlapped}
+    for name in ("pqmf", "stft"):
+        ms_ = [b.elapsed_time(e) for b, e in cev[name]]
+        instep_ms[name] = sum(ms_) / len(ms_) if ms_ else None
+
+    def isolated_ms(fn):
+        """K back-to-back launches of one stage captured in a graph (no host launch gap inside), HIP events around the replay"""
+        fn(); fn()
+        torch.cuda.synchronize()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        try:
+            gk = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gk):
+                for _ in range(args.steps):
+                    fn()
+            gk.replay()
+            torch.cuda.synchronize()
+            a0.record(); gk.replay(); a1.record()
+        except Exception:  # noqa: BLE001
+            torch.cuda.synchronize()
+            a0.record()
+            for _ in range(args.steps):
+                fn()
+            a1.record()
+        torch.cuda.synchronize()
+        return a0.elapsed_time(a1) / args.steps
 
     # isolated: K back-to-back launches of the audio-rate stage alone (its 90 KB memset + the kernel, control
     # signals already in the workspace), captured in a graph so that no host launch gap falls inside the
@@ -641,17 +711,55 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * SECONDS * args.steps / elapsed
-    algo_bytes = RENDER_BYTES_PER_SAMPLE * B * T
-    achieved = algo_bytes / (osc_ms_avg * 1e-3) / 1e9
-    traffic = None
+
+    # ---- the three audio-rate kernels of the step, each alone (isolated) and inside the pipelined schedule (in-step):
+    # algorithmic HBM bytes per sample: render 8 (noise in + audio out), PQMF 8 (in + out),
+    # mel-L1 against a cached target 4 + 4 * n_mels / hop = 5
+    peaks0 = voice.peaks_view(workspaces[0])
+    plan = mel_l1.mel.plan
+    n_part = _lib.load().ias_stft_partials_count(B, T, plan.n_fft, plan.hop_length,
+                                                (0 if plan.mtables is None else 1) | 2 | (0 if plan.segtab is None else 4))
+    parts = torch.empty((n_part, 3), dtype=torch.float64, device=dev)
+    from inverse_audio_synthesis_amd.spectral import LOSS_L1, VALUE_POWER
+    iso_ms = {
+        "render": osc_ms_avg,
+        "pqmf": isolated_ms(lambda: gram.analysis(audio_bufs[0].unsqueeze(1), rowpeak=peaks0)),
+        "stft": isolated_ms(lambda: plan._call(audio_bufs[0], None, target_mel, parts, VALUE_POWER, LOSS_L1, 0.0, peaks0)),
+    }
+    bps = {"render": RENDER_BYTES_PER_SAMPLE, "pqmf": 8.0, "stft": 4.0 + 4.0 * plan.n_out / plan.hop_length}
+    knames = {"render": "voice_audio_kernel", "pqmf": "pqmf_analysis_pipe_kernel",
+              "stft": "stft2_kernel" if plan.n_fft == 1024 and os.environ.get("IAS_STFT_V1") != "1" else "stft_kernel"}
+    table = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             table = json.load(open(tpath))      # keys are rocprofv3 kernel names: "void voice_audio_kernel<0, true>"
-            hits = [v for k, v in table.items() if "voice_audio_kernel" in k and isinstance(v, dict)]
-            traffic = hits[0].get("hbm_bytes_per_launch") if hits else None
         except Exception:  # noqa: BLE001
-            traffic = None
+            table = {}
+
+    def pmc_traffic(kname):
+        hits = [v for k, v in table.items() if kname in k and isinstance(v, dict)]
+        return hits[0].get("hbm_bytes_per_launch") if hits else None
+
+    kernels = {}
+    for name in ("render", "pqmf", "stft"):
+        ab = bps[name] * B * T
+        gbs = ab / (iso_ms[name] * 1e-3) / 1e9
+        kernels[name] = {"kernel": knames[name], "algorithmic_bytes_per_launch": int(ab),
+                         "isolated_avg_us": round(iso_ms[name] * 1e3, 1),
+                         "in_step_avg_us": None if instep_ms[name] is None else round(instep_ms[name] * 1e3, 1),
+                         "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic(knames[name])}
+    # the dominant kernel of the TIMED schedule = the one with the largest in-step duration per step
+    dom = max(kernels, key=lambda n: kernels[n]["in_step_avg_us"] or 0.0)
+    chain_bytes = sum(bps.values()) * B * T          # 21 B here; SURVEY.md rounds the chain to 22 B/sample (497 MB)
+    chain_frac = 22.0 * B * T / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+    algo_bytes = kernels[dom]["algorithmic_bytes_per_launch"]
+    achieved = kernels[dom]["achieved_GBps"]
+    traffic = kernels[dom]["traffic"]
+    kdesc = {"render": "voice_audio_kernel (phase increments + chained fp64 scan + oscillators + mixer)",
+             "pqmf": "pqmf_analysis_pipe_kernel (PQMF(3) analysis on v_mfma_f32_16x16x4_f32)",
+             "stft": knames["stft"] + " (framed radix-8 FFT + power + mel projection + L1 against the cached target)"}
 
     result = {
         "metric": "audio-seconds rendered+lossed/sec (whole node), batch=128 4s@44.1kHz",
@@ -674,16 +782,27 @@ def main():
             "batch_per_gpu": B, "samples_per_voice": T, "launch": launch, "streams": 4, "pipelined": pipelined, "loss": loss_value,
         },
         "roofline": {
-            "kernel": "voice_audio_kernel (phase increments + chained fp64 scan + oscillators + mixer)",
+            "kernel": kdesc[dom],
+            "dominant_by": "largest in-step duration per step of the timed (pipelined) schedule",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_source": "imported from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                              "kernel, gfx950 x2 read correction); not measured by this run",
-            "avg_launch_ms": round(osc_ms_avg, 4), "algorithmic_bytes_per_launch": algo_bytes,
-            "measured": "HIP events around K back-to-back launches of the stage (memset + kernel), not overlapped",
-            "overlapped_avg_launch_ms": round(osc_ms_overlapped, 4),
+            "traffic_source": "imported from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the "
+                              "kernels, gfx950 x2 read correction); not measured by this run",
+            "avg_launch_ms": round(iso_ms[dom], 4), "algorithmic_bytes_per_launch": algo_bytes,
+            "measured": "HIP events around K back-to-back launches of the stage captured in a graph, on the stream it is "
+                        "launched on (isolated); in_step: events on the stage's own stream inside the pipelined schedule",
+            "overlapped_avg_launch_ms": None if instep_ms[dom] is None else round(instep_ms[dom], 4),
+            "kernels": kernels,
+            "chain_bytes_per_step": int(22.0 * B * T), "chain_bytes_listed_kernels": int(chain_bytes),
+            "chain_frac": round(chain_frac, 4),
+            "chain_frac_note": "22 B/sample (SURVEY.md 8d: render 8 + PQMF 8 + mel-L1 5, rounded up) x B x T / ms_per_step "
+                               "/ 8 TB/s: the whole step against the HBM roofline (north_star target 0.70)",
         },
     }
+    # ---- driver-timed secondary legs (N = 1 only, after the headline's timed regions, never inside them): the MFMA
+    # Gram of configs[2] / [3]'s loss and the configs[4] gradient step, a few hundred ms each
+    if rank == 0 and world == 1 and not args.no_legs:
+        result["legs"] = secondary_legs(args, dev)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only (bench contract)
             result["cpu_baseline"] = cpu_baseline(args.cpu_batch)
