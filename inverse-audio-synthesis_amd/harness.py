@@ -50,6 +50,11 @@ class VicregAudioParams(nn.Module):
                                        buffer_size_seconds=cfg.torchsynth.buffer_size_seconds)
         self.voice = Voice(synthconfig=self.synthconfig)
         self.logged = {}
+        # the trunk's 34 num_batches_tracked counters are bumped by ONE multi-tensor add per training forward of THIS
+        # module (installed here, before any forward, so the first step is not counted twice; a training-mode forward of
+        # vision_model outside _step must call self._bump_bn() itself)
+        from .vision import defer_bn_counters
+        self._bump_bn = defer_bn_counters(self.vision_model)
 
     def forward(self, audio, params):
         assert audio.ndim == 2 and params.ndim == 2 and audio.shape[0] == params.shape[0]
@@ -61,10 +66,7 @@ class VicregAudioParams(nn.Module):
             # outside the graph, with voice.randomize(batch))
             audio, params, _is_train = self.voice(None if batch is None else _batch_num(batch))
         x, y = self.forward(audio, params)
-        if self.training and audio.is_cuda:
-            if getattr(self, "_bump_bn", None) is None:
-                from .vision import defer_bn_counters
-                self._bump_bn = defer_bn_counters(self.vision_model)
+        if self.training:
             self._bump_bn()
         loss, repr_loss, std_loss, cov_loss = self.vicreg.loss(x, y)
         self.logged = {f"vicreg/{name}/loss": loss.detach(), f"vicreg/{name}/repr_loss": repr_loss.detach(),

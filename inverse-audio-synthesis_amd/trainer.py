@@ -141,23 +141,31 @@ class Trainer:
                 opt.step()
                 return
             self._graph = g
+            self._graph_logged = m.logged         # the metric tensors of the captured step (graph pool memory)
         g.replay()
+        # evaluate() rebinds module.logged to its own eager tensors; a replay re-runs no Python, so point it back at
+        # the tensors the replayed kernels write
+        m.logged = self._graph_logged
 
     def fit(self, max_steps=None):
         cfg, st = self.cfg, self.cfg[self.stage]
         lo, hi = split_sizes(cfg.num_batches, cfg.ntest_batches)["train"]
         # null / null = one epoch over the train split (what the reference's max_epochs=1 means), shared by the ranks
+        # `steps` is the TOTAL length of the run: a resumed trainer (load_checkpoint -> start_step) runs the remainder, with
+        # the global step number in checkpoint names and in the logging / validation cadence
         steps = max_steps or cfg.trainer.max_steps or st.limit_train_batches or (hi - lo) // self.world
-        start = getattr(self, "start_step", 0)
-        idx = split_indices(cfg.num_batches, cfg.ntest_batches, cfg.seed, steps, "train", self.rank, self.world,
-                            start=start * self.world) if steps <= 1 << 20 else None
+        start = min(getattr(self, "start_step", 0), steps)
+        todo = steps - start
+        idx = split_indices(cfg.num_batches, cfg.ntest_batches, cfg.seed, todo, "train", self.rank, self.world,
+                            start=start * self.world) if 0 < todo <= 1 << 20 else None
         val_every, val_count = st.get("val_check_interval"), st.get("limit_val_batches")
         self.module.train()
         t0 = time.perf_counter()
-        for step in range(steps):
-            batch = idx[step] if idx is not None else split_indices(
+        for i in range(todo):
+            step = start + i                      # global step
+            batch = idx[i] if idx is not None else split_indices(
                 cfg.num_batches, cfg.ntest_batches, cfg.seed, 1, "train", self.rank, self.world,
-                start=(start + step) * self.world)[0]
+                start=step * self.world)[0]
             if self._use_graph():
                 self._graph_step(batch, step)
             else:
@@ -168,7 +176,7 @@ class Trainer:
                 self.optimizer.step()
             if self.scheduler is not None:
                 self.scheduler.step()
-            self._step = start + step + 1
+            self._step = step + 1
             if step % int(cfg.trainer.log_every) == 0 or step == steps - 1:
                 self._log(step, {"elapsed_s": round(time.perf_counter() - t0, 3)})
             every = st.get("checkpoint_every_nbatches")

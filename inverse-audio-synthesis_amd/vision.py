@@ -4,14 +4,21 @@ The reference takes it from torchvision (/root/reference/vicreg_audio_params.py:
 ``mobilenet_v3_small(pretrained=...)``); torchvision is not in this image and there is no network, so
 the architecture (Howard et al. 2019, "small" table) is defined here with torchvision's module layout
 -- ``features.N``, ``.block``, ``fc1/fc2`` -- so torchvision state_dicts load by key.  Weights are
-random-initialised; ``pretrained=True`` only warns.  Convolutions run on MIOpen through PyTorch-ROCm
+random-initialised; ``pretrained=True`` only warns.  On a ROCm device in fp32 the depthwise, stem and thin 1x1
+convolutions, BatchNorm + activation and the squeeze-excitation blocks run on this repo's HIP kernels
+(csrc/conv_kernels.hip, pointwise_kernels.hip, bn_kernels.hip, se_kernels.hip), the wide 1x1 convolutions as
+rocBLAS / hipBLASLt GEMMs; everything else (CPU tensors, other dtypes, IAS_TRUNK_TORCH=1) takes the torch.nn layers
 (the trunk is a caller of the hot path, not part of it).
 """
+import os
 import warnings
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+# IAS_TRUNK_TORCH=1: every layer of the trunk takes its torch.nn fallback (MIOpen / rocBLAS): one switch for A/B debugging
+_TRUNK_TORCH = os.environ.get("IAS_TRUNK_TORCH") == "1"
 
 
 _PW_SUPPORTED = {}
@@ -76,7 +83,7 @@ class PointwiseConv2d(nn.Conv2d):
     per training step at batch 128 for the MobileNet body).  Elsewhere this is the plain nn.Conv2d."""
 
     def forward(self, x):
-        if x.is_cuda and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.groups == 1 and \
+        if x.is_cuda and not _TRUNK_TORCH and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.groups == 1 and \
                 x.dim() == 4 and x.is_contiguous():
             B, C, H, W = x.shape
             if self.bias is None and x.dtype == torch.float32 and _pw_mfma(C, self.out_channels):
@@ -139,7 +146,7 @@ class DepthwiseConv2d(nn.Conv2d):
 
     def forward(self, x):
         k, s = self.kernel_size[0], self.stride[0]
-        if x.is_cuda and x.dtype == torch.float32 and self.groups == self.in_channels == self.out_channels and \
+        if x.is_cuda and not _TRUNK_TORCH and x.dtype == torch.float32 and self.groups == self.in_channels == self.out_channels and \
                 self.bias is None and self.kernel_size in ((3, 3), (5, 5)) and self.stride in ((1, 1), (2, 2)) and \
                 self.padding == ((k - 1) // 2, (k - 1) // 2) and self.dilation == (1, 1):
             return _DepthwiseFn.apply(x, self.weight, k, s)
@@ -183,7 +190,7 @@ class StemConv2d(nn.Conv2d):
     it as an im2col plus a GEMM per sample -- the plain nn.Conv2d elsewhere."""
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32 and (self.in_channels, self.out_channels) == (3, 16) and \
+        if x.is_cuda and not _TRUNK_TORCH and x.dtype == torch.float32 and (self.in_channels, self.out_channels) == (3, 16) and \
                 self.kernel_size == (3, 3) and self.stride == (2, 2) and self.padding == (1, 1) and self.bias is None and \
                 self.groups == 1 and x.shape[0] <= 65535:
             return _StemFn.apply(x, self.weight)
@@ -245,12 +252,15 @@ class BatchNormAct2d(nn.BatchNorm2d):
         self.act_code = _ACT_CODE[act]
 
     def forward(self, x):
-        if self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and self.track_running_stats and \
+        if self.training and x.is_cuda and not _TRUNK_TORCH and x.dtype == torch.float32 and x.dim() == 4 and self.track_running_stats and \
                 self.momentum is not None and self.affine:
             if self.num_batches_tracked is not None and not getattr(self, "counter_deferred", False):
                 self.num_batches_tracked.add_(1)     # (deferred: one multi-tensor add for all layers, see defer_bn_counters)
             return _BNActFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                   self.momentum, self.act_code)
+        if self.training and getattr(self, "counter_deferred", False) and self.num_batches_tracked is not None:
+            # nn.BatchNorm2d bumps the counter itself: undo it here, the deferred multi-tensor add counts this forward
+            self.num_batches_tracked.sub_(1)
         y = super().forward(x)
         if self.act_code == 1:
             return F.relu(y)
@@ -353,7 +363,7 @@ class SqueezeExcitation(nn.Module):
         self.scale_activation = nn.Hardsigmoid()
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
+        if x.is_cuda and not _TRUNK_TORCH and x.dtype == torch.float32 and x.dim() == 4:
             return _SEFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
         s = self.scale_activation(self.fc2(self.activation(self.fc1(self.avgpool(x)))))
         return s * x

@@ -156,3 +156,86 @@ def test_pretrain_full_size_steps(lib, dev, tmp_path):
     assert sd["vicreg.projector.0.weight"].shape == (8192, 1024) and sd["audio_repr.conv1.weight"].shape == (1024, 1024, 2, 2)
     assert sd["vision_model.features.1.block.0.1.running_mean"].abs().sum() > 0   # BatchNorm statistics were updated
     assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+
+
+def test_two_rank_training_keeps_replicas_identical(lib, dev, tmp_path):
+    """conf/config.yaml:8 (strategy ddp) -> pretrain.py:97-99, vicreg_audio_params.py:117-120 (sync_dist metrics): two
+    freshly spawned ranks (children of this process, never a re-exec of it) share the GPU over gloo and run three
+    pretraining steps.  Replicas start from rank 0's parameters although they were built from different seeds, stay
+    bit-identical after every step, draw disjoint batch indices, log the mean of the ranks' metrics, and only rank 0
+    writes checkpoints."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    overrides = SMALL + ["trainer.max_steps=3", f"trainer.out_dir={tmp_path}", "trainer.cuda_graph=false"]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   IAS_DIST_BACKEND="gloo", IAS_MP_OUT=str(tmp_path), IAS_MP_OVERRIDES=json.dumps(overrides))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_trainer_child.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+    recs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    assert [r["world"] for r in recs] == [2, 2]
+    assert recs[0]["initial_digest"] == recs[1]["initial_digest"]              # broadcast at construction
+    assert len(recs[0]["steps"]) == 3
+    for s0, s1 in zip(recs[0]["steps"], recs[1]["steps"]):
+        assert s0["digest"] == s1["digest"], f"replicas diverged at step {s0['step']}"
+        for k in s0["local"]:
+            mean = 0.5 * (s0["local"][k] + s1["local"][k])
+            assert abs(s0["reduced"][k] - mean) <= 1e-6 * max(1.0, abs(mean))  # sync_dist=True
+            assert s0["reduced"][k] == s1["reduced"][k]
+    assert recs[0]["steps"][0]["digest"] != recs[0]["steps"][2]["digest"]      # the parameters did move
+    assert len(set(recs[0]["batches"]) | set(recs[1]["batches"])) == 6          # rank-strided, disjoint
+    assert recs[0]["checkpoint_written_by_this_rank"] and not recs[1]["checkpoint_written_by_this_rank"]
+    assert (tmp_path / "vicreg-last.ckpt").exists()
+
+
+def test_resume_continues_the_run(lib, dev, tmp_path):
+    """Trainer.load_checkpoint restores module, optimizer, scheduler and the step counter: a run cut after two of four
+    steps and resumed reproduces the uninterrupted run's remaining steps (same batches, same learning rates, same
+    losses), and numbers its steps and checkpoints globally."""
+    import os
+    from inverse_audio_synthesis_amd.config import load_config
+    from inverse_audio_synthesis_amd.harness import VicregAudioParams
+    from inverse_audio_synthesis_amd.trainer import Trainer
+    from conftest import ROOT
+    base = SMALL + ["trainer.cuda_graph=false", "param_embed.dropout=0.0", "vicreg.checkpoint_every_nbatches=1"]
+
+    def make(out):
+        cfg = load_config(os.path.join(ROOT, "conf"), "config", base + [f"trainer.out_dir={out}"])
+        torch.manual_seed(int(cfg.seed))
+        return Trainer(cfg, VicregAudioParams(cfg), stage="vicreg")
+
+    full = make(tmp_path / "full").fit(max_steps=4)
+    first = make(tmp_path / "cut")
+    first.fit(max_steps=2)
+    resumed = make(tmp_path / "cut")
+    ck = resumed.load_checkpoint(tmp_path / "cut" / "vicreg-last.ckpt")
+    assert ck["step"] == 2 and resumed.start_step == 2
+    hist = resumed.fit(max_steps=4)
+    assert [h["step"] for h in hist] == [2, 3]
+    for h, ref in zip(hist, full[2:]):
+        assert h["lr"] == ref["lr"]
+        assert abs(h["vicreg/train/loss"] - ref["vicreg/train/loss"]) <= 2e-3 * abs(ref["vicreg/train/loss"])
+    assert (tmp_path / "cut" / "vicreg-step000004.ckpt").exists() and not (tmp_path / "cut" / "vicreg-step000005.ckpt").exists()
+
+
+def test_train_metrics_survive_a_validation_inside_the_captured_loop(lib, dev, tmp_path):
+    """trainer.cuda_graph with val_check_interval < max_steps: evaluate() rebinds module.logged to its own tensors; the
+    replayed step must log the TRAIN metrics again afterwards (they keep changing), not the last validation batch."""
+    import pretrain
+    hist = pretrain.app(SMALL + ["trainer.max_steps=8", f"trainer.out_dir={tmp_path}", "trainer.cuda_graph=true",
+                                 "vicreg.val_check_interval=5", "vicreg.limit_val_batches=1"])
+    train = [h for h in hist if "vicreg/train/loss" in h]
+    assert [h["step"] for h in train] == list(range(8))
+    after = [h["vicreg/train/loss"] for h in train if h["step"] >= 5]
+    assert len(set(after)) == len(after), after          # three different steps, three different losses
+    assert any("vicreg/validation/loss" in h for h in hist)
