@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void vicreg_finish_kernel(const double* __rest
 
 // ------------------------------------------------------------------------ C ABI
 static inline size_t vc_align(size_t x) { return (x + 255) / 256 * 256; }
-struct VicregWs { size_t xt_x, xt_y, colstats, mse, hinge, gram_x, gram_y, xc_x, xc_y, bgram, bgram16, gdiag, total; int Kpad, ntile, ngram, nmse; };
+struct VicregWs { size_t xt_x, xt_y, colstats, mse, hinge, gram_x, gram_y, xc_x, xc_y, bgram, bgram16, gdiag, total; int Kpad, ntile, ngram, nmse, nsplit, ksplit; };
 static VicregWs vicreg_ws(int B, int D) {
   VicregWs w;
   w.Kpad = (B + GT - 1) / GT * GT;   // multiple of 128: the pair kernel's depth, the backward's batch tiles (zero padded)
@@ -602,7 +602,17 @@ static VicregWs vicreg_ws(int B, int D) {
   // backward: centred bf16 copies batch-major [Kpad][D], and the two B x B Grams [2][Kpad][Kpad] fp32
   w.xc_x = o;     o = vc_align(o + sizeof(unsigned short) * (size_t)D * w.Kpad);
   w.xc_y = o;     o = vc_align(o + sizeof(unsigned short) * (size_t)D * w.Kpad);
-  w.bgram = o;    o = vc_align(o + sizeof(float) * 2 * (size_t)w.Kpad * w.Kpad);
+  // the B x B Gram is contracted over D in `nsplit` slices (enough workgroups for the chip at any batch size), each
+  // slice writing its own partial Gram [nsplit][2][Kpad][Kpad]; vicreg_gconv_kernel adds them in slice order
+  {
+    const int bt = w.Kpad / GT, npair = bt * (bt + 1) / 2;
+    int nsplit = 512 / (2 * npair);
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > D / 256) nsplit = D / 256 > 0 ? D / 256 : 1;
+    w.ksplit = ((D + nsplit - 1) / nsplit + GK - 1) / GK * GK;
+    w.nsplit = (D + w.ksplit - 1) / w.ksplit;
+  }
+  w.bgram = o;    o = vc_align(o + sizeof(float) * 2 * (size_t)w.Kpad * w.Kpad * w.nsplit);
   w.bgram16 = o;  o = vc_align(o + sizeof(unsigned short) * 2 * (size_t)w.Kpad * w.Kpad);
   w.gdiag = o;    o = vc_align(o + sizeof(float) * 2 * (size_t)w.Kpad);
   w.total = o;
@@ -675,15 +685,78 @@ extern "C" int ias_vicreg_loss(const float* x, const float* y, float* out, void*
 // cotangents folded into a = g_loss sim + g_repr, b = g_loss std + g_std, c = g_loss cov + g_cov:
 //   grad_v = +-a 2 (x - y) / (B D)  -  b [s_j < 1] vc / (2 D (B - 1) s_j)  +  c kappa (G vc - vc m2_j),
 //   kappa = 4 / ((cfg_batch - 1)^2 D)          (the centring adjoint vanishes: every column of the sum is zero-mean)
-// Kernels: vicreg_bgram_kernel  G = Xc Xc^T on the matrix cores (bf16 in, fp32 accumulate), split over D, fp32 atomics;
+// Kernels: vicreg_bgram_kernel  G = Xc Xc^T on the matrix cores (bf16 in, fp32 accumulate), split over D into slices that
+//                               each write their own partial Gram (summed in slice order: deterministic);
 //          vicreg_grad_kernel   G vc as a second bf16 MFMA product (A = G cast to bf16, B = Xt) for x and y at once,
 //                               epilogue adds the elementwise terms from x, y and the column statistics, writes gx, gy.
 
-__global__ __launch_bounds__(256) void vicreg_bgram_kernel(const unsigned short* __restrict__ Xc_x,
-                                                           const unsigned short* __restrict__ Xc_y, float* __restrict__ G,
-                                                           int D, int Kpad, int ntile, int ksplit /* features per workgroup */) {
-  __shared__ __attribute__((aligned(16))) unsigned short s_a[GT][GLD];
-  __shared__ __attribute__((aligned(16))) unsigned short s_b[GT][GLD];
+// acc += A[row0 .. row0+127][k] B[col0 .. col0+127][k]^T over k in [kbeg, kend) (kbeg a multiple of GK, kend of 8), A / B bf16 row-major
+// with row strides lda / ldb; rows >= arows / brows and k >= kend read as zero.  The k loop is double-buffered as in vicreg_gram_kernel:
+// the next 64-deep chunk of both panels is fetched into registers while the matrix cores work on the current one and
+// written to the other LDS buffer afterwards (one barrier per chunk).
+__device__ __forceinline__ void vc_tile_product(const unsigned short* __restrict__ A, size_t lda, int arows,
+                                                const unsigned short* __restrict__ Bm, size_t ldb, int brows, int row0,
+                                                int col0, int kbeg, int kend, unsigned short (*s_a)[GT][GLD],
+                                                unsigned short (*s_b)[GT][GLD], f32x16 (&acc)[2][2]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
+  uint4 sta[4], stb[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (tid >> 3) + 32 * i, ch = tid & 7;
+      sta[i] = make_uint4(0, 0, 0, 0); stb[i] = make_uint4(0, 0, 0, 0);
+      const bool kin = k0 + ch * 8 + 8 <= kend;            // (kend % 8 == 0; a last chunk shorter than GK reads zeros)
+      if (kin && row0 + rr < arows) sta[i] = *reinterpret_cast<const uint4*>(A + (size_t)(row0 + rr) * lda + k0 + ch * 8);
+      if (kin && col0 + rr < brows) stb[i] = *reinterpret_cast<const uint4*>(Bm + (size_t)(col0 + rr) * ldb + k0 + ch * 8);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (tid >> 3) + 32 * i, ch = tid & 7;
+      *reinterpret_cast<uint4*>(&s_a[buf][rr][ch * 8]) = sta[i];
+      *reinterpret_cast<uint4*>(&s_b[buf][rr][ch * 8]) = stb[i];
+    }
+  };
+  __syncthreads();                         // the buffers may still be read by a previous product of this workgroup
+  fetch(kbeg);
+  commit(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
+    const bool more = k0 + GK < kend;
+    if (more) fetch(k0 + GK);
+#pragma unroll
+    for (int ks = 0; ks < GK / 16; ++ks) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        fa[m] = *reinterpret_cast<const bf16x8*>(&s_a[buf][wr * 64 + m * 32 + r][ks * 16 + h * 8]);
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        fb[n] = *reinterpret_cast<const bf16x8*>(&s_b[buf][wc * 64 + n * 32 + r][ks * 16 + h * 8]);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+    }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+// One upper-triangular 128 x 128 tile of one D-slice of G = Xc Xc^T per workgroup (grid: tiles x slices x branches).
+// The slice's partial tile (and its mirror image) is WRITTEN to that slice's own Gram, once: no atomics, nothing to
+// zero, and the sum over slices is taken in slice order by vicreg_gconv_kernel -- the backward is bit-reproducible
+// (the reference trains with deterministic=True, /root/reference/pretrain.py:100).
+__global__ __launch_bounds__(256, 2) void vicreg_bgram_kernel(const unsigned short* __restrict__ Xc_x,
+                                                              const unsigned short* __restrict__ Xc_y, float* __restrict__ Gp,
+                                                              int D, int Kpad, int ntile, int ksplit /* features per slice */) {
+  __shared__ __attribute__((aligned(16))) unsigned short s_a[2][GT][GLD];
+  __shared__ __attribute__((aligned(16))) unsigned short s_b[2][GT][GLD];
   int t = blockIdx.x, ti = 0;
   {
     int rowlen = ntile;
@@ -692,13 +765,11 @@ __global__ __launch_bounds__(256) void vicreg_bgram_kernel(const unsigned short*
   const int tj = ti + t;
   const int branch = blockIdx.z;
   const unsigned short* Xc = branch ? Xc_y : Xc_x;
-  float* Gb = G + (size_t)branch * Kpad * Kpad;
-  const int kbeg = blockIdx.y * ksplit, kend = min(kbeg + ksplit, D);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int r = lane & 31, h = lane >> 5;
+  float* Gb = Gp + ((size_t)blockIdx.y * 2 + branch) * Kpad * Kpad;
+  const int kbeg = blockIdx.y * ksplit, kend = min(kbeg + ksplit, D);   // D % 8 == 0 is checked on the host
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
   const int row0 = ti * GT, col0 = tj * GT;
-
   f32x16 acc[2][2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -706,38 +777,7 @@ __global__ __launch_bounds__(256) void vicreg_bgram_kernel(const unsigned short*
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
-
-  for (int k0 = kbeg; k0 < kend; k0 += GK) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rr = (tid >> 3) + 32 * i, ch = tid & 7;
-      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
-      if (k0 + ch * 8 + 8 <= D) {     // D % 8 == 0 is checked on the host
-        va = *reinterpret_cast<const uint4*>(Xc + (size_t)(row0 + rr) * D + k0 + ch * 8);
-        vb = *reinterpret_cast<const uint4*>(Xc + (size_t)(col0 + rr) * D + k0 + ch * 8);
-      }
-      *reinterpret_cast<uint4*>(&s_a[rr][ch * 8]) = va;
-      *reinterpret_cast<uint4*>(&s_b[rr][ch * 8]) = vb;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < GK / 16; ++ks) {
-      bf16x8 fa[2], fb[2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-        fa[m] = *reinterpret_cast<const bf16x8*>(&s_a[wr * 64 + m * 32 + r][ks * 16 + h * 8]);
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-        fb[n] = *reinterpret_cast<const bf16x8*>(&s_b[wc * 64 + n * 32 + r][ks * 16 + h * 8]);
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  // accumulate the partial tile (and its mirror image for tiles above the diagonal)
+  vc_tile_product(Xc, (size_t)D, Kpad, Xc, (size_t)D, Kpad, row0, col0, kbeg, kend, s_a, s_b, acc);
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -746,35 +786,38 @@ __global__ __launch_bounds__(256) void vicreg_bgram_kernel(const unsigned short*
       for (int e = 0; e < 16; ++e) {
         const int row = row0 + wr * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         const int col = col0 + wc * 64 + n * 32 + r;
-        atomicAdd(Gb + (size_t)row * Kpad + col, acc[m][n][e]);
-        if (ti != tj) atomicAdd(Gb + (size_t)col * Kpad + row, acc[m][n][e]);
+        Gb[(size_t)row * Kpad + col] = acc[m][n][e];
+        if (ti != tj) Gb[(size_t)col * Kpad + row] = acc[m][n][e];
       }
 }
 
-// G (fp32, both branches) -> bf16 with the diagonal taken out (it stays in fp32: gdiag[branch][b] = G_bb).  The diagonal
-// of G is 10-100x its off-diagonal entries and would carry its bf16 rounding (2^-9) straight into the dominant term
-// G_bb vc_bj of the gradient; the epilogue of vicreg_grad_kernel adds that term in fp32 instead.
-__global__ __launch_bounds__(256) void vicreg_gconv_kernel(const float* __restrict__ G, unsigned short* __restrict__ Gb,
-                                                           float* __restrict__ gdiag, int Kpad) {
+// G = sum over the D-slices of their partial Grams, in slice order (fp32, both branches) -> bf16 with the diagonal taken
+// out (it stays in fp32: gdiag[branch][b] = G_bb).  The diagonal of G is 10-100x its off-diagonal entries and would
+// carry its bf16 rounding (2^-9) straight into the dominant term G_bb vc_bj of the gradient; the epilogue of
+// vicreg_grad_kernel adds that term in fp32 instead.
+__global__ __launch_bounds__(256) void vicreg_gconv_kernel(const float* __restrict__ Gp, unsigned short* __restrict__ Gb,
+                                                           float* __restrict__ gdiag, int Kpad, int nsplit) {
   const size_t n = (size_t)2 * Kpad * Kpad;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const size_t q = i / ((size_t)Kpad * Kpad), rem = i - q * (size_t)Kpad * Kpad;
     const int row = (int)(rem / Kpad), col = (int)(rem - (size_t)row * Kpad);
-    const float v = G[i];
+    float v = 0.0f;
+    for (int sl = 0; sl < nsplit; ++sl) v += Gp[(size_t)sl * n + i];
     if (row == col) gdiag[q * Kpad + row] = v;
     Gb[i] = f2bf(row == col ? 0.0f : v);
   }
 }
 
-// One 128 (batch rows) x 128 (features) tile of gx and gy per workgroup.
-__global__ __launch_bounds__(256) void vicreg_grad_kernel(
+// One 128 (batch rows) x 128 (features) tile of gx and gy per workgroup: the two products (G - diag) vc of the branches
+// one after the other through the same double-buffered LDS panels, then the elementwise terms.
+__global__ __launch_bounds__(256, 2) void vicreg_grad_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const unsigned short* __restrict__ Xt_x,
     const unsigned short* __restrict__ Xt_y, const unsigned short* __restrict__ Gb, const float* __restrict__ gdiag,
     const float* __restrict__ colstats,
     const float* __restrict__ gcoef /* g_loss, g_repr, g_std, g_cov */, float* __restrict__ gx, float* __restrict__ gy,
     int B, int D, int Kpad, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff) {
-  __shared__ __attribute__((aligned(16))) unsigned short s_a[2][GT][GLD];   // G rows (bf16), per branch
-  __shared__ __attribute__((aligned(16))) unsigned short s_b[2][GT][GLD];   // Xt rows (features), per branch
+  __shared__ __attribute__((aligned(16))) unsigned short s_a[2][GT][GLD];   // G rows (bf16)
+  __shared__ __attribute__((aligned(16))) unsigned short s_b[2][GT][GLD];   // Xt rows (features)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int r = lane & 31, h = lane >> 5;
@@ -792,42 +835,8 @@ __global__ __launch_bounds__(256) void vicreg_grad_kernel(
       for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[q][m][n][e] = 0.f;
-
-  for (int k0 = 0; k0 < Kpad; k0 += GK) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const unsigned short* Gq = Gb + (size_t)q * Kpad * Kpad;
-      const unsigned short* Xt = q ? Xt_y : Xt_x;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rr = (tid >> 3) + 32 * i, ch = tid & 7;
-        *reinterpret_cast<uint4*>(&s_a[q][rr][ch * 8]) =
-            *reinterpret_cast<const uint4*>(Gq + (size_t)(row0 + rr) * Kpad + k0 + ch * 8);
-        uint4 vb = make_uint4(0, 0, 0, 0);
-        if (col0 + rr < D) vb = *reinterpret_cast<const uint4*>(Xt + (size_t)(col0 + rr) * Kpad + k0 + ch * 8);
-        *reinterpret_cast<uint4*>(&s_b[q][rr][ch * 8]) = vb;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int ks = 0; ks < GK / 16; ++ks) {
-        bf16x8 fa[2], fb[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-          fa[m] = *reinterpret_cast<const bf16x8*>(&s_a[q][wr * 64 + m * 32 + r][ks * 16 + h * 8]);
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-          fb[n] = *reinterpret_cast<const bf16x8*>(&s_b[q][wc * 64 + n * 32 + r][ks * 16 + h * 8]);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int n = 0; n < 2; ++n)
-            acc[q][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[q][m][n], 0, 0, 0);
-      }
-    __syncthreads();
-  }
+  vc_tile_product(Gb, (size_t)Kpad, Kpad, Xt_x, (size_t)Kpad, D, row0, col0, 0, Kpad, s_a, s_b, acc[0]);
+  vc_tile_product(Gb + (size_t)Kpad * Kpad, (size_t)Kpad, Kpad, Xt_y, (size_t)Kpad, D, row0, col0, 0, Kpad, s_a, s_b, acc[1]);
 
   // epilogue: elementwise terms.  C layout of a 32 x 32 block: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
   const float inv_bm1 = 1.0f / (float)(B - 1);
@@ -869,25 +878,17 @@ extern "C" int ias_vicreg_backward(const float* x, const float* y, const float* 
   const VicregWs w = vicreg_ws(B, D);
   if ((size_t)workspace_bytes < w.total) return IAS_ERR_WORKSPACE;
   char* ws = (char*)workspace;
-  float* G = (float*)(ws + w.bgram);
-  if (hipMemsetAsync(G, 0, sizeof(float) * 2 * (size_t)w.Kpad * w.Kpad, stream) != hipSuccess) return IAS_ERR_LAUNCH;
-  const int bt = w.Kpad / GT;                       // Kpad is a multiple of 128 whenever it exceeds 64... see below
+  float* G = (float*)(ws + w.bgram);                // [nsplit][2][Kpad][Kpad] partial Grams, every word written
+  const int bt = w.Kpad / GT;
   if (w.Kpad % GT) return IAS_ERR_UNSUPPORTED;
-  // split the contraction over D so that about two rounds of workgroups are in flight (every workgroup ends with
-  // 128 x 128 fp32 atomics, twice for tiles above the diagonal: fewer, longer workgroups for large batches)
   const int npair = bt * (bt + 1) / 2;
-  int nsplit = 512 / (2 * npair);
-  if (nsplit < 1) nsplit = 1;
-  if (nsplit > D / 256) nsplit = D / 256 > 0 ? D / 256 : 1;
-  const int ksplit = ((D + nsplit - 1) / nsplit + GK - 1) / GK * GK;
-  nsplit = (D + ksplit - 1) / ksplit;
-  hipLaunchKernelGGL(vicreg_bgram_kernel, dim3(npair, nsplit, 2), dim3(256), 0, stream, (const unsigned short*)(ws + w.xc_x),
-                     (const unsigned short*)(ws + w.xc_y), G, D, w.Kpad, bt, ksplit);
+  hipLaunchKernelGGL(vicreg_bgram_kernel, dim3(npair, w.nsplit, 2), dim3(256), 0, stream, (const unsigned short*)(ws + w.xc_x),
+                     (const unsigned short*)(ws + w.xc_y), G, D, w.Kpad, bt, w.ksplit);
   unsigned short* Gb = (unsigned short*)(ws + w.bgram16);
   float* gdiag = (float*)(ws + w.gdiag);
   int cgrid = (int)((2 * (size_t)w.Kpad * w.Kpad + 255) / 256);
   if (cgrid > 2048) cgrid = 2048;
-  hipLaunchKernelGGL(vicreg_gconv_kernel, dim3(cgrid), dim3(256), 0, stream, G, Gb, gdiag, w.Kpad);
+  hipLaunchKernelGGL(vicreg_gconv_kernel, dim3(cgrid), dim3(256), 0, stream, G, Gb, gdiag, w.Kpad, w.nsplit);
   hipLaunchKernelGGL(vicreg_grad_kernel, dim3((D + GT - 1) / GT, bt), dim3(256), 0, stream, x, y,
                      (const unsigned short*)(ws + w.xt_x), (const unsigned short*)(ws + w.xt_y), Gb, gdiag,
                      (const float*)(ws + w.colstats), gcoef, gx, gy, B, D, w.Kpad, cfg_batch, sim_coeff, std_coeff, cov_coeff);

@@ -121,8 +121,9 @@ def test_retrieval_finds_the_same_voice(lib, dev):
 
 def test_captured_step_reproduces_the_eager_loop(lib, dev, tmp_path):
     """trainer.cuda_graph=true replays render + forward + backward + LARS of a step as one hipGraph; host work (parameter
-    sampling, scheduler) stays outside.  Eight steps of the same small run must give the eager loop's losses, learning
-    rates and final weights up to the run-to-run noise of the VICReg backward's fp32 atomics."""
+    sampling, scheduler) stays outside.  Every reduction of the step has a fixed order (round 3: the VICReg backward's
+    split-K Gram writes per-slice partials instead of fp32 atomics; the reference trains with deterministic=True,
+    pretrain.py:100), so eight steps of the same small run give the eager loop's losses BIT FOR BIT."""
     import pretrain
     args = SMALL + ["trainer.max_steps=8", "param_embed.dropout=0.0"]
     h_e = pretrain.app(args + ["trainer.cuda_graph=false", f"trainer.out_dir={tmp_path / 'eager'}"])
@@ -130,13 +131,13 @@ def test_captured_step_reproduces_the_eager_loop(lib, dev, tmp_path):
     assert len(h_e) == len(h_g) == 8
     for a, b in zip(h_e, h_g):
         assert a["lr"] == b["lr"]
-        assert abs(a["vicreg/train/loss"] - b["vicreg/train/loss"]) <= 2e-3 * abs(a["vicreg/train/loss"]), (a, b)
+        for k in ("vicreg/train/loss", "vicreg/train/repr_loss", "vicreg/train/std_loss", "vicreg/train/cov_loss"):
+            assert a[k] == b[k], (k, a, b)
     assert h_e[0]["vicreg/train/loss"] != h_e[-1]["vicreg/train/loss"]          # the run did train
     se = torch.load(tmp_path / "eager" / "vicreg-last.ckpt", map_location="cpu")["state_dict"]
     sg = torch.load(tmp_path / "graph" / "vicreg-last.ckpt", map_location="cpu")["state_dict"]
     for k in ("audio_repr.conv7.weight", "vicreg.projector.0.weight", "vision_model.features.0.1.running_mean"):
-        d = (se[k] - sg[k]).abs().max().item()
-        assert d <= 2e-3 * max(1.0, se[k].abs().max().item()), (k, d)
+        assert torch.equal(se[k], sg[k]), k
 
 
 def test_pretrain_full_size_steps(lib, dev, tmp_path):

@@ -125,3 +125,18 @@ def test_full_size_properties(lib, dev):
         out2 = [o.item() for o in vicreg_loss(2.0 * x, 2.0 * y, B)]
         assert abs(out2[3] - 16.0 * out[3]) <= 1e-3 * 16.0 * out[3]
         assert abs(out2[1] - 4.0 * out[1]) <= 1e-5 * 4.0 * out[1]
+
+
+@pytest.mark.parametrize("B,D", [(128, 8192), (1024, 8192), (200, 1032)])
+def test_backward_is_bit_reproducible(lib, dev, B, D):
+    """The reference trains with deterministic=True (pretrain.py:100): the HIP backward has no float atomics -- the B x B
+    Gram's D-slices write their own partial tiles and are summed in slice order -- so repeated calls return identical bits."""
+    from inverse_audio_synthesis_amd.vicreg import vicreg_loss
+    x = (randn((B, D), 11) * 0.7).to(dev).requires_grad_()
+    y = (randn((B, D), 12) * 0.7 + 0.1).to(dev).requires_grad_()
+    grads = []
+    for _ in range(3):
+        out = vicreg_loss(x, y, B, 25.0, 25.0, 1.0)
+        grads.append(torch.autograd.grad(out[0], (x, y)))
+    for g in grads[1:]:
+        assert torch.equal(g[0], grads[0][0]) and torch.equal(g[1], grads[0][1])
