@@ -486,6 +486,11 @@ def main():
     # buffers and workspaces in flight the NEXT steps' renders run beside this step's PQMF / STFT.  All K steps and their
     # cross-stream dependencies are captured once into one hipGraph and replayed (issue order matters: see run_steps).
     side_a, side_b, side_c = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    # the small reduction of the STFT's loss partials gets a queue of its own: behind the STFT it lengthens the step's
+    # critical queue, on the control stream it made the NEXT step's control pass (and with it the next render) wait for
+    # the previous STFT (rocprofv3 timeline, profiles/r03b_trace_*: a 60 us bubble on the render queue per step)
+    side_d = torch.cuda.Stream()
+    red_stream = {"control": side_c, "own": side_d}.get(os.environ.get("IAS_BENCH_REDUCE_STREAM", "own"), side_d)
     nbuf = max(2, args.buffers)
     audio_bufs = [torch.empty((B, T), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     workspaces = [voice.new_workspace(dev) for _ in range(nbuf)]
@@ -499,6 +504,7 @@ def main():
         consumed = [None] * nbuf
         ws_free = [None] * nbuf     # audio pass that last read workspace[buf] has finished
         side_c.wait_stream(main)
+        side_d.wait_stream(main)
 
         def issue_control(i):
             # the small control-rate kernels of step i go to their own stream with a private workspace,
@@ -525,7 +531,7 @@ def main():
                     # the STFT queue bounds the step: the 6 us reduction of its partials goes to the control stream
                     with bracket("stft"):
                         loss = mel_l1(audio, target_mel=target_mel, rowpeak=peaks,
-                                      reduce_stream=side_c if reduce_aside else None)
+                                      reduce_stream=red_stream if reduce_aside else None)
                     eb = side_b.record_event()
             else:
                 with torch.cuda.stream(side_a):
@@ -580,6 +586,7 @@ def main():
         main.wait_stream(side_a)
         main.wait_stream(side_b)
         main.wait_stream(side_c)
+        main.wait_stream(side_d)
 
     def sync_all():
         torch.cuda.synchronize()

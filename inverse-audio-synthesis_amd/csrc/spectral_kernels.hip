@@ -20,10 +20,14 @@
 // scratch is 4.6 KB: with 4 waves a workgroup needs 36 KB and a CU holds 4 of them = 4 waves per SIMD; with 10 waves it
 // needs 66 KB and a CU holds 2 = 5 waves per SIMD (the kernel is bound by the latency of its LDS round trips, five per
 // frame, not by a unit: VALU and LDS are each ~50 % busy).  n_fft 1024 (<= 96 VGPRs) takes the 10-wave form.
-#define SP_WAVES_MAX 10
+// n_fft 2048: 9.2 KB of scratch per wave and 29 KB of tables: four-wave workgroups fit two to a CU (2 waves per SIMD
+// for a kernel bound by LDS round-trip latency); one 12-wave workgroup per CU gives 3 (the 164 VGPRs allow no more).
+#define SP_WAVES_MAX 12
 static int stft_waves(int n_fft) {
-  static const int env = getenv("IAS_STFT_WAVES") ? atoi(getenv("IAS_STFT_WAVES")) : 0;   // diagnostics: 8 or 10
-  return (n_fft == 1024 && (env == 8 || env == 10)) ? env : 4;
+  static const int env = getenv("IAS_STFT_WAVES") ? atoi(getenv("IAS_STFT_WAVES")) : 0;   // diagnostics: 4, 8, 10 or 12
+  if (n_fft == 1024) return (env == 8 || env == 10) ? env : 4;
+  if (n_fft == 2048) return env == 4 ? 4 : 12;
+  return 4;
 }
 
 // Complex numbers as 2-wide vectors: complex add/sub are one packed op and a complex multiply is pk_mul +
@@ -1005,7 +1009,7 @@ static size_t stft_lds_bytes(int n_fft, int mel_nnz, int n_out) {
 static int stft_groups(int B, int F, int n_fft) {
   const int waves = stft_waves(n_fft);
   static const int wgs_env = getenv("IAS_STFT_WGS") ? atoi(getenv("IAS_STFT_WGS")) : 0;   // diagnostics
-  int per_row = (wgs_env > 0 ? wgs_env : (waves == 10 ? 512 : (waves == 8 ? 512 : 1024))) / B;
+  int per_row = (wgs_env > 0 ? wgs_env : (waves == 12 ? 256 : (waves >= 8 ? 512 : 1024))) / B;
   if (per_row < 1) per_row = 1;
   int g = (F + per_row - 1) / per_row;
   const int gmin = 2 * waves, gmax = 32 * waves;
@@ -1199,7 +1203,7 @@ extern "C" int ias_stft(const float* audio, const float* tables, const float* mt
   else if (n_fft == 1024) {
     if (stft_waves(n_fft) == 10) IAS_STFT_LAUNCH(10, 10); else if (stft_waves(n_fft) == 8) IAS_STFT_LAUNCH(10, 8); else IAS_STFT_LAUNCH(10, 4);
   }
-  else IAS_STFT_LAUNCH(11, 4);
+  else { if (stft_waves(n_fft) == 12) IAS_STFT_LAUNCH(11, 12); else IAS_STFT_LAUNCH(11, 4); }
 #undef IAS_STFT_LAUNCH
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
