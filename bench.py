@@ -735,7 +735,7 @@ def main():
     }
     bps = {"render": RENDER_BYTES_PER_SAMPLE, "pqmf": 8.0, "stft": 4.0 + 4.0 * plan.n_out / plan.hop_length}
     knames = {"render": "voice_audio_kernel", "pqmf": "pqmf_analysis_pipe_kernel",
-              "stft": "stft2_kernel" if plan.n_fft == 1024 and os.environ.get("IAS_STFT_V1") != "1" else "stft_kernel"}
+              "stft": "stft2_kernel<8, true, 1>" if plan.n_fft == 1024 and os.environ.get("IAS_STFT_V1") != "1" else "stft_kernel"}
     table = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -766,7 +766,7 @@ def main():
     traffic = kernels[dom]["traffic"]
     kdesc = {"render": "voice_audio_kernel (phase increments + chained fp64 scan + oscillators + mixer)",
              "pqmf": "pqmf_analysis_pipe_kernel (PQMF(3) analysis on v_mfma_f32_16x16x4_f32)",
-             "stft": knames["stft"] + " (framed radix-8 FFT + power + mel projection + L1 against the cached target)"}
+             "stft": knames["stft"].split("<")[0] + " (framed radix-8 FFT + power + mel projection + L1 against the cached target)"}
 
     result = {
         "metric": "audio-seconds rendered+lossed/sec (whole node), batch=128 4s@44.1kHz",

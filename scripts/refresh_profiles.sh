@@ -60,5 +60,9 @@ step pmc voice; bash $R/scripts/diag/pmc_voice.sh $tag > /dev/null 2>&1; cp $R/g
 step pmc pqmf; bash $R/scripts/diag/pmc_pqmf.sh $tag N=3 > /dev/null 2>&1; cp $R/gpurun_out/pmcq_$tag/summary.txt $O/pmc_pqmf.txt
 step pmc vicreg; bash $R/scripts/diag/pmc_vicreg.sh $tag 128 > /dev/null 2>&1; cp $R/gpurun_out/pmcg_$tag/summary.txt $O/pmc_vicreg.txt
 step kstats pretrain; bash $R/scripts/diag/kstats_pretrain.sh $tag > $O/kstats_pretrain.txt 2>&1
+step pmc stft; bash $R/scripts/diag/pmc_stft.sh $tag PARTS=loss > /dev/null 2>&1; cp $R/gpurun_out/pmcs_$tag/summary.txt $O/pmc_stft.txt
+step trace; bash $R/scripts/diag/trace_bench.sh $tag > $O/trace_default.txt 2>&1
+step microbench; $R/scripts/diag/_bin/mfma_valu_overlap > $O/mfma_valu_overlap.txt 2>&1; $R/scripts/diag/_bin/mfma_valu_inwave > $O/mfma_valu_inwave.txt 2>&1
+step parity; IAS_PARITY_OUT=$O python3 -m pytest $R/tests/test_voice_gpu.py -q -k headline_size > $O/parity_test.log 2>&1
 step done
 head -c 600 $O/bench_default.json; echo
