@@ -108,3 +108,38 @@ def test_mrstft_cached_targets_equal_recomputed(lib, dev):
     assert torch.equal(m(x, y), m(x, targets=tg))
     with pytest.raises(AssertionError):
         m(x)
+
+
+@pytest.mark.parametrize("env", [{"IAS_STFT_MFMA": "1"}, {"IAS_STFT_V1": "1"}])
+def test_alternative_stft_kernels_in_a_child_process(lib, dev, env):
+    """The kernel choice is read once per process from the environment: the opt-in matrix-core kernel (IAS_STFT_MFMA=1,
+    DESIGN.md section 0) and the round-2 kernel (IAS_STFT_V1=1) are checked in a child process (a fresh interpreter, not a
+    re-exec of this one) against the same oracle and tolerances as the default kernel: mel spectrogram, raw power
+    spectrogram with a hop that is not a multiple of four samples, and the fused mel-L1 loss."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import sys, torch
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+from oracle import spectral_oracle as spo
+from helpers import randn
+from inverse_audio_synthesis_amd.spectral import MelSpectrogram, MelSpectrogramL1, STFTPlan, VALUE_POWER
+dev = torch.device("cuda:0")
+x = randn((3, 20000), 7) * 0.5
+def close(a, ref, tol=1e-4):
+    assert (a - ref).abs().max().item() <= tol * ref.abs().max().item()
+close(MelSpectrogram(sample_rate=44100).to(dev)(x.to(dev)).cpu(), spo.mel_spectrogram(x, sample_rate=44100))
+for hop in (512, 50):
+    plan = STFTPlan(1024, None, hop).to(dev)
+    close(plan.values(x.to(dev), VALUE_POWER).transpose(1, 2).cpu(), spo.spectrogram(x, 1024, None, hop, 2.0))
+a, b = randn((4, 16000), 1) * 0.2, randn((4, 16000), 2) * 0.3
+got = MelSpectrogramL1(sample_rate=16000).to(dev)(a.to(dev), b.to(dev)).item()
+ref = spo.mel_l1(a, b, sample_rate=16000).item()
+assert abs(got - ref) <= 1e-3 * abs(ref), (got, ref)
+print("child ok")
+'''.replace("ROOT", repr(ROOT))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:]
