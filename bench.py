@@ -734,7 +734,8 @@ def main():
         "stft": isolated_ms(lambda: plan._call(audio_bufs[0], None, target_mel, parts, VALUE_POWER, LOSS_L1, 0.0, peaks0)),
     }
     bps = {"render": RENDER_BYTES_PER_SAMPLE, "pqmf": 8.0, "stft": 4.0 + 4.0 * plan.n_out / plan.hop_length}
-    knames = {"render": "voice_audio_kernel", "pqmf": "pqmf_analysis_pipe_kernel",
+    knames = {"render": "voice_audio_kernel",
+              "pqmf": "pqmf_analysis_pipe_kernel" if os.environ.get("IAS_PQMF_NOMOD") else "pqmf_analysis_mod_kernel",
               "stft": "stft2_kernel<8, true, 1>" if plan.n_fft == 1024 and os.environ.get("IAS_STFT_V1") != "1" else "stft_kernel"}
     table = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -765,7 +766,8 @@ def main():
     achieved = kernels[dom]["achieved_GBps"]
     traffic = kernels[dom]["traffic"]
     kdesc = {"render": "voice_audio_kernel (phase increments + chained fp64 scan + oscillators + mixer)",
-             "pqmf": "pqmf_analysis_pipe_kernel (PQMF(3) analysis on v_mfma_f32_16x16x4_f32)",
+             "pqmf": knames["pqmf"] + " (PQMF(3) analysis" + (" in its cosine-modulated form)" if "mod" in knames["pqmf"]
+                                                                 else " on v_mfma_f32_16x16x4_f32)"),
              "stft": knames["stft"].split("<")[0] + " (framed radix-8 FFT + power + mel projection + L1 against the cached target)"}
 
     result = {

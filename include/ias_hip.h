@@ -111,17 +111,27 @@ int ias_voice_control_backward(const float* params01, const float* g_ctrl, const
 int ias_pqmf_packed_taps_len(int N, int K);
 int ias_pqmf_pack_taps(const float* H, float* packed, int N, int K, void* stream);
 
+/* HOST helper: N = 3, K = 63 filters that are the cosine modulation pqmf.py:21-30 builds (H[k][j] = g[j] c_k[j]) ->
+ * the 52 signed prototype taps of the modulated-form kernel, out_host [ias_pqmf_modtab_len() = 64] (copy to the
+ * device once); IAS_ERR_UNSUPPORTED for any other H (then pass modtab = NULL). */
+int ias_pqmf_modtab_len(void);
+int ias_pqmf_build_modtab(const float* H_host, int N, int K, float* out_host);
+
 /* analysis: x [B,T] (= [B,1,T]), H [N,K] (= buffer H[N,1,K]) -> z [B,N,L]   (pqmf.py:49-50).
+ * modtab != NULL (N = 3, K = 63, the device copy of ias_pqmf_build_modtab(H)): the filterbank is evaluated in its
+ * cosine-modulated form (five alternating-sign prototype sums + a 3-point modulation per frame: ~60 instead of 189
+ * multiply-adds; agrees with the tap-ordered chain to ~3e-8 of the output scale, not bit for bit), any alignment.
+ * modtab == NULL:
  * K = 63 with N = 3 or 64, x 16-byte aligned and T % 4 == 0: the filterbank runs on the fp32 matrix cores
  * (v_mfma_f32_16x16x4_f32, exact fp32; N = 3 with z 16-byte aligned and L % 4 == 0: the wave-pipelined kernel) and
  * `packed` is not read.  Otherwise: packed = the ias_pqmf_pack_taps table of H (fast / wide VALU kernels), or NULL
- * (generic one-lane-per-output kernel, 10-100x slower).  Every path evaluates the same tap-ordered fmaf chain per
- * output: results are bit-identical across them.
+ * (generic one-lane-per-output kernel, 10-100x slower).  Every modtab == NULL path evaluates the same tap-ordered fmaf
+ * chain per output: results are bit-identical across them.
  * mean/stdv [N] (both or neither, may be NULL): fused (z - mean[k]) / stdv[k] of
  * AudioEmbedding._preprocess (reference audioembed.py:41,49).
  * rowpeak [B] (may be NULL): row peaks of x; the result is the analysis of x[b] / rowpeak[b] where rowpeak[b] > 1
  * (torchsynth normalize_if_clipping folded in, see ias_voice_peaks_offset). */
-int ias_pqmf_analysis(const float* x, const float* H, const float* packed, float* z, const float* mean,
+int ias_pqmf_analysis(const float* x, const float* H, const float* packed, const float* modtab, float* z, const float* mean,
                       const float* stdv, const float* rowpeak, int B, int T, int N, int K, void* stream);
 
 /* synthesis: z [B,N,L], G [N,K] (= buffer G[1,N,K]) -> out [B, L*N] (= [B,1,L*N])   (pqmf.py:52-55). */

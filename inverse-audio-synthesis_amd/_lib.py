@@ -44,7 +44,9 @@ SYMBOLS = {
     "ias_pqmf_out_len": (_I, [_I, _I, _I]),
     "ias_pqmf_packed_taps_len": (_I, [_I, _I]),
     "ias_pqmf_pack_taps": (_I, [_P, _P, _I, _I, _P]),
-    "ias_pqmf_analysis": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_pqmf_modtab_len": (_I, []),
+    "ias_pqmf_build_modtab": (_I, [_P, _I, _I, _P]),
+    "ias_pqmf_analysis": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_pqmf_synth_taps_len": (_I, [_I, _I]),
     "ias_pqmf_pack_synth_taps": (_I, [_P, _P, _I, _I, _P]),
     "ias_pqmf_synthesis": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

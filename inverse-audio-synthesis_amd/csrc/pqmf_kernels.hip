@@ -951,6 +951,127 @@ static int pqmf_resident_blocks() {
   return blocks;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// N = 3, K = 63 as a cosine-MODULATED filterbank (round 3).  pqmf.py:21-30 builds H[k][j] = g[j] c_k[j], g = 2 x the
+// Kaiser prototype, c_k[j] = cos((2k+1) pi/6 (j - 30.5) + (-1)^k pi/4).  For N = 3 that cosine only takes the values
+// 0, +-1/2, +-sqrt(3)/2, +-1, repeats with period 12 in j, changes sign every 6 and vanishes for j = 2 (mod 6):
+//     v_r[f] = sum_t (-1)^t g[r + 6t] x[3f + r + 6t - 31],   r in {0, 1, 3, 4, 5}            (52 products per frame)
+//     z_0 = A + C,  z_2 = A - C,  z_1 = (v_3 - v_1) - v_5,   A = sqrt(3)/2 (v_4 - v_0),  C = (v_3 - v_1)/2 + v_5
+// i.e. ~60 vector instructions per frame where the three 63-tap correlations take 189 multiply-adds (243 issue slots
+// in the 16x16x4 MFMA form, which -- DESIGN.md section 0 -- are vector-pipe time as well).  The sums are the same real
+// numbers in another order and with the constants factored out: they agree with the tap-ordered chain to ~3e-8 of the
+// output scale (not bit for bit; the reference's conv1d has no defined summation order either).
+// A lane owns 4 consecutive frames: its 72-sample window comes out of the wave's LDS staging as 18 aligned 16-byte
+// reads at a 48-byte lane stride (conflict-free), the 52 signed prototype taps sit in scalar registers.
+#define PQD_FPL 4                       // frames per lane
+#define PQD_WF (64 * PQD_FPL)           // frames per wave tile
+#define PQD_STAGE (3 * PQD_WF + 64)     // staged samples per wave tile (3 per frame + 60 of halo, rounded up)
+#define PQD_NLOAD ((PQD_STAGE + 63) / 64)
+extern "C" int ias_pqmf_modtab_len() { return 64; }
+// H_host [3][63] (host copy of PQMF(3).H) -> out_host [64]: a[r5][t] = (-1)^t g[r + 6t] at r5 * 11 + t for
+// r = (0, 1, 3, 4, 5)[r5]; IAS_ERR_UNSUPPORTED unless H is this modulation of ONE prototype to 2e-6 of its largest tap.
+extern "C" int ias_pqmf_build_modtab(const float* H_host, int N, int K, float* out_host) {
+  if (!H_host || !out_host) return IAS_ERR_ARG;
+  if (N != 3 || K != 63) return IAS_ERR_UNSUPPORTED;
+  double c[3][12], hmax = 0.0;
+  for (int k = 0; k < 3; ++k)
+    for (int r = 0; r < 12; ++r)
+      c[k][r] = cos((2 * k + 1) * (3.14159265358979323846 / 6.0) * ((double)r - 30.5) + ((k & 1) ? -1.0 : 1.0) * 0.78539816339744830962);
+  for (int i = 0; i < 3 * 63; ++i) hmax = fmax(hmax, fabs((double)H_host[i]));
+  double g[63];
+  for (int j = 0; j < 63; ++j) {
+    const int r = j % 12;
+    // the prototype from the band whose modulation is largest at this tap
+    int kb = 0;
+    for (int k = 1; k < 3; ++k) if (fabs(c[k][r]) > fabs(c[kb][r])) kb = k;
+    g[j] = fabs(c[kb][r]) > 0.4 ? (double)H_host[kb * 63 + j] / c[kb][r] : 0.0;
+    for (int k = 0; k < 3; ++k)
+      if (fabs((double)H_host[k * 63 + j] - g[j] * c[k][r]) > 2e-6 * hmax) return IAS_ERR_UNSUPPORTED;
+  }
+  for (int i = 0; i < 64; ++i) out_host[i] = 0.0f;
+  const int rs[5] = {0, 1, 3, 4, 5};
+  for (int r5 = 0; r5 < 5; ++r5)
+    for (int t = 0; rs[r5] + 6 * t < 63; ++t) out_host[r5 * 11 + t] = (float)((t & 1) ? -g[rs[r5] + 6 * t] : g[rs[r5] + 6 * t]);
+  return IAS_OK;
+}
+
+template <bool NORM>
+__global__ __launch_bounds__(PQ_THREADS, 4) void pqmf_analysis_mod_kernel(
+    const float* __restrict__ x, const float* __restrict__ modtab, float* __restrict__ z, const float* __restrict__ mean,
+    const float* __restrict__ stdv, const float* __restrict__ rowpeak, int T, int L, int tiles_x, int ntiles, int zvec) {
+  __shared__ __attribute__((aligned(16))) float s_stage[PQ_THREADS / 64][PQD_STAGE];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* st = s_stage[wave];
+  const int nwaves = gridDim.x * (PQ_THREADS / 64);
+  int tile = blockIdx.x * (PQ_THREADS / 64) + wave;
+
+  // the staged samples of wave tile `t`: x[b][3 f0 - 31 + q], q = lane + 64 i, zero outside the row
+  float nx[PQD_NLOAD];
+  auto fetch = [&](int t) {
+    const int b = t / tiles_x, ft = t - b * tiles_x;
+    const float* xrow = x + (size_t)b * T;
+    const int base = 3 * PQD_WF * ft - 31;
+#pragma unroll
+    for (int i = 0; i < PQD_NLOAD; ++i) {
+      const int idx = base + lane + 64 * i;
+      nx[i] = (idx >= 0 && idx < T) ? xrow[idx] : 0.0f;
+    }
+  };
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += nwaves) {
+    const int b = tile / tiles_x, ft = tile - b * tiles_x;
+#pragma unroll
+    for (int i = 0; i < PQD_NLOAD; ++i)
+      if (lane + 64 * i < PQD_STAGE) st[lane + 64 * i] = nx[i];
+    if (tile + nwaves < ntiles) fetch(tile + nwaves);     // in flight while this tile is computed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the lane's window: samples 12 lane .. 12 lane + 71 of the stage
+    float w[72];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      const pq_f32x4 q = *reinterpret_cast<const pq_f32x4*>(st + 12 * lane + 4 * i);
+      w[4 * i] = q[0]; w[4 * i + 1] = q[1]; w[4 * i + 2] = q[2]; w[4 * i + 3] = q[3];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                     // every read precedes the next tile's staging stores
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float rsc = pqmf_row_scale(rowpeak, b);
+    float o[3][PQD_FPL];
+    constexpr int rs[5] = {0, 1, 3, 4, 5};
+#pragma unroll
+    for (int i = 0; i < PQD_FPL; ++i) {
+      float v[5];
+#pragma unroll
+      for (int r5 = 0; r5 < 5; ++r5) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int t = 0; rs[r5] + 6 * t < 63; ++t) acc = fmaf(modtab[r5 * 11 + t], w[3 * i + rs[r5] + 6 * t], acc);
+        v[r5] = acc;
+      }
+      const float d31 = v[2] - v[1];                      // v_3 - v_1
+      const float A = 0.86602540378443865f * (v[3] - v[0]);
+      const float C = fmaf(0.5f, d31, v[4]);
+      const float z0 = A + C, z1 = d31 - v[4], z2 = A - C;
+      o[0][i] = pqmf_finish(z0, rsc, NORM, NORM ? mean[0] : 0.0f, NORM ? stdv[0] : 1.0f);
+      o[1][i] = pqmf_finish(z1, rsc, NORM, NORM ? mean[1] : 0.0f, NORM ? stdv[1] : 1.0f);
+      o[2][i] = pqmf_finish(z2, rsc, NORM, NORM ? mean[2] : 0.0f, NORM ? stdv[2] : 1.0f);
+    }
+    const int f0 = PQD_WF * ft + PQD_FPL * lane;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float* zr = z + ((size_t)b * 3 + k) * L + f0;
+      if (zvec && f0 + PQD_FPL <= L) *reinterpret_cast<pq_f32x4*>(zr) = (pq_f32x4){o[k][0], o[k][1], o[k][2], o[k][3]};
+      else {
+#pragma unroll
+        for (int i = 0; i < PQD_FPL; ++i) if (f0 + i < L) zr[i] = o[k][i];
+      }
+    }
+  }
+}
+
 // Floats of the transposed tap table (whole polyphase steps, whole pairs); 0 when (N, K) has no fast path.
 extern "C" int ias_pqmf_packed_taps_len(int N, int K) {
   if (N == 3 && K == 63) return PqmfFast<3, 63>::TABLE;
@@ -984,8 +1105,9 @@ extern "C" int ias_pqmf_out_len(int T, int N, int K) {
 // NULL, or an (N, K) for which ias_pqmf_packed_taps_len is 0, runs the generic one-lane-per-output kernel.
 // rowpeak: optional [B] row peaks max |x| (ias_voice_render's workspace, ias_voice_peaks_offset): the analysis of the
 // row normalised as torchsynth's normalize_if_clipping would, without the normalised audio ever being written.
-extern "C" int ias_pqmf_analysis(const float* x, const float* H, const float* packed, float* z, const float* mean,
-                                 const float* stdv, const float* rowpeak, int B, int T, int N, int K, void* stream_) {
+extern "C" int ias_pqmf_analysis(const float* x, const float* H, const float* packed, const float* modtab, float* z,
+                                 const float* mean, const float* stdv, const float* rowpeak, int B, int T, int N, int K,
+                                 void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !H || !z || B <= 0 || B > 65535 || N <= 0 || N > 65535 || K <= 0 || (K & 1) == 0) return IAS_ERR_ARG;
   if ((mean == nullptr) != (stdv == nullptr)) return IAS_ERR_ARG;
@@ -994,7 +1116,21 @@ extern "C" int ias_pqmf_analysis(const float* x, const float* H, const float* pa
   if (L <= 0) return IAS_ERR_ARG;
   if (packed && ((uintptr_t)packed & 7)) return IAS_ERR_ARG;
   static const bool force_valu = getenv("IAS_PQMF_VALU") != nullptr;   // diagnostics: the pre-MFMA kernels
-  if (!force_valu && K == 63 && (N == 3 || N == 64) && T >= 4 && (T & 3) == 0 && ((uintptr_t)x & 15) == 0 &&
+  static const bool no_mod = getenv("IAS_PQMF_NOMOD") != nullptr;      // diagnostics: never the modulated form
+  if (modtab && !no_mod && !force_valu && N == 3 && K == 63 && (long long)B * N * L < 0x7fffff00LL) {
+    // the cosine-modulated form: any alignment, any T
+    const int zvec = ((uintptr_t)z & 15) == 0 && (L & 3) == 0;
+    const int tiles_x = (L + PQD_WF - 1) / PQD_WF;
+    const long long ntiles = (long long)tiles_x * B;
+    if (ntiles > 0x7fffffffLL) return IAS_ERR_ARG;
+    const long long wgs = (ntiles + PQ_THREADS / 64 - 1) / (PQ_THREADS / 64);
+    const long long res = pqmf_resident_blocks();
+    const int grid = (int)(wgs < res ? wgs : res);
+    if (mean) hipLaunchKernelGGL(pqmf_analysis_mod_kernel<true>, dim3(grid), dim3(PQ_THREADS), 0, stream, x, modtab, z, mean,
+                                 stdv, rowpeak, T, L, tiles_x, (int)ntiles, zvec);
+    else hipLaunchKernelGGL(pqmf_analysis_mod_kernel<false>, dim3(grid), dim3(PQ_THREADS), 0, stream, x, modtab, z, mean,
+                            stdv, rowpeak, T, L, tiles_x, (int)ntiles, zvec);
+  } else if (!force_valu && K == 63 && (N == 3 || N == 64) && T >= 4 && (T & 3) == 0 && ((uintptr_t)x & 15) == 0 &&
       (long long)L * N + 4 * K < 0x7fffffffLL) {
     const int zvec = ((uintptr_t)z & 15) == 0 && (L & 3) == 0;
 #define IAS_PQM_LAUNCH(NN, SS, RTT, PSHH, PERCU)                                                                  \

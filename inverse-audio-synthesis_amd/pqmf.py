@@ -46,6 +46,36 @@ def _packed_taps(H, Hc, N, K):
     return hit[1]
 
 
+# N = 3: evaluate the filterbank in its cosine-modulated form (csrc/pqmf_kernels.hip: pqmf_analysis_mod_kernel) when H is
+# that modulation of one prototype (it is for every PQMF(3) this module builds); False: the tap-ordered kernels
+USE_MODULATED = True
+_MODTAB_CACHE = {}
+
+
+def _modulated_taps(H, Hc, N, K):
+    """Device table of the modulated-form kernel for this H, or None (other N / K, H not a cosine modulation).  Built
+    once per (tensor, version): the first call reads H back to the host."""
+    if not USE_MODULATED or N != 3 or K != 63:
+        return None
+    key = (Hc.data_ptr(), H._version, str(Hc.device))
+    hit = _MODTAB_CACHE.get(key)
+    if hit is None:
+        import ctypes
+        lib = _lib.load()
+        host = Hc.detach().to("cpu", torch.float32).contiguous()
+        out = torch.empty(lib.ias_pqmf_modtab_len(), dtype=torch.float32)
+        st = lib.ias_pqmf_build_modtab(ctypes.c_void_p(host.data_ptr()), N, K, ctypes.c_void_p(out.data_ptr()))
+        if st == -2:
+            hit = (None,)
+        else:
+            _lib.check(st, "ias_pqmf_build_modtab")
+            hit = (out.to(Hc.device),)
+        if len(_MODTAB_CACHE) > 64:
+            _MODTAB_CACHE.clear()
+        _MODTAB_CACHE[key] = hit
+    return hit[0]
+
+
 class _AnalysisFn(torch.autograd.Function):
     """PQMF analysis, differentiable w.r.t. the audio.  The adjoint of the strided correlation
     z[k,f] = sum_j H[k,j] x[N f + j - pad] is the polyphase synthesis kernel run with the time-reversed filters and
@@ -98,7 +128,8 @@ def _analysis_nograd(x, H, mean=None, std=None, rowpeak=None):
     L = lib.ias_pqmf_out_len(T, N, K)
     _lib.check(min(L, 0), "ias_pqmf_out_len")
     z = torch.empty((B, N, L), dtype=torch.float32, device=x2.device)
-    st = lib.ias_pqmf_analysis(_lib.ptr(x2), _lib.ptr(Hc), _lib.ptr(_packed_taps(H, Hc, N, K)), _lib.ptr(z),
+    st = lib.ias_pqmf_analysis(_lib.ptr(x2), _lib.ptr(Hc), _lib.ptr(_packed_taps(H, Hc, N, K)),
+                               _lib.ptr(_modulated_taps(H, Hc, N, K)), _lib.ptr(z),
                                _lib.ptr(mean), _lib.ptr(std), _lib.ptr(rowpeak), B, T, N, K, _lib.stream())
     _lib.check(st, "ias_pqmf_analysis")
     return z

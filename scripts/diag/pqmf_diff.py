@@ -21,8 +21,8 @@ peak = torch.linspace(0.5, 3.0, B, device=dev)
 for fused in (False, True):
     za = torch.full((B, N, L), 7.0, device=dev); zm = torch.full((B, N, L), 9.0, device=dev)
     args = (_lib.ptr(mean), _lib.ptr(std), _lib.ptr(peak)) if fused else (None, None, None)
-    lib.ias_pqmf_analysis(_lib.ptr(x), _lib.ptr(Hc), _lib.ptr(packed), _lib.ptr(za), *args, B, T, N, 63, _lib.stream())
-    lib.ias_pqmf_analysis(_lib.ptr(xm), _lib.ptr(Hc), _lib.ptr(packed), _lib.ptr(zm), *args, B, T, N, 63, _lib.stream())
+    lib.ias_pqmf_analysis(_lib.ptr(x), _lib.ptr(Hc), _lib.ptr(packed), None, _lib.ptr(za), *args, B, T, N, 63, _lib.stream())
+    lib.ias_pqmf_analysis(_lib.ptr(xm), _lib.ptr(Hc), _lib.ptr(packed), None, _lib.ptr(zm), *args, B, T, N, 63, _lib.stream())
     torch.cuda.synchronize()
     d = (za != zm)
     print("fused", fused, "ndiff", int(d.sum()), "of", d.numel(), "max", float((za - zm).abs().max()))

@@ -125,5 +125,5 @@ def test_c_abi_rejects_bad_arguments(lib, dev):
                                       256, 513, 1, 2, 1.0, 1e-8, None) == ARG    # MR-STFT mode needs its coefficients
     assert lib.ias_pqmf_pack_taps(p(z), p(z), 200, 63, None) == ARG                  # no packed layout for N > 64
     assert lib.ias_pqmf_packed_taps_len(200, 63) == 0 and lib.ias_pqmf_packed_taps_len(3, 63) > 0
-    assert lib.ias_pqmf_analysis(p(z), p(z), None, p(z), None, None, None, 1, 64, 3, 62, None) == ARG   # even tap count
+    assert lib.ias_pqmf_analysis(p(z), p(z), None, None, p(z), None, None, None, 1, 64, 3, 62, None) == ARG   # even tap count
     torch.cuda.synchronize()

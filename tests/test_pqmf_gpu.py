@@ -110,7 +110,7 @@ def test_packed_taps_follow_filter_updates(lib, dev):
     z2 = torch.empty_like(z1)
     Hc = m.H.reshape(3, 63).contiguous()
     x2 = x.reshape(2, -1)
-    st = lib.ias_pqmf_analysis(_lib.ptr(x2), _lib.ptr(Hc), None, _lib.ptr(z2), None, None, None, 2, 9000, 3, 63,
+    st = lib.ias_pqmf_analysis(_lib.ptr(x2), _lib.ptr(Hc), None, None, _lib.ptr(z2), None, None, None, 2, 9000, 3, 63,
                                _lib.stream())
     assert st == 0
     np.testing.assert_allclose(z2.cpu().numpy(), z1.cpu().numpy(), atol=1e-6)
@@ -184,9 +184,55 @@ def test_matrix_core_path_is_bit_identical_to_the_vector_kernels(lib, dev, N, B,
         za = torch.full((B, N, L), 7.0, device=dev)
         zm = torch.full((B, N, L), 9.0, device=dev)
         args = (_lib.ptr(mean), _lib.ptr(std), _lib.ptr(peak)) if fused else (None, None, None)
-        assert lib.ias_pqmf_analysis(_lib.ptr(xa), _lib.ptr(Hc), _lib.ptr(packed), _lib.ptr(za), *args, B, T, N, 63,
+        assert lib.ias_pqmf_analysis(_lib.ptr(xa), _lib.ptr(Hc), _lib.ptr(packed), None, _lib.ptr(za), *args, B, T, N, 63,
                                      _lib.stream()) == 0
-        assert lib.ias_pqmf_analysis(_lib.ptr(xm), _lib.ptr(Hc), _lib.ptr(packed), _lib.ptr(zm), *args, B, T, N, 63,
+        assert lib.ias_pqmf_analysis(_lib.ptr(xm), _lib.ptr(Hc), _lib.ptr(packed), None, _lib.ptr(zm), *args, B, T, N, 63,
                                      _lib.stream()) == 0
         torch.cuda.synchronize()
         assert torch.equal(za, zm), f"max diff {(za - zm).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("B,T", [(5, 176400), (2, 4100), (3, 12), (1, 1), (2, 31), (3, 1021), (130, 3840), (2, 100003)])
+def test_modulated_form_agrees_with_the_tap_ordered_kernels(lib, dev, B, T):
+    """N = 3: the cosine-modulated evaluation (52 signed prototype products + a 3-point modulation per frame, the
+    default of PQMF(3).analysis) against the tap-ordered fmaf chain of the other kernels, through the C ABI: the same
+    real numbers in another summation order -- 2e-6 of the output scale, with and without the fused band normalisation
+    and row scale, aligned and misaligned rows, ragged and one-sample inputs."""
+    import ctypes
+    from inverse_audio_synthesis_amd import _lib
+    m = _mod(dev, 3)
+    Hc = m.H.reshape(3, 63).contiguous()
+    host = Hc.cpu().contiguous()
+    tab = torch.empty(lib.ias_pqmf_modtab_len())
+    assert lib.ias_pqmf_build_modtab(ctypes.c_void_p(host.data_ptr()), 3, 63, ctypes.c_void_p(tab.data_ptr())) == 0
+    tab = tab.to(dev)
+    x = randn((B, T), 4100 + B).to(dev)
+    xm = torch.empty(B * T + 1, device=dev)[1:]
+    xm.copy_(x.flatten())
+    L = lib.ias_pqmf_out_len(T, 3, 63)
+    mean = torch.linspace(-0.1, 0.1, 3, device=dev)
+    std = torch.linspace(0.5, 1.5, 3, device=dev)
+    peak = torch.linspace(0.5, 3.0, B, device=dev)
+    for fused in (False, True):
+        args = (_lib.ptr(mean), _lib.ptr(std), _lib.ptr(peak)) if fused else (None, None, None)
+        ref = torch.full((B, 3, L), 7.0, device=dev)
+        assert lib.ias_pqmf_analysis(_lib.ptr(x), _lib.ptr(Hc), None, None, _lib.ptr(ref), *args, B, T, 3, 63,
+                                     _lib.stream()) == 0
+        for src in (x, xm):
+            got = torch.full((B, 3, L), 9.0, device=dev)
+            assert lib.ias_pqmf_analysis(_lib.ptr(src), _lib.ptr(Hc), None, _lib.ptr(tab), _lib.ptr(got), *args, B, T, 3, 63,
+                                         _lib.stream()) == 0
+            torch.cuda.synchronize()
+            scale = max(1.0, ref.abs().max().item())
+            assert (got - ref).abs().max().item() <= 2e-6 * scale
+    # and the module takes it by default
+    import inverse_audio_synthesis_amd.pqmf as pq
+    assert pq.USE_MODULATED and pq._modulated_taps(m.H, Hc, 3, 63) is not None
+
+
+def test_modulated_table_is_refused_for_other_filters(lib, dev):
+    import ctypes
+    H = torch.randn(3, 63)
+    tab = torch.empty(lib.ias_pqmf_modtab_len())
+    assert lib.ias_pqmf_build_modtab(ctypes.c_void_p(H.data_ptr()), 3, 63, ctypes.c_void_p(tab.data_ptr())) == -2
+    assert lib.ias_pqmf_build_modtab(ctypes.c_void_p(H.data_ptr()), 4, 63, ctypes.c_void_p(tab.data_ptr())) == -2
