@@ -497,6 +497,10 @@ def main():
     last = {}
 
     defer = not args.no_defer_consumers
+    # IAS_BENCH_PRECLEAR=1: the render's 90 KB memset issued ahead on the control stream instead of in front of the render
+    # (measured: 0.200 vs 0.183 ms per step -- the memset node elsewhere changes the executor's queue assignment for the
+    # worse -- so it is off; kept as a knob)
+    preclear = os.environ.get("IAS_BENCH_PRECLEAR", "0") == "1" and not args.no_pipeline
     reduce_aside = (not args.no_pipeline) and os.environ.get("IAS_BENCH_REDUCE_INLINE") != "1"   # (diag knob)
 
     def run_steps(k, pipelined=True):
@@ -514,6 +518,13 @@ def main():
                 if ws_free[buf] is not None:
                     side_c.wait_event(ws_free[buf])
                 voice.render_control(workspaces[buf])
+                if preclear:
+                    # the re-zeroing of the render's polled words leaves the render queue too (it was a memset node
+                    # between every two renders): here it has to wait for the readers of the row peaks as well
+                    if consumed[buf] is not None:
+                        for e in consumed[buf]:
+                            side_c.wait_event(e)
+                    voice.clear_chain(workspaces[buf])
                 return side_c.record_event()
 
         pending = [None]
@@ -560,7 +571,8 @@ def main():
             if early_ctrl and i + depth < k:
                 ctrl_events[i + depth] = issue_control(i + depth)
             # normalize_if_clipping is folded into the two consumers (row peaks read in place from the workspace)
-            audio = voice.render_audio(workspaces[buf], out=audio_bufs[buf], on_stage=hook, normalize=False)
+            audio = voice.render_audio(workspaces[buf], out=audio_bufs[buf], on_stage=hook, normalize=False,
+                                       precleared=preclear)
             peaks = voice.peaks_view(workspaces[buf])
             ws_free[buf] = main.record_event()
             if not early_ctrl and i + depth < k:

@@ -62,7 +62,9 @@ int ias_voice_render(const float* params01, const float* noise, float* audio, vo
 
 /* One stage of ias_voice_render on a workspace ias_voice_control_ws has filled (ias_voice_render = control +
  * stage 0 [+ stage 1]): 0 the single-pass audio-rate kernel (phase increments, chained fp64 scan across tiles,
- * oscillators, mixer -> unnormalised audio and row peaks), 1 normalize_if_clipping in place. */
+ * oscillators, mixer -> unnormalised audio and row peaks), 1 normalize_if_clipping in place, 2 only the re-zeroing of
+ * the kernel's polled words that stage 0 starts with (pipelines issue it ahead, on another stream, once the render and
+ * the readers of its row peaks are done with the workspace; noise / audio may be NULL), 3 stage 0 without the re-zeroing. */
 int ias_voice_stage(int stage, int math_mode, const float* noise, float* audio, void* workspace,
                     long long workspace_bytes, int B, int T, int Tc, int sample_rate, void* stream);
 

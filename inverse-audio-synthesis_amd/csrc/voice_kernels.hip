@@ -844,20 +844,26 @@ static void voice_audio_launch(hipStream_t stream, const VoiceWs& w, char* ws, c
 //   stage 0: single-pass audio-rate kernel: phase increments, chained fp64 scan across tiles,
 //            oscillators + mixer -> unnormalised audio, row peaks (voice_audio_kernel)
 //   stage 1: normalize_if_clipping in place (voice_normalize_kernel)
+//   stage 2: only the re-zeroing of the polled words (ticket, timeout flag, tile aggregates, row peaks) that stage 0
+//            starts with -- for pipelines that issue it ahead, on another stream, once the previous readers of the
+//            workspace (the render AND the consumers of its row peaks) are done
+//   stage 3: stage 0 without that re-zeroing (a stage 2 on this workspace must have run since its last stage 0 / 3)
 // math_mode: 0 = the tested contract (oracle math "cr"); 1 = hardware fp32 exp2 on the pitch path (A/B only).
 extern "C" int ias_voice_stage(int stage, int math_mode, const float* noise, float* audio, void* workspace,
                                long long workspace_bytes, int B, int T, int Tc, int sample_rate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!noise || !audio || !workspace || sample_rate <= 0 || stage < 0 || stage > 1 || math_mode < 0 || math_mode > 1)
-    return IAS_ERR_ARG;
+  if (!workspace || sample_rate <= 0 || stage < 0 || stage > 3 || math_mode < 0 || math_mode > 1) return IAS_ERR_ARG;
+  if (stage != 2 && (!noise || !audio)) return IAS_ERR_ARG;
   int rc = voice_check_dims(B, T, Tc);
   if (rc) return rc;
   const VoiceWs w = voice_ws_layout(B, T, Tc);
   if ((size_t)workspace_bytes < w.total) return IAS_ERR_WORKSPACE;
   char* ws = (char*)workspace;
-  if (stage == 0) {
-    // ticket, timeout flag, tile aggregates and row peaks are re-zeroed on every call
+  if (stage == 2) {
     if (hipMemsetAsync(ws + w.off_sync, 0, w.sync_bytes, stream) != hipSuccess) return IAS_ERR_LAUNCH;
+  } else if (stage == 0 || stage == 3) {
+    // ticket, timeout flag, tile aggregates and row peaks are re-zeroed on every call
+    if (stage == 0 && hipMemsetAsync(ws + w.off_sync, 0, w.sync_bytes, stream) != hipSuccess) return IAS_ERR_LAUNCH;
     const bool fma_div = ias_div_fma_rate_ok(sample_rate) != 0;   // else: fp64 reciprocal path of the increment
     if (math_mode == VOICE_MATH_CR) {
       if (fma_div) voice_audio_launch<VOICE_MATH_CR, true>(stream, w, ws, noise, audio, B, T, Tc, sample_rate);

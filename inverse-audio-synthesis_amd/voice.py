@@ -194,7 +194,16 @@ class Voice(nn.Module):
                                               c.buffer_size, c.control_buffer_size, c.control_rate, _lib.stream())
         _lib.check(st, "ias_voice_control_ws")
 
-    def render_audio(self, workspace, out=None, on_stage=None, normalize=True):
+    def clear_chain(self, workspace):
+        """Re-zero the polled words of the audio-rate kernel in ``workspace`` on the current stream (what ``render_audio``
+        starts with; pipelines issue it ahead and call ``render_audio(..., precleared=True)``).  The row peaks of the
+        previous render are among those words: their readers must be done."""
+        c = self.synthconfig
+        st = _lib.load().ias_voice_stage(2, self.math_mode, None, None, _lib.ptr(workspace), workspace.numel(), c.batch_size,
+                                         c.buffer_size, c.control_buffer_size, c.sample_rate, _lib.stream())
+        _lib.check(st, "ias_voice_stage(clear)")
+
+    def render_audio(self, workspace, out=None, on_stage=None, normalize=True, precleared=False):
         """Audio-rate pass (+ normalise) from a workspace ``render_control`` has filled -> audio [B,T]."""
         c = self.synthconfig
         lib = _lib.load()
@@ -206,7 +215,8 @@ class Voice(nn.Module):
         hook = on_stage or (lambda name, phase: None)
         for stage, name in enumerate(("oscillators", "normalize")[: 2 if normalize else 1]):
             hook(name, "begin")
-            st = lib.ias_voice_stage(stage, self.math_mode, _lib.ptr(self.noise), _lib.ptr(audio), _lib.ptr(workspace),
+            st = lib.ias_voice_stage(3 if (stage == 0 and precleared) else stage, self.math_mode, _lib.ptr(self.noise),
+                                     _lib.ptr(audio), _lib.ptr(workspace),
                                      workspace.numel(),
                                      c.batch_size, c.buffer_size, c.control_buffer_size, c.sample_rate, _lib.stream())
             _lib.check(st, f"ias_voice_stage({name})")
