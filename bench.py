@@ -485,7 +485,13 @@ def main():
     # depend only on the audio, so they run on two side HIP streams (the control pass on a third); with several audio
     # buffers and workspaces in flight the NEXT steps' renders run beside this step's PQMF / STFT.  All K steps and their
     # cross-stream dependencies are captured once into one hipGraph and replayed (issue order matters: see run_steps).
-    side_a, side_b, side_c = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    # IAS_BENCH_PRIO (diagnostics): "render" = the render's stream at high priority (the step's critical queue since the
+    # PQMF and the STFT got shorter), "consumers" = PQMF / STFT at high priority
+    prio = os.environ.get("IAS_BENCH_PRIO", "")
+    if prio == "render":
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
+    cpr = -1 if prio == "consumers" else 0
+    side_a, side_b, side_c = torch.cuda.Stream(priority=cpr), torch.cuda.Stream(priority=cpr), torch.cuda.Stream()
     # the small reduction of the STFT's loss partials gets a queue of its own: behind the STFT it lengthens the step's
     # critical queue, on the control stream it made the NEXT step's control pass (and with it the next render) wait for
     # the previous STFT (rocprofv3 timeline, profiles/r03b_trace_*: a 60 us bubble on the render queue per step)

@@ -455,10 +455,44 @@ __device__ __forceinline__ float wave_shl1(float x, float fill) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x130, 0xf, 0xf, false));
 }
 
-template <int SP_WAVES, bool MEL, int LOSS>
-__global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES >= 8 ? SP_WAVES / 2 : (3 * SP_WAVES + 3) / 4) void stft2_kernel(const Spec2Args a) {
-  constexpr int SP_THREADS = 64 * SP_WAVES, N2 = 512, R = 8, SCR = 64 * 9;
-  constexpr int NTAB = 8 + 8 + 8 + 4;     // cpx per lane: window pairs, pass-1 twiddles, pass-2 twiddles, unpack twiddles
+// NSUB = 2: n_fft 2048 on the same 8-points-per-lane core.  The 1024 packed complex points split into their even and
+// odd halves (decimation in time), each a 512-point transform through the three radix-8 passes above, one after the
+// other through the same scratch; Z[k] = E[k] + W_1024^k O[k] and Z[k + 512] = E[k] - W_1024^k O[k] are combined in
+// the lane that holds both (same k), which is also exactly the lower / upper split the half-spectrum unpack wants.
+// The round-2 kernel transforms such a frame with a radix-16 first pass at 16 points per lane: 164 VGPRs, 9.2 KB of
+// scratch per wave, 2-3 waves per SIMD and 7x the time of a 1024-point frame; this form costs 2.3x.
+template <int NSUB> __device__ __forceinline__ void stft2_load_frame(const float* __restrict__ arow, int T, int hop, int f,
+                                                                      int lane, float (&x)[16 * NSUB]) {
+  if (NSUB == 1) {
+    float (&x1)[16] = reinterpret_cast<float (&)[16]>(x);
+    load_frame<8, 512>(arow, T, hop, f, lane, x1);
+  } else {
+    // lane, n1: samples 256 n1 + 4 lane .. + 3 = (even point, odd point) of the two half-transforms; x[16 sub + 2 n1 + c]
+    const int g0 = f * hop - 1024;
+    if (g0 >= 0 && g0 + 2048 <= T && ((reinterpret_cast<uintptr_t>(arow + g0) & 15) == 0)) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(arow + g0) + lane;
+#pragma unroll
+      for (int n1 = 0; n1 < 8; ++n1) {
+        const f32x4 q = p[64 * n1];
+        x[2 * n1] = q[0]; x[2 * n1 + 1] = q[1]; x[16 + 2 * n1] = q[2]; x[16 + 2 * n1 + 1] = q[3];
+      }
+    } else {
+#pragma unroll
+      for (int n1 = 0; n1 < 8; ++n1)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          x[16 * (c >> 1) + 2 * n1 + (c & 1)] = arow[reflect_index(g0 + 256 * n1 + 4 * lane + c, T)];
+    }
+  }
+}
+
+template <int SP_WAVES, bool MEL, int LOSS, int NSUB>
+__global__ __launch_bounds__(64 * SP_WAVES, NSUB == 2 ? 3 * SP_WAVES / 8 : (SP_WAVES >= 8 ? SP_WAVES / 2 : (3 * SP_WAVES + 3) / 4))
+void stft2_kernel(const Spec2Args a) {
+  static_assert(NSUB == 1 || (NSUB == 2 && !MEL), "mel filterbanks: n_fft 1024 only");
+  constexpr int SP_THREADS = 64 * SP_WAVES, N2 = 512 * NSUB, R = 8, SCR = 64 * 9, NPK = 4 * NSUB, HALF = N2 / 2;
+  // cpx per lane: window pairs, pass-1 twiddles, pass-2 twiddles, (NSUB = 2: combining twiddles,) unpack twiddles
+  constexpr int NTAB = 8 * NSUB + 8 + 8 + (NSUB == 2 ? 8 : 0) + NPK;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   cpx* s_scr = reinterpret_cast<cpx*>(smem);                        // SP_WAVES x SCR: FFT exchange scratch / power buffer
   cpx* s_tab = s_scr + SP_WAVES * SCR;                              // [NTAB][64]
@@ -467,12 +501,13 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES >= 8 ? SP_WAVES / 2 : (3 * 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  // tables: the old block's entries [0,16) window, [16,32) pass-1, [32,48) pass-2 twiddles; this kernel's unpack
-  // twiddles W_1024^k, k = (lane >> 3) + 8 (lane & 7) + 64 e, are the 8 entries behind the old block's unpack entries
-  constexpr int OLD_UNP = 10;
+  // tables.  n_fft 1024: the old block's entries [0,16) window, [16,32) pass-1, [32,48) pass-2 twiddles, and this
+  // kernel's unpack twiddles W_1024^k, k = (lane >> 3) + 8 (lane & 7) + 64 e, in the 8 entries behind the old block's
+  // unpack entries.  n_fft 2048: this kernel's own section behind the old block (ias_stft_build_tables), in s_tab order.
+  constexpr int OLD_UNP = 10, V2_BASE_2048 = 32 + 32 + 32 + 18;
   for (int i = tid; i < NTAB * 64; i += SP_THREADS) {
     const int pp = i >> 6, l = i & 63;
-    const int src = pp < 24 ? 2 * pp : 48 + OLD_UNP + 2 * (pp - 24);
+    const int src = NSUB == 2 ? V2_BASE_2048 + 2 * pp : (pp < 24 ? 2 * pp : 48 + OLD_UNP + 2 * (pp - 24));
     s_tab[i] = cmk(a.tables[64 * src + l], a.tables[64 * (src + 1) + l]);
   }
   // the scratch doubles as the segment-major power buffer, some of whose words (the padding of the exchange layout,
@@ -486,10 +521,11 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES >= 8 ? SP_WAVES / 2 : (3 * 
     const cpx* wsrc = reinterpret_cast<const cpx*>(a.segtab + IAS_SEG_HDR + 9 * 64);
     for (int i = tid; i < seg_rows * 64; i += SP_THREADS) s_segw[i] = wsrc[i];
   }
-  const cpx* t_win = s_tab + lane;          // [n1]  -> (win[2 n1], win[2 n1 + 1])
-  const cpx* t_tw1 = t_win + 64 * 8;        // [k1]  -> W_512^(lane k1)
-  const cpx* t_tw2 = t_tw1 + 64 * 8;        // [d]   -> W_64^(c d)
-  const cpx* t_twu = t_tw2 + 64 * 8;        // [e]   -> W_1024^k, k = k1 + 8 d + 64 e
+  const cpx* t_win = s_tab + lane;              // [8 sub + n1] -> the window at the lane's two samples of point n1
+  const cpx* t_tw1 = t_win + 64 * 8 * NSUB;     // [k1]  -> W_512^(lane k1)
+  const cpx* t_tw2 = t_tw1 + 64 * 8;            // [d]   -> W_64^(c d)
+  const cpx* t_cmb = t_tw2 + 64 * 8;            // NSUB = 2: [e] -> W_1024^k, k = k1 + 8 d + 64 e
+  const cpx* t_twu = t_cmb + (NSUB == 2 ? 64 * 8 : 0);   // [e] -> W_nfft^k, the lane's lower-half bins
   __syncthreads();                           // the only workgroup barrier before the final reduction
 
   cpx* sA = s_scr + wave * SCR;
@@ -504,13 +540,13 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES >= 8 ? SP_WAVES / 2 : (3 * 
     if (r >= a.F) { r -= a.F; ++q0; }
     b = (int)q0; f = r;
   };
-  float xc[2 * R], xn[2 * R];
+  float xc[16 * NSUB], xn[16 * NSUB];
   int fi = gw, bcur = 0, fcur = 0;
-  if (fi < a.nframes) { row_of(fi, bcur, fcur); load_frame<R, N2>(a.audio + (size_t)bcur * a.T, a.T, a.hop, fcur, lane, xc); }
+  if (fi < a.nframes) { row_of(fi, bcur, fcur); stft2_load_frame<NSUB>(a.audio + (size_t)bcur * a.T, a.T, a.hop, fcur, lane, xc); }
   for (; fi < a.nframes; fi += nw) {
     const bool more = fi + nw < a.nframes;   // wave-uniform
     int bnext = 0, fnext = 0;
-    if (more) { row_of(fi + nw, bnext, fnext); load_frame<R, N2>(a.audio + (size_t)bnext * a.T, a.T, a.hop, fnext, lane, xn); }
+    if (more) { row_of(fi + nw, bnext, fnext); stft2_load_frame<NSUB>(a.audio + (size_t)bnext * a.T, a.T, a.hop, fnext, lane, xn); }
     float pscale = 0.25f;
     if (a.rowpeak != nullptr) { const float pkv = a.rowpeak[bcur]; if (pkv > 1.0f) { const float r = 1.0f / pkv; pscale = 0.25f * (r * r); } }
     const size_t row = (size_t)fi * a.n_out;
@@ -521,44 +557,62 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES >= 8 ? SP_WAVES / 2 : (3 * 
       for (int c = 0; c < 3; ++c) if (64 * c + lane < a.n_out) tgt_m[c] = a.target[row + 64 * c + lane];
     }
 
-    // pass 1: radix 8 over n1 (points 64 n1 + lane), twiddle W_512^(lane k1), scatter to [k1][c][a]
-    cpx v[R];
-#pragma unroll
-    for (int n1 = 0; n1 < R; ++n1) v[n1] = cmk(xc[2 * n1], xc[2 * n1 + 1]) * t_win[64 * n1];
-    dft8(v);
-    {
-      const int c = lane & 7, aa = lane >> 3;
-#pragma unroll
-      for (int q = 0; q < R; ++q) sA[(q * 8 + c) * 9 + aa] = cmul(v[q], t_tw1[64 * q]);
-    }
-    wave_lds_sync();
-    cpx u[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
-    wave_lds_sync();
-    // pass 2: radix 8 over a for each (k1, c); twiddle W_64^(c d); scatter (in place) to [k1][d][c]
-    dft8(u);
-#pragma unroll
-    for (int d = 0; d < 8; ++d) sA[(k1 * 8 + d) * 9 + dd] = cmul(u[d], t_tw2[64 * d]);
-    wave_lds_sync();
-#pragma unroll
-    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
-    wave_lds_sync();
-    // pass 3: radix 8 over c for each (k1, d): u[e] = Z[k1 + 8 d + 64 e]
-    dft8(u);
-    // the upper half (e >= 4, k >= 256) goes to LDS at k - 256 (padded by one complex per 8: conflict-free 8-byte stores)
     const int kl = k1 + 8 * dd;
+    cpx zlo[NPK], zhi[NPK];                  // Z[kl + 64 e] and Z[HALF + kl + 64 e]
+    cpx ue[8];
 #pragma unroll
-    for (int e = 4; e < 8; ++e) { const int i = kl + 64 * (e - 4); sA[i + (i >> 3)] = u[e]; }
+    for (int sub = 0; sub < NSUB; ++sub) {
+      // pass 1: radix 8 over n1 (points 64 n1 + lane), twiddle W_512^(lane k1), scatter to [k1][c][a]
+      cpx v[R];
+#pragma unroll
+      for (int n1 = 0; n1 < R; ++n1) v[n1] = cmk(xc[16 * sub + 2 * n1], xc[16 * sub + 2 * n1 + 1]) * t_win[64 * (8 * sub + n1)];
+      dft8(v);
+      {
+        const int c = lane & 7, aa = lane >> 3;
+#pragma unroll
+        for (int q = 0; q < R; ++q) sA[(q * 8 + c) * 9 + aa] = cmul(v[q], t_tw1[64 * q]);
+      }
+      wave_lds_sync();
+      cpx u[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+      wave_lds_sync();
+      // pass 2: radix 8 over a for each (k1, c); twiddle W_64^(c d); scatter (in place) to [k1][d][c]
+      dft8(u);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) sA[(k1 * 8 + d) * 9 + dd] = cmul(u[d], t_tw2[64 * d]);
+      wave_lds_sync();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+      wave_lds_sync();
+      // pass 3: radix 8 over c for each (k1, d): u[e] = (half-)transform at k1 + 8 d + 64 e
+      dft8(u);
+      if (NSUB == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { zlo[e] = u[e]; zhi[e] = u[4 + e]; }
+      } else if (sub == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ue[e] = u[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const cpx t = cmul(u[e], t_cmb[64 * e]);
+          zlo[e % NPK] = cadd(ue[e], t); zhi[e % NPK] = csub(ue[e], t);
+        }
+      }
+    }
+    // the upper half (k >= HALF) goes to LDS at k - HALF (padded by one complex per 8: conflict-free 8-byte stores)
+#pragma unroll
+    for (int e = 0; e < NPK; ++e) { const int i = kl + 64 * e; sA[i + (i >> 3)] = zhi[e]; }
     wave_lds_sync();
-    // unpack: own bins k = kl + 64 e (e < 4) with Z[512 - k] from the upper half
-    float pk[4], pn[4];
+    // unpack: own bins k = kl + 64 e with Z[N2 - k] from the upper half
+    float pk[NPK], pn[NPK];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NPK; ++e) {
       const int k = kl + 64 * e;
-      const int i = (256 - k) & 255;                         // k = 0: Z[512] = Z[0] (own), the read is a dummy
+      const int i = (HALF - k) & (HALF - 1);                 // k = 0: Z[N2] = Z[0] (own), the read is a dummy
       cpx zn = sA[i + (i >> 3)];
-      const cpx zk = u[e];
+      const cpx zk = zlo[e];
       if (e == 0 && k == 0) zn = zk;
       const cpx w = t_twu[64 * e];
       const float ea = zk.x + zn.x, eb = zk.y - zn.y, od = zk.x - zn.x, os = zk.y + zn.y;
@@ -567,14 +621,14 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES >= 8 ? SP_WAVES / 2 : (3 * 
       pk[e] = fmaf(xi, xi, xr * xr) * pscale;
       pn[e] = fmaf(yi, yi, yr * yr) * pscale;
     }
-    float pmid = fmaf(u[4].y, u[4].y, u[4].x * u[4].x) * (4.0f * pscale);    // lane 0: |Z[256]|^2
+    float pmid = fmaf(zhi[0].y, zhi[0].y, zhi[0].x * zhi[0].x) * (4.0f * pscale);    // lane 0: |Z[HALF]|^2
     if (a.value_mode == 1) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { pk[e] = sqrtf(pk[e]); pn[e] = sqrtf(pn[e]); }
+      for (int e = 0; e < NPK; ++e) { pk[e] = sqrtf(pk[e]); pn[e] = sqrtf(pn[e]); }
       pmid = sqrtf(pmid);
     } else if (a.value_mode == 3) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { pk[e] = sqrtf(fmaxf(pk[e], a.eps)); pn[e] = sqrtf(fmaxf(pn[e], a.eps)); }
+      for (int e = 0; e < NPK; ++e) { pk[e] = sqrtf(fmaxf(pk[e], a.eps)); pn[e] = sqrtf(fmaxf(pn[e], a.eps)); }
       pmid = sqrtf(fmaxf(pmid, a.eps));
     }
     wave_lds_sync();   // every Z read is done: the power values overwrite the scratch
@@ -628,13 +682,13 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES >= 8 ? SP_WAVES / 2 : (3 * 
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const int k = kl + 64 * e; emit(k, pk[e]); emit(512 - k, pn[e]); }
-      if (lane == 0) emit(256, pmid);
+      for (int e = 0; e < NPK; ++e) { const int k = kl + 64 * e; emit(k, pk[e]); emit(N2 - k, pn[e]); }
+      if (lane == 0) emit(HALF, pmid);
     }
     wave_lds_sync();
     if (more) {
 #pragma unroll
-      for (int e = 0; e < 2 * R; ++e) xc[e] = xn[e];
+      for (int e = 0; e < 16 * NSUB; ++e) xc[e] = xn[e];
       bcur = bnext; fcur = fnext;
     }
   }
@@ -1039,9 +1093,9 @@ static int stft2_waves() {
 }
 static bool stft2_enabled(int n_fft, bool mel, bool have_segtab) {
   static const int v1 = getenv("IAS_STFT_V1") ? atoi(getenv("IAS_STFT_V1")) : 0;   // diagnostics: round-2 kernel
-  return !v1 && n_fft == 1024 && (!mel || have_segtab);
+  return !v1 && ((n_fft == 1024 && (!mel || have_segtab)) || (n_fft == 2048 && !mel));
 }
-static int stft2_grid(long long nframes) {
+static int stft2_grid(long long nframes, int n_fft) {
   static const int env = getenv("IAS_STFT2_WGS") ? atoi(getenv("IAS_STFT2_WGS")) : 0;   // diagnostics
   static int ncu = 0;
   if (ncu == 0) {
@@ -1049,7 +1103,7 @@ static int stft2_grid(long long nframes) {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
     ncu = v;
   }
-  const int waves = stft2_waves();
+  const int waves = n_fft == 2048 ? 8 : stft2_waves();
   const long long need = (nframes + waves - 1) / waves;
   // workgroups per CU by LDS (scratch 4.5 KB per wave + 25 KB of tables per workgroup): 10 waves: 2, 8: 2, 5: 3, 4: 3
   const long long cap = env > 0 ? env : (waves >= 8 ? 2LL : 3LL) * ncu;
@@ -1062,7 +1116,7 @@ extern "C" long long ias_stft_partials_count(int B, int T, int n_fft, int hop, i
   const int F = ias_stft_num_frames(T, n_fft, hop);
   if (F < 0 || B <= 0) return IAS_ERR_ARG;
   if (ias_sm_enabled(n_fft, (flags & 1) != 0)) return ias_sm_partials((long long)B * F);
-  if (stft2_enabled(n_fft, (flags & 2) != 0, (flags & 4) != 0)) return stft2_grid((long long)B * F);
+  if (stft2_enabled(n_fft, (flags & 2) != 0, (flags & 4) != 0)) return stft2_grid((long long)B * F, n_fft);
   return (long long)B * stft_grid_x(B, F, n_fft, hop);
 }
 
@@ -1071,8 +1125,10 @@ extern "C" long long ias_stft_partials_count(int B, int T, int n_fft, int hop, i
 extern "C" int ias_stft_tables_len(int n_fft) {
   if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return IAS_ERR_UNSUPPORTED;
   const int N2 = n_fft / 2, R = N2 / 64, np_it = (8 * R + 63) / 64, nunp = (N2 / 2) / 64 + 1;
-  // n_fft 1024: + the unpack twiddles of stft2_kernel (bins k = (lane >> 3) + 8 (lane & 7) + 64 e, e < 4)
-  return 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp + (n_fft == 1024 ? 8 : 0));
+  // n_fft 1024: + the unpack twiddles of stft2_kernel (bins k = (lane >> 3) + 8 (lane & 7) + 64 e, e < 4);
+  // n_fft 2048: + stft2_kernel<NSUB = 2>'s whole table section (window pairs of the two half-transforms, pass-1 / pass-2
+  // twiddles of a 512-point transform, combining twiddles W_1024^k, unpack twiddles W_2048^k: 48 complex per lane)
+  return 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp + (n_fft == 1024 ? 8 : 0) + (n_fft == 2048 ? 96 : 0));
 }
 
 extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float* out_host) {
@@ -1116,6 +1172,19 @@ extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float*
         o[64 * (2 * e) + l] = (float)cos(ang);
         o[64 * (2 * e + 1) + l] = (float)(-sin(ang));
       }
+  if (n_fft == 2048) {
+    const double tau = 6.283185307179586;
+    for (int l = 0; l < 64; ++l) {
+      int e = 0;                                         // entry pairs (re, im) in s_tab order
+      auto put = [&](double re, double im) { o[64 * (2 * e) + l] = (float)re; o[64 * (2 * e + 1) + l] = (float)im; ++e; };
+      for (int sub = 0; sub < 2; ++sub)                  // window at samples 256 n1 + 4 l + 2 sub + {0, 1}
+        for (int n1 = 0; n1 < 8; ++n1) put(window_host[256 * n1 + 4 * l + 2 * sub], window_host[256 * n1 + 4 * l + 2 * sub + 1]);
+      for (int k1 = 0; k1 < 8; ++k1) put(cos(tau * (double)(l * k1) / 512.0), -sin(tau * (double)(l * k1) / 512.0));
+      for (int d = 0; d < 8; ++d) put(cos(tau * (double)((l & 7) * d) / 64.0), -sin(tau * (double)((l & 7) * d) / 64.0));
+      for (int ee = 0; ee < 8; ++ee) { const int k = (l >> 3) + 8 * (l & 7) + 64 * ee; put(cos(tau * k / 1024.0), -sin(tau * k / 1024.0)); }
+      for (int ee = 0; ee < 8; ++ee) { const int k = (l >> 3) + 8 * (l & 7) + 64 * ee; put(cos(tau * k / 2048.0), -sin(tau * k / 2048.0)); }
+    }
+  }
   return IAS_OK;
 }
 
@@ -1155,15 +1224,21 @@ extern "C" int ias_stft(const float* audio, const float* tables, const float* mt
     a2.partials = partials; a2.rowpeak = rowpeak; a2.T = T; a2.F = F; a2.hop = hop; a2.n_out = n_out; a2.nframes = B * F;
     a2.magicF = (unsigned)(0x100000000ULL / (unsigned long long)F);
     a2.value_mode = value_mode; a2.loss_mode = loss_mode; a2.eps = eps;
-    const int waves2 = stft2_waves();
-    const size_t lds2 = sizeof(cpx) * (waves2 * 64 * 9 + 28 * 64 + (mel ? IAS_SEG_MAX_ROWS * 64 : 0)) +
+    const int waves2 = n_fft == 2048 ? 8 : stft2_waves();
+    const size_t lds2 = sizeof(cpx) * (waves2 * 64 * 9 + (n_fft == 2048 ? 48 : 28) * 64 + (mel ? IAS_SEG_MAX_ROWS * 64 : 0)) +
                         (mel ? sizeof(int) * 9 * 64 : 0);
-    const dim3 grid2(stft2_grid(a2.nframes)), block2(64 * waves2);
+    const dim3 grid2(stft2_grid(a2.nframes, n_fft)), block2(64 * waves2);
 #define IAS_STFT2_LAUNCHW(W, MEL, LOSS)                                                                            \
   do {                                                                                                             \
-    (void)hipFuncSetAttribute((const void*)stft2_kernel<W, MEL, LOSS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    (void)hipFuncSetAttribute((const void*)stft2_kernel<W, MEL, LOSS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds2);                                                                          \
-    hipLaunchKernelGGL((stft2_kernel<W, MEL, LOSS>), grid2, block2, lds2, stream, a2);                             \
+    hipLaunchKernelGGL((stft2_kernel<W, MEL, LOSS, 1>), grid2, block2, lds2, stream, a2);                          \
+  } while (0)
+#define IAS_STFT2_LAUNCH2K(LOSS)                                                                                   \
+  do {                                                                                                             \
+    (void)hipFuncSetAttribute((const void*)stft2_kernel<8, false, LOSS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds2);                                                                          \
+    hipLaunchKernelGGL((stft2_kernel<8, false, LOSS, 2>), grid2, block2, lds2, stream, a2);                        \
   } while (0)
 #define IAS_STFT2_LAUNCH(MEL, LOSS)                                                                                \
   do {                                                                                                             \
@@ -1172,9 +1247,11 @@ extern "C" int ias_stft(const float* audio, const float* tables, const float* mt
     else if (waves2 == 8) IAS_STFT2_LAUNCHW(8, MEL, LOSS);                                                         \
     else IAS_STFT2_LAUNCHW(10, MEL, LOSS);                                                                         \
   } while (0)
-    if (mel) { if (loss_mode == 0) IAS_STFT2_LAUNCH(true, 0); else if (loss_mode == 1) IAS_STFT2_LAUNCH(true, 1); else IAS_STFT2_LAUNCH(true, 2); }
+    if (n_fft == 2048) { if (loss_mode == 0) IAS_STFT2_LAUNCH2K(0); else if (loss_mode == 1) IAS_STFT2_LAUNCH2K(1); else IAS_STFT2_LAUNCH2K(2); }
+    else if (mel) { if (loss_mode == 0) IAS_STFT2_LAUNCH(true, 0); else if (loss_mode == 1) IAS_STFT2_LAUNCH(true, 1); else IAS_STFT2_LAUNCH(true, 2); }
     else { if (loss_mode == 0) IAS_STFT2_LAUNCH(false, 0); else if (loss_mode == 1) IAS_STFT2_LAUNCH(false, 1); else IAS_STFT2_LAUNCH(false, 2); }
 #undef IAS_STFT2_LAUNCH
+#undef IAS_STFT2_LAUNCH2K
 #undef IAS_STFT2_LAUNCHW
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   }
