@@ -98,6 +98,18 @@ int ias_voice_grad_nplanes(void);
 int ias_voice_backward(const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
                        float* planes, double* tile_sums, double* partials, float* g_ctrl, int B, int T, int Tc,
                        int sample_rate, void* stream);
+/* The same behind torchsynth's normalize_if_clipping (audio = mix / peak on rows with peak = max |mix| > 1): g_audio is
+ * the cotangent of the NORMALISED audio [B,T]; ias_voice_norm_backward turns it, the audio and the row peaks
+ * (ias_voice_read_peaks) into rownorm [B][4] = {divisor, index t* of the peak sample as int bits (-1: none), correction
+ * -sign(audio[t*]) sum_t g[t] audio[t] / peak, 0} with two launches (scratch: B * ias_voice_norm_scratch_len(T)
+ * doubles); ias_voice_backward_norm applies g / divisor (+ correction at t*) as it reads g_audio.  rownorm NULL =
+ * ias_voice_backward.  Replaces the 14 elementwise / reduce / gather / scatter launches of the torch expression. */
+long long ias_voice_norm_scratch_len(int T);
+int ias_voice_norm_backward(const float* g_audio, const float* audio, const float* peaks, double* scratch,
+                            float* rownorm, int B, int T, void* stream);
+int ias_voice_backward_norm(const float* ctrl, const void* vconst, const float* noise, const float* g_audio,
+                            const float* rownorm, float* planes, double* tile_sums, double* partials, float* g_ctrl,
+                            int B, int T, int Tc, int sample_rate, void* stream);
 
 /* Control-rate half of the same backward: params01 [B,78], g_ctrl [B,5,Tc] fp32 and g_scal [B,12] fp64 (g_ctrl of
  * ias_voice_backward and the sum over tiles of its partials) -> g_params01 [B,78] fp32.  One launch instead of the
@@ -218,6 +230,31 @@ int ias_stft_grad_frames(const float* audio, const float* tables, const int* mel
                          const int* mel_woff, const float* mel_w, int mel_nnz, int n_out, const float* target,
                          const double* coef, float* frame_grad, int B, int T, int n_fft, int hop, int power,
                          int loss_mode, float scale, float eps, void* stream);
+/* The frame part with the overlap-add inside the kernel (round 3; what ias_stft_loss_backward uses when the shape allows:
+ * hop even (n_fft 2048: hop % 4 == 0), hop <= n_fft / 2): a wave walks a chunk of plan_host[0] = G consecutive frames of
+ * one row and adds the windowed frame gradients in frame order in an LDS ring; chunk_spans (>= B * F * n_fft floats,
+ * 16-byte aligned) receives B * plan_host[1] spans of plan_host[2] = (G - 1) hop + n_fft floats: span c, entry i = the
+ * sum over the frames of chunk c (row c / plan[1], frames [j G, j G + G), j = c % plan[1]) at padded sample j G hop + i.
+ * plan_host: int[3] on the HOST, written before return.  IAS_ERR_UNSUPPORTED: shape not served, nothing launched. */
+int ias_stft_grad_spans(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
+                        const int* mel_woff, const float* mel_w, int mel_nnz, int n_out, const float* target,
+                        const double* coef, float* chunk_spans, int B, int T, int n_fft, int hop, int power,
+                        int loss_mode, float scale, float eps, int* plan_host, void* stream);
+
+/* MultiResolutionSTFTLoss scalar glue (auraloss defaults; spectral.py), one launch each, fp64 inside:
+ * ias_mrstft_total: loss[0] (device fp32) = (sum_k sqrt(s_k[0]) / sqrt(s_k[1]) + s_k[2] / counts_host[k]) / nres with
+ *   sums_host a HOST array of nres <= 8 device pointers to the resolutions' ias_reduce_partials sums;
+ * ias_mrstft_coef: coef[2] (device doubles) for ias_stft_loss_backward(loss_mode 2) = {g / (nres sqrt(s[0]) sqrt(s[1]))
+ *   (0 when the denominator is 0), g / (nres count)}, g = g_loss[0] (device fp32; NULL = 1). */
+int ias_mrstft_total(const double* const* sums_host, const double* counts_host, int nres, float* loss, void* stream);
+int ias_mrstft_coef(const double* sums, const float* g_loss, double count, int nres, double* coef, void* stream);
+
+/* Plain L1 between two fp32 arrays of n elements (the sub-band L1 of configs[4]): partials [ias_l1_partials_count(n)][3]
+ * doubles (column 0 = sum |x - y| of a workgroup; finish with ias_reduce_partials(scale = 1/n) for the mean), and
+ * gx = sign(x - y) * g_loss[0] * scale (sign(0) = 0; g_loss device fp32, NULL = 1). */
+long long ias_l1_partials_count(long long n);
+int ias_l1_partials(const float* x, const float* y, long long n, double* partials, void* stream);
+int ias_l1_grad(const float* x, const float* y, const float* g_loss, float scale, long long n, float* gx, void* stream);
 
 /* sums[3] (doubles) = column sums of partials [n][3], fixed order (deterministic); when mean_out is not
  * NULL also mean_out[0] = (float)(sums[0] * scale). */

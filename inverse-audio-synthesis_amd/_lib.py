@@ -40,6 +40,9 @@ SYMBOLS = {
     "ias_voice_grad_nscalars": (_I, []),
     "ias_voice_grad_nplanes": (_I, []),
     "ias_voice_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_voice_backward_norm": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_voice_norm_scratch_len": (_LL, [_I]),
+    "ias_voice_norm_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "ias_voice_control_backward": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ias_pqmf_out_len": (_I, [_I, _I, _I]),
     "ias_pqmf_packed_taps_len": (_I, [_I, _I]),
@@ -63,7 +66,14 @@ SYMBOLS = {
                                    ctypes.c_float, ctypes.c_float, _P]),
     "ias_stft_grad_frames": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, ctypes.c_float,
                                  ctypes.c_float, _P]),
+    "ias_stft_grad_spans": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, ctypes.c_float,
+                                ctypes.c_float, _P, _P]),
     "ias_reduce_partials": (_I, [_P, _LL, _P, _c.c_double, _P, _P]),
+    "ias_mrstft_total": (_I, [_P, _P, _I, _P, _P]),
+    "ias_mrstft_coef": (_I, [_P, _P, _c.c_double, _I, _P, _P]),
+    "ias_l1_partials_count": (_LL, [_LL]),
+    "ias_l1_partials": (_I, [_P, _P, _LL, _P, _P]),
+    "ias_l1_grad": (_I, [_P, _P, _P, _F, _LL, _P, _P]),
     "ias_vicreg_workspace_bytes": (_LL, [_I, _I]),
     "ias_vicreg_colstats_offset": (_LL, [_I, _I]),
     "ias_vicreg_loss": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),

@@ -257,6 +257,35 @@ __global__ __launch_bounds__(SG_THREADS) void stft_grad_ola_kernel(const float* 
   g_audio[(size_t)b * T + j] = g_loss ? acc * g_loss[0] : acc;
 }
 
+// The same from chunk spans (ias_stft_grad_spans): span c of row b covers the padded samples [c G hop, c G hop + L) with
+// the sum over ITS frames; a sample lies in at most two spans (G hop >= N - hop), added lower chunk first.
+__global__ __launch_bounds__(SG_THREADS) void stft_grad_combine_kernel(const float* __restrict__ spans,
+                                                                       const float* __restrict__ g_loss,
+                                                                       float* __restrict__ g_audio, int T, int F, int N,
+                                                                       int hop, int G, int cper, int L) {
+  const int j = blockIdx.x * SG_THREADS + threadIdx.x, b = blockIdx.y;
+  if (j >= T) return;
+  const int pad = N / 2, gh = G * hop;
+  const float* sp = spans + (size_t)b * cper * L;
+  int qs[3];
+  int nq = 0;
+  qs[nq++] = j + pad;
+  if (j >= 1 && j <= pad) qs[nq++] = pad - j;
+  if (j <= T - 2 && j >= T - 1 - pad) qs[nq++] = pad + 2 * (T - 1) - j;
+  float acc = 0.0f;
+  for (int i = 0; i < nq; ++i) {
+    const int q = qs[i];
+    int c = q / gh;
+    if (c > cper - 1) c = cper - 1;
+    float v = 0.0f;
+    if (c >= 1 && q - (c - 1) * gh < L) v = sp[(size_t)(c - 1) * L + (q - (c - 1) * gh)];
+    const int nf = min(F, (c + 1) * G) - c * G;             // frames of chunk c (the last one may be short)
+    if (q - c * gh < (nf - 1) * hop + N) v += sp[(size_t)c * L + (q - c * gh)];
+    acc += v;
+  }
+  g_audio[(size_t)b * T + j] = g_loss ? acc * g_loss[0] : acc;
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 // loss_mode 1: d (scale * sum |V(audio) - target|) / d audio, times the device scalar g_loss[0] (NULL = 1).
 // loss_mode 2: one resolution of the MR-STFT loss (linear bins, power 1, V = sqrt(max(|X|^2, eps))):
@@ -270,6 +299,10 @@ extern "C" int ias_stft_grad_frames(const float* audio, const float* tables, con
                                     const int* mel_woff, const float* mel_w, int mel_nnz, int n_out, const float* target,
                                     const double* coef, float* frame_grad, int B, int T, int n_fft, int hop, int power,
                                     int loss_mode, float scale, float eps, void* stream);   // csrc/spectral_kernels.hip
+extern "C" int ias_stft_grad_spans(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
+                                   const int* mel_woff, const float* mel_w, int mel_nnz, int n_out, const float* target,
+                                   const double* coef, float* chunk_spans, int B, int T, int n_fft, int hop, int power,
+                                   int loss_mode, float scale, float eps, int* plan_host, void* stream);
 
 extern "C" int ias_stft_loss_backward(const float* audio, const float* window, const float* tables, const int* mel_start,
                                       const int* mel_count, const int* mel_woff, const float* mel_w, int mel_nnz,
@@ -290,7 +323,21 @@ extern "C" int ias_stft_loss_backward(const float* audio, const float* window, c
   const int F = 1 + T / hop;
   if (F > 2147483647 / n_fft) return IAS_ERR_UNSUPPORTED;
   if (tables != nullptr && getenv("IAS_STFT_GRAD_V1") == nullptr) {
-    // the frame part on the forward's wave-per-frame FFT core, then the same overlap-add
+    // the frame part on the forward's wave-per-frame FFT core; overlap-add inside the kernel where the shape allows it
+    // (IAS_STFT_GRAD_NOSPAN=1: the [B,F,n_fft] tensor + stft_grad_ola_kernel of round 2)
+    static const bool nospan = getenv("IAS_STFT_GRAD_NOSPAN") != nullptr && atoi(getenv("IAS_STFT_GRAD_NOSPAN")) != 0;
+    if (!nospan && (reinterpret_cast<uintptr_t>(frame_grad) & 15) == 0) {
+      int plan[3] = {0, 0, 0};
+      const int rs = ias_stft_grad_spans(audio, tables, mel_start, mel_count, mel_woff, mel_w, mel ? mel_nnz : 0, n_out,
+                                         target, coef, frame_grad, B, T, n_fft, hop, power, loss_mode, scale, eps, plan,
+                                         stream_);
+      if (rs == IAS_OK) {
+        hipLaunchKernelGGL(stft_grad_combine_kernel, dim3((T + SG_THREADS - 1) / SG_THREADS, B), dim3(SG_THREADS), 0,
+                           stream, frame_grad, g_loss, g_audio, T, F, n_fft, hop, plan[0], plan[1], plan[2]);
+        return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+      }
+      if (rs != IAS_ERR_UNSUPPORTED) return rs;
+    }
     const int rc = ias_stft_grad_frames(audio, tables, mel_start, mel_count, mel_woff, mel_w, mel ? mel_nnz : 0, n_out,
                                         target, coef, frame_grad, B, T, n_fft, hop, power, loss_mode, scale, eps, stream_);
     if (rc != IAS_OK) return rc;
@@ -316,5 +363,131 @@ extern "C" int ias_stft_loss_backward(const float* audio, const float* window, c
                      g);
   hipLaunchKernelGGL(stft_grad_ola_kernel, dim3((T + SG_THREADS - 1) / SG_THREADS, B), dim3(SG_THREADS), 0, stream,
                      frame_grad, g_loss, g_audio, T, F, n_fft, hop);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------ scalar glue
+// The few scalar operations between the fused reductions and the backward kernels, as one launch each instead of a
+// dozen at::native elementwise launches per resolution (profiles/r03b_kstats_gradstep.csv: 6 % of the gradient step's
+// kernel time and most of its launch count).  fp64, the same operations in the same order as the torch expressions
+// they replace (spectral.py: MultiResolutionSTFTLoss._forward, _mrstft_plan_backward).
+#define IAS_MR_MAX_RES 8
+struct MrTotalArgs { const double* sums[IAS_MR_MAX_RES]; double count[IAS_MR_MAX_RES]; int nres; };
+
+// loss = (sum_k sqrt(s_k[0]) / sqrt(s_k[1]) + s_k[2] / count_k) / nres   (auraloss MultiResolutionSTFTLoss defaults:
+// spectral convergence + log-magnitude L1 per resolution, mean over resolutions)
+__global__ void mrstft_total_kernel(const MrTotalArgs a, float* __restrict__ loss) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double total = 0.0;
+  for (int k = 0; k < a.nres; ++k) {
+    const double* s = a.sums[k];
+    const double term = sqrt(s[0]) / sqrt(s[1]) + s[2] / a.count[k];
+    total = k == 0 ? term : total + term;
+  }
+  loss[0] = (float)(total / (double)a.nres);
+}
+
+extern "C" int ias_mrstft_total(const double* const* sums_host, const double* counts_host, int nres, float* loss,
+                                void* stream_) {
+  if (!sums_host || !counts_host || !loss || nres < 1 || nres > IAS_MR_MAX_RES) return IAS_ERR_ARG;
+  MrTotalArgs a;
+  for (int k = 0; k < IAS_MR_MAX_RES; ++k) { a.sums[k] = nullptr; a.count[k] = 1.0; }
+  for (int k = 0; k < nres; ++k) {
+    if (!sums_host[k] || !(counts_host[k] > 0.0)) return IAS_ERR_ARG;
+    a.sums[k] = sums_host[k]; a.count[k] = counts_host[k];
+  }
+  a.nres = nres;
+  hipLaunchKernelGGL(mrstft_total_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, a, loss);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+// coef[0] = g / (nres sqrt(s[0]) sqrt(s[1]))  (0 when the denominator is 0),  coef[1] = g / (nres count): the
+// cotangent coefficients ias_stft_loss_backward (loss_mode 2) takes; g = g_loss[0] (NULL = 1).
+__global__ void mrstft_coef_kernel(const double* __restrict__ s, const float* __restrict__ g_loss, double count,
+                                   int nres, double* __restrict__ coef) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double g = g_loss ? (double)g_loss[0] : 1.0;
+  const double den = sqrt(s[0]) * sqrt(s[1]);
+  coef[0] = den > 0.0 ? g / ((double)nres * den) : 0.0;
+  coef[1] = g / ((double)nres * count);
+}
+
+extern "C" int ias_mrstft_coef(const double* sums, const float* g_loss, double count, int nres, double* coef,
+                               void* stream_) {
+  if (!sums || !coef || nres < 1 || !(count > 0.0)) return IAS_ERR_ARG;
+  hipLaunchKernelGGL(mrstft_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, sums, g_loss, count, nres, coef);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------ plain L1 pair
+// mean |x - y| over n floats as per-workgroup fp64 partials [grid][3] (column 0; ias_reduce_partials finishes in fixed
+// order), and its gradient  gx = sign(x - y) * g_loss[0] * scale  (sign(0) = 0, torch.abs' convention): the SubbandL1
+// loss (spectral.py) without the sub / abs / mean / sign / mul / expand launches.
+#define L1_THREADS 256
+#define L1_PER_WG (L1_THREADS * 4 * 8)
+__global__ __launch_bounds__(L1_THREADS) void l1_partials_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                 long long n, double* __restrict__ partials) {
+  __shared__ double s_red[L1_THREADS / 64];
+  const long long base = (long long)blockIdx.x * L1_PER_WG;
+  float acc = 0.0f;
+  const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const long long i = base + ((long long)it * L1_THREADS + threadIdx.x) * 4;
+    if (vec && i + 3 < n) {
+      const float4 a = *reinterpret_cast<const float4*>(x + i), b = *reinterpret_cast<const float4*>(y + i);
+      acc += (fabsf(a.x - b.x) + fabsf(a.y - b.y)) + (fabsf(a.z - b.z) + fabsf(a.w - b.w));
+    } else {
+      for (int e = 0; e < 4; ++e) if (i + e < n) acc += fabsf(x[i + e] - y[i + e]);
+    }
+  }
+  double v = (double)acc;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < L1_THREADS / 64; ++w) t += s_red[w];
+    partials[(size_t)blockIdx.x * 3] = t; partials[(size_t)blockIdx.x * 3 + 1] = 0.0; partials[(size_t)blockIdx.x * 3 + 2] = 0.0;
+  }
+}
+
+__global__ __launch_bounds__(L1_THREADS) void l1_grad_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ g_loss, float scale, long long n,
+                                                             float* __restrict__ gx) {
+  const float g = (g_loss ? g_loss[0] : 1.0f) * scale;
+  const long long base = (long long)blockIdx.x * L1_PER_WG;
+  const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gx)) & 15) == 0;
+  auto sg = [&](float d) { return d > 0.0f ? g : (d < 0.0f ? -g : 0.0f); };
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const long long i = base + ((long long)it * L1_THREADS + threadIdx.x) * 4;
+    if (vec && i + 3 < n) {
+      const float4 a = *reinterpret_cast<const float4*>(x + i), b = *reinterpret_cast<const float4*>(y + i);
+      *reinterpret_cast<float4*>(gx + i) = make_float4(sg(a.x - b.x), sg(a.y - b.y), sg(a.z - b.z), sg(a.w - b.w));
+    } else {
+      for (int e = 0; e < 4; ++e) if (i + e < n) gx[i + e] = sg(x[i + e] - y[i + e]);
+    }
+  }
+}
+
+extern "C" long long ias_l1_partials_count(long long n) {
+  if (n <= 0) return IAS_ERR_ARG;
+  return (n + L1_PER_WG - 1) / L1_PER_WG;
+}
+
+extern "C" int ias_l1_partials(const float* x, const float* y, long long n, double* partials, void* stream_) {
+  if (!x || !y || !partials || n <= 0 || (n + L1_PER_WG - 1) / L1_PER_WG > 2147483647LL) return IAS_ERR_ARG;
+  hipLaunchKernelGGL(l1_partials_kernel, dim3((unsigned)((n + L1_PER_WG - 1) / L1_PER_WG)), dim3(L1_THREADS), 0,
+                     (hipStream_t)stream_, x, y, n, partials);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+extern "C" int ias_l1_grad(const float* x, const float* y, const float* g_loss, float scale, long long n, float* gx,
+                           void* stream_) {
+  if (!x || !y || !gx || n <= 0 || (n + L1_PER_WG - 1) / L1_PER_WG > 2147483647LL) return IAS_ERR_ARG;
+  hipLaunchKernelGGL(l1_grad_kernel, dim3((unsigned)((n + L1_PER_WG - 1) / L1_PER_WG)), dim3(L1_THREADS), 0,
+                     (hipStream_t)stream_, x, y, g_loss, scale, n, gx);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }

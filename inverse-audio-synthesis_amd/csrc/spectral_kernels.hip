@@ -727,12 +727,20 @@ struct SgwArgs {
   const int* mel_start; const int* mel_count; const int* mel_woff; const float* mel_w;   // MEL: the forward's CSR filters
   int T, F, hop, groups, power2, loss_mode, n_out, mel_nnz;
   float scale, eps;
+  int G, cper, L, nchunks;   // SPAN kernels: frames per chunk, chunks per row, floats per chunk span, B * cper
 };
 
 // MEL: the loss is taken on O = melW^T V (loss_mode 1 only).  V goes to LDS, a lane computes two outputs with the
 // forward's padded filter loops, their cotangents are scattered back to the bins with LDS float atomics (a bin lies under
 // at most two triangular filters: the sum of two terms does not depend on their order), then the bins continue as above.
-template <int LOG2N, bool MEL>
+//
+// SPAN (round 3): overlap-add inside the kernel.  A wave owns a CHUNK of G consecutive frames of one row and walks it
+// in order; the windowed frame gradients are added into a ring of n_fft floats in LDS (one wave, program order: the
+// sum over frames is in frame order, deterministic), and after every frame the hop samples no later frame of the chunk
+// touches leave the ring for the chunk's span  frame_grad[chunk][L], L = (G - 1) hop + n_fft.  The [B,F,n_fft] tensor
+// (8.5 - 10 floats per audio sample, written here and read again by stft_grad_ola_kernel) shrinks to ~1.2 - 1.5
+// floats per sample; stft_grad_combine_kernel adds the two chunks that meet at a sample, lower chunk first.
+template <int LOG2N, bool MEL, bool SPAN>
 __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
   constexpr int SP_WAVES = 4, SP_THREADS = 256;
   constexpr int NFFT = 1 << LOG2N, N2 = NFFT / 2, R = N2 / 64, NPAIR = 8 * R, NP_IT = (NPAIR + 63) / 64;
@@ -740,9 +748,10 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
   constexpr int NTAB = 64 * (2 * R + 2 * R + 16 * NP_IT + 2 * NUNP);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   cpx* s_scr = reinterpret_cast<cpx*>(smem);
-  cpx* s_tab = s_scr + SP_WAVES * SCR;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
-  const float* arow = a.audio + (size_t)b * a.T;
+  float* s_ring = reinterpret_cast<float*>(s_scr + SP_WAVES * SCR);          // SPAN: [wave][NFFT]
+  cpx* s_tab = s_scr + SP_WAVES * SCR + (SPAN ? SP_WAVES * N2 : 0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (SPAN) for (int i = tid; i < SP_WAVES * NFFT; i += SP_THREADS) s_ring[i] = 0.0f;
   for (int i = tid; i < NTAB / 2; i += SP_THREADS) {
     const int pp = i >> 6, l = i & 63;
     s_tab[i] = cmk(a.tables[64 * (2 * pp) + l], a.tables[64 * (2 * pp + 1) + l]);
@@ -845,10 +854,16 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
     return live ? gv / (2.0f * v) : 0.0f;
   };
 
-  const int f_begin = blockIdx.x * a.groups;
-  const int f_end = min(f_begin + a.groups, a.F);
   float xc[2 * R];
-  for (int f = f_begin + wave; f < f_end; f += SP_WAVES) {
+  float* ring = s_ring + wave * NFFT;
+  const int cstep = SPAN ? (int)gridDim.x * SP_WAVES : 1;
+  for (int c = SPAN ? (int)blockIdx.x * SP_WAVES + wave : 0; c < (SPAN ? a.nchunks : 1); c += cstep) {
+  int b, f_lo, f_hi;
+  if (SPAN) { b = c / a.cper; f_lo = (c - b * a.cper) * a.G; f_hi = min(f_lo + a.G, a.F); }
+  else { b = blockIdx.y; f_lo = blockIdx.x * a.groups + wave; f_hi = min((int)blockIdx.x * a.groups + a.groups, a.F); }
+  const float* arow = a.audio + (size_t)b * a.T;
+  float* span = a.frame_grad + (size_t)c * a.L;
+  for (int f = f_lo; f < f_hi; f += SPAN ? 1 : SP_WAVES) {
     load_frame<R, N2>(arow, a.T, a.hop, f, lane, xc);
     cpx v[R];
 #pragma unroll
@@ -963,26 +978,283 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
     wave_lds_sync();
     fft(v);
     // z[m] = conj(out[m]) = y[2m] + i y[2m+1];  frame_grad = window * y
-    float* out = a.frame_grad + ((size_t)b * a.F + f) * NFFT;
+    if (SPAN) {
+      const int rb = ((f - f_lo) * a.hop) & (NFFT - 1);     // ring position of the frame's first sample (hop is even)
 #pragma unroll
-    for (int n1 = 0; n1 < R; ++n1) {
-      const int m = 64 * n1 + lane;
-      const cpx o = sA[m + (m >> 3)];
-      const cpx w2 = t_win[64 * n1];
-      *reinterpret_cast<cpx*>(out + 2 * m) = cmk(w2.x * o.x, -w2.y * o.y);
+      for (int n1 = 0; n1 < R; ++n1) {
+        const int m = 64 * n1 + lane;
+        const cpx o = sA[m + (m >> 3)];
+        const cpx w2 = t_win[64 * n1];
+        cpx* rp = reinterpret_cast<cpx*>(ring + ((rb + 2 * m) & (NFFT - 1)));
+        const cpx cur = *rp;
+        *rp = cmk(cur.x + w2.x * o.x, cur.y - w2.y * o.y);
+      }
+      wave_lds_sync();
+      float* sp = span + (size_t)(f - f_lo) * a.hop;         // the hop samples no later frame of the chunk reaches
+      for (int i = lane; i < a.hop; i += 64) {
+        const int idx = (rb + i) & (NFFT - 1);
+        sp[i] = ring[idx];
+        ring[idx] = 0.0f;
+      }
+      wave_lds_sync();
+    } else {
+      float* out = a.frame_grad + ((size_t)b * a.F + f) * NFFT;
+#pragma unroll
+      for (int n1 = 0; n1 < R; ++n1) {
+        const int m = 64 * n1 + lane;
+        const cpx o = sA[m + (m >> 3)];
+        const cpx w2 = t_win[64 * n1];
+        *reinterpret_cast<cpx*>(out + 2 * m) = cmk(w2.x * o.x, -w2.y * o.y);
+      }
+      wave_lds_sync();
+    }
+  }
+  if (SPAN && f_hi > f_lo) {                                 // the chunk's tail: what is left in the ring
+    const int nf = f_hi - f_lo, rb = (nf * a.hop) & (NFFT - 1);
+    float* sp = span + (size_t)nf * a.hop;
+    for (int i = lane; i < NFFT - a.hop; i += 64) {
+      const int idx = (rb + i) & (NFFT - 1);
+      sp[i] = ring[idx];
+      ring[idx] = 0.0f;
     }
     wave_lds_sync();
+  }
+  }
+}
+
+// Backward of the linear-bin losses for n_fft 2048 on the 8-points-per-lane core (round 3): the forward of
+// stft2_kernel<.., NSUB = 2> (two 512-point half-transforms, in-lane combine, half-spectrum unpack), the cotangent per
+// bin pair in registers, then the inverse 1024-point transform split the other way round (decimation in frequency):
+//     A_p[k] = (Zin[k] + (-1)^p Zin[k + 512]) e^{+2 pi i k p / 1024},   z[2m + p] = IDFT_512(A_p)[m],   p = 0, 1,
+// Zin[k + 512] reaches the lane that owns k through one LDS exchange (it is computed as the partner value of bin 512 - k),
+// each IDFT_512 runs as the three forward passes on the conjugate, and a lane ends up with the four samples 4m .. 4m+3
+// of its m = k1 + 8 d + 64 e: one 16-byte store per (lane, e).  Same arithmetic as stft_grad_wave_kernel<11, false>,
+// which needs 198 VGPRs and 9.2 KB of scratch per wave (2 waves per SIMD) for its radix-16 first pass.
+//
+// SPAN: as in stft_grad_wave_kernel (a wave walks a chunk of G consecutive frames, overlap-add in an LDS ring, hop % 4
+// == 0).  The ring is kept in 16-byte units q = sample / 4 at slot q ^ ((q >> 3) & 7): the lanes' units m = k1 + 8 d
+// (+ 64 e) are 8 apart for consecutive lanes, the swizzle spreads them over the banks.
+template <int SP_WAVES, bool SPAN>
+__global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void stft_grad2k_kernel(const SgwArgs a, int nframes, unsigned magicF) {
+  constexpr int SP_THREADS = 64 * SP_WAVES, N2 = 1024, HALF = 512, NFFT = 2048, SCR = 64 * 9, NB = N2 + 1;
+  constexpr int NTAB = 16 + 8 + 8 + 8 + 8 + 16;   // stft2's 2048 section + the window at the lane's OUTPUT samples
+  constexpr int V2_BASE_2048 = 32 + 32 + 32 + 18;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  cpx* s_scr = reinterpret_cast<cpx*>(smem);
+  f32x4* s_ring = reinterpret_cast<f32x4*>(s_scr + SP_WAVES * SCR);         // SPAN: [wave][NFFT / 4]
+  cpx* s_tab = s_scr + SP_WAVES * SCR + (SPAN ? SP_WAVES * N2 : 0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (SPAN) for (int i = tid; i < SP_WAVES * NFFT / 4; i += SP_THREADS) s_ring[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  for (int i = tid; i < NTAB * 64; i += SP_THREADS) {
+    const int pp = i >> 6, l = i & 63, src = V2_BASE_2048 + 2 * pp;
+    s_tab[i] = cmk(a.tables[64 * src + l], a.tables[64 * (src + 1) + l]);
+  }
+  const cpx* t_win = s_tab + lane;              // [8 sub + n1]
+  const cpx* t_tw1 = t_win + 64 * 16;
+  const cpx* t_tw2 = t_tw1 + 64 * 8;
+  const cpx* t_cmb = t_tw2 + 64 * 8;            // [e] -> W_1024^k
+  const cpx* t_twu = t_cmb + 64 * 8;            // [e] -> W_2048^k
+  const cpx* t_wo = t_twu + 64 * 8;             // [2 e + h] -> window at samples 4 m + 2 h + {0, 1}, m = k1 + 8 d + 64 e
+  __syncthreads();
+  cpx* sA = s_scr + wave * SCR;
+  const int k1 = lane >> 3, dd = lane & 7, kl = k1 + 8 * dd;
+  float c0 = 0.0f, c1 = 0.0f;
+  if (a.loss_mode == 2) { c0 = (float)a.coef[0]; c1 = (float)a.coef[1]; }
+  auto bin_value = [&](float p) { return a.power2 ? p : sqrtf(a.loss_mode == 2 ? fmaxf(p, a.eps) : p); };
+  auto value_grad = [&](float v, float t) {
+    const float d = v - t;
+    const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+    return a.loss_mode == 2 ? c0 * d + c1 * sg / v : sg * a.scale;
+  };
+  auto power_grad = [&](float gv, float v) {
+    if (a.power2) return gv;
+    const bool live = a.loss_mode == 2 ? v > sqrtf(a.eps) : v > 0.0f;
+    return live ? gv / (2.0f * v) : 0.0f;
+  };
+  auto pad = [](int i) { return i + (i >> 3); };
+  // the three radix-8 passes of a 512-point transform: v = the lane's points 64 n1 + lane -> u[e] at kl + 64 e
+  auto fft512 = [&](cpx (&v)[8], cpx (&u)[8]) {
+    dft8(v);
+    {
+      const int c = lane & 7, aa = lane >> 3;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sA[(q * 8 + c) * 9 + aa] = cmul(v[q], t_tw1[64 * q]);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+    wave_lds_sync();
+    dft8(u);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) sA[(k1 * 8 + d) * 9 + dd] = cmul(u[d], t_tw2[64 * d]);
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+    wave_lds_sync();
+    dft8(u);
+  };
+
+  const int gw = blockIdx.x * SP_WAVES + wave, nw = gridDim.x * SP_WAVES;
+  f32x4* ring = s_ring + wave * (NFFT / 4);
+  auto slot = [](int q) { return q ^ ((q >> 3) & 7); };
+  for (int c = gw; c < (SPAN ? a.nchunks : nframes); c += nw) {
+  int b, f_lo, f_hi;
+  if (SPAN) { b = c / a.cper; f_lo = (c - b * a.cper) * a.G; f_hi = min(f_lo + a.G, a.F); }
+  else {
+    unsigned q0 = __umulhi((unsigned)c, magicF);
+    int fr0 = c - (int)q0 * a.F;
+    if (fr0 >= a.F) { fr0 -= a.F; ++q0; }
+    b = (int)q0; f_lo = fr0; f_hi = fr0 + 1;
+  }
+  f32x4* span = reinterpret_cast<f32x4*>(a.frame_grad + (size_t)c * a.L);   // SPAN (L % 4 == 0)
+  for (int fr = f_lo; fr < f_hi; ++fr) {
+    const int fi = b * a.F + fr;
+    float xc[32];
+    stft2_load_frame<2>(a.audio + (size_t)b * a.T, a.T, a.hop, fr, lane, xc);
+    const float* trow = a.target + (size_t)fi * NB;
+    // ---- forward: Z[k], Z[k + 512] for k = kl + 64 e
+    cpx zlo[8], zhi[8];
+    {
+      cpx ue[8], u[8], v[8];
+#pragma unroll
+      for (int n1 = 0; n1 < 8; ++n1) v[n1] = cmk(xc[2 * n1], xc[2 * n1 + 1]) * t_win[64 * n1];
+      fft512(v, ue);
+#pragma unroll
+      for (int n1 = 0; n1 < 8; ++n1) v[n1] = cmk(xc[16 + 2 * n1], xc[16 + 2 * n1 + 1]) * t_win[64 * (8 + n1)];
+      fft512(v, u);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const cpx t = cmul(u[e], t_cmb[64 * e]); zlo[e] = cadd(ue[e], t); zhi[e] = csub(ue[e], t); }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sA[pad(kl + 64 * e)] = zhi[e];
+    wave_lds_sync();
+    // ---- per bin pair (k, N2 - k): X, value, cotangent, the pair's two inverse inputs
+    cpx zk_in[8], zn_in[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = kl + 64 * e;
+      cpx zn = sA[pad((HALF - k) & (HALF - 1))];
+      const cpx zk = zlo[e];
+      if (e == 0 && k == 0) zn = zk;
+      const cpx w = t_twu[64 * e];                              // W_N^k = e^{-2 pi i k / N}
+      const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+      const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+      const cpx t = cmul(w, zo);
+      const cpx xk = cadd(ze, t);                               // X[k]
+      const cpx xq = cmk(ze.x - t.x, -(ze.y - t.y));            // X[N2 - k]
+      const float vk = bin_value(xk.x * xk.x + xk.y * xk.y), vq = bin_value(xq.x * xq.x + xq.y * xq.y);
+      const float gk = value_grad(vk, trow[k]), gq = value_grad(vq, trow[N2 - k]);
+      const cpx ck = xk * (2.0f * power_grad(gk, vk));          // G[k]
+      const cpx cq = xq * (2.0f * power_grad(gq, vq));          // G[N2 - k]
+      if (e == 0 && k == 0) {
+        zk_in[e] = cmk(ck.x + cq.x, ck.x - cq.x);              // edge bins (real X): a[0] + i b[0]
+        zn_in[e] = zk_in[e];
+      } else {
+        const cpx bk = cmul(ck, cmk(w.x, -w.y));                // b[k] = G[k] e^{+2 pi i k / N}
+        const cpx bn = cmul(cq, cmk(-w.x, -w.y));               // b[N2 - k] = G[N2 - k] (-W^k)
+        const cpx ak = cmk(0.5f * (ck.x + cq.x), 0.5f * (ck.y - cq.y));
+        const cpx sk = cmk(0.5f * (bk.x + bn.x), 0.5f * (bk.y - bn.y));
+        zk_in[e] = cmk(ak.x - sk.y, ak.y + sk.x);              // Zin[k]
+        zn_in[e] = cmk(ak.x + sk.y, -ak.y + sk.x);             // Zin[N2 - k] = conj(ak) + i conj(sk)
+      }
+    }
+    // bin HALF pairs with itself: X[HALF] = conj(Z[HALF]) (lane 0 holds Z[HALF] = zhi[0])
+    cpx zh_in;
+    {
+      const cpx xh = cmk(zhi[0].x, -zhi[0].y);
+      const float vh = bin_value(xh.x * xh.x + xh.y * xh.y);
+      const float gh = value_grad(vh, trow[HALF]);
+      const cpx ch = xh * (2.0f * power_grad(gh, vh));
+      zh_in = cmk(ch.x, -ch.y);                                 // (ch + conj ch)/2 + i (i ch + conj(i ch))/2 = conj(ch)
+    }
+    wave_lds_sync();                                            // every Z read is done
+    // ---- Zin[k + 512] to the lane that owns k: it was computed as the partner value of bin 512 - k
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int k = kl + 64 * e; if (k != 0) sA[pad(HALF - k)] = zn_in[e]; }
+    if (lane == 0) sA[0] = zh_in;
+    wave_lds_sync();
+    cpx a0[8], a1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const cpx zu = sA[pad(kl + 64 * e)];
+      const cpx wc = t_cmb[64 * e];                             // W_1024^k; its conjugate is e^{+2 pi i k / 1024}
+      a0[e] = cadd(zk_in[e], zu);
+      a1[e] = cmul(csub(zk_in[e], zu), cmk(wc.x, -wc.y));
+    }
+    wave_lds_sync();
+    // ---- the two inverse half-transforms, as forward passes on the conjugate
+    cpx r0[8], r1[8];
+    {
+      cpx v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sA[pad(kl + 64 * e)] = cmk(a0[e].x, -a0[e].y);
+      wave_lds_sync();
+#pragma unroll
+      for (int n1 = 0; n1 < 8; ++n1) v[n1] = sA[pad(64 * n1 + lane)];
+      wave_lds_sync();
+      fft512(v, r0);
+      wave_lds_sync();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sA[pad(kl + 64 * e)] = cmk(a1[e].x, -a1[e].y);
+      wave_lds_sync();
+#pragma unroll
+      for (int n1 = 0; n1 < 8; ++n1) v[n1] = sA[pad(64 * n1 + lane)];
+      wave_lds_sync();
+      fft512(v, r1);
+      wave_lds_sync();
+    }
+    // ---- frame_grad: samples 4 m .. 4 m + 3 of m = kl + 64 e = (y[2(2m)], y[2(2m)+1], y[2(2m+1)], y[2(2m+1)+1]) x window
+    if (SPAN) {
+      const int h4 = a.hop >> 2, rb = ((fr - f_lo) * h4) & (NFFT / 4 - 1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int m = kl + 64 * e;
+        const cpx w0 = t_wo[64 * (2 * e)], w1 = t_wo[64 * (2 * e + 1)];
+        f32x4* rp = ring + slot((rb + m) & (NFFT / 4 - 1));
+        const f32x4 cur = *rp;
+        *rp = (f32x4){cur[0] + w0.x * r0[e].x, cur[1] - w0.y * r0[e].y, cur[2] + w1.x * r1[e].x, cur[3] - w1.y * r1[e].y};
+      }
+      wave_lds_sync();
+      f32x4* sp = span + (size_t)(fr - f_lo) * h4;
+      for (int i = lane; i < h4; i += 64) {
+        f32x4* rp = ring + slot((rb + i) & (NFFT / 4 - 1));
+        sp[i] = *rp;
+        *rp = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+      }
+      wave_lds_sync();
+    } else {
+      float* out = a.frame_grad + (size_t)fi * NFFT;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int m = kl + 64 * e;
+        const cpx w0 = t_wo[64 * (2 * e)], w1 = t_wo[64 * (2 * e + 1)];
+        *reinterpret_cast<f32x4*>(out + 4 * m) = (f32x4){w0.x * r0[e].x, -w0.y * r0[e].y, w1.x * r1[e].x, -w1.y * r1[e].y};
+      }
+    }
+  }
+  if (SPAN && f_hi > f_lo) {                                 // the chunk's tail: what is left in the ring
+    const int h4 = a.hop >> 2, nf = f_hi - f_lo, rb = (nf * h4) & (NFFT / 4 - 1);
+    f32x4* sp = span + (size_t)nf * h4;
+    for (int i = lane; i < NFFT / 4 - h4; i += 64) {
+      f32x4* rp = ring + slot((rb + i) & (NFFT / 4 - 1));
+      sp[i] = *rp;
+      *rp = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    wave_lds_sync();
+  }
   }
 }
 
 // frame_grad [B,F,n_fft] <- d loss / d (windowed frames) (see stft_grad_wave_kernel); tables: ias_stft_build_tables of
 // the plan's window; mel_*: the forward's CSR filterbank or NULL (linear bins, n_out = n_fft/2+1); target [B,F,n_out];
 // coef: device doubles [2] (loss_mode 2, linear bins only).
-extern "C" int ias_stft_grad_frames(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
-                                    const int* mel_woff, const float* mel_w, int mel_nnz, int n_out, const float* target,
-                                    const double* coef, float* frame_grad, int B, int T, int n_fft, int hop, int power,
-                                    int loss_mode, float scale, float eps, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+// plan != NULL: the SPAN kernels (overlap-add inside the kernel); frame_grad then receives B * plan[1] chunk spans of
+// plan[2] floats (plan[0] = frames per chunk), IAS_ERR_UNSUPPORTED when the shape does not allow it.
+static int grad_frames_launch(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
+                              const int* mel_woff, const float* mel_w, int mel_nnz, int n_out, const float* target,
+                              const double* coef, float* frame_grad, int B, int T, int n_fft, int hop, int power,
+                              int loss_mode, float scale, float eps, int* plan, hipStream_t stream) {
   if (!audio || !tables || !target || !frame_grad || B <= 0 || B > 65535 || hop <= 0) return IAS_ERR_ARG;
   if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return IAS_ERR_UNSUPPORTED;
   if ((power != 1 && power != 2) || (loss_mode != 1 && loss_mode != 2) || (loss_mode == 2 && !coef)) return IAS_ERR_ARG;
@@ -991,35 +1263,114 @@ extern "C" int ias_stft_grad_frames(const float* audio, const float* tables, con
   if (!mel && n_out != n_fft / 2 + 1) return IAS_ERR_ARG;
   const int F = ias_stft_num_frames(T, n_fft, hop);
   if (F < 0 || F > 2147483647 / n_fft) return IAS_ERR_ARG;
+  const bool span = plan != nullptr;
   SgwArgs a;
   a.audio = audio; a.tables = tables; a.target = target; a.coef = coef; a.frame_grad = frame_grad;
   a.T = T; a.F = F; a.hop = hop; a.power2 = power == 2; a.loss_mode = loss_mode; a.scale = scale; a.eps = eps;
   a.mel_start = mel_start; a.mel_count = mel_count; a.mel_woff = mel_woff; a.mel_w = mel_w;
   a.n_out = n_out; a.mel_nnz = mel ? mel_nnz : 0;
+  a.G = a.cper = a.L = a.nchunks = 0;
   static const int wgs_env = getenv("IAS_STFT_GRAD_WGS") ? atoi(getenv("IAS_STFT_GRAD_WGS")) : 0;   // diagnostics
   int per_row = (wgs_env > 0 ? wgs_env : 1024) / B;   // one resident round (measured: 2.36 -> 2.29 ms for the MR-STFT loss)
   if (per_row < 1) per_row = 1;
   int g = (F + per_row - 1) / per_row;
   if (g < 8) g = 8;
   a.groups = g;
+  int ncu = 256, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+  if (span && (hop > n_fft / 2 || (hop & 1) || (long long)B * F >= 2000000000LL)) return IAS_ERR_UNSUPPORTED;
+  // chunks for `nwaves` resident waves: every wave one chunk of G consecutive frames (G hop >= n_fft - hop: a sample then
+  // lies in at most two chunk spans), chunks never cross rows
+  auto make_plan = [&](long long nwaves) -> bool {
+    long long cper0 = nwaves / B;
+    if (cper0 < 1) cper0 = 1;
+    int G = (int)((F + cper0 - 1) / cper0);
+    const int gmin = (n_fft - hop + hop - 1) / hop;
+    if (G < gmin) G = gmin;
+    if (G >= F) G = F;
+    const int cper = (F + G - 1) / G;
+    const long long L = (long long)(G - 1) * hop + n_fft;
+    if ((long long)B * cper * L > (long long)B * F * n_fft || (long long)B * cper > 2000000000LL) return false;
+    a.G = G; a.cper = cper; a.L = (int)L; a.nchunks = B * cper;
+    plan[0] = G; plan[1] = cper; plan[2] = (int)L;
+    return true;
+  };
+  static const int v1_2k = getenv("IAS_STFT_V1") ? atoi(getenv("IAS_STFT_V1")) : 0;   // diagnostics: round-2 kernels
+  if (n_fft == 2048 && !mel && !v1_2k && (long long)B * F < 2000000000LL && (reinterpret_cast<uintptr_t>(frame_grad) & 15) == 0 &&
+      (!span || (hop & 3) == 0)) {
+    constexpr int W2 = 8;
+    const size_t lds2 = sizeof(cpx) * (W2 * 64 * 9 + 64 * 64 + (span ? W2 * 1024 : 0));
+    if (span) {
+      if (!make_plan((long long)ncu * W2)) return IAS_ERR_UNSUPPORTED;
+      const long long need = ((long long)a.nchunks + W2 - 1) / W2;
+      const int grid2 = (int)(need < (long long)ncu ? need : (long long)ncu);
+      (void)hipFuncSetAttribute((const void*)stft_grad2k_kernel<W2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      hipLaunchKernelGGL((stft_grad2k_kernel<W2, true>), dim3(grid2), dim3(64 * W2), lds2, stream, a, B * F, 0u);
+    } else {
+      const long long need = ((long long)B * F + W2 - 1) / W2;
+      const int grid2 = (int)(need < 2LL * ncu ? need : 2LL * ncu);
+      (void)hipFuncSetAttribute((const void*)stft_grad2k_kernel<W2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      hipLaunchKernelGGL((stft_grad2k_kernel<W2, false>), dim3(grid2), dim3(64 * W2), lds2, stream, a, B * F,
+                         (unsigned)(0x100000000ULL / (unsigned long long)F));
+    }
+    return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+  }
   const int R = n_fft / 128, scr = 8 * R * 9, np_it = (8 * R + 63) / 64, nunp = (n_fft / 4) / 64 + 1;
   size_t lds = sizeof(cpx) * 4 * scr + sizeof(float) * 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp) + 16;
+  if (span) lds += sizeof(float) * 4 * n_fft;
   if (mel)
     lds += sizeof(float) * (mel_padded_words(mel_nnz, n_out) + ((3 * n_out + 3) & ~3) +
                             4 * (((n_out + 3) & ~3) + n_fft / 2 + 1 + 7));
   if (lds > 150 * 1024) return IAS_ERR_UNSUPPORTED;
-  const dim3 grid((F + g - 1) / g, B), block(256);
-#define IAS_SGW_LAUNCH(LOG2N, MEL)                                                                                \
+  dim3 grid((F + g - 1) / g, B), block(256);
+#define IAS_SGW_LAUNCH(LOG2N, MEL, SPAN)                                                                          \
   do {                                                                                                             \
     if (lds > 64 * 1024)                                                                                           \
-      (void)hipFuncSetAttribute((const void*)stft_grad_wave_kernel<LOG2N, MEL>,                                    \
+      (void)hipFuncSetAttribute((const void*)stft_grad_wave_kernel<LOG2N, MEL, SPAN>,                              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
-    hipLaunchKernelGGL((stft_grad_wave_kernel<LOG2N, MEL>), grid, block, lds, stream, a);                          \
+    if (SPAN) {                                                                                                    \
+      int nb = 0;                                                                                                  \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stft_grad_wave_kernel<LOG2N, MEL, SPAN>, 256, lds) !=  \
+              hipSuccess || nb < 1)                                                                                \
+        nb = 1;                                                                                                    \
+      if (!make_plan((long long)ncu * nb * 4)) return IAS_ERR_UNSUPPORTED;                                         \
+      const long long need = ((long long)a.nchunks + 3) / 4;                                                       \
+      grid = dim3((unsigned)(need < (long long)ncu * nb ? need : (long long)ncu * nb));                            \
+    }                                                                                                              \
+    hipLaunchKernelGGL((stft_grad_wave_kernel<LOG2N, MEL, SPAN>), grid, block, lds, stream, a);                    \
   } while (0)
-  if (mel) { if (n_fft == 512) IAS_SGW_LAUNCH(9, true); else if (n_fft == 1024) IAS_SGW_LAUNCH(10, true); else IAS_SGW_LAUNCH(11, true); }
-  else { if (n_fft == 512) IAS_SGW_LAUNCH(9, false); else if (n_fft == 1024) IAS_SGW_LAUNCH(10, false); else IAS_SGW_LAUNCH(11, false); }
+#define IAS_SGW_PICK(MEL, SPAN)                                                                                    \
+  do {                                                                                                             \
+    if (n_fft == 512) IAS_SGW_LAUNCH(9, MEL, SPAN);                                                                \
+    else if (n_fft == 1024) IAS_SGW_LAUNCH(10, MEL, SPAN);                                                         \
+    else IAS_SGW_LAUNCH(11, MEL, SPAN);                                                                            \
+  } while (0)
+  if (mel) { if (span) IAS_SGW_PICK(true, true); else IAS_SGW_PICK(true, false); }
+  else { if (span) IAS_SGW_PICK(false, true); else IAS_SGW_PICK(false, false); }
+#undef IAS_SGW_PICK
 #undef IAS_SGW_LAUNCH
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+extern "C" int ias_stft_grad_frames(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
+                                    const int* mel_woff, const float* mel_w, int mel_nnz, int n_out, const float* target,
+                                    const double* coef, float* frame_grad, int B, int T, int n_fft, int hop, int power,
+                                    int loss_mode, float scale, float eps, void* stream_) {
+  return grad_frames_launch(audio, tables, mel_start, mel_count, mel_woff, mel_w, mel_nnz, n_out, target, coef, frame_grad,
+                            B, T, n_fft, hop, power, loss_mode, scale, eps, nullptr, (hipStream_t)stream_);
+}
+
+// The same with the overlap-add inside the kernel: chunk_spans (at least B * F * n_fft floats, 16-byte aligned) receives
+// B * plan_host[1] spans of plan_host[2] floats, span c = row c / plan[1], frames [j G, j G + G) with j = c % plan[1],
+// G = plan_host[0]: span[i] = sum over the chunk's frames f covering padded sample j G hop + i of window x frame
+// gradient, in frame order.  stft_grad_combine_kernel (ias_stft_loss_backward) adds the (at most two) chunks per sample.
+extern "C" int ias_stft_grad_spans(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
+                                   const int* mel_woff, const float* mel_w, int mel_nnz, int n_out, const float* target,
+                                   const double* coef, float* chunk_spans, int B, int T, int n_fft, int hop, int power,
+                                   int loss_mode, float scale, float eps, int* plan_host, void* stream_) {
+  if (!plan_host) return IAS_ERR_ARG;
+  return grad_frames_launch(audio, tables, mel_start, mel_count, mel_woff, mel_w, mel_nnz, n_out, target, coef, chunk_spans,
+                            B, T, n_fft, hop, power, loss_mode, scale, eps, plan_host, (hipStream_t)stream_);
 }
 
 // sums[0..2] = sum over n partial triples (fixed order: deterministic); optionally
@@ -1127,8 +1478,9 @@ extern "C" int ias_stft_tables_len(int n_fft) {
   const int N2 = n_fft / 2, R = N2 / 64, np_it = (8 * R + 63) / 64, nunp = (N2 / 2) / 64 + 1;
   // n_fft 1024: + the unpack twiddles of stft2_kernel (bins k = (lane >> 3) + 8 (lane & 7) + 64 e, e < 4);
   // n_fft 2048: + stft2_kernel<NSUB = 2>'s whole table section (window pairs of the two half-transforms, pass-1 / pass-2
-  // twiddles of a 512-point transform, combining twiddles W_1024^k, unpack twiddles W_2048^k: 48 complex per lane)
-  return 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp + (n_fft == 1024 ? 8 : 0) + (n_fft == 2048 ? 96 : 0));
+  // twiddles of a 512-point transform, combining twiddles W_1024^k, unpack twiddles W_2048^k, and for the backward
+  // (stft_grad2k_kernel) the window at the lane's output samples: 64 complex per lane)
+  return 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp + (n_fft == 1024 ? 8 : 0) + (n_fft == 2048 ? 128 : 0));
 }
 
 extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float* out_host) {
@@ -1183,6 +1535,12 @@ extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float*
       for (int d = 0; d < 8; ++d) put(cos(tau * (double)((l & 7) * d) / 64.0), -sin(tau * (double)((l & 7) * d) / 64.0));
       for (int ee = 0; ee < 8; ++ee) { const int k = (l >> 3) + 8 * (l & 7) + 64 * ee; put(cos(tau * k / 1024.0), -sin(tau * k / 1024.0)); }
       for (int ee = 0; ee < 8; ++ee) { const int k = (l >> 3) + 8 * (l & 7) + 64 * ee; put(cos(tau * k / 2048.0), -sin(tau * k / 2048.0)); }
+      // the backward's window: samples 4 m + 2 h + {0, 1} of m = (l >> 3) + 8 (l & 7) + 64 e
+      for (int ee = 0; ee < 8; ++ee)
+        for (int h = 0; h < 2; ++h) {
+          const int m = (l >> 3) + 8 * (l & 7) + 64 * ee;
+          put(window_host[4 * m + 2 * h], window_host[4 * m + 2 * h + 1]);
+        }
     }
   }
   return IAS_OK;

@@ -122,10 +122,14 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_inc_kernel(
 __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_sample_kernel(
     const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst, const float* __restrict__ noise,
     const float* __restrict__ g_mixed, float* __restrict__ planes, const double* __restrict__ tile_sums,
-    double* __restrict__ partials /* [B][ntiles][IAS_GRAD_NS] */, int T, int Tc, int ntiles, float scale) {
+    double* __restrict__ partials /* [B][ntiles][IAS_GRAD_NS] */, int T, int Tc, int ntiles, float scale,
+    const float* __restrict__ rownorm /* NULL, or [B][4]: peak divisor, index of the peak sample, its correction */) {
   __shared__ double s_w[2 * GRAD_WAVES];
   __shared__ double s_red[GRAD_WAVES * 8];
   const int tid = threadIdx.x, tile = blockIdx.x, b = blockIdx.y;
+  // the cotangent of the un-normalised mix from that of the normalised audio (voice_norm_finish_kernel)
+  const float n_div = rownorm ? rownorm[4 * b] : 1.0f, n_corr = rownorm ? rownorm[4 * b + 2] : 0.0f;
+  const int n_tstar = rownorm ? __float_as_int(rownorm[4 * b + 1]) : -1;
   const IasVoiceConst vc = vconst[b];
   const float* cb = ctrl + (size_t)b * IAS_NCTRL * Tc;
   float* pl = planes + (size_t)b * IAS_GRAD_PLANES * T;
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_sample_kernel(
     a2 = ok ? fabsf(pl[(size_t)PL_INC2 * T + j]) : 0.0f;
     nzv = ok ? nrow[j] : 0.0f;
     gv = ok ? grow[j] : 0.0f;
+    if (rownorm) { gv = gv / n_div; if (j == n_tstar) gv = gv + n_corr; }
   };
   float n_inc1, n_inc2, n_nz, n_g;
   fetch(0, n_inc1, n_inc2, n_nz, n_g);
@@ -200,6 +205,82 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_sample_kernel(
     o[GS_KPART] = s_out[3]; o[GS_SHAPE] = s_out[4]; o[GS_GAIN] = s_out[5];
     o[GS_PHI_1] = s_out[6]; o[GS_PHI_2] = s_out[7];
   }
+}
+
+// ------------------------------------------------------------------------------------------------ K0 (normalisation)
+// audio = mix / peak on rows with peak = max |mix| > 1 (torchsynth normalize_if_clipping), attained at t*:
+//   g_mix[t] = g[t] / peak,  and the peak takes  -sign(audio[t*]) sum_t g[t] audio[t] / peak  at t*
+// (autograd's max-of-abs convention: the whole gradient to the first sample that attains the maximum).  Two launches
+// instead of the 14 torch ones: per-tile partial (dot, max |audio|, its first index), then per row the fixed-order finish
+// -> rownorm [B][4] = {divisor (peak or 1), t* (int bits; -1: no correction), correction, 0}, applied by K1 as it reads g.
+#define NORM_TILE (GRAD_THREADS * 4 * 8)
+__global__ __launch_bounds__(GRAD_THREADS) void voice_norm_partial_kernel(const float* __restrict__ g,
+                                                                          const float* __restrict__ audio, int T,
+                                                                          int ntiles, double* __restrict__ part /* [B][ntiles][2] */) {
+  __shared__ double s_dot[GRAD_WAVES];
+  __shared__ float s_max[GRAD_WAVES];
+  __shared__ int s_idx[GRAD_WAVES];
+  const int tid = threadIdx.x, tile = blockIdx.x, b = blockIdx.y;
+  const float* grow = g + (size_t)b * T;
+  const float* arow = audio + (size_t)b * T;
+  double dot = 0.0;
+  float mx = -1.0f;
+  int mi = 0x7fffffff;
+  for (int it = 0; it < 8; ++it) {
+    const int j0 = tile * NORM_TILE + (it * GRAD_THREADS + tid) * 4;
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + e;
+      if (j < T) {
+        const float av = arow[j];
+        dot += (double)(grow[j] * av);
+        const float m = fabsf(av);
+        if (m > mx) { mx = m; mi = j; }        // j ascends within the thread: the first index of its maximum
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    dot += __shfl_xor(dot, d, 64);
+    const float om = __shfl_xor(mx, d, 64);
+    const int oi = __shfl_xor(mi, d, 64);
+    if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+  }
+  if ((tid & 63) == 0) { s_dot[tid >> 6] = dot; s_max[tid >> 6] = mx; s_idx[tid >> 6] = mi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < GRAD_WAVES; ++w) {
+      dot += s_dot[w];
+      if (s_max[w] > mx || (s_max[w] == mx && s_idx[w] < mi)) { mx = s_max[w]; mi = s_idx[w]; }
+    }
+    double* o = part + ((size_t)b * ntiles + tile) * 2;
+    o[0] = dot;
+    o[1] = __hiloint2double(__float_as_int(mx), mi);
+  }
+}
+
+__global__ void voice_norm_finish_kernel(const double* __restrict__ part, const float* __restrict__ audio,
+                                         const float* __restrict__ peaks, int B, int T, int ntiles,
+                                         float* __restrict__ rownorm) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double dot = 0.0;
+  float mx = -1.0f;
+  int mi = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const double* o = part + ((size_t)b * ntiles + t) * 2;
+    dot += o[0];
+    const float om = __int_as_float(__double2hiint(o[1]));
+    const int oi = __double2loint(o[1]);
+    if (om > mx) { mx = om; mi = oi; }          // tiles ascend: ties keep the earlier index
+  }
+  const float pk = peaks[b];
+  const bool clip = pk > 1.0f;
+  const float av = audio[(size_t)b * T + mi];
+  const float sg = av > 0.0f ? 1.0f : (av < 0.0f ? -1.0f : 0.0f);
+  rownorm[4 * b] = clip ? pk : 1.0f;
+  rownorm[4 * b + 1] = __int_as_float(clip ? mi : -1);
+  rownorm[4 * b + 2] = clip ? -sg * (float)dot / pk : 0.0f;
+  rownorm[4 * b + 3] = 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------ K2
@@ -369,9 +450,40 @@ extern "C" int ias_voice_grad_nplanes(void) { return IAS_GRAD_PLANES; }
 // partials [B, ntiles, ias_voice_grad_nscalars()] fp64 out (sum over tiles = gradient of the per-voice
 // constants in the order f0_1 depth_1 phi_1 f0_2 depth_2 phi_2 kpart shape gain lvl0 lvl1 lvl2);
 // g_ctrl [B,5,Tc] fp32 out.  ntiles = ias_voice_grad_tiles(T).
+extern "C" int ias_voice_backward_norm(const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
+                                       const float* rownorm, float* planes, double* tile_sums, double* partials,
+                                       float* g_ctrl, int B, int T, int Tc, int sample_rate, void* stream_);
 extern "C" int ias_voice_backward(const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
                                   float* planes, double* tile_sums, double* partials, float* g_ctrl, int B, int T,
                                   int Tc, int sample_rate, void* stream_) {
+  return ias_voice_backward_norm(ctrl, vconst, noise, g_mixed, nullptr, planes, tile_sums, partials, g_ctrl, B, T, Tc,
+                                 sample_rate, stream_);
+}
+
+// rownorm [B][4] from the cotangent g [B,T] of the NORMALISED audio [B,T] and the row peaks of the un-normalised mix
+// (ias_voice_read_peaks); scratch: ias_voice_norm_scratch_len(T) * B doubles.  Feed rownorm and g to
+// ias_voice_backward_norm: the division by the peak and the correction at the peak sample happen as g is read.
+extern "C" long long ias_voice_norm_scratch_len(int T) {
+  if (T <= 0) return IAS_ERR_ARG;
+  return 2LL * ((T + NORM_TILE - 1) / NORM_TILE);
+}
+extern "C" int ias_voice_norm_backward(const float* g_audio, const float* audio, const float* peaks, double* scratch,
+                                       float* rownorm, int B, int T, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!g_audio || !audio || !peaks || !scratch || !rownorm || B <= 0 || B > 65535 || T <= 0) return IAS_ERR_ARG;
+  const int ntiles = (T + NORM_TILE - 1) / NORM_TILE;
+  hipLaunchKernelGGL(voice_norm_partial_kernel, dim3(ntiles, B), dim3(GRAD_THREADS), 0, stream, g_audio, audio, T,
+                     ntiles, scratch);
+  hipLaunchKernelGGL(voice_norm_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, scratch, audio, peaks, B, T,
+                     ntiles, rownorm);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+// the same as ias_voice_backward with the cotangent of the normalised audio and its rownorm (NULL: g_mixed is the
+// cotangent of the mix itself)
+extern "C" int ias_voice_backward_norm(const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
+                                       const float* rownorm, float* planes, double* tile_sums, double* partials,
+                                       float* g_ctrl, int B, int T, int Tc, int sample_rate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!ctrl || !vconst || !noise || !g_mixed || !planes || !tile_sums || !partials || !g_ctrl) return IAS_ERR_ARG;
   if (B <= 0 || B > 65535 || T <= 1 || Tc <= 1 || sample_rate <= 0) return IAS_ERR_ARG;
@@ -386,7 +498,7 @@ extern "C" int ias_voice_backward(const float* ctrl, const void* vconst, const f
   hipLaunchKernelGGL(voice_grad_inc_kernel, grid, block, 0, stream, ctrl, vc, planes, tile_sums, T, Tc, ntiles,
                      1.0 / (double)sample_rate, scale);
   hipLaunchKernelGGL(voice_grad_sample_kernel, grid, block, 0, stream, ctrl, vc, noise, g_mixed, planes, tile_sums,
-                     partials, T, Tc, ntiles, scale);
+                     partials, T, Tc, ntiles, scale, rownorm);
   hipLaunchKernelGGL(voice_grad_pitch_kernel, grid, block, 0, stream, ctrl, vc, planes, partials, T, Tc, ntiles,
                      scale);
   hipLaunchKernelGGL(voice_grad_ctrl_kernel, dim3((Tc + CT_INTERVALS - 1) / CT_INTERVALS, IAS_NCTRL, B), block, 0,

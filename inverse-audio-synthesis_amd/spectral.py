@@ -340,14 +340,18 @@ class MultiResolutionSTFTLoss(nn.Module):
                     s = plan.loss_sums(x, tgt, VALUE_MAG_CLAMPED, LOSS_MRSTFT, self.eps)
                     s.record_stream(cur)
                     sums.append(s)
-        total, saved = None, []
+        saved = []
         for k, (tgt, s) in enumerate(zip(targets, sums)):
             if streams is not None:
                 cur.wait_stream(streams[k])
-            term = torch.sqrt(s[0]) / torch.sqrt(s[1]) + s[2] / tgt.numel()
-            total = term if total is None else total + term
             saved.append((tgt, s))
-        return (total / len(self.plans)).float(), saved
+        # (sum_k sqrt(s_k[0]) / sqrt(s_k[1]) + s_k[2] / count_k) / nres in fp64 -> fp32, one launch
+        n = len(sums)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in sums])
+        counts = (ctypes.c_double * n)(*[float(t.numel()) for t in targets])
+        _lib.check(_lib.load().ias_mrstft_total(ptrs, counts, n, _lib.ptr(loss), _lib.stream()), "ias_mrstft_total")
+        return loss, saved
 
 
 class _MRSTFTFn(torch.autograd.Function):
@@ -368,7 +372,7 @@ class _MRSTFTFn(torch.autograd.Function):
         lib = _lib.load()
         B, T = a.shape
         nres = len(module.plans)
-        g64 = g_loss.to(torch.float64).reshape(())
+        g32 = g_loss.to(torch.float32).reshape(()).contiguous()
         cur = torch.cuda.current_stream(a.device)
         streams = module._streams(a.device) if module.parallel else None
         grads = []
@@ -377,7 +381,7 @@ class _MRSTFTFn(torch.autograd.Function):
             if streams is not None:
                 streams[i].wait_stream(cur)
             with torch.cuda.stream(streams[i] if streams is not None else cur):
-                grads.append(_mrstft_plan_backward(lib, plan, a, tgt, s, g64, nres, float(module.eps), cur))
+                grads.append(_mrstft_plan_backward(lib, plan, a, tgt, s, g32, nres, float(module.eps), cur))
         g_total = None
         for i, g_audio in enumerate(grads):      # joined in a fixed order
             if streams is not None:
@@ -386,15 +390,16 @@ class _MRSTFTFn(torch.autograd.Function):
         return (g_total.reshape(ctx.shape), None) + (None,) * len(module.plans)
 
 
-def _mrstft_plan_backward(lib, plan, a, tgt, s, g64, nres, eps, consumer_stream):
+def _mrstft_plan_backward(lib, plan, a, tgt, s, g32, nres, eps, consumer_stream):
     """One resolution's d loss / d audio (on the current stream; the result is handed to ``consumer_stream``)."""
     B, T = a.shape
     here = torch.cuda.current_stream(a.device)
-    g64.record_stream(here)
-    # d (sqrt(l0) / sqrt(l1)) / dV = (V - T) / (sqrt(l0) sqrt(l1));  d (l2 / count) / dV = sign(V - T) / (V count)
-    den = torch.sqrt(s[0]) * torch.sqrt(s[1])
-    c0 = torch.where(den > 0, g64 / (nres * den), torch.zeros_like(den))
-    coef = torch.stack([c0, g64 / (nres * tgt.numel())]).contiguous()
+    g32.record_stream(here)
+    # d (sqrt(l0) / sqrt(l1)) / dV = (V - T) / (sqrt(l0) sqrt(l1));  d (l2 / count) / dV = sign(V - T) / (V count):
+    # coef = [g / (nres sqrt(l0) sqrt(l1)) or 0, g / (nres count)], one launch
+    coef = torch.empty(2, dtype=torch.float64, device=a.device)
+    _lib.check(lib.ias_mrstft_coef(_lib.ptr(s), _lib.ptr(g32), float(tgt.numel()), nres, _lib.ptr(coef), _lib.stream()),
+               "ias_mrstft_coef")
     frame_grad = torch.empty((B, plan.num_frames(T), plan.n_fft), dtype=torch.float32, device=a.device)
     g_audio = torch.empty_like(a)
     st = lib.ias_stft_loss_backward(_lib.ptr(a), _lib.ptr(plan.window), _lib.ptr(plan.tables), None, None, None,
@@ -424,4 +429,41 @@ class SubbandL1(nn.Module):
         if target_bands is None:
             target_bands = self.target(target_audio)
         z = self.gram(audio if audio.dim() == 3 else audio.unsqueeze(1))
-        return (z - target_bands.detach()).abs().mean()
+        return l1_mean(z, target_bands.detach())
+
+
+class _L1MeanFn(torch.autograd.Function):
+    """mean |x - y| with the gradient w.r.t. x: two fused launches each way (csrc/spectral_grad_kernels.hip) instead of
+    the sub / abs / mean and sign / mul / expand chains."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        lib = _lib.load()
+        xc, yc = x.detach().contiguous(), y.contiguous()
+        _lib.require_f32(xc, yc)
+        assert xc.shape == yc.shape
+        n = xc.numel()
+        nwg = lib.ias_l1_partials_count(n)
+        partials = torch.empty((nwg, 3), dtype=torch.float64, device=xc.device)
+        _lib.check(lib.ias_l1_partials(_lib.ptr(xc), _lib.ptr(yc), n, _lib.ptr(partials), _lib.stream()), "ias_l1_partials")
+        sums = torch.empty(3, dtype=torch.float64, device=xc.device)
+        mean = torch.empty((), dtype=torch.float32, device=xc.device)
+        _lib.check(lib.ias_reduce_partials(_lib.ptr(partials), nwg, _lib.ptr(sums), 1.0 / n, _lib.ptr(mean), _lib.stream()),
+                   "ias_reduce_partials")
+        ctx.save_for_backward(xc, yc)
+        return mean
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, yc = ctx.saved_tensors
+        lib = _lib.load()
+        g32 = g.to(torch.float32).reshape(()).contiguous()
+        gx = torch.empty_like(xc)
+        _lib.check(lib.ias_l1_grad(_lib.ptr(xc), _lib.ptr(yc), _lib.ptr(g32), 1.0 / xc.numel(), xc.numel(), _lib.ptr(gx),
+                                   _lib.stream()), "ias_l1_grad")
+        return gx, None
+
+
+def l1_mean(x, y):
+    """mean |x - y| (fp32 tensors of one shape on the device; differentiable w.r.t. x)."""
+    return _L1MeanFn.apply(x, y)

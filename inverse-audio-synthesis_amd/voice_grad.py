@@ -149,8 +149,24 @@ def control_graph(params01, cfg):
     return ctrl, scal
 
 
-def audio_rate_backward(voice, params01, g_mixed):
-    """HIP adjoint of the audio-rate render: g_mixed [B,T] -> (g_ctrl [B,5,Tc] fp32, g_constants [B,12] fp64)."""
+def normalisation_rows(g_audio, audio, peaks):
+    """rownorm [B,4] for ``audio_rate_backward``: the adjoint of torchsynth's normalize_if_clipping (audio = mix / peak
+    on rows with peak = max |mix| > 1) folded into two small launches: the divisor per row and the correction
+    -sign(audio[t*]) * sum_t g[t] audio[t] / peak at the peak sample t* (csrc/voice_grad_kernels.hip, K0)."""
+    lib = _lib.load()
+    B, T = audio.shape
+    _lib.require_f32(g_audio, audio, peaks)
+    scratch = torch.empty((B, lib.ias_voice_norm_scratch_len(T)), dtype=torch.float64, device=audio.device)
+    rownorm = torch.empty((B, 4), dtype=torch.float32, device=audio.device)
+    _lib.check(lib.ias_voice_norm_backward(_lib.ptr(g_audio), _lib.ptr(audio), _lib.ptr(peaks), _lib.ptr(scratch),
+                                           _lib.ptr(rownorm), B, T, _lib.stream()), "ias_voice_norm_backward")
+    return rownorm
+
+
+def audio_rate_backward(voice, params01, g_mixed, rownorm=None):
+    """HIP adjoint of the audio-rate render: g_mixed [B,T] -> (g_ctrl [B,5,Tc] fp32, g_constants [B,12] fp64).
+    ``rownorm``: ``normalisation_rows`` of a normalised render; ``g_mixed`` is then the cotangent of the normalised
+    audio."""
     c = voice.synthconfig
     lib = _lib.load()
     B, T, Tc = c.batch_size, c.buffer_size, c.control_buffer_size
@@ -163,10 +179,10 @@ def audio_rate_backward(voice, params01, g_mixed):
     tile_sums = torch.empty((B, ntiles, 2), dtype=torch.float64, device=dev)
     partials = torch.empty((B, ntiles, lib.ias_voice_grad_nscalars()), dtype=torch.float64, device=dev)
     g_ctrl = torch.empty((B, 5, Tc), dtype=torch.float32, device=dev)
-    st = lib.ias_voice_backward(_lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(voice.noise), _lib.ptr(g_mixed),
-                                _lib.ptr(planes), _lib.ptr(tile_sums), _lib.ptr(partials), _lib.ptr(g_ctrl),
-                                B, T, Tc, c.sample_rate, _lib.stream())
-    _lib.check(st, "ias_voice_backward")
+    st = lib.ias_voice_backward_norm(_lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(voice.noise), _lib.ptr(g_mixed),
+                                     _lib.ptr(rownorm), _lib.ptr(planes), _lib.ptr(tile_sums), _lib.ptr(partials),
+                                     _lib.ptr(g_ctrl), B, T, Tc, c.sample_rate, _lib.stream())
+    _lib.check(st, "ias_voice_backward_norm")
     return g_ctrl, partials.sum(dim=1)
 
 
@@ -258,20 +274,11 @@ class _RenderFn(torch.autograd.Function):
     def backward(ctx, g_audio):
         p, audio, peaks = ctx.saved_tensors
         voice = ctx.voice
-        g = g_audio.to(torch.float32)
-        if ctx.normalize:
-            # audio = mixed / peak on rows with peak > 1 (peak = max |mixed|, attained at t*):
-            #   g_mixed = g / peak, and the peak itself takes -sign(mixed[t*]) * sum_t g[t] audio[t] / peak at t*
-            clip = peaks > 1.0
-            pk = torch.where(clip, peaks, torch.ones_like(peaks)).unsqueeze(1)
-            g_mixed = g / pk
-            dot = (g * audio).sum(dim=1)
-            tstar = audio.abs().argmax(dim=1, keepdim=True)
-            corr = -torch.sign(audio.gather(1, tstar)).squeeze(1) * dot / pk.squeeze(1)
-            g_mixed.scatter_add_(1, tstar, torch.where(clip, corr, torch.zeros_like(corr)).unsqueeze(1))
-        else:
-            g_mixed = g
-        g_ctrl, g_scal = audio_rate_backward(voice, p, g_mixed)
+        g = g_audio.to(torch.float32).contiguous()
+        # audio = mixed / peak on rows with peak > 1 (peak = max |mixed|, attained at t*):
+        #   g_mixed = g / peak, and the peak itself takes -sign(mixed[t*]) * sum_t g[t] audio[t] / peak at t*
+        rownorm = normalisation_rows(g, audio, peaks) if ctx.normalize else None
+        g_ctrl, g_scal = audio_rate_backward(voice, p, g, rownorm)
         g_p = _control_backward(voice.synthconfig, p, g_ctrl, g_scal)
         return g_p.to(torch.float32), None, None
 

@@ -11,6 +11,7 @@ g = torch.Generator().manual_seed(0)
 a = (torch.randn(B, 176400, generator=g) * 0.1).to(dev).requires_grad_(True)
 t = (torch.randn(B, 176400, generator=g) * 0.1).to(dev)
 mr = MultiResolutionSTFTLoss().to(dev)
+if os.environ.get('SERIAL'): mr.parallel = False      # the resolutions one after the other: isolated kernel times
 tm = mr.target(t)
 def step():
     a.grad = None

@@ -107,3 +107,76 @@ def test_audio_to_params_loop_end_to_end(lib, dev):
         step[:, cols] = q.grad[:, cols]
         p = (p - 0.03 * step / step.abs().max().clamp_min(1e-12)).clamp(0.01, 0.99)
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+@pytest.mark.parametrize("n_fft,hop,B,T", [(512, 50, 3, 9001), (1024, 120, 2, 30001), (2048, 240, 2, 40000),
+                                           (2048, 512, 1, 5000), (1024, 512, 5, 2000), (512, 128, 70, 3000)])
+def test_chunk_spans_equal_the_folded_frame_tensor(lib, dev, n_fft, hop, B, T):
+    """ias_stft_grad_spans (overlap-add inside the frame kernel: per-wave chunks of consecutive frames, LDS ring) against
+    ias_stft_grad_frames' [B,F,n_fft] tensor overlap-added on the host in fp64: every entry of every chunk span is the sum
+    over the chunk's frames at that padded sample; ragged last chunks, rows that share a workgroup, one-chunk rows."""
+    import ctypes
+    from inverse_audio_synthesis_amd import _lib
+    from inverse_audio_synthesis_amd.spectral import STFTPlan, VALUE_MAG
+    plan = STFTPlan(n_fft, None, hop).to(dev)
+    x, y = (randn((B, T), 31) * 0.3).to(dev), (randn((B, T), 32) * 0.3).to(dev)
+    tgt = plan.values(y, VALUE_MAG)
+    F = plan.num_frames(T)
+    frames = torch.zeros((B, F, n_fft), dtype=torch.float32, device=dev)
+    spans = torch.full((B * F * n_fft,), float("nan"), dtype=torch.float32, device=dev)
+    args = [_lib.ptr(x), _lib.ptr(plan.tables), None, None, None, None, 0, plan.n_out, _lib.ptr(tgt), None]
+    tail = [B, T, n_fft, hop, 1, 1, 1.0, 0.0]
+    _lib.check(lib.ias_stft_grad_frames(*args, _lib.ptr(frames), *tail, _lib.stream()), "ias_stft_grad_frames")
+    host_plan = (ctypes.c_int * 3)()
+    _lib.check(lib.ias_stft_grad_spans(*args, _lib.ptr(spans), *tail, host_plan, _lib.stream()), "ias_stft_grad_spans")
+    G, cper, L = host_plan[0], host_plan[1], host_plan[2]
+    assert cper == -(-F // G) and L == (G - 1) * hop + n_fft and B * cper * L <= spans.numel()
+    assert cper == 1 or G * hop >= n_fft - hop
+    fr = frames.cpu().double()
+    got = spans[:B * cper * L].cpu().double().reshape(B, cper, L)
+    scale = fr.abs().max().item()
+    for j in range(cper):
+        nf = min(F, (j + 1) * G) - j * G
+        ref = torch.zeros((B, L), dtype=torch.float64)
+        for i in range(nf):
+            ref[:, i * hop:i * hop + n_fft] += fr[:, j * G + i]
+        used = (nf - 1) * hop + n_fft
+        assert torch.isfinite(got[:, j, :used]).all()
+        assert (got[:, j, :used] - ref[:, :used]).abs().max().item() <= 2e-6 * scale * (n_fft // hop + 1)
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 1000), (1, 7), (2, 3, 8193)])
+def test_l1_mean_and_gradient_match_torch(lib, dev, shape):
+    """spectral.l1_mean (the SubbandL1 loss: fused |x - y| partial sums + fixed-order reduction, fused sign * g / n
+    backward) against the torch expression it replaces; exact zeros of x - y get zero gradient (torch.abs' convention)."""
+    from inverse_audio_synthesis_amd.spectral import l1_mean
+    x, y = randn(shape, 41).to(dev), randn(shape, 42).to(dev)
+    x.view(-1)[::5] = y.view(-1)[::5]
+    xa = x.clone().requires_grad_(True)
+    loss = l1_mean(xa, y)
+    (2.5 * loss).backward()
+    xr = x.clone().requires_grad_(True)
+    ref = (xr - y).abs().mean()
+    (2.5 * ref).backward()
+    assert abs(loss.item() - ref.item()) <= 2e-6 * abs(ref.item())
+    assert torch.allclose(xa.grad, xr.grad, rtol=1e-6, atol=0.0)
+    assert (xa.grad.view(-1)[::5] == 0).all()
+
+
+def test_normalisation_rows_match_the_torch_expression(lib, dev):
+    """voice_grad.normalisation_rows (divisor, peak index, correction per row) against the torch expression of the
+    normalize_if_clipping adjoint, on rows that clip and rows that do not."""
+    from inverse_audio_synthesis_amd.voice_grad import normalisation_rows
+    B, T = 5, 50001
+    mix = randn((B, T), 51) * torch.tensor([0.1, 0.5, 2.0, 0.2, 3.0]).unsqueeze(1)
+    peaks = mix.abs().max(dim=1).values
+    audio = mix / torch.where(peaks > 1, peaks, torch.ones_like(peaks)).unsqueeze(1)
+    g = randn((B, T), 52)
+    rows = normalisation_rows(g.to(dev), audio.to(dev), peaks.to(dev)).cpu()
+    clip = peaks > 1
+    tstar = audio.abs().argmax(dim=1)
+    dot = (g.double() * audio.double()).sum(dim=1)
+    corr = -torch.sign(audio[torch.arange(B), tstar]).double() * dot / peaks.double()
+    assert torch.equal(rows[:, 0], torch.where(clip, peaks, torch.ones_like(peaks)))
+    assert torch.equal(rows[:, 1].view(torch.int32), torch.where(clip, tstar.int(), torch.full_like(tstar.int(), -1)))
+    assert torch.allclose(rows[:, 2].double(), torch.where(clip, corr, torch.zeros_like(corr)), rtol=1e-5, atol=1e-6)
