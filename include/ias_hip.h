@@ -232,14 +232,22 @@ int ias_stft_grad_frames(const float* audio, const float* tables, const int* mel
                          int loss_mode, float scale, float eps, void* stream);
 /* The frame part with the overlap-add inside the kernel (round 3; what ias_stft_loss_backward uses when the shape allows:
  * hop even (n_fft 2048: hop % 4 == 0), hop <= n_fft / 2): a wave walks a chunk of plan_host[0] = G consecutive frames of
- * one row and adds the windowed frame gradients in frame order in an LDS ring; chunk_spans (>= B * F * n_fft floats,
- * 16-byte aligned) receives B * plan_host[1] spans of plan_host[2] = (G - 1) hop + n_fft floats: span c, entry i = the
+ * one row and adds the windowed frame gradients in frame order in an LDS ring; chunk_spans (B * plan[1] * plan[2] floats
+ * <= B * F * n_fft, 16-byte aligned) receives B * plan_host[1] spans of plan_host[2] = (G - 1) hop + n_fft floats: span c, entry i = the
  * sum over the frames of chunk c (row c / plan[1], frames [j G, j G + G), j = c % plan[1]) at padded sample j G hop + i.
  * plan_host: int[3] on the HOST, written before return.  IAS_ERR_UNSUPPORTED: shape not served, nothing launched. */
 int ias_stft_grad_spans(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
                         const int* mel_woff, const float* mel_w, int mel_nnz, int n_out, const float* target,
                         const double* coef, float* chunk_spans, int B, int T, int n_fft, int hop, int power,
                         int loss_mode, float scale, float eps, int* plan_host, void* stream);
+/* The plan ias_stft_grad_spans will use for a shape, without launching (size the span buffer with it: B * plan[1] *
+ * plan[2] floats; mel_nnz = 0: linear bins, n_out = n_fft/2+1), and the finish for several resolutions at once:
+ * g_audio [B,T] = g_loss[0] (device fp32, NULL = 1) * sum over the resolutions, in their order, of the overlap-added and
+ * reflect-folded chunk spans.  spans_host: HOST array of nres <= 8 device pointers; plans_host: HOST ints [nres][5] =
+ * {n_fft, hop, plan[0], plan[1], plan[2]}. */
+int ias_stft_grad_span_plan(int B, int T, int n_fft, int hop, int mel_nnz, int n_out, int* plan_host);
+int ias_stft_grad_combine(const float* const* spans_host, const int* plans_host, int nres, const float* g_loss,
+                          float* g_audio, int B, int T, void* stream);
 
 /* MultiResolutionSTFTLoss scalar glue (auraloss defaults; spectral.py), one launch each, fp64 inside:
  * ias_mrstft_total: loss[0] (device fp32) = (sum_k sqrt(s_k[0]) / sqrt(s_k[1]) + s_k[2] / counts_host[k]) / nres with

@@ -286,6 +286,67 @@ __global__ __launch_bounds__(SG_THREADS) void stft_grad_combine_kernel(const flo
   g_audio[(size_t)b * T + j] = g_loss ? acc * g_loss[0] : acc;
 }
 
+// Several resolutions at once (MR-STFT): g_audio = g_loss * sum over the resolutions, in their order, of the above --
+// one pass over the audio gradient instead of one per resolution plus the additions.
+#define IAS_COMBINE_MAX 8
+struct CombineArgs {
+  const float* spans[IAS_COMBINE_MAX];
+  int N[IAS_COMBINE_MAX], hop[IAS_COMBINE_MAX], G[IAS_COMBINE_MAX], cper[IAS_COMBINE_MAX], L[IAS_COMBINE_MAX], F[IAS_COMBINE_MAX];
+  int nres;
+};
+__global__ __launch_bounds__(SG_THREADS) void stft_grad_combine_multi_kernel(const CombineArgs a,
+                                                                             const float* __restrict__ g_loss,
+                                                                             float* __restrict__ g_audio, int T) {
+  const int j = blockIdx.x * SG_THREADS + threadIdx.x, b = blockIdx.y;
+  if (j >= T) return;
+  float total = 0.0f;
+  for (int r = 0; r < a.nres; ++r) {
+    const int N = a.N[r], hop = a.hop[r], G = a.G[r], cper = a.cper[r], L = a.L[r], F = a.F[r];
+    const int pad = N / 2, gh = G * hop;
+    const float* sp = a.spans[r] + (size_t)b * cper * L;
+    int qs[3];
+    int nq = 0;
+    qs[nq++] = j + pad;
+    if (j >= 1 && j <= pad) qs[nq++] = pad - j;
+    if (j <= T - 2 && j >= T - 1 - pad) qs[nq++] = pad + 2 * (T - 1) - j;
+    float acc = 0.0f;
+    for (int i = 0; i < nq; ++i) {
+      const int q = qs[i];
+      int c = q / gh;
+      if (c > cper - 1) c = cper - 1;
+      float v = 0.0f;
+      if (c >= 1 && q - (c - 1) * gh < L) v = sp[(size_t)(c - 1) * L + (q - (c - 1) * gh)];
+      const int nf = min(F, (c + 1) * G) - c * G;
+      if (q - c * gh < (nf - 1) * hop + N) v += sp[(size_t)c * L + (q - c * gh)];
+      acc += v;
+    }
+    total = r == 0 ? acc : total + acc;
+  }
+  g_audio[(size_t)b * T + j] = g_loss ? total * g_loss[0] : total;
+}
+
+// spans_host: HOST array of nres <= 8 device pointers (ias_stft_grad_spans outputs for the same audio [B,T]);
+// plans_host: HOST ints [nres][5] = {n_fft, hop, G, chunks per row, floats per span}.
+extern "C" int ias_stft_grad_combine(const float* const* spans_host, const int* plans_host, int nres, const float* g_loss,
+                                     float* g_audio, int B, int T, void* stream_) {
+  if (!spans_host || !plans_host || !g_audio || nres < 1 || nres > IAS_COMBINE_MAX || B <= 0 || B > 65535 || T <= 0)
+    return IAS_ERR_ARG;
+  CombineArgs a;
+  for (int r = 0; r < IAS_COMBINE_MAX; ++r) { a.spans[r] = nullptr; a.N[r] = a.hop[r] = a.G[r] = a.cper[r] = a.L[r] = a.F[r] = 1; }
+  for (int r = 0; r < nres; ++r) {
+    const int* p = plans_host + 5 * r;
+    if (!spans_host[r] || p[0] <= 0 || p[1] <= 0 || p[2] <= 0 || p[3] <= 0 || p[4] != (p[2] - 1) * p[1] + p[0]) return IAS_ERR_ARG;
+    if (T <= p[0] / 2) return IAS_ERR_ARG;
+    a.spans[r] = spans_host[r]; a.N[r] = p[0]; a.hop[r] = p[1]; a.G[r] = p[2]; a.cper[r] = p[3]; a.L[r] = p[4];
+    a.F[r] = 1 + T / p[1];
+    if (p[3] != (a.F[r] + p[2] - 1) / p[2]) return IAS_ERR_ARG;
+  }
+  a.nres = nres;
+  hipLaunchKernelGGL(stft_grad_combine_multi_kernel, dim3((T + SG_THREADS - 1) / SG_THREADS, B), dim3(SG_THREADS), 0,
+                     (hipStream_t)stream_, a, g_loss, g_audio, T);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 // loss_mode 1: d (scale * sum |V(audio) - target|) / d audio, times the device scalar g_loss[0] (NULL = 1).
 // loss_mode 2: one resolution of the MR-STFT loss (linear bins, power 1, V = sqrt(max(|X|^2, eps))):

@@ -1254,12 +1254,13 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
 static int grad_frames_launch(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
                               const int* mel_woff, const float* mel_w, int mel_nnz, int n_out, const float* target,
                               const double* coef, float* frame_grad, int B, int T, int n_fft, int hop, int power,
-                              int loss_mode, float scale, float eps, int* plan, hipStream_t stream) {
-  if (!audio || !tables || !target || !frame_grad || B <= 0 || B > 65535 || hop <= 0) return IAS_ERR_ARG;
+                              int loss_mode, float scale, float eps, int* plan, hipStream_t stream, bool dry = false) {
+  if (!dry && (!audio || !tables || !target || !frame_grad)) return IAS_ERR_ARG;
+  if (B <= 0 || B > 65535 || hop <= 0) return IAS_ERR_ARG;
   if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return IAS_ERR_UNSUPPORTED;
-  if ((power != 1 && power != 2) || (loss_mode != 1 && loss_mode != 2) || (loss_mode == 2 && !coef)) return IAS_ERR_ARG;
-  const bool mel = mel_start != nullptr;
-  if (mel && (!mel_count || !mel_woff || !mel_w || mel_nnz <= 0 || n_out <= 0 || loss_mode != 1)) return IAS_ERR_ARG;
+  if ((power != 1 && power != 2) || (loss_mode != 1 && loss_mode != 2) || (!dry && loss_mode == 2 && !coef)) return IAS_ERR_ARG;
+  const bool mel = mel_start != nullptr || (dry && mel_nnz > 0);
+  if (!dry && mel && (!mel_count || !mel_woff || !mel_w || mel_nnz <= 0 || n_out <= 0 || loss_mode != 1)) return IAS_ERR_ARG;
   if (!mel && n_out != n_fft / 2 + 1) return IAS_ERR_ARG;
   const int F = ias_stft_num_frames(T, n_fft, hop);
   if (F < 0 || F > 2147483647 / n_fft) return IAS_ERR_ARG;
@@ -1302,6 +1303,7 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
     const size_t lds2 = sizeof(cpx) * (W2 * 64 * 9 + 64 * 64 + (span ? W2 * 1024 : 0));
     if (span) {
       if (!make_plan((long long)ncu * W2)) return IAS_ERR_UNSUPPORTED;
+      if (dry) return IAS_OK;
       const long long need = ((long long)a.nchunks + W2 - 1) / W2;
       const int grid2 = (int)(need < (long long)ncu ? need : (long long)ncu);
       (void)hipFuncSetAttribute((const void*)stft_grad2k_kernel<W2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
@@ -1334,6 +1336,7 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
               hipSuccess || nb < 1)                                                                                \
         nb = 1;                                                                                                    \
       if (!make_plan((long long)ncu * nb * 4)) return IAS_ERR_UNSUPPORTED;                                         \
+      if (dry) return IAS_OK;                                                                                      \
       const long long need = ((long long)a.nchunks + 3) / 4;                                                       \
       grid = dim3((unsigned)(need < (long long)ncu * nb ? need : (long long)ncu * nb));                            \
     }                                                                                                              \
@@ -1360,7 +1363,16 @@ extern "C" int ias_stft_grad_frames(const float* audio, const float* tables, con
                             B, T, n_fft, hop, power, loss_mode, scale, eps, nullptr, (hipStream_t)stream_);
 }
 
-// The same with the overlap-add inside the kernel: chunk_spans (at least B * F * n_fft floats, 16-byte aligned) receives
+// The chunk plan ias_stft_grad_spans will use for this shape (the device's occupancy enters it), without launching:
+// plan_host[3] = {G, chunks per row, floats per chunk span}.  mel_nnz / n_out as for the launch (mel_nnz = 0: linear bins).
+extern "C" int ias_stft_grad_span_plan(int B, int T, int n_fft, int hop, int mel_nnz, int n_out, int* plan_host) {
+  if (!plan_host) return IAS_ERR_ARG;
+  if (mel_nnz > 0 && (n_out <= 0 || n_out > n_fft / 2 + 1)) return IAS_ERR_ARG;
+  return grad_frames_launch(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, mel_nnz, n_out, nullptr, nullptr, nullptr,
+                            B, T, n_fft, hop, 1, 1, 1.0f, 0.0f, plan_host, nullptr, true);
+}
+
+// The same with the overlap-add inside the kernel: chunk_spans (B * plan[1] * plan[2] floats, 16-byte aligned) receives
 // B * plan_host[1] spans of plan_host[2] floats, span c = row c / plan[1], frames [j G, j G + G) with j = c % plan[1],
 // G = plan_host[0]: span[i] = sum over the chunk's frames f covering padded sample j G hop + i of window x frame
 // gradient, in frame order.  stft_grad_combine_kernel (ias_stft_loss_backward) adds the (at most two) chunks per sample.
@@ -1368,7 +1380,7 @@ extern "C" int ias_stft_grad_spans(const float* audio, const float* tables, cons
                                    const int* mel_woff, const float* mel_w, int mel_nnz, int n_out, const float* target,
                                    const double* coef, float* chunk_spans, int B, int T, int n_fft, int hop, int power,
                                    int loss_mode, float scale, float eps, int* plan_host, void* stream_) {
-  if (!plan_host) return IAS_ERR_ARG;
+  if (!plan_host || (reinterpret_cast<uintptr_t>(chunk_spans) & 15) != 0) return IAS_ERR_ARG;
   return grad_frames_launch(audio, tables, mel_start, mel_count, mel_woff, mel_w, mel_nnz, n_out, target, coef, chunk_spans,
                             B, T, n_fft, hop, power, loss_mode, scale, eps, plan_host, (hipStream_t)stream_);
 }

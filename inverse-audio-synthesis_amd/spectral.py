@@ -303,6 +303,7 @@ class MultiResolutionSTFTLoss(nn.Module):
         super().__init__()
         self.eps = eps
         self.parallel = True      # the resolutions on side streams (False: one after the other on the caller's stream)
+        self.fused_combine = True # backward: one combine launch for all resolutions (False: one per resolution + adds)
         self.plans = nn.ModuleList([STFTPlan(n, w, h) for n, h, w in zip(fft_sizes, hop_sizes, win_lengths)])
 
     def target(self, y):
@@ -375,13 +376,40 @@ class _MRSTFTFn(torch.autograd.Function):
         g32 = g_loss.to(torch.float32).reshape(()).contiguous()
         cur = torch.cuda.current_stream(a.device)
         streams = module._streams(a.device) if module.parallel else None
+        eps = float(module.eps)
+        # chunk plans of the fused overlap-add (csrc/spectral_kernels.hip, SPAN kernels); any unsupported shape -> the
+        # per-resolution path (frame tensor / spans + one combine each, summed with torch)
+        plans = []
+        for plan in module.plans:
+            hp = (ctypes.c_int * 3)()
+            if module.fused_combine and lib.ias_stft_grad_span_plan(B, T, plan.n_fft, plan.hop_length, 0, plan.n_out, hp) == 0:
+                plans.append((hp[0], hp[1], hp[2]))
+        if len(plans) == nres and nres <= 8:
+            spans = []
+            for i, plan in enumerate(module.plans):
+                tgt, s = rest[2 * i], rest[2 * i + 1]
+                if streams is not None:
+                    streams[i].wait_stream(cur)
+                with torch.cuda.stream(streams[i] if streams is not None else cur):
+                    spans.append(_mrstft_plan_spans(lib, plan, a, tgt, s, g32, nres, eps, plans[i], cur))
+            if streams is not None:
+                for st in streams[:nres]:
+                    cur.wait_stream(st)
+            g_total = torch.empty_like(a)
+            ptrs = (ctypes.c_void_p * nres)(*[sp.data_ptr() for sp in spans])
+            flat = []
+            for plan, (G, cper, L) in zip(module.plans, plans):
+                flat += [plan.n_fft, plan.hop_length, G, cper, L]
+            _lib.check(lib.ias_stft_grad_combine(ptrs, (ctypes.c_int * len(flat))(*flat), nres, None, _lib.ptr(g_total),
+                                                 B, T, _lib.stream()), "ias_stft_grad_combine")
+            return (g_total.reshape(ctx.shape), None) + (None,) * nres
         grads = []
         for i, plan in enumerate(module.plans):
             tgt, s = rest[2 * i], rest[2 * i + 1]
             if streams is not None:
                 streams[i].wait_stream(cur)
             with torch.cuda.stream(streams[i] if streams is not None else cur):
-                grads.append(_mrstft_plan_backward(lib, plan, a, tgt, s, g32, nres, float(module.eps), cur))
+                grads.append(_mrstft_plan_backward(lib, plan, a, tgt, s, g32, nres, eps, cur))
         g_total = None
         for i, g_audio in enumerate(grads):      # joined in a fixed order
             if streams is not None:
@@ -390,16 +418,38 @@ class _MRSTFTFn(torch.autograd.Function):
         return (g_total.reshape(ctx.shape), None) + (None,) * len(module.plans)
 
 
+def _mrstft_coef(lib, s, g32, count, nres, device):
+    """[g / (nres sqrt(l0) sqrt(l1)) or 0, g / (nres count)]: the cotangent coefficients of one resolution
+    (d (sqrt(l0) / sqrt(l1)) / dV = (V - T) / (sqrt(l0) sqrt(l1));  d (l2 / count) / dV = sign(V - T) / (V count))."""
+    coef = torch.empty(2, dtype=torch.float64, device=device)
+    _lib.check(lib.ias_mrstft_coef(_lib.ptr(s), _lib.ptr(g32), float(count), nres, _lib.ptr(coef), _lib.stream()),
+               "ias_mrstft_coef")
+    return coef
+
+
+def _mrstft_plan_spans(lib, plan, a, tgt, s, g32, nres, eps, chunk_plan, consumer_stream):
+    """One resolution's chunk spans of d loss / d (windowed frames), overlap-added inside the kernel (on the current
+    stream; the result is handed to ``consumer_stream``, where ``ias_stft_grad_combine`` finishes all resolutions)."""
+    B, T = a.shape
+    g32.record_stream(torch.cuda.current_stream(a.device))
+    coef = _mrstft_coef(lib, s, g32, tgt.numel(), nres, a.device)
+    G, cper, L = chunk_plan
+    spans = torch.empty(B * cper * L, dtype=torch.float32, device=a.device)
+    hp = (ctypes.c_int * 3)()
+    st = lib.ias_stft_grad_spans(_lib.ptr(a), _lib.ptr(plan.tables), None, None, None, None, 0, plan.n_out, _lib.ptr(tgt),
+                                 _lib.ptr(coef), _lib.ptr(spans), B, T, plan.n_fft, plan.hop_length, 1, LOSS_MRSTFT, 0.0,
+                                 eps, hp, _lib.stream())
+    _lib.check(st, "ias_stft_grad_spans")
+    assert (hp[0], hp[1], hp[2]) == chunk_plan
+    spans.record_stream(consumer_stream)
+    return spans
+
+
 def _mrstft_plan_backward(lib, plan, a, tgt, s, g32, nres, eps, consumer_stream):
     """One resolution's d loss / d audio (on the current stream; the result is handed to ``consumer_stream``)."""
     B, T = a.shape
-    here = torch.cuda.current_stream(a.device)
-    g32.record_stream(here)
-    # d (sqrt(l0) / sqrt(l1)) / dV = (V - T) / (sqrt(l0) sqrt(l1));  d (l2 / count) / dV = sign(V - T) / (V count):
-    # coef = [g / (nres sqrt(l0) sqrt(l1)) or 0, g / (nres count)], one launch
-    coef = torch.empty(2, dtype=torch.float64, device=a.device)
-    _lib.check(lib.ias_mrstft_coef(_lib.ptr(s), _lib.ptr(g32), float(tgt.numel()), nres, _lib.ptr(coef), _lib.stream()),
-               "ias_mrstft_coef")
+    g32.record_stream(torch.cuda.current_stream(a.device))
+    coef = _mrstft_coef(lib, s, g32, tgt.numel(), nres, a.device)
     frame_grad = torch.empty((B, plan.num_frames(T), plan.n_fft), dtype=torch.float32, device=a.device)
     g_audio = torch.empty_like(a)
     st = lib.ias_stft_loss_backward(_lib.ptr(a), _lib.ptr(plan.window), _lib.ptr(plan.tables), None, None, None,

@@ -64,6 +64,11 @@ def test_mrstft_gradient(lib, dev, T):
     assert rel_l2(g, ref) <= 5e-3, rel_l2(g, ref)
     with torch.no_grad():
         assert abs(m(x.to(dev), y.to(dev)).item() - loss.item()) <= 1e-7 * abs(loss.item())
+    # one combine launch for all resolutions == one per resolution + additions (same chunk spans, same order per sample)
+    m.fused_combine = False
+    xb = x.to(dev).requires_grad_(True)
+    m(xb, y.to(dev)).backward()
+    assert torch.allclose(xb.grad, xa.grad, rtol=0.0, atol=1e-6 * xa.grad.abs().max().item())
 
 
 def test_gradient_is_deterministic_and_forward_unchanged(lib, dev):
