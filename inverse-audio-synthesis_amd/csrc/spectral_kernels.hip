@@ -402,8 +402,8 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES == 10 ? 5 : 1) void stft_ke
           if (oka) l0 += fabsf(va - ta);
           if (okb) l0 += fabsf(vb - tb);
         } else if (LOSS2) {
-          if (oka) { const float d = ta - va; l0 = fmaf(d, d, l0); l1 = fmaf(ta, ta, l1); l2 += fabsf(logf(va) - logf(ta)); }
-          if (okb) { const float d = tb - vb; l0 = fmaf(d, d, l0); l1 = fmaf(tb, tb, l1); l2 += fabsf(logf(vb) - logf(tb)); }
+          if (oka) { const float d = ta - va; l0 = fmaf(d, d, l0); l1 = fmaf(ta, ta, l1); l2 += fabsf(__log2f(va) - __log2f(ta)); }
+          if (okb) { const float d = tb - vb; l0 = fmaf(d, d, l0); l1 = fmaf(tb, tb, l1); l2 += fabsf(__log2f(vb) - __log2f(tb)); }
         }
       }
     }
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES == 10 ? 5 : 1) void stft_ke
 
   if (a.partials != nullptr) {
     __shared__ float s_red[SP_WAVES][4];
-    l0 = wave_sum_f(l0); l1 = wave_sum_f(l1); l2 = wave_sum_f(l2);
+    l0 = wave_sum_f(l0); l1 = wave_sum_f(l1); l2 = wave_sum_f(l2) * 0.6931471805599453f;   // log-magnitude terms were taken in log2
     if (lane == 0) { s_red[wave][0] = l0; s_red[wave][1] = l1; s_red[wave][2] = l2; }
     __syncthreads();
     if (tid < 3) {
@@ -558,6 +558,13 @@ void stft2_kernel(const Spec2Args a) {
     }
 
     const int kl = k1 + 8 * dd;
+    // linear bins: the same for the lane's 2 NPK (+ 1) bins
+    float tg_k[NPK], tg_n[NPK], tg_mid = 0.f;
+    if (!MEL && LOSS != 0) {
+#pragma unroll
+      for (int e = 0; e < NPK; ++e) { tg_k[e] = a.target[row + kl + 64 * e]; tg_n[e] = a.target[row + N2 - kl - 64 * e]; }
+      if (lane == 0) tg_mid = a.target[row + HALF];
+    }
     cpx zlo[NPK], zhi[NPK];                  // Z[kl + 64 e] and Z[HALF + kl + 64 e]
     cpx ue[8];
 #pragma unroll
@@ -624,26 +631,20 @@ void stft2_kernel(const Spec2Args a) {
     float pmid = fmaf(zhi[0].y, zhi[0].y, zhi[0].x * zhi[0].x) * (4.0f * pscale);    // lane 0: |Z[HALF]|^2
     if (a.value_mode == 1) {
 #pragma unroll
-      for (int e = 0; e < NPK; ++e) { pk[e] = sqrtf(pk[e]); pn[e] = sqrtf(pn[e]); }
-      pmid = sqrtf(pmid);
+      for (int e = 0; e < NPK; ++e) { pk[e] = __builtin_amdgcn_sqrtf(pk[e]); pn[e] = __builtin_amdgcn_sqrtf(pn[e]); }   // v_sqrt_f32, 1 ulp
+      pmid = __builtin_amdgcn_sqrtf(pmid);
     } else if (a.value_mode == 3) {
 #pragma unroll
-      for (int e = 0; e < NPK; ++e) { pk[e] = sqrtf(fmaxf(pk[e], a.eps)); pn[e] = sqrtf(fmaxf(pn[e], a.eps)); }
-      pmid = sqrtf(fmaxf(pmid, a.eps));
+      for (int e = 0; e < NPK; ++e) { pk[e] = __builtin_amdgcn_sqrtf(fmaxf(pk[e], a.eps)); pn[e] = __builtin_amdgcn_sqrtf(fmaxf(pn[e], a.eps)); }
+      pmid = __builtin_amdgcn_sqrtf(fmaxf(pmid, a.eps));
     }
     wave_lds_sync();   // every Z read is done: the power values overwrite the scratch
     auto emit_t = [&](int m, float val, float t) {
       if (a.out != nullptr) a.out[row + m] = val;
       if (LOSS == 1) l0 += fabsf(val - t);
-      else if (LOSS == 2) { const float d = t - val; l0 = fmaf(d, d, l0); l1 = fmaf(t, t, l1); l2 += fabsf(logf(val) - logf(t)); }
+      else if (LOSS == 2) { const float d = t - val; l0 = fmaf(d, d, l0); l1 = fmaf(t, t, l1); l2 += fabsf(__log2f(val) - __log2f(t)); }
     };
-    auto emit = [&](int m, float val) {
-      float t = 0.f;
-      if (LOSS != 0) t = a.target[row + m];
-      if (a.out != nullptr) a.out[row + m] = val;
-      if (LOSS == 1) l0 += fabsf(val - t);
-      else if (LOSS == 2) { const float d = t - val; l0 = fmaf(d, d, l0); l1 = fmaf(t, t, l1); l2 += fabsf(logf(val) - logf(t)); }
-    };
+
     if (MEL) {
       // segment-major store: position t of segment j at row (base + t), column j % 64
 #pragma unroll
@@ -682,8 +683,8 @@ void stft2_kernel(const Spec2Args a) {
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < NPK; ++e) { const int k = kl + 64 * e; emit(k, pk[e]); emit(N2 - k, pn[e]); }
-      if (lane == 0) emit(HALF, pmid);
+      for (int e = 0; e < NPK; ++e) { const int k = kl + 64 * e; emit_t(k, pk[e], tg_k[e]); emit_t(N2 - k, pn[e], tg_n[e]); }
+      if (lane == 0) emit_t(HALF, pmid, tg_mid);
     }
     wave_lds_sync();
     if (more) {
@@ -695,7 +696,7 @@ void stft2_kernel(const Spec2Args a) {
 
   if (a.partials != nullptr) {
     __shared__ float s_red[SP_WAVES][4];
-    l0 = wave_sum_f(l0); l1 = wave_sum_f(l1); l2 = wave_sum_f(l2);
+    l0 = wave_sum_f(l0); l1 = wave_sum_f(l1); l2 = wave_sum_f(l2) * 0.6931471805599453f;   // log-magnitude terms were taken in log2
     if (lane == 0) { s_red[wave][0] = l0; s_red[wave][1] = l1; s_red[wave][2] = l2; }
     __syncthreads();
     if (tid < 3) {
@@ -842,16 +843,16 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
     wave_lds_sync();
   };
   // value V of a bin from its power; d loss / d V from value and target (linear bins); d loss / d |X|^2 from d loss / d V
-  auto bin_value = [&](float p) { return a.power2 ? p : sqrtf(a.loss_mode == 2 ? fmaxf(p, a.eps) : p); };
+  auto bin_value = [&](float p) { return a.power2 ? p : __builtin_amdgcn_sqrtf(a.loss_mode == 2 ? fmaxf(p, a.eps) : p); };   // v_sqrt_f32
   auto value_grad = [&](float v, float t) {
     const float d = v - t;
     const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-    return a.loss_mode == 2 ? c0 * d + c1 * sg / v : sg * a.scale;
+    return a.loss_mode == 2 ? c0 * d + c1 * sg * __builtin_amdgcn_rcpf(v) : sg * a.scale;   // v_rcp_f32 (1 ulp)
   };
   auto power_grad = [&](float gv, float v) {
     if (a.power2) return gv;
     const bool live = a.loss_mode == 2 ? v > sqrtf(a.eps) : v > 0.0f;   // a clamped (or zero) bin passes nothing
-    return live ? gv / (2.0f * v) : 0.0f;
+    return live ? 0.5f * gv * __builtin_amdgcn_rcpf(v) : 0.0f;
   };
 
   float xc[2 * R];
@@ -865,6 +866,17 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
   float* span = a.frame_grad + (size_t)c * a.L;
   for (int f = f_lo; f < f_hi; f += SPAN ? 1 : SP_WAVES) {
     load_frame<R, N2>(arow, a.T, a.hop, f, lane, xc);
+    const float* trow = a.target + ((size_t)b * a.F + f) * (MEL ? a.n_out : NB);
+    // linear bins: the lane's target values are requested with the frame and consumed after the forward transform
+    float tk_[NUNP], tq_[NUNP];
+    if (!MEL) {
+#pragma unroll
+      for (int i = 0; i < NUNP; ++i) {
+        const int k = lane + 64 * i;
+        tk_[i] = tq_[i] = 0.0f;
+        if (k <= N2 / 2) { tk_[i] = trow[k]; tq_[i] = trow[N2 - k]; }
+      }
+    }
     cpx v[R];
 #pragma unroll
     for (int n1 = 0; n1 < R; ++n1) v[n1] = cmk(xc[2 * n1], xc[2 * n1 + 1]) * t_win[64 * n1];
@@ -872,7 +884,6 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
     // unpack per bin pair (k, N2 - k), k = lane + 64 i <= N2 / 2: X and V of both bins in registers
     cpx xk_[NUNP], xq_[NUNP];
     float vk_[NUNP], vq_[NUNP], gk_[NUNP], gq_[NUNP];
-    const float* trow = a.target + ((size_t)b * a.F + f) * (MEL ? a.n_out : NB);
 #pragma unroll
     for (int i = 0; i < NUNP; ++i) {
       const int k = lane + 64 * i;
@@ -888,7 +899,7 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
         xq_[i] = cmk(ze.x - t.x, -(ze.y - t.y));          // X[N2 - k]
         vk_[i] = bin_value(xk_[i].x * xk_[i].x + xk_[i].y * xk_[i].y);
         vq_[i] = bin_value(xq_[i].x * xq_[i].x + xq_[i].y * xq_[i].y);
-        if (!MEL) { gk_[i] = value_grad(vk_[i], trow[k]); gq_[i] = value_grad(vq_[i], trow[N2 - k]); }
+        if (!MEL) { gk_[i] = value_grad(vk_[i], tk_[i]); gq_[i] = value_grad(vq_[i], tq_[i]); }
       }
     }
     if (MEL) {
@@ -1061,16 +1072,16 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
   const int k1 = lane >> 3, dd = lane & 7, kl = k1 + 8 * dd;
   float c0 = 0.0f, c1 = 0.0f;
   if (a.loss_mode == 2) { c0 = (float)a.coef[0]; c1 = (float)a.coef[1]; }
-  auto bin_value = [&](float p) { return a.power2 ? p : sqrtf(a.loss_mode == 2 ? fmaxf(p, a.eps) : p); };
+  auto bin_value = [&](float p) { return a.power2 ? p : __builtin_amdgcn_sqrtf(a.loss_mode == 2 ? fmaxf(p, a.eps) : p); };   // v_sqrt_f32
   auto value_grad = [&](float v, float t) {
     const float d = v - t;
     const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-    return a.loss_mode == 2 ? c0 * d + c1 * sg / v : sg * a.scale;
+    return a.loss_mode == 2 ? c0 * d + c1 * sg * __builtin_amdgcn_rcpf(v) : sg * a.scale;   // v_rcp_f32 (1 ulp)
   };
   auto power_grad = [&](float gv, float v) {
     if (a.power2) return gv;
     const bool live = a.loss_mode == 2 ? v > sqrtf(a.eps) : v > 0.0f;
-    return live ? gv / (2.0f * v) : 0.0f;
+    return live ? 0.5f * gv * __builtin_amdgcn_rcpf(v) : 0.0f;
   };
   auto pad = [](int i) { return i + (i >> 3); };
   // the three radix-8 passes of a 512-point transform: v = the lane's points 64 n1 + lane -> u[e] at kl + 64 e
@@ -1113,6 +1124,11 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
     float xc[32];
     stft2_load_frame<2>(a.audio + (size_t)b * a.T, a.T, a.hop, fr, lane, xc);
     const float* trow = a.target + (size_t)fi * NB;
+    // the lane's target values are requested with the frame and consumed after the forward transform
+    float tk_[8], tq_[8], th_ = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { tk_[e] = trow[kl + 64 * e]; tq_[e] = trow[N2 - kl - 64 * e]; }
+    if (lane == 0) th_ = trow[HALF];
     // ---- forward: Z[k], Z[k + 512] for k = kl + 64 e
     cpx zlo[8], zhi[8];
     {
@@ -1144,7 +1160,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
       const cpx xk = cadd(ze, t);                               // X[k]
       const cpx xq = cmk(ze.x - t.x, -(ze.y - t.y));            // X[N2 - k]
       const float vk = bin_value(xk.x * xk.x + xk.y * xk.y), vq = bin_value(xq.x * xq.x + xq.y * xq.y);
-      const float gk = value_grad(vk, trow[k]), gq = value_grad(vq, trow[N2 - k]);
+      const float gk = value_grad(vk, tk_[e]), gq = value_grad(vq, tq_[e]);
       const cpx ck = xk * (2.0f * power_grad(gk, vk));          // G[k]
       const cpx cq = xq * (2.0f * power_grad(gq, vq));          // G[N2 - k]
       if (e == 0 && k == 0) {
@@ -1164,7 +1180,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
     {
       const cpx xh = cmk(zhi[0].x, -zhi[0].y);
       const float vh = bin_value(xh.x * xh.x + xh.y * xh.y);
-      const float gh = value_grad(vh, trow[HALF]);
+      const float gh = value_grad(vh, th_);
       const cpx ch = xh * (2.0f * power_grad(gh, vh));
       zh_in = cmk(ch.x, -ch.y);                                 // (ch + conj ch)/2 + i (i ch + conj(i ch))/2 = conj(ch)
     }
