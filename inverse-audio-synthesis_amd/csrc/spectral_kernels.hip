@@ -322,8 +322,8 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES == 10 ? 5 : 1) void stft_ke
         const cpx xq = cmk(ze.x - t.x, -(ze.y - t.y));  // X[N2-k] = conj(ze - t)
         float vk = xk.x * xk.x + xk.y * xk.y, vn = xq.x * xq.x + xq.y * xq.y;
         if (a.rowpeak != nullptr) { vk *= pscale; vn *= pscale; }
-        if (a.value_mode == 1) { vk = sqrtf(vk); vn = sqrtf(vn); }
-        else if (a.value_mode == 3) { vk = sqrtf(fmaxf(vk, a.eps)); vn = sqrtf(fmaxf(vn, a.eps)); }
+        if (a.value_mode == 1) { vk = __builtin_amdgcn_sqrtf(vk); vn = __builtin_amdgcn_sqrtf(vn); }   // v_sqrt_f32, 1 ulp
+        else if (a.value_mode == 3) { vk = __builtin_amdgcn_sqrtf(fmaxf(vk, a.eps)); vn = __builtin_amdgcn_sqrtf(fmaxf(vn, a.eps)); }
         pk[i] = vk; pn[i] = vn;
       }
     }
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
   };
   auto power_grad = [&](float gv, float v) {
     if (a.power2) return gv;
-    const bool live = a.loss_mode == 2 ? v > sqrtf(a.eps) : v > 0.0f;   // a clamped (or zero) bin passes nothing
+    const bool live = a.loss_mode == 2 ? v > __builtin_amdgcn_sqrtf(a.eps) : v > 0.0f;   // a clamped (or zero) bin passes nothing
     return live ? 0.5f * gv * __builtin_amdgcn_rcpf(v) : 0.0f;
   };
 
@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
   };
   auto power_grad = [&](float gv, float v) {
     if (a.power2) return gv;
-    const bool live = a.loss_mode == 2 ? v > sqrtf(a.eps) : v > 0.0f;
+    const bool live = a.loss_mode == 2 ? v > __builtin_amdgcn_sqrtf(a.eps) : v > 0.0f;
     return live ? 0.5f * gv * __builtin_amdgcn_rcpf(v) : 0.0f;
   };
   auto pad = [](int i) { return i + (i >> 3); };
