@@ -19,10 +19,12 @@
 // The Gram is the one dense contraction of the path: 2*B*D^2 flops nominal per branch
 // (vicreg.py:47-48), of which the symmetric half is executed.
 #include "ias_common.h"
+#include <cstdlib>
 #include <hip/hip_bf16.h>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float vc_f32x4;
 
 #define VC_COLS 64        // columns per colstats workgroup
 #define VC_THREADS 1024  // 16 waves per workgroup: the column pass is latency-bound with few workgroups
@@ -551,6 +553,173 @@ __global__ __launch_bounds__(GP_THREADS, 2) void vicreg_gram_pair_kernel(const u
   }
 }
 
+// ---- Gram for deep contractions (batch > 128: BASELINE configs[3], global batch 1024), 256 x 256 tiles --------------
+// vicreg_gram_kernel above (128 x 128 tiles, operands staged through registers, ds_write_b128) is bound by the LDS store
+// path: 8 ds_write_b128 per thread and 64-deep chunk = 832 LDS cycles per CU against 1024 MFMA cycles, on top of 512
+// cycles of fragment reads (profiles/r03b_kstats_vicreg1024.csv: 0.29 of the bf16 peak).  Here:
+//   * 256 x 256 tile per workgroup, 8 waves as 2 (rows) x 4 (columns), 128 x 64 per wave on v_mfma_f32_16x16x32_bf16
+//     (32 accumulator tiles = 128 VGPRs): 24 fragment reads feed 64 MFMAs per wave and 64-deep K-tile (reads 37 % of the
+//     MFMA time instead of 50 %, and half the staged bytes per flop);
+//   * both operands' K-tiles (256 rows x 128 B each) come in by LDS-DMA (global_load_lds, 16 B per lane: no VGPRs, no
+//     ds_write) into two 64 KB buffers, K-tile kt + 1 requested in pieces between the MFMA groups of K-tile kt;
+//   * LDS image: row r at r * 128 B, its 16-byte granule g at slot g ^ ((r >> 1) & 7) -- lane-linear for the DMA (the
+//     SOURCE address is permuted), conflict-free for the 16 x 32 fragment reads (ds_read_b128 lane groups);
+//   * fragments by inline-asm ds_read_b128, double-buffered in registers: the reads of the next (k-step, row half) are
+//     issued before the 16 MFMAs of the current one and waited for with a counted lgkmcnt; one raw barrier per K-tile.
+// Tile (ti, tj), ti <= tj, of branch b per workgroup; partial = sum of squares of its off-diagonal elements (x 2 above
+// the diagonal).  Rows beyond D repeat row D - 1 on the way in and are masked in the epilogue.
+#define G2_T 256
+#define G2_BK 64
+#define G2_THREADS 512
+#define G2_TILE_BYTES (G2_T * G2_BK * 2)
+#define G2_BUF_BYTES (2 * G2_TILE_BYTES)
+
+#define G2_WAIT(N, X, Y) do { asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3]) : : "memory"); } while (0)
+
+__global__ __launch_bounds__(G2_THREADS, 2) void vicreg_gram256_kernel(const unsigned short* __restrict__ Xt_x,
+                                                                       const unsigned short* __restrict__ Xt_y,
+                                                                       double* __restrict__ part_x,
+                                                                       double* __restrict__ part_y, int D, int Kpad,
+                                                                       int ntile, int ntri) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_g2[];   // 2 buffers x (A 32 KB + B 32 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r = lane & 15, q = lane >> 4;
+  // XCD placement as in vicreg_gram_pair_kernel: an XCD's L2 serves one branch
+  const int xslot = blockIdx.x & 7, branch = xslot >> 2;
+  const int item = (blockIdx.x >> 3) * 4 + (xslot & 3);
+  if (item >= ntri) return;
+  const unsigned short* Xt = branch ? Xt_y : Xt_x;
+  int t = item, ti = 0;
+  {
+    int rowlen = ntile;
+    while (t >= rowlen) { t -= rowlen; --rowlen; ++ti; }
+  }
+  const int tj = ti + t;
+  const int nkt = Kpad / G2_BK;
+
+  // ---- LDS-DMA pieces: a K-tile is 64 pieces of 1 KB (8 rows x 128 B), piece = wave + 8 i; pieces 0..31 operand A
+  unsigned src_off[8];            // element offset of this lane's 16 bytes of piece i at K-tile 0
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int piece = wave + 8 * i, pp = piece & 31;
+    const int row = 8 * pp + (lane >> 3);
+    const int g = (lane & 7) ^ ((row >> 1) & 7);
+    int grow = (i >= 4 ? tj : ti) * G2_T + row;
+    grow = grow < D ? grow : D - 1;
+    src_off[i] = (unsigned)grow * (unsigned)Kpad + (unsigned)(g * 8);
+  }
+  auto request = [&](int kt, int i) {
+    const int piece = wave + 8 * i, pp = piece & 31;
+    unsigned char* dst = s_g2 + (kt & 1) * G2_BUF_BYTES + (i >= 4 ? G2_TILE_BYTES : 0) + pp * 1024;
+    __builtin_amdgcn_global_load_lds((gram_glb_void*)(Xt + (size_t)src_off[i] + (size_t)kt * G2_BK), (gram_lds_void*)dst,
+                                     16, 0, 0);
+  };
+
+  // ---- fragment addresses
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)s_g2;
+  const unsigned sw0 = (unsigned)((q ^ ((r >> 1) & 7)) << 4), sw1 = (unsigned)(((4 + q) ^ ((r >> 1) & 7)) << 4);
+  const unsigned a_lane = (unsigned)((wr * 128 + r) * 128), b_lane = (unsigned)(G2_TILE_BYTES + (wc * 64 + r) * 128);
+
+  vc_f32x4 acc[8][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (vc_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // K-tile 0
+#pragma unroll
+  for (int i = 0; i < 8; ++i) request(0, i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 fa[2][4], fb[2][4];
+  for (int kt = 0; kt < nkt; ++kt) {
+    const unsigned buf = lds0 + (unsigned)((kt & 1) * G2_BUF_BYTES);
+    const bool more = kt + 1 < nkt;
+    auto read_a = [&](bf16x8 (&dst)[4], int ks, int mq) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) gp_lds_read_b128(dst[m], buf + a_lane + (ks ? sw1 : sw0) + (unsigned)(mq * 8192 + m * 2048));
+    };
+    auto read_b = [&](bf16x8 (&dst)[4], int ks) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) gp_lds_read_b128(dst[n], buf + b_lane + (ks ? sw1 : sw0) + (unsigned)(n * 2048));
+    };
+    auto mfma16 = [&](const bf16x8 (&A)[4], const bf16x8 (&Bf)[4], int mq) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc[mq * 4 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[m], Bf[n], acc[mq * 4 + m][n], 0, 0, 0);
+    };
+    read_a(fa[0], 0, 0);
+    read_b(fb[0], 0);
+    // unit 0: (k-step 0, rows 0..63 of the wave)
+    read_a(fa[1], 0, 1);
+    if (more) { request(kt + 1, 0); request(kt + 1, 1); request(kt + 1, 2); }
+    G2_WAIT(4, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma16(fa[0], fb[0], 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // unit 1: (k-step 0, rows 64..127)
+    read_a(fa[0], 1, 0);
+    read_b(fb[1], 1);
+    if (more) { request(kt + 1, 3); request(kt + 1, 4); request(kt + 1, 5); }
+    G2_WAIT(8, fa[1], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma16(fa[1], fb[0], 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // unit 2: (k-step 1, rows 0..63)
+    read_a(fa[1], 1, 1);
+    if (more) { request(kt + 1, 6); request(kt + 1, 7); }
+    G2_WAIT(4, fa[0], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma16(fa[0], fb[1], 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // unit 3: (k-step 1, rows 64..127)
+    G2_WAIT(0, fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma16(fa[1], fb[1], 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // K-tile kt + 1 has landed (this wave's pieces), every wave is done reading K-tile kt
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue: C/D layout of a 16 x 16 tile: col = lane & 15, row = 4 (lane >> 4) + reg
+  float ss = 0.f;
+  const bool diag = ti == tj, ragged = (D % G2_T) != 0 && (tj == ntile - 1);
+  if (diag || ragged) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = wr * 128 + 16 * m + 4 * q + e, col = wc * 64 + 16 * n + r;
+          const bool ok = ti * G2_T + row < D && tj * G2_T + col < D && !(diag && row == col);
+          const float v = acc[m][n][e];
+          if (ok) ss = fmaf(v, v, ss);
+        }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss = fmaf(acc[m][n][e], acc[m][n][e], ss);
+  }
+  for (int d = 32; d > 0; d >>= 1) ss += __shfl_xor(ss, d, 64);
+  double* s_part = reinterpret_cast<double*>(s_g2);       // the staging buffers are idle now (barrier above)
+  if (lane == 0) s_part[wave] = (double)ss;
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < G2_THREADS / 64; ++w) tot += s_part[w];
+    (branch ? part_y : part_x)[item] = diag ? tot : 2.0 * tot;
+  }
+}
+
 // out[0..3] = loss, repr_loss, std_loss, cov_loss (fp32)
 __global__ __launch_bounds__(256) void vicreg_finish_kernel(const double* __restrict__ hingepart,
                                                             const double* __restrict__ msepart, int nmse,
@@ -650,9 +819,15 @@ extern "C" int ias_vicreg_stage(int stage, const float* x, const float* y, float
                        mse, hinge, (unsigned short*)(ws + w.xc_x), (unsigned short*)(ws + w.xc_y), B, D, w.Kpad);
   int ngram = w.ngram;
   int nitems = 0;
+  // deep contractions: 256 x 256 tiles (IAS_VICREG_GRAM128=1: the 128 x 128 register-staged kernel of round 2)
+  static const bool gram128 = getenv("IAS_VICREG_GRAM128") != nullptr && atoi(getenv("IAS_VICREG_GRAM128")) != 0;
+  const int nt256 = (D + G2_T - 1) / G2_T;
+  const bool use256 = w.Kpad > 128 && !gram128 && D >= G2_T && (unsigned long long)D * (unsigned long long)w.Kpad < (1ull << 31);
   if (w.Kpad == 128) {
     nitems = gp_nitems(w.ntile);       // pair kernel: one workgroup per (branch, row-panel pair, run of column panels)
     ngram = nitems;
+  } else if (use256) {
+    ngram = nt256 * (nt256 + 1) / 2;
   }
   if (stage < 0 || stage == 1) {
     if (w.Kpad == 128) {
@@ -660,6 +835,11 @@ extern "C" int ias_vicreg_stage(int stage, const float* x, const float* y, float
       (void)hipFuncSetAttribute((const void*)vicreg_gram_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(vicreg_gram_pair_kernel, dim3(8 * ((nitems + 3) / 4)), dim3(GP_THREADS), lds, stream, xt_x, xt_y,
                          gram_x, gram_y, D, w.ntile, nitems);
+    } else if (use256) {
+      const size_t lds = 2 * (size_t)G2_BUF_BYTES;
+      (void)hipFuncSetAttribute((const void*)vicreg_gram256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(vicreg_gram256_kernel, dim3(8 * ((ngram + 3) / 4)), dim3(G2_THREADS), lds, stream, xt_x, xt_y,
+                         gram_x, gram_y, D, w.Kpad, nt256, ngram);
     } else {
       hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram, 2), dim3(256), 0, stream, xt_x, xt_y, gram_x, gram_y, D, w.Kpad,
                          w.ntile);
