@@ -576,28 +576,16 @@ __global__ __launch_bounds__(GP_THREADS, 2) void vicreg_gram_pair_kernel(const u
 
 #define G2_WAIT(N, X, Y) do { asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3]) : : "memory"); } while (0)
 
-__global__ __launch_bounds__(G2_THREADS, 2) void vicreg_gram256_kernel(const unsigned short* __restrict__ Xt_x,
-                                                                       const unsigned short* __restrict__ Xt_y,
-                                                                       double* __restrict__ part_x,
-                                                                       double* __restrict__ part_y, int D, int Kpad,
-                                                                       int ntile, int ntri) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_g2[];   // 2 buffers x (A 32 KB + B 32 KB)
+// acc[8][4] (16 x 16 tiles: rows wr*128 + 16 m + 4 (lane >> 4) + reg, columns wc*64 + 16 n + (lane & 15)) +=
+// A[row0 .. +255][k] B[col0 .. +255][k]^T over k in [k0, k0 + 64 nkt), A / B bf16 row-major with row strides lda / ldb
+// (elements; every offset < 2^31).  Rows >= arows / brows repeat the last valid row: mask them in the epilogue.
+// s_g2: the workgroup's 128 KB staging area; on return every wave has passed the barrier behind the last K-tile.
+__device__ __forceinline__ void g2_product(const unsigned short* __restrict__ A, unsigned lda, int arows, int row0,
+                                           const unsigned short* __restrict__ Bm, unsigned ldb, int brows, int col0,
+                                           int k0, int nkt, unsigned char* s_g2, vc_f32x4 (&acc)[8][4]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int r = lane & 15, q = lane >> 4;
-  // XCD placement as in vicreg_gram_pair_kernel: an XCD's L2 serves one branch
-  const int xslot = blockIdx.x & 7, branch = xslot >> 2;
-  const int item = (blockIdx.x >> 3) * 4 + (xslot & 3);
-  if (item >= ntri) return;
-  const unsigned short* Xt = branch ? Xt_y : Xt_x;
-  int t = item, ti = 0;
-  {
-    int rowlen = ntile;
-    while (t >= rowlen) { t -= rowlen; --rowlen; ++ti; }
-  }
-  const int tj = ti + t;
-  const int nkt = Kpad / G2_BK;
-
   // ---- LDS-DMA pieces: a K-tile is 64 pieces of 1 KB (8 rows x 128 B), piece = wave + 8 i; pieces 0..31 operand A
   unsigned src_off[8];            // element offset of this lane's 16 bytes of piece i at K-tile 0
 #pragma unroll
@@ -605,27 +593,21 @@ __global__ __launch_bounds__(G2_THREADS, 2) void vicreg_gram256_kernel(const uns
     const int piece = wave + 8 * i, pp = piece & 31;
     const int row = 8 * pp + (lane >> 3);
     const int g = (lane & 7) ^ ((row >> 1) & 7);
-    int grow = (i >= 4 ? tj : ti) * G2_T + row;
-    grow = grow < D ? grow : D - 1;
-    src_off[i] = (unsigned)grow * (unsigned)Kpad + (unsigned)(g * 8);
+    int grow = (i >= 4 ? col0 : row0) + row;
+    const int lim = i >= 4 ? brows : arows;
+    grow = grow < lim ? grow : lim - 1;
+    src_off[i] = (unsigned)grow * (i >= 4 ? ldb : lda) + (unsigned)(k0 + g * 8);
   }
   auto request = [&](int kt, int i) {
     const int piece = wave + 8 * i, pp = piece & 31;
     unsigned char* dst = s_g2 + (kt & 1) * G2_BUF_BYTES + (i >= 4 ? G2_TILE_BYTES : 0) + pp * 1024;
-    __builtin_amdgcn_global_load_lds((gram_glb_void*)(Xt + (size_t)src_off[i] + (size_t)kt * G2_BK), (gram_lds_void*)dst,
-                                     16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gram_glb_void*)((i >= 4 ? Bm : A) + (size_t)src_off[i] + (size_t)kt * G2_BK),
+                                     (gram_lds_void*)dst, 16, 0, 0);
   };
-
   // ---- fragment addresses
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)s_g2;
   const unsigned sw0 = (unsigned)((q ^ ((r >> 1) & 7)) << 4), sw1 = (unsigned)(((4 + q) ^ ((r >> 1) & 7)) << 4);
   const unsigned a_lane = (unsigned)((wr * 128 + r) * 128), b_lane = (unsigned)(G2_TILE_BYTES + (wc * 64 + r) * 128);
-
-  vc_f32x4 acc[8][4];
-#pragma unroll
-  for (int m = 0; m < 8; ++m)
-#pragma unroll
-    for (int n = 0; n < 4; ++n) acc[m][n] = (vc_f32x4){0.f, 0.f, 0.f, 0.f};
 
   // K-tile 0
 #pragma unroll
@@ -645,12 +627,12 @@ __global__ __launch_bounds__(G2_THREADS, 2) void vicreg_gram256_kernel(const uns
 #pragma unroll
       for (int n = 0; n < 4; ++n) gp_lds_read_b128(dst[n], buf + b_lane + (ks ? sw1 : sw0) + (unsigned)(n * 2048));
     };
-    auto mfma16 = [&](const bf16x8 (&A)[4], const bf16x8 (&Bf)[4], int mq) {
+    auto mfma16 = [&](const bf16x8 (&Af)[4], const bf16x8 (&Bf)[4], int mq) {
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n)
-          acc[mq * 4 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[m], Bf[n], acc[mq * 4 + m][n], 0, 0, 0);
+          acc[mq * 4 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[m], Bf[n], acc[mq * 4 + m][n], 0, 0, 0);
     };
     read_a(fa[0], 0, 0);
     read_b(fb[0], 0);
@@ -685,6 +667,38 @@ __global__ __launch_bounds__(G2_THREADS, 2) void vicreg_gram256_kernel(const uns
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
+}
+
+__device__ __forceinline__ void g2_tri_item(int item, int ntile, int& ti, int& tj) {
+  int t = item;
+  ti = 0;
+  int rowlen = ntile;
+  while (t >= rowlen) { t -= rowlen; --rowlen; ++ti; }
+  tj = ti + t;
+}
+
+__global__ __launch_bounds__(G2_THREADS, 2) void vicreg_gram256_kernel(const unsigned short* __restrict__ Xt_x,
+                                                                       const unsigned short* __restrict__ Xt_y,
+                                                                       double* __restrict__ part_x,
+                                                                       double* __restrict__ part_y, int D, int Kpad,
+                                                                       int ntile, int ntri) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_g2[];   // 2 buffers x (A 32 KB + B 32 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r = lane & 15, q = lane >> 4;
+  // XCD placement as in vicreg_gram_pair_kernel: an XCD's L2 serves one branch
+  const int xslot = blockIdx.x & 7, branch = xslot >> 2;
+  const int item = (blockIdx.x >> 3) * 4 + (xslot & 3);
+  if (item >= ntri) return;
+  const unsigned short* Xt = branch ? Xt_y : Xt_x;
+  int ti, tj;
+  g2_tri_item(item, ntile, ti, tj);
+  vc_f32x4 acc[8][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (vc_f32x4){0.f, 0.f, 0.f, 0.f};
+  g2_product(Xt, (unsigned)Kpad, D, ti * G2_T, Xt, (unsigned)Kpad, D, tj * G2_T, 0, Kpad / G2_BK, s_g2, acc);
 
   // ---- epilogue: C/D layout of a 16 x 16 tile: col = lane & 15, row = 4 (lane >> 4) + reg
   float ss = 0.f;
@@ -753,7 +767,12 @@ __global__ __launch_bounds__(256) void vicreg_finish_kernel(const double* __rest
 
 // ------------------------------------------------------------------------ C ABI
 static inline size_t vc_align(size_t x) { return (x + 255) / 256 * 256; }
-struct VicregWs { size_t xt_x, xt_y, colstats, mse, hinge, gram_x, gram_y, xc_x, xc_y, bgram, bgram16, gdiag, total; int Kpad, ntile, ngram, nmse, nsplit, ksplit; };
+struct VicregWs { size_t xt_x, xt_y, colstats, mse, hinge, gram_x, gram_y, xc_x, xc_y, bgram, bgram16, gdiag, total; int Kpad, ntile, ngram, nmse, nsplit, ksplit; bool t256; };
+// IAS_VICREG_GRAM128=1 (diagnostics): the 128 x 128 register-staged kernels of round 2 for batch > 128 as well
+static bool vicreg_force128() {
+  static const bool v = getenv("IAS_VICREG_GRAM128") != nullptr && atoi(getenv("IAS_VICREG_GRAM128")) != 0;
+  return v;
+}
 static VicregWs vicreg_ws(int B, int D) {
   VicregWs w;
   w.Kpad = (B + GT - 1) / GT * GT;   // multiple of 128: the pair kernel's depth, the backward's batch tiles (zero padded)
@@ -773,9 +792,12 @@ static VicregWs vicreg_ws(int B, int D) {
   w.xc_y = o;     o = vc_align(o + sizeof(unsigned short) * (size_t)D * w.Kpad);
   // the B x B Gram is contracted over D in `nsplit` slices (enough workgroups for the chip at any batch size), each
   // slice writing its own partial Gram [nsplit][2][Kpad][Kpad]; vicreg_gconv_kernel adds them in slice order
+  // batch > 128: the 256 x 256 LDS-DMA kernels (forward Gram; backward when D is a multiple of the 64-deep K-tile)
+  w.t256 = w.Kpad > 128 && !vicreg_force128() && D >= 256 && (unsigned long long)D * (unsigned long long)w.Kpad < (1ull << 31);
   {
-    const int bt = w.Kpad / GT, npair = bt * (bt + 1) / 2;
-    int nsplit = 512 / (2 * npair);
+    const bool b256 = w.t256 && D % 64 == 0;
+    const int bt = b256 ? (w.Kpad + 255) / 256 : w.Kpad / GT, npair = bt * (bt + 1) / 2;
+    int nsplit = (b256 ? 256 : 512) / (2 * npair);      // one resident round: 1 (256 tiles) / 2 (128 tiles) workgroups per CU
     if (nsplit < 1) nsplit = 1;
     if (nsplit > D / 256) nsplit = D / 256 > 0 ? D / 256 : 1;
     w.ksplit = ((D + nsplit - 1) / nsplit + GK - 1) / GK * GK;
@@ -819,10 +841,9 @@ extern "C" int ias_vicreg_stage(int stage, const float* x, const float* y, float
                        mse, hinge, (unsigned short*)(ws + w.xc_x), (unsigned short*)(ws + w.xc_y), B, D, w.Kpad);
   int ngram = w.ngram;
   int nitems = 0;
-  // deep contractions: 256 x 256 tiles (IAS_VICREG_GRAM128=1: the 128 x 128 register-staged kernel of round 2)
-  static const bool gram128 = getenv("IAS_VICREG_GRAM128") != nullptr && atoi(getenv("IAS_VICREG_GRAM128")) != 0;
+  // deep contractions: 256 x 256 tiles
   const int nt256 = (D + G2_T - 1) / G2_T;
-  const bool use256 = w.Kpad > 128 && !gram128 && D >= G2_T && (unsigned long long)D * (unsigned long long)w.Kpad < (1ull << 31);
+  const bool use256 = w.t256;
   if (w.Kpad == 128) {
     nitems = gp_nitems(w.ntile);       // pair kernel: one workgroup per (branch, row-panel pair, run of column panels)
     ngram = nitems;
@@ -1048,6 +1069,172 @@ __global__ __launch_bounds__(256, 2) void vicreg_grad_kernel(
   }
 }
 
+// ---- the same two products for batch > 128 on the 256 x 256 LDS-DMA tile product (g2_product) -------------------------
+// One upper-triangular 256 x 256 tile of one D-slice of G per workgroup (grid: tiles x slices x branches), written once
+// to the slice's own Gram (fixed-order sum over the slices in vicreg_gconv256_kernel: deterministic).
+__global__ __launch_bounds__(G2_THREADS, 2) void vicreg_bgram256_kernel(const unsigned short* __restrict__ Xc_x,
+                                                                        const unsigned short* __restrict__ Xc_y,
+                                                                        float* __restrict__ Gp, int D, int Kpad, int nt,
+                                                                        int ksplit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_g2[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3, r = lane & 15, q = lane >> 4;
+  int ti, tj;
+  g2_tri_item(blockIdx.x, nt, ti, tj);
+  const int branch = blockIdx.z;
+  const unsigned short* Xc = branch ? Xc_y : Xc_x;
+  float* Gb = Gp + ((size_t)blockIdx.y * 2 + branch) * Kpad * Kpad;
+  const int kbeg = blockIdx.y * ksplit, kend = min(kbeg + ksplit, D);     // D % 64 == 0, ksplit % 64 == 0 (host)
+  vc_f32x4 acc[8][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (vc_f32x4){0.f, 0.f, 0.f, 0.f};
+  g2_product(Xc, (unsigned)D, Kpad, ti * G2_T, Xc, (unsigned)D, Kpad, tj * G2_T, kbeg, (kend - kbeg) / G2_BK, s_g2, acc);
+  // rows of the tile through LDS (see vicreg_grad256_kernel): 16-byte stores, 1 KB per wave and row.  Only the upper
+  // triangle of tiles is written; vicreg_gconv256_kernel mirrors it when it folds the slices.
+  float* s_c = reinterpret_cast<float*>(s_g2);
+  const int tid = threadIdx.x, c4 = tid & 63, j0 = tj * G2_T + 4 * c4;
+  for (int half = 0; half < 2; ++half) {
+    if (wr == half) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            s_c[(16 * m + 4 * q + e) * 256 + ((wc * 64 + 16 * n + r) ^ (q << 4))] = acc[m][n][e];
+    }
+    __syncthreads();
+    for (int i = 0; i < 16; ++i) {
+      const int rl = 8 * i + (tid >> 6);
+      const int row = ti * G2_T + 128 * half + rl;
+      if (row < Kpad && j0 < Kpad)                               // Kpad % 4 == 0: the four columns are in or out together
+        *reinterpret_cast<vc_f32x4*>(Gb + (size_t)row * Kpad + j0) =
+            *reinterpret_cast<const vc_f32x4*>(s_c + rl * 256 + ((4 * c4) ^ (((rl >> 2) & 3) << 4)));
+    }
+    __syncthreads();
+  }
+}
+
+// G = sum over the D-slices of their partial Grams, in slice order, for the upper-triangular 256 x 256 tiles
+// vicreg_bgram256_kernel wrote; one 64 x 64 block per workgroup: bf16 with the diagonal taken out (gdiag, see
+// vicreg_gconv_kernel), written in place and -- off the diagonal tiles -- mirrored through an LDS transpose.
+__global__ __launch_bounds__(256) void vicreg_gconv256_kernel(const float* __restrict__ Gp, unsigned short* __restrict__ Gb,
+                                                              float* __restrict__ gdiag, int Kpad, int nsplit, int nt) {
+  __shared__ float s_t[64][65];
+  int ti, tj;
+  g2_tri_item(blockIdx.x >> 4, nt, ti, tj);
+  const int sub = blockIdx.x & 15, branch = blockIdx.y;
+  const int r0 = ti * G2_T + (sub >> 2) * 64, c0 = tj * G2_T + (sub & 3) * 64;
+  if (r0 >= Kpad || c0 >= Kpad) return;                          // Kpad % 64 == 0: a block is inside or outside
+  const size_t plane = (size_t)Kpad * Kpad, n2 = 2 * plane;
+  const int tid = threadIdx.x, cc = tid & 63;
+  for (int rr = tid >> 6; rr < 64; rr += 4) {
+    const int row = r0 + rr, col = c0 + cc;
+    const size_t i = (size_t)branch * plane + (size_t)row * Kpad + col;
+    float v = 0.0f;
+    for (int s0 = 0; s0 < nsplit; s0 += 8) {                     // eight slices in flight, added in slice order
+      float a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = s0 + u < nsplit ? Gp[(size_t)(s0 + u) * n2 + i] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += a[u];
+    }
+    if (row == col) { gdiag[(size_t)branch * Kpad + row] = v; v = 0.0f; }
+    Gb[i] = f2bf(v);
+    s_t[rr][cc] = v;
+  }
+  if (ti == tj) return;
+  __syncthreads();
+  for (int rr = tid >> 6; rr < 64; rr += 4)                      // row c0 + rr of the mirror image, columns r0 + cc
+    Gb[(size_t)branch * plane + (size_t)(c0 + rr) * Kpad + r0 + cc] = f2bf(s_t[cc][rr]);
+}
+
+// One 256 (batch rows) x 256 (features) tile of gx (branch 0) or gy (branch 1) per workgroup: (G - diag) vc on the
+// matrix cores, then the elementwise terms (the epilogue of vicreg_grad_kernel, one branch).
+__global__ __launch_bounds__(G2_THREADS, 2) void vicreg_grad256_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const unsigned short* __restrict__ Xt_x,
+    const unsigned short* __restrict__ Xt_y, const unsigned short* __restrict__ Gb, const float* __restrict__ gdiag,
+    const float* __restrict__ colstats, const float* __restrict__ gcoef, float* __restrict__ gx, float* __restrict__ gy,
+    int B, int D, int Kpad, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_g2[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3, r = lane & 15, q = lane >> 4;
+  const int col0 = blockIdx.x * G2_T, row0 = blockIdx.y * G2_T, branch = blockIdx.z;
+  const float gl = gcoef[0];
+  const float ca = gl * sim_coeff + gcoef[1], cb = gl * std_coeff + gcoef[2], cc = gl * cov_coeff + gcoef[3];
+  const float kappa = 4.0f / ((float)(cfg_batch - 1) * (float)(cfg_batch - 1) * (float)D);
+  vc_f32x4 acc[8][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (vc_f32x4){0.f, 0.f, 0.f, 0.f};
+  g2_product(Gb + (size_t)branch * Kpad * Kpad, (unsigned)Kpad, Kpad, row0, branch ? Xt_y : Xt_x, (unsigned)Kpad, D, col0, 0,
+             Kpad / G2_BK, s_g2, acc);
+  // ---- epilogue through LDS (the staging area is idle: every wave has passed the product's last barrier): the tile goes
+  // to LDS half by half (128 rows x 256 fp32 = 128 KB; 16-column groups XOR-swizzled by the lane's row quarter, so the
+  // accumulator stores are conflict-free), then every thread owns 4 fixed columns and walks the rows with 16-byte
+  // accesses to x, y and the gradient (1 KB per wave and row) instead of 64-byte fragments of four rows each.
+  const float inv_bm1 = 1.0f / (float)(B - 1);
+  const float repr_k = (branch ? -ca : ca) * 2.0f / ((float)B * (float)D);
+  float* gout = branch ? gy : gx;
+  const float* own = branch ? y : x;
+  float* s_c = reinterpret_cast<float*>(s_g2);
+  const int tid = threadIdx.x, c4 = tid & 63, j0 = col0 + 4 * c4;
+  float mu[4], av[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int j = j0 + c;
+    mu[c] = 0.f; av[c] = 0.f;
+    if (j < D) {
+      mu[c] = colstats[(size_t)branch * D + j];
+      const float m2 = colstats[(size_t)(2 + branch) * D + j];
+      const float sd = sqrtf(m2 * inv_bm1 + 0.0001f);
+      // coefficient of vc: variance hinge (active where s < 1) and the diagonal part of the covariance term
+      av[c] = (sd < 1.0f ? -cb / (2.0f * (float)D * (float)(B - 1) * sd) : 0.0f) - cc * kappa * m2;
+    }
+  }
+  const bool vec = (D & 3) == 0 && j0 + 3 < D;
+  for (int half = 0; half < 2; ++half) {
+    if (wr == half) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            s_c[(16 * m + 4 * q + e) * 256 + ((wc * 64 + 16 * n + r) ^ (q << 4))] = acc[m][n][e];
+    }
+    __syncthreads();
+    for (int i = 0; i < 16; ++i) {
+      const int rl = 8 * i + (tid >> 6);                       // row inside the half
+      const int b = row0 + 128 * half + rl;
+      if (b >= B) continue;
+      const vc_f32x4 cv = *reinterpret_cast<const vc_f32x4*>(s_c + rl * 256 + ((4 * c4) ^ (((rl >> 2) & 3) << 4)));
+      const float gd = gdiag[(size_t)branch * Kpad + b];
+      const size_t idx = (size_t)b * D + j0;
+      if (vec) {
+        const vc_f32x4 xv = *reinterpret_cast<const vc_f32x4*>(x + idx), yv = *reinterpret_cast<const vc_f32x4*>(y + idx);
+        vc_f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float v = (branch ? yv[c] : xv[c]) - mu[c];
+          o[c] = repr_k * (xv[c] - yv[c]) + av[c] * v + cc * kappa * (cv[c] + gd * v);
+        }
+        *reinterpret_cast<vc_f32x4*>(gout + idx) = o;
+      } else {
+        for (int c = 0; c < 4; ++c) {
+          if (j0 + c >= D) break;
+          const float v = own[idx + c] - mu[c];
+          gout[idx + c] = repr_k * (x[idx + c] - y[idx + c]) + av[c] * v + cc * kappa * (cv[c] + gd * v);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Backward of ias_vicreg_loss on the SAME workspace (it must still hold the forward's column statistics and centred
 // bf16 copies): gcoef [4] device floats = the cotangents of (loss, repr_loss, std_loss, cov_loss) -> gx, gy [B,D] fp32.
 extern "C" int ias_vicreg_backward(const float* x, const float* y, const float* gcoef, float* gx, float* gy, void* workspace,
@@ -1062,16 +1249,36 @@ extern "C" int ias_vicreg_backward(const float* x, const float* y, const float* 
   const int bt = w.Kpad / GT;
   if (w.Kpad % GT) return IAS_ERR_UNSUPPORTED;
   const int npair = bt * (bt + 1) / 2;
-  hipLaunchKernelGGL(vicreg_bgram_kernel, dim3(npair, w.nsplit, 2), dim3(256), 0, stream, (const unsigned short*)(ws + w.xc_x),
-                     (const unsigned short*)(ws + w.xc_y), G, D, w.Kpad, bt, w.ksplit);
+  const bool b256 = w.t256 && D % 64 == 0;
+  const size_t lds256 = 2 * (size_t)G2_BUF_BYTES;
+  const int bt2 = (w.Kpad + G2_T - 1) / G2_T;
+  if (b256) {
+    (void)hipFuncSetAttribute((const void*)vicreg_bgram256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+    hipLaunchKernelGGL(vicreg_bgram256_kernel, dim3(bt2 * (bt2 + 1) / 2, w.nsplit, 2), dim3(G2_THREADS), lds256, stream,
+                       (const unsigned short*)(ws + w.xc_x), (const unsigned short*)(ws + w.xc_y), G, D, w.Kpad, bt2, w.ksplit);
+  } else {
+    hipLaunchKernelGGL(vicreg_bgram_kernel, dim3(npair, w.nsplit, 2), dim3(256), 0, stream, (const unsigned short*)(ws + w.xc_x),
+                       (const unsigned short*)(ws + w.xc_y), G, D, w.Kpad, bt, w.ksplit);
+  }
   unsigned short* Gb = (unsigned short*)(ws + w.bgram16);
   float* gdiag = (float*)(ws + w.gdiag);
   int cgrid = (int)((2 * (size_t)w.Kpad * w.Kpad + 255) / 256);
   if (cgrid > 2048) cgrid = 2048;
-  hipLaunchKernelGGL(vicreg_gconv_kernel, dim3(cgrid), dim3(256), 0, stream, G, Gb, gdiag, w.Kpad, w.nsplit);
-  hipLaunchKernelGGL(vicreg_grad_kernel, dim3((D + GT - 1) / GT, bt), dim3(256), 0, stream, x, y,
-                     (const unsigned short*)(ws + w.xt_x), (const unsigned short*)(ws + w.xt_y), Gb, gdiag,
-                     (const float*)(ws + w.colstats), gcoef, gx, gy, B, D, w.Kpad, cfg_batch, sim_coeff, std_coeff, cov_coeff);
+  if (b256)
+    hipLaunchKernelGGL(vicreg_gconv256_kernel, dim3(16 * (bt2 * (bt2 + 1) / 2), 2), dim3(256), 0, stream, G, Gb, gdiag, w.Kpad,
+                       w.nsplit, bt2);
+  else
+    hipLaunchKernelGGL(vicreg_gconv_kernel, dim3(cgrid), dim3(256), 0, stream, G, Gb, gdiag, w.Kpad, w.nsplit);
+  if (b256) {
+    (void)hipFuncSetAttribute((const void*)vicreg_grad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+    hipLaunchKernelGGL(vicreg_grad256_kernel, dim3((D + G2_T - 1) / G2_T, bt2, 2), dim3(G2_THREADS), lds256, stream, x, y,
+                       (const unsigned short*)(ws + w.xt_x), (const unsigned short*)(ws + w.xt_y), Gb, gdiag,
+                       (const float*)(ws + w.colstats), gcoef, gx, gy, B, D, w.Kpad, cfg_batch, sim_coeff, std_coeff, cov_coeff);
+  } else {
+    hipLaunchKernelGGL(vicreg_grad_kernel, dim3((D + GT - 1) / GT, bt), dim3(256), 0, stream, x, y,
+                       (const unsigned short*)(ws + w.xt_x), (const unsigned short*)(ws + w.xt_y), Gb, gdiag,
+                       (const float*)(ws + w.colstats), gcoef, gx, gy, B, D, w.Kpad, cfg_batch, sim_coeff, std_coeff, cov_coeff);
+  }
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
