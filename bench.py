@@ -758,7 +758,7 @@ def main():
     bps = {"render": RENDER_BYTES_PER_SAMPLE, "pqmf": 8.0, "stft": 4.0 + 4.0 * plan.n_out / plan.hop_length}
     knames = {"render": "voice_audio_kernel",
               "pqmf": "pqmf_analysis_pipe_kernel" if os.environ.get("IAS_PQMF_NOMOD") else "pqmf_analysis_mod_kernel",
-              "stft": "stft2_kernel<8, true, 1>" if plan.n_fft == 1024 and os.environ.get("IAS_STFT_V1") != "1" else "stft_kernel"}
+              "stft": "stft2_kernel<8, true, 1, 1>" if plan.n_fft == 1024 and os.environ.get("IAS_STFT_V1") != "1" else "stft_kernel"}
     table = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):

@@ -5,7 +5,7 @@
 #   kstats_{default,nopipeline,vicreg128,vicreg1024,gradstep}.csv     rocprofv3 --kernel-trace --stats of the same commands
 #   traffic.json                                                      FETCH_SIZE / WRITE_SIZE PMC passes (separate runs) over
 #                                                                     scripts/diag/time_stages.py, per kernel and launch
-#   pmc_voice.txt / pmc_pqmf.txt / pmc_vicreg.txt / kstats_pretrain.txt   SQ counter summaries of the named kernels
+#   pmc_voice.txt / pmc_pqmf.txt / pmc_vicreg.txt / pmc_vicreg1024.txt / kstats_pretrain.txt   SQ counter summaries of the named kernels
 # Copy what is to be judged into profiles/ afterwards (scripts/collect_profiles.py <tag> <prefix>).
 tag=${1:-rXX}
 R=$GRAFT_REPO_ROOT
@@ -59,6 +59,7 @@ PY
 step pmc voice; bash $R/scripts/diag/pmc_voice.sh $tag > /dev/null 2>&1; cp $R/gpurun_out/pmcv_$tag/summary.txt $O/pmc_voice.txt
 step pmc pqmf; bash $R/scripts/diag/pmc_pqmf.sh $tag N=3 > /dev/null 2>&1; cp $R/gpurun_out/pmcq_$tag/summary.txt $O/pmc_pqmf.txt
 step pmc vicreg; bash $R/scripts/diag/pmc_vicreg.sh $tag 128 > /dev/null 2>&1; cp $R/gpurun_out/pmcg_$tag/summary.txt $O/pmc_vicreg.txt
+step pmc vicreg1024; bash $R/scripts/diag/pmc_vicreg.sh ${tag}_1024 1024 > /dev/null 2>&1; cp $R/gpurun_out/pmcg_${tag}_1024/summary.txt $O/pmc_vicreg1024.txt
 step kstats pretrain; bash $R/scripts/diag/kstats_pretrain.sh $tag > $O/kstats_pretrain.txt 2>&1
 step pmc stft; bash $R/scripts/diag/pmc_stft.sh $tag PARTS=loss > /dev/null 2>&1; cp $R/gpurun_out/pmcs_$tag/summary.txt $O/pmc_stft.txt
 step trace; bash $R/scripts/diag/trace_bench.sh $tag > $O/trace_default.txt 2>&1
