@@ -320,7 +320,58 @@ def secondary_legs(args, dev):
         legs[name] = leg
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    try:
+        leg = pretrain_leg(dev)
+    except Exception as e:  # noqa: BLE001
+        leg = {"error": f"{type(e).__name__}: {e}"}
+    leg["wall_s"] = round(time.perf_counter() - t0, 2)
+    legs["pretrain"] = leg
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     return legs
+
+
+def pretrain_leg(dev, B=128, steps=5, reps=5):
+    """One VICReg pretraining step of BASELINE configs[2] per GPU (B=128 x 4 s @ 44.1 kHz, dim 1024, embeddim 8192): render
+    + PQMF + MobileNetV3 trunk + projector + VICReg loss + backward + LARS, as the Trainer's captured hipGraph
+    (trainer.cuda_graph=true): the SURVEY 8(f) rows in one number.  Parameters are sampled on the host per step and copied
+    in, everything else replays.  -> {"ms_per_step": median over `reps` regions of `steps` replays, ...}"""
+    from inverse_audio_synthesis_amd.config import load_config
+    from inverse_audio_synthesis_amd.harness import VicregAudioParams
+    from inverse_audio_synthesis_amd.trainer import Trainer
+    import warnings
+    torch.manual_seed(42)
+    cfg = load_config(os.path.join(ROOT, "conf"), "config", [f"vicreg.batch_size={B}", "trainer.cuda_graph=true"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = VicregAudioParams(cfg)
+    tr = Trainer(cfg, model, stage="vicreg", device=dev)
+    model.train()
+    for i in range(5):                       # 3 eager warm-up steps, capture, first replays
+        tr._graph_step(i, i)
+    torch.cuda.synchronize()
+    times = []
+    k = 10
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            tr._graph_step(k, k)
+            k += 1
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) / steps)
+    times.sort()
+    loss = float(model.logged["vicreg/train/loss"])
+    ms = times[len(times) // 2]
+    del tr, model
+    return {"ms_per_step": round(ms, 3), "ms_per_step_min": round(times[0], 3), "steps": steps, "timed_regions": reps,
+            "value": round(B * SECONDS / (ms * 1e-3), 1), "unit": "audio-s/s trained",
+            "workload": f"VICReg pretraining step, batch {B} x {SECONDS:g} s @ {SAMPLE_RATE} Hz per GPU (configs[2] shape): render + "
+                        "PQMF(3) + MobileNetV3-small trunk + projector 8192 + VICReg loss, backward, LARS; fp32 (bf16 only "
+                        "inside the VICReg Gram), random init, synthetic parameters",
+            "launch": "hipgraph (Trainer._graph_step)", "loss": loss}
 
 
 def run_gradstep(args, rank, world, dev):
