@@ -996,7 +996,10 @@ extern "C" int ias_pqmf_build_modtab(const float* H_host, int N, int K, float* o
 }
 
 template <bool NORM>
-__global__ __launch_bounds__(PQ_THREADS, 4) void pqmf_analysis_mod_kernel(
+#ifndef IAS_PQMF_MOD_MINW
+#define IAS_PQMF_MOD_MINW 4   // waves per SIMD the kernel is compiled for (register budget 512 / MINW)
+#endif
+__global__ __launch_bounds__(PQ_THREADS, IAS_PQMF_MOD_MINW) void pqmf_analysis_mod_kernel(
     const float* __restrict__ x, const float* __restrict__ modtab, float* __restrict__ z, const float* __restrict__ mean,
     const float* __restrict__ stdv, const float* __restrict__ rowpeak, int T, int L, int tiles_x, int ntiles, int zvec) {
   __shared__ __attribute__((aligned(16))) float s_stage[PQ_THREADS / 64][PQD_STAGE];

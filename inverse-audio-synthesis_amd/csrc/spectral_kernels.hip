@@ -142,15 +142,27 @@ __device__ __forceinline__ void load_frame(const float* __restrict__ arow, int T
                                            float (&x)[2 * R]) {
   const int g0 = f * hop - N2;
   if (g0 >= 0 && g0 + 2 * N2 <= T && (((g0 | T) & 1) == 0)) {
-    const float2* p = reinterpret_cast<const float2*>(arow + g0) + lane;
+    // interior frame: R 8-byte loads off ONE address register pair (immediate offsets 512 n1).  The pointer is made
+    // opaque and the edge path's values pass through empty asm statements: left alone, the compiler sinks the loads of
+    // both paths into one block of 2 R single-dword loads from 2 R separate 64-bit addresses (32 address VGPRs, twice
+    // the memory instructions) -- for every frame, to share code with the two edge frames per row.
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) f32x2_t* glb_f2p;    // stays a GLOBAL pointer through the asm
+    glb_f2p p = (glb_f2p)(reinterpret_cast<const f32x2_t*>(arow + g0) + lane);
+#ifndef IAS_LOADFRAME_PLAIN
+    asm volatile("" : "+v"(p));
+#endif
 #pragma unroll
-    for (int n1 = 0; n1 < R; ++n1) { const float2 q = p[64 * n1]; x[2 * n1] = q.x; x[2 * n1 + 1] = q.y; }
+    for (int n1 = 0; n1 < R; ++n1) { const f32x2_t q = p[64 * n1]; x[2 * n1] = q[0]; x[2 * n1 + 1] = q[1]; }
   } else {
 #pragma unroll
     for (int n1 = 0; n1 < R; ++n1) {
       const int m = g0 + 2 * (64 * n1 + lane);
       x[2 * n1] = arow[reflect_index(m, T)];
       x[2 * n1 + 1] = arow[reflect_index(m + 1, T)];
+#ifndef IAS_LOADFRAME_PLAIN
+      asm volatile("" : "+v"(x[2 * n1]), "+v"(x[2 * n1 + 1]));
+#endif
     }
   }
 }
@@ -446,7 +458,26 @@ struct Spec2Args {
   unsigned magicF;         // floor(2^32 / F)
   int value_mode, loss_mode;
   float eps;
+#ifdef IAS_S2_STAMPS
+  unsigned long long* stamps;   // diagnostics build only: [workgroup][wave][256] s_memtime values
+#endif
 };
+// In-kernel stamps (diagnostic build -DIAS_S2_STAMPS only; the product build compiles none of this): where a wave's
+// cycles go, phase by phase.  scripts/diag/stft2_stamps.py builds and reads them.
+#ifdef IAS_S2_STAMPS
+static unsigned long long* g_s2_stamps = nullptr;
+extern "C" int ias_stft2_set_stamps(unsigned long long* p) { g_s2_stamps = p; return 0; }
+#define S2_STAMP(id)                                                                                     \
+  do {                                                                                                   \
+    if (a.stamps != nullptr && stamp_n < 255) {                                                          \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                        \
+      if (lane == 0) a.stamps[((size_t)blockIdx.x * SP_WAVES + wave) * 256 + 1 + stamp_n] = (t_ << 8) | (id); \
+      ++stamp_n;                                                                                         \
+    }                                                                                                    \
+  } while (0)
+#else
+#define S2_STAMP(id) do {} while (0)
+#endif
 // lane l <- x of lane l-1 (lane 0 <- fill) / lane l+1 (lane 63 <- fill): one DPP move across the whole wave
 __device__ __forceinline__ float wave_shr1(float x, float fill) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x138, 0xf, 0xf, false));
@@ -470,6 +501,7 @@ template <int NSUB> __device__ __forceinline__ void stft2_load_frame(const float
     // lane, n1: samples 256 n1 + 4 lane .. + 3 = (even point, odd point) of the two half-transforms; x[16 sub + 2 n1 + c]
     const int g0 = f * hop - 1024;
     if (g0 >= 0 && g0 + 2048 <= T && ((reinterpret_cast<uintptr_t>(arow + g0) & 15) == 0)) {
+      // (no opaque pointer here, unlike load_frame: measured slower for the 2048-point kernels, 145 vs 123 us forward)
       const f32x4* p = reinterpret_cast<const f32x4*>(arow + g0) + lane;
 #pragma unroll
       for (int n1 = 0; n1 < 8; ++n1) {
@@ -480,24 +512,34 @@ template <int NSUB> __device__ __forceinline__ void stft2_load_frame(const float
 #pragma unroll
       for (int n1 = 0; n1 < 8; ++n1)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c) {
           x[16 * (c >> 1) + 2 * n1 + (c & 1)] = arow[reflect_index(g0 + 256 * n1 + 4 * lane + c, T)];
+        }
     }
   }
 }
 
+#ifndef IAS_STFT2_MINW
+// waves per SIMD the 8-wave n_fft 1024 kernel is compiled for (register budget 512 / MINW).  Alone it does not matter
+// (4: 112 VGPRs, 52.8 us; 5: 84 VGPRs, 53.1 us); in the headline step it decides how many of its waves fit on a SIMD next
+// to the persistent render's (147 VGPRs each): step 0.192 / 0.173 / 0.173 / 0.179 ms at 4 / 5 / 6 / 8 (8 spills).
+#define IAS_STFT2_MINW 5
+#endif
 template <int SP_WAVES, bool MEL, int LOSS, int NSUB>
-__global__ __launch_bounds__(64 * SP_WAVES, NSUB == 2 ? 3 * SP_WAVES / 8 : (SP_WAVES >= 8 ? SP_WAVES / 2 : (3 * SP_WAVES + 3) / 4))
+__global__ __launch_bounds__(64 * SP_WAVES, NSUB == 2 ? 3 * SP_WAVES / 8 : (SP_WAVES >= 8 ? (SP_WAVES == 8 ? IAS_STFT2_MINW : SP_WAVES / 2) : (3 * SP_WAVES + 3) / 4))
 void stft2_kernel(const Spec2Args a) {
   static_assert(NSUB == 1 || (NSUB == 2 && !MEL), "mel filterbanks: n_fft 1024 only");
   constexpr int SP_THREADS = 64 * SP_WAVES, N2 = 512 * NSUB, R = 8, SCR = 64 * 9, NPK = 4 * NSUB, HALF = N2 / 2;
   // cpx per lane: window pairs, pass-1 twiddles, pass-2 twiddles, (NSUB = 2: combining twiddles,) unpack twiddles
   constexpr int NTAB = 8 * NSUB + 8 + 8 + (NSUB == 2 ? 8 : 0) + NPK;
+  // The frame-invariant tables are LDS objects of their own, not slices of the dynamic array that holds the exchange
+  // scratch: to the compiler a table read and a scratch store in ONE array may alias, so every twiddle / offset / weight
+  // read placed behind a scratch store stayed behind it -- one serial LDS round trip per element of a pass.
   extern __shared__ __attribute__((aligned(16))) float smem[];
   cpx* s_scr = reinterpret_cast<cpx*>(smem);                        // SP_WAVES x SCR: FFT exchange scratch / power buffer
-  cpx* s_tab = s_scr + SP_WAVES * SCR;                              // [NTAB][64]
-  cpx* s_segw = s_tab + NTAB * 64;                                  // MEL: [rows][64] (up, down)
-  int* s_sega = reinterpret_cast<int*>(s_segw + (MEL ? IAS_SEG_MAX_ROWS * 64 : 0));   // MEL: [9][64] store offsets
+  __shared__ cpx s_tab[NTAB * 64];                                  // [NTAB][64]
+  __shared__ cpx s_segw[MEL ? IAS_SEG_MAX_ROWS * 64 : 1];           // MEL: [rows][64] (up, down)
+  __shared__ int s_sega[MEL ? 9 * 64 : 1];                          // MEL: [9][64] store offsets
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -530,6 +572,7 @@ void stft2_kernel(const Spec2Args a) {
 
   cpx* sA = s_scr + wave * SCR;
   float* P2 = reinterpret_cast<float*>(sA);
+
   float l0 = 0.f, l1 = 0.f, l2 = 0.f;
   const int gw = blockIdx.x * SP_WAVES + wave, nw = gridDim.x * SP_WAVES;
   const int k1 = lane >> 3, dd = lane & 7;   // after the last pass the lane holds Z[k1 + 8 dd + 64 e]
@@ -541,14 +584,35 @@ void stft2_kernel(const Spec2Args a) {
     b = (int)q0; f = r;
   };
   float xc[16 * NSUB], xn[16 * NSUB];
+#ifdef IAS_S2_STAMPS
+  int stamp_n = 0;
+#endif
   int fi = gw, bcur = 0, fcur = 0;
-  if (fi < a.nframes) { row_of(fi, bcur, fcur); stft2_load_frame<NSUB>(a.audio + (size_t)bcur * a.T, a.T, a.hop, fcur, lane, xc); }
+  // the row peak travels with the frame's samples (requested one frame ahead): read where it is used, its wait -- the
+  // memory counter is in order -- would drain the prefetch of the next frame in every iteration
+  float pk_cur = 0.0f, pk_next = 0.0f;
+  if (fi < a.nframes) {
+    row_of(fi, bcur, fcur);
+    stft2_load_frame<NSUB>(a.audio + (size_t)bcur * a.T, a.T, a.hop, fcur, lane, xc);
+    if (a.rowpeak != nullptr) pk_cur = a.rowpeak[bcur];
+    // the first frame's loads are consumed HERE, outside the loop: left pending into the loop header they make the
+    // compiler wait for "everything older" at the first use inside the body, which is behind the next frame's prefetch in
+    // program order -- a full drain of the memory pipeline (vmcnt(0)) in every iteration
+#pragma unroll
+    for (int e = 0; e < 16 * NSUB; ++e) asm volatile("" : "+v"(xc[e]));
+    asm volatile("" : "+v"(pk_cur));
+  }
   for (; fi < a.nframes; fi += nw) {
     const bool more = fi + nw < a.nframes;   // wave-uniform
+    S2_STAMP(1);
     int bnext = 0, fnext = 0;
-    if (more) { row_of(fi + nw, bnext, fnext); stft2_load_frame<NSUB>(a.audio + (size_t)bnext * a.T, a.T, a.hop, fnext, lane, xn); }
+    if (more) {
+      row_of(fi + nw, bnext, fnext);
+      stft2_load_frame<NSUB>(a.audio + (size_t)bnext * a.T, a.T, a.hop, fnext, lane, xn);
+      if (a.rowpeak != nullptr) pk_next = a.rowpeak[bnext];
+    }
     float pscale = 0.25f;
-    if (a.rowpeak != nullptr) { const float pkv = a.rowpeak[bcur]; if (pkv > 1.0f) { const float r = 1.0f / pkv; pscale = 0.25f * (r * r); } }
+    if (pk_cur > 1.0f) { const float r = __builtin_amdgcn_rcpf(pk_cur); pscale = 0.25f * (r * r); }
     const size_t row = (size_t)fi * a.n_out;
     // MEL: the frame's target row is requested now and consumed after the transform
     float tgt_m[3] = {0.f, 0.f, 0.f};
@@ -579,19 +643,25 @@ void stft2_kernel(const Spec2Args a) {
 #pragma unroll
         for (int q = 0; q < R; ++q) sA[(q * 8 + c) * 9 + aa] = cmul(v[q], t_tw1[64 * q]);
       }
+      S2_STAMP(2);
       wave_lds_sync();
+      S2_STAMP(3);
       cpx u[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
       wave_lds_sync();
+      S2_STAMP(4);
       // pass 2: radix 8 over a for each (k1, c); twiddle W_64^(c d); scatter (in place) to [k1][d][c]
       dft8(u);
 #pragma unroll
       for (int d = 0; d < 8; ++d) sA[(k1 * 8 + d) * 9 + dd] = cmul(u[d], t_tw2[64 * d]);
+      S2_STAMP(5);
       wave_lds_sync();
+      S2_STAMP(6);
 #pragma unroll
       for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
       wave_lds_sync();
+      S2_STAMP(7);
       // pass 3: radix 8 over c for each (k1, d): u[e] = (half-)transform at k1 + 8 d + 64 e
       dft8(u);
       if (NSUB == 1) {
@@ -611,7 +681,9 @@ void stft2_kernel(const Spec2Args a) {
     // the upper half (k >= HALF) goes to LDS at k - HALF (padded by one complex per 8: conflict-free 8-byte stores)
 #pragma unroll
     for (int e = 0; e < NPK; ++e) { const int i = kl + 64 * e; sA[i + (i >> 3)] = zhi[e]; }
+    S2_STAMP(8);
     wave_lds_sync();
+    S2_STAMP(9);
     // unpack: own bins k = kl + 64 e with Z[N2 - k] from the upper half
     float pk[NPK], pn[NPK];
 #pragma unroll
@@ -638,7 +710,9 @@ void stft2_kernel(const Spec2Args a) {
       for (int e = 0; e < NPK; ++e) { pk[e] = __builtin_amdgcn_sqrtf(fmaxf(pk[e], a.eps)); pn[e] = __builtin_amdgcn_sqrtf(fmaxf(pn[e], a.eps)); }
       pmid = __builtin_amdgcn_sqrtf(fmaxf(pmid, a.eps));
     }
+    S2_STAMP(10);
     wave_lds_sync();   // every Z read is done: the power values overwrite the scratch
+    S2_STAMP(11);
     auto emit_t = [&](int m, float val, float t) {
       if (a.out != nullptr) a.out[row + m] = val;
       if (LOSS == 1) l0 += fabsf(val - t);
@@ -650,21 +724,40 @@ void stft2_kernel(const Spec2Args a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { P2[s_sega[64 * e + lane]] = pk[e]; P2[s_sega[64 * (4 + e) + lane]] = pn[e]; }
       if (lane == 0) P2[s_sega[64 * 8]] = pmid;
+      S2_STAMP(12);
       wave_lds_sync();
+      S2_STAMP(13);
+      // per segment group: the rows four at a time, their eight reads in flight together (one read, one wait, one fma per
+      // row -- the rolled loop -- is a serial chain of LDS round trips)
       float U[3], D[3];
       int rbase = 0;
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         float us = 0.f, ds = 0.f;
-        for (int t = 0; t < seg_r[g]; ++t) {
-          const float pv = P2[(rbase + t) * IAS_SEG_STRIDE + lane];
-          const cpx w = s_segw[(rbase + t) * 64 + lane];
-          us = fmaf(w.x, pv, us);
-          ds = fmaf(w.y, pv, ds);
+        const int n = seg_r[g];
+        int t = 0;
+        for (; t + 4 <= n; t += 4) {
+          float pv[4]; cpx w[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { pv[u] = P2[(rbase + t + u) * IAS_SEG_STRIDE + lane]; w[u] = s_segw[(rbase + t + u) * 64 + lane]; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { us = fmaf(w[u].x, pv[u], us); ds = fmaf(w[u].y, pv[u], ds); }
+        }
+        if (t < n) {                                       // up to three rows left: read all three slots (in bounds), use n - t
+          float pv[3]; cpx w[3];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int row = min(rbase + t + u, IAS_SEG_MAX_ROWS - 1);
+            pv[u] = P2[row * IAS_SEG_STRIDE + lane]; w[u] = s_segw[row * 64 + lane];
+          }
+#pragma unroll
+          for (int u = 0; u < 3; ++u)
+            if (t + u < n) { us = fmaf(w[u].x, pv[u], us); ds = fmaf(w[u].y, pv[u], ds); }
         }
         U[g] = us; D[g] = ds;
-        rbase += seg_r[g];
+        rbase += n;
       }
+      S2_STAMP(14);
       // mel m = U[segment m] + D[segment m + 1]; slot i = 64 g + lane holds segment s0 + i
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -686,14 +779,18 @@ void stft2_kernel(const Spec2Args a) {
       for (int e = 0; e < NPK; ++e) { const int k = kl + 64 * e; emit_t(k, pk[e], tg_k[e]); emit_t(N2 - k, pn[e], tg_n[e]); }
       if (lane == 0) emit_t(HALF, pmid, tg_mid);
     }
+    S2_STAMP(15);
     wave_lds_sync();
     if (more) {
 #pragma unroll
       for (int e = 0; e < 16 * NSUB; ++e) xc[e] = xn[e];
-      bcur = bnext; fcur = fnext;
+      bcur = bnext; fcur = fnext; pk_cur = pk_next;
     }
   }
 
+#ifdef IAS_S2_STAMPS
+  if (a.stamps != nullptr && lane == 0) a.stamps[((size_t)blockIdx.x * SP_WAVES + wave) * 256] = stamp_n;
+#endif
   if (a.partials != nullptr) {
     __shared__ float s_red[SP_WAVES][4];
     l0 = wave_sum_f(l0); l1 = wave_sum_f(l1); l2 = wave_sum_f(l2) * 0.6931471805599453f;   // log-magnitude terms were taken in log2
@@ -1610,9 +1707,11 @@ extern "C" int ias_stft(const float* audio, const float* tables, const float* mt
     a2.partials = partials; a2.rowpeak = rowpeak; a2.T = T; a2.F = F; a2.hop = hop; a2.n_out = n_out; a2.nframes = B * F;
     a2.magicF = (unsigned)(0x100000000ULL / (unsigned long long)F);
     a2.value_mode = value_mode; a2.loss_mode = loss_mode; a2.eps = eps;
+#ifdef IAS_S2_STAMPS
+    a2.stamps = g_s2_stamps;
+#endif
     const int waves2 = n_fft == 2048 ? 8 : stft2_waves();
-    const size_t lds2 = sizeof(cpx) * (waves2 * 64 * 9 + (n_fft == 2048 ? 48 : 28) * 64 + (mel ? IAS_SEG_MAX_ROWS * 64 : 0)) +
-                        (mel ? sizeof(int) * 9 * 64 : 0);
+    const size_t lds2 = sizeof(cpx) * (waves2 * 64 * 9);       // the exchange scratch; the tables are static LDS objects
     const dim3 grid2(stft2_grid(a2.nframes, n_fft)), block2(64 * waves2);
 #define IAS_STFT2_LAUNCHW(W, MEL, LOSS)                                                                            \
   do {                                                                                                             \
