@@ -847,7 +847,9 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   cpx* s_scr = reinterpret_cast<cpx*>(smem);
   float* s_ring = reinterpret_cast<float*>(s_scr + SP_WAVES * SCR);          // SPAN: [wave][NFFT]
-  cpx* s_tab = s_scr + SP_WAVES * SCR + (SPAN ? SP_WAVES * N2 : 0);
+  // the tables are an LDS object of their own: carved out of the array that holds the scratch, every table read behind a
+  // scratch store was ordered after it (see stft2_kernel)
+  __shared__ cpx s_tab[NTAB / 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (SPAN) for (int i = tid; i < SP_WAVES * NFFT; i += SP_THREADS) s_ring[i] = 0.0f;
   for (int i = tid; i < NTAB / 2; i += SP_THREADS) {
@@ -855,7 +857,7 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
     s_tab[i] = cmk(a.tables[64 * (2 * pp) + l], a.tables[64 * (2 * pp + 1) + l]);
   }
   // MEL: padded weights + descriptors (as in stft_kernel), then per wave the output cotangents and the bin cotangents
-  float* s_melw = reinterpret_cast<float*>(s_tab + NTAB / 2);
+  float* s_melw = reinterpret_cast<float*>(s_scr + SP_WAVES * SCR + (SPAN ? SP_WAVES * N2 : 0));
   const int melw_words = MEL ? mel_padded_words(a.mel_nnz, a.n_out) : 0;
   int* s_meli = reinterpret_cast<int*>(s_melw + melw_words);            // [3][n_out]: start, padded count, padded offset
   const int so_words = MEL ? ((a.n_out + 3) & ~3) : 0;
@@ -1150,7 +1152,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
   extern __shared__ __attribute__((aligned(16))) float smem[];
   cpx* s_scr = reinterpret_cast<cpx*>(smem);
   f32x4* s_ring = reinterpret_cast<f32x4*>(s_scr + SP_WAVES * SCR);         // SPAN: [wave][NFFT / 4]
-  cpx* s_tab = s_scr + SP_WAVES * SCR + (SPAN ? SP_WAVES * N2 : 0);
+  __shared__ cpx s_tab[NTAB * 64];                                          // an LDS object of its own (see stft2_kernel)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (SPAN) for (int i = tid; i < SP_WAVES * NFFT / 4; i += SP_THREADS) s_ring[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
@@ -1413,7 +1415,7 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
   if (n_fft == 2048 && !mel && !v1_2k && (long long)B * F < 2000000000LL && (reinterpret_cast<uintptr_t>(frame_grad) & 15) == 0 &&
       (!span || (hop & 3) == 0)) {
     constexpr int W2 = 8;
-    const size_t lds2 = sizeof(cpx) * (W2 * 64 * 9 + 64 * 64 + (span ? W2 * 1024 : 0));
+    const size_t lds2 = sizeof(cpx) * (W2 * 64 * 9 + (span ? W2 * 1024 : 0));       // + 32 KB of static tables
     if (span) {
       if (!make_plan((long long)ncu * W2)) return IAS_ERR_UNSUPPORTED;
       if (dry) return IAS_OK;
@@ -1431,16 +1433,17 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   }
   const int R = n_fft / 128, scr = 8 * R * 9, np_it = (8 * R + 63) / 64, nunp = (n_fft / 4) / 64 + 1;
-  size_t lds = sizeof(cpx) * 4 * scr + sizeof(float) * 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp) + 16;
+  const size_t lds_static = sizeof(float) * 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp);   // the kernel's table object
+  size_t lds = sizeof(cpx) * 4 * scr + 16;
   if (span) lds += sizeof(float) * 4 * n_fft;
   if (mel)
     lds += sizeof(float) * (mel_padded_words(mel_nnz, n_out) + ((3 * n_out + 3) & ~3) +
                             4 * (((n_out + 3) & ~3) + n_fft / 2 + 1 + 7));
-  if (lds > 150 * 1024) return IAS_ERR_UNSUPPORTED;
+  if (lds + lds_static > 150 * 1024) return IAS_ERR_UNSUPPORTED;
   dim3 grid((F + g - 1) / g, B), block(256);
 #define IAS_SGW_LAUNCH(LOG2N, MEL, SPAN)                                                                          \
   do {                                                                                                             \
-    if (lds > 64 * 1024)                                                                                           \
+    if (lds + lds_static > 48 * 1024)                                                                              \
       (void)hipFuncSetAttribute((const void*)stft_grad_wave_kernel<LOG2N, MEL, SPAN>,                              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
     if (SPAN) {                                                                                                    \
