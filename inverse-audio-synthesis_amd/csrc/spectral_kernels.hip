@@ -805,6 +805,166 @@ void stft2_kernel(const Spec2Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// n_fft 512 (linear bins: STFT-L1 and the third MR-STFT resolution) on the 8-points-per-lane core: TWO frames per wave.
+// A 512-point frame is 256 packed complex points = 4 per lane: stft_kernel<9> runs its two radix-8 passes with 32 of
+// the 64 lanes.  Here a lane holds four points of frame A and four of frame B; pass 1 is two radix-4 transforms (n1 of
+// each frame), and what is left -- for each of the 2 x 4 (frame, k1) slots a 64-point transform over the lane index --
+// is exactly passes 2 and 3 of the 1024-point kernel with the slot in place of its k1.  After the last pass lane
+// (slot = lane >> 3, d = lane & 7) holds Z_frame[k1 + 4 d + 32 e] (frame = slot >> 2, k1 = slot & 3): lanes 0..31 own
+// frame A, lanes 32..63 frame B, each with the 4 + 4 bins of the half-spectrum unpack (as stft2_kernel, N/2 = 256).
+template <int SP_WAVES, int LOSS>
+__global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES >= 8 ? SP_WAVES / 2 : (3 * SP_WAVES + 3) / 4)
+void stft2h_kernel(const Spec2Args a) {
+  constexpr int SP_THREADS = 64 * SP_WAVES, SCR = 64 * 9, N2 = 256, HALF = 128;
+  constexpr int NTAB = 4 + 4 + 8 + 4;        // cpx per lane: window pairs, pass-1 twiddles, pass-2 twiddles, unpack twiddles
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  cpx* s_scr = reinterpret_cast<cpx*>(smem);
+  __shared__ cpx s_tab[NTAB * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // the n_fft 512 block of ias_stft_build_tables: [0,8) window, [8,16) pass 1, [16,32) pass 2, [38,46) this kernel's unpack
+  for (int i = tid; i < NTAB * 64; i += SP_THREADS) {
+    const int pp = i >> 6, l = i & 63, src = pp < 16 ? 2 * pp : 38 + 2 * (pp - 16);
+    s_tab[i] = cmk(a.tables[64 * src + l], a.tables[64 * (src + 1) + l]);
+  }
+  const cpx* t_win = s_tab + lane;           // [n1]  -> the window at the lane's two samples of point n1
+  const cpx* t_tw1 = t_win + 64 * 4;         // [k1]  -> W_256^(lane k1)
+  const cpx* t_tw2 = t_tw1 + 64 * 4;         // [d]   -> W_64^(c d), c = lane & 7
+  const cpx* t_twu = t_tw2 + 64 * 8;         // [e]   -> W_512^k, k = kl + 32 e
+  __syncthreads();
+
+  cpx* sA = s_scr + wave * SCR;
+  float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+  const int gw = blockIdx.x * SP_WAVES + wave, nw = gridDim.x * SP_WAVES;
+  const int slot = lane >> 3, dd = lane & 7, fr = lane >> 5, kl = (slot & 3) + 4 * dd;
+  const int npairs = (a.nframes + 1) >> 1;
+  auto row_of = [&](int fi, int& b, int& f) {
+    unsigned q0 = __umulhi((unsigned)fi, a.magicF);
+    int r = fi - (int)q0 * a.F;
+    if (r >= a.F) { r -= a.F; ++q0; }
+    b = (int)q0; f = r;
+  };
+  // frames 2 pi and 2 pi + 1 (the last pair of an odd list repeats its first frame; the repeat is not emitted)
+  auto load_pair = [&](int pi, float (&x)[16], int& bA, int& bB) {
+    const int fiA = 2 * pi, fiB = min(2 * pi + 1, a.nframes - 1);
+    int fA, fB;
+    row_of(fiA, bA, fA); row_of(fiB, bB, fB);
+    float (&xa)[8] = reinterpret_cast<float (&)[8]>(x[0]);
+    float (&xb)[8] = reinterpret_cast<float (&)[8]>(x[8]);
+    load_frame<4, 256>(a.audio + (size_t)bA * a.T, a.T, a.hop, fA, lane, xa);
+    load_frame<4, 256>(a.audio + (size_t)bB * a.T, a.T, a.hop, fB, lane, xb);
+  };
+  float xc[16], xn[16];
+  int pi = gw, bA = 0, bB = 0;
+  if (pi < npairs) {
+    load_pair(pi, xc, bA, bB);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(xc[e]));      // consumed outside the loop (see stft2_kernel)
+  }
+  for (; pi < npairs; pi += nw) {
+    const bool more = pi + nw < npairs;      // wave-uniform
+    int bAn = 0, bBn = 0;
+    if (more) load_pair(pi + nw, xn, bAn, bBn);
+    const bool own = fr == 0 || 2 * pi + 1 < a.nframes;                // this lane's frame exists
+    const int fi = own ? 2 * pi + fr : 2 * pi;
+    const size_t row = (size_t)fi * a.n_out;
+    float pscale = 0.25f;
+    if (a.rowpeak != nullptr) { const float pkv = a.rowpeak[fr ? bB : bA]; if (pkv > 1.0f) { const float r = __builtin_amdgcn_rcpf(pkv); pscale = 0.25f * (r * r); } }
+    float tg_k[4], tg_n[4], tg_mid = 0.f;
+    if (LOSS != 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { tg_k[e] = a.target[row + kl + 32 * e]; tg_n[e] = a.target[row + N2 - kl - 32 * e]; }
+      if (kl == 0) tg_mid = a.target[row + HALF];
+    }
+    // pass 1: radix 4 over n1 for both frames; slot q = 4 frame + k1; twiddle W_256^(lane k1); scatter to [q][c][a]
+    cpx v[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) {
+      v[n1] = cmk(xc[2 * n1], xc[2 * n1 + 1]) * t_win[64 * n1];
+      v[4 + n1] = cmk(xc[8 + 2 * n1], xc[8 + 2 * n1 + 1]) * t_win[64 * n1];
+    }
+    {
+      cpx (&va)[4] = reinterpret_cast<cpx (&)[4]>(v[0]);
+      cpx (&vb)[4] = reinterpret_cast<cpx (&)[4]>(v[4]);
+      dftR<4>(va); dftR<4>(vb);
+      const int c = lane & 7, aa = lane >> 3;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sA[(q * 8 + c) * 9 + aa] = cmul(v[q], t_tw1[64 * (q & 3)]);
+    }
+    wave_lds_sync();
+    cpx u[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+    wave_lds_sync();
+    // pass 2: radix 8 over a for each (slot, c); twiddle W_64^(c d); scatter (in place) to [slot][d][c]
+    dft8(u);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) sA[(slot * 8 + d) * 9 + dd] = cmul(u[d], t_tw2[64 * d]);
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+    wave_lds_sync();
+    // pass 3: radix 8 over c: u[e] = Z_frame[kl + 32 e]
+    dft8(u);
+    // the upper halves (k >= 128) go to LDS, frame-major
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sA[fr * HALF + kl + 32 * e] = u[4 + e];
+    wave_lds_sync();
+    float pk[4], pn[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = kl + 32 * e;
+      cpx zn = sA[fr * HALF + ((HALF - k) & (HALF - 1))];    // k = 0: Z[N2] = Z[0] (own), the read is a dummy
+      const cpx zk = u[e];
+      if (e == 0 && k == 0) zn = zk;
+      const cpx w = t_twu[64 * e];
+      const float ea = zk.x + zn.x, eb = zk.y - zn.y, od = zk.x - zn.x, os = zk.y + zn.y;
+      const float tx = fmaf(w.y, od, w.x * os), ty = fmaf(-w.x, od, w.y * os);
+      const float xr = ea + tx, xi = eb + ty, yr = ea - tx, yi = eb - ty;
+      pk[e] = fmaf(xi, xi, xr * xr) * pscale;
+      pn[e] = fmaf(yi, yi, yr * yr) * pscale;
+    }
+    float pmid = fmaf(u[4].y, u[4].y, u[4].x * u[4].x) * (4.0f * pscale);    // lanes with kl = 0: |Z[128]|^2
+    if (a.value_mode == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pk[e] = __builtin_amdgcn_sqrtf(pk[e]); pn[e] = __builtin_amdgcn_sqrtf(pn[e]); }
+      pmid = __builtin_amdgcn_sqrtf(pmid);
+    } else if (a.value_mode == 3) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pk[e] = __builtin_amdgcn_sqrtf(fmaxf(pk[e], a.eps)); pn[e] = __builtin_amdgcn_sqrtf(fmaxf(pn[e], a.eps)); }
+      pmid = __builtin_amdgcn_sqrtf(fmaxf(pmid, a.eps));
+    }
+    auto emit_t = [&](int m, float val, float t) {
+      if (a.out != nullptr) a.out[row + m] = val;
+      if (LOSS == 1) l0 += fabsf(val - t);
+      else if (LOSS == 2) { const float d = t - val; l0 = fmaf(d, d, l0); l1 = fmaf(t, t, l1); l2 += fabsf(__log2f(val) - __log2f(t)); }
+    };
+    if (own) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const int k = kl + 32 * e; emit_t(k, pk[e], tg_k[e]); emit_t(N2 - k, pn[e], tg_n[e]); }
+      if (kl == 0) emit_t(HALF, pmid, tg_mid);
+    }
+    wave_lds_sync();
+    if (more) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xc[e] = xn[e];
+      bA = bAn; bB = bBn;
+    }
+  }
+  if (a.partials != nullptr) {
+    __shared__ float s_red[SP_WAVES][4];
+    l0 = wave_sum_f(l0); l1 = wave_sum_f(l1); l2 = wave_sum_f(l2) * 0.6931471805599453f;   // log-magnitude terms were taken in log2
+    if (lane == 0) { s_red[wave][0] = l0; s_red[wave][1] = l1; s_red[wave][2] = l2; }
+    __syncthreads();
+    if (tid < 3) {
+      double sacc = 0.0;
+      for (int w = 0; w < SP_WAVES; ++w) sacc += (double)s_red[w][tid];
+      a.partials[(size_t)blockIdx.x * 3 + tid] = sacc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Backward of the linear-bin losses, frame part, on the same wave-per-frame FFT core (round 2).
 //
 // d loss / d x_f for  loss_mode 1: scale * sum |V - t|  and  loss_mode 2: one MR-STFT resolution (cotangent
@@ -1572,7 +1732,7 @@ static int stft2_waves() {
 }
 static bool stft2_enabled(int n_fft, bool mel, bool have_segtab) {
   static const int v1 = getenv("IAS_STFT_V1") ? atoi(getenv("IAS_STFT_V1")) : 0;   // diagnostics: round-2 kernel
-  return !v1 && ((n_fft == 1024 && (!mel || have_segtab)) || (n_fft == 2048 && !mel));
+  return !v1 && ((n_fft == 1024 && (!mel || have_segtab)) || ((n_fft == 2048 || n_fft == 512) && !mel));
 }
 static int stft2_grid(long long nframes, int n_fft) {
   static const int env = getenv("IAS_STFT2_WGS") ? atoi(getenv("IAS_STFT2_WGS")) : 0;   // diagnostics
@@ -1582,7 +1742,8 @@ static int stft2_grid(long long nframes, int n_fft) {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
     ncu = v;
   }
-  const int waves = n_fft == 2048 ? 8 : stft2_waves();
+  const int waves = n_fft == 1024 ? stft2_waves() : 8;
+  if (n_fft == 512) nframes = (nframes + 1) / 2;             // two frames per wave
   const long long need = (nframes + waves - 1) / waves;
   // workgroups per CU by LDS (scratch 4.5 KB per wave + 25 KB of tables per workgroup): 10 waves: 2, 8: 2, 5: 3, 4: 3
   const long long cap = env > 0 ? env : (waves >= 8 ? 2LL : 3LL) * ncu;
@@ -1608,7 +1769,7 @@ extern "C" int ias_stft_tables_len(int n_fft) {
   // n_fft 2048: + stft2_kernel<NSUB = 2>'s whole table section (window pairs of the two half-transforms, pass-1 / pass-2
   // twiddles of a 512-point transform, combining twiddles W_1024^k, unpack twiddles W_2048^k, and for the backward
   // (stft_grad2k_kernel) the window at the lane's output samples: 64 complex per lane)
-  return 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp + (n_fft == 1024 ? 8 : 0) + (n_fft == 2048 ? 128 : 0));
+  return 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp + (n_fft == 1024 || n_fft == 512 ? 8 : 0) + (n_fft == 2048 ? 128 : 0));
 }
 
 extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float* out_host) {
@@ -1649,6 +1810,13 @@ extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float*
     for (int e = 0; e < 4; ++e)
       for (int l = 0; l < 64; ++l) {
         const double ang = w0 * (double)((l >> 3) + 8 * (l & 7) + 64 * e);
+        o[64 * (2 * e) + l] = (float)cos(ang);
+        o[64 * (2 * e + 1) + l] = (float)(-sin(ang));
+      }
+  if (n_fft == 512)                                        // stft2h_kernel: bins k = ((l >> 3) & 3) + 4 (l & 7) + 32 e, e < 4
+    for (int e = 0; e < 4; ++e)
+      for (int l = 0; l < 64; ++l) {
+        const double ang = w0 * (double)(((l >> 3) & 3) + 4 * (l & 7) + 32 * e);
         o[64 * (2 * e) + l] = (float)cos(ang);
         o[64 * (2 * e + 1) + l] = (float)(-sin(ang));
       }
@@ -1713,7 +1881,7 @@ extern "C" int ias_stft(const float* audio, const float* tables, const float* mt
 #ifdef IAS_S2_STAMPS
     a2.stamps = g_s2_stamps;
 #endif
-    const int waves2 = n_fft == 2048 ? 8 : stft2_waves();
+    const int waves2 = n_fft == 1024 ? stft2_waves() : 8;
     const size_t lds2 = sizeof(cpx) * (waves2 * 64 * 9);       // the exchange scratch; the tables are static LDS objects
     const dim3 grid2(stft2_grid(a2.nframes, n_fft)), block2(64 * waves2);
 #define IAS_STFT2_LAUNCHW(W, MEL, LOSS)                                                                            \
@@ -1735,11 +1903,17 @@ extern "C" int ias_stft(const float* audio, const float* tables, const float* mt
     else if (waves2 == 8) IAS_STFT2_LAUNCHW(8, MEL, LOSS);                                                         \
     else IAS_STFT2_LAUNCHW(10, MEL, LOSS);                                                                         \
   } while (0)
-    if (n_fft == 2048) { if (loss_mode == 0) IAS_STFT2_LAUNCH2K(0); else if (loss_mode == 1) IAS_STFT2_LAUNCH2K(1); else IAS_STFT2_LAUNCH2K(2); }
+#define IAS_STFT2_LAUNCHH(LOSS)                                                                                    \
+  do {                                                                                                             \
+    hipLaunchKernelGGL((stft2h_kernel<8, LOSS>), grid2, block2, lds2, stream, a2);                                 \
+  } while (0)
+    if (n_fft == 512) { if (loss_mode == 0) IAS_STFT2_LAUNCHH(0); else if (loss_mode == 1) IAS_STFT2_LAUNCHH(1); else IAS_STFT2_LAUNCHH(2); }
+    else if (n_fft == 2048) { if (loss_mode == 0) IAS_STFT2_LAUNCH2K(0); else if (loss_mode == 1) IAS_STFT2_LAUNCH2K(1); else IAS_STFT2_LAUNCH2K(2); }
     else if (mel) { if (loss_mode == 0) IAS_STFT2_LAUNCH(true, 0); else if (loss_mode == 1) IAS_STFT2_LAUNCH(true, 1); else IAS_STFT2_LAUNCH(true, 2); }
     else { if (loss_mode == 0) IAS_STFT2_LAUNCH(false, 0); else if (loss_mode == 1) IAS_STFT2_LAUNCH(false, 1); else IAS_STFT2_LAUNCH(false, 2); }
 #undef IAS_STFT2_LAUNCH
 #undef IAS_STFT2_LAUNCH2K
+#undef IAS_STFT2_LAUNCHH
 #undef IAS_STFT2_LAUNCHW
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   }

@@ -16,7 +16,9 @@
 #include "ias_common.h"
 #include "voice_table.h"
 
-#define CG_THREADS 512    // 8 waves per voice (2 per SIMD; 16 would cap the kernel at 128 VGPRs and spill)
+#ifndef CG_THREADS
+#define CG_THREADS 512    // 8 waves per voice (2 per SIMD; 16 would cap the kernel at 128 VGPRs and spill: 467 us instead of 240)
+#endif
 #define CG_NSCAL 12
 
 __constant__ IasParamRange c_cg_table[78] = IAS_PARAM_TABLE_INIT;

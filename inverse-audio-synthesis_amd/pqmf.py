@@ -26,24 +26,26 @@ def design_filters(N, taps, cutoff, beta):
     return H, G
 
 
-def _packed_taps(H, Hc, N, K):
-    """Duplicated (h, h) tap table of H for the fast kernel.
+_PACKED_CACHE = {}
 
-    Kept as an attribute of the caller's H tensor object together with the tensor version and address it was
-    packed from, so an in-place write to H (or a new H) packs again.
-    """
+
+def _packed_taps(H, Hc, N, K):
+    """Duplicated (h, h) tap table of H for the fast kernel, cached per (storage address, tensor version, device): an
+    in-place write to H (or a new H) packs again.  (A module-level table like ``_MODTAB_CACHE``; round 2 hung the cache
+    off the tensor object.)"""
     lib = _lib.load()
     n = lib.ias_pqmf_packed_taps_len(N, K)
     if n <= 0:
         return None
-    tag = (Hc.data_ptr(), H._version)
-    hit = getattr(H, "_ias_packed_taps", None)
-    if hit is None or hit[0] != tag:
+    key = (Hc.data_ptr(), H._version, str(Hc.device), N, K)
+    hit = _PACKED_CACHE.get(key)
+    if hit is None:
         packed = torch.empty(n, dtype=torch.float32, device=Hc.device)
         _lib.check(lib.ias_pqmf_pack_taps(_lib.ptr(Hc), _lib.ptr(packed), N, K, _lib.stream()), "ias_pqmf_pack_taps")
-        hit = (tag, packed)
-        H._ias_packed_taps = hit
-    return hit[1]
+        if len(_PACKED_CACHE) > 64:
+            _PACKED_CACHE.clear()
+        hit = _PACKED_CACHE[key] = (packed, Hc)          # Hc kept alive: its address is part of the key
+    return hit[0]
 
 
 # N = 3: evaluate the filterbank in its cosine-modulated form (csrc/pqmf_kernels.hip: pqmf_analysis_mod_kernel) when H is
@@ -72,6 +74,7 @@ def _modulated_taps(H, Hc, N, K):
             hit = (out.to(Hc.device),)
         if len(_MODTAB_CACHE) > 64:
             _MODTAB_CACHE.clear()
+        hit = hit + (Hc,)                                 # Hc kept alive: its address is part of the key
         _MODTAB_CACHE[key] = hit
     return hit[0]
 
@@ -95,8 +98,7 @@ class _AnalysisFn(torch.autograd.Function):
         g = g_z.to(torch.float32)
         if std is not None:
             g = g / std.reshape(1, N, 1)
-        G = torch.flip(H.reshape(N, -1), dims=[1]).reshape(1, N, -1) / float(N)
-        g_x = pqmf_synthesis(g, G)[:, 0, :T]
+        g_x = pqmf_synthesis(g, _adjoint_filters(H))[:, 0, :T]
         if g_x.shape[-1] < T:
             g_x = torch.nn.functional.pad(g_x, (0, T - g_x.shape[-1]))
         return g_x.reshape(ctx.shape), None, None, None
@@ -135,21 +137,41 @@ def _analysis_nograd(x, H, mean=None, std=None, rowpeak=None):
     return z
 
 
+_ADJOINT_CACHE = {}
+_SYNTH_CACHE = {}
+
+
+def _adjoint_filters(H):
+    """G [1,N,K] = flip(H) / N: the synthesis filters whose polyphase synthesis is the adjoint of the analysis with H.
+    Cached per (storage address, version, device) of H -- the backward built it (flip, divide, pack: three launches) on
+    every call.  The cache holds H, so its address cannot be reused while the entry lives."""
+    key = (H.data_ptr(), H._version, str(H.device), tuple(H.shape))
+    hit = _ADJOINT_CACHE.get(key)
+    if hit is None:
+        N = H.shape[0]
+        G = (torch.flip(H.detach().reshape(N, -1), dims=[1]).reshape(1, N, -1) / float(N)).contiguous()
+        if len(_ADJOINT_CACHE) > 64:
+            _ADJOINT_CACHE.clear()
+        hit = _ADJOINT_CACHE[key] = (G, H)
+    return hit[0]
+
+
 def _packed_synth_taps(G, Gc, N, K):
-    """Phase-major tap table of G for the wide synthesis kernel, cached on the caller's G tensor like the analysis one."""
+    """Phase-major tap table of G for the wide synthesis kernel, cached like the analysis one."""
     lib = _lib.load()
     n = lib.ias_pqmf_synth_taps_len(N, K)
     if n <= 0:
         return None
-    tag = (Gc.data_ptr(), G._version)
-    hit = getattr(G, "_ias_packed_synth_taps", None)
-    if hit is None or hit[0] != tag:
+    key = (Gc.data_ptr(), G._version, str(Gc.device), N, K)
+    hit = _SYNTH_CACHE.get(key)
+    if hit is None:
         packed = torch.empty(n, dtype=torch.float32, device=Gc.device)
         _lib.check(lib.ias_pqmf_pack_synth_taps(_lib.ptr(Gc), _lib.ptr(packed), N, K, _lib.stream()),
                    "ias_pqmf_pack_synth_taps")
-        hit = (tag, packed)
-        G._ias_packed_synth_taps = hit
-    return hit[1]
+        if len(_SYNTH_CACHE) > 64:
+            _SYNTH_CACHE.clear()
+        hit = _SYNTH_CACHE[key] = (packed, Gc)            # Gc kept alive: its address is part of the key
+    return hit[0]
 
 
 def pqmf_synthesis(z, G):

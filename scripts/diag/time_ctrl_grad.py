@@ -1,0 +1,22 @@
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from inverse_audio_synthesis_amd import _lib
+from inverse_audio_synthesis_amd import voice_spec as S
+lib = _lib.load()
+dev = torch.device("cuda:0")
+B, Tc = 64, 1764
+g = torch.Generator().manual_seed(0)
+p = torch.rand(B, 78, generator=g).to(dev)
+g_ctrl = torch.randn(B, 5, Tc, generator=g).to(dev)
+g_scal = torch.randn(B, 12, generator=g, dtype=torch.float64).to(dev)
+out = torch.empty(B, 78, device=dev)
+def run():
+    st = lib.ias_voice_control_backward(_lib.ptr(p), _lib.ptr(g_ctrl), _lib.ptr(g_scal), _lib.ptr(out), B, Tc, 441, _lib.stream())
+    assert st == 0, st
+for _ in range(3): run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): run()
+e1.record(); torch.cuda.synchronize()
+print(os.environ.get("IAS_HIP_LIB", "default").split("/")[-1], f"{e0.elapsed_time(e1) / 20 * 1000:.1f} us", float(out.abs().sum()))
