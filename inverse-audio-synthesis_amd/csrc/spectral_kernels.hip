@@ -1521,6 +1521,209 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
   }
 }
 
+// Backward of the linear-bin losses for n_fft 512, two frames per wave (the lane layout of stft2h_kernel), overlap-add
+// inside the kernel (SPAN form only: ias_stft_grad_spans).  A wave walks its chunk two consecutive frames at a time:
+// forward transform of both, cotangents per bin pair in the lane that owns the pair (lanes 0..31 frame A, 32..63 frame
+// B), the inverse inputs Zin of both frames through the scratch in natural order, ONE more run of the three passes on
+// their conjugates, then frame A's lanes add their windowed samples into the ring, after them frame B's (frame order:
+// deterministic), and the 2 hop samples no later frame reaches leave the ring.
+template <int SP_WAVES>
+__global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 2) void stft_grad512_kernel(const SgwArgs a) {
+  constexpr int SP_THREADS = 64 * SP_WAVES, SCR = 64 * 9, NFFT = 512, N2 = 256, HALF = 128, NB = 257;
+  constexpr int NTAB = 4 + 4 + 8 + 4 + 8;    // stft2h's tables + the window at the lane's OUTPUT samples
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  cpx* s_scr = reinterpret_cast<cpx*>(smem);
+  float* s_ring = reinterpret_cast<float*>(s_scr + SP_WAVES * SCR);         // [wave][NFFT]
+  __shared__ cpx s_tab[NTAB * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < SP_WAVES * NFFT; i += SP_THREADS) s_ring[i] = 0.0f;
+  // n_fft 512 block of ias_stft_build_tables: [0,8) window, [8,16) pass 1, [16,32) pass 2, [38,46) unpack, [46,62) output window
+  for (int i = tid; i < NTAB * 64; i += SP_THREADS) {
+    const int pp = i >> 6, l = i & 63, src = pp < 16 ? 2 * pp : 38 + 2 * (pp - 16);
+    s_tab[i] = cmk(a.tables[64 * src + l], a.tables[64 * (src + 1) + l]);
+  }
+  const cpx* t_win = s_tab + lane;
+  const cpx* t_tw1 = t_win + 64 * 4;
+  const cpx* t_tw2 = t_tw1 + 64 * 4;
+  const cpx* t_twu = t_tw2 + 64 * 8;          // [e] -> W_512^k, k = kl + 32 e (e < 4)
+  const cpx* t_wo = t_twu + 64 * 4;           // [e] -> window at samples 2 m, 2 m + 1, m = kl + 32 e (e < 8)
+  __syncthreads();
+  cpx* sA = s_scr + wave * SCR;
+  float* ring = s_ring + wave * NFFT;
+  const int slot = lane >> 3, dd = lane & 7, fr = lane >> 5, kl = (slot & 3) + 4 * dd;
+  float c0 = 0.0f, c1 = 0.0f;
+  if (a.loss_mode == 2) { c0 = (float)a.coef[0]; c1 = (float)a.coef[1]; }
+  auto bin_value = [&](float p) { return a.power2 ? p : __builtin_amdgcn_sqrtf(a.loss_mode == 2 ? fmaxf(p, a.eps) : p); };
+  auto value_grad = [&](float v, float t) {
+    const float d = v - t;
+    const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+    return a.loss_mode == 2 ? c0 * d + c1 * sg * __builtin_amdgcn_rcpf(v) : sg * a.scale;
+  };
+  auto power_grad = [&](float gv, float v) {
+    if (a.power2) return gv;
+    const bool live = a.loss_mode == 2 ? v > __builtin_amdgcn_sqrtf(a.eps) : v > 0.0f;
+    return live ? 0.5f * gv * __builtin_amdgcn_rcpf(v) : 0.0f;
+  };
+  auto pad = [](int i) { return i + (i >> 3); };
+  // v[0..3] / v[4..7]: the lane's points 64 n1 + lane of frame A / B  ->  u[e] = transform of the lane's own frame
+  // (slot >> 2) at kl + 32 e
+  auto fft2 = [&](cpx (&v)[8], cpx (&u)[8]) {
+    cpx (&va)[4] = reinterpret_cast<cpx (&)[4]>(v[0]);
+    cpx (&vb)[4] = reinterpret_cast<cpx (&)[4]>(v[4]);
+    dftR<4>(va); dftR<4>(vb);
+    {
+      const int c = lane & 7, aa = lane >> 3;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sA[(q * 8 + c) * 9 + aa] = cmul(v[q], t_tw1[64 * (q & 3)]);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+    wave_lds_sync();
+    dft8(u);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) sA[(slot * 8 + d) * 9 + dd] = cmul(u[d], t_tw2[64 * d]);
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+    wave_lds_sync();
+    dft8(u);
+  };
+
+  const int cstep = (int)gridDim.x * SP_WAVES;
+  for (int c = (int)blockIdx.x * SP_WAVES + wave; c < a.nchunks; c += cstep) {
+    const int b = c / a.cper, f_lo = (c - b * a.cper) * a.G, f_hi = min(f_lo + a.G, a.F);
+    const float* arow = a.audio + (size_t)b * a.T;
+    float* span = a.frame_grad + (size_t)c * a.L;
+    for (int f = f_lo; f < f_hi; f += 2) {
+      const bool hasB = f + 1 < f_hi;                         // wave-uniform
+      const bool own = fr == 0 || hasB;
+      float xc[16];
+      {
+        float (&xa)[8] = reinterpret_cast<float (&)[8]>(xc[0]);
+        float (&xb)[8] = reinterpret_cast<float (&)[8]>(xc[8]);
+        load_frame<4, 256>(arow, a.T, a.hop, f, lane, xa);
+        load_frame<4, 256>(arow, a.T, a.hop, hasB ? f + 1 : f, lane, xb);
+      }
+      const float* trow = a.target + ((size_t)b * a.F + f + (own ? fr : 0)) * NB;
+      float tk_[4], tq_[4], th_ = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { tk_[e] = trow[kl + 32 * e]; tq_[e] = trow[N2 - kl - 32 * e]; }
+      if (kl == 0) th_ = trow[HALF];
+      // ---- forward
+      cpx u[8];
+      {
+        cpx v[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 4; ++n1) {
+          v[n1] = cmk(xc[2 * n1], xc[2 * n1 + 1]) * t_win[64 * n1];
+          v[4 + n1] = cmk(xc[8 + 2 * n1], xc[8 + 2 * n1 + 1]) * t_win[64 * n1];
+        }
+        fft2(v, u);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sA[fr * HALF + kl + 32 * e] = u[4 + e];
+      wave_lds_sync();
+      // ---- per bin pair (k, N2 - k): X, value, cotangent, the pair's two inverse inputs
+      cpx zk_in[4], zn_in[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = kl + 32 * e;
+        cpx zn = sA[fr * HALF + ((HALF - k) & (HALF - 1))];
+        const cpx zk = u[e];
+        if (e == 0 && k == 0) zn = zk;
+        const cpx w = t_twu[64 * e];                              // W_N^k = e^{-2 pi i k / N}
+        const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        const cpx t = cmul(w, zo);
+        const cpx xk = cadd(ze, t);                               // X[k]
+        const cpx xq = cmk(ze.x - t.x, -(ze.y - t.y));            // X[N2 - k]
+        const float vk = bin_value(xk.x * xk.x + xk.y * xk.y), vq = bin_value(xq.x * xq.x + xq.y * xq.y);
+        const float gk = value_grad(vk, tk_[e]), gq = value_grad(vq, tq_[e]);
+        const cpx ck = xk * (2.0f * power_grad(gk, vk));          // G[k]
+        const cpx cq = xq * (2.0f * power_grad(gq, vq));          // G[N2 - k]
+        if (e == 0 && k == 0) {
+          zk_in[e] = cmk(ck.x + cq.x, ck.x - cq.x);              // edge bins (real X): a[0] + i b[0]
+          zn_in[e] = zk_in[e];
+        } else {
+          const cpx bk = cmul(ck, cmk(w.x, -w.y));                // b[k] = G[k] e^{+2 pi i k / N}
+          const cpx bn = cmul(cq, cmk(-w.x, -w.y));               // b[N2 - k] = G[N2 - k] (-W^k)
+          const cpx ak = cmk(0.5f * (ck.x + cq.x), 0.5f * (ck.y - cq.y));
+          const cpx sk = cmk(0.5f * (bk.x + bn.x), 0.5f * (bk.y - bn.y));
+          zk_in[e] = cmk(ak.x - sk.y, ak.y + sk.x);              // Zin[k]
+          zn_in[e] = cmk(ak.x + sk.y, -ak.y + sk.x);             // Zin[N2 - k]
+        }
+      }
+      // bin HALF pairs with itself: X[HALF] = conj(Z[HALF]) (the lanes with kl = 0 hold Z[HALF] = u[4])
+      cpx zh_in;
+      {
+        const cpx xh = cmk(u[4].x, -u[4].y);
+        const float vh = bin_value(xh.x * xh.x + xh.y * xh.y);
+        const float gh = value_grad(vh, th_);
+        const cpx ch = xh * (2.0f * power_grad(gh, vh));
+        zh_in = cmk(ch.x, -ch.y);
+      }
+      wave_lds_sync();                                            // every Z read is done
+      // ---- conj(Zin) of both frames in natural order (frame-major, padded), then the lane's points of it
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = kl + 32 * e;
+        sA[pad(fr * N2 + k)] = cmk(zk_in[e].x, -zk_in[e].y);
+        if (k != 0) sA[pad(fr * N2 + N2 - k)] = cmk(zn_in[e].x, -zn_in[e].y);
+      }
+      if (kl == 0) sA[pad(fr * N2 + HALF)] = cmk(zh_in.x, -zh_in.y);
+      wave_lds_sync();
+      cpx r[8];
+      {
+        cpx v[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 4; ++n1) { v[n1] = sA[pad(64 * n1 + lane)]; v[4 + n1] = sA[pad(N2 + 64 * n1 + lane)]; }
+        wave_lds_sync();
+        fft2(v, r);
+      }
+      wave_lds_sync();
+      // ---- z[m] = conj(out[m]) = y[2m] + i y[2m+1], m = kl + 32 e: window, into the ring -- frame A's lanes, then B's
+      // (the ring holds ONE frame length: frame A's first hop samples have to leave before frame B's last hop samples,
+      // which wrap onto them, arrive -- per frame: add, then flush the hop samples no later frame reaches)
+      const int rbA = ((f - f_lo) * a.hop) & (NFFT - 1);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (half == 1 && !hasB) break;                            // wave-uniform
+        const int rb = (rbA + half * a.hop) & (NFFT - 1);
+        if (fr == half) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int m = kl + 32 * e;
+            const cpx w2 = t_wo[64 * e];
+            cpx* rp = reinterpret_cast<cpx*>(ring + ((rb + 2 * m) & (NFFT - 1)));
+            const cpx cur = *rp;
+            *rp = cmk(cur.x + w2.x * r[e].x, cur.y - w2.y * r[e].y);
+          }
+        }
+        wave_lds_sync();
+        float* sp = span + (size_t)(f + half - f_lo) * a.hop;
+        for (int i = lane; i < a.hop; i += 64) {
+          const int idx = (rb + i) & (NFFT - 1);
+          sp[i] = ring[idx];
+          ring[idx] = 0.0f;
+        }
+        wave_lds_sync();
+      }
+    }
+    if (f_hi > f_lo) {                                            // the chunk's tail: what is left in the ring
+      const int nf = f_hi - f_lo, rb = (nf * a.hop) & (NFFT - 1);
+      float* sp = span + (size_t)nf * a.hop;
+      for (int i = lane; i < NFFT - a.hop; i += 64) {
+        const int idx = (rb + i) & (NFFT - 1);
+        sp[i] = ring[idx];
+        ring[idx] = 0.0f;
+      }
+      wave_lds_sync();
+    }
+  }
+}
+
 // frame_grad [B,F,n_fft] <- d loss / d (windowed frames) (see stft_grad_wave_kernel); tables: ias_stft_build_tables of
 // the plan's window; mel_*: the forward's CSR filterbank or NULL (linear bins, n_out = n_fft/2+1); target [B,F,n_out];
 // coef: device doubles [2] (loss_mode 2, linear bins only).
@@ -1590,6 +1793,20 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
       hipLaunchKernelGGL((stft_grad2k_kernel<W2, false>), dim3(grid2), dim3(64 * W2), lds2, stream, a, B * F,
                          (unsigned)(0x100000000ULL / (unsigned long long)F));
     }
+    return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+  }
+  static const int v1_512 = getenv("IAS_STFT_V1") ? atoi(getenv("IAS_STFT_V1")) : 0;
+  if (n_fft == 512 && span && !mel && !v1_512) {
+    constexpr int W5 = 8;
+    const size_t lds5 = sizeof(cpx) * (W5 * 64 * 9) + sizeof(float) * W5 * 512;
+    (void)hipFuncSetAttribute((const void*)stft_grad512_kernel<W5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stft_grad512_kernel<W5>, 64 * W5, lds5) != hipSuccess || nb < 1) nb = 1;
+    if (!make_plan((long long)ncu * nb * W5)) return IAS_ERR_UNSUPPORTED;
+    if (dry) return IAS_OK;
+    const long long need = ((long long)a.nchunks + W5 - 1) / W5;
+    const int grid5 = (int)(need < (long long)ncu * nb ? need : (long long)ncu * nb);
+    hipLaunchKernelGGL((stft_grad512_kernel<W5>), dim3(grid5), dim3(64 * W5), lds5, stream, a);
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   }
   const int R = n_fft / 128, scr = 8 * R * 9, np_it = (8 * R + 63) / 64, nunp = (n_fft / 4) / 64 + 1;
@@ -1769,7 +1986,7 @@ extern "C" int ias_stft_tables_len(int n_fft) {
   // n_fft 2048: + stft2_kernel<NSUB = 2>'s whole table section (window pairs of the two half-transforms, pass-1 / pass-2
   // twiddles of a 512-point transform, combining twiddles W_1024^k, unpack twiddles W_2048^k, and for the backward
   // (stft_grad2k_kernel) the window at the lane's output samples: 64 complex per lane)
-  return 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp + (n_fft == 1024 || n_fft == 512 ? 8 : 0) + (n_fft == 2048 ? 128 : 0));
+  return 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp + (n_fft == 1024 ? 8 : 0) + (n_fft == 512 ? 24 : 0) + (n_fft == 2048 ? 128 : 0));
 }
 
 extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float* out_host) {
@@ -1819,6 +2036,13 @@ extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float*
         const double ang = w0 * (double)(((l >> 3) & 3) + 4 * (l & 7) + 32 * e);
         o[64 * (2 * e) + l] = (float)cos(ang);
         o[64 * (2 * e + 1) + l] = (float)(-sin(ang));
+      }
+  if (n_fft == 512)                                        // stft_grad512_kernel: the window at samples 2 m, 2 m + 1, m = kl + 32 e
+    for (int e = 0; e < 8; ++e)
+      for (int l = 0; l < 64; ++l) {
+        const int m = ((l >> 3) & 3) + 4 * (l & 7) + 32 * e;
+        o[64 * (8 + 2 * e) + l] = window_host[2 * m];
+        o[64 * (8 + 2 * e + 1) + l] = window_host[2 * m + 1];
       }
   if (n_fft == 2048) {
     const double tau = 6.283185307179586;
