@@ -143,3 +143,23 @@ print("child ok")
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("B,T", [(3, 5200), (1, 700), (2, 5000)])
+def test_stft_l1_at_512_with_odd_and_even_frame_counts(lib, dev, B, T):
+    """n_fft 512 runs two frames per wave (stft2h_kernel): an odd total frame count leaves the last wave one real frame and
+    one repeat that must not be counted; loss and values against the oracle, and the backward (stft_grad512_kernel, which
+    pairs frames inside a chunk) against autograd through it."""
+    from inverse_audio_synthesis_amd.spectral import STFTL1, STFTPlan, VALUE_POWER
+    a, b = randn((B, T), 60 + B) * 0.2, randn((B, T), 70 + B) * 0.25
+    m = STFTL1(n_fft=512, hop_length=128, power=2.0).to(dev)
+    xa = a.to(dev).requires_grad_(True)
+    got = m(xa, b.to(dev))
+    ad = a.double().requires_grad_(True)
+    ref = spo.stft_l1(ad, b.double(), n_fft=512, hop_length=128, power=2.0)
+    assert abs(got.item() - ref.item()) <= LOSS_RTOL * abs(ref.item())
+    got.backward()
+    (g,) = torch.autograd.grad(ref, ad)
+    assert torch.linalg.norm(xa.grad.cpu().double() - g) <= 2e-3 * torch.linalg.norm(g)
+    out = STFTPlan(512, None, 128).to(dev).values(a.to(dev), VALUE_POWER).transpose(1, 2)
+    _close_to_scale(out.cpu(), spo.spectrogram(a, 512, None, 128, 2.0))
