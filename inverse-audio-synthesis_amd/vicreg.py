@@ -19,6 +19,17 @@ import torch.nn.functional as F
 from . import _lib
 
 
+_ZERO = {}
+
+
+def _zero_scalar(device):
+    """A cached fp32 zero [1] per device (never written)."""
+    z = _ZERO.get(device)
+    if z is None:
+        z = _ZERO[device] = torch.zeros(1, dtype=torch.float32, device=device)
+    return z
+
+
 class _VICRegLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, cfg_batch, sim_coeff, std_coeff, cov_coeff):
@@ -36,6 +47,9 @@ class _VICRegLossFn(torch.autograd.Function):
         _lib.check(st, "ias_vicreg_loss")
         ctx.save_for_backward(xc, yc, ws)     # the workspace keeps the column statistics / centred bf16 copies
         ctx.consts = (int(cfg_batch), float(sim_coeff), float(std_coeff), float(cov_coeff))
+        # unused outputs (repr / std / cov when only the loss is differentiated) arrive as None in backward instead of as
+        # three freshly filled zero tensors
+        ctx.set_materialize_grads(False)
         return out[0], out[1], out[2], out[3]
 
     @staticmethod
@@ -44,7 +58,11 @@ class _VICRegLossFn(torch.autograd.Function):
         cfg_batch, sim, std, cov = ctx.consts
         B, D = x.shape
         lib = _lib.load()
-        gcoef = torch.stack([g.to(torch.float32).reshape(()) for g in (g_loss, g_repr, g_std, g_cov)])
+        grads = (g_loss, g_repr, g_std, g_cov)
+        if all(g is None for g in grads):
+            return None, None, None, None, None, None
+        zero = _zero_scalar(x.device)
+        gcoef = torch.cat([zero if g is None else g.to(torch.float32).reshape(1) for g in grads])
         if D % 8 != 0:
             return _vicreg_backward_torch(x, y, gcoef, cfg_batch, sim, std, cov) + (None, None, None, None)
         gx, gy = torch.empty_like(x), torch.empty_like(y)

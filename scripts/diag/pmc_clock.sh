@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/pmc_clock
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/pmc_clock -o out --output-format csv -- \
-  python3 $R/bench.py --steps 3 --warmup 1 --no-graph --no-pipeline --no-cpu-baseline > $R/gpurun_out/pmc_clock/log.txt 2>&1
+  python3 $R/bench.py --steps 3 --warmup 1 --no-graph --no-pipeline --no-cpu-baseline --no-legs > $R/gpurun_out/pmc_clock/log.txt 2>&1
 python3 - <<PY
 import csv, glob, collections
 dur = {}

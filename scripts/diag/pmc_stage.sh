@@ -10,7 +10,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "SQ_INST_CYCLES_SMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY"; do
   name=$(echo $set | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/pmc_$tag/$name -o out --output-format csv -- \
-    python3 $R/bench.py --steps 3 --warmup 1 --no-graph --no-pipeline --no-cpu-baseline > $R/gpurun_out/pmc_$tag/$name.log 2>&1
+    python3 $R/bench.py --steps 3 --warmup 1 --no-graph --no-pipeline --no-cpu-baseline --no-legs > $R/gpurun_out/pmc_$tag/$name.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections

@@ -25,8 +25,9 @@ kst() { # name, bench args...
   step kstats $name
   rocprofv3 --kernel-trace --stats -d $O/prof_$name -o out --output-format csv -- python3 $R/bench.py "$@" > $O/prof_$name.log 2>&1
   f=$(find $O/prof_$name -name out_kernel_stats.csv | head -1); [ -n "$f" ] && cp $f $O/kstats_$name.csv
+  rm -rf $O/prof_$name          # the raw kernel trace is tens of MB; gpurun merges at most 64 MiB back
 }
-kst default --no-cpu-baseline
+kst default --no-cpu-baseline --no-legs
 kst nopipeline --no-pipeline --no-graph --no-cpu-baseline
 kst vicreg128 --workload vicreg --no-cpu-baseline --no-graph --steps 20 --warmup 3
 kst vicreg1024 --workload vicreg --batch 1024 --no-cpu-baseline --no-graph --steps 20 --warmup 3
@@ -55,6 +56,7 @@ for k in sorted(set(fe) | set(wr)):
               "hbm_bytes_per_launch": int((2 * fe.get(k, 0.0) + wr.get(k, 0.0)) * 1024)}
 json.dump(out, open(O + "/traffic.json", "w"), indent=1)
 PY
+rm -rf $O/pmc_fetch $O/pmc_write
 
 step pmc voice; bash $R/scripts/diag/pmc_voice.sh $tag > /dev/null 2>&1; cp $R/gpurun_out/pmcv_$tag/summary.txt $O/pmc_voice.txt
 step pmc pqmf; bash $R/scripts/diag/pmc_pqmf.sh $tag N=3 > /dev/null 2>&1; cp $R/gpurun_out/pmcq_$tag/summary.txt $O/pmc_pqmf.txt
@@ -65,5 +67,8 @@ step pmc stft; bash $R/scripts/diag/pmc_stft.sh $tag PARTS=loss > /dev/null 2>&1
 step trace; bash $R/scripts/diag/trace_bench.sh $tag > $O/trace_default.txt 2>&1
 step microbench; $R/scripts/diag/_bin/mfma_valu_overlap > $O/mfma_valu_overlap.txt 2>&1; $R/scripts/diag/_bin/mfma_valu_inwave > $O/mfma_valu_inwave.txt 2>&1
 step parity; IAS_PARITY_OUT=$O python3 -m pytest $R/tests/test_voice_gpu.py -q -k headline_size > $O/parity_test.log 2>&1
+# raw counter / trace directories of the helper scripts: the summaries above are what is kept
+rm -rf $R/gpurun_out/pmcv_$tag $R/gpurun_out/pmcq_$tag $R/gpurun_out/pmcg_$tag $R/gpurun_out/pmcg_${tag}_1024 $R/gpurun_out/pmcs_$tag \
+       $R/gpurun_out/kstats_pt_$tag/prof $R/gpurun_out/trace_$tag
 step done
 head -c 600 $O/bench_default.json; echo
