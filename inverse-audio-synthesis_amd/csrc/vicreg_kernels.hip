@@ -26,7 +26,8 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float vc_f32x4;
 
-#define VC_COLS 64        // columns per colstats workgroup
+#define VC_COLS 32        // columns per colstats workgroup: D / 32 = 256 workgroups at D = 8192, one per CU (64 columns
+                          // per workgroup left half the chip idle: 60 us at B = 1024 against an HBM time of ~30)
 #define VC_THREADS 1024  // 16 waves per workgroup: the column pass is latency-bound with few workgroups
 #define GT 128            // gram output tile (GT x GT)
 #define GK 64             // k-chunk staged per iteration
@@ -38,22 +39,25 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 
 // x, y: [B, D] fp32.  Xt_*: [D][Kpad] bf16 (zero padded in k).  colstats: [4][D] = mean_x, mean_y, m2_x, m2_y
 // msepart: [gridDim.x] fp64.
+// A wave covers the workgroup's 32 columns (128-byte row segments) of TWO rows at a time: lane = (row half, column).
 __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
     const float* __restrict__ x, const float* __restrict__ y, unsigned short* __restrict__ Xt_x,
     unsigned short* __restrict__ Xt_y, float* __restrict__ colstats, double* __restrict__ msepart,
     double* __restrict__ hingepart, unsigned short* __restrict__ Xc_x, unsigned short* __restrict__ Xc_y, int B, int D,
     int Kpad) {
-  __shared__ float s_red[4][VC_THREADS / 64][VC_COLS];
+  constexpr int NW = VC_THREADS / 64, RPI = 2 * NW;              // rows per iteration of the workgroup
+  __shared__ float s_red[4][NW][64];
   __shared__ float s_mean[2][VC_COLS];
   __shared__ unsigned short s_tile[2][VC_COLS][64 + 2];
-  __shared__ double s_mse[VC_THREADS / 64];
+  __shared__ double s_mse[NW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j0 = blockIdx.x * VC_COLS, j = j0 + lane;
+  const int col = lane & (VC_COLS - 1), rsub = lane >> 5;
+  const int j0 = blockIdx.x * VC_COLS, j = j0 + col;
   const bool jok = j < D;
 
-  // pass 1: column sums (wave w takes rows w, w+4, ...), sum (x-y)^2
+  // pass 1: column sums (wave w takes rows 2 w + rsub, + 32, ...), sum (x-y)^2
   float sx = 0.f, sy = 0.f, se = 0.f;
-  for (int b = wave; b < B; b += VC_THREADS / 64) {
+  for (int b = 2 * wave + rsub; b < B; b += RPI) {
     if (jok) {
       const float xv = x[(size_t)b * D + j], yv = y[(size_t)b * D + j];
       sx += xv; sy += yv;
@@ -66,24 +70,27 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
   for (int d = 32; d > 0; d >>= 1) se += __shfl_xor(se, d, 64);
   if (lane == 0) s_mse[wave] = (double)se;
   __syncthreads();
-  if (wave == 0) {
+  if (wave == 0 && lane < VC_COLS) {
     float mx = 0.f, my = 0.f;
-    for (int w = 0; w < VC_THREADS / 64; ++w) { mx += s_red[0][w][lane]; my += s_red[1][w][lane]; }
+    for (int w = 0; w < NW; ++w) {                               // fixed order: waves, row halves
+      mx += s_red[0][w][lane]; mx += s_red[0][w][lane + 32];
+      my += s_red[1][w][lane]; my += s_red[1][w][lane + 32];
+    }
     s_mean[0][lane] = mx / (float)B;
     s_mean[1][lane] = my / (float)B;
     if (lane == 0) {
       double m = 0.0;
-      for (int w = 0; w < VC_THREADS / 64; ++w) m += s_mse[w];
+      for (int w = 0; w < NW; ++w) m += s_mse[w];
       msepart[blockIdx.x] = m;
     }
   }
   __syncthreads();
-  const float mx = s_mean[0][lane], my = s_mean[1][lane];
+  const float mx = s_mean[0][col], my = s_mean[1][col];
 
   // pass 2: centred sum of squares + bf16 transpose, 64 rows at a time
   float qx = 0.f, qy = 0.f;
   for (int b0 = 0; b0 < Kpad; b0 += 64) {
-    for (int r = wave; r < 64; r += VC_THREADS / 64) {
+    for (int r = 2 * wave + rsub; r < 64; r += RPI) {
       const int b = b0 + r;
       float cx = 0.f, cy = 0.f;
       if (jok && b < B) {
@@ -93,13 +100,13 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
         qy = fmaf(cy, cy, qy);
       }
       const unsigned short bx = f2bf(cx), by = f2bf(cy);
-      s_tile[0][lane][r] = bx;
-      s_tile[1][lane][r] = by;
+      s_tile[0][col][r] = bx;
+      s_tile[1][col][r] = by;
       // the same values batch-major, Xc[Kpad][D] (zero rows beyond B): the backward's B x B Gram contracts over D
       if (jok) { Xc_x[(size_t)b * D + j] = bx; Xc_y[(size_t)b * D + j] = by; }
     }
     __syncthreads();
-    // write out: 64 columns x 64 k as 128-byte rows; thread -> (column c = tid/4, 16 k values)
+    // write out: 32 columns x 64 k as 128-byte rows; thread -> (column c = tid/4, 16 k values)
     {
       const int c = tid >> 2, part = tid & 3;
       if (tid < 4 * VC_COLS && j0 + c < D) {
@@ -120,20 +127,22 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
   }
   s_red[2][wave][lane] = qx; s_red[3][wave][lane] = qy;
   __syncthreads();
-  if (wave == 0 && jok) {
-    float ax = 0.f, ay = 0.f;
-    for (int w = 0; w < VC_THREADS / 64; ++w) { ax += s_red[2][w][lane]; ay += s_red[3][w][lane]; }
-    colstats[0 * (size_t)D + j] = mx;
-    colstats[1 * (size_t)D + j] = my;
-    colstats[2 * (size_t)D + j] = ax;
-    colstats[3 * (size_t)D + j] = ay;
+  const bool fin = wave == 0 && lane < VC_COLS && j0 + lane < D;
+  float ax = 0.f, ay = 0.f;
+  if (fin) {
+    for (int w = 0; w < NW; ++w) {
+      ax += s_red[2][w][lane]; ax += s_red[2][w][lane + 32];
+      ay += s_red[3][w][lane]; ay += s_red[3][w][lane + 32];
+    }
+    colstats[0 * (size_t)D + j0 + lane] = s_mean[0][lane];
+    colstats[1 * (size_t)D + j0 + lane] = s_mean[1][lane];
+    colstats[2 * (size_t)D + j0 + lane] = ax;
+    colstats[3 * (size_t)D + j0 + lane] = ay;
   }
-  // variance hinge of this workgroup's columns: sum_j relu(1 - sqrt(var_j + 1e-4)) for x and y
+  // variance hinge partial of this column block
   if (wave == 0) {
     float h = 0.f;
-    if (jok) {
-      float ax = 0.f, ay = 0.f;
-      for (int w = 0; w < VC_THREADS / 64; ++w) { ax += s_red[2][w][lane]; ay += s_red[3][w][lane]; }
+    if (fin) {
       const float inv_bm1 = 1.0f / (float)(B - 1);
       h = fmaxf(1.0f - sqrtf(ax * inv_bm1 + 0.0001f), 0.f) + fmaxf(1.0f - sqrtf(ay * inv_bm1 + 0.0001f), 0.f);
     }
