@@ -1012,14 +1012,21 @@ __global__ __launch_bounds__(256) void vicreg_gconv_kernel(const float* __restri
     const size_t q = i / ((size_t)Kpad * Kpad), rem = i - q * (size_t)Kpad * Kpad;
     const int row = (int)(rem / Kpad), col = (int)(rem - (size_t)row * Kpad);
     float v = 0.0f;
-    for (int sl = 0; sl < nsplit; ++sl) v += Gp[(size_t)sl * n + i];
+    for (int s0 = 0; s0 < nsplit; s0 += 8) {                     // eight slices in flight, added in slice order
+      float a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = s0 + u < nsplit ? Gp[(size_t)(s0 + u) * n + i] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += a[u];
+    }
     if (row == col) gdiag[q * Kpad + row] = v;
     Gb[i] = f2bf(row == col ? 0.0f : v);
   }
 }
 
-// One 128 (batch rows) x 128 (features) tile of gx and gy per workgroup: the two products (G - diag) vc of the branches
-// one after the other through the same double-buffered LDS panels, then the elementwise terms.
+// One 128 (batch rows) x 128 (features) tile of gx (branch 0) or gy (branch 1) per workgroup: the product (G - diag) vc
+// through the double-buffered LDS panels, then the elementwise terms.  (Both branches in one workgroup, round 2, were 64
+// workgroups at B = 128, D = 8192: a quarter of the chip.)
 __global__ __launch_bounds__(256, 2) void vicreg_grad_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const unsigned short* __restrict__ Xt_x,
     const unsigned short* __restrict__ Xt_y, const unsigned short* __restrict__ Gb, const float* __restrict__ gdiag,
@@ -1031,36 +1038,34 @@ __global__ __launch_bounds__(256, 2) void vicreg_grad_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int r = lane & 31, h = lane >> 5;
-  const int col0 = blockIdx.x * GT, row0 = blockIdx.y * GT;
+  const int col0 = blockIdx.x * GT, row0 = blockIdx.y * GT, branch = blockIdx.z;   // one branch per workgroup (grid.z = 2)
   const float gl = gcoef[0];
   const float ca = gl * sim_coeff + gcoef[1], cb = gl * std_coeff + gcoef[2], cc = gl * cov_coeff + gcoef[3];
   const float kappa = 4.0f / ((float)(cfg_batch - 1) * (float)(cfg_batch - 1) * (float)D);
 
-  f32x16 acc[2][2][2];   // [branch][m][n]
+  f32x16 acc[2][2];   // [m][n]
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[q][m][n][e] = 0.f;
-  vc_tile_product(Gb, (size_t)Kpad, Kpad, Xt_x, (size_t)Kpad, D, row0, col0, 0, Kpad, s_a, s_b, acc[0]);
-  vc_tile_product(Gb + (size_t)Kpad * Kpad, (size_t)Kpad, Kpad, Xt_y, (size_t)Kpad, D, row0, col0, 0, Kpad, s_a, s_b, acc[1]);
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+  vc_tile_product(Gb + (size_t)branch * Kpad * Kpad, (size_t)Kpad, Kpad, branch ? Xt_y : Xt_x, (size_t)Kpad, D, row0, col0, 0,
+                  Kpad, s_a, s_b, acc);
 
   // epilogue: elementwise terms.  C layout of a 32 x 32 block: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
   const float inv_bm1 = 1.0f / (float)(B - 1);
-  const float repr_k = ca * 2.0f / ((float)B * (float)D);
+  const float repr_k = (branch ? -ca : ca) * 2.0f / ((float)B * (float)D);
+  float* gout = branch ? gy : gx;
+  const float* own = branch ? y : x;
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int j = col0 + wc * 64 + n * 32 + r;
     if (j >= D) continue;
-    const float mx = colstats[j], my = colstats[(size_t)D + j];
-    const float m2x = colstats[2 * (size_t)D + j], m2y = colstats[3 * (size_t)D + j];
-    const float sx = sqrtf(m2x * inv_bm1 + 0.0001f), sy = sqrtf(m2y * inv_bm1 + 0.0001f);
+    const float mu = colstats[(size_t)branch * D + j], m2 = colstats[(size_t)(2 + branch) * D + j];
+    const float sd = sqrtf(m2 * inv_bm1 + 0.0001f);
     // coefficient of vc: variance hinge (active where s < 1) and the diagonal part of the covariance term
-    const float ax = (sx < 1.0f ? -cb / (2.0f * (float)D * (float)(B - 1) * sx) : 0.0f) - cc * kappa * m2x;
-    const float ay = (sy < 1.0f ? -cb / (2.0f * (float)D * (float)(B - 1) * sy) : 0.0f) - cc * kappa * m2y;
+    const float av = (sd < 1.0f ? -cb / (2.0f * (float)D * (float)(B - 1) * sd) : 0.0f) - cc * kappa * m2;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1069,11 +1074,8 @@ __global__ __launch_bounds__(256, 2) void vicreg_grad_kernel(
         if (b >= B) continue;
         const size_t idx = (size_t)b * D + j;
         const float xv = x[idx], yv = y[idx];
-        const float dr = repr_k * (xv - yv);
-        const float gbx = gdiag[b], gby = gdiag[Kpad + b];   // G_bb, fp32
-        const float vx = xv - mx, vy = yv - my;
-        gx[idx] = dr + ax * vx + cc * kappa * (acc[0][m][n][e] + gbx * vx);
-        gy[idx] = -dr + ay * vy + cc * kappa * (acc[1][m][n][e] + gby * vy);
+        const float v = own[idx] - mu;
+        gout[idx] = repr_k * (xv - yv) + av * v + cc * kappa * (acc[m][n][e] + gdiag[(size_t)branch * Kpad + b] * v);
       }
   }
 }
@@ -1284,7 +1286,7 @@ extern "C" int ias_vicreg_backward(const float* x, const float* y, const float* 
                        (const unsigned short*)(ws + w.xt_x), (const unsigned short*)(ws + w.xt_y), Gb, gdiag,
                        (const float*)(ws + w.colstats), gcoef, gx, gy, B, D, w.Kpad, cfg_batch, sim_coeff, std_coeff, cov_coeff);
   } else {
-    hipLaunchKernelGGL(vicreg_grad_kernel, dim3((D + GT - 1) / GT, bt), dim3(256), 0, stream, x, y,
+    hipLaunchKernelGGL(vicreg_grad_kernel, dim3((D + GT - 1) / GT, bt, 2), dim3(256), 0, stream, x, y,
                        (const unsigned short*)(ws + w.xt_x), (const unsigned short*)(ws + w.xt_y), Gb, gdiag,
                        (const float*)(ws + w.colstats), gcoef, gx, gy, B, D, w.Kpad, cfg_batch, sim_coeff, std_coeff, cov_coeff);
   }
