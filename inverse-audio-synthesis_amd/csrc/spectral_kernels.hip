@@ -1880,17 +1880,18 @@ extern "C" int ias_stft_grad_spans(const float* audio, const float* tables, cons
 
 // sums[0..2] = sum over n partial triples (fixed order: deterministic); optionally
 // mean_out[0] = (float)(sums[0] * scale)  (the L1 mean, without further elementwise launches)
-__global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __restrict__ partials, long long n,
-                                                               double* __restrict__ sums, double scale,
-                                                               float* __restrict__ mean_out) {
-  __shared__ double s[1024][3];
+#define RP_THREADS 256    // 4 waves: finds a free CU slot beside the FFT kernels (the 16-wave form waited 20 us for one)
+__global__ __launch_bounds__(RP_THREADS) void reduce_partials_kernel(const double* __restrict__ partials, long long n,
+                                                                     double* __restrict__ sums, double scale,
+                                                                     float* __restrict__ mean_out) {
+  __shared__ double s[RP_THREADS][3];
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  for (long long i = threadIdx.x; i < n; i += 1024) {
+  for (long long i = threadIdx.x; i < n; i += RP_THREADS) {
     a0 += partials[i * 3]; a1 += partials[i * 3 + 1]; a2 += partials[i * 3 + 2];
   }
   s[threadIdx.x][0] = a0; s[threadIdx.x][1] = a1; s[threadIdx.x][2] = a2;
   __syncthreads();
-  for (int d = 512; d > 0; d >>= 1) {
+  for (int d = RP_THREADS / 2; d > 0; d >>= 1) {
     if (threadIdx.x < d)
       for (int k = 0; k < 3; ++k) s[threadIdx.x][k] += s[threadIdx.x + d][k];
     __syncthreads();
@@ -2176,7 +2177,7 @@ extern "C" int ias_stft(const float* audio, const float* tables, const float* mt
 extern "C" int ias_reduce_partials(const double* partials, long long n, double* sums, double scale, float* mean_out,
                                    void* stream_) {
   if (!partials || !sums || n <= 0) return IAS_ERR_ARG;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream_, partials, n, sums, scale,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(RP_THREADS), 0, (hipStream_t)stream_, partials, n, sums, scale,
                      mean_out);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
