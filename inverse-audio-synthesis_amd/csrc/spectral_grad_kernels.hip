@@ -292,6 +292,7 @@ __global__ __launch_bounds__(SG_THREADS) void stft_grad_combine_kernel(const flo
 struct CombineArgs {
   const float* spans[IAS_COMBINE_MAX];
   int N[IAS_COMBINE_MAX], hop[IAS_COMBINE_MAX], G[IAS_COMBINE_MAX], cper[IAS_COMBINE_MAX], L[IAS_COMBINE_MAX], F[IAS_COMBINE_MAX];
+  unsigned magic[IAS_COMBINE_MAX];      // floor(2^32 / (G hop)): q / (G hop) without an integer division (3 x nres per sample)
   int nres;
 };
 __global__ __launch_bounds__(SG_THREADS) void stft_grad_combine_multi_kernel(const CombineArgs a,
@@ -312,7 +313,8 @@ __global__ __launch_bounds__(SG_THREADS) void stft_grad_combine_multi_kernel(con
     float acc = 0.0f;
     for (int i = 0; i < nq; ++i) {
       const int q = qs[i];
-      int c = q / gh;
+      int c = (int)__umulhi((unsigned)q, a.magic[r]);         // floor(q / gh) or one less
+      if (q - c * gh >= gh) ++c;
       if (c > cper - 1) c = cper - 1;
       float v = 0.0f;
       if (c >= 1 && q - (c - 1) * gh < L) v = sp[(size_t)(c - 1) * L + (q - (c - 1) * gh)];
@@ -332,13 +334,15 @@ extern "C" int ias_stft_grad_combine(const float* const* spans_host, const int* 
   if (!spans_host || !plans_host || !g_audio || nres < 1 || nres > IAS_COMBINE_MAX || B <= 0 || B > 65535 || T <= 0)
     return IAS_ERR_ARG;
   CombineArgs a;
-  for (int r = 0; r < IAS_COMBINE_MAX; ++r) { a.spans[r] = nullptr; a.N[r] = a.hop[r] = a.G[r] = a.cper[r] = a.L[r] = a.F[r] = 1; }
+  for (int r = 0; r < IAS_COMBINE_MAX; ++r) { a.spans[r] = nullptr; a.N[r] = a.hop[r] = a.G[r] = a.cper[r] = a.L[r] = a.F[r] = 1; a.magic[r] = 0; }
   for (int r = 0; r < nres; ++r) {
     const int* p = plans_host + 5 * r;
     if (!spans_host[r] || p[0] <= 0 || p[1] <= 0 || p[2] <= 0 || p[3] <= 0 || p[4] != (p[2] - 1) * p[1] + p[0]) return IAS_ERR_ARG;
     if (T <= p[0] / 2) return IAS_ERR_ARG;
     a.spans[r] = spans_host[r]; a.N[r] = p[0]; a.hop[r] = p[1]; a.G[r] = p[2]; a.cper[r] = p[3]; a.L[r] = p[4];
     a.F[r] = 1 + T / p[1];
+    if ((long long)p[2] * p[1] > 0x7fffffffLL || (long long)T + p[0] > 0x7fffffffLL) return IAS_ERR_ARG;
+    a.magic[r] = (unsigned)(0x100000000ULL / (unsigned long long)((long long)p[2] * p[1]));
     if (p[3] != (a.F[r] + p[2] - 1) / p[2]) return IAS_ERR_ARG;
   }
   a.nres = nres;
