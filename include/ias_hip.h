@@ -117,6 +117,12 @@ int ias_voice_backward_norm(const float* ctrl, const void* vconst, const float* 
  * test reference).  IAS_ERR_UNSUPPORTED when Tc does not fit LDS (> ~3000 points) or control_rate != 441. */
 int ias_voice_control_backward(const float* params01, const float* g_ctrl, const double* g_scal, float* g_params01,
                                int B, int Tc, int control_rate, void* stream);
+/* The same in three launches (round 3): the six-envelope phase -- 60 % of the fp64 pow / log work -- on 6 x B workgroups
+ * instead of B.  workspace: ias_voice_control_backward_ws_bytes(B, Tc) bytes of device memory, 16-byte aligned. */
+long long ias_voice_control_backward_ws_bytes(int B, int Tc);
+int ias_voice_control_backward_ws(const float* params01, const float* g_ctrl, const double* g_scal, float* g_params01,
+                                  void* workspace, long long workspace_bytes, int B, int Tc, int control_rate,
+                                  void* stream);
 
 /* Transposed, zero-padded tap table: ias_pqmf_packed_taps_len(N, K) floats -- the fast kernel's layout for N = 3, 4
  * with K = 63, the wide kernel's [K][8|16|32|64] layout for other N <= 64 with K <= 255, 0 otherwise (generic

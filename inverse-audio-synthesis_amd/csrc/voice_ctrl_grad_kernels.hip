@@ -13,6 +13,12 @@
 // a contiguous run of control points, so the two cumulative sums (LFO phase forward, its gradient backward) are a
 // local loop plus one workgroup scan.  Values needed twice are recomputed rather than stored (an ADSR value is three
 // pow() calls); LDS holds the LFO phases, their gradients and the six envelope gradients.
+//
+// Round 3 (ias_voice_control_backward_ws): one workgroup per voice is 64 workgroups at configs[4]'s share of a GPU, and
+// two thirds of the kernel's time are fp64 pow() / log() of the six envelopes, which are independent of each other.  The
+// split form runs the envelope VALUES (voice_env_value_kernel) and the envelope BACKWARD (voice_env_grad_kernel) on
+// 6 x B workgroups each, around the per-voice kernel that keeps the scans and the modulation matrix, and a small finish:
+// 245 -> 115 us at B = 64, bit-identical output.
 #include "ias_common.h"
 #include "voice_table.h"
 
@@ -128,9 +134,37 @@ __device__ __forceinline__ void cg_lfo_shapes(double arg, double* sh, double* ds
   sh[4] = ((c > 0.0 ? 1.0 : (c < 0.0 ? -1.0 : 0.0)) + 1.0) * 0.5;   dsh[4] = 0.0;
 }
 
+// value of parameter idx at its normalised setting u, and d value / d u (ModuleParameterRange.from_0to1)
+__device__ __forceinline__ void cg_param_value(int idx, double u, double* v_out, double* dv_out) {
+  const IasParamRange r = c_cg_table[idx];
+  const double ic = 1.0 / r.curve;
+  double v, dv;
+  if (!r.symmetric) {
+    const double uc = u >= 1e-300 ? u : 1e-300;
+    v = r.lo + r.span * pow(uc, ic);
+    dv = u >= 1e-300 ? r.span * ic * pow(uc, ic - 1.0) : 0.0;
+  } else {
+    const double dist = 2.0 * u - 1.0, ad = fabs(dist);
+    const double ac = ad >= 1e-300 ? ad : 1e-300;
+    const double sg = dist > 0.0 ? 1.0 : (dist < 0.0 ? -1.0 : 0.0);
+    v = r.lo + r.span * (sg * pow(ac, ic) + 1.0);
+    dv = ad >= 1e-300 ? r.span * ic * pow(ac, ic - 1.0) * 2.0 : 0.0;   // sign(d)^2 = 1
+  }
+  *v_out = v; *dv_out = dv;
+}
+
+// SPLIT (round 3): the six-envelope phase -- 60 % of the kernel's fp64 pow / log work, and independent per envelope once
+// the envelope cotangents exist -- leaves this kernel: it writes the cotangents (genv [B][6][Tc] fp32), the parameter
+// values and d value / d params01 ([B][2][78] fp64) and everything it knows of the gradient; voice_env_grad_kernel (one
+// workgroup per (envelope, voice): 6 x the workgroups) and voice_ctrl_finish_kernel complete it.  One workgroup per voice
+// is 64 workgroups of 8 waves at configs[4]'s share: a quarter of the CUs at 2 waves per SIMD.
+template <bool SPLIT>
 __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
     const float* __restrict__ params01, const float* __restrict__ g_ctrl, const double* __restrict__ g_scal,
-    float* __restrict__ g_params01, int Tc, int ppt /* points per thread */, double cr) {
+    float* __restrict__ g_params01, int Tc, int ppt /* points per thread */, double cr,
+    float* __restrict__ ws_genv /* SPLIT: [B][6][Tc] */, double* __restrict__ ws_vdv /* SPLIT: [B][2][78] */,
+    double* __restrict__ ws_part /* SPLIT: [B][40]: [36] = this kernel's own share of d loss / d note_on */,
+    const double* __restrict__ ws_env /* SPLIT: [B][6][Tc] envelope values */) {
   extern __shared__ __attribute__((aligned(16))) double cg_smem[];
   double* s_arg = cg_smem;                 // [2][Tc] LFO phases
   double* s_garg = s_arg + 2 * Tc;         // [2][Tc] d loss / d phase
@@ -144,21 +178,8 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
 
   // ---- parameter values and d value / d params01 (ModuleParameterRange.from_0to1)
   if (tid < 78) {
-    const IasParamRange r = c_cg_table[tid];
-    const double u = (double)params01[(size_t)b * 78 + tid];
-    const double ic = 1.0 / r.curve;
     double v, dv;
-    if (!r.symmetric) {
-      const double uc = u >= 1e-300 ? u : 1e-300;
-      v = r.lo + r.span * pow(uc, ic);
-      dv = u >= 1e-300 ? r.span * ic * pow(uc, ic - 1.0) : 0.0;
-    } else {
-      const double dist = 2.0 * u - 1.0, ad = fabs(dist);
-      const double ac = ad >= 1e-300 ? ad : 1e-300;
-      const double sg = dist > 0.0 ? 1.0 : (dist < 0.0 ? -1.0 : 0.0);
-      v = r.lo + r.span * (sg * pow(ac, ic) + 1.0);
-      dv = ad >= 1e-300 ? r.span * ic * pow(ac, ic - 1.0) * 2.0 : 0.0;   // sign(d)^2 = 1
-    }
+    cg_param_value(tid, (double)params01[(size_t)b * 78 + tid], &v, &dv);
     s_v[tid] = v; s_dv[tid] = dv; s_gv[tid] = 0.0;
   }
   __syncthreads();
@@ -175,14 +196,17 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
   }
   CgHeads heads[6];
 #pragma unroll
-  for (int e = 0; e < 6; ++e) heads[e] = cg_heads(env[e], note_on, cr);
+  for (int e = 0; e < 6; ++e) { heads[e].d = 0.0; heads[e].r = 0.0; if (!SPLIT) heads[e] = cg_heads(env[e], note_on, cr); }
+  auto adsr_val = [&](int e, int i) {
+    return SPLIT ? ws_env[((size_t)b * 6 + e) * Tc + i] : cg_adsr(i, env[e], note_on, cr, heads[e]);
+  };
 
   // ---- LFO phases: arg[i] = cumsum(2 pi max(f + depth * rate_env, 0) / cr) + phi
   for (int m = 0; m < 2; ++m) {
     const double f = s_v[lfo_base[m]], dep = s_v[lfo_base[m] + 1], phi = s_v[lfo_base[m] + 2];
     double run = 0.0;
     for (int i = i_lo; i < i_hi; ++i) {
-      const double fr = fmax(f + dep * cg_adsr(i, env[4 + m], note_on, cr, heads[4 + m]), 0.0);
+      const double fr = fmax(f + dep * adsr_val(4 + m, i), 0.0);
       run += two_pi * fr / cr;
       s_arg[m * Tc + i] = run;
     }
@@ -207,13 +231,13 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
   for (int m = 0; m < 2; ++m) for (int s = 0; s < 5; ++s) gmode[m][s] = 0.0;
   for (int i = i_lo; i < i_hi; ++i) {
     double src[4], mix[2], sh[2][5], dsh[2][5], amp[2];
-    src[0] = cg_adsr(i, env[0], note_on, cr, heads[0]);
-    src[1] = cg_adsr(i, env[1], note_on, cr, heads[1]);
+    src[0] = adsr_val(0, i);
+    src[1] = adsr_val(1, i);
     for (int m = 0; m < 2; ++m) {
       cg_lfo_shapes(s_arg[m * Tc + i], sh[m], dsh[m]);
       mix[m] = 0.0;
       for (int s = 0; s < 5; ++s) mix[m] += mode[m][s] * sh[m][s];
-      amp[m] = cg_adsr(i, env[2 + m], note_on, cr, heads[2 + m]);
+      amp[m] = adsr_val(2 + m, i);
       src[2 + m] = mix[m] * amp[m];
     }
     double go[5], gsrc[4];
@@ -256,7 +280,7 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
     double gphi = (i_hi > i_lo) ? run : 0.0, gf = 0.0, gdep = 0.0;   // sum of g_arg over the thread's points
     for (int i = i_lo; i < i_hi; ++i) {
       const double ginc = s_garg[m * Tc + i] + after;       // sum_{i' >= i} g_arg[i']
-      const double renv = cg_adsr(i, env[4 + m], note_on, cr, heads[4 + m]);
+      const double renv = adsr_val(4 + m, i);
       const double gfr = (f + dep * renv >= 0.0) ? ginc * two_pi / cr : 0.0;   // clamp_min passes at >= 0
       gf += gfr; gdep += gfr * renv;
       s_genv[(4 + m) * Tc + i] = (float)(gfr * dep);
@@ -270,7 +294,13 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
 
   // ---- the six envelopes: env = A * D * R
   double g_note_on = 0.0;
-  for (int e = 0; e < 6; ++e) {
+  if (SPLIT) {
+    float* ge = ws_genv + (size_t)b * 6 * Tc;
+    for (int e = 0; e < 6; ++e)
+      for (int i = i_lo; i < i_hi; ++i) ge[(size_t)e * Tc + i] = s_genv[e * Tc + i];
+    if (tid < 78) { ws_vdv[((size_t)b * 2) * 78 + tid] = s_v[tid]; ws_vdv[((size_t)b * 2 + 1) * 78 + tid] = s_dv[tid]; }
+  }
+  for (int e = 0; e < (SPLIT ? 0 : 6); ++e) {
     const CgAdsr p = env[e];
     const double na = fmin(p.attack, note_on);
     const double nd0 = fmax(note_on - p.attack, 0.0);
@@ -316,6 +346,7 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
   if (tid == 0) {
     const double* gs = g_scal + (size_t)b * CG_NSCAL;
     s_gv[IAS_P_KEYBOARD_DURATION] += g_note_on;
+    if (SPLIT) ws_part[(size_t)b * 40 + 36] = s_gv[IAS_P_KEYBOARD_DURATION];
     const double midi = s_v[IAS_P_KEYBOARD_MIDI_F0], dep2 = s_v[IAS_P_VCO_2_MOD_DEPTH];
     const double F = 440.0 * exp2((midi + fmax(dep2, 0.0) - 69.0) / 12.0);
     const double lg = log10(F);
@@ -338,6 +369,114 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
   if (tid < 78) g_params01[(size_t)b * 78 + tid] = (float)(s_gv[tid] * s_dv[tid]);
 }
 
+// Envelope values of the split form: ws_env[b][e][i] = ADSR envelope e of voice b at control point i (fp64), one
+// workgroup per (envelope, voice).
+#define EG_THREADS 512
+__global__ __launch_bounds__(EG_THREADS) void voice_env_value_kernel(const float* __restrict__ params01,
+                                                                     double* __restrict__ ws_env, int Tc, int ppt, double cr) {
+  __shared__ double s_p[6];
+  const int tid = threadIdx.x, e = blockIdx.x, b = blockIdx.y;
+  const int adsr_base[6] = {IAS_P_ADSR_1_ATTACK, IAS_P_ADSR_2_ATTACK, IAS_P_LFO_1_AMP_ADSR_ATTACK,
+                            IAS_P_LFO_2_AMP_ADSR_ATTACK, IAS_P_LFO_1_RATE_ADSR_ATTACK, IAS_P_LFO_2_RATE_ADSR_ATTACK};
+  if (tid < 6) {
+    const int idx = tid < 5 ? adsr_base[e] + tid : IAS_P_KEYBOARD_DURATION;
+    double v, dv;
+    cg_param_value(idx, (double)params01[(size_t)b * 78 + idx], &v, &dv);
+    s_p[tid] = v;
+  }
+  __syncthreads();
+  CgAdsr p;
+  p.attack = s_p[0]; p.decay = s_p[1]; p.sustain = s_p[2]; p.release = s_p[3]; p.alpha = s_p[4];
+  const double note_on = s_p[5];
+  const CgHeads heads = cg_heads(p, note_on, cr);
+  const int i_lo = min(tid * ppt, Tc), i_hi = min(i_lo + ppt, Tc);
+  double* out = ws_env + ((size_t)b * 6 + e) * Tc;
+  for (int i = i_lo; i < i_hi; ++i) out[i] = cg_adsr(i, p, note_on, cr, heads);
+}
+
+// The six-envelope phase of the split form: one workgroup per (envelope, voice).  ws_part [B][6][6] fp64 receives the
+// envelope's d loss / d (attack, decay, sustain, release, alpha) and its share of d loss / d note_on.
+__global__ __launch_bounds__(EG_THREADS) void voice_env_grad_kernel(const float* __restrict__ ws_genv,
+                                                                    const double* __restrict__ ws_vdv,
+                                                                    double* __restrict__ ws_part, int Tc, int ppt, double cr) {
+  __shared__ double s_red[6][EG_THREADS / 64];
+  const int tid = threadIdx.x, e = blockIdx.x, b = blockIdx.y;
+  const int adsr_base[6] = {IAS_P_ADSR_1_ATTACK, IAS_P_ADSR_2_ATTACK, IAS_P_LFO_1_AMP_ADSR_ATTACK,
+                            IAS_P_LFO_2_AMP_ADSR_ATTACK, IAS_P_LFO_1_RATE_ADSR_ATTACK, IAS_P_LFO_2_RATE_ADSR_ATTACK};
+  const double* v = ws_vdv + (size_t)b * 2 * 78;
+  const int o = adsr_base[e];
+  CgAdsr p;
+  p.attack = v[o]; p.decay = v[o + 1]; p.sustain = v[o + 2]; p.release = v[o + 3]; p.alpha = v[o + 4];
+  const double note_on = v[IAS_P_KEYBOARD_DURATION];
+  const CgHeads heads = cg_heads(p, note_on, cr);
+  const double na = fmin(p.attack, note_on);
+  const double nd0 = fmax(note_on - p.attack, 0.0);
+  const double nd = fmin(nd0, p.decay);
+  const int i_lo = min(tid * ppt, Tc), i_hi = min(i_lo + ppt, Tc);
+  const float* ge = ws_genv + ((size_t)b * 6 + e) * Tc;
+  CgRampGrad ga = {0, 0, 0}, gd = {0, 0, 0}, gr = {0, 0, 0};
+  double gsus = 0.0;
+  for (int i = i_lo; i < i_hi; ++i) {
+    const double g = (double)ge[i];
+    double ya, qa, ta, yd, qd, td, yr, qr, tr; bool la, ld, lr;
+    const double a = cg_ramp(i, na, p.alpha, 0.0, false, false, cr, &ya, &qa, &ta, &la);
+    const double dr = cg_ramp(i, nd, p.alpha, na, true, true, cr, &yd, &qd, &td, &ld, heads.d);
+    const double r = cg_ramp(i, p.release, p.alpha, note_on, true, true, cr, &yr, &qr, &tr, &lr, heads.r);
+    const double d = (1.0 - p.sustain) * dr + p.sustain;
+    cg_ramp_back(g * d * r, a, ya, qa, ta, la, na, p.alpha, false, false, cr, ga);
+    cg_ramp_back(g * a * r * (1.0 - p.sustain), dr, yd, qd, td, ld, nd, p.alpha, true, true, cr, gd);
+    cg_ramp_back(g * a * d, r, yr, qr, tr, lr, p.release, p.alpha, true, true, cr, gr);
+    gsus += g * a * r * (1.0 - dr);
+  }
+  // six workgroup sums at once (thread order within a wave, wave order across: the order of cg_block_sum)
+  double vals[6] = {ga.duration + gd.start, gd.duration, gr.duration, gr.start, ga.alpha + gd.alpha + gr.alpha, gsus};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) vals[k] = cg_wave_sum(vals[k]);
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s_red[k][tid >> 6] = vals[k];
+  __syncthreads();
+  if (tid == 0) {
+    double t[6];
+    for (int k = 0; k < 6; ++k) {
+      t[k] = 0.0;
+      for (int w = 0; w < EG_THREADS / 64; ++w) t[k] += s_red[k][w];
+    }
+    const double g_na = t[0], g_nd = t[1], g_rel = t[2], g_no_r = t[3], g_alpha = t[4], g_sus = t[5];
+    double g_att = 0.0, g_dec = 0.0, g_no = g_no_r;
+    // torch.minimum: the smaller argument takes the gradient, a tie splits it
+    if (p.attack < note_on) g_att += g_na; else if (p.attack > note_on) g_no += g_na; else { g_att += 0.5 * g_na; g_no += 0.5 * g_na; }
+    double g_nd0 = 0.0;
+    if (nd0 < p.decay) g_nd0 = g_nd; else if (nd0 > p.decay) g_dec += g_nd; else { g_nd0 = 0.5 * g_nd; g_dec += 0.5 * g_nd; }
+    if (note_on - p.attack >= 0.0) { g_no += g_nd0; g_att -= g_nd0; }      // clamp_min passes at >= 0
+    double* out = ws_part + (size_t)b * 40 + e * 6;
+    out[0] = g_att; out[1] = g_dec; out[2] = g_sus; out[3] = g_rel; out[4] = g_alpha; out[5] = g_no;
+  }
+}
+
+// g_params01 of the 30 envelope parameters, and the envelopes' share of d loss / d note_on added (in envelope order) to
+// what voice_ctrl_grad_kernel<true> left there.
+__global__ __launch_bounds__(64) void voice_ctrl_finish_kernel(const double* __restrict__ ws_vdv,
+                                                               const double* __restrict__ ws_part,
+                                                               float* __restrict__ g_params01) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int adsr_base[6] = {IAS_P_ADSR_1_ATTACK, IAS_P_ADSR_2_ATTACK, IAS_P_LFO_1_AMP_ADSR_ATTACK,
+                            IAS_P_LFO_2_AMP_ADSR_ATTACK, IAS_P_LFO_1_RATE_ADSR_ATTACK, IAS_P_LFO_2_RATE_ADSR_ATTACK};
+  const double* dv = ws_vdv + ((size_t)b * 2 + 1) * 78;
+  const double* part = ws_part + (size_t)b * 40;
+  if (tid < 30) {
+    const int e = tid / 5, k = tid - 5 * e, pidx = adsr_base[e] + k;
+    g_params01[(size_t)b * 78 + pidx] = (float)(part[e * 6 + k] * dv[pidx]);
+  } else if (tid == 32) {
+    double g_no = 0.0;
+    for (int e = 0; e < 6; ++e) g_no += part[e * 6 + 5];
+    // voice_ctrl_grad_kernel<true> wrote (float)(gv dv) for note_on without this share; its gv is recovered in fp64 from
+    // the parts it saved next to dv (ws_vdv[b][0][..] holds the values, that partial gradient is kept in ws_part[b][36])
+    g_params01[(size_t)b * 78 + IAS_P_KEYBOARD_DURATION] =
+        (float)((part[36] + g_no) * dv[IAS_P_KEYBOARD_DURATION]);
+  }
+}
+
 // params01 [B,78]; g_ctrl [B,5,Tc] fp32 and g_scal [B,12] fp64 (ias_voice_backward's g_ctrl and the tile sum of its
 // partials); g_params01 [B,78] out.  IAS_ERR_UNSUPPORTED when the control buffer does not fit LDS (Tc > ~3000):
 // the caller then differentiates voice_grad.control_graph with torch.
@@ -348,9 +487,45 @@ extern "C" int ias_voice_control_backward(const float* params01, const float* g_
   const size_t lds = sizeof(double) * 4 * (size_t)Tc + sizeof(float) * 6 * (size_t)Tc;
   if (lds > 150 * 1024) return IAS_ERR_UNSUPPORTED;
   if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute((const void*)voice_ctrl_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)voice_ctrl_grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int ppt = (Tc + CG_THREADS - 1) / CG_THREADS;
-  hipLaunchKernelGGL(voice_ctrl_grad_kernel, dim3(B), dim3(CG_THREADS), lds, (hipStream_t)stream_, params01, g_ctrl,
-                     g_scal, g_params01, Tc, ppt, (double)control_rate);
+  hipLaunchKernelGGL(voice_ctrl_grad_kernel<false>, dim3(B), dim3(CG_THREADS), lds, (hipStream_t)stream_, params01, g_ctrl,
+                     g_scal, g_params01, Tc, ppt, (double)control_rate, (float*)nullptr, (double*)nullptr, (double*)nullptr,
+                     (const double*)nullptr);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+// The same in four launches (round 3): envelope values and the six-envelope phase on 6 x B workgroups each.  workspace:
+// ias_voice_control_backward_ws_bytes(B, Tc) bytes of device memory (16-byte aligned), contents undefined before and after.
+extern "C" long long ias_voice_control_backward_ws_bytes(int B, int Tc) {
+  if (B <= 0 || Tc <= 1) return IAS_ERR_ARG;
+  return (long long)sizeof(float) * B * 6 * Tc + (long long)sizeof(double) * B * (2 * 78 + 40 + 6 * (long long)Tc) + 64;
+}
+extern "C" int ias_voice_control_backward_ws(const float* params01, const float* g_ctrl, const double* g_scal,
+                                             float* g_params01, void* workspace, long long workspace_bytes, int B, int Tc,
+                                             int control_rate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!params01 || !g_ctrl || !g_scal || !g_params01 || !workspace || B <= 0 || B > 65535 || Tc <= 1 || control_rate <= 0)
+    return IAS_ERR_ARG;
+  if (control_rate != IAS_CONTROL_RATE) return IAS_ERR_UNSUPPORTED;
+  if (workspace_bytes < ias_voice_control_backward_ws_bytes(B, Tc) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return IAS_ERR_WORKSPACE;
+  const size_t lds = sizeof(double) * 4 * (size_t)Tc + sizeof(float) * 6 * (size_t)Tc;
+  if (lds > 150 * 1024) return IAS_ERR_UNSUPPORTED;
+  // doubles first (alignment), then the envelope cotangents
+  double* ws_vdv = (double*)workspace;
+  double* ws_part = ws_vdv + (size_t)B * 2 * 78;
+  double* ws_env = ws_part + (size_t)B * 40;
+  float* ws_genv = (float*)(ws_env + (size_t)B * 6 * Tc);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)voice_ctrl_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int ppt = (Tc + CG_THREADS - 1) / CG_THREADS;
+  const int eppt = (Tc + EG_THREADS - 1) / EG_THREADS;
+  hipLaunchKernelGGL(voice_env_value_kernel, dim3(6, B), dim3(EG_THREADS), 0, stream, params01, ws_env, Tc, eppt,
+                     (double)control_rate);
+  hipLaunchKernelGGL(voice_ctrl_grad_kernel<true>, dim3(B), dim3(CG_THREADS), lds, stream, params01, g_ctrl, g_scal,
+                     g_params01, Tc, ppt, (double)control_rate, ws_genv, ws_vdv, ws_part, (const double*)ws_env);
+  hipLaunchKernelGGL(voice_env_grad_kernel, dim3(6, B), dim3(EG_THREADS), 0, stream, ws_genv, ws_vdv, ws_part, Tc, eppt,
+                     (double)control_rate);
+  hipLaunchKernelGGL(voice_ctrl_finish_kernel, dim3(B), dim3(64), 0, stream, ws_vdv, ws_part, g_params01);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }

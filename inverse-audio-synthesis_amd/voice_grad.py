@@ -231,11 +231,13 @@ def _control_backward_hip(cfg, p, g_ctrl, g_scal):
     g_ctrl = g_ctrl.to(torch.float32).contiguous()
     g_scal = g_scal.to(torch.float64).contiguous()
     out = torch.empty((p.shape[0], S.NPARAMS), dtype=torch.float32, device=p.device)
-    st = lib.ias_voice_control_backward(_lib.ptr(p), _lib.ptr(g_ctrl), _lib.ptr(g_scal), _lib.ptr(out), p.shape[0],
-                                        cfg.control_buffer_size, cfg.control_rate, _lib.stream())
+    nws = lib.ias_voice_control_backward_ws_bytes(p.shape[0], cfg.control_buffer_size)
+    ws = torch.empty(max(int(nws), 16), dtype=torch.uint8, device=p.device)
+    st = lib.ias_voice_control_backward_ws(_lib.ptr(p), _lib.ptr(g_ctrl), _lib.ptr(g_scal), _lib.ptr(out), _lib.ptr(ws),
+                                           ws.numel(), p.shape[0], cfg.control_buffer_size, cfg.control_rate, _lib.stream())
     if st == -2:      # IAS_ERR_UNSUPPORTED: control buffer too long for LDS -> torch graph
         return None
-    _lib.check(st, "ias_voice_control_backward")
+    _lib.check(st, "ias_voice_control_backward_ws")
     return out
 
 
