@@ -118,6 +118,27 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_inc_kernel(
   block_sums<2>(acc, tile_sums + ((size_t)b * ntiles + tile) * 2, s_red, tid);
 }
 
+// c1, c2 = sums over the tiles t of [lo, hi) -- ascending t, or descending when DESC -- of src[t * stride + off1 / off2],
+// in every thread.  The values are fetched by up to GRAD_THREADS lanes at once and added from LDS in the stated order
+// (the straightforward loop was a chain of up to ntiles dependent global loads at the head of every workgroup).
+template <bool DESC>
+__device__ __forceinline__ void tile_carry(const double* __restrict__ src, size_t stride, int off1, int off2, int lo, int hi,
+                                           double* s_buf /* [2][GRAD_THREADS] */, int tid, double& c1, double& c2) {
+  c1 = 0.0; c2 = 0.0;
+  const int n = hi - lo;
+  for (int base = 0; base < n; base += GRAD_THREADS) {
+    const int m = min(GRAD_THREADS, n - base);
+    if (tid < m) {
+      const int t = DESC ? hi - 1 - (base + tid) : lo + base + tid;
+      s_buf[tid] = src[(size_t)t * stride + off1];
+      s_buf[GRAD_THREADS + tid] = src[(size_t)t * stride + off2];
+    }
+    __syncthreads();
+    for (int i = 0; i < m; ++i) { c1 += s_buf[i]; c2 += s_buf[GRAD_THREADS + i]; }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ K1
 __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_sample_kernel(
     const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst, const float* __restrict__ noise,
@@ -137,10 +158,10 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_sample_kernel(
   const float* grow = g_mixed + (size_t)b * T;
 
   // carry-in: the increments of the earlier tiles (fp64 sums of fp32 values below 2^19 are exact)
-  double carry1 = 0.0, carry2 = 0.0;
-  for (int t = 0; t < tile; ++t) {
-    carry1 += tile_sums[((size_t)b * ntiles + t) * 2];
-    carry2 += tile_sums[((size_t)b * ntiles + t) * 2 + 1];
+  double carry1, carry2;
+  {
+    __shared__ double s_carry[2 * GRAD_THREADS];
+    tile_carry<false>(tile_sums + (size_t)b * ntiles * 2, 2, 0, 1, 0, tile, s_carry, tid, carry1, carry2);
   }
   // lvl0 lvl1 lvl2 kpart shape gain phi_1 phi_2
   double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -294,10 +315,11 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_pitch_kernel(
   const float* cb = ctrl + (size_t)b * IAS_NCTRL * Tc;
   float* pl = planes + (size_t)b * IAS_GRAD_PLANES * T;
   // carry-in of the reverse scan: g_arg totals of the later tiles (K1 left them in the phi slots)
-  double carry1 = 0.0, carry2 = 0.0;
-  for (int t = ntiles - 1; t > tile; --t) {
-    carry1 += partials[((size_t)b * ntiles + t) * IAS_GRAD_NS + GS_PHI_1];
-    carry2 += partials[((size_t)b * ntiles + t) * IAS_GRAD_NS + GS_PHI_2];
+  double carry1, carry2;
+  {
+    __shared__ double s_carry[2 * GRAD_THREADS];
+    tile_carry<true>(partials + (size_t)b * ntiles * IAS_GRAD_NS, IAS_GRAD_NS, GS_PHI_1, GS_PHI_2, tile + 1, ntiles, s_carry, tid,
+                     carry1, carry2);
   }
   const double k = 0.6931471805599453 / 12.0;   // d inc / d pitch = inc * ln2 / 12
   double acc[4] = {0.0, 0.0, 0.0, 0.0};        // f0_1 depth_1 f0_2 depth_2

@@ -1,6 +1,6 @@
 """voice control-rate backward: one launch (SPLIT=0) vs the three-launch form -- developer tool."""
 import os, sys, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from inverse_audio_synthesis_amd import _lib
 from inverse_audio_synthesis_amd import voice_spec as S
 lib = _lib.load()
