@@ -75,6 +75,10 @@ int ias_voice_read_status(const void* workspace, unsigned* status, int B, int T,
 /* Byte offset inside the workspace of the B row peaks (fp32, max |x| of the un-normalised mix) of the last render.
  * ias_pqmf_analysis / ias_stft take that address as `rowpeak` to fold normalize_if_clipping into their own pass
  * (render with normalize = 0): the normalised audio is then never written or re-read. */
+/* Byte offsets of the control signals [B,5,Tc] fp32 / the per-voice constants [B] x 64 B that the last render (or
+ * ias_voice_control_ws) left in the workspace: ias_voice_backward's ctrl / vconst without a second control pass. */
+long long ias_voice_ctrl_offset(int B, int T, int Tc);
+long long ias_voice_vconst_offset(int B, int T, int Tc);
 long long ias_voice_peaks_offset(int B, int T, int Tc);
 
 /* Copy the B row peaks (max |x| before normalisation) of the last render out of the workspace. */

@@ -35,6 +35,8 @@ SYMBOLS = {
     "ias_voice_stage": (_I, [_I, _I, _P, _P, _P, _LL, _I, _I, _I, _I, _P]),
     "ias_voice_read_status": (_I, [_P, _P, _I, _I, _I, _P]),
     "ias_voice_peaks_offset": (_LL, [_I, _I, _I]),
+    "ias_voice_ctrl_offset": (_LL, [_I, _I, _I]),
+    "ias_voice_vconst_offset": (_LL, [_I, _I, _I]),
     "ias_voice_read_peaks": (_I, [_P, _P, _I, _I, _I, _P]),
     "ias_voice_grad_tiles": (_I, [_I]),
     "ias_voice_grad_nscalars": (_I, []),

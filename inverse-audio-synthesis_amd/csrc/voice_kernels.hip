@@ -911,6 +911,17 @@ extern "C" int ias_voice_read_status(const void* workspace, unsigned* status_dev
 
 // Byte offset of the row peaks [B] (fp32 bit patterns of max |x| before normalisation) inside the workspace: consumers
 // that fold the normalisation in (ias_pqmf_analysis / ias_stft `rowpeak`) read them in place.
+// Byte offsets of the control signals [B,5,Tc] fp32 and of the per-voice constants [B] (64 B each) the last render (or
+// ias_voice_control_ws) left in the workspace: what ias_voice_backward takes as ctrl / vconst, without a second control pass.
+extern "C" long long ias_voice_ctrl_offset(int B, int T, int Tc) {
+  if (B <= 0 || T <= 0 || Tc <= 1) return IAS_ERR_ARG;
+  return (long long)voice_ws_layout(B, T, Tc).off_ctrl;
+}
+extern "C" long long ias_voice_vconst_offset(int B, int T, int Tc) {
+  if (B <= 0 || T <= 0 || Tc <= 1) return IAS_ERR_ARG;
+  return (long long)voice_ws_layout(B, T, Tc).off_vconst;
+}
+
 extern "C" long long ias_voice_peaks_offset(int B, int T, int Tc) {
   if (B <= 0 || T <= 0 || Tc <= 1) return IAS_ERR_ARG;
   return (long long)voice_ws_layout(B, T, Tc).off_peak;

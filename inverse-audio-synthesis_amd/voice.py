@@ -287,6 +287,19 @@ class Voice(nn.Module):
         _lib.check(st, "ias_voice_control_debug")
         return dbg
 
+    def rendered_control(self, workspace=None):
+        """(ctrl [B,5,Tc] fp32, vconst [B,16] fp32) copied out of the workspace the last render used: the control
+        signals and per-voice constants of THAT render, for its backward (no second control pass)."""
+        c = self.synthconfig
+        ws = self._workspace if workspace is None else workspace
+        lib = _lib.load()
+        oc = int(lib.ias_voice_ctrl_offset(c.batch_size, c.buffer_size, c.control_buffer_size))
+        ov = int(lib.ias_voice_vconst_offset(c.batch_size, c.buffer_size, c.control_buffer_size))
+        nc = c.batch_size * 5 * c.control_buffer_size * 4
+        ctrl = ws[oc:oc + nc].view(torch.float32).reshape(c.batch_size, 5, c.control_buffer_size).clone()
+        vconst = ws[ov:ov + c.batch_size * 64].view(torch.float32).reshape(c.batch_size, 16).clone()
+        return ctrl, vconst
+
     def control_signals(self, params01=None):
         """Mod-matrix outputs [B,5,Tc] of the control-rate kernel (diagnostics / tests)."""
         c = self.synthconfig

@@ -163,7 +163,7 @@ def normalisation_rows(g_audio, audio, peaks):
     return rownorm
 
 
-def audio_rate_backward(voice, params01, g_mixed, rownorm=None):
+def audio_rate_backward(voice, params01, g_mixed, rownorm=None, control=None):
     """HIP adjoint of the audio-rate render: g_mixed [B,T] -> (g_ctrl [B,5,Tc] fp32, g_constants [B,12] fp64).
     ``rownorm``: ``normalisation_rows`` of a normalised render; ``g_mixed`` is then the cotangent of the normalised
     audio."""
@@ -172,7 +172,8 @@ def audio_rate_backward(voice, params01, g_mixed, rownorm=None):
     B, T, Tc = c.batch_size, c.buffer_size, c.control_buffer_size
     g_mixed = g_mixed.to(torch.float32).contiguous()
     _lib.require_f32(g_mixed, voice.noise)
-    ctrl, vconst = voice.control_signals(params01)
+    # the forward's control signals when the caller kept them (voice.rendered_control()), else one more control pass
+    ctrl, vconst = control if control is not None else voice.control_signals(params01)
     dev = g_mixed.device
     ntiles = lib.ias_voice_grad_tiles(T)
     planes = torch.empty((B, lib.ias_voice_grad_nplanes(), T), dtype=torch.float32, device=dev)
@@ -268,19 +269,20 @@ class _RenderFn(torch.autograd.Function):
         p = params01.detach().to(torch.float32).contiguous()
         audio = voice._render_nograd(p, normalize)
         peaks = voice.read_peaks() if normalize else None
+        ctrl, vconst = voice.rendered_control()
         ctx.voice, ctx.normalize = voice, normalize
-        ctx.save_for_backward(p, audio, peaks)
+        ctx.save_for_backward(p, audio, peaks, ctrl, vconst)
         return audio
 
     @staticmethod
     def backward(ctx, g_audio):
-        p, audio, peaks = ctx.saved_tensors
+        p, audio, peaks, ctrl, vconst = ctx.saved_tensors
         voice = ctx.voice
         g = g_audio.to(torch.float32).contiguous()
         # audio = mixed / peak on rows with peak > 1 (peak = max |mixed|, attained at t*):
         #   g_mixed = g / peak, and the peak itself takes -sign(mixed[t*]) * sum_t g[t] audio[t] / peak at t*
         rownorm = normalisation_rows(g, audio, peaks) if ctx.normalize else None
-        g_ctrl, g_scal = audio_rate_backward(voice, p, g, rownorm)
+        g_ctrl, g_scal = audio_rate_backward(voice, p, g, rownorm, (ctrl, vconst))
         g_p = _control_backward(voice.synthconfig, p, g_ctrl, g_scal)
         return g_p.to(torch.float32), None, None
 
