@@ -165,6 +165,9 @@ int ias_pqmf_synth_taps_len(int N, int K);
 int ias_pqmf_pack_synth_taps(const float* G, float* packed, int N, int K, void* stream);
 int ias_pqmf_synthesis(const float* z, const float* G, const float* packed, float* out, int B, int L, int N, int K,
                        void* stream);
+/* The same into out [B, T_out], T_out <= L * N: the first T_out samples of every row, contiguous. */
+int ias_pqmf_synthesis_t(const float* z, const float* G, const float* packed, float* out, int B, int L, int N, int K,
+                         int T_out, void* stream);
 
 /* ---- STFT / mel spectral losses.  No live reference code: spec = the commented mel block at
  * reference conf/config.yaml:51-61 and its use at audio_to_params.py:150-153 (torchaudio

@@ -57,6 +57,7 @@ SYMBOLS = {
     "ias_pqmf_synth_taps_len": (_I, [_I, _I]),
     "ias_pqmf_pack_synth_taps": (_I, [_P, _P, _I, _I, _P]),
     "ias_pqmf_synthesis": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_pqmf_synthesis_t": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ias_stft_num_frames": (_I, [_I, _I, _I]),
     "ias_stft_partials_count": (_LL, [_I, _I, _I, _I, _I]),
     "ias_stft_tables_len": (_I, [_I]),

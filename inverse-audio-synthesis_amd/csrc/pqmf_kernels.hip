@@ -821,11 +821,11 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_analysis_generic_kernel(
 // out[b,t] = N * sum_k sum_{j : (t-pad+j) % N == 0} G[k,j] * z[b,k,(t-pad+j)/N],  t in [0, L*N)
 __global__ __launch_bounds__(PQ_THREADS) void pqmf_synthesis_kernel(
     const float* __restrict__ z, const float* __restrict__ G, float* __restrict__ out,
-    int L, int N, int K, int pad) {
+    int L, int N, int K, int pad, int Tout /* samples kept per row (<= L * N), the row stride of out */) {
   const int To = L * N;
   const int t = blockIdx.x * PQ_THREADS + threadIdx.x;
   const int b = blockIdx.y;
-  if (t >= To) return;
+  if (t >= Tout) return;
   // first tap j0 >= 0 with (t - pad + j0) % N == 0
   int rem = (t - pad) % N;
   if (rem < 0) rem += N;
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_synthesis_kernel(
     for (int k = 0; k < N; ++k) a = fmaf(G[(size_t)k * K + j], zb[(size_t)k * L + m], a);
     acc = fmaf(a, (float)N, acc);
   }
-  out[(size_t)b * To + t] = acc;
+  out[(size_t)b * Tout + t] = acc;
 }
 
 // Wide synthesis (any N <= 64, odd K <= 255).  With t = N m + r:  out[N m + r] = N sum_d sum_k Gt[d][k][r] z[k][m + d],
@@ -869,7 +869,8 @@ template <int NPAD>
 __global__ __launch_bounds__(PQ_THREADS) void pqmf_synthesis_wide_kernel(
     const float* __restrict__ z, const float* __restrict__ Gt, float* __restrict__ out, int L, int N, int dmin,
     int nd, int rs /* LDS row stride (odd), >= 128 + nd - 1 and >= N + 1 scaled: see host */,
-    unsigned live /* bit (half * 16 + di): some phase of that half has a tap at frame offset di (K <= N: one di per half) */) {
+    unsigned live /* bit (half * 16 + di): some phase of that half has a tap at frame offset di (K <= N: one di per half) */,
+    int Tout /* samples kept per row (<= L * N), the row stride of out */) {
   constexpr int HB = NPAD / 2;
   extern __shared__ __attribute__((aligned(16))) float s_zrows[];   // [N][rs]; reused as the output tile [128][N + 1]
   const int tid = threadIdx.x, b = blockIdx.y;
@@ -904,11 +905,11 @@ __global__ __launch_bounds__(PQ_THREADS) void pqmf_synthesis_wide_kernel(
     if (ph < N) s_zrows[fl * os + ph] = acc[r];
   }
   __syncthreads();
-  const long long t0 = (long long)m0 * N, To = (long long)L * N;
-  float* ob = out + (size_t)b * To;
+  const long long t0 = (long long)m0 * N;
+  float* ob = out + (size_t)b * Tout;
   for (int i = tid; i < PQW_FRAMES * N; i += PQ_THREADS) {
     const int f = i / N, ph = i - f * N;
-    if (t0 + i < To) ob[t0 + i] = s_zrows[f * os + ph];
+    if (t0 + i < Tout) ob[t0 + i] = s_zrows[f * os + ph];
   }
 }
 
@@ -1235,13 +1236,22 @@ extern "C" int ias_pqmf_pack_synth_taps(const float* G, float* packed, int N, in
 
 // z [B,N,L], G [N,K] (module buffer G[1,N,K]), out [B, L*N] (the reference's [B,1,L*N]).
 // packed: ias_pqmf_pack_synth_taps table of G (wide kernel), or NULL (generic one-lane-per-output kernel).
+// The same into out [B, T_out], T_out <= L * N: the first T_out samples of every row, contiguous (the adjoint of an
+// analysis of T_out samples: no strided view of a [B, L * N] result for the next kernel to walk).
+extern "C" int ias_pqmf_synthesis_t(const float* z, const float* G, const float* packed, float* out, int B, int L,
+                                    int N, int K, int T_out, void* stream_);
 extern "C" int ias_pqmf_synthesis(const float* z, const float* G, const float* packed, float* out, int B, int L,
                                   int N, int K, void* stream_) {
+  if ((long long)L * N > 0x7fffffffLL) return IAS_ERR_ARG;
+  return ias_pqmf_synthesis_t(z, G, packed, out, B, L, N, K, L * N, stream_);
+}
+extern "C" int ias_pqmf_synthesis_t(const float* z, const float* G, const float* packed, float* out, int B, int L,
+                                    int N, int K, int T_out, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!z || !G || !out || B <= 0 || B > 65535 || L <= 0 || N <= 0 || K <= 0 || (K & 1) == 0) return IAS_ERR_ARG;
   const int pad = (K - 1) / 2;
   const long long To = (long long)L * N;
-  if (To > 0x7fffffffLL) return IAS_ERR_ARG;
+  if (To > 0x7fffffffLL || T_out <= 0 || T_out > To) return IAS_ERR_ARG;
   if (packed && ias_pqmf_synth_taps_len(N, K) > 0) {
     const PqmfSynthGeom g = pqmf_synth_geom(N, K);
     const int npad = pqmf_wide_npad(N, K);
@@ -1266,7 +1276,7 @@ extern "C" int ias_pqmf_synthesis(const float* z, const float* G, const float* p
       if (g.nd > 16) live = 0xffffffffu;
 #define IAS_PQS_LAUNCH(NP)                                                                                       \
       hipLaunchKernelGGL((pqmf_synthesis_wide_kernel<NP>), grid, block, lds, stream, z, packed, out, L, N, g.dmin, \
-                         g.nd, rs, live)
+                         g.nd, rs, live, T_out)
       if (npad == 8) IAS_PQS_LAUNCH(8);
       else if (npad == 16) IAS_PQS_LAUNCH(16);
       else if (npad == 32) IAS_PQS_LAUNCH(32);
@@ -1275,7 +1285,7 @@ extern "C" int ias_pqmf_synthesis(const float* z, const float* G, const float* p
       return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
     }
   }
-  hipLaunchKernelGGL(pqmf_synthesis_kernel, dim3((int)((To + PQ_THREADS - 1) / PQ_THREADS), B), dim3(PQ_THREADS), 0,
-                     stream, z, G, out, L, N, K, pad);
+  hipLaunchKernelGGL(pqmf_synthesis_kernel, dim3((int)((T_out + PQ_THREADS - 1) / PQ_THREADS), B), dim3(PQ_THREADS), 0,
+                     stream, z, G, out, L, N, K, pad, T_out);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }

@@ -98,7 +98,8 @@ class _AnalysisFn(torch.autograd.Function):
         g = g_z.to(torch.float32)
         if std is not None:
             g = g / std.reshape(1, N, 1)
-        g_x = pqmf_synthesis(g, _adjoint_filters(H))[:, 0, :T]
+        LN = g.shape[-1] * N
+        g_x = pqmf_synthesis(g, _adjoint_filters(H), out_len=min(T, LN))[:, 0, :]
         if g_x.shape[-1] < T:
             g_x = torch.nn.functional.pad(g_x, (0, T - g_x.shape[-1]))
         return g_x.reshape(ctx.shape), None, None, None
@@ -174,18 +175,21 @@ def _packed_synth_taps(G, Gc, N, K):
     return hit[0]
 
 
-def pqmf_synthesis(z, G):
-    """z [B,N,L], G [1,N,K] -> [B,1,L*N]."""
+def pqmf_synthesis(z, G, out_len=None):
+    """z [B,N,L], G [1,N,K] -> [B,1,L*N]  (``out_len``: only the first ``out_len`` <= L*N samples, as a contiguous
+    [B,1,out_len] -- what the analysis' adjoint wants)."""
     lib = _lib.load()
     zc = z.contiguous()
     Gc = G.reshape(-1, G.shape[-1]).contiguous()
     _lib.require_f32(zc, Gc)
     B, N, L = zc.shape
     assert Gc.shape[0] == N
-    out = torch.empty((B, 1, L * N), dtype=torch.float32, device=zc.device)
-    st = lib.ias_pqmf_synthesis(_lib.ptr(zc), _lib.ptr(Gc), _lib.ptr(_packed_synth_taps(G, Gc, N, Gc.shape[1])),
-                                _lib.ptr(out), B, L, N, Gc.shape[1], _lib.stream())
-    _lib.check(st, "ias_pqmf_synthesis")
+    To = L * N if out_len is None else int(out_len)
+    assert 0 < To <= L * N
+    out = torch.empty((B, 1, To), dtype=torch.float32, device=zc.device)
+    st = lib.ias_pqmf_synthesis_t(_lib.ptr(zc), _lib.ptr(Gc), _lib.ptr(_packed_synth_taps(G, Gc, N, Gc.shape[1])),
+                                  _lib.ptr(out), B, L, N, Gc.shape[1], To, _lib.stream())
+    _lib.check(st, "ias_pqmf_synthesis_t")
     return out
 
 
