@@ -295,36 +295,68 @@ struct CombineArgs {
   unsigned magic[IAS_COMBINE_MAX];      // floor(2^32 / (G hop)): q / (G hop) without an integer division (3 x nres per sample)
   int nres;
 };
+// one resolution's share of sample j (overlap-added chunk spans + the reflect-pad adjoint)
+__device__ __forceinline__ float combine_one(const CombineArgs& a, int r, const float* __restrict__ sp, int j, int T) {
+  const int N = a.N[r], hop = a.hop[r], G = a.G[r], cper = a.cper[r], L = a.L[r], F = a.F[r];
+  const int pad = N / 2, gh = G * hop;
+  int qs[3];
+  int nq = 0;
+  qs[nq++] = j + pad;
+  if (j >= 1 && j <= pad) qs[nq++] = pad - j;
+  if (j <= T - 2 && j >= T - 1 - pad) qs[nq++] = pad + 2 * (T - 1) - j;
+  float acc = 0.0f;
+  for (int i = 0; i < nq; ++i) {
+    const int q = qs[i];
+    int c = (int)__umulhi((unsigned)q, a.magic[r]);         // floor(q / gh) or one less
+    if (q - c * gh >= gh) ++c;
+    if (c > cper - 1) c = cper - 1;
+    float v = 0.0f;
+    if (c >= 1 && q - (c - 1) * gh < L) v = sp[(size_t)(c - 1) * L + (q - (c - 1) * gh)];
+    const int nf = min(F, (c + 1) * G) - c * G;
+    if (q - c * gh < (nf - 1) * hop + N) v += sp[(size_t)c * L + (q - c * gh)];
+    acc += v;
+  }
+  return acc;
+}
+
+// A thread owns the sample pair (j, j + 1), j even.  Away from the reflected ends of a resolution the pair sits at an even
+// offset of one or two chunk spans (hop, G hop, L and n_fft / 2 are all even: a pair never straddles a chunk or a span
+// end): 8-byte loads, half the load instructions of the one-sample form.
 __global__ __launch_bounds__(SG_THREADS) void stft_grad_combine_multi_kernel(const CombineArgs a,
                                                                              const float* __restrict__ g_loss,
                                                                              float* __restrict__ g_audio, int T) {
-  const int j = blockIdx.x * SG_THREADS + threadIdx.x, b = blockIdx.y;
+  const int j = 2 * (blockIdx.x * SG_THREADS + threadIdx.x), b = blockIdx.y;
   if (j >= T) return;
-  float total = 0.0f;
+  const bool two = j + 1 < T;
+  float t0 = 0.0f, t1 = 0.0f;
   for (int r = 0; r < a.nres; ++r) {
     const int N = a.N[r], hop = a.hop[r], G = a.G[r], cper = a.cper[r], L = a.L[r], F = a.F[r];
     const int pad = N / 2, gh = G * hop;
     const float* sp = a.spans[r] + (size_t)b * cper * L;
-    int qs[3];
-    int nq = 0;
-    qs[nq++] = j + pad;
-    if (j >= 1 && j <= pad) qs[nq++] = pad - j;
-    if (j <= T - 2 && j >= T - 1 - pad) qs[nq++] = pad + 2 * (T - 1) - j;
-    float acc = 0.0f;
-    for (int i = 0; i < nq; ++i) {
-      const int q = qs[i];
-      int c = (int)__umulhi((unsigned)q, a.magic[r]);         // floor(q / gh) or one less
+    float v0, v1;
+    const bool even = ((hop | L) & 1) == 0 && ((reinterpret_cast<uintptr_t>(sp) & 7) == 0);
+    if (two && even && j > pad && j + 1 < T - 1 - pad) {
+      const int q = j + pad;
+      int c = (int)__umulhi((unsigned)q, a.magic[r]);
       if (q - c * gh >= gh) ++c;
       if (c > cper - 1) c = cper - 1;
-      float v = 0.0f;
-      if (c >= 1 && q - (c - 1) * gh < L) v = sp[(size_t)(c - 1) * L + (q - (c - 1) * gh)];
+      const int off = q - c * gh;
+      float2 lo = make_float2(0.0f, 0.0f), hi = make_float2(0.0f, 0.0f);
+      if (c >= 1 && off + gh < L) lo = *reinterpret_cast<const float2*>(sp + (size_t)(c - 1) * L + off + gh);
       const int nf = min(F, (c + 1) * G) - c * G;
-      if (q - c * gh < (nf - 1) * hop + N) v += sp[(size_t)c * L + (q - c * gh)];
-      acc += v;
+      if (off < (nf - 1) * hop + N) hi = *reinterpret_cast<const float2*>(sp + (size_t)c * L + off);
+      v0 = lo.x + hi.x; v1 = lo.y + hi.y;
+    } else {
+      v0 = combine_one(a, r, sp, j, T);
+      v1 = two ? combine_one(a, r, sp, j + 1, T) : 0.0f;
     }
-    total = r == 0 ? acc : total + acc;
+    t0 = r == 0 ? v0 : t0 + v0;
+    t1 = r == 0 ? v1 : t1 + v1;
   }
-  g_audio[(size_t)b * T + j] = g_loss ? total * g_loss[0] : total;
+  const float g = g_loss ? g_loss[0] : 1.0f;
+  float* o = g_audio + (size_t)b * T + j;
+  if (two && (((size_t)b * T + j) & 1) == 0) *reinterpret_cast<float2*>(o) = make_float2(g_loss ? t0 * g : t0, g_loss ? t1 * g : t1);
+  else { o[0] = g_loss ? t0 * g : t0; if (two) o[1] = g_loss ? t1 * g : t1; }
 }
 
 // spans_host: HOST array of nres <= 8 device pointers (ias_stft_grad_spans outputs for the same audio [B,T]);
@@ -346,7 +378,7 @@ extern "C" int ias_stft_grad_combine(const float* const* spans_host, const int* 
     if (p[3] != (a.F[r] + p[2] - 1) / p[2]) return IAS_ERR_ARG;
   }
   a.nres = nres;
-  hipLaunchKernelGGL(stft_grad_combine_multi_kernel, dim3((T + SG_THREADS - 1) / SG_THREADS, B), dim3(SG_THREADS), 0,
+  hipLaunchKernelGGL(stft_grad_combine_multi_kernel, dim3(((T + 1) / 2 + SG_THREADS - 1) / SG_THREADS, B), dim3(SG_THREADS), 0,
                      (hipStream_t)stream_, a, g_loss, g_audio, T);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
