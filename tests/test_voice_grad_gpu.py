@@ -163,3 +163,28 @@ def test_gradient_is_finite_at_the_ends_of_the_parameter_ranges(lib, dev):
     for b in range(3):
         if ok[b].all() and ref[b].norm() > 0:
             assert rel_l2(g[b], ref[b]) <= 5e-2, (b, rel_l2(g[b], ref[b]))
+
+
+def test_control_backward_in_four_launches_equals_the_single_kernel(lib, dev):
+    """ias_voice_control_backward_ws (envelope values and envelope gradients on 6 x B workgroups around the per-voice
+    kernel) against ias_voice_control_backward (everything in one workgroup per voice): same arithmetic per control point,
+    same summation orders -> the same bits."""
+    from inverse_audio_synthesis_amd import _lib
+    B, Tc = 5, 441
+    g = torch.Generator().manual_seed(3)
+    p = torch.rand(B, 78, generator=g).to(dev)
+    p[0, :] = 0.0
+    p[1, :] = 1.0
+    g_ctrl = torch.randn(B, 5, Tc, generator=g).to(dev)
+    g_scal = torch.randn(B, 12, generator=g, dtype=torch.float64).to(dev)
+    one, four = torch.empty(B, 78, device=dev), torch.empty(B, 78, device=dev)
+    _lib.check(lib.ias_voice_control_backward(_lib.ptr(p), _lib.ptr(g_ctrl), _lib.ptr(g_scal), _lib.ptr(one), B, Tc, 441,
+                                              _lib.stream()), "ias_voice_control_backward")
+    ws = torch.empty(int(lib.ias_voice_control_backward_ws_bytes(B, Tc)), dtype=torch.uint8, device=dev)
+    _lib.check(lib.ias_voice_control_backward_ws(_lib.ptr(p), _lib.ptr(g_ctrl), _lib.ptr(g_scal), _lib.ptr(four), _lib.ptr(ws),
+                                                 ws.numel(), B, Tc, 441, _lib.stream()), "ias_voice_control_backward_ws")
+    assert torch.isfinite(one[2:]).all()                 # rows 0/1 sit on the range ends, where the curve maps' derivatives
+    assert torch.allclose(one, four, rtol=0.0, atol=0.0, equal_nan=True)      # are not finite (in torch autograd neither)
+    small = torch.empty(16, dtype=torch.uint8, device=dev)
+    assert lib.ias_voice_control_backward_ws(_lib.ptr(p), _lib.ptr(g_ctrl), _lib.ptr(g_scal), _lib.ptr(four), _lib.ptr(small),
+                                             small.numel(), B, Tc, 441, _lib.stream()) == -4      # IAS_ERR_WORKSPACE
