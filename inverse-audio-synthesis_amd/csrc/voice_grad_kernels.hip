@@ -370,7 +370,7 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_pitch_kernel(
 // loads, then each wave sums whole intervals in a fixed order (no atomics: bit-reproducible).
 #define CT_INTERVALS 40
 #define CT_SUB 6              // threads per interval in the reduction (CT_INTERVALS * CT_SUB <= GRAD_THREADS)
-#define CT_CAP 4608          // staged samples per workgroup (host checks (CT_INTERVALS + 1) * (1/scale + 2) <= cap)
+#define CT_CAP 4608          // staged samples per workgroup (the host picks nint with (nint + 1) * (1/scale + 2) <= cap)
 
 // the voice's interval sums [5][Tc][2] fp64 live in its spare scratch plane (8-byte aligned inside it)
 __device__ __forceinline__ double* ct_interval_sums(float* planes, int b, int T) {
@@ -389,13 +389,13 @@ __device__ __forceinline__ int ct_first_sample(int k, float scale, int T) {
 }
 
 __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_ctrl_kernel(
-    float* __restrict__ planes, int T, int Tc, float scale) {
+    float* __restrict__ planes, int T, int Tc, float scale, int nint /* intervals per workgroup, <= CT_INTERVALS */) {
   __shared__ float s_p0[CT_CAP], s_p1[CT_CAP];
   __shared__ int s_start[CT_INTERVALS + 1];
   __shared__ int s_range[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k0 = blockIdx.x * CT_INTERVALS, row = blockIdx.y, b = blockIdx.z;
-  const int k1 = min(k0 + CT_INTERVALS, Tc), nk = k1 - k0;
+  const int k0 = blockIdx.x * nint, row = blockIdx.y, b = blockIdx.z;
+  const int k1 = min(k0 + nint, Tc), nk = k1 - k0;
   const int plane_of_row[IAS_NCTRL] = {PL_GARG1, PL_GAMP1, PL_GARG2, PL_GAMP2, PL_GAMPN};
   const float* src = planes + ((size_t)b * IAS_GRAD_PLANES + plane_of_row[row]) * T;
   if (tid < 2) s_range[tid] = ct_first_sample(tid == 0 ? k0 : k1, scale, T);
@@ -512,8 +512,10 @@ extern "C" int ias_voice_backward_norm(const float* ctrl, const void* vconst, co
   const int ntiles = (T + GRAD_TILE - 1) / GRAD_TILE;
   if (ntiles > 65535) return IAS_ERR_UNSUPPORTED;
   const float scale = (float)(Tc - 1) / (float)(T - 1);
-  // K3 stages CT_INTERVALS + 1 control intervals of samples in LDS and keeps its interval sums in the spare plane
-  if ((double)(CT_INTERVALS + 1) * ((double)(T - 1) / (double)(Tc - 1) + 2.0) > (double)CT_CAP) return IAS_ERR_UNSUPPORTED;
+  // K3 stages nint + 1 control intervals of samples in LDS (as many as fit, at most CT_INTERVALS) and keeps its interval
+  // sums in the spare plane
+  const int nint = min(CT_INTERVALS, (int)((double)CT_CAP / ((double)(T - 1) / (double)(Tc - 1) + 2.0)) - 1);
+  if (nint < 1) return IAS_ERR_UNSUPPORTED;
   if ((size_t)IAS_NCTRL * Tc * 2 * sizeof(double) + 8 > (size_t)T * sizeof(float)) return IAS_ERR_UNSUPPORTED;
   const IasVoiceConst* vc = (const IasVoiceConst*)vconst;
   const dim3 grid(ntiles, B), block(GRAD_THREADS);
@@ -523,8 +525,8 @@ extern "C" int ias_voice_backward_norm(const float* ctrl, const void* vconst, co
                      partials, T, Tc, ntiles, scale, rownorm);
   hipLaunchKernelGGL(voice_grad_pitch_kernel, grid, block, 0, stream, ctrl, vc, planes, partials, T, Tc, ntiles,
                      scale);
-  hipLaunchKernelGGL(voice_grad_ctrl_kernel, dim3((Tc + CT_INTERVALS - 1) / CT_INTERVALS, IAS_NCTRL, B), block, 0,
-                     stream, planes, T, Tc, scale);
+  hipLaunchKernelGGL(voice_grad_ctrl_kernel, dim3((Tc + nint - 1) / nint, IAS_NCTRL, B), block, 0,
+                     stream, planes, T, Tc, scale, nint);
   hipLaunchKernelGGL(voice_grad_ctrl_combine_kernel, dim3((Tc + GRAD_THREADS - 1) / GRAD_THREADS, IAS_NCTRL, B), block,
                      0, stream, planes, g_ctrl, T, Tc);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;

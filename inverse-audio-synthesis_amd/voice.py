@@ -38,8 +38,10 @@ class SynthConfig:
         self.no_grad = bool(no_grad)
         self.debug = bool(debug)
         self.eps = float(eps)
-        assert self.control_rate == S.CONTROL_RATE and self.eps == S.EPS, \
-            "the HIP control kernel is built for control_rate=441, eps=1e-6"
+        # the control rate is a kernel argument (a render whose control window per tile or whose samples per control
+        # interval do not fit the kernels' LDS stages is refused by the C ABI with IAS_ERR_UNSUPPORTED); eps is compiled in
+        assert self.control_rate > 0 and self.control_buffer_size > 1, "control_rate * buffer_size_seconds must exceed 1"
+        assert self.eps == S.EPS, "the HIP control kernels are built for eps=1e-6"
 
 
 class _ModuleView:

@@ -70,6 +70,26 @@ def test_gradient_matches_oracle_autograd(lib, dev, B, sr, sec, seed, normalize)
     assert (torch.sign(g[big]) == torch.sign(ref[big])).all()
 
 
+@pytest.mark.parametrize("control_rate,sr,sec", [(100, 16000, 1.0), (882, 44100, 1.0)])
+def test_gradient_at_other_control_rates(lib, dev, control_rate, sr, sec):
+    """the backward kernels take the control rate as an argument as well (interval sums of the transposed upsample,
+    ramps of the control-rate backward)"""
+    from inverse_audio_synthesis_amd.voice import SynthConfig, Voice
+    B = 4
+    cfg = so.VoiceConfig(B, sr, sec, control_rate=control_rate)
+    v = Voice(SynthConfig(batch_size=B, sample_rate=sr, buffer_size_seconds=sec, control_rate=control_rate,
+                          reproducible=False)).to(dev)
+    p0 = so.sample_params01(cfg, 9)
+    w = torch.randn((B, cfg.buffer_size), generator=torch.Generator().manual_seed(31))
+    ref = _oracle_grad(cfg, p0, so.make_noise(cfg), w, True)
+    p = p0.to(dev).requires_grad_(True)
+    (v.render(p) * w.to(dev)).sum().backward()
+    g = p.grad.cpu().double()
+    assert torch.isfinite(g).all()
+    assert max(rel_l2(g[b], ref[b]) for b in range(B)) <= 2e-2
+    assert rel_l2(g, ref) <= 5e-3
+
+
 def test_gradient_is_deterministic_and_leaves_forward_untouched(lib, dev):
     v = _voice(dev, 4, 16000, 1.0)
     p0 = so.sample_params01(so.VoiceConfig(4, 16000, 1.0), 5).to(dev)
