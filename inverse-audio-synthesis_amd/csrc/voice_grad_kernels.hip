@@ -26,7 +26,9 @@
 #include "ias_common.h"
 #include "voice_math.h"
 #include "wave_ops.h"
+#include "voice_trig.h"
 #include <cstdint>
+#include <cstdlib>
 
 #define GRAD_THREADS 256
 #define GRAD_WAVES (GRAD_THREADS / 64)
@@ -461,7 +463,426 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_ctrl_combine_kernel(f
   g_ctrl[((size_t)b * IAS_NCTRL + row) * Tc + i] = (float)v;
 }
 
+
+// ================================================================================================ lane-consecutive form
+// K1 / K2 / K3 again for rows with at least 16 samples per control interval (scale * 16 <= 1; every shape the reference
+// uses: 100 samples per interval), with the sample-to-thread mapping of the forward kernel: a thread owns G16_SPT
+// CONSECUTIVE samples of the tile.
+//   * the phase of a sample is (tile carry) + (threads before it: ONE wave scan of the thread totals + the earlier waves'
+//     totals) + a running sum inside the thread: two barriers per tile instead of two per 256 samples (the chunk loop of
+//     the first form was a chain of 16 workgroup scans), no DPP scan per sample.
+//   * global memory is touched in whole 1 KB rows per wave instruction, as in the forward kernel: the wave's 1024 samples
+//     of each input plane arrive in a 4 KB LDS block by LDS-DMA (16 KB per wave for the four planes), a lane reads its
+//     16 samples from there, the two g_arg planes leave through the blocks of the increments.  (Lanes reading their 64
+//     bytes straight from global memory -- 16-byte pieces 64 bytes apart -- made the kernel 2.4x slower than its
+//     arithmetic: 142 us for the loads and stores alone.)
+//   * the transposed upsample is folded in: a thread's samples lie in at most two control intervals (k_first, k_first + 1),
+//     so it leaves per row the two partial interval sums (A = sum w0 g, B = sum w1 g; accumulated in fp32 over its <= 16
+//     samples), and one thread per (row, interval) adds the partials of the threads that touch the interval in sample
+//     order, in fp64 -> per-TILE interval sums [B][ntiles][5][kslots][2] (fixed order, no atomics).  The three amplitude
+//     planes and the two pitch planes of the first form are never written, K3's pass over five planes is gone;
+//     voice_grad_fold_combine_kernel adds the <= 2 tiles an interval lies in.
+//   * sin / cos / tanh: the forward kernel's fp32 revolution split (voice_trig.h) instead of the fp64 reduction.
+// A tile that is not whole (the row's last) or a row length that is not a multiple of 4 takes the same code with guarded
+// scalar accesses instead of the LDS blocks.
+#define G16_SPT 16
+#define G16_NOK 0x3fffffff       // k_first of a thread that owns no sample
+#define G16_WAVE_FLOATS 4096     // staging per wave: four planes of 1024 samples
+#define G16_LDS_BYTES (GRAD_WAVES * G16_WAVE_FLOATS * 4)
+typedef float g16_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void g16_lds_void;
+typedef const __attribute__((address_space(1))) void g16_glb_void;
+
+__device__ __forceinline__ double* g16_tile_sums(float* planes, int b, int T, int tile, int kslots) {
+  return ct_interval_sums(planes, b, T) + (size_t)tile * IAS_NCTRL * kslots * 2;
+}
+__device__ __forceinline__ const double* g16_tile_sums(const float* planes, int b, int T, int tile, int kslots) {
+  return ct_interval_sums(const_cast<float*>(planes), b, T) + (size_t)tile * IAS_NCTRL * kslots * 2;
+}
+
+// The wave's 1024 samples [j_wave, j_wave + 1024) of a plane row -> its LDS block, by LDS-DMA.  Block layout (the forward
+// kernel's): position p's 16 samples are its own 64 bytes, the four 16-byte granules XOR-permuted by (p >> 2) & 3 --
+// conflict-free for the ds_read/write_b128 of consecutive positions, and lane-linear (the DMA's destination order) once
+// the SOURCE granule of DMA lane i is i ^ (i >> 4).
+__device__ __forceinline__ void g16_dma(const float* __restrict__ row, int j_wave, float* blk, int lane) {
+  const float* src = row + j_wave + 4 * (lane ^ (lane >> 4));
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    __builtin_amdgcn_global_load_lds((g16_glb_void*)(src + q * 256), (g16_lds_void*)(blk + q * 256), 16, 0, 0);
+}
+__device__ __forceinline__ float* g16_slot(float* blk, int pos, int q) { return blk + pos * 16 + 4 * (q ^ ((pos >> 2) & 3)); }
+// the block back to a plane row, whole 1 KB rows per instruction
+__device__ __forceinline__ void g16_copy_out(float* __restrict__ row, int j_wave, const float* blk, int lane) {
+  const int dst = 4 * (lane ^ (lane >> 4));
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<g16_f4*>(row + j_wave + q * 256 + dst) = *reinterpret_cast<const g16_f4*>(blk + q * 256 + lane * 4);
+}
+// four consecutive samples (group q of position pos): from the wave's block, or guarded from the row itself
+template <bool FAST>
+__device__ __forceinline__ void g16_get4(const float* blk, int pos, int q, const float* __restrict__ row, int j, int T,
+                                         float (&v)[4]) {
+  if (FAST) {
+    const g16_f4 x = *reinterpret_cast<const g16_f4*>(g16_slot(const_cast<float*>(blk), pos, q));
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  } else {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) v[x] = j + x < T ? row[j + x] : 0.0f;
+  }
+}
+
+// LDS of a lane-consecutive kernel besides the staging blocks
+struct G16Shared {
+  double w[2 * GRAD_WAVES];
+  double red[GRAD_WAVES * 8];
+  double carry[2 * GRAD_THREADS];
+  int kfirst[GRAD_THREADS];
+  double out[8];
+};
+// The fold partials {A, B of interval k_first; A, B of interval k_first + 1} of fold row r, sample-order position p of the
+// tile: kept in the LAST plane block of the wave that owns the position (free once its sample loop is done).
+// REV: wave w owns positions 64 (3 - w) ... (K2 walks the tile backwards).
+template <bool REV>
+__device__ __forceinline__ g16_f4* g16_fold_slot(float* stage, int r, int p) {
+  const int w = REV ? GRAD_WAVES - 1 - (p >> 6) : (p >> 6);
+  return reinterpret_cast<g16_f4*>(stage + w * G16_WAVE_FLOATS + 3 * 1024 + r * 256 + (p & 63) * 4);
+}
+// s_kfirst[p] non-decreasing in p (G16_NOK: none).  Thread idx < NR * kslots adds, for interval k_lo + kk, the partials of
+// the positions with k_first in {k - 1, k} in ascending p -> out[(rows[r] * kslots + kk) * 2 + {0, 1}].
+template <int NR, bool REV>
+__device__ __forceinline__ void g16_fold(float* stage, const int* s_kfirst, int k_lo, int kslots, const int (&rows)[NR],
+                                         double* __restrict__ out, int tid) {
+  for (int idx = tid; idx < NR * kslots; idx += GRAD_THREADS) {
+    const int r = idx / kslots, kk = idx - r * kslots, k = k_lo + kk;
+    int lo = 0, hi = GRAD_THREADS;                     // first p with k_first(p) >= k - 1
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (s_kfirst[m] < k - 1) lo = m + 1; else hi = m; }
+    double A = 0.0, B = 0.0;
+    for (int p = lo; p < GRAD_THREADS; ++p) {
+      const int kf = s_kfirst[p];
+      if (kf > k) break;
+      const g16_f4 f = *g16_fold_slot<REV>(stage, r, p);
+      if (kf == k) { A += (double)f.x; B += (double)f.y; } else { A += (double)f.z; B += (double)f.w; }
+    }
+    out[((size_t)rows[r] * kslots + kk) * 2] = A;
+    out[((size_t)rows[r] * kslots + kk) * 2 + 1] = B;
+  }
+}
+// the three control points a thread's samples interpolate between (its run lies in at most two intervals)
+struct G16Ctrl { float v0, v1, v2; };
+__device__ __forceinline__ G16Ctrl g16_ctrl(const float* __restrict__ crow, int k_first, int Tc) {
+  G16Ctrl c;
+  c.v0 = crow[min(k_first, Tc - 1)]; c.v1 = crow[min(k_first + 1, Tc - 1)]; c.v2 = crow[min(k_first + 2, Tc - 1)];
+  return c;
+}
+// lerp of a sample in interval k_first (first) or k_first + 1 -- the arithmetic of ias_lerp on the same operands
+__device__ __forceinline__ float g16_lerp(const G16Ctrl& c, bool first, float w0, float w1) {
+  return ias_lerp(first ? c.v0 : c.v1, first ? c.v1 : c.v2, w0, w1);
+}
+
+template <bool FAST>
+__device__ __forceinline__ void g16_sample_tile(
+    G16Shared& sh, float* stage, const float* __restrict__ cb, const IasVoiceConst& vc, const float* __restrict__ nrow,
+    const float* __restrict__ grow, float* __restrict__ pl, const double* __restrict__ tile_sums_b,
+    double* __restrict__ partials_bt, double* __restrict__ isum_bt, int T, int Tc, int tile, float scale, float n_div,
+    float n_corr, int n_tstar, bool norm, int kslots) {
+  double* s_w = sh.w; double* s_red = sh.red; double* s_carry = sh.carry; double* s_out = sh.out;
+  int* s_kfirst = sh.kfirst;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j_wave = tile * GRAD_TILE + wave * 1024, j0 = j_wave + lane * G16_SPT;
+  const float* pi1 = pl + (size_t)PL_INC1 * T;
+  const float* pi2 = pl + (size_t)PL_INC2 * T;
+  float* blk = stage + wave * G16_WAVE_FLOATS;      // blocks: inc_1 (-> g_arg1) | inc_2 (-> g_arg2) | noise | g
+  if (FAST) {
+    g16_dma(pi1, j_wave, blk, lane);
+    g16_dma(pi2, j_wave, blk + 1024, lane);
+    g16_dma(nrow, j_wave, blk + 2048, lane);
+    g16_dma(grow, j_wave, blk + 3072, lane);
+  }
+  double carry1, carry2;
+  tile_carry<false>(tile_sums_b, 2, 0, 1, 0, tile, s_carry, tid, carry1, carry2);
+  if (FAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the wave's own DMA has landed
+  double tot1 = 0.0, tot2 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float a1[4], a2[4];
+    g16_get4<FAST>(blk, lane, q, pi1, j0 + 4 * q, T, a1);
+    g16_get4<FAST>(blk + 1024, lane, q, pi2, j0 + 4 * q, T, a2);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { tot1 += (double)fabsf(a1[x]); tot2 += (double)fabsf(a2[x]); }   // sign = clamp flag (K0)
+  }
+  const double in1 = wave_incl_scan(tot1, lane), in2 = wave_incl_scan(tot2, lane);
+  if (lane == 63) { s_w[wave] = in1; s_w[GRAD_WAVES + wave] = in2; }
+  __syncthreads();
+  double run1 = carry1 + (in1 - tot1), run2 = carry2 + (in2 - tot2);   // sums of fp32 values below 2^19: exact in any order
+  for (int w = 0; w < wave; ++w) { run1 += s_w[w]; run2 += s_w[GRAD_WAVES + w]; }
+
+  const float n_inv = 1.0f / n_div;            // (the first form divides every sample: one rounding apart)
+  const int k_first = (int)ias_mul(scale, (float)j0);
+  const G16Ctrl ca1 = g16_ctrl(cb + 1 * Tc, k_first, Tc), ca2 = g16_ctrl(cb + 3 * Tc, k_first, Tc),
+                can = g16_ctrl(cb + 4 * Tc, k_first, Tc);
+  // lvl0 lvl1 lvl2 kpart shape gain: fp32 over the thread's 16 samples, fp64 across threads and tiles; phi_1 phi_2 (the
+  // g_arg totals K2's suffix sums continue from): fp64 throughout
+  float accf[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  double accp[2] = {0.0, 0.0};
+  float ta[3] = {0.f, 0.f, 0.f}, tw[3] = {0.f, 0.f, 0.f}, pa[3] = {0.f, 0.f, 0.f}, pw[3] = {0.f, 0.f, 0.f};
+  // Four samples per trip of a loop that is NOT unrolled (fully unrolled, the 16 samples' live values spilled at every
+  // register budget); the increments are read again from the block.
+#pragma unroll 1
+  for (int q = 0; q < G16_SPT / 4; ++q) {
+    const int jq = j0 + 4 * q;
+    float a1[4], a2[4], nz[4], gg[4], o1[4], o2[4];
+    g16_get4<FAST>(blk, lane, q, pi1, jq, T, a1);
+    g16_get4<FAST>(blk + 1024, lane, q, pi2, jq, T, a2);
+    g16_get4<FAST>(blk + 2048, lane, q, nrow, jq, T, nz);
+    g16_get4<FAST>(blk + 3072, lane, q, grow, jq, T, gg);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int j = jq + x;
+      float g = gg[x];
+      if (norm) { g = g * n_inv; if (j == n_tstar) g = g + n_corr; }
+      run1 += (double)fabsf(a1[x]); run2 += (double)fabsf(a2[x]);
+      const float arg1 = ias_add((float)run1, vc.phi_1), arg2 = ias_add((float)run2, vc.phi_2);
+      const float real = ias_mul(scale, (float)j);
+      const int i0 = (int)real;
+      const float w1 = ias_sub(real, (float)i0), w0 = ias_sub(1.0f, w1);
+      const bool first = i0 == k_first;
+      const float amp1 = g16_lerp(ca1, first, w0, w1), amp2 = g16_lerp(ca2, first, w0, w1), ampn = g16_lerp(can, first, w0, w1);
+      float fp, ft;
+      voice_rev_split(arg1, fp, ft);
+      const float s1 = __builtin_amdgcn_sinf(fp + ft), c1 = __builtin_amdgcn_cosf(fp + ft);
+      float s2, c2;
+      bool flip;
+      voice_sincos(arg2, s2, c2, flip);
+      if (flip) { s2 = -s2; c2 = -c2; }
+      const float th = __builtin_copysignf(voice_tanh_abs(vc.kpart * s2 * 0.5f), s2);
+      const float env2 = 1.0f + vc.shape * c2;
+      const float core2 = vc.shape_gain * th * env2;
+      const float x_amp1 = g * vc.lvl0 * c1, x_amp2 = g * vc.lvl1 * core2, x_ampn = g * vc.lvl2 * nz[x];
+      const float g_arg1 = -g * vc.lvl0 * amp1 * s1;
+      const float ga2 = g * vc.lvl1 * amp2;                      // d loss / d (gain * tanh * env2)
+      const float sech2 = 1.0f - th * th;
+      const float g_arg2 = ga2 * vc.shape_gain * (sech2 * (0.5f * vc.kpart) * c2 * env2 - th * vc.shape * s2);
+      o1[x] = g_arg1; o2[x] = g_arg2;
+      // samples beyond T carry g = 0: every term below vanishes
+      accf[0] += g * c1 * amp1;
+      accf[1] += g * core2 * amp2;
+      accf[2] += g * nz[x] * ampn;
+      accf[3] += ga2 * vc.shape_gain * sech2 * (0.5f * s2) * env2;
+      accf[4] += ga2 * vc.shape_gain * th * c2;
+      accf[5] += ga2 * th * env2;
+      accp[0] += (double)g_arg1;
+      accp[1] += (double)g_arg2;
+      // the transposed upsample of the three amplitude rows: totals and the share of the thread's first interval
+      const float m0 = first ? 1.0f : 0.0f;
+      const float xs[3] = {x_amp1, x_amp2, x_ampn};
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float xw = w1 * xs[r];
+        ta[r] += xs[r]; tw[r] += xw;
+        pa[r] = fmaf(m0, xs[r], pa[r]); pw[r] = fmaf(m0, xw, pw[r]);
+      }
+    }
+    if (FAST) {      // the cotangents of the phases take the places of the increments they came from
+      *reinterpret_cast<g16_f4*>(g16_slot(blk, lane, q)) = (g16_f4){o1[0], o1[1], o1[2], o1[3]};
+      *reinterpret_cast<g16_f4*>(g16_slot(blk + 1024, lane, q)) = (g16_f4){o2[0], o2[1], o2[2], o2[3]};
+    } else {
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        if (jq + x < T) { pl[(size_t)PL_GARG1 * T + jq + x] = o1[x]; pl[(size_t)PL_GARG2 * T + jq + x] = o2[x]; }
+    }
+  }
+  if (FAST) {
+    g16_copy_out(pl + (size_t)PL_GARG1 * T, j_wave, blk, lane);
+    g16_copy_out(pl + (size_t)PL_GARG2 * T, j_wave, blk + 1024, lane);
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    *g16_fold_slot<false>(stage, r, tid) = (g16_f4){pa[r] - pw[r], pw[r], (ta[r] - pa[r]) - (tw[r] - pw[r]), tw[r] - pw[r]};
+  s_kfirst[tid] = j0 < T ? k_first : G16_NOK;
+  const double acc[8] = {(double)accf[0], (double)accf[1], (double)accf[2], (double)accf[3], (double)accf[4], (double)accf[5],
+                         accp[0], accp[1]};
+  block_sums<8>(acc, s_out, s_red, tid);      // its barriers also publish the fold partials and s_kfirst
+  __syncthreads();
+  if (tid == 0) {
+    partials_bt[GS_LVL0] = s_out[0]; partials_bt[GS_LVL1] = s_out[1]; partials_bt[GS_LVL2] = s_out[2];
+    partials_bt[GS_KPART] = s_out[3]; partials_bt[GS_SHAPE] = s_out[4]; partials_bt[GS_GAIN] = s_out[5];
+    partials_bt[GS_PHI_1] = s_out[6]; partials_bt[GS_PHI_2] = s_out[7];
+  }
+  const int rows[3] = {1, 3, 4};               // amp1, amp2, ampn among the five control rows
+  g16_fold<3, false>(stage, s_kfirst, (int)ias_mul(scale, (float)(tile * GRAD_TILE)), kslots, rows, isum_bt, tid);
+}
+
+__global__ __launch_bounds__(GRAD_THREADS, 2) void voice_grad_sample16_kernel(
+    const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst, const float* __restrict__ noise,
+    const float* __restrict__ g_mixed, float* __restrict__ planes, const double* __restrict__ tile_sums,
+    double* __restrict__ partials, int T, int Tc, int ntiles, float scale, const float* __restrict__ rownorm, int kslots) {
+  extern __shared__ __attribute__((aligned(16))) float g16_stage[];
+  __shared__ G16Shared sh;
+  const int tile = blockIdx.x, b = blockIdx.y;
+  const float n_div = rownorm ? rownorm[4 * b] : 1.0f, n_corr = rownorm ? rownorm[4 * b + 2] : 0.0f;
+  const int n_tstar = rownorm ? __float_as_int(rownorm[4 * b + 1]) : -1;
+  const IasVoiceConst vc = vconst[b];
+  const float* cb = ctrl + (size_t)b * IAS_NCTRL * Tc;
+  float* pl = planes + (size_t)b * IAS_GRAD_PLANES * T;
+  double* isum = g16_tile_sums(planes, b, T, tile, kslots);
+  const bool fast = (T & 3) == 0 && (tile + 1) * GRAD_TILE <= T;
+  if (fast)
+    g16_sample_tile<true>(sh, g16_stage, cb, vc, noise + (size_t)b * T, g_mixed + (size_t)b * T, pl,
+                          tile_sums + (size_t)b * ntiles * 2, partials + ((size_t)b * ntiles + tile) * IAS_GRAD_NS, isum, T, Tc,
+                          tile, scale, n_div, n_corr, n_tstar, rownorm != nullptr, kslots);
+  else
+    g16_sample_tile<false>(sh, g16_stage, cb, vc, noise + (size_t)b * T, g_mixed + (size_t)b * T, pl,
+                           tile_sums + (size_t)b * ntiles * 2, partials + ((size_t)b * ntiles + tile) * IAS_GRAD_NS, isum, T, Tc,
+                           tile, scale, n_div, n_corr, n_tstar, rownorm != nullptr, kslots);
+}
+
+// K2 in the same form: suffix sums of g_arg (thread order = DESCENDING sample order: wave w owns the positions
+// 64 (3 - w) ..., lane l the position 63 - l of those), the pitch-modulation cotangents folded into interval sums (rows 0
+// and 2), partial sums for f0 and depth.
+template <bool FAST>
+__device__ __forceinline__ void g16_pitch_tile(G16Shared& sh, float* stage, const float* __restrict__ cb,
+                                               const IasVoiceConst& vc, const float* __restrict__ pl,
+                                               const double* __restrict__ partials_b, double* __restrict__ partials_bt,
+                                               double* __restrict__ isum_bt, int T, int Tc, int ntiles, int tile, float scale,
+                                               int kslots) {
+  double* s_w = sh.w; double* s_red = sh.red; double* s_carry = sh.carry; double* s_out = sh.out;
+  int* s_kfirst = sh.kfirst;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rt = GRAD_THREADS - 1 - tid, pos = 63 - lane;   // position of the thread's run in the tile / in its wave's block
+  const int j_wave = tile * GRAD_TILE + (GRAD_WAVES - 1 - wave) * 1024, j0 = j_wave + pos * G16_SPT;
+  const float* pg1 = pl + (size_t)PL_GARG1 * T;
+  const float* pg2 = pl + (size_t)PL_GARG2 * T;
+  const float* pi1 = pl + (size_t)PL_INC1 * T;
+  const float* pi2 = pl + (size_t)PL_INC2 * T;
+  float* blk = stage + wave * G16_WAVE_FLOATS;      // blocks: g_arg1 | g_arg2 | inc_1 | inc_2
+  if (FAST) {
+    g16_dma(pg1, j_wave, blk, lane);
+    g16_dma(pg2, j_wave, blk + 1024, lane);
+    g16_dma(pi1, j_wave, blk + 2048, lane);
+    g16_dma(pi2, j_wave, blk + 3072, lane);
+  }
+  // carry-in of the reverse scan: g_arg totals of the later tiles (K1 left them in the phi slots)
+  double carry1, carry2;
+  tile_carry<true>(partials_b, IAS_GRAD_NS, GS_PHI_1, GS_PHI_2, tile + 1, ntiles, s_carry, tid, carry1, carry2);
+  if (FAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  double tot1 = 0.0, tot2 = 0.0;
+#pragma unroll
+  for (int q = 3; q >= 0; --q) {
+    float g1[4], g2[4];
+    g16_get4<FAST>(blk, pos, q, pg1, j0 + 4 * q, T, g1);
+    g16_get4<FAST>(blk + 1024, pos, q, pg2, j0 + 4 * q, T, g2);
+#pragma unroll
+    for (int x = 3; x >= 0; --x) { tot1 += (double)g1[x]; tot2 += (double)g2[x]; }   // the order of the running sums below
+  }
+  const double in1 = wave_incl_scan(tot1, lane), in2 = wave_incl_scan(tot2, lane);
+  if (lane == 63) { s_w[wave] = in1; s_w[GRAD_WAVES + wave] = in2; }
+  __syncthreads();
+  double run1 = carry1 + (in1 - tot1), run2 = carry2 + (in2 - tot2);
+  for (int w = 0; w < wave; ++w) { run1 += s_w[w]; run2 += s_w[GRAD_WAVES + w]; }
+
+  const int k_first = (int)ias_mul(scale, (float)j0);
+  const G16Ctrl cp1 = g16_ctrl(cb, k_first, Tc), cp2 = g16_ctrl(cb + 2 * Tc, k_first, Tc);
+  const double k = 0.6931471805599453 / 12.0;   // d inc / d pitch = inc * ln2 / 12
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};        // f0_1 depth_1 f0_2 depth_2
+  float ta[2] = {0.f, 0.f}, tw[2] = {0.f, 0.f}, pa[2] = {0.f, 0.f}, pw[2] = {0.f, 0.f};
+#pragma unroll 1
+  for (int q = G16_SPT / 4 - 1; q >= 0; --q) {              // see K1
+    const int jq = j0 + 4 * q;
+    float ga1[4], ga2[4], inc1[4], inc2[4];
+    g16_get4<FAST>(blk, pos, q, pg1, jq, T, ga1);
+    g16_get4<FAST>(blk + 1024, pos, q, pg2, jq, T, ga2);
+    g16_get4<FAST>(blk + 2048, pos, q, pi1, jq, T, inc1);
+    g16_get4<FAST>(blk + 3072, pos, q, pi2, jq, T, inc2);
+#pragma unroll
+    for (int x = 3; x >= 0; --x) {
+      run1 += (double)ga1[x]; run2 += (double)ga2[x];          // inclusive suffix sums
+      const double gc1 = inc1[x] > 0.0f ? run1 * ((double)inc1[x] * k) : 0.0;
+      const double gc2 = inc2[x] > 0.0f ? run2 * ((double)inc2[x] * k) : 0.0;
+      const float real = ias_mul(scale, (float)(jq + x));
+      const int i0 = (int)real;
+      const float w1 = ias_sub(real, (float)i0), w0 = ias_sub(1.0f, w1);
+      const bool first = i0 == k_first;
+      const float pm1 = g16_lerp(cp1, first, w0, w1), pm2 = g16_lerp(cp2, first, w0, w1);
+      acc[0] += gc1; acc[1] += gc1 * (double)pm1;
+      acc[2] += gc2; acc[3] += gc2 * (double)pm2;
+      const float m0 = first ? 1.0f : 0.0f;
+      const float xs[2] = {(float)(gc1 * (double)vc.depth_1), (float)(gc2 * (double)vc.depth_2)};
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const float xw = w1 * xs[r];
+        ta[r] += xs[r]; tw[r] += xw;
+        pa[r] = fmaf(m0, xs[r], pa[r]); pw[r] = fmaf(m0, xw, pw[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+    *g16_fold_slot<true>(stage, r, rt) = (g16_f4){pa[r] - pw[r], pw[r], (ta[r] - pa[r]) - (tw[r] - pw[r]), tw[r] - pw[r]};
+  s_kfirst[rt] = j0 < T ? k_first : G16_NOK;
+  block_sums<4>(acc, s_out, s_red, tid);
+  __syncthreads();
+  if (tid == 0) {
+    partials_bt[GS_F0_1] = s_out[0]; partials_bt[GS_DEPTH_1] = s_out[1];
+    partials_bt[GS_F0_2] = s_out[2]; partials_bt[GS_DEPTH_2] = s_out[3];
+  }
+  const int rows[2] = {0, 2};
+  g16_fold<2, true>(stage, s_kfirst, (int)ias_mul(scale, (float)(tile * GRAD_TILE)), kslots, rows, isum_bt, tid);
+}
+
+__global__ __launch_bounds__(GRAD_THREADS, 2) void voice_grad_pitch16_kernel(
+    const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst, float* __restrict__ planes,
+    double* __restrict__ partials, int T, int Tc, int ntiles, float scale, int kslots) {
+  extern __shared__ __attribute__((aligned(16))) float g16_stage[];
+  __shared__ G16Shared sh;
+  const int tile = blockIdx.x, b = blockIdx.y;
+  const IasVoiceConst vc = vconst[b];
+  const float* cb = ctrl + (size_t)b * IAS_NCTRL * Tc;
+  const float* pl = planes + (size_t)b * IAS_GRAD_PLANES * T;
+  double* isum = g16_tile_sums(planes, b, T, tile, kslots);
+  const bool fast = (T & 3) == 0 && (tile + 1) * GRAD_TILE <= T;
+  if (fast)
+    g16_pitch_tile<true>(sh, g16_stage, cb, vc, pl, partials + (size_t)b * ntiles * IAS_GRAD_NS,
+                         partials + ((size_t)b * ntiles + tile) * IAS_GRAD_NS, isum, T, Tc, ntiles, tile, scale, kslots);
+  else
+    g16_pitch_tile<false>(sh, g16_stage, cb, vc, pl, partials + (size_t)b * ntiles * IAS_GRAD_NS,
+                          partials + ((size_t)b * ntiles + tile) * IAS_GRAD_NS, isum, T, Tc, ntiles, tile, scale, kslots);
+}
+
+// g_ctrl[i] = A[i] + B[i - 1] (the last control point is its own upper neighbour) from the per-tile interval sums: an
+// interval's samples [first(k), first(k + 1)) lie in the tiles first(k) / GRAD_TILE ... (first(k + 1) - 1) / GRAD_TILE,
+// added in ascending tile order.
+__device__ __forceinline__ double g16_interval(const float* planes, int b, int T, int row, int k, int which, float scale,
+                                               int kslots) {
+  const int f0 = ct_first_sample(k, scale, T), f1 = ct_first_sample(k + 1, scale, T);
+  double v = 0.0;
+  if (f1 > f0)
+    for (int t = f0 / GRAD_TILE; t <= (f1 - 1) / GRAD_TILE; ++t) {
+      const int kk = k - (int)ias_mul(scale, (float)(t * GRAD_TILE));
+      if (kk >= 0 && kk < kslots) v += g16_tile_sums(planes, b, T, t, kslots)[((size_t)row * kslots + kk) * 2 + which];
+    }
+  return v;
+}
+__global__ __launch_bounds__(GRAD_THREADS) void voice_grad_fold_combine_kernel(const float* __restrict__ planes,
+                                                                               float* __restrict__ g_ctrl, int T, int Tc,
+                                                                               float scale, int kslots) {
+  const int i = blockIdx.x * GRAD_THREADS + threadIdx.x, row = blockIdx.y, b = blockIdx.z;
+  if (i >= Tc) return;
+  double v = g16_interval(planes, b, T, row, i, 0, scale, kslots);
+  if (i > 0) v += g16_interval(planes, b, T, row, i - 1, 1, scale, kslots);
+  if (i == Tc - 1) v += g16_interval(planes, b, T, row, i, 1, scale, kslots);
+  g_ctrl[((size_t)b * IAS_NCTRL + row) * Tc + i] = (float)v;
+}
+
+
 // ------------------------------------------------------------------------------------------------ C ABI
+// IAS_VOICE_GRAD_V1=1: the chunk-scan kernels + separate transposed upsample for every shape (A/B, and what shapes with
+// fewer than 16 samples per control interval take anyway)
+static bool voice_grad_force_v1() {
+  static const bool v = [] { const char* e = getenv("IAS_VOICE_GRAD_V1"); return e && e[0] && e[0] != '0'; }();
+  return v;
+}
 extern "C" int ias_voice_grad_tiles(int T) { return T > 0 ? (T + GRAD_TILE - 1) / GRAD_TILE : IAS_ERR_ARG; }
 extern "C" int ias_voice_grad_nscalars(void) { return IAS_GRAD_NS; }
 extern "C" int ias_voice_grad_nplanes(void) { return IAS_GRAD_PLANES; }
@@ -512,15 +933,36 @@ extern "C" int ias_voice_backward_norm(const float* ctrl, const void* vconst, co
   const int ntiles = (T + GRAD_TILE - 1) / GRAD_TILE;
   if (ntiles > 65535) return IAS_ERR_UNSUPPORTED;
   const float scale = (float)(Tc - 1) / (float)(T - 1);
-  // K3 stages nint + 1 control intervals of samples in LDS (as many as fit, at most CT_INTERVALS) and keeps its interval
-  // sums in the spare plane
+  // lane-consecutive form: >= 16 samples per control interval and the per-tile interval sums fit the spare plane
+  const int kslots = (int)(scale * (float)GRAD_TILE) + 3;
+  const bool fold = scale * 16.0f <= 1.0f && !voice_grad_force_v1() &&
+                    (size_t)ntiles * IAS_NCTRL * kslots * 2 * sizeof(double) + 8 <= (size_t)T * sizeof(float);
+  // first form: K3 stages nint + 1 control intervals of samples in LDS (as many as fit, at most CT_INTERVALS) and keeps
+  // its interval sums in the spare plane
   const int nint = min(CT_INTERVALS, (int)((double)CT_CAP / ((double)(T - 1) / (double)(Tc - 1) + 2.0)) - 1);
-  if (nint < 1) return IAS_ERR_UNSUPPORTED;
-  if ((size_t)IAS_NCTRL * Tc * 2 * sizeof(double) + 8 > (size_t)T * sizeof(float)) return IAS_ERR_UNSUPPORTED;
+  if (!fold && (nint < 1 || (size_t)IAS_NCTRL * Tc * 2 * sizeof(double) + 8 > (size_t)T * sizeof(float)))
+    return IAS_ERR_UNSUPPORTED;
   const IasVoiceConst* vc = (const IasVoiceConst*)vconst;
   const dim3 grid(ntiles, B), block(GRAD_THREADS);
   hipLaunchKernelGGL(voice_grad_inc_kernel, grid, block, 0, stream, ctrl, vc, planes, tile_sums, T, Tc, ntiles,
                      1.0 / (double)sample_rate, scale);
+  if (fold) {
+    static const bool lds_ok = [] {      // 64 KB of staging blocks + the static part: above the default dynamic limit
+      const bool a = hipFuncSetAttribute((const void*)voice_grad_sample16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         G16_LDS_BYTES) == hipSuccess;
+      const bool c = hipFuncSetAttribute((const void*)voice_grad_pitch16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         G16_LDS_BYTES) == hipSuccess;
+      return a && c;
+    }();
+    if (!lds_ok) return IAS_ERR_LAUNCH;
+    hipLaunchKernelGGL(voice_grad_sample16_kernel, grid, block, G16_LDS_BYTES, stream, ctrl, vc, noise, g_mixed, planes,
+                       tile_sums, partials, T, Tc, ntiles, scale, rownorm, kslots);
+    hipLaunchKernelGGL(voice_grad_pitch16_kernel, grid, block, G16_LDS_BYTES, stream, ctrl, vc, planes, partials, T, Tc,
+                       ntiles, scale, kslots);
+    hipLaunchKernelGGL(voice_grad_fold_combine_kernel, dim3((Tc + GRAD_THREADS - 1) / GRAD_THREADS, IAS_NCTRL, B), block, 0,
+                       stream, planes, g_ctrl, T, Tc, scale, kslots);
+    return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(voice_grad_sample_kernel, grid, block, 0, stream, ctrl, vc, noise, g_mixed, planes, tile_sums,
                      partials, T, Tc, ntiles, scale, rownorm);
   hipLaunchKernelGGL(voice_grad_pitch_kernel, grid, block, 0, stream, ctrl, vc, planes, partials, T, Tc, ntiles,

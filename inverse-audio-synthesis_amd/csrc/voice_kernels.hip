@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include "voice_math.h"
 #include "wave_ops.h"
+#include "voice_trig.h"
 #include "voice_table.h"
 
 #define VOICE_THREADS 256                     // control-rate kernels
@@ -204,42 +205,6 @@ extern "C" int ias_voice_debug_set_stamps(unsigned long long* p) {
 #else
 #define VSTAMP(slot) do {} while (0)
 #endif
-
-// a / (2 pi) in revolutions as fp + t: fp = fract(fl(a * c_hi)) exactly, t = the exact rounding residual of that
-// product + a * c_lo (c_hi + c_lo = 1 / (2 pi) to 2^-52 relative) -- the fp64 product of the first version in five
-// fp32 instructions; |error| < 1e-9 revolutions for |a| <= 1e6 rad.
-__device__ __forceinline__ void voice_rev_split(float a, float& fp, float& t) {
-  const float c_hi = 0.15915493667125702f, c_lo = 6.4206382432985265e-09f;
-  const float p = a * c_hi;
-  const float e = fmaf(a, c_hi, -p);
-  fp = __builtin_amdgcn_fractf(p);
-  t = fmaf(a, c_lo, e);
-}
-__device__ __forceinline__ float voice_cos(float a) {
-  float fp, t;
-  voice_rev_split(a, fp, t);
-  return __builtin_amdgcn_cosf(fp + t);
-}
-// sin and cos of the square-saw VCO's phase.  The shaper multiplies sin by up to ~2500 before tanh, so sin needs
-// RELATIVE accuracy at its zero crossings: reduce to r2 in [-1/4, 1/4] around the nearest crossing (fp - q/2 is exact,
-// the residual t is added last), sin(2 pi r) = (-1)^q sin(2 pi r2), q = rint(2 r) in {0, 1, 2}.
-// -> sin(2 pi r2), cos(2 pi r2) and flip = (q == 1): the true values are both negated when flip is set (the caller
-// folds the sign into its products: two selects instead of a sign factor and two multiplies).
-__device__ __forceinline__ void voice_sincos(float a, float& s, float& c, bool& flip) {
-  float fp, t;
-  voice_rev_split(a, fp, t);
-  const float r = fp + t;
-  const float q = __builtin_rintf(r + r);
-  const float r2 = fmaf(q, -0.5f, fp) + t;
-  flip = (q == 1.0f);
-  s = __builtin_amdgcn_sinf(r2);
-  c = __builtin_amdgcn_cosf(r2);
-}
-// |tanh(z)| = (1 - e^{-2|z|}) / (1 + e^{-2|z|})   (v_exp_f32 + v_rcp_f32; max abs error 1.3e-7)
-__device__ __forceinline__ float voice_tanh_abs(float z) {
-  const float t = __builtin_amdgcn_exp2f(-2.885390081777927f * fabsf(z));
-  return (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
-}
 
 typedef __attribute__((address_space(3))) void voice_lds_void;
 typedef const __attribute__((address_space(3))) char voice_lds_cchar;       // 32-bit LDS addresses: one v_mad / shift-add

@@ -1,32 +1,29 @@
-"""Voice render forward + backward at the headline size (HIP events) and gradient error vs the fp64 oracle on a small case."""
+"""Audio-rate Voice backward alone at the configs[4] shape (B=64 x 4 s @ 44.1 kHz): time per call and a checksum of its
+outputs.  IAS_VOICE_GRAD_V1=1 selects the chunk-scan kernels (A/B).  usage: python scripts/diag/time_voice_grad.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import torch
 from inverse_audio_synthesis_amd.voice import SynthConfig, Voice
-from oracle import synth_oracle as so
+from inverse_audio_synthesis_amd.voice_grad import audio_rate_backward, normalisation_rows
 
 dev = torch.device("cuda:0")
-for (B, sr, sec, seed) in ((4, 16000, 1.0, 0), (4, 16000, 1.0, 2), (2, 44100, 4.0, 3)):
-    cfg = so.VoiceConfig(B, sr, sec)
-    v = Voice(SynthConfig(batch_size=B, sample_rate=sr, buffer_size_seconds=sec, reproducible=False)).to(dev)
-    p0 = so.sample_params01(cfg, seed)
-    w = torch.randn((B, cfg.buffer_size), generator=torch.Generator().manual_seed(100 + seed))
-    pd = p0.double().requires_grad_(True)
-    (ref,) = torch.autograd.grad((so.render_from_params01(cfg, pd, so.make_noise(cfg), "f64") * w.double()).sum(), pd)
-    p = p0.to(dev).requires_grad_(True)
-    (v.render(p) * w.to(dev)).sum().backward()
-    g = p.grad.cpu().double()
-    rel = [((g[b] - ref[b]).norm() / ref[b].norm()).item() for b in range(B)]
-    print(f"B={B} sr={sr} sec={sec} seed={seed}: rel L2 per voice {['%.1e' % r for r in rel]} batch {((g - ref).norm() / ref.norm()).item():.1e}")
-
-B = int(os.environ.get("B", 128))
+B = int(os.environ.get("B", 64))
 v = Voice(SynthConfig(batch_size=B, reproducible=False)).to(dev)
-p = torch.rand(B, 78, generator=torch.Generator().manual_seed(1000)).to(dev)
-for _ in range(2):
-    q = p.clone().requires_grad_(True); a = v.render(q); a.square().mean().backward()
+v.randomize(3)
+audio = v.render()
+g = torch.randn(audio.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+rn = normalisation_rows(g, audio, v.peaks_view()) if hasattr(v, "peaks_view") else None
+ctl = v.rendered_control()
+for _ in range(3):
+    gc, gs = audio_rate_backward(v, v.params01, g, rn, ctl)
 torch.cuda.synchronize()
-ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-q = p.clone().requires_grad_(True)
-ev[0].record(); a = v.render(q); ev[1].record(); loss = a.square().mean(); ev[2].record(); loss.backward(); ev[3].record()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+N = 20
+e0.record()
+for _ in range(N):
+    gc, gs = audio_rate_backward(v, v.params01, g, rn, ctl)
+e1.record()
 torch.cuda.synchronize()
-print(f"B={B} 4 s @ 44.1 kHz: forward {ev[0].elapsed_time(ev[1]):.3f} ms, loss {ev[1].elapsed_time(ev[2]):.3f} ms, backward {ev[2].elapsed_time(ev[3]):.3f} ms")
+print(f"voice backward B={B}: {e0.elapsed_time(e1) / N * 1e3:.1f} us  g_ctrl {gc.double().abs().sum().item():.9e}  "
+      f"g_scal {gs.abs().sum().item():.9e}  finite {bool(torch.isfinite(gc).all() and torch.isfinite(gs).all())}")
