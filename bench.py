@@ -379,7 +379,7 @@ def run_gradstep(args, rank, world, dev):
     64-band PQMF sub-band L1} -> gradient w.r.t. the 78 normalised parameters, all HIP (render and its backward,
     spectral_kernels / spectral_grad_kernels, wide PQMF analysis and its adjoint).  Batch-split, no data-path collective."""
     from inverse_audio_synthesis_amd.pqmf import PQMF
-    from inverse_audio_synthesis_amd.spectral import MultiResolutionSTFTLoss, SubbandL1
+    from inverse_audio_synthesis_amd.spectral import MultiResolutionSTFTLoss, ParallelLossSum, SubbandL1
     from inverse_audio_synthesis_amd.voice import SynthConfig, Voice
     B = args.batch or 64
     cfg = SynthConfig(batch_size=B, sample_rate=SAMPLE_RATE, buffer_size_seconds=SECONDS, reproducible=False)
@@ -388,6 +388,8 @@ def run_gradstep(args, rank, world, dev):
     gram = PQMF(N=64).to(dev)
     mr = MultiResolutionSTFTLoss().to(dev)
     sub = SubbandL1(gram)
+    both = ParallelLossSum(mr, sub)          # the two loss branches on streams of their own, forward and backward
+    both.parallel = os.environ.get("IAS_BENCH_SERIAL_LOSSES", "0") in ("", "0")
     params = torch.rand(B, 78, generator=torch.Generator().manual_seed(1000 + rank)).to(dev).requires_grad_(True)
     tgt = voice.render(torch.rand(B, 78, generator=torch.Generator().manual_seed(2000 + rank)).to(dev)).clone()
     tb, tm = sub.target(tgt), mr.target(tgt)
@@ -397,7 +399,7 @@ def run_gradstep(args, rank, world, dev):
         if ev: ev[0].record()
         a = voice.render(params)
         if ev: ev[1].record()
-        loss = mr(a, targets=tm) + sub(a, target_bands=tb)
+        loss = both(a, [dict(targets=tm), dict(target_bands=tb)])
         if ev: ev[2].record()
         (g,) = torch.autograd.grad(loss, params)
         if ev: ev[3].record()

@@ -81,6 +81,12 @@ long long ias_voice_ctrl_offset(int B, int T, int Tc);
 long long ias_voice_vconst_offset(int B, int T, int Tc);
 long long ias_voice_peaks_offset(int B, int T, int Tc);
 
+/* ctrl [B,5,Tc], vconst [B,16] and (peaks_out non-NULL) the row peaks [B] of the last render, copied out of its workspace in
+ * one launch: what Voice's autograd node keeps for the backward (torchsynth has no counterpart: the reference never
+ * differentiates through its synth, /root/reference/audio_to_params.py:56-172). */
+int ias_voice_save_for_backward(const void* workspace, float* ctrl_out, float* vconst_out, float* peaks_out, int B, int T,
+                                int Tc, void* stream);
+
 /* Copy the B row peaks (max |x| before normalisation) of the last render out of the workspace. */
 int ias_voice_read_peaks(const void* workspace, float* peaks, int B, int T, int Tc, void* stream);
 

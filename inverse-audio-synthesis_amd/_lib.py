@@ -38,6 +38,7 @@ SYMBOLS = {
     "ias_voice_ctrl_offset": (_LL, [_I, _I, _I]),
     "ias_voice_vconst_offset": (_LL, [_I, _I, _I]),
     "ias_voice_read_peaks": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ias_voice_save_for_backward": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ias_voice_grad_tiles": (_I, [_I]),
     "ias_voice_grad_nscalars": (_I, []),
     "ias_voice_grad_nplanes": (_I, []),

@@ -892,6 +892,31 @@ extern "C" long long ias_voice_peaks_offset(int B, int T, int Tc) {
   return (long long)voice_ws_layout(B, T, Tc).off_peak;
 }
 
+// What a render's backward needs of its workspace, copied out in ONE launch (three device-to-device copies were three
+// memcpy nodes of a captured step: 30 us between the render and its first consumer): ctrl [B,5,Tc], vconst [B,16] floats,
+// peaks [B] (NULL: not wanted).
+__global__ __launch_bounds__(256) void voice_save_kernel(const float* __restrict__ ctrl, const float* __restrict__ vconst,
+                                                         const float* __restrict__ peak, float* __restrict__ ctrl_out,
+                                                         float* __restrict__ vconst_out, float* __restrict__ peaks_out,
+                                                         long long nctrl, int nvc, int npk) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < nctrl) ctrl_out[i] = ctrl[i];
+  if (i < nvc) vconst_out[i] = vconst[i];
+  if (peaks_out && i < npk) peaks_out[i] = peak[i];
+}
+extern "C" int ias_voice_save_for_backward(const void* workspace, float* ctrl_out, float* vconst_out, float* peaks_out, int B,
+                                           int T, int Tc, void* stream_) {
+  if (!workspace || !ctrl_out || !vconst_out || B <= 0 || T <= 0 || Tc <= 1) return IAS_ERR_ARG;
+  const VoiceWs w = voice_ws_layout(B, T, Tc);
+  const char* ws = (const char*)workspace;
+  const long long nctrl = (long long)B * IAS_NCTRL * Tc;
+  static_assert(sizeof(IasVoiceConst) == 64, "vconst rows are 16 floats");
+  hipLaunchKernelGGL(voice_save_kernel, dim3((unsigned)((nctrl + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                     (const float*)(ws + w.off_ctrl), (const float*)(ws + w.off_vconst), (const float*)(ws + w.off_peak),
+                     ctrl_out, vconst_out, peaks_out, nctrl, B * 16, B);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
 // Row peaks (|x| max before normalisation) of the last render, for tests/diagnostics.
 extern "C" int ias_voice_read_peaks(const void* workspace, float* peaks_dev, int B, int T, int Tc, void* stream_) {
   if (!workspace || !peaks_dev) return IAS_ERR_ARG;

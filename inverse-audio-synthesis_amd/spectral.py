@@ -461,6 +461,51 @@ def _mrstft_plan_backward(lib, plan, a, tgt, s, g32, nres, eps, consumer_stream)
     return g_audio
 
 
+class ParallelLossSum(nn.Module):
+    """sum_k loss_k(audio, **kwargs_k) with the terms issued on streams of their own: the first on the caller's stream,
+    every other one on a side stream forked from it (and joined before the sum).  autograd runs a node's backward on the
+    stream its forward ran on, so the terms' backward passes overlap the same way.  configs[4] pairs the 3-resolution
+    STFT loss with the 64-band sub-band L1: issued one after the other, the sub-band branch (PQMF analysis, L1, its
+    gradient and the PQMF adjoint: 0.17 ms) waited behind the STFT kernels, whose tails leave most of the chip idle."""
+
+    def __init__(self, *losses):
+        super().__init__()
+        self.losses = nn.ModuleList(losses)
+        self.parallel = True
+
+    def _streams(self, device):
+        # A first term with side streams of its own (MultiResolutionSTFTLoss: one per resolution) lends them: the extra
+        # terms then queue behind its SHORTER resolutions, forward and backward, instead of opening more branches than the
+        # device has hardware queues (a fifth branch of the captured step was run behind the longest one).
+        first = self.losses[0]
+        if hasattr(first, "_streams") and getattr(first, "parallel", False):
+            own = list(first._streams(device))
+            if len(own) >= len(self.losses) - 1:
+                return own[:len(self.losses) - 1]
+        pool = self.__dict__.setdefault("_side_streams", {})
+        if device not in pool:
+            pool[device] = [torch.cuda.Stream(device) for _ in self.losses[1:]]
+        return pool[device]
+
+    def forward(self, audio, kwargs_list):
+        assert len(kwargs_list) == len(self.losses)
+        if not (audio.is_cuda and self.parallel) or len(self.losses) == 1:
+            return sum(m(audio, **kw) for m, kw in zip(self.losses, kwargs_list))
+        cur = torch.cuda.current_stream(audio.device)
+        side = self._streams(audio.device)
+        terms = []
+        for s, m, kw in zip(side, list(self.losses)[1:], kwargs_list[1:]):      # fork: they wait for the audio only
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                terms.append(m(audio, **kw))
+        total = self.losses[0](audio, **kwargs_list[0])
+        for s, t in zip(side, terms):                                               # join
+            cur.wait_stream(s)
+            t.record_stream(cur)
+            total = total + t
+        return total
+
+
 class SubbandL1(nn.Module):
     """mean |PQMF(a) - PQMF(target)|: an L1 loss in the sub-band domain of a ``pqmf.PQMF`` filterbank (BASELINE
     configs[4] pairs the 64-band PQMF with the multi-resolution STFT loss in one gradient step; the reference has no

@@ -302,6 +302,19 @@ class Voice(nn.Module):
         vconst = ws[ov:ov + c.batch_size * 64].view(torch.float32).reshape(c.batch_size, 16).clone()
         return ctrl, vconst
 
+    def saved_for_backward(self, with_peaks=True, workspace=None):
+        """(ctrl [B,5,Tc], vconst [B,16], peaks [B] or None) of the last render, out of its workspace in one launch:
+        what the render's autograd node keeps (``rendered_control`` + ``read_peaks`` are three copies)."""
+        c = self.synthconfig
+        ws = self._workspace if workspace is None else workspace
+        ctrl = torch.empty((c.batch_size, 5, c.control_buffer_size), dtype=torch.float32, device=ws.device)
+        vconst = torch.empty((c.batch_size, 16), dtype=torch.float32, device=ws.device)
+        peaks = torch.empty(c.batch_size, dtype=torch.float32, device=ws.device) if with_peaks else None
+        _lib.check(_lib.load().ias_voice_save_for_backward(_lib.ptr(ws), _lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(peaks),
+                                                           c.batch_size, c.buffer_size, c.control_buffer_size,
+                                                           _lib.stream()), "ias_voice_save_for_backward")
+        return ctrl, vconst, peaks
+
     def control_signals(self, params01=None):
         """Mod-matrix outputs [B,5,Tc] of the control-rate kernel (diagnostics / tests)."""
         c = self.synthconfig

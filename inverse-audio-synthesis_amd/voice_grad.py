@@ -268,8 +268,7 @@ class _RenderFn(torch.autograd.Function):
     def forward(ctx, params01, voice, normalize):
         p = params01.detach().to(torch.float32).contiguous()
         audio = voice._render_nograd(p, normalize)
-        peaks = voice.read_peaks() if normalize else None
-        ctrl, vconst = voice.rendered_control()
+        ctrl, vconst, peaks = voice.saved_for_backward(with_peaks=normalize)
         ctx.voice, ctx.normalize = voice, normalize
         ctx.save_for_backward(p, audio, peaks, ctrl, vconst)
         return audio

@@ -125,3 +125,28 @@ def test_grad_step_against_oracle_and_at_full_size(lib, dev):
             fd = (loss_at(pc + eps * d) - loss_at(pc - eps * d)) / (2 * eps)
             an = (gq.double() * d.double()).sum().item()
             assert abs(fd - an) <= 3e-2 * abs(fd) + 1e-6, (fd, an)
+
+
+def test_parallel_loss_sum_equals_the_serial_sum(lib, dev):
+    """ParallelLossSum issues the sub-band branch on a side stream (forward and, through autograd's stream rule, backward):
+    same kernels, same order inside each branch -> the same loss and the same audio gradient as the plain sum."""
+    from inverse_audio_synthesis_amd.pqmf import PQMF
+    from inverse_audio_synthesis_amd.spectral import MultiResolutionSTFTLoss, ParallelLossSum, SubbandL1
+    B, T = 3, 44100
+    g = torch.Generator().manual_seed(5)
+    tgt = (torch.randn(B, T, generator=g) * 0.2).to(dev)
+    mr, sub = MultiResolutionSTFTLoss().to(dev), SubbandL1(PQMF(N=64).to(dev))
+    both = ParallelLossSum(mr, sub)
+    tm, tb = mr.target(tgt), sub.target(tgt)
+    out = []
+    for parallel in (True, False, True):
+        both.parallel = parallel
+        a = (torch.randn(B, T, generator=torch.Generator().manual_seed(6)) * 0.2).to(dev).requires_grad_(True)
+        loss = both(a, [dict(targets=tm), dict(target_bands=tb)])
+        (ga,) = torch.autograd.grad(loss, a)
+        torch.cuda.synchronize()
+        out.append((loss.detach().clone(), ga.clone()))
+    ref = mr(a, targets=tm) + sub(a, target_bands=tb)
+    assert torch.equal(out[1][0], ref.detach())
+    for l, ga in (out[0], out[2]):
+        assert torch.equal(l, out[1][0]) and torch.equal(ga, out[1][1])
