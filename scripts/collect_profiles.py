@@ -7,7 +7,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 names = ["bench_default.json", "bench_nopipeline.json", "bench_vicreg128.json", "bench_vicreg1024.json", "bench_gradstep.json",
          "kstats_default.csv", "kstats_nopipeline.csv", "kstats_vicreg128.csv", "kstats_vicreg1024.csv", "kstats_gradstep.csv",
-         "pmc_voice.txt", "pmc_pqmf.txt", "pmc_vicreg.txt", "pmc_vicreg1024.txt", "kstats_pretrain.txt", "pmc_stft.txt", "trace_default.txt",
+         "pmc_voice.txt", "pmc_pqmf.txt", "pmc_vicreg.txt", "pmc_vicreg1024.txt", "kstats_pretrain.txt", "pmc_stft.txt", "trace_default.txt", "trace_gradstep.txt",
          "mfma_valu_overlap.txt", "mfma_valu_inwave.txt", "parity_vs_torch_seed0.json", "parity_vs_torch_seed1.json"]
 for n in names:
     p = os.path.join(src, n)

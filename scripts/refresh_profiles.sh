@@ -65,6 +65,7 @@ step pmc vicreg1024; bash $R/scripts/diag/pmc_vicreg.sh ${tag}_1024 1024 > /dev/
 step kstats pretrain; bash $R/scripts/diag/kstats_pretrain.sh $tag > $O/kstats_pretrain.txt 2>&1
 step pmc stft; bash $R/scripts/diag/pmc_stft.sh $tag PARTS=loss > /dev/null 2>&1; cp $R/gpurun_out/pmcs_$tag/summary.txt $O/pmc_stft.txt
 step trace; bash $R/scripts/diag/trace_bench.sh $tag > $O/trace_default.txt 2>&1
+step trace gradstep; bash $R/scripts/diag/trace_gradstep.sh $tag > $O/trace_gradstep.txt 2>&1; rm -rf $R/gpurun_out/trace_gs_$tag
 step microbench; $R/scripts/diag/_bin/mfma_valu_overlap > $O/mfma_valu_overlap.txt 2>&1; $R/scripts/diag/_bin/mfma_valu_inwave > $O/mfma_valu_inwave.txt 2>&1
 step parity; IAS_PARITY_OUT=$O python3 -m pytest $R/tests/test_voice_gpu.py -q -k headline_size > $O/parity_test.log 2>&1
 # raw counter / trace directories of the helper scripts: the summaries above are what is kept
