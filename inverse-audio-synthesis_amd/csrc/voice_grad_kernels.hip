@@ -877,11 +877,11 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_fold_combine_kernel(c
 
 
 // ------------------------------------------------------------------------------------------------ C ABI
-// IAS_VOICE_GRAD_V1=1: the chunk-scan kernels + separate transposed upsample for every shape (A/B, and what shapes with
-// fewer than 16 samples per control interval take anyway)
+// IAS_VOICE_GRAD_V1=1: the chunk-scan kernels + separate transposed upsample for every shape (A/B and the test that compares
+// the two forms; read at every call)
 static bool voice_grad_force_v1() {
-  static const bool v = [] { const char* e = getenv("IAS_VOICE_GRAD_V1"); return e && e[0] && e[0] != '0'; }();
-  return v;
+  const char* e = getenv("IAS_VOICE_GRAD_V1");
+  return e && e[0] && e[0] != '0';
 }
 extern "C" int ias_voice_grad_tiles(int T) { return T > 0 ? (T + GRAD_TILE - 1) / GRAD_TILE : IAS_ERR_ARG; }
 extern "C" int ias_voice_grad_nscalars(void) { return IAS_GRAD_NS; }

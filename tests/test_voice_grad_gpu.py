@@ -46,8 +46,12 @@ def test_control_graph_matches_hip_control_kernels(lib, dev):
         assert ((scal_t - got).abs() / (1.0 + got.abs())).max().item() <= 1e-5
 
 
+# 8002 samples: not a multiple of 4 -> every tile of the backward takes the guarded scalar path instead of the LDS-DMA
+# blocks; 16000 x 1 s: three whole tiles + a partial one; 44100 x 4 s: 43 + 1.  (At 11025 Hz the highest pitches alias and
+# the fp32 phases of the product decorrelate from the fp64 oracle's: not a usable gradient reference.)
 @pytest.mark.parametrize("B,sr,sec,seed,normalize", [(4, 16000, 1.0, 0, True), (4, 16000, 1.0, 2, True),
-                                                     (4, 16000, 1.0, 1, False), (2, 44100, 4.0, 3, True)])
+                                                     (4, 16000, 1.0, 1, False), (2, 44100, 4.0, 3, True),
+                                                     (4, 16000, 0.500125, 4, True)])
 def test_gradient_matches_oracle_autograd(lib, dev, B, sr, sec, seed, normalize):
     cfg = so.VoiceConfig(B, sr, sec)
     v = _voice(dev, B, sr, sec)
@@ -88,6 +92,37 @@ def test_gradient_at_other_control_rates(lib, dev, control_rate, sr, sec):
     assert torch.isfinite(g).all()
     assert max(rel_l2(g[b], ref[b]) for b in range(B)) <= 2e-2
     assert rel_l2(g, ref) <= 5e-3
+
+
+def test_lane_consecutive_backward_agrees_with_the_chunk_scan_kernels(lib, dev, monkeypatch):
+    """The default audio-rate backward (16 consecutive samples per thread, LDS-DMA blocks, transposed upsample folded in)
+    against the first form (IAS_VOICE_GRAD_V1=1, read at every call) on the same inputs: whole tiles, a partial tile, a
+    row length that is not a multiple of 4 (guarded scalar accesses), with and without the normalisation adjoint.  The two
+    differ in the sin / cos range reduction (fp32 split vs fp64), in fp32 vs fp64 partial sums inside a thread and in the
+    order of the interval sums: agreement to 1e-5 of each output's largest element; the default form is bit-reproducible."""
+    from inverse_audio_synthesis_amd.voice import SynthConfig, Voice
+    from inverse_audio_synthesis_amd.voice_grad import audio_rate_backward, normalisation_rows
+    for B, sr, sec in ((3, 44100, 0.5), (2, 16000, 0.500125), (2, 44100, 4.0)):
+        v = Voice(SynthConfig(batch_size=B, sample_rate=sr, buffer_size_seconds=sec, reproducible=False)).to(dev)
+        v.randomize(21)
+        audio = v.render()
+        g = torch.randn(audio.shape, generator=torch.Generator().manual_seed(8)).to(dev)
+        ctl = v.rendered_control()
+        for rn in (None, normalisation_rows(g, audio, v.read_peaks())):
+            monkeypatch.delenv("IAS_VOICE_GRAD_V1", raising=False)
+            c_new, s_new = audio_rate_backward(v, v.params01, g, rn, ctl)
+            c_again, s_again = audio_rate_backward(v, v.params01, g, rn, ctl)
+            monkeypatch.setenv("IAS_VOICE_GRAD_V1", "1")
+            c_old, s_old = audio_rate_backward(v, v.params01, g, rn, ctl)
+            monkeypatch.delenv("IAS_VOICE_GRAD_V1", raising=False)
+            assert torch.equal(c_new, c_again) and torch.equal(s_new, s_again)
+            assert torch.isfinite(c_new).all() and torch.isfinite(s_new).all()
+            for row in range(5):
+                err = (c_new[:, row] - c_old[:, row]).abs().max().item()
+                assert err <= 1e-5 * c_old[:, row].abs().max().item() + 1e-12, (B, sr, sec, row, err)
+            for k in range(s_old.shape[1]):
+                err = (s_new[:, k] - s_old[:, k]).abs().max().item()
+                assert err <= 1e-5 * s_old[:, k].abs().max().item() + 1e-12, (B, sr, sec, k, err)
 
 
 def test_gradient_is_deterministic_and_leaves_forward_untouched(lib, dev):
