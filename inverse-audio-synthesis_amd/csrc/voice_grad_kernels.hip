@@ -32,7 +32,10 @@
 
 #define GRAD_THREADS 256
 #define GRAD_WAVES (GRAD_THREADS / 64)
-#define GRAD_CHUNKS 16
+#ifndef GRAD_CHUNKS
+#define GRAD_CHUNKS 16      // samples per thread and tile: 16, or 8 (the lane-consecutive kernels' blocks: 64 / 32 bytes per lane;
+                            // 8 gives them 16 waves per CU instead of 8 and was measured no faster: 95 + 69 vs 94 + 64 us)
+#endif
 #define GRAD_TILE (GRAD_THREADS * GRAD_CHUNKS)
 #define IAS_GRAD_NS 12      // f0_1 depth_1 phi_1 f0_2 depth_2 phi_2 kpart shape gain lvl0 lvl1 lvl2
 #define IAS_GRAD_PLANES 8   // inc_1 inc_2 | g_amp1 g_amp2 g_ampn | g_arg1->g_pm1 g_arg2->g_pm2 | interval sums of K3
@@ -485,10 +488,13 @@ __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_ctrl_combine_kernel(f
 //   * sin / cos / tanh: the forward kernel's fp32 revolution split (voice_trig.h) instead of the fp64 reduction.
 // A tile that is not whole (the row's last) or a row length that is not a multiple of 4 takes the same code with guarded
 // scalar accesses instead of the LDS blocks.
-#define G16_SPT 16
+#define G16_SPT GRAD_CHUNKS
+#define G16_NQ (G16_SPT / 4)     // 16-byte granules per lane
+#define G16_BLK (64 * G16_SPT)   // floats of one plane block of a wave
 #define G16_NOK 0x3fffffff       // k_first of a thread that owns no sample
-#define G16_WAVE_FLOATS 4096     // staging per wave: four planes of 1024 samples
+#define G16_WAVE_FLOATS (4 * G16_BLK)     // staging per wave: four plane blocks
 #define G16_LDS_BYTES (GRAD_WAVES * G16_WAVE_FLOATS * 4)
+static_assert(G16_SPT == 8 || G16_SPT == 16, "lane-consecutive kernels: 8 or 16 samples per thread");
 typedef float g16_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void g16_lds_void;
 typedef const __attribute__((address_space(1))) void g16_glb_void;
@@ -500,22 +506,25 @@ __device__ __forceinline__ const double* g16_tile_sums(const float* planes, int 
   return ct_interval_sums(const_cast<float*>(planes), b, T) + (size_t)tile * IAS_NCTRL * kslots * 2;
 }
 
-// The wave's 1024 samples [j_wave, j_wave + 1024) of a plane row -> its LDS block, by LDS-DMA.  Block layout (the forward
-// kernel's): position p's 16 samples are its own 64 bytes, the four 16-byte granules XOR-permuted by (p >> 2) & 3 --
-// conflict-free for the ds_read/write_b128 of consecutive positions, and lane-linear (the DMA's destination order) once
-// the SOURCE granule of DMA lane i is i ^ (i >> 4).
+// The wave's 64 * G16_SPT samples from j_wave on of a plane row -> its LDS block, by LDS-DMA.  Block layout (the forward
+// kernel's, for 4 or 2 granules per position): position p's samples are its own 64 / 32 bytes, its 16-byte granules
+// XOR-permuted by (p >> 2) & 3 / (p >> 3) & 1 -- 16 consecutive positions then cover all 64 banks with each granule index:
+// conflict-free ds_read/write_b128 -- and lane-linear (the DMA's destination order) once the SOURCE granule of DMA lane i
+// is i ^ ((i >> 4) & (G16_NQ - 1)).
 __device__ __forceinline__ void g16_dma(const float* __restrict__ row, int j_wave, float* blk, int lane) {
-  const float* src = row + j_wave + 4 * (lane ^ (lane >> 4));
+  const float* src = row + j_wave + 4 * (lane ^ ((lane >> 4) & (G16_NQ - 1)));
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < G16_NQ; ++q)
     __builtin_amdgcn_global_load_lds((g16_glb_void*)(src + q * 256), (g16_lds_void*)(blk + q * 256), 16, 0, 0);
 }
-__device__ __forceinline__ float* g16_slot(float* blk, int pos, int q) { return blk + pos * 16 + 4 * (q ^ ((pos >> 2) & 3)); }
+__device__ __forceinline__ float* g16_slot(float* blk, int pos, int q) {
+  return blk + pos * G16_SPT + 4 * (q ^ ((pos >> (G16_NQ == 4 ? 2 : 3)) & (G16_NQ - 1)));
+}
 // the block back to a plane row, whole 1 KB rows per instruction
 __device__ __forceinline__ void g16_copy_out(float* __restrict__ row, int j_wave, const float* blk, int lane) {
-  const int dst = 4 * (lane ^ (lane >> 4));
+  const int dst = 4 * (lane ^ ((lane >> 4) & (G16_NQ - 1)));
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < G16_NQ; ++q)
     *reinterpret_cast<g16_f4*>(row + j_wave + q * 256 + dst) = *reinterpret_cast<const g16_f4*>(blk + q * 256 + lane * 4);
 }
 // four consecutive samples (group q of position pos): from the wave's block, or guarded from the row itself
@@ -540,12 +549,12 @@ struct G16Shared {
   double out[8];
 };
 // The fold partials {A, B of interval k_first; A, B of interval k_first + 1} of fold row r, sample-order position p of the
-// tile: kept in the LAST plane block of the wave that owns the position (free once its sample loop is done).
+// tile: kept in the last TWO plane blocks of the wave that owns the position (free once its sample loop is done).
 // REV: wave w owns positions 64 (3 - w) ... (K2 walks the tile backwards).
 template <bool REV>
 __device__ __forceinline__ g16_f4* g16_fold_slot(float* stage, int r, int p) {
   const int w = REV ? GRAD_WAVES - 1 - (p >> 6) : (p >> 6);
-  return reinterpret_cast<g16_f4*>(stage + w * G16_WAVE_FLOATS + 3 * 1024 + r * 256 + (p & 63) * 4);
+  return reinterpret_cast<g16_f4*>(stage + w * G16_WAVE_FLOATS + 2 * G16_BLK + r * 256 + (p & 63) * 4);
 }
 // s_kfirst[p] non-decreasing in p (G16_NOK: none).  Thread idx < NR * kslots adds, for interval k_lo + kk, the partials of
 // the positions with k_first in {k - 1, k} in ascending p -> out[(rows[r] * kslots + kk) * 2 + {0, 1}].
@@ -589,25 +598,25 @@ __device__ __forceinline__ void g16_sample_tile(
   int* s_kfirst = sh.kfirst;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j_wave = tile * GRAD_TILE + wave * 1024, j0 = j_wave + lane * G16_SPT;
+  const int j_wave = tile * GRAD_TILE + wave * G16_BLK, j0 = j_wave + lane * G16_SPT;
   const float* pi1 = pl + (size_t)PL_INC1 * T;
   const float* pi2 = pl + (size_t)PL_INC2 * T;
   float* blk = stage + wave * G16_WAVE_FLOATS;      // blocks: inc_1 (-> g_arg1) | inc_2 (-> g_arg2) | noise | g
   if (FAST) {
     g16_dma(pi1, j_wave, blk, lane);
-    g16_dma(pi2, j_wave, blk + 1024, lane);
-    g16_dma(nrow, j_wave, blk + 2048, lane);
-    g16_dma(grow, j_wave, blk + 3072, lane);
+    g16_dma(pi2, j_wave, blk + G16_BLK, lane);
+    g16_dma(nrow, j_wave, blk + 2 * G16_BLK, lane);
+    g16_dma(grow, j_wave, blk + 3 * G16_BLK, lane);
   }
   double carry1, carry2;
   tile_carry<false>(tile_sums_b, 2, 0, 1, 0, tile, s_carry, tid, carry1, carry2);
   if (FAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the wave's own DMA has landed
   double tot1 = 0.0, tot2 = 0.0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < G16_NQ; ++q) {
     float a1[4], a2[4];
     g16_get4<FAST>(blk, lane, q, pi1, j0 + 4 * q, T, a1);
-    g16_get4<FAST>(blk + 1024, lane, q, pi2, j0 + 4 * q, T, a2);
+    g16_get4<FAST>(blk + G16_BLK, lane, q, pi2, j0 + 4 * q, T, a2);
 #pragma unroll
     for (int x = 0; x < 4; ++x) { tot1 += (double)fabsf(a1[x]); tot2 += (double)fabsf(a2[x]); }   // sign = clamp flag (K0)
   }
@@ -633,9 +642,9 @@ __device__ __forceinline__ void g16_sample_tile(
     const int jq = j0 + 4 * q;
     float a1[4], a2[4], nz[4], gg[4], o1[4], o2[4];
     g16_get4<FAST>(blk, lane, q, pi1, jq, T, a1);
-    g16_get4<FAST>(blk + 1024, lane, q, pi2, jq, T, a2);
-    g16_get4<FAST>(blk + 2048, lane, q, nrow, jq, T, nz);
-    g16_get4<FAST>(blk + 3072, lane, q, grow, jq, T, gg);
+    g16_get4<FAST>(blk + G16_BLK, lane, q, pi2, jq, T, a2);
+    g16_get4<FAST>(blk + 2 * G16_BLK, lane, q, nrow, jq, T, nz);
+    g16_get4<FAST>(blk + 3 * G16_BLK, lane, q, grow, jq, T, gg);
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
       const int j = jq + x;
@@ -685,7 +694,7 @@ __device__ __forceinline__ void g16_sample_tile(
     }
     if (FAST) {      // the cotangents of the phases take the places of the increments they came from
       *reinterpret_cast<g16_f4*>(g16_slot(blk, lane, q)) = (g16_f4){o1[0], o1[1], o1[2], o1[3]};
-      *reinterpret_cast<g16_f4*>(g16_slot(blk + 1024, lane, q)) = (g16_f4){o2[0], o2[1], o2[2], o2[3]};
+      *reinterpret_cast<g16_f4*>(g16_slot(blk + G16_BLK, lane, q)) = (g16_f4){o2[0], o2[1], o2[2], o2[3]};
     } else {
 #pragma unroll
       for (int x = 0; x < 4; ++x)
@@ -694,7 +703,7 @@ __device__ __forceinline__ void g16_sample_tile(
   }
   if (FAST) {
     g16_copy_out(pl + (size_t)PL_GARG1 * T, j_wave, blk, lane);
-    g16_copy_out(pl + (size_t)PL_GARG2 * T, j_wave, blk + 1024, lane);
+    g16_copy_out(pl + (size_t)PL_GARG2 * T, j_wave, blk + G16_BLK, lane);
   }
 #pragma unroll
   for (int r = 0; r < 3; ++r)
@@ -713,7 +722,7 @@ __device__ __forceinline__ void g16_sample_tile(
   g16_fold<3, false>(stage, s_kfirst, (int)ias_mul(scale, (float)(tile * GRAD_TILE)), kslots, rows, isum_bt, tid);
 }
 
-__global__ __launch_bounds__(GRAD_THREADS, 2) void voice_grad_sample16_kernel(
+__global__ __launch_bounds__(GRAD_THREADS, G16_SPT == 8 ? 4 : 2) void voice_grad_sample16_kernel(
     const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst, const float* __restrict__ noise,
     const float* __restrict__ g_mixed, float* __restrict__ planes, const double* __restrict__ tile_sums,
     double* __restrict__ partials, int T, int Tc, int ntiles, float scale, const float* __restrict__ rownorm, int kslots) {
@@ -751,7 +760,7 @@ __device__ __forceinline__ void g16_pitch_tile(G16Shared& sh, float* stage, cons
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rt = GRAD_THREADS - 1 - tid, pos = 63 - lane;   // position of the thread's run in the tile / in its wave's block
-  const int j_wave = tile * GRAD_TILE + (GRAD_WAVES - 1 - wave) * 1024, j0 = j_wave + pos * G16_SPT;
+  const int j_wave = tile * GRAD_TILE + (GRAD_WAVES - 1 - wave) * G16_BLK, j0 = j_wave + pos * G16_SPT;
   const float* pg1 = pl + (size_t)PL_GARG1 * T;
   const float* pg2 = pl + (size_t)PL_GARG2 * T;
   const float* pi1 = pl + (size_t)PL_INC1 * T;
@@ -759,9 +768,9 @@ __device__ __forceinline__ void g16_pitch_tile(G16Shared& sh, float* stage, cons
   float* blk = stage + wave * G16_WAVE_FLOATS;      // blocks: g_arg1 | g_arg2 | inc_1 | inc_2
   if (FAST) {
     g16_dma(pg1, j_wave, blk, lane);
-    g16_dma(pg2, j_wave, blk + 1024, lane);
-    g16_dma(pi1, j_wave, blk + 2048, lane);
-    g16_dma(pi2, j_wave, blk + 3072, lane);
+    g16_dma(pg2, j_wave, blk + G16_BLK, lane);
+    g16_dma(pi1, j_wave, blk + 2 * G16_BLK, lane);
+    g16_dma(pi2, j_wave, blk + 3 * G16_BLK, lane);
   }
   // carry-in of the reverse scan: g_arg totals of the later tiles (K1 left them in the phi slots)
   double carry1, carry2;
@@ -769,10 +778,10 @@ __device__ __forceinline__ void g16_pitch_tile(G16Shared& sh, float* stage, cons
   if (FAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   double tot1 = 0.0, tot2 = 0.0;
 #pragma unroll
-  for (int q = 3; q >= 0; --q) {
+  for (int q = G16_NQ - 1; q >= 0; --q) {
     float g1[4], g2[4];
     g16_get4<FAST>(blk, pos, q, pg1, j0 + 4 * q, T, g1);
-    g16_get4<FAST>(blk + 1024, pos, q, pg2, j0 + 4 * q, T, g2);
+    g16_get4<FAST>(blk + G16_BLK, pos, q, pg2, j0 + 4 * q, T, g2);
 #pragma unroll
     for (int x = 3; x >= 0; --x) { tot1 += (double)g1[x]; tot2 += (double)g2[x]; }   // the order of the running sums below
   }
@@ -792,9 +801,9 @@ __device__ __forceinline__ void g16_pitch_tile(G16Shared& sh, float* stage, cons
     const int jq = j0 + 4 * q;
     float ga1[4], ga2[4], inc1[4], inc2[4];
     g16_get4<FAST>(blk, pos, q, pg1, jq, T, ga1);
-    g16_get4<FAST>(blk + 1024, pos, q, pg2, jq, T, ga2);
-    g16_get4<FAST>(blk + 2048, pos, q, pi1, jq, T, inc1);
-    g16_get4<FAST>(blk + 3072, pos, q, pi2, jq, T, inc2);
+    g16_get4<FAST>(blk + G16_BLK, pos, q, pg2, jq, T, ga2);
+    g16_get4<FAST>(blk + 2 * G16_BLK, pos, q, pi1, jq, T, inc1);
+    g16_get4<FAST>(blk + 3 * G16_BLK, pos, q, pi2, jq, T, inc2);
 #pragma unroll
     for (int x = 3; x >= 0; --x) {
       run1 += (double)ga1[x]; run2 += (double)ga2[x];          // inclusive suffix sums
@@ -831,7 +840,7 @@ __device__ __forceinline__ void g16_pitch_tile(G16Shared& sh, float* stage, cons
   g16_fold<2, true>(stage, s_kfirst, (int)ias_mul(scale, (float)(tile * GRAD_TILE)), kslots, rows, isum_bt, tid);
 }
 
-__global__ __launch_bounds__(GRAD_THREADS, 2) void voice_grad_pitch16_kernel(
+__global__ __launch_bounds__(GRAD_THREADS, G16_SPT == 8 ? 4 : 2) void voice_grad_pitch16_kernel(
     const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst, float* __restrict__ planes,
     double* __restrict__ partials, int T, int Tc, int ntiles, float scale, int kslots) {
   extern __shared__ __attribute__((aligned(16))) float g16_stage[];
@@ -933,9 +942,9 @@ extern "C" int ias_voice_backward_norm(const float* ctrl, const void* vconst, co
   const int ntiles = (T + GRAD_TILE - 1) / GRAD_TILE;
   if (ntiles > 65535) return IAS_ERR_UNSUPPORTED;
   const float scale = (float)(Tc - 1) / (float)(T - 1);
-  // lane-consecutive form: >= 16 samples per control interval and the per-tile interval sums fit the spare plane
+  // lane-consecutive form: >= G16_SPT samples per control interval and the per-tile interval sums fit the spare plane
   const int kslots = (int)(scale * (float)GRAD_TILE) + 3;
-  const bool fold = scale * 16.0f <= 1.0f && !voice_grad_force_v1() &&
+  const bool fold = scale * (float)G16_SPT <= 1.0f && !voice_grad_force_v1() &&
                     (size_t)ntiles * IAS_NCTRL * kslots * 2 * sizeof(double) + 8 <= (size_t)T * sizeof(float);
   // first form: K3 stages nint + 1 control intervals of samples in LDS (as many as fit, at most CT_INTERVALS) and keeps
   // its interval sums in the spare plane
