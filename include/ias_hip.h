@@ -120,6 +120,11 @@ int ias_voice_norm_backward(const float* g_audio, const float* audio, const floa
 int ias_voice_backward_norm(const float* ctrl, const void* vconst, const float* noise, const float* g_audio,
                             const float* rownorm, float* planes, double* tile_sums, double* partials, float* g_ctrl,
                             int B, int T, int Tc, int sample_rate, void* stream);
+/* ias_voice_backward_norm that also leaves g_scal [B, ias_voice_grad_nscalars()] fp64 = partials summed over the tiles (in
+ * tile order) -- the gradient of the per-voice constants -- instead of leaving that sum to the caller. */
+int ias_voice_backward_sums(const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
+                            const float* rownorm, float* planes, double* tile_sums, double* partials, float* g_ctrl,
+                            double* g_scal, int B, int T, int Tc, int sample_rate, void* stream);
 
 /* Control-rate half of the same backward: params01 [B,78], g_ctrl [B,5,Tc] fp32 and g_scal [B,12] fp64 (g_ctrl of
  * ias_voice_backward and the sum over tiles of its partials) -> g_params01 [B,78] fp32.  One launch instead of the

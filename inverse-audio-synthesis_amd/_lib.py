@@ -44,6 +44,7 @@ SYMBOLS = {
     "ias_voice_grad_nplanes": (_I, []),
     "ias_voice_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_voice_backward_norm": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_voice_backward_sums": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_voice_norm_scratch_len": (_LL, [_I]),
     "ias_voice_norm_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "ias_voice_control_backward": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -862,28 +862,58 @@ __global__ __launch_bounds__(GRAD_THREADS, G16_SPT == 8 ? 4 : 2) void voice_grad
 // g_ctrl[i] = A[i] + B[i - 1] (the last control point is its own upper neighbour) from the per-tile interval sums: an
 // interval's samples [first(k), first(k + 1)) lie in the tiles first(k) / GRAD_TILE ... (first(k + 1) - 1) / GRAD_TILE,
 // added in ascending tile order.
-__device__ __forceinline__ double g16_interval(const float* planes, int b, int T, int row, int k, int which, float scale,
-                                               int kslots) {
-  const int f0 = ct_first_sample(k, scale, T), f1 = ct_first_sample(k + 1, scale, T);
-  double v = 0.0;
-  if (f1 > f0)
-    for (int t = f0 / GRAD_TILE; t <= (f1 - 1) / GRAD_TILE; ++t) {
-      const int kk = k - (int)ias_mul(scale, (float)(t * GRAD_TILE));
-      if (kk >= 0 && kk < kslots) v += g16_tile_sums(planes, b, T, t, kslots)[((size_t)row * kslots + kk) * 2 + which];
-    }
-  return v;
-}
+// One thread per control point, all five rows (the interval bounds are found once); the workgroups of the first column
+// also add the voice's per-tile partial sums of the 12 constants (fixed order) -> g_scal [B][IAS_GRAD_NS] (NULL: skipped).
 __global__ __launch_bounds__(GRAD_THREADS) void voice_grad_fold_combine_kernel(const float* __restrict__ planes,
-                                                                               float* __restrict__ g_ctrl, int T, int Tc,
-                                                                               float scale, int kslots) {
-  const int i = blockIdx.x * GRAD_THREADS + threadIdx.x, row = blockIdx.y, b = blockIdx.z;
+                                                                               float* __restrict__ g_ctrl,
+                                                                               const double* __restrict__ partials,
+                                                                               double* __restrict__ g_scal, int T, int Tc,
+                                                                               int ntiles, float scale, int kslots) {
+  const int i = blockIdx.x * GRAD_THREADS + threadIdx.x, b = blockIdx.y;
+  if (g_scal && blockIdx.x == 0) {
+    // wave w adds constants w, w + 4, w + 8: lane l takes the tiles l, l + 64, ..., then one wave sum (a fixed tree: the
+    // tiles' values all in flight at once -- one thread walking the 44 tiles was 44 dependent L2 round trips)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < IAS_GRAD_NS; k += GRAD_WAVES) {
+      const double* p = partials + (size_t)b * ntiles * IAS_GRAD_NS + k;
+      double v = 0.0;
+      for (int t = lane; t < ntiles; t += 64) v += p[(size_t)t * IAS_GRAD_NS];
+      v = wave_total(v);
+      if (lane == 0) g_scal[(size_t)b * IAS_GRAD_NS + k] = v;
+    }
+  }
   if (i >= Tc) return;
-  double v = g16_interval(planes, b, T, row, i, 0, scale, kslots);
-  if (i > 0) v += g16_interval(planes, b, T, row, i - 1, 1, scale, kslots);
-  if (i == Tc - 1) v += g16_interval(planes, b, T, row, i, 1, scale, kslots);
-  g_ctrl[((size_t)b * IAS_NCTRL + row) * Tc + i] = (float)v;
+  // samples of interval i - 1: [fm, f0), of interval i: [f0, f1)
+  const int fm = i > 0 ? ct_first_sample(i - 1, scale, T) : 0, f0 = ct_first_sample(i, scale, T),
+            f1 = ct_first_sample(i + 1, scale, T);
+  double v[IAS_NCTRL] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  auto add = [&](int k, int lo, int hi, int which) {
+    if (hi <= lo) return;
+    for (int t = lo / GRAD_TILE; t <= (hi - 1) / GRAD_TILE; ++t) {
+      const int kk = k - (int)ias_mul(scale, (float)(t * GRAD_TILE));
+      if (kk < 0 || kk >= kslots) continue;
+      const double* q = g16_tile_sums(planes, b, T, t, kslots) + (size_t)kk * 2 + which;
+#pragma unroll
+      for (int row = 0; row < IAS_NCTRL; ++row) v[row] += q[(size_t)row * kslots * 2];
+    }
+  };
+  add(i, f0, f1, 0);                          // A[i]
+  if (i > 0) add(i - 1, fm, f0, 1);           // B[i - 1]
+  if (i == Tc - 1) add(i, f0, f1, 1);         // the last control point is its own upper neighbour
+#pragma unroll
+  for (int row = 0; row < IAS_NCTRL; ++row) g_ctrl[((size_t)b * IAS_NCTRL + row) * Tc + i] = (float)v[row];
 }
 
+// g_scal [B][IAS_GRAD_NS] = the per-tile partial sums added in tile order (first form: its combine kernel does not)
+__global__ void voice_grad_scalars_kernel(const double* __restrict__ partials, double* __restrict__ g_scal, int B, int ntiles) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * IAS_GRAD_NS) return;
+  const int b = idx / IAS_GRAD_NS, k = idx - b * IAS_GRAD_NS;
+  const double* p = partials + (size_t)b * ntiles * IAS_GRAD_NS + k;
+  double v = 0.0;
+  for (int t = 0; t < ntiles; ++t) v += p[(size_t)t * IAS_GRAD_NS];
+  g_scal[idx] = v;
+}
 
 // ------------------------------------------------------------------------------------------------ C ABI
 // IAS_VOICE_GRAD_V1=1: the chunk-scan kernels + separate transposed upsample for every shape (A/B and the test that compares
@@ -905,6 +935,9 @@ extern "C" int ias_voice_grad_nplanes(void) { return IAS_GRAD_PLANES; }
 extern "C" int ias_voice_backward_norm(const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
                                        const float* rownorm, float* planes, double* tile_sums, double* partials,
                                        float* g_ctrl, int B, int T, int Tc, int sample_rate, void* stream_);
+extern "C" int ias_voice_backward_sums(const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
+                                       const float* rownorm, float* planes, double* tile_sums, double* partials,
+                                       float* g_ctrl, double* g_scal, int B, int T, int Tc, int sample_rate, void* stream_);
 extern "C" int ias_voice_backward(const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
                                   float* planes, double* tile_sums, double* partials, float* g_ctrl, int B, int T,
                                   int Tc, int sample_rate, void* stream_) {
@@ -936,6 +969,14 @@ extern "C" int ias_voice_norm_backward(const float* g_audio, const float* audio,
 extern "C" int ias_voice_backward_norm(const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
                                        const float* rownorm, float* planes, double* tile_sums, double* partials,
                                        float* g_ctrl, int B, int T, int Tc, int sample_rate, void* stream_) {
+  return ias_voice_backward_sums(ctrl, vconst, noise, g_mixed, rownorm, planes, tile_sums, partials, g_ctrl, nullptr, B, T, Tc,
+                                 sample_rate, stream_);
+}
+// ... and g_scal [B, ias_voice_grad_nscalars()] fp64 (NULL: not wanted) = partials summed over the tiles, in tile order, by the
+// last launch
+extern "C" int ias_voice_backward_sums(const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
+                                       const float* rownorm, float* planes, double* tile_sums, double* partials,
+                                       float* g_ctrl, double* g_scal, int B, int T, int Tc, int sample_rate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!ctrl || !vconst || !noise || !g_mixed || !planes || !tile_sums || !partials || !g_ctrl) return IAS_ERR_ARG;
   if (B <= 0 || B > 65535 || T <= 1 || Tc <= 1 || sample_rate <= 0) return IAS_ERR_ARG;
@@ -968,8 +1009,8 @@ extern "C" int ias_voice_backward_norm(const float* ctrl, const void* vconst, co
                        tile_sums, partials, T, Tc, ntiles, scale, rownorm, kslots);
     hipLaunchKernelGGL(voice_grad_pitch16_kernel, grid, block, G16_LDS_BYTES, stream, ctrl, vc, planes, partials, T, Tc,
                        ntiles, scale, kslots);
-    hipLaunchKernelGGL(voice_grad_fold_combine_kernel, dim3((Tc + GRAD_THREADS - 1) / GRAD_THREADS, IAS_NCTRL, B), block, 0,
-                       stream, planes, g_ctrl, T, Tc, scale, kslots);
+    hipLaunchKernelGGL(voice_grad_fold_combine_kernel, dim3((Tc + GRAD_THREADS - 1) / GRAD_THREADS, B), block, 0, stream,
+                       planes, g_ctrl, partials, g_scal, T, Tc, ntiles, scale, kslots);
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(voice_grad_sample_kernel, grid, block, 0, stream, ctrl, vc, noise, g_mixed, planes, tile_sums,
@@ -980,5 +1021,8 @@ extern "C" int ias_voice_backward_norm(const float* ctrl, const void* vconst, co
                      stream, planes, T, Tc, scale, nint);
   hipLaunchKernelGGL(voice_grad_ctrl_combine_kernel, dim3((Tc + GRAD_THREADS - 1) / GRAD_THREADS, IAS_NCTRL, B), block,
                      0, stream, planes, g_ctrl, T, Tc);
+  if (g_scal)
+    hipLaunchKernelGGL(voice_grad_scalars_kernel, dim3((B * IAS_GRAD_NS + 255) / 256), dim3(256), 0, stream, partials, g_scal,
+                       B, ntiles);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }

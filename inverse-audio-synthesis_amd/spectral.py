@@ -14,6 +14,7 @@ the reference left commented out (audio_to_params.py:56-172); ``MultiResolutionS
 respect to its first argument (the prediction) through the same kernels.
 """
 import ctypes
+import os
 import math
 
 import torch

@@ -180,11 +180,12 @@ def audio_rate_backward(voice, params01, g_mixed, rownorm=None, control=None):
     tile_sums = torch.empty((B, ntiles, 2), dtype=torch.float64, device=dev)
     partials = torch.empty((B, ntiles, lib.ias_voice_grad_nscalars()), dtype=torch.float64, device=dev)
     g_ctrl = torch.empty((B, 5, Tc), dtype=torch.float32, device=dev)
-    st = lib.ias_voice_backward_norm(_lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(voice.noise), _lib.ptr(g_mixed),
+    g_scal = torch.empty((B, lib.ias_voice_grad_nscalars()), dtype=torch.float64, device=dev)
+    st = lib.ias_voice_backward_sums(_lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(voice.noise), _lib.ptr(g_mixed),
                                      _lib.ptr(rownorm), _lib.ptr(planes), _lib.ptr(tile_sums), _lib.ptr(partials),
-                                     _lib.ptr(g_ctrl), B, T, Tc, c.sample_rate, _lib.stream())
-    _lib.check(st, "ias_voice_backward_norm")
-    return g_ctrl, partials.sum(dim=1)
+                                     _lib.ptr(g_ctrl), _lib.ptr(g_scal), B, T, Tc, c.sample_rate, _lib.stream())
+    _lib.check(st, "ias_voice_backward_sums")
+    return g_ctrl, g_scal
 
 
 def _control_backward_eager(cfg, p, g_ctrl, g_scal):
