@@ -445,7 +445,23 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES == 10 ? 5 : 1) void stft_ke
 // row reads of a segment-major power buffer, frames dealt to waves from one flat [B*F] list.
 #define IAS_SEG_MAX_ROWS 17
 #define IAS_SEG_HDR 16
-#define IAS_SEG_STRIDE 65
+#define IAS_SEG_STRIDE 74
+// Exchange scratch of stft2_kernel: 64 rows of IAS_S2_ROW complex values per wave, element (row, col) at IAS_S2_AT.
+// With rows of 9 (the usual odd padding) the pass-1 scatter [(q 8 + c)][a] has 16 consecutive lanes at 9 c + a (c < 8,
+// a in {2j, 2j + 1}) and 9 * 7 + 1 wraps onto 0: a 2-way bank conflict in every 16 lanes of those eight stores; the
+// upper-half stores of the unpack (index i + i / 8) wrap the same way: SQ_LDS_BANK_CONFLICT = 56 cycles per frame in the
+// transform alone (profiles/r03f_pmc_stft.txt, the kernel without the mel part).  Rows of 10 (10 c + a covers
+// {0,10,20,30,8,18,28,6} + {0,1}) and two pad elements per eight in the upper half: 40 conflict cycles per frame, 15 %
+// fewer LDS cycles overall, the row reads (lane 10 + q) become 16-byte reads.  (An address model "stores are checked 16
+// lanes at a time, loads 32" fits both measurements, but the layout it then recommends -- one more element in front of
+// the rows with bit 4 set -- measured 104 cycles: the 16-byte reads follow other rules.  Kept at plain rows of 10.)
+// 640 complex values per wave also hold the mel projection's segment-major power rows at a stride of 74 floats.
+#ifndef IAS_S2_ROW
+#define IAS_S2_ROW 10
+#endif
+#define IAS_S2_AT(row, col) ((row) * IAS_S2_ROW + (col))
+#define IAS_S2_UP(i) ((i) + (IAS_S2_ROW - 8) * ((i) >> 3))
+static_assert(IAS_SEG_MAX_ROWS * IAS_SEG_STRIDE + 1 <= 2 * 64 * IAS_S2_ROW, "segment-major rows fit the wave's scratch");
 struct Spec2Args {
   const float* audio;      // [B,T]
   const float* tables;     // ias_stft_build_tables block (n_fft 1024: with the unpack twiddles of this kernel at the end)
@@ -529,7 +545,7 @@ template <int SP_WAVES, bool MEL, int LOSS, int NSUB>
 __global__ __launch_bounds__(64 * SP_WAVES, NSUB == 2 ? 3 * SP_WAVES / 8 : (SP_WAVES >= 8 ? (SP_WAVES == 8 ? IAS_STFT2_MINW : SP_WAVES / 2) : (3 * SP_WAVES + 3) / 4))
 void stft2_kernel(const Spec2Args a) {
   static_assert(NSUB == 1 || (NSUB == 2 && !MEL), "mel filterbanks: n_fft 1024 only");
-  constexpr int SP_THREADS = 64 * SP_WAVES, N2 = 512 * NSUB, R = 8, SCR = 64 * 9, NPK = 4 * NSUB, HALF = N2 / 2;
+  constexpr int SP_THREADS = 64 * SP_WAVES, N2 = 512 * NSUB, R = 8, SCR = 64 * IAS_S2_ROW, NPK = 4 * NSUB, HALF = N2 / 2;
   // cpx per lane: window pairs, pass-1 twiddles, pass-2 twiddles, (NSUB = 2: combining twiddles,) unpack twiddles
   constexpr int NTAB = 8 * NSUB + 8 + 8 + (NSUB == 2 ? 8 : 0) + NPK;
   // The frame-invariant tables are LDS objects of their own, not slices of the dynamic array that holds the exchange
@@ -641,25 +657,25 @@ void stft2_kernel(const Spec2Args a) {
       {
         const int c = lane & 7, aa = lane >> 3;
 #pragma unroll
-        for (int q = 0; q < R; ++q) sA[(q * 8 + c) * 9 + aa] = cmul(v[q], t_tw1[64 * q]);
+        for (int q = 0; q < R; ++q) sA[IAS_S2_AT(q * 8 + c, aa)] = cmul(v[q], t_tw1[64 * q]);
       }
       S2_STAMP(2);
       wave_lds_sync();
       S2_STAMP(3);
       cpx u[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+      for (int q = 0; q < 8; ++q) u[q] = sA[IAS_S2_AT(lane, q)];
       wave_lds_sync();
       S2_STAMP(4);
       // pass 2: radix 8 over a for each (k1, c); twiddle W_64^(c d); scatter (in place) to [k1][d][c]
       dft8(u);
 #pragma unroll
-      for (int d = 0; d < 8; ++d) sA[(k1 * 8 + d) * 9 + dd] = cmul(u[d], t_tw2[64 * d]);
+      for (int d = 0; d < 8; ++d) sA[IAS_S2_AT(k1 * 8 + d, dd)] = cmul(u[d], t_tw2[64 * d]);
       S2_STAMP(5);
       wave_lds_sync();
       S2_STAMP(6);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+      for (int q = 0; q < 8; ++q) u[q] = sA[IAS_S2_AT(lane, q)];
       wave_lds_sync();
       S2_STAMP(7);
       // pass 3: radix 8 over c for each (k1, d): u[e] = (half-)transform at k1 + 8 d + 64 e
@@ -678,9 +694,9 @@ void stft2_kernel(const Spec2Args a) {
         }
       }
     }
-    // the upper half (k >= HALF) goes to LDS at k - HALF (padded by one complex per 8: conflict-free 8-byte stores)
+    // the upper half (k >= HALF) goes to LDS at k - HALF (padded per 8 complex values, IAS_S2_UP)
 #pragma unroll
-    for (int e = 0; e < NPK; ++e) { const int i = kl + 64 * e; sA[i + (i >> 3)] = zhi[e]; }
+    for (int e = 0; e < NPK; ++e) { const int i = kl + 64 * e; sA[IAS_S2_UP(i)] = zhi[e]; }
     S2_STAMP(8);
     wave_lds_sync();
     S2_STAMP(9);
@@ -690,7 +706,7 @@ void stft2_kernel(const Spec2Args a) {
     for (int e = 0; e < NPK; ++e) {
       const int k = kl + 64 * e;
       const int i = (HALF - k) & (HALF - 1);                 // k = 0: Z[N2] = Z[0] (own), the read is a dummy
-      cpx zn = sA[i + (i >> 3)];
+      cpx zn = sA[IAS_S2_UP(i)];
       const cpx zk = zlo[e];
       if (e == 0 && k == 0) zn = zk;
       const cpx w = t_twu[64 * e];
@@ -2107,7 +2123,7 @@ extern "C" int ias_stft(const float* audio, const float* tables, const float* mt
     a2.stamps = g_s2_stamps;
 #endif
     const int waves2 = n_fft == 1024 ? stft2_waves() : 8;
-    const size_t lds2 = sizeof(cpx) * (waves2 * 64 * 9);       // the exchange scratch; the tables are static LDS objects
+    const size_t lds2 = sizeof(cpx) * (waves2 * 64 * IAS_S2_ROW);       // the exchange scratch; the tables are static LDS objects
     const dim3 grid2(stft2_grid(a2.nframes, n_fft)), block2(64 * waves2);
 #define IAS_STFT2_LAUNCHW(W, MEL, LOSS)                                                                            \
   do {                                                                                                             \
