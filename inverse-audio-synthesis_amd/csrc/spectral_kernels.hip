@@ -831,7 +831,7 @@ void stft2_kernel(const Spec2Args a) {
 template <int SP_WAVES, int LOSS>
 __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES >= 8 ? SP_WAVES / 2 : (3 * SP_WAVES + 3) / 4)
 void stft2h_kernel(const Spec2Args a) {
-  constexpr int SP_THREADS = 64 * SP_WAVES, SCR = 64 * 9, N2 = 256, HALF = 128;
+  constexpr int SP_THREADS = 64 * SP_WAVES, SCR = 64 * IAS_S2_ROW, N2 = 256, HALF = 128;
   constexpr int NTAB = 4 + 4 + 8 + 4;        // cpx per lane: window pairs, pass-1 twiddles, pass-2 twiddles, unpack twiddles
   extern __shared__ __attribute__((aligned(16))) float smem[];
   cpx* s_scr = reinterpret_cast<cpx*>(smem);
@@ -905,20 +905,20 @@ void stft2h_kernel(const Spec2Args a) {
       dftR<4>(va); dftR<4>(vb);
       const int c = lane & 7, aa = lane >> 3;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) sA[(q * 8 + c) * 9 + aa] = cmul(v[q], t_tw1[64 * (q & 3)]);
+      for (int q = 0; q < 8; ++q) sA[(q * 8 + c) * IAS_S2_ROW + aa] = cmul(v[q], t_tw1[64 * (q & 3)]);
     }
     wave_lds_sync();
     cpx u[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+    for (int q = 0; q < 8; ++q) u[q] = sA[lane * IAS_S2_ROW + q];
     wave_lds_sync();
     // pass 2: radix 8 over a for each (slot, c); twiddle W_64^(c d); scatter (in place) to [slot][d][c]
     dft8(u);
 #pragma unroll
-    for (int d = 0; d < 8; ++d) sA[(slot * 8 + d) * 9 + dd] = cmul(u[d], t_tw2[64 * d]);
+    for (int d = 0; d < 8; ++d) sA[(slot * 8 + d) * IAS_S2_ROW + dd] = cmul(u[d], t_tw2[64 * d]);
     wave_lds_sync();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+    for (int q = 0; q < 8; ++q) u[q] = sA[lane * IAS_S2_ROW + q];
     wave_lds_sync();
     // pass 3: radix 8 over c: u[e] = Z_frame[kl + 32 e]
     dft8(u);
@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
 // (+ 64 e) are 8 apart for consecutive lanes, the swizzle spreads them over the banks.
 template <int SP_WAVES, bool SPAN>
 __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void stft_grad2k_kernel(const SgwArgs a, int nframes, unsigned magicF) {
-  constexpr int SP_THREADS = 64 * SP_WAVES, N2 = 1024, HALF = 512, NFFT = 2048, SCR = 64 * 9, NB = N2 + 1;
+  constexpr int SP_THREADS = 64 * SP_WAVES, N2 = 1024, HALF = 512, NFFT = 2048, SCR = 64 * IAS_S2_ROW, NB = N2 + 1;
   constexpr int NTAB = 16 + 8 + 8 + 8 + 8 + 16;   // stft2's 2048 section + the window at the lane's OUTPUT samples
   constexpr int V2_BASE_2048 = 32 + 32 + 32 + 18;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1365,18 +1365,18 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
     {
       const int c = lane & 7, aa = lane >> 3;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) sA[(q * 8 + c) * 9 + aa] = cmul(v[q], t_tw1[64 * q]);
+      for (int q = 0; q < 8; ++q) sA[(q * 8 + c) * IAS_S2_ROW + aa] = cmul(v[q], t_tw1[64 * q]);
     }
     wave_lds_sync();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+    for (int q = 0; q < 8; ++q) u[q] = sA[lane * IAS_S2_ROW + q];
     wave_lds_sync();
     dft8(u);
 #pragma unroll
-    for (int d = 0; d < 8; ++d) sA[(k1 * 8 + d) * 9 + dd] = cmul(u[d], t_tw2[64 * d]);
+    for (int d = 0; d < 8; ++d) sA[(k1 * 8 + d) * IAS_S2_ROW + dd] = cmul(u[d], t_tw2[64 * d]);
     wave_lds_sync();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+    for (int q = 0; q < 8; ++q) u[q] = sA[lane * IAS_S2_ROW + q];
     wave_lds_sync();
     dft8(u);
   };
@@ -1545,7 +1545,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
 // deterministic), and the 2 hop samples no later frame reaches leave the ring.
 template <int SP_WAVES>
 __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 2) void stft_grad512_kernel(const SgwArgs a) {
-  constexpr int SP_THREADS = 64 * SP_WAVES, SCR = 64 * 9, NFFT = 512, N2 = 256, HALF = 128, NB = 257;
+  constexpr int SP_THREADS = 64 * SP_WAVES, SCR = 64 * IAS_S2_ROW, NFFT = 512, N2 = 256, HALF = 128, NB = 257;
   constexpr int NTAB = 4 + 4 + 8 + 4 + 8;    // stft2h's tables + the window at the lane's OUTPUT samples
   extern __shared__ __attribute__((aligned(16))) float smem[];
   cpx* s_scr = reinterpret_cast<cpx*>(smem);
@@ -1591,18 +1591,18 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 2) void stft_grad512_kern
     {
       const int c = lane & 7, aa = lane >> 3;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) sA[(q * 8 + c) * 9 + aa] = cmul(v[q], t_tw1[64 * (q & 3)]);
+      for (int q = 0; q < 8; ++q) sA[(q * 8 + c) * IAS_S2_ROW + aa] = cmul(v[q], t_tw1[64 * (q & 3)]);
     }
     wave_lds_sync();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+    for (int q = 0; q < 8; ++q) u[q] = sA[lane * IAS_S2_ROW + q];
     wave_lds_sync();
     dft8(u);
 #pragma unroll
-    for (int d = 0; d < 8; ++d) sA[(slot * 8 + d) * 9 + dd] = cmul(u[d], t_tw2[64 * d]);
+    for (int d = 0; d < 8; ++d) sA[(slot * 8 + d) * IAS_S2_ROW + dd] = cmul(u[d], t_tw2[64 * d]);
     wave_lds_sync();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) u[q] = sA[lane * 9 + q];
+    for (int q = 0; q < 8; ++q) u[q] = sA[lane * IAS_S2_ROW + q];
     wave_lds_sync();
     dft8(u);
   };
@@ -1794,7 +1794,7 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
   if (n_fft == 2048 && !mel && !v1_2k && (long long)B * F < 2000000000LL && (reinterpret_cast<uintptr_t>(frame_grad) & 15) == 0 &&
       (!span || (hop & 3) == 0)) {
     constexpr int W2 = 8;
-    const size_t lds2 = sizeof(cpx) * (W2 * 64 * 9 + (span ? W2 * 1024 : 0));       // + 32 KB of static tables
+    const size_t lds2 = sizeof(cpx) * (W2 * 64 * IAS_S2_ROW + (span ? W2 * 1024 : 0));       // + 32 KB of static tables
     if (span) {
       if (!make_plan((long long)ncu * W2)) return IAS_ERR_UNSUPPORTED;
       if (dry) return IAS_OK;
@@ -1814,7 +1814,7 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
   static const int v1_512 = getenv("IAS_STFT_V1") ? atoi(getenv("IAS_STFT_V1")) : 0;
   if (n_fft == 512 && span && !mel && !v1_512) {
     constexpr int W5 = 8;
-    const size_t lds5 = sizeof(cpx) * (W5 * 64 * 9) + sizeof(float) * W5 * 512;
+    const size_t lds5 = sizeof(cpx) * (W5 * 64 * IAS_S2_ROW) + sizeof(float) * W5 * 512;
     (void)hipFuncSetAttribute((const void*)stft_grad512_kernel<W5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stft_grad512_kernel<W5>, 64 * W5, lds5) != hipSuccess || nb < 1) nb = 1;
