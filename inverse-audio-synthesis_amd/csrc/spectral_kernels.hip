@@ -1018,7 +1018,7 @@ template <int LOG2N, bool MEL, bool SPAN>
 __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
   constexpr int SP_WAVES = 4, SP_THREADS = 256;
   constexpr int NFFT = 1 << LOG2N, N2 = NFFT / 2, R = N2 / 64, NPAIR = 8 * R, NP_IT = (NPAIR + 63) / 64;
-  constexpr int SCR = NPAIR * 9, NUNP = (N2 / 2) / 64 + 1, NB = N2 + 1;
+  constexpr int SCR = NPAIR * IAS_S2_ROW, NUNP = (N2 / 2) / 64 + 1, NB = N2 + 1;
   constexpr int NTAB = 64 * (2 * R + 2 * R + 16 * NP_IT + 2 * NUNP);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   cpx* s_scr = reinterpret_cast<cpx*>(smem);
@@ -1066,13 +1066,13 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
   float c0 = 0.0f, c1 = 0.0f;
   if (a.loss_mode == 2) { c0 = (float)a.coef[0]; c1 = (float)a.coef[1]; }
 
-  // the three passes of stft_kernel: v = the lane's R points (64 n1 + lane) -> DFT in natural order, sA[k + (k >> 3)]
+  // the three passes of stft_kernel: v = the lane's R points (64 n1 + lane) -> DFT in natural order, sA[IAS_S2_UP(k)]
   auto fft = [&](cpx (&v)[R]) {
     dftR<R>(v);
     {
       const int c = lane & 7, aa = lane >> 3;
 #pragma unroll
-      for (int k1 = 0; k1 < R; ++k1) sA[(k1 * 8 + c) * 9 + aa] = cmul(v[k1], t_tw1[64 * k1]);
+      for (int k1 = 0; k1 < R; ++k1) sA[(k1 * 8 + c) * IAS_S2_ROW + aa] = cmul(v[k1], t_tw1[64 * k1]);
     }
     wave_lds_sync();
     cpx u[NP_IT][8];
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
       const int p = lane + 64 * i;
       if (p < NPAIR) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) u[i][q] = sA[p * 9 + q];
+        for (int q = 0; q < 8; ++q) u[i][q] = sA[p * IAS_S2_ROW + q];
       }
     }
     wave_lds_sync();
@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
         const int k1 = p >> 3, c = p & 7;
         dft8(u[i]);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) sA[(k1 * 8 + d) * 9 + c] = cmul(u[i][d], t_tw2[64 * (8 * i + d)]);
+        for (int d = 0; d < 8; ++d) sA[(k1 * 8 + d) * IAS_S2_ROW + c] = cmul(u[i][d], t_tw2[64 * (8 * i + d)]);
       }
     }
     wave_lds_sync();
@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
       const int p = lane + 64 * i;
       if (p < NPAIR) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) u[i][q] = sA[p * 9 + q];
+        for (int q = 0; q < 8; ++q) u[i][q] = sA[p * IAS_S2_ROW + q];
       }
     }
     wave_lds_sync();
@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
         const int k1 = p >> 3, d = p & 7;
         dft8(u[i]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const int k = k1 + R * d + 8 * R * e; sA[k + (k >> 3)] = u[i][e]; }
+        for (int e = 0; e < 8; ++e) { const int k = k1 + R * d + 8 * R * e; sA[IAS_S2_UP(k)] = u[i][e]; }
       }
     }
     wave_lds_sync();
@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
       vk_[i] = vq_[i] = gk_[i] = gq_[i] = 0.0f;
       if (k <= N2 / 2) {
         const int kn = (N2 - k) & (N2 - 1);
-        const cpx zk = sA[k + (k >> 3)], zn = sA[kn + (kn >> 3)];
+        const cpx zk = sA[IAS_S2_UP(k)], zn = sA[IAS_S2_UP(kn)];
         const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
         const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
         const cpx t = cmul(t_twu[64 * i], zo);            // W_N^k Zo[k]
@@ -1254,13 +1254,13 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
       const int k = lane + 64 * i;
       if (k <= N2 / 2) {
         const int kn = (N2 - k) & (N2 - 1);
-        sA[k + (k >> 3)] = cmk(zk_in[i].x, -zk_in[i].y);
-        if (kn != k) sA[kn + (kn >> 3)] = cmk(zn_in[i].x, -zn_in[i].y);
+        sA[IAS_S2_UP(k)] = cmk(zk_in[i].x, -zk_in[i].y);
+        if (kn != k) sA[IAS_S2_UP(kn)] = cmk(zn_in[i].x, -zn_in[i].y);
       }
     }
     wave_lds_sync();
 #pragma unroll
-    for (int n1 = 0; n1 < R; ++n1) { const int p = 64 * n1 + lane; v[n1] = sA[p + (p >> 3)]; }
+    for (int n1 = 0; n1 < R; ++n1) { const int p = 64 * n1 + lane; v[n1] = sA[IAS_S2_UP(p)]; }
     wave_lds_sync();
     fft(v);
     // z[m] = conj(out[m]) = y[2m] + i y[2m+1];  frame_grad = window * y
@@ -1269,7 +1269,7 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
 #pragma unroll
       for (int n1 = 0; n1 < R; ++n1) {
         const int m = 64 * n1 + lane;
-        const cpx o = sA[m + (m >> 3)];
+        const cpx o = sA[IAS_S2_UP(m)];
         const cpx w2 = t_win[64 * n1];
         cpx* rp = reinterpret_cast<cpx*>(ring + ((rb + 2 * m) & (NFFT - 1)));
         const cpx cur = *rp;
@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
 #pragma unroll
       for (int n1 = 0; n1 < R; ++n1) {
         const int m = 64 * n1 + lane;
-        const cpx o = sA[m + (m >> 3)];
+        const cpx o = sA[IAS_S2_UP(m)];
         const cpx w2 = t_win[64 * n1];
         *reinterpret_cast<cpx*>(out + 2 * m) = cmk(w2.x * o.x, -w2.y * o.y);
       }
@@ -1825,7 +1825,7 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
     hipLaunchKernelGGL((stft_grad512_kernel<W5>), dim3(grid5), dim3(64 * W5), lds5, stream, a);
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   }
-  const int R = n_fft / 128, scr = 8 * R * 9, np_it = (8 * R + 63) / 64, nunp = (n_fft / 4) / 64 + 1;
+  const int R = n_fft / 128, scr = 8 * R * IAS_S2_ROW, np_it = (8 * R + 63) / 64, nunp = (n_fft / 4) / 64 + 1;
   const size_t lds_static = sizeof(float) * 64 * (2 * R + 2 * R + 16 * np_it + 2 * nunp);   // the kernel's table object
   size_t lds = sizeof(cpx) * 4 * scr + 16;
   if (span) lds += sizeof(float) * 4 * n_fft;
