@@ -1358,7 +1358,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
     const bool live = a.loss_mode == 2 ? v > __builtin_amdgcn_sqrtf(a.eps) : v > 0.0f;
     return live ? 0.5f * gv * __builtin_amdgcn_rcpf(v) : 0.0f;
   };
-  auto pad = [](int i) { return i + (i >> 3); };
+  auto pad = [](int i) { return IAS_S2_UP(i); };   // i < 512: two pad elements per eight (see IAS_S2_ROW)
   // the three radix-8 passes of a 512-point transform: v = the lane's points 64 n1 + lane -> u[e] at kl + 64 e
   auto fft512 = [&](cpx (&v)[8], cpx (&u)[8]) {
     dft8(v);
@@ -1581,7 +1581,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 2) void stft_grad512_kern
     const bool live = a.loss_mode == 2 ? v > __builtin_amdgcn_sqrtf(a.eps) : v > 0.0f;
     return live ? 0.5f * gv * __builtin_amdgcn_rcpf(v) : 0.0f;
   };
-  auto pad = [](int i) { return i + (i >> 3); };
+  auto pad = [](int i) { return IAS_S2_UP(i); };   // i < 512: two pad elements per eight (see IAS_S2_ROW)
   // v[0..3] / v[4..7]: the lane's points 64 n1 + lane of frame A / B  ->  u[e] = transform of the lane's own frame
   // (slot >> 2) at kl + 32 e
   auto fft2 = [&](cpx (&v)[8], cpx (&u)[8]) {
