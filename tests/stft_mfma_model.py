@@ -214,6 +214,9 @@ def build_segtab(lib, n_fft, mel):
     return out
 
 
+SEG_STRIDE = 74          # csrc/stft2_kernels.hip: IAS_SEG_STRIDE (floats per row of the segment-major power buffer)
+
+
 def seg_mel(tab, Pbins, n_out):
     """Pbins [513] -> mel [n_out] through the lanes' store offsets, the row-wise gather and the U/D shift"""
     hdr = tab[:16].view(np.int32)
@@ -221,7 +224,7 @@ def seg_mel(tab, Pbins, n_out):
     rows, rA, rB, rC, s0, nseg = (int(v) for v in hdr[1:7])
     addr = tab[16:16 + 9 * 64].view(np.int32).reshape(9, 64)
     wt = tab[16 + 9 * 64:].astype(np.float64).reshape(rows, 64, 2)
-    buf = np.full(17 * 65 + 64, 1e30)                     # stale scratch: must only ever meet zero weights
+    buf = np.full(17 * SEG_STRIDE + 64, 1e30)             # stale scratch: must only ever meet zero weights
     seen = set()
     for e in range(4):
         k = (LANES >> 3) + 8 * (LANES & 7) + 64 * e
@@ -237,7 +240,7 @@ def seg_mel(tab, Pbins, n_out):
         for t in range(rg):
             r = base[g] + t
             w = wt[r]
-            pv = buf[r * 65 + LANES]
+            pv = buf[r * SEG_STRIDE + LANES]
             pv = np.where((w[:, 0] == 0) & (w[:, 1] == 0), 0.0, pv)      # 0 x stale = 0 in the kernel too (finite stale)
             U[g] += w[:, 0] * pv
             D[g] += w[:, 1] * pv
