@@ -11,7 +11,7 @@
 //   * mel projection without gathers at per-filter offsets.  A triangular filterbank puts every bin under at most two
 //     ADJACENT filters, so the bins split into contiguous segments (between two filter centres) and
 //         mel[m] = U[m] + D[m+1],   U[j] = sum over segment j of up_k P_k,   D[j] = sum over segment j of down_k P_k.
-//     The power values are stored segment-major ([position in segment][segment], row stride 74 floats): a lane that owns
+//     The power values are stored segment-major ([position in segment][segment], row stride 72 floats): a lane that owns
 //     segment j then reads position t of all segments as one conflict-free row, with the two weights of that bin as one
 //     8-byte read from a table of the same shape.  Each bin is read once (513 reads per frame instead of ~1100 at
 //     per-lane offsets), U/D meet through one DPP wave shift.
@@ -33,9 +33,9 @@
 // then rows x 64 x (up, down) weights.  Slot i = segment s0 + i lives in group i / 64 (A, B, C) on lane i % 64; row
 // r of group g holds position r - base(g) of the group's segments.
 #define IAS_SEG_MAGIC 0x5e67ab
-#define IAS_SEG_MAX_ROWS 17          // rows x 74 floats fit the wave's 5120-byte FFT scratch (spectral_kernels.hip: IAS_S2_ROW)
+#define IAS_SEG_MAX_ROWS 17          // rows x 72 floats fit the wave's 5120-byte FFT scratch (spectral_kernels.hip: IAS_S2_ROW)
 #define IAS_SEG_HDR 16
-#define IAS_SEG_STRIDE 74
+#define IAS_SEG_STRIDE 72
 
 struct SegPlan {
   int rows, r[3], s0, nseg;

@@ -214,7 +214,7 @@ def build_segtab(lib, n_fft, mel):
     return out
 
 
-SEG_STRIDE = 74          # csrc/stft2_kernels.hip: IAS_SEG_STRIDE (floats per row of the segment-major power buffer)
+SEG_STRIDE = 72          # csrc/stft2_kernels.hip: IAS_SEG_STRIDE (floats per row of the segment-major power buffer)
 
 
 def seg_mel(tab, Pbins, n_out):
