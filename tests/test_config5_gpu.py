@@ -150,3 +150,13 @@ def test_parallel_loss_sum_equals_the_serial_sum(lib, dev):
     assert torch.equal(out[1][0], ref.detach())
     for l, ga in (out[0], out[2]):
         assert torch.equal(l, out[1][0]) and torch.equal(ga, out[1][1])
+    # a first term without side streams of its own: the module opens one per extra term
+    swapped = ParallelLossSum(sub, mr)
+    a2 = a.detach().clone().requires_grad_(True)
+    l2 = swapped(a2, [dict(target_bands=tb), dict(targets=tm)])
+    (g2,) = torch.autograd.grad(l2, a2)
+    torch.cuda.synchronize()
+    assert torch.equal(l2.detach(), out[1][0]) and torch.equal(g2, out[1][1])
+    # no gradient wanted: the same value
+    with torch.no_grad():
+        assert torch.equal(both(a, [dict(targets=tm), dict(target_bands=tb)]), out[1][0])
