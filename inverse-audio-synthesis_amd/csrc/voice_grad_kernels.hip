@@ -793,8 +793,10 @@ __device__ __forceinline__ void g16_pitch_tile(G16Shared& sh, float* stage, cons
 
   const int k_first = (int)ias_mul(scale, (float)j0);
   const G16Ctrl cp1 = g16_ctrl(cb, k_first, Tc), cp2 = g16_ctrl(cb + 2 * Tc, k_first, Tc);
-  const double k = 0.6931471805599453 / 12.0;   // d inc / d pitch = inc * ln2 / 12
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};        // f0_1 depth_1 f0_2 depth_2
+  const float kf = (float)(0.6931471805599453 / 12.0);   // d inc / d pitch = inc * ln2 / 12
+  // f0_1 depth_1 f0_2 depth_2: fp32 over the thread's samples, fp64 across threads and tiles (as K1's six); the suffix sums
+  // themselves stay fp64, their products with the increments are fp32 (the cotangent they give is stored as fp32 anyway)
+  float accf[4] = {0.f, 0.f, 0.f, 0.f};
   float ta[2] = {0.f, 0.f}, tw[2] = {0.f, 0.f}, pa[2] = {0.f, 0.f}, pw[2] = {0.f, 0.f};
 #pragma unroll 1
   for (int q = G16_SPT / 4 - 1; q >= 0; --q) {              // see K1
@@ -807,17 +809,17 @@ __device__ __forceinline__ void g16_pitch_tile(G16Shared& sh, float* stage, cons
 #pragma unroll
     for (int x = 3; x >= 0; --x) {
       run1 += (double)ga1[x]; run2 += (double)ga2[x];          // inclusive suffix sums
-      const double gc1 = inc1[x] > 0.0f ? run1 * ((double)inc1[x] * k) : 0.0;
-      const double gc2 = inc2[x] > 0.0f ? run2 * ((double)inc2[x] * k) : 0.0;
+      const float gc1 = inc1[x] > 0.0f ? (float)run1 * (inc1[x] * kf) : 0.0f;     // the sign of the increment is K0's clamp flag
+      const float gc2 = inc2[x] > 0.0f ? (float)run2 * (inc2[x] * kf) : 0.0f;
       const float real = ias_mul(scale, (float)(jq + x));
       const int i0 = (int)real;
       const float w1 = ias_sub(real, (float)i0), w0 = ias_sub(1.0f, w1);
       const bool first = i0 == k_first;
       const float pm1 = g16_lerp(cp1, first, w0, w1), pm2 = g16_lerp(cp2, first, w0, w1);
-      acc[0] += gc1; acc[1] += gc1 * (double)pm1;
-      acc[2] += gc2; acc[3] += gc2 * (double)pm2;
+      accf[0] += gc1; accf[1] += gc1 * pm1;
+      accf[2] += gc2; accf[3] += gc2 * pm2;
       const float m0 = first ? 1.0f : 0.0f;
-      const float xs[2] = {(float)(gc1 * (double)vc.depth_1), (float)(gc2 * (double)vc.depth_2)};
+      const float xs[2] = {gc1 * vc.depth_1, gc2 * vc.depth_2};
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const float xw = w1 * xs[r];
@@ -826,6 +828,7 @@ __device__ __forceinline__ void g16_pitch_tile(G16Shared& sh, float* stage, cons
       }
     }
   }
+  const double acc[4] = {(double)accf[0], (double)accf[1], (double)accf[2], (double)accf[3]};
 #pragma unroll
   for (int r = 0; r < 2; ++r)
     *g16_fold_slot<true>(stage, r, rt) = (g16_f4){pa[r] - pw[r], pw[r], (ta[r] - pa[r]) - (tw[r] - pw[r]), tw[r] - pw[r]};
