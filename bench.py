@@ -286,7 +286,8 @@ def run_vicreg(args, rank, world, dev):
                                 if os.environ.get("IAS_VICREG_GRAM128", "0") not in ("", "0") or D < 256 else
                                 "vicreg_gram256_kernel (256 x 256 tiles, LDS-DMA; both branches, one launch)"),
                      "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "traffic": pmc_traffic_of("vicreg_gram_pair_kernel" if kpad == 128 else "vicreg_gram256_kernel"),
                      "avg_launch_ms": round(gram_ms, 4), "flops_executed": executed, "flops_nominal_2BD2_per_branch_x2": nominal,
                      "frac_nominal": round(nominal / (gram_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                      "measured": "HIP events around K back-to-back launches of stage 1 (the Gram) on the global batch"},
@@ -372,6 +373,17 @@ def pretrain_leg(dev, B=128, steps=5, reps=5):
                         "PQMF(3) + MobileNetV3-small trunk + projector 8192 + VICReg loss, backward, LARS; fp32 (bf16 only "
                         "inside the VICReg Gram), random init, synthetic parameters",
             "launch": "hipgraph (Trainer._graph_step)", "loss": loss}
+
+
+def pmc_traffic_of(kname):
+    """HBM-side bytes per launch of a kernel from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    scripts/refresh_profiles.sh), or None."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:  # noqa: BLE001
+        return None
+    hits = [v for k, v in table.items() if kname in k and isinstance(v, dict)]
+    return hits[0].get("hbm_bytes_per_launch") if hits else None
 
 
 def run_gradstep(args, rank, world, dev):

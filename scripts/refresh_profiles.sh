@@ -62,6 +62,31 @@ step pmc voice; bash $R/scripts/diag/pmc_voice.sh $tag > /dev/null 2>&1; cp $R/g
 step pmc pqmf; bash $R/scripts/diag/pmc_pqmf.sh $tag N=3 > /dev/null 2>&1; cp $R/gpurun_out/pmcq_$tag/summary.txt $O/pmc_pqmf.txt
 step pmc vicreg; bash $R/scripts/diag/pmc_vicreg.sh $tag 128 > /dev/null 2>&1; cp $R/gpurun_out/pmcg_$tag/summary.txt $O/pmc_vicreg.txt
 step pmc vicreg1024; bash $R/scripts/diag/pmc_vicreg.sh ${tag}_1024 1024 > /dev/null 2>&1; cp $R/gpurun_out/pmcg_${tag}_1024/summary.txt $O/pmc_vicreg1024.txt
+# the Gram kernels' FETCH_SIZE / WRITE_SIZE (their own passes inside pmc_vicreg.sh) -> traffic.json, for the vicreg bench lines
+python3 - <<PY
+import json, re
+O = "$O"
+def parse(path):
+    out, cur = {}, None
+    try:
+        for line in open(path):
+            if line[:1] not in (" ", "\n") and "calls" not in line:
+                cur = line.split("(")[0].strip(); out.setdefault(cur, {})
+            else:
+                m = re.match(r"^\s+(\w+)\s+([0-9.]+)", line)
+                if m and cur: out[cur][m.group(1)] = float(m.group(2))
+    except OSError:
+        pass
+    return out
+t = json.load(open(O + "/traffic.json"))
+for path, kname in ((O + "/pmc_vicreg.txt", "vicreg_gram_pair_kernel"), (O + "/pmc_vicreg1024.txt", "vicreg_gram256_kernel")):
+    d = parse(path).get(kname, {})
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        t[kname] = {"FETCH_SIZE_KB_avg": round(d["FETCH_SIZE"], 1), "WRITE_SIZE_KB_avg": round(d["WRITE_SIZE"], 1),
+                    "hbm_bytes_per_launch": int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024),
+                    "_note": "bytes beyond L2 (FETCH_SIZE counts L2 misses; part of them are served by the Infinity Cache)"}
+json.dump(t, open(O + "/traffic.json", "w"), indent=1)
+PY
 step kstats pretrain; bash $R/scripts/diag/kstats_pretrain.sh $tag > $O/kstats_pretrain.txt 2>&1
 step pmc stft; bash $R/scripts/diag/pmc_stft.sh $tag PARTS=loss > /dev/null 2>&1; cp $R/gpurun_out/pmcs_$tag/summary.txt $O/pmc_stft.txt
 step trace; bash $R/scripts/diag/trace_bench.sh $tag > $O/trace_default.txt 2>&1
