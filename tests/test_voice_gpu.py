@@ -222,3 +222,14 @@ def test_normalisation_folded_into_the_consumers(lib, dev):
     m_fold = mel.mel.plan.values(raw, rowpeak=peaks)
     m_ref = mel.mel.plan.values(norm)
     assert ((m_fold - m_ref).abs() <= 1e-5 * m_ref.abs() + 1e-6).all()
+
+
+def test_saved_for_backward_equals_the_three_copies(lib, dev):
+    """ias_voice_save_for_backward (one launch) against rendered_control() + read_peaks() (three device copies)."""
+    v = _voice(dev, 5, 16000, 1.0)
+    v(9)
+    ctrl, vconst, peaks = v.saved_for_backward()
+    c2, v2 = v.rendered_control()
+    assert torch.equal(ctrl, c2) and torch.equal(vconst, v2) and torch.equal(peaks, v.read_peaks())
+    c3, v3, p3 = v.saved_for_backward(with_peaks=False)
+    assert p3 is None and torch.equal(c3, c2) and torch.equal(v3, v2)
