@@ -558,19 +558,37 @@ __device__ __forceinline__ g16_f4* g16_fold_slot(float* stage, int r, int p) {
 }
 // s_kfirst[p] non-decreasing in p (G16_NOK: none).  Thread idx < NR * kslots adds, for interval k_lo + kk, the partials of
 // the positions with k_first in {k - 1, k} in ascending p -> out[(rows[r] * kslots + kk) * 2 + {0, 1}].
+// Only ~3 x 45 threads of the workgroup work here while the rest wait at the kernel's end, so the step is a latency chain:
+// the first position comes from arithmetic (an under-estimate, corrected by at most a few probes; a binary search was 8
+// dependent LDS reads), and the partials are read eight positions at a time (16 reads in flight) and added in order --
+// the loop that read one position per trip took 16 us of each tile kernel's 95 / 61 us.
 template <int NR, bool REV>
 __device__ __forceinline__ void g16_fold(float* stage, const int* s_kfirst, int k_lo, int kslots, const int (&rows)[NR],
-                                         double* __restrict__ out, int tid) {
+                                         double* __restrict__ out, int tid, float scale, int tile_base) {
+  const float inv = (1.0f / scale) * (1.0f / (float)G16_SPT);
   for (int idx = tid; idx < NR * kslots; idx += GRAD_THREADS) {
     const int r = idx / kslots, kk = idx - r * kslots, k = k_lo + kk;
-    int lo = 0, hi = GRAD_THREADS;                     // first p with k_first(p) >= k - 1
-    while (lo < hi) { const int m = (lo + hi) >> 1; if (s_kfirst[m] < k - 1) lo = m + 1; else hi = m; }
+    // first p with k_first(p) >= k - 1: k_first(p) = trunc(scale (tile_base + SPT p)), so p >= ((k - 1) / scale - tile_base) / SPT
+    int p = (int)floorf((float)(k - 1) * inv - (float)tile_base * (1.0f / (float)G16_SPT)) - 1;
+    p = max(0, min(p, GRAD_THREADS - 1));
+    // (a step back is only ever needed if the estimate was rounded up; positions without samples carry G16_NOK and end it)
+    for (int g = 0; g < 4 && p > 0 && s_kfirst[p - 1] >= k - 1 && s_kfirst[p - 1] != G16_NOK; ++g) --p;
+    while (p < GRAD_THREADS && s_kfirst[p] < k - 1) ++p;
     double A = 0.0, B = 0.0;
-    for (int p = lo; p < GRAD_THREADS; ++p) {
-      const int kf = s_kfirst[p];
-      if (kf > k) break;
-      const g16_f4 f = *g16_fold_slot<REV>(stage, r, p);
-      if (kf == k) { A += (double)f.x; B += (double)f.y; } else { A += (double)f.z; B += (double)f.w; }
+    bool done = false;
+    for (int base = p; base < GRAD_THREADS && !done; base += 8) {
+      int kf[8]; g16_f4 f[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int pp = min(base + u, GRAD_THREADS - 1);
+        kf[u] = base + u < GRAD_THREADS ? s_kfirst[pp] : G16_NOK;
+        f[u] = *g16_fold_slot<REV>(stage, r, pp);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (done || kf[u] > k) { done = true; continue; }
+        if (kf[u] == k) { A += (double)f[u].x; B += (double)f[u].y; } else { A += (double)f[u].z; B += (double)f[u].w; }
+      }
     }
     out[((size_t)rows[r] * kslots + kk) * 2] = A;
     out[((size_t)rows[r] * kslots + kk) * 2 + 1] = B;
@@ -719,7 +737,8 @@ __device__ __forceinline__ void g16_sample_tile(
     partials_bt[GS_PHI_1] = s_out[6]; partials_bt[GS_PHI_2] = s_out[7];
   }
   const int rows[3] = {1, 3, 4};               // amp1, amp2, ampn among the five control rows
-  g16_fold<3, false>(stage, s_kfirst, (int)ias_mul(scale, (float)(tile * GRAD_TILE)), kslots, rows, isum_bt, tid);
+  g16_fold<3, false>(stage, s_kfirst, (int)ias_mul(scale, (float)(tile * GRAD_TILE)), kslots, rows, isum_bt, tid, scale,
+                     tile * GRAD_TILE);
 }
 
 __global__ __launch_bounds__(GRAD_THREADS, G16_SPT == 8 ? 4 : 2) void voice_grad_sample16_kernel(
@@ -840,7 +859,8 @@ __device__ __forceinline__ void g16_pitch_tile(G16Shared& sh, float* stage, cons
     partials_bt[GS_F0_2] = s_out[2]; partials_bt[GS_DEPTH_2] = s_out[3];
   }
   const int rows[2] = {0, 2};
-  g16_fold<2, true>(stage, s_kfirst, (int)ias_mul(scale, (float)(tile * GRAD_TILE)), kslots, rows, isum_bt, tid);
+  g16_fold<2, true>(stage, s_kfirst, (int)ias_mul(scale, (float)(tile * GRAD_TILE)), kslots, rows, isum_bt, tid, scale,
+                    tile * GRAD_TILE);
 }
 
 __global__ __launch_bounds__(GRAD_THREADS, G16_SPT == 8 ? 4 : 2) void voice_grad_pitch16_kernel(
