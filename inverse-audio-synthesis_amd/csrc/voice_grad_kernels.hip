@@ -560,8 +560,9 @@ __device__ __forceinline__ g16_f4* g16_fold_slot(float* stage, int r, int p) {
 // the positions with k_first in {k - 1, k} in ascending p -> out[(rows[r] * kslots + kk) * 2 + {0, 1}].
 // Only ~3 x 45 threads of the workgroup work here while the rest wait at the kernel's end, so the step is a latency chain:
 // the first position comes from arithmetic (an under-estimate, corrected by at most a few probes; a binary search was 8
-// dependent LDS reads), and the partials are read eight positions at a time (16 reads in flight) and added in order --
-// the loop that read one position per trip took 16 us of each tile kernel's 95 / 61 us.
+// dependent LDS reads), and the partials are read eight positions at a time (16 reads in flight) and added in order
+// (95 / 61 -> 94 / 60 us; with the whole transposed upsample compiled out -- this step AND the per-sample interval partials --
+// the two kernels take 79 / 46 us).
 template <int NR, bool REV>
 __device__ __forceinline__ void g16_fold(float* stage, const int* s_kfirst, int k_lo, int kslots, const int (&rows)[NR],
                                          double* __restrict__ out, int tid, float scale, int tile_base) {
