@@ -182,11 +182,12 @@ def vicreg_cpu_baseline(B, D):
 
 
 def run_vicreg(args, rank, world, dev):
-    """BASELINE configs[2] / [3]: the projector loss on [B, 8192] embeddings, forward + backward.  N = 1: the local
-    loss.  N > 1: x and y all-gathered over RCCL (FullGatherLayer), the loss on the global batch with denominator
-    B_global - 1, gradients reduce-scattered back -- one real exchange step per direction."""
+    """BASELINE configs[2] / [3]: the projector loss on [B, 8192] embeddings, forward + backward, through
+    ``vicreg.global_batch_loss`` -- the function ``VICReg.loss`` calls.  N = 1: the local loss.  N > 1: cat(x, y) all-gathered
+    over RCCL, the loss on the global batch with denominator B_global - 1, the gradient reduce-scattered back -- one real
+    exchange step per direction."""
     from inverse_audio_synthesis_amd import _lib
-    from inverse_audio_synthesis_amd.vicreg import FullGatherLayer, vicreg_loss
+    from inverse_audio_synthesis_amd.vicreg import global_batch_loss
     lib = _lib.load()
     B, D = args.batch or BATCH, 8192
     x = torch.randn(B, D, generator=torch.Generator().manual_seed(2 * rank)).to(dev).requires_grad_()
@@ -195,12 +196,9 @@ def run_vicreg(args, rank, world, dev):
     state = {}
 
     def step():
-        if gather:
-            xy = torch.cat(FullGatherLayer.apply(torch.cat([x, y], dim=1)), dim=0)     # ONE collective for both branches
-            xa, ya = xy[:, :D], xy[:, D:]
-        else:
-            xa, ya = x, y
-        out = vicreg_loss(xa.contiguous(), ya.contiguous(), B * world, 25.0, 25.0, 1.0)
+        # the code VICReg.loss runs (inverse-audio-synthesis_amd/vicreg.py): N > 1 = ONE all-gather of cat(x, y, dim=1), the
+        # loss on the gathered buffer in place with denominator B * world - 1, one reduce-scatter of its cotangent
+        out = global_batch_loss(x, y, B, 25.0, 25.0, 1.0, gather=True)
         gx, gy = torch.autograd.grad(out[0], (x, y))          # backward of the loss (and of the gather)
         state["out"] = tuple(v.detach() for v in out)
         state["grads"] = (gx, gy)

@@ -315,6 +315,17 @@ int ias_vicreg_backward(const float* x, const float* y, const float* gcoef, floa
                         long long workspace_bytes, int B, int D, int cfg_batch, float sim_coeff, float std_coeff,
                         float cov_coeff, void* stream);
 
+/* The same pair for x, y (and gx, gy) that are COLUMN BLOCKS of wider row-major matrices: row strides ld / ldg in floats
+ * (>= D; with ld != D or ldg != D: multiples of 4 and 16-byte aligned base pointers).  This is how the global-batch loss
+ * of the gather the reference keeps commented out (vicreg.py:38-39 with FullGatherLayer :79-95) runs without copies:
+ * ONE all-gather of cat(x, y, dim=1) lands in a [W B_l, 2 D] buffer, x = buf[:, :D], y = buf[:, D:] are consumed in
+ * place, and the two gradient blocks are written straight into the [W B_l, 2 D] cotangent the backward reduce-scatters. */
+int ias_vicreg_loss_ld(const float* x, const float* y, long long ld, float* out, void* workspace, long long workspace_bytes,
+                       int B, int D, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff, void* stream);
+int ias_vicreg_backward_ld(const float* x, const float* y, long long ld, const float* gcoef, float* gx, float* gy,
+                           long long ldg, void* workspace, long long workspace_bytes, int B, int D, int cfg_batch,
+                           float sim_coeff, float std_coeff, float cov_coeff, void* stream);
+
 /* One stage of ias_vicreg_loss on the same workspace: 0 column pass, 1 the Gram kernel(s) on the matrix cores,
  * 2 the final reduction (stage < 0: all of them = ias_vicreg_loss).  Lets a caller time the Gram alone. */
 int ias_vicreg_stage(int stage, const float* x, const float* y, float* out, void* workspace, long long workspace_bytes,

@@ -7,12 +7,11 @@ When ``gram`` is this package's PQMF and ``img_preprocess`` is a ``ChannelNormal
 reshape (a pure view) and the normalisation run as ONE HIP kernel (the fused epilogue of
 csrc/pqmf_kernels.hip) instead of a 90 MB intermediate read + write.
 """
-import os
-
 import torch
 import torch.nn as nn
 
 from .pqmf import PQMF, pqmf_analysis
+from .vision import trunk_torch
 
 
 class ChannelNormalize(nn.Module):
@@ -105,7 +104,7 @@ class AudioEmbedding(nn.Module):
             return (c.kernel_size == (2, 2) and c.stride == (1, 1) and c.padding == (0, 0) and c.dilation == (1, 1)
                     and c.groups == 1 and c.padding_mode == "zeros")
         # IAS_TRUNK_TORCH=1: the nn.Conv2d head (A/B debugging; the trunk layers honour the same switch in vision.py)
-        if t.is_cuda and t.dtype == torch.float32 and os.environ.get("IAS_TRUNK_TORCH") != "1" and \
+        if t.is_cuda and t.dtype == torch.float32 and not trunk_torch() and \
                 all(plain2x2(getattr(self, f"conv{i}")) for i in range(1, 8)):
             t = t.permute(0, 2, 3, 1)                 # channels-last once; the head stays channels-last
             for i in range(7, 0, -1):

@@ -374,7 +374,7 @@ extern "C" int ias_stft_grad_combine(const float* const* spans_host, const int* 
     a.spans[r] = spans_host[r]; a.N[r] = p[0]; a.hop[r] = p[1]; a.G[r] = p[2]; a.cper[r] = p[3]; a.L[r] = p[4];
     a.F[r] = 1 + T / p[1];
     if ((long long)p[2] * p[1] > 0x7fffffffLL || (long long)T + p[0] > 0x7fffffffLL) return IAS_ERR_ARG;
-    a.magic[r] = (unsigned)(0x100000000ULL / (unsigned long long)((long long)p[2] * p[1]));
+    a.magic[r] = (long long)p[2] * p[1] == 1 ? 0xFFFFFFFFu : (unsigned)(0x100000000ULL / (unsigned long long)((long long)p[2] * p[1]));
     if (p[3] != (a.F[r] + p[2] - 1) / p[2]) return IAS_ERR_ARG;
   }
   a.nres = nres;

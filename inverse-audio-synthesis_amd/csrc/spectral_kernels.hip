@@ -1814,7 +1814,7 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
       const int grid2 = (int)(need < 2LL * ncu ? need : 2LL * ncu);
       (void)hipFuncSetAttribute((const void*)stft_grad2k_kernel<W2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       hipLaunchKernelGGL((stft_grad2k_kernel<W2, false>), dim3(grid2), dim3(64 * W2), lds2, stream, a, B * F,
-                         (unsigned)(0x100000000ULL / (unsigned long long)F));
+                         (F == 1 ? 0xFFFFFFFFu /* 2^32 / 1 does not fit: q0 = fi - 1, which row_of's one-step correction fixes */ : (unsigned)(0x100000000ULL / (unsigned long long)F)));
     }
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   }
@@ -2124,7 +2124,7 @@ extern "C" int ias_stft(const float* audio, const float* tables, const float* mt
     Spec2Args a2;
     a2.audio = audio; a2.tables = tables; a2.segtab = mel ? segtab : nullptr; a2.out = out; a2.target = target;
     a2.partials = partials; a2.rowpeak = rowpeak; a2.T = T; a2.F = F; a2.hop = hop; a2.n_out = n_out; a2.nframes = B * F;
-    a2.magicF = (unsigned)(0x100000000ULL / (unsigned long long)F);
+    a2.magicF = (F == 1 ? 0xFFFFFFFFu /* 2^32 / 1 does not fit: q0 = fi - 1, which row_of's one-step correction fixes */ : (unsigned)(0x100000000ULL / (unsigned long long)F));
     a2.value_mode = value_mode; a2.loss_mode = loss_mode; a2.eps = eps;
 #ifdef IAS_S2_STAMPS
     a2.stamps = g_s2_stamps;

@@ -763,7 +763,7 @@ int ias_sm_launch(const float* audio, const float* mtab, bool mel, float* out, c
   a.T = T; a.F = F; a.hop = hop; a.n_out = n_out; a.nframes = B * F; a.ngroups = (a.nframes + 15) / 16;
   static const int noticket = getenv("IAS_STFT_NOTICKET") ? atoi(getenv("IAS_STFT_NOTICKET")) : 0;   // diagnostics
   a.ticket = noticket ? nullptr : ticket;
-  a.magicF = (unsigned)(0x100000000ULL / (unsigned long long)F);
+  a.magicF = (F == 1 ? 0xFFFFFFFFu /* 2^32 / 1 does not fit: q0 = fi - 1, which row_of's one-step correction fixes */ : (unsigned)(0x100000000ULL / (unsigned long long)F));
   a.value_mode = value_mode; a.loss_mode = loss_mode; a.eps = eps;
 #ifdef IAS_SM_STAMPS
   a.stamps = g_sm_stamps;

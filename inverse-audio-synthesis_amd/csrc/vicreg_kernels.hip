@@ -44,7 +44,7 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
     const float* __restrict__ x, const float* __restrict__ y, unsigned short* __restrict__ Xt_x,
     unsigned short* __restrict__ Xt_y, float* __restrict__ colstats, double* __restrict__ msepart,
     double* __restrict__ hingepart, unsigned short* __restrict__ Xc_x, unsigned short* __restrict__ Xc_y, int B, int D,
-    int Kpad) {
+    int Kpad, size_t ld /* row stride of x and y in floats (>= D: x, y may be column blocks of a wider matrix) */) {
   constexpr int NW = VC_THREADS / 64, RPI = 2 * NW;              // rows per iteration of the workgroup
   __shared__ float s_red[4][NW][64];
   __shared__ float s_mean[2][VC_COLS];
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
   float sx = 0.f, sy = 0.f, se = 0.f;
   for (int b = 2 * wave + rsub; b < B; b += RPI) {
     if (jok) {
-      const float xv = x[(size_t)b * D + j], yv = y[(size_t)b * D + j];
+      const float xv = x[(size_t)b * ld + j], yv = y[(size_t)b * ld + j];
       sx += xv; sy += yv;
       const float d = xv - yv;
       se = fmaf(d, d, se);
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
       const int b = b0 + r;
       float cx = 0.f, cy = 0.f;
       if (jok && b < B) {
-        cx = x[(size_t)b * D + j] - mx;
-        cy = y[(size_t)b * D + j] - my;
+        cx = x[(size_t)b * ld + j] - mx;
+        cy = y[(size_t)b * ld + j] - my;
         qx = fmaf(cx, cx, qx);
         qy = fmaf(cy, cy, qy);
       }
@@ -830,11 +830,11 @@ extern "C" long long ias_vicreg_workspace_bytes(int B, int D) {
 // stage < 0: the whole loss; 0: column pass (means, centred bf16 transposes, MSE / hinge partials); 1: the Gram
 // kernel(s) on the matrix cores; 2: the final reduction.  Stages run on a workspace the earlier stages have filled
 // (bench.py times stage 1 alone with HIP events for the MFMA roofline).
-extern "C" int ias_vicreg_stage(int stage, const float* x, const float* y, float* out, void* workspace,
-                                long long workspace_bytes, int B, int D, int cfg_batch, float sim_coeff, float std_coeff,
-                                float cov_coeff, void* stream_) {
+static int vicreg_stage_ld(int stage, const float* x, const float* y, long long ld, float* out, void* workspace,
+                           long long workspace_bytes, int B, int D, int cfg_batch, float sim_coeff, float std_coeff,
+                           float cov_coeff, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!x || !y || !out || !workspace || B < 2 || D < 1 || cfg_batch < 2 || stage > 2) return IAS_ERR_ARG;
+  if (!x || !y || !out || !workspace || B < 2 || D < 1 || cfg_batch < 2 || stage > 2 || ld < D) return IAS_ERR_ARG;
   const VicregWs w = vicreg_ws(B, D);
   if ((size_t)workspace_bytes < w.total) return IAS_ERR_WORKSPACE;
   char* ws = (char*)workspace;
@@ -847,7 +847,7 @@ extern "C" int ias_vicreg_stage(int stage, const float* x, const float* y, float
   double* gram_y = (double*)(ws + w.gram_y);
   if (stage < 0 || stage == 0)
     hipLaunchKernelGGL(vicreg_colstats_kernel, dim3(w.nmse), dim3(VC_THREADS), 0, stream, x, y, xt_x, xt_y, colstats,
-                       mse, hinge, (unsigned short*)(ws + w.xc_x), (unsigned short*)(ws + w.xc_y), B, D, w.Kpad);
+                       mse, hinge, (unsigned short*)(ws + w.xc_x), (unsigned short*)(ws + w.xc_y), B, D, w.Kpad, (size_t)ld);
   int ngram = w.ngram;
   int nitems = 0;
   // deep contractions: 256 x 256 tiles
@@ -881,11 +881,27 @@ extern "C" int ias_vicreg_stage(int stage, const float* x, const float* y, float
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
+extern "C" int ias_vicreg_stage(int stage, const float* x, const float* y, float* out, void* workspace,
+                                long long workspace_bytes, int B, int D, int cfg_batch, float sim_coeff, float std_coeff,
+                                float cov_coeff, void* stream_) {
+  return vicreg_stage_ld(stage, x, y, D, out, workspace, workspace_bytes, B, D, cfg_batch, sim_coeff, std_coeff, cov_coeff,
+                         stream_);
+}
+
 extern "C" int ias_vicreg_loss(const float* x, const float* y, float* out, void* workspace, long long workspace_bytes,
                                int B, int D, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff,
                                void* stream_) {
-  return ias_vicreg_stage(-1, x, y, out, workspace, workspace_bytes, B, D, cfg_batch, sim_coeff, std_coeff, cov_coeff,
-                          stream_);
+  return vicreg_stage_ld(-1, x, y, D, out, workspace, workspace_bytes, B, D, cfg_batch, sim_coeff, std_coeff, cov_coeff,
+                         stream_);
+}
+
+// The same loss on x, y that are column blocks of wider row-major matrices (row stride ld >= D floats): the gathered
+// [W B_l, 2 D] buffer of FullGatherLayer(cat(x, y, dim=1)) is consumed in place, x = buf[:, :D], y = buf[:, D:].
+extern "C" int ias_vicreg_loss_ld(const float* x, const float* y, long long ld, float* out, void* workspace,
+                                  long long workspace_bytes, int B, int D, int cfg_batch, float sim_coeff, float std_coeff,
+                                  float cov_coeff, void* stream_) {
+  return vicreg_stage_ld(-1, x, y, ld, out, workspace, workspace_bytes, B, D, cfg_batch, sim_coeff, std_coeff, cov_coeff,
+                         stream_);
 }
 
 
@@ -1032,7 +1048,7 @@ __global__ __launch_bounds__(256, 2) void vicreg_grad_kernel(
     const unsigned short* __restrict__ Xt_y, const unsigned short* __restrict__ Gb, const float* __restrict__ gdiag,
     const float* __restrict__ colstats,
     const float* __restrict__ gcoef /* g_loss, g_repr, g_std, g_cov */, float* __restrict__ gx, float* __restrict__ gy,
-    int B, int D, int Kpad, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff) {
+    int B, int D, int Kpad, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff, size_t ld, size_t ldg) {
   __shared__ __attribute__((aligned(16))) unsigned short s_a[2][GT][GLD];   // G rows (bf16)
   __shared__ __attribute__((aligned(16))) unsigned short s_b[2][GT][GLD];   // Xt rows (features)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1072,10 +1088,10 @@ __global__ __launch_bounds__(256, 2) void vicreg_grad_kernel(
       for (int e = 0; e < 16; ++e) {
         const int b = row0 + wr * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (b >= B) continue;
-        const size_t idx = (size_t)b * D + j;
+        const size_t idx = (size_t)b * ld + j;
         const float xv = x[idx], yv = y[idx];
         const float v = own[idx] - mu;
-        gout[idx] = repr_k * (xv - yv) + av * v + cc * kappa * (acc[m][n][e] + gdiag[(size_t)branch * Kpad + b] * v);
+        gout[(size_t)b * ldg + j] = repr_k * (xv - yv) + av * v + cc * kappa * (acc[m][n][e] + gdiag[(size_t)branch * Kpad + b] * v);
       }
   }
 }
@@ -1168,7 +1184,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void vicreg_grad256_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const unsigned short* __restrict__ Xt_x,
     const unsigned short* __restrict__ Xt_y, const unsigned short* __restrict__ Gb, const float* __restrict__ gdiag,
     const float* __restrict__ colstats, const float* __restrict__ gcoef, float* __restrict__ gx, float* __restrict__ gy,
-    int B, int D, int Kpad, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff) {
+    int B, int D, int Kpad, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff, size_t ld, size_t ldg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_g2[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3, r = lane & 15, q = lane >> 4;
@@ -1206,7 +1222,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void vicreg_grad256_kernel(
       av[c] = (sd < 1.0f ? -cb / (2.0f * (float)D * (float)(B - 1) * sd) : 0.0f) - cc * kappa * m2;
     }
   }
-  const bool vec = (D & 3) == 0 && j0 + 3 < D;
+  const bool vec = (D & 3) == 0 && ((ld | ldg) & 3) == 0 && j0 + 3 < D;   // (16-byte aligned bases: checked by the caller)
   for (int half = 0; half < 2; ++half) {
     if (wr == half) {
 #pragma unroll
@@ -1224,7 +1240,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void vicreg_grad256_kernel(
       if (b >= B) continue;
       const vc_f32x4 cv = *reinterpret_cast<const vc_f32x4*>(s_c + rl * 256 + ((4 * c4) ^ (((rl >> 2) & 3) << 4)));
       const float gd = gdiag[(size_t)branch * Kpad + b];
-      const size_t idx = (size_t)b * D + j0;
+      const size_t idx = (size_t)b * ld + j0, odx = (size_t)b * ldg + j0;
       if (vec) {
         const vc_f32x4 xv = *reinterpret_cast<const vc_f32x4*>(x + idx), yv = *reinterpret_cast<const vc_f32x4*>(y + idx);
         vc_f32x4 o;
@@ -1233,12 +1249,12 @@ __global__ __launch_bounds__(G2_THREADS, 2) void vicreg_grad256_kernel(
           const float v = (branch ? yv[c] : xv[c]) - mu[c];
           o[c] = repr_k * (xv[c] - yv[c]) + av[c] * v + cc * kappa * (cv[c] + gd * v);
         }
-        *reinterpret_cast<vc_f32x4*>(gout + idx) = o;
+        *reinterpret_cast<vc_f32x4*>(gout + odx) = o;
       } else {
         for (int c = 0; c < 4; ++c) {
           if (j0 + c >= D) break;
           const float v = own[idx + c] - mu[c];
-          gout[idx + c] = repr_k * (x[idx + c] - y[idx + c]) + av[c] * v + cc * kappa * (cv[c] + gd * v);
+          gout[odx + c] = repr_k * (x[idx + c] - y[idx + c]) + av[c] * v + cc * kappa * (cv[c] + gd * v);
         }
       }
     }
@@ -1248,11 +1264,14 @@ __global__ __launch_bounds__(G2_THREADS, 2) void vicreg_grad256_kernel(
 
 // Backward of ias_vicreg_loss on the SAME workspace (it must still hold the forward's column statistics and centred
 // bf16 copies): gcoef [4] device floats = the cotangents of (loss, repr_loss, std_loss, cov_loss) -> gx, gy [B,D] fp32.
-extern "C" int ias_vicreg_backward(const float* x, const float* y, const float* gcoef, float* gx, float* gy, void* workspace,
-                                   long long workspace_bytes, int B, int D, int cfg_batch, float sim_coeff, float std_coeff,
-                                   float cov_coeff, void* stream_) {
+static int vicreg_backward_ld(const float* x, const float* y, long long ld, const float* gcoef, float* gx, float* gy,
+                              long long ldg, void* workspace, long long workspace_bytes, int B, int D, int cfg_batch,
+                              float sim_coeff, float std_coeff, float cov_coeff, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!x || !y || !gcoef || !gx || !gy || !workspace || B < 2 || D < 8 || (D & 7) || cfg_batch < 2) return IAS_ERR_ARG;
+  if (!x || !y || !gcoef || !gx || !gy || !workspace || B < 2 || D < 8 || (D & 7) || cfg_batch < 2 || ld < D || ldg < D)
+    return IAS_ERR_ARG;
+  // the 256-tile epilogue moves 16 bytes per access: strided views must keep that alignment
+  if ((ld != D || ldg != D) && ((((size_t)x | (size_t)y | (size_t)gx | (size_t)gy) & 15) || ((ld | ldg) & 3))) return IAS_ERR_ARG;
   const VicregWs w = vicreg_ws(B, D);
   if ((size_t)workspace_bytes < w.total) return IAS_ERR_WORKSPACE;
   char* ws = (char*)workspace;
@@ -1284,13 +1303,31 @@ extern "C" int ias_vicreg_backward(const float* x, const float* y, const float* 
     (void)hipFuncSetAttribute((const void*)vicreg_grad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
     hipLaunchKernelGGL(vicreg_grad256_kernel, dim3((D + G2_T - 1) / G2_T, bt2, 2), dim3(G2_THREADS), lds256, stream, x, y,
                        (const unsigned short*)(ws + w.xt_x), (const unsigned short*)(ws + w.xt_y), Gb, gdiag,
-                       (const float*)(ws + w.colstats), gcoef, gx, gy, B, D, w.Kpad, cfg_batch, sim_coeff, std_coeff, cov_coeff);
+                       (const float*)(ws + w.colstats), gcoef, gx, gy, B, D, w.Kpad, cfg_batch, sim_coeff, std_coeff, cov_coeff,
+                       (size_t)ld, (size_t)ldg);
   } else {
     hipLaunchKernelGGL(vicreg_grad_kernel, dim3((D + GT - 1) / GT, bt, 2), dim3(256), 0, stream, x, y,
                        (const unsigned short*)(ws + w.xt_x), (const unsigned short*)(ws + w.xt_y), Gb, gdiag,
-                       (const float*)(ws + w.colstats), gcoef, gx, gy, B, D, w.Kpad, cfg_batch, sim_coeff, std_coeff, cov_coeff);
+                       (const float*)(ws + w.colstats), gcoef, gx, gy, B, D, w.Kpad, cfg_batch, sim_coeff, std_coeff, cov_coeff,
+                       (size_t)ld, (size_t)ldg);
   }
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+extern "C" int ias_vicreg_backward(const float* x, const float* y, const float* gcoef, float* gx, float* gy, void* workspace,
+                                   long long workspace_bytes, int B, int D, int cfg_batch, float sim_coeff, float std_coeff,
+                                   float cov_coeff, void* stream_) {
+  return vicreg_backward_ld(x, y, D, gcoef, gx, gy, D, workspace, workspace_bytes, B, D, cfg_batch, sim_coeff, std_coeff,
+                            cov_coeff, stream_);
+}
+
+// Backward of ias_vicreg_loss_ld: x, y with row stride ld, gx, gy WRITTEN with row stride ldg (the two column blocks of
+// the [W B_l, 2 D] cotangent that FullGatherLayer's backward reduce-scatters: no split / cat copies either way).
+extern "C" int ias_vicreg_backward_ld(const float* x, const float* y, long long ld, const float* gcoef, float* gx, float* gy,
+                                      long long ldg, void* workspace, long long workspace_bytes, int B, int D, int cfg_batch,
+                                      float sim_coeff, float std_coeff, float cov_coeff, void* stream_) {
+  return vicreg_backward_ld(x, y, ld, gcoef, gx, gy, ldg, workspace, workspace_bytes, B, D, cfg_batch, sim_coeff, std_coeff,
+                            cov_coeff, stream_);
 }
 
 extern "C" long long ias_vicreg_colstats_offset(int B, int D) {

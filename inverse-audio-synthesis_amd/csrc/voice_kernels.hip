@@ -911,7 +911,8 @@ extern "C" int ias_voice_save_for_backward(const void* workspace, float* ctrl_ou
   const char* ws = (const char*)workspace;
   const long long nctrl = (long long)B * IAS_NCTRL * Tc;
   static_assert(sizeof(IasVoiceConst) == 64, "vconst rows are 16 floats");
-  hipLaunchKernelGGL(voice_save_kernel, dim3((unsigned)((nctrl + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+  const long long nthreads = nctrl > 16LL * B ? nctrl : 16LL * B;      // (Tc of 2 or 3: the vconst copy is the longest)
+  hipLaunchKernelGGL(voice_save_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
                      (const float*)(ws + w.off_ctrl), (const float*)(ws + w.off_vconst), (const float*)(ws + w.off_peak),
                      ctrl_out, vconst_out, peaks_out, nctrl, B * 16, B);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;

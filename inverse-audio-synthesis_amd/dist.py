@@ -29,8 +29,12 @@ def init_from_env(backend=None):
             # IAS_DIST_BACKEND=gloo: ranks that share one GPU (tests, rehearsals on a one-GPU box); RCCL otherwise
             backend = os.environ.get("IAS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
+        if torch.cuda.is_available():
+            # whatever the backend: the current device (and with it torch.cuda.current_stream(), which every kernel launch
+            # of this package reads) must be the one the Trainer places the module on.  Ranks that share GPUs over gloo
+            # (LOCAL_RANK >= device count: tests, rehearsals) wrap around
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world

@@ -54,7 +54,12 @@ class VicregAudioParams(nn.Module):
         # module (installed here, before any forward, so the first step is not counted twice; a training-mode forward of
         # vision_model outside _step must call self._bump_bn() itself)
         from .vision import defer_bn_counters
-        self._bump_bn = defer_bn_counters(self.vision_model)
+        defer_bn_counters(self.vision_model)
+
+    def _bump_bn(self):
+        # the counters are resolved at call time: Trainer's module.to(device) rebinds every buffer after construction
+        from .vision import bump_bn_counters
+        bump_bn_counters(self.vision_model)
 
     def forward(self, audio, params):
         assert audio.ndim == 2 and params.ndim == 2 and audio.shape[0] == params.shape[0]

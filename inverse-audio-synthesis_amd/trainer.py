@@ -52,7 +52,7 @@ class Trainer:
     def __init__(self, cfg, module, stage="vicreg", device=None):
         self.cfg, self.module, self.stage = cfg, module, stage
         self.rank, self.local_rank, self.world = ias_dist.init_from_env()
-        self.device = device or torch.device("cuda", self.local_rank)
+        self.device = device or torch.device("cuda", torch.cuda.current_device() if self.world > 1 else self.local_rank)
         # (the entry points seed BEFORE building the module, as runsetup.py:22 does; GradBucketer then broadcasts
         # rank 0's parameters and buffers, as Lightning's DDP does, so replicas start identical by construction)
         self.module.to(self.device)

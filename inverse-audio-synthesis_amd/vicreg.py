@@ -93,9 +93,91 @@ def _vicreg_backward_torch(x, y, gcoef, cfg_batch, sim, std, cov):
     return a * d_repr + branch(x), -a * d_repr + branch(y)
 
 
+class _VICRegPairLossFn(torch.autograd.Function):
+    """The same loss on xy [B, 2 D] = cat(x, y, dim=1), consumed in place as two column blocks (ias_vicreg_loss_ld) and
+    differentiated into ONE [B, 2 D] cotangent (ias_vicreg_backward_ld): the shape in which the gathered batch arrives
+    from, and its gradient goes back to, the single collective of ``gather_rows``.  No split / cat copies."""
+
+    @staticmethod
+    def forward(ctx, xy, cfg_batch, sim_coeff, std_coeff, cov_coeff):
+        lib = _lib.load()
+        xyc = xy.detach().contiguous()
+        _lib.require_f32(xyc)
+        assert xyc.dim() == 2 and xyc.shape[1] % 2 == 0
+        B, D = xyc.shape[0], xyc.shape[1] // 2
+        assert D % 8 == 0, "pair form: embedding width must be a multiple of 8 (use vicreg_loss on the two halves)"
+        need = lib.ias_vicreg_workspace_bytes(B, D)
+        _lib.check(min(int(need), 0), "ias_vicreg_workspace_bytes")
+        ws = torch.empty(int(need), dtype=torch.uint8, device=xyc.device)
+        out = torch.empty(4, dtype=torch.float32, device=xyc.device)
+        base = xyc.data_ptr()
+        st = lib.ias_vicreg_loss_ld(base, base + 4 * D, 2 * D, _lib.ptr(out), _lib.ptr(ws), ws.numel(), B, D,
+                                    int(cfg_batch), float(sim_coeff), float(std_coeff), float(cov_coeff), _lib.stream())
+        _lib.check(st, "ias_vicreg_loss_ld")
+        ctx.save_for_backward(xyc, ws)
+        ctx.consts = (int(cfg_batch), float(sim_coeff), float(std_coeff), float(cov_coeff))
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[2], out[3]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_repr, g_std, g_cov):
+        xy, ws = ctx.saved_tensors
+        cfg_batch, sim, std, cov = ctx.consts
+        B, D = xy.shape[0], xy.shape[1] // 2
+        grads = (g_loss, g_repr, g_std, g_cov)
+        if all(g is None for g in grads):
+            return None, None, None, None, None
+        zero = _zero_scalar(xy.device)
+        gcoef = torch.cat([zero if g is None else g.to(torch.float32).reshape(1) for g in grads])
+        g = torch.empty_like(xy)
+        base, gbase = xy.data_ptr(), g.data_ptr()
+        st = _lib.load().ias_vicreg_backward_ld(base, base + 4 * D, 2 * D, _lib.ptr(gcoef), gbase, gbase + 4 * D, 2 * D,
+                                                _lib.ptr(ws), ws.numel(), B, D, cfg_batch, sim, std, cov, _lib.stream())
+        _lib.check(st, "ias_vicreg_backward_ld")
+        return g, None, None, None, None
+
+
 def vicreg_loss(x, y, cfg_batch_size, sim_coeff=25.0, std_coeff=25.0, cov_coeff=1.0):
     """(loss, repr_loss, std_loss, cov_loss) of vicreg.py:35-58 for x, y [B, D] on a ROCm device."""
     return _VICRegLossFn.apply(x, y, cfg_batch_size, sim_coeff, std_coeff, cov_coeff)
+
+
+def vicreg_loss_pair(xy, cfg_batch_size, sim_coeff=25.0, std_coeff=25.0, cov_coeff=1.0):
+    """``vicreg_loss(xy[:, :D], xy[:, D:], ...)`` for xy [B, 2 D] without materialising the halves."""
+    return _VICRegPairLossFn.apply(xy, cfg_batch_size, sim_coeff, std_coeff, cov_coeff)
+
+
+def _gather_active(gather):
+    """``gather`` as VICReg.gather_distributed: falsy = local loss; True = gather when the group has more than one rank;
+    "always" = gather on a one-rank group too (runs the collective branches on a single GPU: tests, bench)."""
+    return bool(gather) and dist.is_available() and dist.is_initialized() and \
+        (dist.get_world_size() > 1 or gather == "always")
+
+
+def global_batch_loss(x, y, batch_per_rank, sim_coeff=25.0, std_coeff=25.0, cov_coeff=1.0, gather=True):
+    """The loss of vicreg.py:35-58 with the cross-rank gather the reference keeps commented out (:38-39) switched on: the
+    BASELINE configs[3] path, shared by ``VICReg.loss`` and ``bench.py --workload vicreg --gpus N``.
+
+    * ONE collective per direction: ``gather_rows(cat(x, y, dim=1))`` (all-gather forward, reduce-scatter backward) instead
+      of one FullGatherLayer per branch; the gathered [W B_l, 2 D] buffer is consumed in place (``vicreg_loss_pair``).
+    * Covariance denominator ``batch_per_rank * world - 1``.  vicreg.py:47-48 divides by the CONFIGURED batch size minus
+      one; in facebookresearch/vicreg, where the gather is live, that configured size is the global batch.  Here
+      ``cfg.vicreg.batch_size`` is the per-rank batch (it sizes the synth: vicreg_audio_params.py:87), so the global value
+      is batch_per_rank x world.  Without the gather the denominator stays the configured per-rank value, quirk included.
+    * All four terms are taken on the gathered batch.  (The reference computes repr_loss before the commented gather, on
+      the local rows; the gathered MSE is the mean of the ranks' local MSEs: the sync_dist-logged metric and, after the
+      DDP average, every parameter gradient are the same.)
+    Every rank returns the same 4-tuple; a rank's x.grad / y.grad are W x its rows of d loss / d (x_g, y_g), as
+    FullGatherLayer's summing backward (vicreg.py:92-95) defines, which the gradient average over ranks turns back into
+    d loss / d theta."""
+    if not _gather_active(gather):
+        return vicreg_loss(x, y, batch_per_rank, sim_coeff, std_coeff, cov_coeff)
+    world = dist.get_world_size()
+    D = x.shape[1]
+    xy = gather_rows(torch.cat([x, y], dim=1))
+    if D % 8 != 0:
+        return vicreg_loss(xy[:, :D], xy[:, D:], batch_per_rank * world, sim_coeff, std_coeff, cov_coeff)
+    return vicreg_loss_pair(xy, batch_per_rank * world, sim_coeff, std_coeff, cov_coeff)
 
 
 class VICReg(nn.Module):
@@ -115,13 +197,8 @@ class VICReg(nn.Module):
 
     def loss(self, x, y):
         assert x.shape[1] == self.embeddim
-        # "always": gather on a one-rank group too (runs the RCCL branch on a single GPU; tests and bench)
-        if self.gather_distributed and dist.is_available() and dist.is_initialized() and \
-                (dist.get_world_size() > 1 or self.gather_distributed == "always"):
-            x = torch.cat(FullGatherLayer.apply(x), dim=0)
-            y = torch.cat(FullGatherLayer.apply(y), dim=0)
         v = self.cfg.vicreg
-        return vicreg_loss(x, y, v.batch_size, v.sim_coeff, v.std_coeff, v.cov_coeff)
+        return global_batch_loss(x, y, v.batch_size, v.sim_coeff, v.std_coeff, v.cov_coeff, gather=self.gather_distributed)
 
 
 def Projector(cfg, reprdim):
@@ -189,6 +266,41 @@ class FullGatherLayer(torch.autograd.Function):
             return out
         dist.all_reduce(stacked)
         return stacked[dist.get_rank()]
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    """``torch.cat(FullGatherLayer.apply(x), dim=0)`` as one [W B_l, ...] tensor: the all-gather lands in the result
+    (no tuple of views, no cat), the backward reduce-scatters the cotangent as it stands (no stack)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        world = dist.get_world_size()
+        x = x.contiguous()
+        ctx.rows = x.shape[0]
+        if dist.get_backend() == "nccl":
+            out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            dist.all_gather_into_tensor(out, x)
+            return out
+        parts = [torch.zeros_like(x) for _ in range(world)]
+        dist.all_gather(parts, x)
+        return torch.cat(parts, dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        if dist.get_backend() == "nccl":
+            out = torch.empty((ctx.rows,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+            dist.reduce_scatter_tensor(out, g)
+            return out
+        g = g.clone()
+        dist.all_reduce(g)
+        r = dist.get_rank()
+        return g[r * ctx.rows:(r + 1) * ctx.rows]
+
+
+def gather_rows(x):
+    """Rows of every rank, rank-major: value and gradient of ``torch.cat(FullGatherLayer.apply(x), dim=0)``."""
+    return _GatherRowsFn.apply(x)
 
 
 def exclude_bias_and_norm(p):

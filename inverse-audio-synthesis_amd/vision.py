@@ -17,8 +17,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-# IAS_TRUNK_TORCH=1: every layer of the trunk takes its torch.nn fallback (MIOpen / rocBLAS): one switch for A/B debugging
-_TRUNK_TORCH = os.environ.get("IAS_TRUNK_TORCH") == "1"
+def trunk_torch():
+    """IAS_TRUNK_TORCH=1: every layer of the trunk AND the conv head of audioembed.py take their torch.nn fallback
+    (MIOpen / rocBLAS): one switch for A/B debugging, read at every forward in this one place."""
+    return os.environ.get("IAS_TRUNK_TORCH") == "1"
 
 
 _PW_SUPPORTED = {}
@@ -83,7 +85,7 @@ class PointwiseConv2d(nn.Conv2d):
     per training step at batch 128 for the MobileNet body).  Elsewhere this is the plain nn.Conv2d."""
 
     def forward(self, x):
-        if x.is_cuda and not _TRUNK_TORCH and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.groups == 1 and \
+        if x.is_cuda and not trunk_torch() and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.groups == 1 and \
                 x.dim() == 4 and x.is_contiguous():
             B, C, H, W = x.shape
             if self.bias is None and x.dtype == torch.float32 and _pw_mfma(C, self.out_channels):
@@ -146,7 +148,7 @@ class DepthwiseConv2d(nn.Conv2d):
 
     def forward(self, x):
         k, s = self.kernel_size[0], self.stride[0]
-        if x.is_cuda and not _TRUNK_TORCH and x.dtype == torch.float32 and self.groups == self.in_channels == self.out_channels and \
+        if x.is_cuda and not trunk_torch() and x.dtype == torch.float32 and self.groups == self.in_channels == self.out_channels and \
                 self.bias is None and self.kernel_size in ((3, 3), (5, 5)) and self.stride in ((1, 1), (2, 2)) and \
                 self.padding == ((k - 1) // 2, (k - 1) // 2) and self.dilation == (1, 1):
             return _DepthwiseFn.apply(x, self.weight, k, s)
@@ -190,7 +192,7 @@ class StemConv2d(nn.Conv2d):
     it as an im2col plus a GEMM per sample -- the plain nn.Conv2d elsewhere."""
 
     def forward(self, x):
-        if x.is_cuda and not _TRUNK_TORCH and x.dtype == torch.float32 and (self.in_channels, self.out_channels) == (3, 16) and \
+        if x.is_cuda and not trunk_torch() and x.dtype == torch.float32 and (self.in_channels, self.out_channels) == (3, 16) and \
                 self.kernel_size == (3, 3) and self.stride == (2, 2) and self.padding == (1, 1) and self.bias is None and \
                 self.groups == 1 and x.shape[0] <= 65535:
             return _StemFn.apply(x, self.weight)
@@ -252,16 +254,18 @@ class BatchNormAct2d(nn.BatchNorm2d):
         self.act_code = _ACT_CODE[act]
 
     def forward(self, x):
-        if self.training and x.is_cuda and not _TRUNK_TORCH and x.dtype == torch.float32 and x.dim() == 4 and self.track_running_stats and \
+        if self.training and x.is_cuda and not trunk_torch() and x.dtype == torch.float32 and x.dim() == 4 and self.track_running_stats and \
                 self.momentum is not None and self.affine:
             if self.num_batches_tracked is not None and not getattr(self, "counter_deferred", False):
                 self.num_batches_tracked.add_(1)     # (deferred: one multi-tensor add for all layers, see defer_bn_counters)
             return _BNActFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                   self.momentum, self.act_code)
-        if self.training and getattr(self, "counter_deferred", False) and self.num_batches_tracked is not None:
-            # nn.BatchNorm2d bumps the counter itself: undo it here, the deferred multi-tensor add counts this forward
-            self.num_batches_tracked.sub_(1)
         y = super().forward(x)
+        if self.training and getattr(self, "counter_deferred", False) and self.num_batches_tracked is not None and \
+                self.track_running_stats:
+            # nn.BatchNorm2d bumped the counter itself (and, with momentum=None, has just used the bumped value as its
+            # averaging factor): undo it AFTER the forward, the deferred multi-tensor add counts this step
+            self.num_batches_tracked.sub_(1)
         if self.act_code == 1:
             return F.relu(y)
         if self.act_code == 2:
@@ -271,17 +275,21 @@ class BatchNormAct2d(nn.BatchNorm2d):
 
 def defer_bn_counters(module):
     """The 34 BatchNormAct2d layers of the trunk each bump their ``num_batches_tracked`` with a one-element launch per
-    step.  After this call they leave it to the returned function, which adds 1 to all of them in ONE multi-tensor launch
-    (call it once per training forward)."""
-    bns = [m for m in module.modules() if isinstance(m, BatchNormAct2d) and m.num_batches_tracked is not None]
-    for m in bns:
-        m.counter_deferred = True
-    counters = [m.num_batches_tracked for m in bns]
+    step.  After this call they leave it to ``bump_bn_counters(module)``, which adds 1 to all of them in ONE multi-tensor
+    launch (call it once per training forward).  Nothing is captured here: the counters are looked up when they are
+    bumped, so ``module.to(device)`` (which REBINDS the buffers) and ``copy.deepcopy`` keep working."""
+    for m in module.modules():
+        if isinstance(m, BatchNormAct2d) and m.num_batches_tracked is not None:
+            m.counter_deferred = True
 
-    def bump():
-        if counters:
-            torch._foreach_add_(counters, 1)
-    return bump
+
+def bump_bn_counters(module):
+    """+1 on the ``num_batches_tracked`` of every BatchNormAct2d under ``module`` that defers its counter, as they are
+    bound NOW."""
+    counters = [m.num_batches_tracked for m in module.modules()
+                if isinstance(m, BatchNormAct2d) and getattr(m, "counter_deferred", False) and m.num_batches_tracked is not None]
+    if counters:
+        torch._foreach_add_(counters, 1)
 
 
 def _divisible(v, d=8):
@@ -363,7 +371,7 @@ class SqueezeExcitation(nn.Module):
         self.scale_activation = nn.Hardsigmoid()
 
     def forward(self, x):
-        if x.is_cuda and not _TRUNK_TORCH and x.dtype == torch.float32 and x.dim() == 4:
+        if x.is_cuda and not trunk_torch() and x.dtype == torch.float32 and x.dim() == 4:
             return _SEFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
         s = self.scale_activation(self.fc2(self.activation(self.fc1(self.avgpool(x)))))
         return s * x

@@ -55,6 +55,24 @@ def _body_full_gather(rank, world):
     return bool(ok_fwd and torch.allclose(x.grad, want, atol=1e-6))
 
 
+def _body_gather_rows(rank, world):
+    """gather_rows(x) = cat(FullGatherLayer.apply(x), 0) in value and gradient (the one collective of the global-batch
+    loss, inverse-audio-synthesis_amd/vicreg.py:global_batch_loss; reference /root/reference/vicreg.py:38-39,79-95)."""
+    from inverse_audio_synthesis_amd.vicreg import FullGatherLayer, gather_rows
+    from oracle import vicreg_oracle as vo
+    local = [torch.randn(3, 6, generator=torch.Generator().manual_seed(20 + r)) for r in range(world)]
+    x = local[rank].clone().requires_grad_()
+    got = gather_rows(x)
+    ok = torch.equal(got, torch.cat(vo.full_gather_forward(local), 0))
+    wts = [torch.randn(world * 3, 6, generator=torch.Generator().manual_seed(300 + rr)) for rr in range(world)]
+    (got * wts[rank]).sum().backward()
+    want = vo.full_gather_backward([tuple(wts[rr][q * 3:(q + 1) * 3] for q in range(world)) for rr in range(world)], rank)
+    ok = ok and torch.allclose(x.grad, want, atol=1e-6)
+    x2 = local[rank].clone().requires_grad_()
+    (torch.cat(FullGatherLayer.apply(x2), 0) * wts[rank]).sum().backward()
+    return bool(ok and torch.allclose(x.grad, x2.grad, atol=1e-6))
+
+
 def _body_grad_bucketer(rank, world):
     from inverse_audio_synthesis_amd.dist import GradBucketer, all_reduce_mean
     torch.manual_seed(0)  # same init on every rank
@@ -89,6 +107,10 @@ def _body_grad_bucketer(rank, world):
 # ---- tests ------------------------------------------------------------------------------------
 def test_full_gather_layer_two_ranks():
     assert _spawn("_body_full_gather") == [True, True]
+
+
+def test_gather_rows_two_ranks():
+    assert _spawn("_body_gather_rows") == [True, True]
 
 
 def test_grad_bucketer_two_ranks():

@@ -87,3 +87,69 @@ def test_grad_bucketer_on_rccl(lib, dev, nccl_group):
     for g, p in zip(got, ref.parameters()):
         assert torch.allclose(g, p.grad, atol=1e-5)
     assert all_reduce_mean(torch.tensor(3.0, device=dev)).item() == 3.0
+
+
+def _spawn_two(script, extra_env, tmp_path, timeout=600):
+    """Two FRESH child processes (never a re-exec of this one) as ranks 0 / 1 over gloo on the one GPU."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   IAS_DIST_BACKEND="gloo", IAS_MP_OUT=str(tmp_path), **extra_env)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=timeout)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    return outs
+
+
+@pytest.mark.parametrize("Bl,D", [(64, 512), (96, 1024)])
+def test_module_loss_with_the_gather_on_at_world_size_two(lib, dev, tmp_path, Bl, D):
+    """BASELINE configs[3] through the MODULE at world size 2 (/root/reference/vicreg.py:38-39 un-commented, :47-48,
+    :79-95): every rank's ``VICReg.loss`` 4-tuple equals the oracle's loss on the concatenated [2 B_l, D] batch with the
+    denominator B_global - 1 (cfg.vicreg.batch_size is the per-rank batch), one collective per direction, and a rank's
+    gradient is W x its rows of the oracle's autograd gradient -- FullGatherLayer's backward SUMS the ranks' cotangents
+    (:92-95) and every rank holds the same loss; the gradient average over ranks (DDP) takes the W out again.
+    (96 rows per rank: global batch 192 > 128 runs the 256-tile kernels through the strided entry points.)"""
+    from oracle import vicreg_oracle as vo
+    _spawn_two("mp_vicreg_child.py", {"IAS_MP_BL": str(Bl), "IAS_MP_D": str(D)}, tmp_path)
+    W = 2
+    xg = torch.randn(W * Bl, D, generator=torch.Generator().manual_seed(0)).requires_grad_()
+    yg = torch.randn(W * Bl, D, generator=torch.Generator().manual_seed(1)).requires_grad_()
+    ref = vo.loss(xg, yg, W * Bl, D)
+    ref[0].backward()
+    wrong = vo.loss(xg.detach(), yg.detach(), Bl, D)            # the per-rank denominator round 3 shipped: ~W^2 too large
+    assert wrong[3].item() > 3.0 * ref[3].item()
+    for r in range(W):
+        rec = torch.load(tmp_path / f"vicreg_rank{r}.pt")
+        for got, want, tol in zip(rec["out"], ref, (2e-3, 1e-5, 1e-5, 2e-3)):
+            assert abs(got - want.item()) <= tol * abs(want.item()), (r, rec["out"], [float(v) for v in ref])
+        assert rec["collectives_forward"] == 1 and rec["collectives_total"] == 2      # ONE exchange per direction
+        # what vicreg.py:92-95 defines: every rank contributes the oracle's gradient rows, summed over the W ranks
+        wx = vo.full_gather_backward([tuple(xg.grad[q * Bl:(q + 1) * Bl] for q in range(W))] * W, r)
+        wy = vo.full_gather_backward([tuple(yg.grad[q * Bl:(q + 1) * Bl] for q in range(W))] * W, r)
+        assert torch.equal(wx, W * xg.grad[r * Bl:(r + 1) * Bl])
+        assert (rec["gx"] - wx).abs().max().item() <= 2e-3 * wx.abs().max().item()
+        assert (rec["gy"] - wy).abs().max().item() <= 2e-3 * wy.abs().max().item()
+
+
+def test_two_rank_training_with_gathered_embeddings(lib, dev, tmp_path):
+    """trainer.gather_embeddings=true at world size 2: three pretraining steps with the global-batch loss; replicas stay
+    bit-identical, and both ranks log the SAME loss terms (the gathered loss is a function of the global batch)."""
+    import json
+    from test_training_gpu import SMALL
+    overrides = SMALL + ["trainer.max_steps=3", f"trainer.out_dir={tmp_path}", "trainer.cuda_graph=false",
+                         "trainer.gather_embeddings=true"]
+    _spawn_two("mp_trainer_child.py", {"IAS_MP_OVERRIDES": json.dumps(overrides)}, tmp_path)
+    recs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    assert recs[0]["initial_digest"] == recs[1]["initial_digest"] and len(recs[0]["steps"]) == 3
+    for s0, s1 in zip(recs[0]["steps"], recs[1]["steps"]):
+        assert s0["digest"] == s1["digest"], f"replicas diverged at step {s0['step']}"
+        for k in s0["local"]:
+            assert abs(s0["local"][k] - s1["local"][k]) <= 1e-5 * max(1.0, abs(s0["local"][k])), (k, s0["local"], s1["local"])
+    assert recs[0]["steps"][0]["digest"] != recs[0]["steps"][2]["digest"]

@@ -100,6 +100,27 @@ def test_stft_random_shapes(lib, dev):
         assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item(), (n_fft, win, hop, T)
 
 
+@pytest.mark.parametrize("n_fft", [512, 1024, 2048])
+def test_stft_single_frame_rows(lib, dev, n_fft):
+    """n_fft / 2 < T < hop: ONE frame per row (F = 1).  The flat frame list [B F] is decoded with a multiply-high by
+    floor(2^32 / F), which does not fit 32 bits at F = 1; with B >= 3 a wrapped constant sends frames 2.. to the wrong row."""
+    from inverse_audio_synthesis_amd.spectral import STFTL1, STFTPlan, VALUE_POWER
+    B, T, hop = 5, n_fft // 2 + 90, n_fft
+    assert lib.ias_stft_num_frames(T, n_fft, hop) == 1
+    x, y = randn((B, T), 5) * 0.4, randn((B, T), 6) * 0.4
+    ref = spo.spectrogram(x, n_fft, n_fft, hop, 2.0)
+    out = STFTPlan(n_fft, n_fft, hop).to(dev).values(x.to(dev), VALUE_POWER).transpose(1, 2).cpu()
+    assert out.shape == ref.shape == (B, n_fft // 2 + 1, 1)
+    assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    xg = x.to(dev).requires_grad_()
+    loss = STFTL1(n_fft, hop).to(dev)(xg, y.to(dev))
+    xr = x.clone().requires_grad_()
+    lref = spo.stft_l1(xr, y, n_fft, hop)
+    assert abs(loss.item() - lref.item()) <= 1e-3 * abs(lref.item())
+    loss.backward(); lref.backward()
+    assert (xg.grad.cpu() - xr.grad).abs().max().item() <= 2e-3 * xr.grad.abs().max().item()
+
+
 def test_c_abi_rejects_bad_arguments(lib, dev):
     """Every entry point returns a negative IAS_ERR_* for null pointers / impossible dimensions instead of launching
     (the reference's behaviour at this boundary is a bare assert / exception)."""

@@ -240,3 +240,22 @@ def test_train_metrics_survive_a_validation_inside_the_captured_loop(lib, dev, t
     after = [h["vicreg/train/loss"] for h in train if h["step"] >= 5]
     assert len(set(after)) == len(after), after          # three different steps, three different losses
     assert any("vicreg/validation/loss" in h for h in hist)
+
+
+@pytest.mark.parametrize("graph", ["false", "true"])
+def test_bn_counters_follow_the_module_to_the_device(lib, dev, tmp_path, graph):
+    """The trunk's num_batches_tracked counters are bumped by one multi-tensor add per training step (vision.defer_bn_counters).
+    Trainer.__init__ moves the module AFTER construction, which rebinds every buffer: the bump must reach the tensors the
+    module holds now, eager and replayed, and a checkpoint must carry the step count (torch.nn.BatchNorm2d semantics,
+    /root/reference/vicreg_audio_params.py:52-54 -> torchvision BatchNorm2d)."""
+    import pretrain
+    steps = 6
+    pretrain.app(SMALL + [f"trainer.max_steps={steps}", f"trainer.out_dir={tmp_path}", f"trainer.cuda_graph={graph}"])
+    sd = torch.load(tmp_path / "vicreg-last.ckpt", map_location="cpu")["state_dict"]
+    counters = {k: int(v) for k, v in sd.items() if k.endswith("num_batches_tracked") and k.startswith("vision_model.")}
+    assert len(counters) == 34
+    assert set(counters.values()) == {steps}, counters
+    # the projector's / paramembed's BatchNorm1d layers count for themselves (two branches through the projector per step)
+    other = {k: int(v) for k, v in sd.items() if k.endswith("num_batches_tracked") and not k.startswith("vision_model.")
+             and not k.startswith("audio_repr.")}
+    assert other and all(v >= steps for v in other.values()), other

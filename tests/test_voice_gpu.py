@@ -233,3 +233,25 @@ def test_saved_for_backward_equals_the_three_copies(lib, dev):
     assert torch.equal(ctrl, c2) and torch.equal(vconst, v2) and torch.equal(peaks, v.read_peaks())
     c3, v3, p3 = v.saved_for_backward(with_peaks=False)
     assert p3 is None and torch.equal(c3, c2) and torch.equal(v3, v2)
+
+
+def test_saved_for_backward_with_a_two_point_control_buffer(lib, dev):
+    """Tc = 2: the vconst copy (16 floats per voice) is longer than the control copy (10 per voice); the one launch must
+    cover both (B = 64: 1024 vconst floats against 640 control floats)."""
+    B = 64
+    v = _voice(dev, B, 16000, 0.0068)
+    assert v.synthconfig.control_buffer_size == 2
+    audio, params, _ = v(3)
+    cfg = so.VoiceConfig(batch_size=B, sample_rate=16000, buffer_size_seconds=0.0068)
+    ref = so.render_from_params01(cfg, params.cpu(), so.make_noise(cfg), "cr")
+    assert (audio.cpu() - ref).abs().max().item() <= 1e-4
+    ctrl = torch.full((B, 5, 2), float("nan"), device=dev)
+    vconst = torch.full((B, 16), float("nan"), device=dev)
+    peaks = torch.full((B,), float("nan"), device=dev)
+    from inverse_audio_synthesis_amd import _lib
+    c = v.synthconfig
+    _lib.check(lib.ias_voice_save_for_backward(_lib.ptr(v._workspace), _lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(peaks), B,
+                                               c.buffer_size, c.control_buffer_size, _lib.stream()), "save")
+    c2, v2 = v.rendered_control()
+    assert torch.equal(ctrl, c2) and torch.equal(peaks, v.read_peaks())
+    assert torch.equal(vconst.view(torch.int32), v2.view(torch.int32))          # every word copied (bit compare: NaN-safe)
