@@ -228,6 +228,19 @@ __device__ __forceinline__ float voice_exp2_cr_lds(float t, unsigned tab_biased)
   return (float)(p * tv);
 }
 typedef const __attribute__((address_space(1))) void voice_glb_void;
+// LDS address of control row k: k * VOICE_CTRL_ROW + biased base, ONE v_mad_u32_u24 (left to itself the compiler turns
+// the same expression into v_and + v_subrev + a 64-bit v_mad_u64_u32 per sample and phase).
+__device__ __forceinline__ voice_lds_cchar* voice_ctrl_row(float real, unsigned ctrl_biased) {
+  unsigned addr;
+  const int k = (int)real;                       // real >= 0: trunc = floor
+  asm("v_mad_u32_u24 %0, %1, 40, %2" : "=v"(addr) : "v"(k), "s"(ctrl_biased));
+  return (voice_lds_cchar*)(uintptr_t)addr;
+}
+static_assert(IAS_NCTRL * 8 == 40, "voice_ctrl_row: the row stride is an immediate");
+// Linear upsample of one control signal: fl(w0 a + fl(w1 b)), the ONE fused multiply-add torch's CPU kernel
+// (nn.Upsample(mode="linear", align_corners=True) -> ATen cpu_upsample_linear, x0 * w0 + x1 * w1 contracted by the
+// compiler) evaluates: bit-equal to the op on this build's torch (tests/test_voice_math_cpu.py).
+__device__ __forceinline__ float voice_lerp(float w0, float w1, voice_f2 q) { return fmaf(w0, q.x, w1 * q.y); }
 // Phase increment of one VCO sample, fl(fl(2 pi hz) / sr) with hz = fl(440 fl(2^fl((c - 69) / 12))): bit-identical to
 // ias_vco_inc (MATH_CR).  FMA_DIV: the sample rate is one ias_div_fma is verified for (sr_f = the rate, sr_r = fl32 of
 // its reciprocal), otherwise the fp64 reciprocal product is used.
@@ -331,9 +344,9 @@ __device__ __forceinline__ void voice_phase_a(const char* s_ctrl, const double* 
     // interpolation position (ias_interp_pos_fast): k = trunc(real) (real >= 0), w1 = real - k = fract(real), exactly
     const float real = scale * (jf0 + (float)e);
     const float w1 = __builtin_amdgcn_fractf(real), w0 = 1.0f - w1;
-    voice_lds_cchar* cp = (voice_lds_cchar*)(uintptr_t)((unsigned)__umul24((unsigned)(int)real, VOICE_CTRL_ROW) + ctrl_biased);
+    voice_lds_cchar* cp = voice_ctrl_row(real, ctrl_biased);
     const voice_f2 q1 = *(voice_lds_cfloat2*)cp, q2 = *(voice_lds_cfloat2*)(cp + 16);
-    const float pm1 = w0 * q1.x + w1 * q1.y, pm2 = w0 * q2.x + w1 * q2.y;
+    const float pm1 = voice_lerp(w0, w1, q1), pm2 = voice_lerp(w0, w1, q2);
     float a = voice_inc<MATH, FMA_DIV>(vc.f0_1, vc.depth_1, pm1, s_tab, inv_sample_rate, sr_f, sr_r);
     float d = voice_inc<MATH, FMA_DIV>(vc.f0_2, vc.depth_2, pm2, s_tab, inv_sample_rate, sr_f, sr_r);
     if (!FAST && j0 + e >= T) { a = 0.0f; d = 0.0f; }
@@ -391,9 +404,9 @@ __device__ __forceinline__ void voice_phase_b(const char* s_ctrl, float* s_stage
     }
     const float real = scale * (jf0 + (float)e);
     const float w1 = __builtin_amdgcn_fractf(real), w0 = 1.0f - w1;
-    voice_lds_cchar* cp = (voice_lds_cchar*)(uintptr_t)((unsigned)__umul24((unsigned)(int)real, VOICE_CTRL_ROW) + ctrl_biased);
+    voice_lds_cchar* cp = voice_ctrl_row(real, ctrl_biased);
     const voice_f2 qa = *(voice_lds_cfloat2*)(cp + 8), qb = *(voice_lds_cfloat2*)(cp + 24), qn = *(voice_lds_cfloat2*)(cp + 32);
-    const float amp1 = w0 * qa.x + w1 * qa.y, amp2 = w0 * qb.x + w1 * qb.y, ampn = w0 * qn.x + w1 * qn.y;
+    const float amp1 = voice_lerp(w0, w1, qa), amp2 = voice_lerp(w0, w1, qb), ampn = voice_lerp(w0, w1, qn);
     run1 += (double)inc1[e]; run2 += (double)inc2[e];
     const float arg1 = (float)run1 + vc.phi_1, arg2 = (float)run2 + vc.phi_2;
     float s2, c2;
@@ -402,7 +415,7 @@ __device__ __forceinline__ void voice_phase_b(const char* s_ctrl, float* s_stage
     const float v1 = voice_cos(arg1) * amp1;
     // square = tanh(k sin / 2) is odd in sin: magnitude from |s2|, sign = sign(s2) ^ flip (signs commute with the
     // correctly rounded multiplications that follow)
-    const float sqm = __builtin_copysignf(voice_tanh_abs((vc.kpart * s2) * 0.5f), s2);
+    const float sqm = __builtin_copysignf(voice_tanh_abs_half(vc.kpart * s2), s2);
     const float sc = vc.shape * c2;
     const float v2 = ((vc.shape_gain * (flip ? -sqm : sqm)) * (1.0f + (flip ? -sc : sc))) * amp2;
     float om = vc.lvl0 * v1;
@@ -505,6 +518,14 @@ __global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) void voice_audio_ke
   while (have_cur || have_next) {
     gu64* row = (gu64*)(agg + ((size_t)cur.b * ntiles) * 2);
     VSTAMP(0);
+    // (the put comes first: its wait for the control points' loads would otherwise cover the requests issued below)
+    if (have_next) {
+      // the next tile's control points (fetched during the previous phase B) -> LDS
+      char* dst = s_ctrl0 + (slot ^ 1) * ctrl_bytes;
+      if (tid < IAS_NCTRL * next.ncp) voice_ctrl_put(dst, next, tid, pre);
+      for (int i = tid + AUDIO_THREADS; i < IAS_NCTRL * next.ncp; i += AUDIO_THREADS)   // windows wider than 51 points
+        voice_ctrl_put(dst, next, i, voice_ctrl_elem(ctrl, next, Tc, i));
+    }
     unsigned long long early1 = VOICE_READY_BIT, early2 = VOICE_READY_BIT;
     if (have_cur) {
       // the current tile's look-back words and noise are requested now and examined after phase A of the next tile
@@ -520,13 +541,6 @@ __global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) void voice_audio_ke
           __builtin_amdgcn_global_load_lds((voice_glb_void*)(nsrc + q * 256),
                                            (voice_lds_void*)(s_stage + wave_u * (64 * VOICE_SPT) + q * 256), 16, 0, 0);
       }
-    }
-    if (have_next) {
-      // the next tile's control points (fetched during the previous phase B) -> LDS
-      char* dst = s_ctrl0 + (slot ^ 1) * ctrl_bytes;
-      if (tid < IAS_NCTRL * next.ncp) voice_ctrl_put(dst, next, tid, pre);
-      for (int i = tid + AUDIO_THREADS; i < IAS_NCTRL * next.ncp; i += AUDIO_THREADS)   // windows wider than 51 points
-        voice_ctrl_put(dst, next, i, voice_ctrl_elem(ctrl, next, Tc, i));
     }
     __syncthreads();   // (1) the next tile's control points are staged
     VSTAMP(1);
@@ -797,11 +811,12 @@ static void voice_audio_launch(hipStream_t stream, const VoiceWs& w, char* ws, c
   const size_t lds = sizeof(double) * VOICE_TAB_DOUBLES + sizeof(float) * VOICE_TILE + 2 * sizeof(float2) * IAS_NCTRL * (size_t)maxctrl;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)voice_audio_kernel<MATH, FMA_DIV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int grid = voice_audio_grid<MATH, FMA_DIV>(lds, w.ntiles * B);
+  const int ntiles = w.ntiles;
+  const int grid = voice_audio_grid<MATH, FMA_DIV>(lds, ntiles * B);
   hipLaunchKernelGGL((voice_audio_kernel<MATH, FMA_DIV>), dim3(grid), dim3(AUDIO_THREADS), lds, stream,
                      (const float*)(ws + w.off_ctrl), (const IasVoiceConst*)(ws + w.off_vconst), noise, audio,
                      (unsigned long long*)(ws + w.off_agg), (unsigned int*)(ws + w.off_sync),
-                     (unsigned*)(ws + w.off_peak), T, Tc, w.ntiles, B, 1.0 / (double)sample_rate, sr_f,
+                     (unsigned*)(ws + w.off_peak), T, Tc, ntiles, B, 1.0 / (double)sample_rate, sr_f,
                      1.0f / sr_f, scale, maxctrl);
 }
 

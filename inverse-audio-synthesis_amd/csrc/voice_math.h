@@ -280,7 +280,11 @@ IAS_HD void ias_interp_pos_fast(int j, float scale, int Tc, int& i0, int& i1, fl
   w1 = ias_sub(real, (float)k);
   w0 = ias_sub(1.0f, w1);
 }
-IAS_HD float ias_lerp(float a, float b, float w0, float w1) { return ias_add(ias_mul(w0, a), ias_mul(w1, b)); }
+// fl(w0 a + fl(w1 b)): ONE fused multiply-add on the rounded second product -- what torch's CPU kernel of
+// nn.Upsample(mode="linear", align_corners=True) evaluates (ATen cpu_upsample_linear: `x0 * w0 + x1 * w1`, contracted
+// by the compiler into fma(x0, w0, x1 * w1)); bit-equal to the torch op (tests/test_voice_math_cpu.py).  Rounds 1-3
+// had the three-rounding form fl(fl(w0 a) + fl(w1 b)), which differs from the op in 24 % of the samples by one ulp.
+IAS_HD float ias_lerp(float a, float b, float w0, float w1) { return fmaf(w0, a, ias_mul(w1, b)); }
 
 IAS_HD float ias_midi_to_hz(float midi) {
   return ias_mul(440.0f, ias_exp2_cr(ias_div(ias_sub(midi, 69.0f), 12.0f)));
@@ -350,54 +354,6 @@ __device__ __forceinline__ float ias_mix_sample_dev(float arg1, float arg2, floa
   return o;
 }
 
-// ---- two samples at a time: the fp32 half of the per-sample arithmetic is written on 2-wide vectors
-// (v_pk_mul_f32 / v_pk_add_f32: same operations, same rounding, per component; a packed op takes the SIMD
-// as long as its two plain halves, so this halves the instruction count, not the arithmetic time).
-typedef float ias_f2 __attribute__((ext_vector_type(2)));
-
-// ias_interp_pos_fast for samples (j0, j1): truncated control index k[2] and the lerp weights.
-__device__ __forceinline__ void ias_interp_pair(int j0, int j1, float scale, int (&k)[2], ias_f2& w0, ias_f2& w1) {
-  const ias_f2 real = scale * (ias_f2){(float)j0, (float)j1};
-  k[0] = (int)real.x; k[1] = (int)real.y;
-  w1 = real - (ias_f2){(float)k[0], (float)k[1]};
-  w0 = 1.0f - w1;
-}
-// lerp of two samples from their (c[i], c[i+1]) table entries
-__device__ __forceinline__ ias_f2 ias_lerp_pair(float2 q0, float2 q1, ias_f2 w0, ias_f2 w1) {
-  return w0 * (ias_f2){q0.x, q1.x} + w1 * (ias_f2){q0.y, q1.y};
-}
-// ias_vco_inc_fast for two samples.  sr_f / sr_r: the sample rate and fl32 of its reciprocal when the rate is one
-// ias_div_fma is verified for (sr_f > 0), otherwise the fp64 reciprocal product is used.
-__device__ __forceinline__ ias_f2 ias_vco_inc_pair(float f0, float depth, ias_f2 pm, double inv_sample_rate,
-                                                   float sr_f, float sr_r) {
-  ias_f2 c = f0 + depth * pm;
-  c.x = fminf(fmaxf(c.x, 0.0f), 127.0f);
-  c.y = fminf(fmaxf(c.y, 0.0f), 127.0f);
-  const ias_f2 s = c - 69.0f;
-  const float r12 = 1.0f / 12.0f;
-  const ias_f2 e = {ias_exp2_cr_fast(ias_div_fma(s.x, 12.0f, r12)), ias_exp2_cr_fast(ias_div_fma(s.y, 12.0f, r12))};
-  const ias_f2 w = (float)IAS_TWO_PI_D * (440.0f * e);
-  if (sr_f > 0.0f) return (ias_f2){ias_div_fma(w.x, sr_f, sr_r), ias_div_fma(w.y, sr_f, sr_r)};
-  return (ias_f2){ias_div_by_recip(w.x, inv_sample_rate), ias_div_by_recip(w.y, inv_sample_rate)};
-}
-// ias_mix_sample_dev for two samples
-__device__ __forceinline__ ias_f2 ias_mix_pair_dev(ias_f2 arg1, ias_f2 arg2, ias_f2 amp1, ias_f2 amp2, ias_f2 ampn,
-                                                   ias_f2 noise, const IasVoiceConst& vc) {
-  float sx, sy, cx, cy;
-  ias_sincos_dev(arg2.x, sx, cx);
-  ias_sincos_dev(arg2.y, sy, cy);
-  const ias_f2 s2 = {sx, sy}, c2 = {cx, cy};
-  const ias_f2 c1 = {ias_cos_dev(arg1.x), ias_cos_dev(arg1.y)};
-  const ias_f2 v1 = c1 * amp1;
-  const ias_f2 z = (vc.kpart * s2) * 0.5f;
-  const ias_f2 sq = {ias_tanh_dev(z.x), ias_tanh_dev(z.y)};
-  const ias_f2 v2 = ((vc.shape_gain * sq) * (1.0f + vc.shape * c2)) * amp2;
-  const ias_f2 nz = noise * ampn;
-  ias_f2 o = vc.lvl0 * v1;
-  o = o + vc.lvl1 * v2;
-  o = o + vc.lvl2 * nz;
-  return o;
-}
 #endif
 
 // unnormalised mixer output for one sample, given both phases (fp32, phi added).

@@ -22,7 +22,9 @@ linear/align_corners).  Two math modes:
   the small matmuls / sums that feed the oscillator phase (LFO shape mix, LFO mode
   normalisation, mod matrix) are float64-accumulated dot products rounded once
   (torch's fp32 BLAS / vectorised reductions round differently from host to host),
-  the linear upsample is written out as fl(fl(w0*a)+fl(w1*b)) and the final mixer
+  the linear upsample is written out as fl(w0*a + fl(w1*b)) -- one fused multiply-add
+  on the rounded second product, which is what torch's CPU kernel of nn.Upsample
+  computes (bit-equal to the op: tests/test_voice_math_cpu.py) -- and the final mixer
   as a left-to-right mul/add chain.  This is the bit-reproducible definition the
   HIP kernels implement; the difference between the two modes is the irreducible
   libm-to-libm / BLAS-to-BLAS spread of the reference itself (quantified in tests
@@ -107,7 +109,26 @@ class _Math:
         i1 = i0 + (i0 < Tc - 1).long()
         w1 = torch.clamp(real - i0.float(), 0.0, 1.0)
         w0 = 1.0 - w1
-        return w0 * ctrl[..., i0] + w1 * ctrl[..., i1]
+        return fma32(w0, ctrl[..., i0], w1 * ctrl[..., i1])
+
+
+def fma32(a, b, c):
+    """fl32(a * b + c) for fp32 tensors with ONE rounding (a hardware fma), emulated in float64: the product of two
+    floats is exact in double; its sum with c is taken with round-to-odd (the double sum, nudged onto the odd neighbour
+    when it was inexact), which makes the final rounding to fp32 the rounding of the exact value (no double rounding)."""
+    p = a.double() * b.double()
+    c = c.double().expand_as(p)
+    s = p + c
+    bb = s - p                                  # TwoSum: s + err = p + c exactly
+    err = (p - (s - bb)) + (c - bb)
+    inexact = (err != 0) & torch.isfinite(s)
+    bits = s.contiguous().view(torch.int64)
+    even = (bits & 1) == 0
+    # move an even-mantissa inexact sum one ulp toward the exact value: for a positive s the next double up is bits + 1
+    toward_up = (err > 0) == (s > 0)            # away from zero in magnitude
+    step = torch.where(toward_up, torch.ones_like(bits), -torch.ones_like(bits))
+    bits = torch.where(inexact & even, bits + step, bits)
+    return bits.view(torch.float64).float()
 
 
 # --------------------------------------------------------------------- parameters

@@ -14,7 +14,9 @@ voice.set_parameters01(torch.rand(B, 78, generator=torch.Generator().manual_seed
 ws = voice.new_workspace(dev)
 audio = torch.empty((B, voice.synthconfig.buffer_size), dtype=torch.float32, device=dev)
 voice.render_control(ws)
-ntiles = (voice.synthconfig.buffer_size + 4095) // 4096
+V2 = True
+TILE = 4096
+ntiles = (voice.synthconfig.buffer_size + TILE - 1) // TILE
 stamps = torch.zeros((B, ntiles, 4, 12), dtype=torch.int64, device=dev)
 lib = ctypes.CDLL(os.environ["IAS_HIP_LIB"])
 for _ in range(3):
@@ -26,6 +28,15 @@ torch.cuda.synchronize()
 st = stamps.cpu().double()[:, 1: ntiles - 1]          # full tiles, not the first of a row
 names = ["issue + stage ctrl + barrier 1", "phase A (next tile)", "look-back (wave 0)", "barrier 2", "phase B + stores", "barrier 3"]
 print("s_memtime ticks = shader cycles; one loop iteration = phase A of the next tile + look-back and phase B of this one; mean per wave")
+if not V2:
+    # wave tiles: a tile carries the stamps of the one wave that rendered it
+    flat = st.reshape(-1, 12)
+    flat = flat[flat[:, 0] > 0]
+    names = ["put + ticket + DMA issue", "phase A (next tile) + publish", "look-back", "wait noise DMA", "phase B + stores", "-"]
+    d = [(flat[:, i + 1] - flat[:, i]).mean().item() for i in range(6)]
+    print("wave tiles: " + ", ".join(f"{n} {x:.0f}" for n, x in zip(names, d)) + f"; iteration {(flat[:, 6] - flat[:, 0]).mean().item():.0f} cycles over {flat.shape[0]} tiles")
+    print(f"kernel span {(flat[:, 11].max() - flat[:, 10].min()).item() / 100:.1f} us")
+    sys.exit(0)
 for w in range(4):
     d = [(st[:, :, w, i + 1] - st[:, :, w, i]).mean().item() for i in range(6)]
     print(f"wave {w}: " + ", ".join(f"{n} {x:.0f}" for n, x in zip(names, d)) + f"; iteration {(st[:, :, w, 6] - st[:, :, w, 0]).mean().item():.0f} cycles")
