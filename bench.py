@@ -13,6 +13,7 @@ Rank 0 prints ONE JSON line with the driver's contract fields plus "roofline" (d
 HIP-event timed inside the timed region) and "cpu_baseline" (the oracle timed on the host cores).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -118,6 +119,7 @@ def cpu_baseline(cpu_batch):
         "value": round(best[0], 2),
         "unit": "audio-s/s",
         "cores": best[1],
+        "host_threads": cores,
         "kind": "port",
         "sample": f"render+PQMF(3)+mel-L1 over {cpu_batch} voices x {SECONDS:g} s @ {SAMPLE_RATE} Hz (oracle, torch CPU ops): "
                   + "; ".join(f"{r[2]} passes in {r[3]:.1f} s on {r[1]} threads = {r[0]:.1f} audio-s/s" for r in runs),
@@ -528,25 +530,46 @@ def main():
 
     ev = {"begin": [], "end": []}
     cev = {"pqmf": [], "stft": []}      # (begin, end) HIP events on the consumers' own streams (in-step durations)
+    # instrument["on"]: False, "events" (HIP events around the stages: eager passes only) or "stamps" (ias_stamp launches
+    # around the stages: device timestamps that can be captured INTO a graph, so the in-step durations of the line belong
+    # to a replayed graph like the one the timed regions replay -- HIP events cannot be read back from a replay)
     instrument = {"on": False}
+    STAGES = ("render", "pqmf", "stft")
+    stamp_buf = torch.zeros((len(STAGES), max(args.steps, args.warmup, 2), 2), dtype=torch.int64, device=dev)
+    stamp_n = {n: 0 for n in STAGES}
+
+    def stamp(name, which):
+        i = stamp_n[name]
+        cell = stamp_buf[STAGES.index(name), i, which:which + 1]
+        _lib.check(_lib.load().ias_stamp(ctypes.c_void_p(cell.data_ptr()), _lib.stream()), "ias_stamp")
+        if which == 1:
+            stamp_n[name] = i + 1
 
     def bracket(name):
-        """with bracket("pqmf"): ... -- HIP events on the CURRENT stream around the launches inside (eager passes only)"""
+        """with bracket("pqmf"): ... -- timestamps on the CURRENT stream around the launches inside"""
         class _B:
             def __enter__(self_):
-                if instrument["on"]:
+                if instrument["on"] == "events":
                     self_.e0 = torch.cuda.Event(enable_timing=True); self_.e0.record()
+                elif instrument["on"] == "stamps":
+                    stamp(name, 0)
             def __exit__(self_, *exc):
-                if instrument["on"]:
+                if instrument["on"] == "events":
                     e1 = torch.cuda.Event(enable_timing=True); e1.record()
                     cev[name].append((self_.e0, e1))
+                elif instrument["on"] == "stamps":
+                    stamp(name, 1)
         return _B()
 
     def hook(name, phase):
-        if instrument["on"] and name == "oscillators":
+        if name != "oscillators":
+            return
+        if instrument["on"] == "events":
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             ev[phase].append(e)
+        elif instrument["on"] == "stamps":
+            stamp("render", 0 if phase == "begin" else 1)
 
     # Dataflow of one step: control-rate pass -> audio-rate render -> audio -> {PQMF, spectral loss}.  The two consumers
     # depend only on the audio, so they run on two side HIP streams (the control pass on a third); with several audio
@@ -741,19 +764,53 @@ def main():
     def timed_pass(pipe):
         ev["begin"].clear(); ev["end"].clear()
         cev["pqmf"].clear(); cev["stft"].clear()
-        instrument["on"] = True
+        instrument["on"] = "events"
         torch.cuda.synchronize()
         run_steps(args.steps, pipe)
         torch.cuda.synchronize()
         instrument["on"] = False
         ms = [b.elapsed_time(e) for b, e in zip(ev["begin"], ev["end"])]
-        return sum(ms) / len(ms)
+        out = {"render": sum(ms) / len(ms)}
+        for name in ("pqmf", "stft"):
+            ms_ = [b.elapsed_time(e) for b, e in cev[name]]
+            out[name] = sum(ms_) / len(ms_) if ms_ else None
+        return out
 
-    osc_ms_overlapped = timed_pass(pipelined)
-    instep_ms = {"render": osc_ms_overlapped}
-    for name in ("pqmf", "stft"):
-        ms_ = [b.elapsed_time(e) for b, e in cev[name]]
-        instep_ms[name] = sum(ms_) / len(ms_) if ms_ else None
+    def stamped_replay(pipe):
+        """The K-step schedule captured ONCE MORE with a device timestamp before and after every stage (six one-thread
+        launches per step on the stages' own streams) and replayed: -> in-step duration per stage [ms], step time of the
+        instrumented replay [ms] (next to ms_per_step it shows what the stamps cost)."""
+        for n in STAGES:
+            stamp_n[n] = 0
+        stamp_buf.zero_()
+        instrument["on"] = "stamps"
+        torch.cuda.synchronize()
+        gi = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gi):
+            run_steps(args.steps, pipe)
+        instrument["on"] = False
+        gi.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); gi.replay(); e1.record()
+        torch.cuda.synchronize()
+        t = stamp_buf.cpu().double()[:, :args.steps]
+        dur = (t[:, :, 1] - t[:, :, 0]) * 1e-5                # 100 MHz ticks -> ms
+        return {n: float(dur[i].mean()) for i, n in enumerate(STAGES)}, e0.elapsed_time(e1) / args.steps
+
+    instep_source, stamped_step_ms = "HIP events around the stages in an eager pass of the schedule", None
+    instep_ms = None
+    if graph is not None:
+        try:
+            instep_ms, stamped_step_ms = stamped_replay(pipelined)
+            instep_source = ("device timestamps (ias_stamp: s_memrealtime, 10 ns) captured into a second graph of the same "
+                             "K-step schedule, one replay; includes the launch gap behind each stamp")
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"[bench] stamped replay failed ({type(e).__name__}: {e}); eager events instead\n")
+            instrument["on"] = False
+            torch.cuda.synchronize()
+    if instep_ms is None:
+        instep_ms = timed_pass(pipelined)
 
     def isolated_ms(fn):
         """K back-to-back launches of one stage captured in a graph (no host launch gap inside), HIP events around the replay"""
@@ -834,15 +891,49 @@ def main():
         hits = [v for k, v in table.items() if kname in k and isinstance(v, dict)]
         return hits[0].get("hbm_bytes_per_launch") if hits else None
 
+    # SQ counters per launch (profiles/counters.json: scripts/make_counters.py from the rocprofv3 --pmc summaries) and the
+    # static VALU cost per instruction (profiles/isa_costs.json: scripts/isa_costs.py on the ISA of the built kernels):
+    # imported like `traffic`, recomputable from profiles/<round>_pmc_{voice,stft,pqmf}.txt
+    def load_json(name):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:  # noqa: BLE001
+            return {}
+    counters, isa_costs = load_json("counters.json"), load_json("isa_costs.json")
+    N_CU, N_SIMD, CLOCK_MHZ = 256, 1024, 2100.0     # shader clock under these kernels: 2.10-2.15 GHz (s_memtime / s_memrealtime)
+    units = {"render": ("sample-wave (64 samples)", B * T / 64.0), "pqmf": ("frame", B * (T // 3)),
+             "stft": ("frame", B * (1 + T // plan.hop_length))}
+
     kernels = {}
     for name in ("render", "pqmf", "stft"):
         ab = bps[name] * B * T
         gbs = ab / (iso_ms[name] * 1e-3) / 1e9
-        kernels[name] = {"kernel": knames[name], "algorithmic_bytes_per_launch": int(ab),
-                         "isolated_avg_us": round(iso_ms[name] * 1e3, 1),
-                         "in_step_avg_us": None if instep_ms[name] is None else round(instep_ms[name] * 1e3, 1),
-                         "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(knames[name])}
+        k = {"kernel": knames[name], "algorithmic_bytes_per_launch": int(ab),
+             "isolated_avg_us": round(iso_ms[name] * 1e3, 1),
+             "in_step_avg_us": None if instep_ms[name] is None else round(instep_ms[name] * 1e3, 1),
+             "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+             "traffic": pmc_traffic(knames[name])}
+        c = next((v for kk, v in counters.items() if isinstance(v, dict) and knames[name].split("<")[0] in kk), None)
+        cost = next((v for kk, v in isa_costs.items() if isinstance(v, dict) and knames[name].split("<")[0] in kk), None)
+        cycles = iso_ms[name] * 1e-3 * CLOCK_MHZ * 1e6            # shader clocks of one isolated launch
+        fracs = {"hbm": k["frac"]}
+        if c and "SQ_INSTS_VALU" in c:
+            k["valu_insts"] = int(c["SQ_INSTS_VALU"])
+            k["valu_insts_per_unit"] = round(c["SQ_INSTS_VALU"] / units[name][1], 1)
+            k["unit_of_work"] = units[name][0]
+            if cost:
+                k["valu_clk_per_inst"] = cost["valu_clk_per_inst"]
+                k["frac_valu"] = round(c["SQ_INSTS_VALU"] * cost["valu_clk_per_inst"] / (N_SIMD * cycles), 4)
+                fracs["valu"] = k["frac_valu"]
+            if "SQ_LDS_IDX_ACTIVE" in c:
+                k["lds_busy_frac"] = round(c["SQ_LDS_IDX_ACTIVE"] / (N_CU * cycles), 4)
+                fracs["lds"] = k["lds_busy_frac"]
+                if c["SQ_LDS_IDX_ACTIVE"] > 0 and "SQ_LDS_BANK_CONFLICT" in c:
+                    k["lds_conflict_frac"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 4)
+            k["counters_round"] = counters.get("_round")
+        # what the counters say binds the kernel: the largest of its HBM, vector-pipe and LDS-pipe fractions
+        k["bound"] = max(fracs, key=fracs.get)
+        kernels[name] = k
     # the dominant kernel of the TIMED schedule = the one with the largest in-step duration per step
     dom = max(kernels, key=lambda n: kernels[n]["in_step_avg_us"] or 0.0)
     chain_bytes = sum(bps.values()) * B * T          # 21 B here; SURVEY.md rounds the chain to 22 B/sample (497 MB)
@@ -880,12 +971,19 @@ def main():
             "dominant_by": "largest in-step duration per step of the timed (pipelined) schedule",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "limited_by": kernels[dom]["bound"],
+            "limited_by_note": "`bound`/`frac` price the kernel against the HBM roofline as the contract asks; `limited_by` and "
+                               "kernels.*.bound name the pipe the SQ counters show busiest (frac = HBM, frac_valu = SQ_INSTS_VALU x "
+                               "static clocks per instruction / (1024 SIMDs x clocks of an isolated launch at 2.1 GHz), lds_busy_frac = "
+                               "SQ_LDS_IDX_ACTIVE / (256 CUs x the same clocks); counters imported from profiles/counters.json, "
+                               "instruction costs from profiles/isa_costs.json)",
             "traffic_source": "imported from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the "
                               "kernels, gfx950 x2 read correction); not measured by this run",
             "avg_launch_ms": round(iso_ms[dom], 4), "algorithmic_bytes_per_launch": algo_bytes,
             "measured": "HIP events around K back-to-back launches of the stage captured in a graph, on the stream it is "
-                        "launched on (isolated); in_step: events on the stage's own stream inside the pipelined schedule",
+                        "launched on (isolated); in_step: " + instep_source,
             "overlapped_avg_launch_ms": None if instep_ms[dom] is None else round(instep_ms[dom], 4),
+            "stamped_replay_ms_per_step": None if stamped_step_ms is None else round(stamped_step_ms, 4),
             "kernels": kernels,
             "chain_bytes_per_step": int(22.0 * B * T), "chain_bytes_listed_kernels": int(chain_bytes),
             "chain_frac": round(chain_frac, 4),

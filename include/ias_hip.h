@@ -26,6 +26,10 @@ int ias_version(void);
 /* dst[0..n) = src[0..n) with 16-byte accesses; n % 4 == 0.  Bench calibration of the HBM rate. */
 int ias_stream_copy(const float* src, float* dst, long long n, void* stream);
 
+/* dst[0] = the device's constant 100 MHz counter (10 ns ticks) at the point of the stream where the call is placed;
+ * capturable into a hipGraph (measurement plumbing of bench.py; no reference counterpart). */
+int ias_stamp(unsigned long long* dst, void* stream);
+
 /* ---- Voice render: torchsynth.synth.Voice as called at
  * reference vicreg_audio_params.py:86-94,114; audio_to_params.py:196-203,215,240-257; pretrain.py:75.
  * B voices, T = buffer_size samples, Tc = control buffer size (buffer_size_seconds * 441). */

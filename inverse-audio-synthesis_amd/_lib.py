@@ -27,6 +27,7 @@ _F = _c.c_float
 SYMBOLS = {
     "ias_version": (_I, []),
     "ias_stream_copy": (_I, [_P, _P, _LL, _P]),
+    "ias_stamp": (_I, [_P, _P]),
     "ias_voice_workspace_bytes": (_LL, [_I, _I, _I]),
     "ias_voice_control": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ias_voice_control_ws": (_I, [_P, _P, _LL, _I, _I, _I, _I, _P]),

@@ -18,3 +18,13 @@ extern "C" int ias_stream_copy(const float* src, float* dst, long long n, void* 
                      (float4*)dst, n / 4);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
+
+// One device timestamp (s_memrealtime: the constant 100 MHz counter, 10 ns per tick) into dst[0], as a stream-ordered
+// launch: bench.py brackets the stages of the step with these INSIDE a captured graph (HIP events cannot be read back
+// from a replayed graph), so the in-step durations it reports belong to the replayed schedule it times.
+__global__ void stamp_kernel(unsigned long long* dst) { dst[0] = __builtin_amdgcn_s_memrealtime(); }
+extern "C" int ias_stamp(unsigned long long* dst, void* stream_) {
+  if (!dst) return IAS_ERR_ARG;
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, dst);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
