@@ -901,8 +901,10 @@ def main():
             return {}
     counters, isa_costs = load_json("counters.json"), load_json("isa_costs.json")
     N_CU, N_SIMD, CLOCK_MHZ = 256, 1024, 2100.0     # shader clock under these kernels: 2.10-2.15 GHz (s_memtime / s_memrealtime)
-    units = {"render": ("sample-wave (64 samples)", B * T / 64.0), "pqmf": ("frame", B * (T // 3)),
-             "stft": ("frame", B * (1 + T // plan.hop_length))}
+    # SQ_INSTS_VALU counts wave instructions: the unit is what ONE WAVE INSTRUCTION STREAM covers
+    units = {"render": ("sample per lane (a wave: 64 samples)", B * T / 64.0),
+             "pqmf": ("4 frames per lane (a wave: 256 frames)", B * (T // 3) / 256.0),
+             "stft": ("frame (one wave per frame)", B * (1 + T // plan.hop_length))}
 
     kernels = {}
     for name in ("render", "pqmf", "stft"):
