@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void vicreg_gram_kernel(const unsigned shor
 // (~30 B/clk per CU at best), not the matrix cores.  So a workgroup keeps a PAIR of row panels (256 rows x K = 128) in
 // registers as A fragments (128 VGPRs per lane) and streams the column panels past them: one 32 KB panel fetched feeds
 // 64 MFMAs per wave (two tiles), 16 B/clk at full matrix rate.  The panels come in by LDS-DMA (no VGPR staging) into a
-// ring of four 32 KB slots, requested three steps ahead; one raw s_barrier per step.  LDS image of a panel:
+// ring of four 32 KB slots (the pair of panels being read + the pair landing); one raw s_barrier per PAIR of steps.  LDS image of a panel:
 // [128 rows][16 granules of 16 B], granule g of row r at slot g ^ (r & 15) -- conflict-free for the fragment reads
 // (16 consecutive rows, same granule) and lane-linear for the DMA once the SOURCE address is permuted the same way.
 // Tiles below the diagonal of a pair (2p+1, 2p) are computed and given weight 0 (1.5 % of the work).
@@ -391,12 +391,12 @@ __global__ __launch_bounds__(GP_THREADS, 2) void vicreg_gram_pair_kernel(const u
   __builtin_amdgcn_s_barrier();        // every wave has its fragments: the slots can be reused
 
   GPSTAMP(1);
-  // ---- stream the column panels: requested GP_RING - 1 steps ahead, one barrier per step
+  // ---- stream the column panels
   const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)s_ring;
 #ifndef GP_NO_LOAD
-  if (requested < nsteps) { request(tj0 + requested, (requested + 2) % GP_RING); ++requested; }   // slot 0 is free now
+  for (; requested < min(nsteps, 4); ++requested) request(tj0 + requested, (requested + 2) % GP_RING);   // slots 0, 1 are free now
 #else
-  if (requested < nsteps) ++requested;
+  requested = min(nsteps, 4);
 #endif
   float tot = 0.f;
   const int ti = 2 * p + (wr >> 1);    // the row panel this wave's rows belong to
@@ -446,22 +446,29 @@ __global__ __launch_bounds__(GP_THREADS, 2) void vicreg_gram_pair_kernel(const u
     tot += (ti == tjP) ? ss : 2.0f * ss;
   };
 
-  // one step: MFMAs of panel s into accC, plain square sums of accP (the previous step) in their shadow
-  auto step = [&](int s, f32x16 (&accC)[2][2], const f32x16 (&accP)[2][2], bool haveP) {
-    // this wave's loads of panel s have landed once at most the loads of the later panels requested so far are
-    // outstanding (vector memory operations retire in order); the barrier extends that to every wave's part and frees
-    // the slot of panel s - 1
-    const int later = requested - 1 - s;
+  // Two steps per barrier (round 4).  With a barrier per step all eight waves start their 32 MFMAs together and finish
+  // together, and the ~1,100 cycles between two streams (barrier, first fragment reads, the rest of the epilogue) leave
+  // the matrix cores idle: in-kernel stamps had a step at 3,650 cycles for 2,050 of matrix work, with and without the
+  // panel loads.  A barrier now covers a PAIR of steps: the fragments of the second panel are read while the first
+  // one's MFMAs run.  Ring: the pair being read (two slots) + the pair landing (two slots); the landing pair is requested
+  // in the FIRST step of the pair before (one 1 KB piece per k step), so it has the second step's duration to arrive.
+  auto sync_pair = [&](int s, int npanels) {
+    // this wave's loads of panels s .. s + npanels - 1 have landed once at most the loads of the later panels requested
+    // so far are outstanding (vector memory operations retire in order); the barrier extends that to every wave's part
+    // and frees the slots of the pair before
+    const int later = requested - (s + npanels);
     if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+  };
+  // one step: MFMAs of panel s into accC, plain square sums of accP (the previous step) in their shadow; `nreq` panels
+  // (0, 1 or 2) are requested on the way, a piece per k step
+  auto step = [&](int s, f32x16 (&accC)[2][2], const f32x16 (&accP)[2][2], bool haveP, int nreq) {
     GPSTAMP(2 + 2 * s);
-    // the next panel's four 1 KB pieces are issued one at a time between the groups of MFMAs below (as a burst right
-    // after the barrier, the 32 DMA instructions of the eight waves queue up in front of the matrix work)
-    const bool req = requested < nsteps;
-    const int req_tj = tj0 + requested, req_slot = (requested + 2) % GP_RING;
-    if (req) ++requested;
+    const int req_tj0 = tj0 + requested, req_slot0 = (requested + 2) % GP_RING;
+    const int req_tj1 = req_tj0 + 1, req_slot1 = (requested + 3) % GP_RING;
+    requested += nreq;
 
     // B fragments by inline-asm ds_read_b128: through the compiler's own LDS loads every step would first drain ALL
     // outstanding LDS-DMA (it cannot tell the slot being read from the slots being filled and inserts vmcnt(0)), which
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(GP_THREADS, 2) void vicreg_gram_pair_kernel(const u
         }
       }
 #ifndef GP_NO_LOAD
-      if (req && (ks & 1) == 0) request_piece(req_tj, req_slot, ks >> 1);
+      if (ks < 4 ? nreq >= 1 : nreq >= 2) request_piece(ks < 4 ? req_tj0 : req_tj1, ks < 4 ? req_slot0 : req_slot1, ks & 3);
 #endif
       __builtin_amdgcn_sched_barrier(0);   // keep this k step's MFMAs between the issue of the next reads and their wait
 #pragma unroll
@@ -527,11 +534,15 @@ __global__ __launch_bounds__(GP_THREADS, 2) void vicreg_gram_pair_kernel(const u
       for (int e = 0; e < 16; ++e) { acc0[m][n][e] = 0.f; acc1[m][n][e] = 0.f; }
   int s = 0;
   for (; s + 1 < nsteps; s += 2) {
-    step(s, acc0, acc1, s > 0);
-    step(s + 1, acc1, acc0, true);
+    sync_pair(s, 2);
+    // the slots of panels s - 2, s - 1 are free: panels s + 2, s + 3 go there (at s = 0 they were requested above)
+    const int nreq = max(0, min(nsteps, s + 4) - requested);
+    step(s, acc0, acc1, s > 0, nreq);
+    step(s + 1, acc1, acc0, true, 0);
   }
   if (s < nsteps) {
-    step(s, acc0, acc1, s > 0);
+    sync_pair(s, 1);
+    step(s, acc0, acc1, s > 0, 0);
     // the last tile's squares, not hidden behind anything
     float ss = 0.f;
 #pragma unroll

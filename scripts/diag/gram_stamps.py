@@ -1,7 +1,7 @@
 """Per-step timing of vicreg_gram_pair_kernel from in-kernel s_memtime stamps (diagnostic build libias_gpstamps.so)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-os.environ["IAS_HIP_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", "libias_gpstamps.so")
+os.environ["IAS_HIP_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", os.environ.get("GP_LIB", "libias_gpstamps.so"))
 import torch
 from inverse_audio_synthesis_amd import _lib
 lib = _lib.load()
@@ -29,3 +29,9 @@ for w in range(8):
     waits = [(f[:, 2 + 2 * k] - (f[:, 1] if k == 0 else f[:, 1 + 2 * k])).mean().item() for k in range(10)]
     comps = [(f[:, 3 + 2 * k] - f[:, 2 + 2 * k]).mean().item() for k in range(10)]
     print(f"wave {w}: setup {setup:6.0f}; steady wait+barrier {sum(waits[3:]) / 7:6.0f}, MFMA stream {sum(comps[3:]) / 7:6.0f}; item total {(f[:, 30] - f[:, 0]).mean().item():7.0f}")
+
+for w in (0, 4):
+    f = full[:, w]
+    waits = [(f[:, 2 + 2 * k] - (f[:, 1] if k == 0 else f[:, 1 + 2 * k])).mean().item() for k in range(10)]
+    comps = [(f[:, 3 + 2 * k] - f[:, 2 + 2 * k]).mean().item() for k in range(10)]
+    print(f"wave {w} per step: gap before " + " ".join(f"{x:5.0f}" for x in waits) + " | stream " + " ".join(f"{x:5.0f}" for x in comps))
