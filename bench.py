@@ -366,13 +366,14 @@ def pretrain_leg(dev, B=128, steps=5, reps=5):
     times.sort()
     loss = float(model.logged["vicreg/train/loss"])
     ms = times[len(times) // 2]
+    gemm_tuning = tr.gemm_tuning
     del tr, model
     return {"ms_per_step": round(ms, 3), "ms_per_step_min": round(times[0], 3), "steps": steps, "timed_regions": reps,
             "value": round(B * SECONDS / (ms * 1e-3), 1), "unit": "audio-s/s trained",
             "workload": f"VICReg pretraining step, batch {B} x {SECONDS:g} s @ {SAMPLE_RATE} Hz per GPU (configs[2] shape): render + "
                         "PQMF(3) + MobileNetV3-small trunk + projector 8192 + VICReg loss, backward, LARS; fp32 (bf16 only "
                         "inside the VICReg Gram), random init, synthetic parameters",
-            "launch": "hipgraph (Trainer._graph_step)", "loss": loss}
+            "launch": "hipgraph (Trainer._graph_step)", "loss": loss, "gemm_tuning": gemm_tuning}
 
 
 def pmc_traffic_of(kname):

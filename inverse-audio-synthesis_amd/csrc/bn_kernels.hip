@@ -174,6 +174,126 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_scalar_kernel(const float
   }
 }
 
+// ---- small maps (round 4): ONE workgroup per channel, ONE launch per direction ----------------------------------------
+// 24 of the trunk's 34 BatchNorm layers sit on 15 x 16 and 8 x 8 maps: a channel is 128 x 240 (or 64) values, 120 KB at
+// most.  The three-launch form above spends 26 us forward and 35 us backward on such a layer, nearly all of it launch and
+// latency (partials, a finalize launch over C numbers, apply).  Here a 1024-thread workgroup keeps its channel in
+// registers (up to NV 16-byte vectors per thread): statistics, finalize and apply (forward), or dz / xhat sums, finalize
+// and dx (backward) in one pass over HBM -- x is read once instead of twice, (x, dy) once instead of twice.
+// Sums: per thread in fp32 over its <= 4 NV values (shifted by K = x[0, c, 0] in the forward), then in fp64 across the
+// wave (xor butterfly: the same pairing for every lane count) and across the 16 waves in wave order: fixed order.
+#define BNF_THREADS 1024
+__device__ __forceinline__ void bnf_block_sum2(double& a, double& b, double (*s_red)[2]) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();                       // (s_red may still be read from a previous use)
+  if (lane == 0) { s_red[wave][0] = a; s_red[wave][1] = b; }
+  __syncthreads();
+  double ta = 0.0, tb = 0.0;
+  for (int w = 0; w < BNF_THREADS / 64; ++w) { ta += s_red[w][0]; tb += s_red[w][1]; }
+  a = ta; b = tb;
+}
+// vector i (of B * HW / 4) of channel c: batch i / hwv, vector i % hwv of the plane
+__device__ __forceinline__ size_t bnf_off(int i, int hwv, int C, int c) {
+  const int b = i / hwv, j = i - b * hwv;
+  return ((size_t)b * C + c) * hwv + j;
+}
+
+template <int NV>
+__global__ __launch_bounds__(BNF_THREADS) void bn_fused_forward_kernel(
+    const float4* __restrict__ x, const float* __restrict__ weight, const float* __restrict__ bias,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float4* __restrict__ y, float* __restrict__ save_mean,
+    float* __restrict__ save_invstd, int B, int C, int hwv, float eps, float momentum, int act) {
+  __shared__ double s_red[BNF_THREADS / 64][2];
+  const int c = blockIdx.x, tid = threadIdx.x, nvec = B * hwv;
+  const float k = reinterpret_cast<const float*>(x)[(size_t)c * hwv * 4];
+  float4 v[NV];
+  float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+  for (int e = 0; e < NV; ++e) {
+    const int i = tid + e * BNF_THREADS;
+    if (i < nvec) {
+      v[e] = x[bnf_off(i, hwv, C, c)];
+      const float d0 = v[e].x - k, d1 = v[e].y - k, d2 = v[e].z - k, d3 = v[e].w - k;
+      p0 += d0; p0 += d1; p0 += d2; p0 += d3;
+      p1 = fmaf(d0, d0, p1); p1 = fmaf(d1, d1, p1); p1 = fmaf(d2, d2, p1); p1 = fmaf(d3, d3, p1);
+    }
+  }
+  double s1 = (double)p0, s2 = (double)p1;
+  bnf_block_sum2(s1, s2, s_red);
+  const double n = (double)nvec * 4.0, dm = s1 / n;
+  double var = s2 / n - dm * dm;
+  if (var < 0.0) var = 0.0;
+  const double mean_d = (double)k + dm;
+  const float mean = (float)mean_d, invstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (tid == 0) {
+    save_mean[c] = mean; save_invstd[c] = invstd;
+    if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean_d);
+    if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * (n > 1.0 ? n / (n - 1.0) : 1.0));
+  }
+  const float w = weight ? weight[c] : 1.0f, bb = bias ? bias[c] : 0.0f;
+#pragma unroll
+  for (int e = 0; e < NV; ++e) {
+    const int i = tid + e * BNF_THREADS;
+    if (i < nvec) {
+      float4 o;
+      o.x = bn_act(fmaf(w, (v[e].x - mean) * invstd, bb), act); o.y = bn_act(fmaf(w, (v[e].y - mean) * invstd, bb), act);
+      o.z = bn_act(fmaf(w, (v[e].z - mean) * invstd, bb), act); o.w = bn_act(fmaf(w, (v[e].w - mean) * invstd, bb), act);
+      y[bnf_off(i, hwv, C, c)] = o;
+    }
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(BNF_THREADS) void bn_fused_backward_kernel(
+    const float4* __restrict__ x, const float4* __restrict__ dy, const float* __restrict__ weight,
+    const float* __restrict__ bias, const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+    float4* __restrict__ dx, float* __restrict__ gw, float* __restrict__ gb, int B, int C, int hwv, int act) {
+  __shared__ double s_red[BNF_THREADS / 64][2];
+  const int c = blockIdx.x, tid = threadIdx.x, nvec = B * hwv;
+  const float m = save_mean[c], is = save_invstd[c], w = weight ? weight[c] : 1.0f, bb = bias ? bias[c] : 0.0f;
+  float4 xh[NV], dz[NV];
+  float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+  for (int e = 0; e < NV; ++e) {
+    const int i = tid + e * BNF_THREADS;
+    if (i < nvec) {
+      const size_t o = bnf_off(i, hwv, C, c);
+      const float4 xv = x[o], gv = dy[o];
+      xh[e].x = (xv.x - m) * is; xh[e].y = (xv.y - m) * is; xh[e].z = (xv.z - m) * is; xh[e].w = (xv.w - m) * is;
+      dz[e].x = gv.x * bn_act_grad(fmaf(w, xh[e].x, bb), act); dz[e].y = gv.y * bn_act_grad(fmaf(w, xh[e].y, bb), act);
+      dz[e].z = gv.z * bn_act_grad(fmaf(w, xh[e].z, bb), act); dz[e].w = gv.w * bn_act_grad(fmaf(w, xh[e].w, bb), act);
+      p0 += dz[e].x; p0 += dz[e].y; p0 += dz[e].z; p0 += dz[e].w;
+      p1 = fmaf(dz[e].x, xh[e].x, p1); p1 = fmaf(dz[e].y, xh[e].y, p1); p1 = fmaf(dz[e].z, xh[e].z, p1); p1 = fmaf(dz[e].w, xh[e].w, p1);
+    }
+  }
+  double s1 = (double)p0, s2 = (double)p1;
+  bnf_block_sum2(s1, s2, s_red);
+  if (tid == 0) { if (gb) gb[c] = (float)s1; if (gw) gw[c] = (float)s2; }
+  const float inv_n = 1.0f / (float)((long long)nvec * 4);
+  const float a = (float)s1 * inv_n, b2 = (float)s2 * inv_n, ws = w * is;
+#pragma unroll
+  for (int e = 0; e < NV; ++e) {
+    const int i = tid + e * BNF_THREADS;
+    if (i < nvec) {
+      float4 o;
+      o.x = ws * (dz[e].x - a - xh[e].x * b2); o.y = ws * (dz[e].y - a - xh[e].y * b2);
+      o.z = ws * (dz[e].z - a - xh[e].z * b2); o.w = ws * (dz[e].w - a - xh[e].w * b2);
+      dx[bnf_off(i, hwv, C, c)] = o;
+    }
+  }
+}
+// vectors per thread the one-workgroup form needs for this layer, or 0 if it does not apply (IAS_BN_UNFUSED=1: never)
+static int bn_fused_nv(const void* p0, const void* p1, const void* p2, int B, int C, int HW) {
+  static const bool off = getenv("IAS_BN_UNFUSED") && atoi(getenv("IAS_BN_UNFUSED")) != 0;
+  if (off || (HW & 3) || ((((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15) != 0) || C < 32) return 0;
+  const long long nvec = (long long)B * (HW >> 2);
+  if (nvec <= 2 * BNF_THREADS) return 2;
+  if (nvec <= 8 * BNF_THREADS) return 8;
+  return 0;
+}
+
 // ------------------------------------------------------------------------ C ABI
 static int bn_split(int B, int C) {
   static const int target = getenv("IAS_BN_WGS") ? atoi(getenv("IAS_BN_WGS")) : 2048;   // (diagnostics knob)
@@ -219,6 +339,15 @@ extern "C" int ias_bn_act_forward(const float* x, const float* weight, const flo
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !y || !save_mean || !save_invstd || !scratch || B <= 0 || C <= 0 || C > 65535 || HW <= 0 || act < 0 || act > 2)
     return IAS_ERR_ARG;
+  if (const int nv = bn_fused_nv(x, y, nullptr, B, C, HW)) {
+    if (nv == 2)
+      hipLaunchKernelGGL((bn_fused_forward_kernel<2>), dim3(C), dim3(BNF_THREADS), 0, stream, (const float4*)x, weight, bias,
+                         running_mean, running_var, (float4*)y, save_mean, save_invstd, B, C, HW >> 2, eps, momentum, act);
+    else
+      hipLaunchKernelGGL((bn_fused_forward_kernel<8>), dim3(C), dim3(BNF_THREADS), 0, stream, (const float4*)x, weight, bias,
+                         running_mean, running_var, (float4*)y, save_mean, save_invstd, B, C, HW >> 2, eps, momentum, act);
+    return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+  }
   const int S = bn_split(B, C);
   hipLaunchKernelGGL((bn_partials_kernel<0>), dim3(C, S), dim3(BN_THREADS), 0, stream, x, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, scratch, B, C,
@@ -237,6 +366,15 @@ extern "C" int ias_bn_act_backward(const float* x, const float* dy, const float*
   if (!x || !dy || !dx || !save_mean || !save_invstd || !scratch || !sums || B <= 0 || C <= 0 || C > 65535 || HW <= 0 ||
       act < 0 || act > 2)
     return IAS_ERR_ARG;
+  if (const int nv = bn_fused_nv(x, dy, dx, B, C, HW)) {
+    if (nv == 2)
+      hipLaunchKernelGGL((bn_fused_backward_kernel<2>), dim3(C), dim3(BNF_THREADS), 0, stream, (const float4*)x,
+                         (const float4*)dy, weight, bias, save_mean, save_invstd, (float4*)dx, gw, gb, B, C, HW >> 2, act);
+    else
+      hipLaunchKernelGGL((bn_fused_backward_kernel<8>), dim3(C), dim3(BNF_THREADS), 0, stream, (const float4*)x,
+                         (const float4*)dy, weight, bias, save_mean, save_invstd, (float4*)dx, gw, gb, B, C, HW >> 2, act);
+    return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+  }
   const int S = bn_split(B, C);
   hipLaunchKernelGGL((bn_partials_kernel<1>), dim3(C, S), dim3(BN_THREADS), 0, stream, x, dy, save_mean, save_invstd, weight,
                      bias, scratch, B, C, HW, act);

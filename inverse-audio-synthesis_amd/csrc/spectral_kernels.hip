@@ -134,6 +134,46 @@ __device__ __forceinline__ void wave_lds_sync() {
 #endif
 }
 
+// ---- register <-> lane-bits transpose (round 4): the first exchange of the radix-8 kernels without LDS.
+// Pass 1 leaves element (k1, a, c) in register k1 of lane 8 a + c; pass 2 wants it in register a of lane 8 k1 + c: an
+// 8 x 8 transpose between the register index and lane bits 3..5.  Bit by bit: register bit 0 <-> lane bit 3 (distance 8
+// inside a row of 16: two bank-masked DPP row rotations and a copy per register pair), bit 1 <-> lane bit 4
+// (v_permlane16_swap: rows 1, 3 of one register against rows 0, 2 of the other), bit 2 <-> lane bit 5
+// (v_permlane32_swap).  32 + 8 + 8 = 48 VALU instructions for the 8 complex values of a lane, against 8 ds_write_b64
+// (6 LDS cycles each) + 8 ds_read_b64 and two LDS round trips of latency (checked lane by lane against the LDS transpose:
+// scripts/diag/permlane_swap.hip).  The second exchange transposes the register index with lane bits 0..2, for which
+// gfx950 has no swap instruction (three DPP instructions per pair and level: 72): it stays in LDS.
+typedef unsigned x_u2 __attribute__((ext_vector_type(2)));
+template <int L> __device__ __forceinline__ void xchg_pair(float& f0, float& f1) {
+  unsigned r0 = __float_as_uint(f0), r1 = __float_as_uint(f1);
+  if (L == 5) { const x_u2 t = __builtin_amdgcn_permlane32_swap(r0, r1, false, false); r0 = t.x; r1 = t.y; }
+  else if (L == 4) { const x_u2 t = __builtin_amdgcn_permlane16_swap(r0, r1, false, false); r0 = t.x; r1 = t.y; }
+  else {
+    // lanes with bit 3 set (banks 2, 3 of a row of 16): r0 <- r1 of lane ^ 8; lanes with bit 3 clear: r1 <- r0 of lane ^ 8
+    const unsigned old0 = r0;
+    r0 = __builtin_amdgcn_update_dpp(r0, r1, 0x128 /* row_ror:8 */, 0xf, 0xc, false);
+    r1 = __builtin_amdgcn_update_dpp(r1, old0, 0x128, 0xf, 0x3, false);
+  }
+  f0 = __uint_as_float(r0); f1 = __uint_as_float(r1);
+}
+// u[k1] of lane (a, c)  ->  u[a] of lane (k1, c)
+__device__ __forceinline__ void xchg_reg_lane345(cpx (&u)[8]) {
+#pragma unroll
+  for (int comp = 0; comp < 2; ++comp) {
+    float f[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) f[q] = comp ? u[q].y : u[q].x;
+    xchg_pair<3>(f[0], f[1]); xchg_pair<3>(f[2], f[3]); xchg_pair<3>(f[4], f[5]); xchg_pair<3>(f[6], f[7]);
+    xchg_pair<4>(f[0], f[2]); xchg_pair<4>(f[1], f[3]); xchg_pair<4>(f[4], f[6]); xchg_pair<4>(f[5], f[7]);
+    xchg_pair<5>(f[0], f[4]); xchg_pair<5>(f[1], f[5]); xchg_pair<5>(f[2], f[6]); xchg_pair<5>(f[3], f[7]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { if (comp) u[q].y = f[q]; else u[q].x = f[q]; }
+  }
+}
+#ifndef IAS_S2_REGX
+#define IAS_S2_REGX 1      // stft2_kernel: first exchange in registers (0: both through LDS, the round-3 form)
+#endif
+
 // Loads the 2R samples of frame f that lane `lane` owns in pass 1 (points 64*n1 + lane, n1 < R).
 // Interior frames on 8-byte-aligned rows: R coalesced 8-byte loads (512 B per wave instruction);
 // frames that touch the row ends (reflect padding) or odd alignments: per-sample indexing.
@@ -661,6 +701,15 @@ void stft2_kernel(const Spec2Args a) {
 #pragma unroll
       for (int n1 = 0; n1 < R; ++n1) v[n1] = cmk(xc[16 * sub + 2 * n1], xc[16 * sub + 2 * n1 + 1]) * t_win[64 * (8 * sub + n1)];
       dft8(v);
+      cpx u[8];
+#if IAS_S2_REGX
+#pragma unroll
+      for (int q = 0; q < R; ++q) u[q] = cmul(v[q], t_tw1[64 * q]);
+      S2_STAMP(2);
+      xchg_reg_lane345(u);
+      S2_STAMP(3);
+      S2_STAMP(4);
+#else
       {
         const int c = lane & 7, aa = lane >> 3;
 #pragma unroll
@@ -669,11 +718,11 @@ void stft2_kernel(const Spec2Args a) {
       S2_STAMP(2);
       wave_lds_sync();
       S2_STAMP(3);
-      cpx u[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) u[q] = sA[IAS_S2_AT(lane, q)];
       wave_lds_sync();
       S2_STAMP(4);
+#endif
       // pass 2: radix 8 over a for each (k1, c); twiddle W_64^(c d); scatter (in place) to [k1][d][c]
       dft8(u);
 #pragma unroll

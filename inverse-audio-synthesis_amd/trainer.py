@@ -48,11 +48,39 @@ def split_indices(num_batches, ntest_batches, seed, count, part, rank=0, world=1
     return [lo + _feistel_perm((start + k * world + rank) % m, m, sd) for k in range(count)]
 
 
+TUNING_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "tunableop_gfx950.csv")
+
+
+def setup_gemm_tuning(mode):
+    """The step's library GEMMs (8192-wide projector, kernel-2 conv head as GEMMs, the six wide 1x1 convolutions as
+    strided-batched GEMMs: 5.6 of the 13 ms of a batch-128 step) run at 100-120 TFLOP/s with the libraries' default
+    solutions.  torch's TunableOp picks the fastest rocBLAS / hipBLASLt solution per shape; the choices measured on an
+    MI355X are shipped (``tuning/tunableop_gfx950.csv``: fp32 in, fp32 out -- only the kernel changes, not the arithmetic
+    type) and looked up at run time: 13.0 -> 12.4 ms per step.  The file carries the library versions it was recorded
+    with; TunableOp ignores it when they differ.  -> what was set up ("off", "file", "online", or "unavailable")."""
+    mode = str(mode or "off").lower()
+    if mode in ("off", "false", "none", "0") or not torch.cuda.is_available():
+        return "off"
+    try:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(mode == "online")
+        if os.path.exists(TUNING_FILE):
+            tunable.set_filename(TUNING_FILE if mode != "online" else os.path.join(os.getcwd(), "tunableop_online.csv"), False)
+            tunable.read_file(TUNING_FILE)
+        return "online" if mode == "online" else "file"
+    except Exception as ex:  # noqa: BLE001 -- a torch build without TunableOp: the libraries' defaults
+        import warnings
+        warnings.warn(f"trainer.gemm_tuning: TunableOp not available ({type(ex).__name__}: {ex})")
+        return "unavailable"
+
+
 class Trainer:
     def __init__(self, cfg, module, stage="vicreg", device=None):
         self.cfg, self.module, self.stage = cfg, module, stage
         self.rank, self.local_rank, self.world = ias_dist.init_from_env()
         self.device = device or torch.device("cuda", torch.cuda.current_device() if self.world > 1 else self.local_rank)
+        self.gemm_tuning = setup_gemm_tuning(cfg.trainer.get("gemm_tuning", "off"))
         # (the entry points seed BEFORE building the module, as runsetup.py:22 does; GradBucketer then broadcasts
         # rank 0's parameters and buffers, as Lightning's DDP does, so replicas start identical by construction)
         self.module.to(self.device)

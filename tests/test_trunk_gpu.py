@@ -84,7 +84,9 @@ def test_trunk_matches_plain_conv2d_modules(lib, dev):
         assert (a - b).abs().max().item() <= 2e-3 * max(1e-3, b.abs().max().item())
 
 
-@pytest.mark.parametrize("shape", [(8, 16, 120, 123), (4, 24, 30, 31), (3, 5, 7, 9), (16, 576, 8, 8), (2, 3, 1, 1)])
+# (the last three shapes take the one-workgroup-per-channel kernels: 2 and 8 vectors per thread, a ragged vector count)
+@pytest.mark.parametrize("shape", [(8, 16, 120, 123), (4, 24, 30, 31), (3, 5, 7, 9), (16, 576, 8, 8), (2, 3, 1, 1),
+                                   (128, 96, 8, 8), (128, 240, 15, 16), (100, 40, 15, 16)])
 @pytest.mark.parametrize("act", [None, torch.nn.ReLU, torch.nn.Hardswish])
 def test_fused_batchnorm_activation_matches_torch(lib, dev, shape, act):
     """BatchNormAct2d (ias_bn_act_forward / _backward) against nn.BatchNorm2d + activation in fp64 on the same data:
@@ -109,10 +111,24 @@ def test_fused_batchnorm_activation_matches_torch(lib, dev, shape, act):
         yr.backward(up.double())
         assert (yf.detach().cpu().double() - yr.detach()).abs().max().item() <= 2e-5 * max(1.0, yr.abs().max().item())
         sc = max(1.0, xr.grad.abs().max().item())
-        assert (xf.grad.cpu().double() - xr.grad).abs().max().item() <= 5e-5 * sc, "dx"
+        ddx = (xf.grad.cpu().double() - xr.grad).abs()
+        if act is torch.nn.ReLU:
+            # at the ReLU kink the derivative jumps: an element whose pre-activation value is within fp32 rounding of 0
+            # may land on the other side in fp32 (a few among the millions of the large shapes); they are left out
+            xd = xr.detach()
+            mu, var = xd.mean(dim=(0, 2, 3), keepdim=True), xd.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+            z = (xd - mu) / torch.sqrt(var + 0.001) * ref.weight.detach().view(1, -1, 1, 1) + ref.bias.detach().view(1, -1, 1, 1)
+            away = z.abs() > 1e-4
+            assert (~away).double().mean().item() <= 1e-3
+            ddx = ddx[away]
+        assert ddx.max().item() <= 5e-5 * sc, "dx"
+        flip = torch.zeros(C, dtype=torch.float64)      # what the left-out kink elements could move a channel's sums by
+        if act is torch.nn.ReLU:
+            xhat = (xd - mu) / torch.sqrt(var + 0.001)
+            flip = ((~away) * up.double().abs() * (1.0 + xhat.abs())).sum(dim=(0, 2, 3))
         for name in ("weight", "bias"):
             gf, gr = getattr(fused, name).grad.cpu().double(), getattr(ref, name).grad
-            assert (gf - gr).abs().max().item() <= 1e-4 * max(1.0, gr.abs().max().item()), name
+            assert ((gf - gr).abs() <= 1e-4 * max(1.0, gr.abs().max().item()) + flip).all(), name
         fused.zero_grad(); ref.zero_grad()
     assert (fused.running_mean.cpu().double() - ref.running_mean).abs().max().item() <= 1e-5 * 50
     assert (fused.running_var.cpu().double() - ref.running_var).abs().max().item() <= 1e-5 * max(1.0, ref.running_var.max().item())
