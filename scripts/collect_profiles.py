@@ -16,6 +16,11 @@ for n in names:
         print("copied", n)
     else:
         print("MISSING", n)
+c = os.path.join(src, "counters.json")
+if os.path.exists(c):
+    shutil.copy(c, os.path.join(dst, "counters.json"))
+    shutil.copy(c, os.path.join(dst, f"{prefix}_counters.json"))
+    print("copied counters.json")
 t = os.path.join(src, "traffic.json")
 if os.path.exists(t):
     shutil.copy(t, os.path.join(dst, "traffic.json"))

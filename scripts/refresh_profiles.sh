@@ -6,6 +6,7 @@
 #   traffic.json                                                      FETCH_SIZE / WRITE_SIZE PMC passes (separate runs) over
 #                                                                     scripts/diag/time_stages.py, per kernel and launch
 #   pmc_voice.txt / pmc_pqmf.txt / pmc_vicreg.txt / pmc_vicreg1024.txt / kstats_pretrain.txt   SQ counter summaries of the named kernels
+#   counters.json                                                     the SQ counters bench.py imports (scripts/make_counters.py over pmc_{voice,stft,pqmf}.txt)
 # Copy what is to be judged into profiles/ afterwards (scripts/collect_profiles.py <tag> <prefix>).
 tag=${1:-rXX}
 R=$GRAFT_REPO_ROOT
@@ -89,6 +90,7 @@ json.dump(t, open(O + "/traffic.json", "w"), indent=1)
 PY
 step kstats pretrain; bash $R/scripts/diag/kstats_pretrain.sh $tag > $O/kstats_pretrain.txt 2>&1
 step pmc stft; bash $R/scripts/diag/pmc_stft.sh $tag PARTS=loss > /dev/null 2>&1; cp $R/gpurun_out/pmcs_$tag/summary.txt $O/pmc_stft.txt
+step counters; python3 $R/scripts/make_counters.py $O $tag $O/counters.json > /dev/null 2>&1
 step trace; bash $R/scripts/diag/trace_bench.sh $tag > $O/trace_default.txt 2>&1
 step trace gradstep; bash $R/scripts/diag/trace_gradstep.sh $tag > $O/trace_gradstep.txt 2>&1; rm -rf $R/gpurun_out/trace_gs_$tag
 step microbench; $R/scripts/diag/_bin/mfma_valu_overlap > $O/mfma_valu_overlap.txt 2>&1; $R/scripts/diag/_bin/mfma_valu_inwave > $O/mfma_valu_inwave.txt 2>&1
