@@ -65,8 +65,11 @@ def setup_gemm_tuning(mode):
         import torch.cuda.tunable as tunable
         tunable.enable(True)
         tunable.tuning_enable(mode == "online")
+        # whatever TunableOp writes goes to a scratch file (online: ./tunableop_online.csv), never into the shipped table
+        import tempfile
+        tunable.set_filename(os.path.join(os.getcwd(), "tunableop_online.csv") if mode == "online" else
+                             os.path.join(tempfile.gettempdir(), f"ias_tunableop_{os.getpid()}.csv"), False)
         if os.path.exists(TUNING_FILE):
-            tunable.set_filename(TUNING_FILE if mode != "online" else os.path.join(os.getcwd(), "tunableop_online.csv"), False)
             tunable.read_file(TUNING_FILE)
         return "online" if mode == "online" else "file"
     except Exception as ex:  # noqa: BLE001 -- a torch build without TunableOp: the libraries' defaults
