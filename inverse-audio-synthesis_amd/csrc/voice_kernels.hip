@@ -175,6 +175,9 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_modmix_kernel(
 // -------------------------------------------------------------------- audio rate
 #define VOICE_MAXCTRL 320  // control points staged per tile (covers sample rates down to ~6 kHz)
 #define VOICE_SPIN_LIMIT (1u << 24)
+#ifndef VOICE_SPIN_SLEEP
+#define VOICE_SPIN_SLEEP 8   // s_sleep units (64 clocks) between two polls of the look-back (2: 98-100 us, 8: 96-97.5, 32: 96-99; same box)
+#endif
 #define VOICE_READY_BIT 0x8000000000000000ull
 #ifndef VOICE_MIN_WAVES
 #define VOICE_MIN_WAVES 3    // waves per SIMD the audio kernel is compiled for (<= 168 VGPRs: two tiles' increments)
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) void voice_audio_ke
             x2 = __hip_atomic_load(row + t * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = (x1 & x2 & VOICE_READY_BIT) != 0;
           }
-          if (!__all(ok)) __builtin_amdgcn_s_sleep(2);
+          if (!__all(ok)) __builtin_amdgcn_s_sleep(VOICE_SPIN_SLEEP);
         }
         if (t < cur.tile) {
           a1 += __longlong_as_double((long long)(x1 & ~VOICE_READY_BIT));
