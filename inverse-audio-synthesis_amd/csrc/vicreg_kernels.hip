@@ -708,11 +708,40 @@ __global__ __launch_bounds__(G2_THREADS, 2) void vicreg_gram256_kernel(const uns
   const int r = lane & 15, q = lane >> 4;
   // XCD placement as in vicreg_gram_pair_kernel: an XCD's L2 serves one branch
   const int xslot = blockIdx.x & 7, branch = xslot >> 2;
+#ifndef G2_NO_STRIPS
+  // Round 4: which tiles an XCD works on at the same time.  Workgroups go to the XCDs round-robin by block index; dealt
+  // tile by tile along the rows of the triangle (rounds 2-3), the 32 tiles resident on an XCD were one row panel against
+  // 32 column panels -- 33 panels of 512 KB through a 4 MB L2, 12.7 x the operands fetched from beyond it
+  // (profiles/r03g_traffic.json).  Now an XCD takes CONTIGUOUS runs of 32 tiles of an enumeration that walks strips of
+  // four tile rows column by column: its resident tiles are 4 row panels x 8 column panels (6 MB).
+  const int q8 = blockIdx.x >> 3;                       // this XCD's q8-th workgroup
+  const int item = (q8 >> 5) * 128 + (xslot & 3) * 32 + (q8 & 31);
+  if (item >= ntri) return;
+  int ti, tj;
+  {
+    int t = item, I = 0;
+    for (;;) {                                          // strip I: tile rows 4 I .. 4 I + h - 1, columns 4 I .. ntile - 1
+      const int h = min(4, ntile - 4 * I), w = ntile - 4 * I;
+      const int cnt = h * w - h * (h - 1) / 2;          // the strip's tiles on or above the diagonal
+      if (t < cnt) {
+        // column-major inside the strip: column c (from the strip's first) has min(c + 1, h) tiles
+        int c = 0;
+        while (c < h - 1 && t >= c + 1) { t -= c + 1; ++c; }
+        if (c == h - 1) { c += t / h; t -= (t / h) * h; }
+        ti = 4 * I + t; tj = 4 * I + c;
+        break;
+      }
+      t -= cnt; ++I;
+    }
+  }
+  const unsigned short* Xt = branch ? Xt_y : Xt_x;
+#else
   const int item = (blockIdx.x >> 3) * 4 + (xslot & 3);
   if (item >= ntri) return;
   const unsigned short* Xt = branch ? Xt_y : Xt_x;
   int ti, tj;
   g2_tri_item(item, ntile, ti, tj);
+#endif
   vc_f32x4 acc[8][4];
 #pragma unroll
   for (int m = 0; m < 8; ++m)
@@ -879,7 +908,8 @@ static int vicreg_stage_ld(int stage, const float* x, const float* y, long long 
     } else if (use256) {
       const size_t lds = 2 * (size_t)G2_BUF_BYTES;
       (void)hipFuncSetAttribute((const void*)vicreg_gram256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(vicreg_gram256_kernel, dim3(8 * ((ngram + 3) / 4)), dim3(G2_THREADS), lds, stream, xt_x, xt_y,
+      // (q8 = block >> 3 runs over 32 per 128 items: see the kernel's enumeration)
+      hipLaunchKernelGGL(vicreg_gram256_kernel, dim3(8 * 32 * ((ngram + 127) / 128)), dim3(G2_THREADS), lds, stream, xt_x, xt_y,
                          gram_x, gram_y, D, w.Kpad, nt256, ngram);
     } else {
       hipLaunchKernelGGL(vicreg_gram_kernel, dim3(w.ngram, 2), dim3(256), 0, stream, xt_x, xt_y, gram_x, gram_y, D, w.Kpad,
