@@ -588,6 +588,23 @@ template <int NSUB> __device__ __forceinline__ void stft2_load_frame(const float
 // to the persistent render's (147 VGPRs each): step 0.192 / 0.173 / 0.173 / 0.179 ms at 4 / 5 / 6 / 8 (8 spills).
 #define IAS_STFT2_MINW 5
 #endif
+// stft2_kernel's own scratch indexing.  With the first exchange in registers (IAS_S2_REGX) only the pass-2 scatter, ONE set
+// of row reads and the upper-half stores / mirrored reads of the unpack touch the scratch, and the layout search of
+// scripts/diag/lds_exchange_model.py (same lane groups and bank moduli) no longer has to keep the pass-1 scatter clean:
+// rows of 9 complex values with two pad elements per eight in the upper half leave 8 conflict cycles per frame (the
+// mirrored reads) instead of 40 -- the pass-2 scatter, 2-way at rows of 10, is clean, the row reads are eight ds_read_b64
+// instead of four ds_read_b128 (the same LDS cycles).  The other radix-8 kernels keep IAS_S2_ROW = 10 (their pass-1
+// scatter goes through LDS).  The wave's scratch stays 64 x IAS_S2_ROW values (the mel power rows need them).
+#if IAS_S2_REGX
+#define S2X_ROW 9
+#define S2X_PAD 2
+#else
+#define S2X_ROW IAS_S2_ROW
+#define S2X_PAD (IAS_S2_ROW - 8)
+#endif
+#define S2X_AT(row, col) ((row) * S2X_ROW + (col))
+#define S2X_UP(i) ((i) + S2X_PAD * ((i) >> 3))
+static_assert(64 * S2X_ROW <= 64 * IAS_S2_ROW && 256 + S2X_PAD * 32 <= 64 * IAS_S2_ROW, "stft2 scratch indexing fits the wave's scratch");
 template <int SP_WAVES, bool MEL, int LOSS, int NSUB>
 __global__ __launch_bounds__(64 * SP_WAVES, NSUB == 2 ? 3 * SP_WAVES / 8 : (SP_WAVES >= 8 ? (SP_WAVES == 8 ? IAS_STFT2_MINW : SP_WAVES / 2) : (3 * SP_WAVES + 3) / 4))
 void stft2_kernel(const Spec2Args a) {
@@ -713,25 +730,25 @@ void stft2_kernel(const Spec2Args a) {
       {
         const int c = lane & 7, aa = lane >> 3;
 #pragma unroll
-        for (int q = 0; q < R; ++q) sA[IAS_S2_AT(q * 8 + c, aa)] = cmul(v[q], t_tw1[64 * q]);
+        for (int q = 0; q < R; ++q) sA[S2X_AT(q * 8 + c, aa)] = cmul(v[q], t_tw1[64 * q]);
       }
       S2_STAMP(2);
       wave_lds_sync();
       S2_STAMP(3);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) u[q] = sA[IAS_S2_AT(lane, q)];
+      for (int q = 0; q < 8; ++q) u[q] = sA[S2X_AT(lane, q)];
       wave_lds_sync();
       S2_STAMP(4);
 #endif
       // pass 2: radix 8 over a for each (k1, c); twiddle W_64^(c d); scatter (in place) to [k1][d][c]
       dft8(u);
 #pragma unroll
-      for (int d = 0; d < 8; ++d) sA[IAS_S2_AT(k1 * 8 + d, dd)] = cmul(u[d], t_tw2[64 * d]);
+      for (int d = 0; d < 8; ++d) sA[S2X_AT(k1 * 8 + d, dd)] = cmul(u[d], t_tw2[64 * d]);
       S2_STAMP(5);
       wave_lds_sync();
       S2_STAMP(6);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) u[q] = sA[IAS_S2_AT(lane, q)];
+      for (int q = 0; q < 8; ++q) u[q] = sA[S2X_AT(lane, q)];
       wave_lds_sync();
       S2_STAMP(7);
       // pass 3: radix 8 over c for each (k1, d): u[e] = (half-)transform at k1 + 8 d + 64 e
@@ -752,7 +769,7 @@ void stft2_kernel(const Spec2Args a) {
     }
     // the upper half (k >= HALF) goes to LDS at k - HALF (padded per 8 complex values, IAS_S2_UP)
 #pragma unroll
-    for (int e = 0; e < NPK; ++e) { const int i = kl + 64 * e; sA[IAS_S2_UP(i)] = zhi[e]; }
+    for (int e = 0; e < NPK; ++e) { const int i = kl + 64 * e; sA[S2X_UP(i)] = zhi[e]; }
     S2_STAMP(8);
     wave_lds_sync();
     S2_STAMP(9);
@@ -762,7 +779,7 @@ void stft2_kernel(const Spec2Args a) {
     for (int e = 0; e < NPK; ++e) {
       const int k = kl + 64 * e;
       const int i = (HALF - k) & (HALF - 1);                 // k = 0: Z[N2] = Z[0] (own), the read is a dummy
-      cpx zn = sA[IAS_S2_UP(i)];
+      cpx zn = sA[S2X_UP(i)];
       const cpx zk = zlo[e];
       if (e == 0 && k == 0) zn = zk;
       const cpx w = t_twu[64 * e];
