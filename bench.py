@@ -235,7 +235,10 @@ def run_vicreg(args, rank, world, dev):
     elapsed = regions[len(regions) // 2]
     out = [float(v) for v in state["out"]]
 
-    # ---- the Gram kernel alone (stage 1 of ias_vicreg_stage on a filled workspace), HIP events around K launches
+    # ---- the covariance contraction alone (stage 1 of ias_vicreg_stage on a filled workspace), HIP events around K launches.
+    # The product path contracts over the batch where the padded batch <= D (B x B matrix, 2 B^2 D flops: SURVEY 8(d)'s
+    # identity); the feature-side D x D kernels of rounds 1-3 (2 B D^2 flops) are timed next to it under
+    # ias_vicreg_set_form(0), and the whole forward + backward once more in that form: `roofline.dxd`.
     Bg = B * world
     xg = torch.randn(Bg, D, generator=torch.Generator().manual_seed(100)).to(dev)
     yg = torch.randn(Bg, D, generator=torch.Generator().manual_seed(101)).to(dev)
@@ -247,27 +250,72 @@ def run_vicreg(args, rank, world, dev):
         _lib.check(lib.ias_vicreg_stage(k, _lib.ptr(xg), _lib.ptr(yg), _lib.ptr(o4), _lib.ptr(ws), need, Bg, D, Bg, 25.0, 25.0,
                                         1.0, _lib.stream()), "ias_vicreg_stage")
 
-    stage(-1)
-    torch.cuda.synchronize()
-    g2 = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g2):
-        for _ in range(args.steps):
-            stage(1)
-    g2.replay()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    best = 1e9
-    for _ in range(15):      # short bursts (K x ~20 us): the fastest of 15 replays, as `isolated` of the headline's stages
-        e0.record(); g2.replay(); e1.record()
+    def time_graph(fn, reps=15):
+        """-> ms per call of fn: K calls captured into one graph, the fastest of `reps` replays (short bursts)"""
+        fn()
         torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / args.steps)
-    gram_ms = best
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(args.steps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for _ in range(reps):
+            e0.record(); g.replay(); e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / args.steps)
+        return best
+
     kpad = (Bg + 127) // 128 * 128
     ntile = (D + 127) // 128
-    # both branches, the upper triangle at 128 x 128 granularity (the 256 x 256 kernel executes 1.5 % more: not counted)
-    executed = 2.0 * (ntile * (ntile + 1) // 2) * 2.0 * 128 * 128 * kpad
+    batch_side = kpad <= D and os.environ.get("IAS_VICREG_DXD", "0") in ("", "0")
+    stage(-1)
+    gram_ms = time_graph(lambda: stage(1))
+    loss_default = o4.tolist()
     nominal = 2.0 * 2.0 * Bg * D * D                                          # 2 B D^2 per branch (vicreg.py:47-48)
+    # feature side: both branches, the upper triangle at 128 x 128 granularity (the 256 x 256 kernel executes 1.5 % more)
+    executed_dxd = 2.0 * (ntile * (ntile + 1) // 2) * 2.0 * 128 * 128 * kpad
+    dxd_name = ("vicreg_gram_pair_kernel" if kpad == 128 else
+                ("vicreg_gram_kernel (128 x 128 tiles; both branches, one launch)"
+                 if os.environ.get("IAS_VICREG_GRAM128", "0") not in ("", "0") or D < 256 else
+                 "vicreg_gram256_kernel (256 x 256 tiles, LDS-DMA; both branches, one launch)"))
+    dxd = None
+    if batch_side:
+        t256 = kpad > 128 and os.environ.get("IAS_VICREG_GRAM128", "0") in ("", "0")
+        bt = (kpad + 255) // 256 if t256 else kpad // 128
+        tile = 256 if t256 else 128
+        executed = 2.0 * (bt * (bt + 1) // 2) * 2.0 * tile * tile * D         # upper-triangular tiles of Xc Xc^T, both branches
+        kernel = ("vicreg_bgram256_kernel + vicreg_gconv256_kernel" if t256 else "vicreg_bgram_kernel + vicreg_gconv_kernel") + \
+                 " (Xc Xc^T, B x B, in D-slices + the fixed-order fold that also sums its squares)"
+        # the D x D kernels on the same inputs, and the whole step in that form
+        _lib.check(lib.ias_vicreg_set_form(0), "ias_vicreg_set_form")
+        try:
+            need0 = int(lib.ias_vicreg_workspace_bytes(Bg, D))
+            if need0 > need:
+                ws = torch.empty(need0, dtype=torch.uint8, device=dev)
+                need = need0
+            stage(-1)
+            dxd_ms = time_graph(lambda: stage(1))
+            loss_dxd = o4.tolist()
+            step_dxd_ms = None
+            if not gather:
+                step_dxd_ms = time_graph(step, reps=7)
+        finally:
+            _lib.check(lib.ias_vicreg_set_form(-1), "ias_vicreg_set_form")
+        a_dxd = executed_dxd / (dxd_ms * 1e-3) / 1e12
+        dxd = {"kernel": dxd_name, "note": "the feature-side contraction of rounds 1-3 (ias_vicreg_set_form(0)): NOT on the "
+                                           "product path at this shape, timed here for continuity",
+               "avg_launch_ms": round(dxd_ms, 4), "flops_executed": executed_dxd, "achieved": round(a_dxd, 1),
+               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(a_dxd / MFMA_BF16_PEAK_TFLOPS, 4),
+               "traffic": pmc_traffic_of("vicreg_gram_pair_kernel" if kpad == 128 else "vicreg_gram256_kernel"),
+               "step_ms_in_this_form": round(step_dxd_ms, 4) if step_dxd_ms else None,
+               "cov_loss": loss_dxd[3], "cov_loss_batch_side": loss_default[3]}
+    else:
+        executed, kernel = executed_dxd, dxd_name
     achieved = executed / (gram_ms * 1e-3) / 1e12
+    step_bytes = 16.0 * B * D                                                 # read x, y; write gx, gy (fp32), per rank
     result = {
         "metric": "VICReg.loss forward+backward, embeddings [B, 8192] per GPU (BASELINE configs[2]; N>1: configs[3] with "
                   "the FullGatherLayer all-gather / reduce-scatter over RCCL)",
@@ -281,16 +329,18 @@ def run_vicreg(args, rank, world, dev):
                    "collective": "all_gather_into_tensor fwd + reduce_scatter_tensor bwd (RCCL)" if gather else None,
                    "rccl_world_size": dist.get_world_size() if gather else 1,
                    "loss": out[0], "repr_loss": out[1], "std_loss": out[2], "cov_loss": out[3]},
-        "roofline": {"kernel": "vicreg_gram_pair_kernel" if kpad == 128 else
-                               ("vicreg_gram_kernel (128 x 128 tiles; both branches, one launch)"
-                                if os.environ.get("IAS_VICREG_GRAM128", "0") not in ("", "0") or D < 256 else
-                                "vicreg_gram256_kernel (256 x 256 tiles, LDS-DMA; both branches, one launch)"),
+        "roofline": {"kernel": kernel, "form": "batch side (B x B)" if batch_side else "feature side (D x D)",
                      "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                     "traffic": pmc_traffic_of("vicreg_gram_pair_kernel" if kpad == 128 else "vicreg_gram256_kernel"),
+                     "traffic": None if batch_side else pmc_traffic_of("vicreg_gram_pair_kernel" if kpad == 128 else "vicreg_gram256_kernel"),
                      "avg_launch_ms": round(gram_ms, 4), "flops_executed": executed, "flops_nominal_2BD2_per_branch_x2": nominal,
-                     "frac_nominal": round(nominal / (gram_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                     "measured": "HIP events around K back-to-back launches of stage 1 (the Gram) on the global batch"},
+                     "frac_nominal": None if batch_side else round(nominal / (gram_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "step_hbm": {"algorithmic_bytes_per_step": step_bytes, "what": "x, y read, gx, gy written (fp32), per rank",
+                                  "achieved_GBps": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
+                                  "frac": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+                     "dxd": dxd,
+                     "measured": "HIP events around K back-to-back launches of stage 1 (the covariance contraction) on the "
+                                 "global batch, fastest of 15 replays"},
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = vicreg_cpu_baseline(B, D)
@@ -313,8 +363,9 @@ def secondary_legs(args, dev):
                    "timed_regions": r["timed_regions"], "value": r["value"], "unit": r["unit"],
                    "workload": r["config"]["workload"], "launch": r["config"]["launch"]}
             rf = r["roofline"]
-            leg["roofline"] = {k: rf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
-                                                  "frac_nominal", "flops_executed", "algorithmic_bytes_per_step") if k in rf}
+            leg["roofline"] = {k: rf[k] for k in ("kernel", "form", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
+                                                  "frac_nominal", "flops_executed", "algorithmic_bytes_per_step", "step_hbm",
+                                                  "dxd") if k in rf}
         except Exception as e:  # noqa: BLE001 -- a failing leg must not take the headline line down
             leg = {"error": f"{type(e).__name__}: {e}"}
         leg["wall_s"] = round(time.perf_counter() - t0, 2)

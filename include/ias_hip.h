@@ -335,6 +335,14 @@ int ias_vicreg_backward_ld(const float* x, const float* y, long long ld, const f
 int ias_vicreg_stage(int stage, const float* x, const float* y, float* out, void* workspace, long long workspace_bytes,
                      int B, int D, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff, void* stream);
 
+/* Which side the covariance term (vicreg.py:47-51) is contracted on.  sum_{i != j} cov_ij^2 over the D x D matrix
+ * cov = Xc^T Xc / (n - 1) equals (||Xc Xc^T||_F^2 - sum_j (Xc^T Xc)_jj^2) / (n - 1)^2: the B x B matrix Xc Xc^T costs
+ * 2 B^2 D flops instead of 2 B D^2 (64x fewer at the reference's B = 128, D = 8192) and is the matrix the backward
+ * needs anyway.  form 1: batch side wherever the padded batch (multiple of 128) <= D and D % 8 == 0; 0: always the
+ * D x D kernels; -1 (default): 1 unless the environment has IAS_VICREG_DXD=1.  Process-wide; forward and backward of one
+ * loss must run under the same setting (the batch-side forward leaves the B x B matrix in the workspace for the backward). */
+int ias_vicreg_set_form(int form);
+
 /* ---- AudioEmbedding trunk: the depthwise convolutions and the stem of torchvision's mobilenet_v3_small.features
  * (reference vicreg_audio_params.py:52-54, audioembed.py:61), NCHW fp32, padding (K-1)/2, no bias.
  * K in {3, 5}, stride S in {1, 2}.  ias_conv_out_size: output extent of one spatial dimension. */

@@ -91,6 +91,7 @@ SYMBOLS = {
     "ias_vicreg_loss_ld": (_I, [_P, _P, _LL, _P, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
     "ias_vicreg_backward_ld": (_I, [_P, _P, _LL, _P, _P, _P, _LL, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
     "ias_vicreg_stage": (_I, [_I, _P, _P, _P, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
+    "ias_vicreg_set_form": (_I, [_I]),
     "ias_conv_out_size": (_I, [_I, _I, _I]),
     "ias_dwconv_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ias_dwconv_backward_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -43,10 +43,11 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
     const float* __restrict__ x, const float* __restrict__ y, unsigned short* __restrict__ Xt_x,
     unsigned short* __restrict__ Xt_y, float* __restrict__ colstats, double* __restrict__ msepart,
-    double* __restrict__ hingepart, unsigned short* __restrict__ Xc_x, unsigned short* __restrict__ Xc_y, int B, int D,
-    int Kpad, size_t ld /* row stride of x and y in floats (>= D: x, y may be column blocks of a wider matrix) */) {
+    double* __restrict__ hingepart, double* __restrict__ diagpart, unsigned short* __restrict__ Xc_x,
+    unsigned short* __restrict__ Xc_y, int B, int D, int Kpad,
+    size_t ld /* row stride of x and y in floats (>= D: x, y may be column blocks of a wider matrix) */) {
   constexpr int NW = VC_THREADS / 64, RPI = 2 * NW;              // rows per iteration of the workgroup
-  __shared__ float s_red[4][NW][64];
+  __shared__ float s_red[6][NW][64];
   __shared__ float s_mean[2][VC_COLS];
   __shared__ unsigned short s_tile[2][VC_COLS][64 + 2];
   __shared__ double s_mse[NW];
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
   const float mx = s_mean[0][col], my = s_mean[1][col];
 
   // pass 2: centred sum of squares + bf16 transpose, 64 rows at a time
-  float qx = 0.f, qy = 0.f;
+  float qx = 0.f, qy = 0.f, rx = 0.f, ry = 0.f;                 // (r*: the same sums over the bf16-ROUNDED values)
   for (int b0 = 0; b0 < Kpad; b0 += 64) {
     for (int r = 2 * wave + rsub; r < 64; r += RPI) {
       const int b = b0 + r;
@@ -100,6 +101,9 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
         qy = fmaf(cy, cy, qy);
       }
       const unsigned short bx = f2bf(cx), by = f2bf(cy);
+      const float fx = __uint_as_float((unsigned)bx << 16), fy = __uint_as_float((unsigned)by << 16);
+      rx = fmaf(fx, fx, rx);
+      ry = fmaf(fy, fy, ry);
       s_tile[0][col][r] = bx;
       s_tile[1][col][r] = by;
       // the same values batch-major, Xc[Kpad][D] (zero rows beyond B): the backward's B x B Gram contracts over D
@@ -126,13 +130,16 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
     __syncthreads();
   }
   s_red[2][wave][lane] = qx; s_red[3][wave][lane] = qy;
+  s_red[4][wave][lane] = rx; s_red[5][wave][lane] = ry;
   __syncthreads();
   const bool fin = wave == 0 && lane < VC_COLS && j0 + lane < D;
-  float ax = 0.f, ay = 0.f;
+  float ax = 0.f, ay = 0.f, tx = 0.f, ty = 0.f;
   if (fin) {
     for (int w = 0; w < NW; ++w) {
       ax += s_red[2][w][lane]; ax += s_red[2][w][lane + 32];
       ay += s_red[3][w][lane]; ay += s_red[3][w][lane + 32];
+      tx += s_red[4][w][lane]; tx += s_red[4][w][lane + 32];
+      ty += s_red[5][w][lane]; ty += s_red[5][w][lane + 32];
     }
     colstats[0 * (size_t)D + j0 + lane] = s_mean[0][lane];
     colstats[1 * (size_t)D + j0 + lane] = s_mean[1][lane];
@@ -148,6 +155,11 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
     }
     for (int d = 32; d > 0; d >>= 1) h += __shfl_xor(h, d, 64);
     if (lane == 0) hingepart[blockIdx.x] = (double)h;
+    // the diagonal of the D x D Gram of the ROUNDED matrices, squared and summed: what the batch-side form of the
+    // covariance term (vicreg_stage_ld) takes off ||Xc Xc^T||_F^2
+    double dg = (double)tx * (double)tx + (double)ty * (double)ty;
+    for (int d = 32; d > 0; d >>= 1) dg += __shfl_xor(dg, d, 64);
+    if (lane == 0) diagpart[blockIdx.x] = dg;
   }
 }
 
@@ -787,13 +799,16 @@ __global__ __launch_bounds__(G2_THREADS, 2) void vicreg_gram256_kernel(const uns
 __global__ __launch_bounds__(256) void vicreg_finish_kernel(const double* __restrict__ hingepart,
                                                             const double* __restrict__ msepart, int nmse,
                                                             const double* __restrict__ gram_x,
-                                                            const double* __restrict__ gram_y, int ngram, int B, int D,
-                                                            int cfg_batch, float sim_coeff, float std_coeff,
+                                                            const double* __restrict__ gram_y, int ngram,
+                                                            const double* __restrict__ diagpart /* batch-side form: [nmse], else null */,
+                                                            int B, int D, int cfg_batch, float sim_coeff, float std_coeff,
                                                             float cov_coeff, float* __restrict__ out) {
   __shared__ double s[256][4];
   double mse = 0.0, hinge = 0.0, gx = 0.0, gy = 0.0;
   for (int i = threadIdx.x; i < nmse; i += 256) mse += msepart[i];
-  for (int i = threadIdx.x; i < ngram; i += 256) { gx += gram_x[i]; gy += gram_y[i]; }
+  for (int i = threadIdx.x; i < ngram; i += 256) { gx += gram_x[i]; if (gram_y) gy += gram_y[i]; }
+  if (diagpart)                                                  // gram_x holds sum G_ab^2 = sum over ALL of C: take C's diagonal off
+    for (int i = threadIdx.x; i < nmse; i += 256) gy -= diagpart[i];
   for (int i = threadIdx.x; i < nmse; i += 256) hinge += hingepart[i];
   s[threadIdx.x][0] = mse; s[threadIdx.x][1] = hinge; s[threadIdx.x][2] = gx; s[threadIdx.x][3] = gy;
   __syncthreads();
@@ -816,12 +831,30 @@ __global__ __launch_bounds__(256) void vicreg_finish_kernel(const double* __rest
 
 // ------------------------------------------------------------------------ C ABI
 static inline size_t vc_align(size_t x) { return (x + 255) / 256 * 256; }
-struct VicregWs { size_t xt_x, xt_y, colstats, mse, hinge, gram_x, gram_y, xc_x, xc_y, bgram, bgram16, gdiag, total; int Kpad, ntile, ngram, nmse, nsplit, ksplit; bool t256; };
+struct VicregWs { size_t xt_x, xt_y, colstats, mse, hinge, diag, gram_x, gram_y, xc_x, xc_y, bgram, bgram16, gdiag, g2part, total; int Kpad, ntile, ngram, nmse, nsplit, ksplit, ng2; bool t256, b256, dual; };
 // IAS_VICREG_GRAM128=1 (diagnostics): the 128 x 128 register-staged kernels of round 2 for batch > 128 as well
 static bool vicreg_force128() {
   static const bool v = getenv("IAS_VICREG_GRAM128") != nullptr && atoi(getenv("IAS_VICREG_GRAM128")) != 0;
   return v;
 }
+// The covariance term from the batch side.  sum_{i != j} C_ij^2 with C = Xc^T Xc (D x D) equals ||G||_F^2 - sum_j C_jj^2
+// with G = Xc Xc^T (B x B): the same number from 2 B^2 D flops instead of 2 B D^2, and G is what the backward needs
+// anyway (G vc).  Taken whenever the padded batch is no larger than the embedding (B = 128 / 1024 against D = 8192: 64x /
+// 8x fewer flops); the feature-side kernels stay for batch > D.  No cancellation on this side of the switch: C has rank
+// < B, so ||C||_F^2 >= (tr C)^2 / (B - 1) >= D / (B - 1) times its diagonal's share.
+// ias_vicreg_set_form(0 / 1 / -1): feature side always / batch side where it applies / default (env IAS_VICREG_DXD=1 -> 0).
+static int g_vicreg_form = -1;
+extern "C" int ias_vicreg_set_form(int form) {
+  if (form < -1 || form > 1) return IAS_ERR_ARG;
+  g_vicreg_form = form;
+  return IAS_OK;
+}
+static bool vicreg_batch_side(int Kpad, int D) {
+  static const bool env_dxd = getenv("IAS_VICREG_DXD") != nullptr && atoi(getenv("IAS_VICREG_DXD")) != 0;
+  const bool want = g_vicreg_form < 0 ? !env_dxd : g_vicreg_form == 1;
+  return want && D >= 8 && (D & 7) == 0 && Kpad <= D;
+}
+
 static VicregWs vicreg_ws(int B, int D) {
   VicregWs w;
   w.Kpad = (B + GT - 1) / GT * GT;   // multiple of 128: the pair kernel's depth, the backward's batch tiles (zero padded)
@@ -834,6 +867,7 @@ static VicregWs vicreg_ws(int B, int D) {
   w.colstats = o; o = vc_align(o + sizeof(float) * 4 * (size_t)D);
   w.mse = o;      o = vc_align(o + sizeof(double) * w.nmse);
   w.hinge = o;    o = vc_align(o + sizeof(double) * w.nmse);
+  w.diag = o;     o = vc_align(o + sizeof(double) * w.nmse);
   w.gram_x = o;   o = vc_align(o + sizeof(double) * w.ngram);
   w.gram_y = o;   o = vc_align(o + sizeof(double) * w.ngram);
   // backward: centred bf16 copies batch-major [Kpad][D], and the two B x B Grams [2][Kpad][Kpad] fp32
@@ -843,8 +877,10 @@ static VicregWs vicreg_ws(int B, int D) {
   // slice writing its own partial Gram [nsplit][2][Kpad][Kpad]; vicreg_gconv_kernel adds them in slice order
   // batch > 128: the 256 x 256 LDS-DMA kernels (forward Gram; backward when D is a multiple of the 64-deep K-tile)
   w.t256 = w.Kpad > 128 && !vicreg_force128() && D >= 256 && (unsigned long long)D * (unsigned long long)w.Kpad < (1ull << 31);
+  w.dual = vicreg_batch_side(w.Kpad, D);
   {
     const bool b256 = w.t256 && D % 64 == 0;
+    w.b256 = b256;
     const int bt = b256 ? (w.Kpad + 255) / 256 : w.Kpad / GT, npair = bt * (bt + 1) / 2;
     int nsplit = (b256 ? 256 : 512) / (2 * npair);      // one resident round: 1 (256 tiles) / 2 (128 tiles) workgroups per CU
     if (nsplit < 1) nsplit = 1;
@@ -855,6 +891,13 @@ static VicregWs vicreg_ws(int B, int D) {
   w.bgram = o;    o = vc_align(o + sizeof(float) * 2 * (size_t)w.Kpad * w.Kpad * w.nsplit);
   w.bgram16 = o;  o = vc_align(o + sizeof(unsigned short) * 2 * (size_t)w.Kpad * w.Kpad);
   w.gdiag = o;    o = vc_align(o + sizeof(float) * 2 * (size_t)w.Kpad);
+  {                                                              // partial sums of G_ab^2, one or two per fold workgroup
+    const int bt2 = (w.Kpad + 255) / 256;
+    size_t cgrid = (2 * (size_t)w.Kpad * w.Kpad + 255) / 256;
+    if (cgrid > 2048) cgrid = 2048;
+    w.ng2 = w.b256 ? 2 * 16 * (bt2 * (bt2 + 1) / 2) : 2 * (int)cgrid;
+  }
+  w.g2part = o;   o = vc_align(o + sizeof(double) * (size_t)w.ng2);
   w.total = o;
   return w;
 }
@@ -870,6 +913,8 @@ extern "C" long long ias_vicreg_workspace_bytes(int B, int D) {
 // stage < 0: the whole loss; 0: column pass (means, centred bf16 transposes, MSE / hinge partials); 1: the Gram
 // kernel(s) on the matrix cores; 2: the final reduction.  Stages run on a workspace the earlier stages have filled
 // (bench.py times stage 1 alone with HIP events for the MFMA roofline).
+static void vicreg_launch_batch_gram(const VicregWs& w, char* ws, int D, hipStream_t stream, bool squares);
+
 static int vicreg_stage_ld(int stage, const float* x, const float* y, long long ld, float* out, void* workspace,
                            long long workspace_bytes, int B, int D, int cfg_batch, float sim_coeff, float std_coeff,
                            float cov_coeff, void* stream_) {
@@ -887,7 +932,18 @@ static int vicreg_stage_ld(int stage, const float* x, const float* y, long long 
   double* gram_y = (double*)(ws + w.gram_y);
   if (stage < 0 || stage == 0)
     hipLaunchKernelGGL(vicreg_colstats_kernel, dim3(w.nmse), dim3(VC_THREADS), 0, stream, x, y, xt_x, xt_y, colstats,
-                       mse, hinge, (unsigned short*)(ws + w.xc_x), (unsigned short*)(ws + w.xc_y), B, D, w.Kpad, (size_t)ld);
+                       mse, hinge, (double*)(ws + w.diag), (unsigned short*)(ws + w.xc_x), (unsigned short*)(ws + w.xc_y), B, D,
+                       w.Kpad, (size_t)ld);
+  if (w.dual) {
+    // batch side: G = Xc Xc^T in D-slices, folded (and squared, summed) in slice order; the backward finds G in place
+    if (w.Kpad % GT) return IAS_ERR_UNSUPPORTED;
+    if (stage < 0 || stage == 1) vicreg_launch_batch_gram(w, ws, D, stream, true);
+    if (stage < 0 || stage == 2)
+      hipLaunchKernelGGL(vicreg_finish_kernel, dim3(1), dim3(256), 0, stream, hinge, mse, w.nmse, (const double*)(ws + w.g2part),
+                         (const double*)nullptr, w.ng2, (const double*)(ws + w.diag), B, D, cfg_batch, sim_coeff, std_coeff,
+                         cov_coeff, out);
+    return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+  }
   int ngram = w.ngram;
   int nitems = 0;
   // deep contractions: 256 x 256 tiles
@@ -918,7 +974,7 @@ static int vicreg_stage_ld(int stage, const float* x, const float* y, long long 
   }
   if (stage < 0 || stage == 2)
     hipLaunchKernelGGL(vicreg_finish_kernel, dim3(1), dim3(256), 0, stream, hinge, mse, w.nmse, gram_x, gram_y,
-                       ngram, B, D, cfg_batch, sim_coeff, std_coeff, cov_coeff, out);
+                       ngram, (const double*)nullptr, B, D, cfg_batch, sim_coeff, std_coeff, cov_coeff, out);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
@@ -1063,8 +1119,11 @@ __global__ __launch_bounds__(256, 2) void vicreg_bgram_kernel(const unsigned sho
 // carry its bf16 rounding (2^-9) straight into the dominant term G_bb vc_bj of the gradient; the epilogue of
 // vicreg_grad_kernel adds that term in fp32 instead.
 __global__ __launch_bounds__(256) void vicreg_gconv_kernel(const float* __restrict__ Gp, unsigned short* __restrict__ Gb,
-                                                           float* __restrict__ gdiag, int Kpad, int nsplit) {
+                                                           float* __restrict__ gdiag, int Kpad, int nsplit,
+                                                           double* __restrict__ g2part /* [gridDim.x][2] or null */) {
+  __shared__ double s_sq[4][2];
   const size_t n = (size_t)2 * Kpad * Kpad;
+  double sq[2] = {0.0, 0.0};                                      // sum of G_ab^2 per branch (the diagonal included)
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const size_t q = i / ((size_t)Kpad * Kpad), rem = i - q * (size_t)Kpad * Kpad;
     const int row = (int)(rem / Kpad), col = (int)(rem - (size_t)row * Kpad);
@@ -1076,8 +1135,20 @@ __global__ __launch_bounds__(256) void vicreg_gconv_kernel(const float* __restri
 #pragma unroll
       for (int u = 0; u < 8; ++u) v += a[u];
     }
+    sq[q] += (double)v * (double)v;
     if (row == col) gdiag[q * Kpad + row] = v;
     Gb[i] = f2bf(row == col ? 0.0f : v);
+  }
+  if (g2part) {                                                  // fixed order: lanes (butterfly), then waves
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      for (int d = 32; d > 0; d >>= 1) sq[k] += __shfl_xor(sq[k], d, 64);
+      if ((threadIdx.x & 63) == 0) s_sq[threadIdx.x >> 6][k] = sq[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2)
+      g2part[2 * (size_t)blockIdx.x + threadIdx.x] =
+          ((s_sq[0][threadIdx.x] + s_sq[1][threadIdx.x]) + s_sq[2][threadIdx.x]) + s_sq[3][threadIdx.x];
   }
 }
 
@@ -1189,15 +1260,21 @@ __global__ __launch_bounds__(G2_THREADS, 2) void vicreg_bgram256_kernel(const un
 // vicreg_bgram256_kernel wrote; one 64 x 64 block per workgroup: bf16 with the diagonal taken out (gdiag, see
 // vicreg_gconv_kernel), written in place and -- off the diagonal tiles -- mirrored through an LDS transpose.
 __global__ __launch_bounds__(256) void vicreg_gconv256_kernel(const float* __restrict__ Gp, unsigned short* __restrict__ Gb,
-                                                              float* __restrict__ gdiag, int Kpad, int nsplit, int nt) {
+                                                              float* __restrict__ gdiag, int Kpad, int nsplit, int nt,
+                                                              double* __restrict__ g2part /* [2][gridDim.x] or null */) {
   __shared__ float s_t[64][65];
+  __shared__ double s_sq[4];
   int ti, tj;
   g2_tri_item(blockIdx.x >> 4, nt, ti, tj);
   const int sub = blockIdx.x & 15, branch = blockIdx.y;
   const int r0 = ti * G2_T + (sub >> 2) * 64, c0 = tj * G2_T + (sub & 3) * 64;
-  if (r0 >= Kpad || c0 >= Kpad) return;                          // Kpad % 64 == 0: a block is inside or outside
+  if (r0 >= Kpad || c0 >= Kpad) {                                // Kpad % 64 == 0: a block is inside or outside
+    if (g2part && threadIdx.x == 0) g2part[(size_t)branch * gridDim.x + blockIdx.x] = 0.0;
+    return;
+  }
   const size_t plane = (size_t)Kpad * Kpad, n2 = 2 * plane;
   const int tid = threadIdx.x, cc = tid & 63;
+  double sq = 0.0;                                               // sum of G_ab^2 over the block (the diagonal included)
   for (int rr = tid >> 6; rr < 64; rr += 4) {
     const int row = r0 + rr, col = c0 + cc;
     const size_t i = (size_t)branch * plane + (size_t)row * Kpad + col;
@@ -1209,12 +1286,19 @@ __global__ __launch_bounds__(256) void vicreg_gconv256_kernel(const float* __res
 #pragma unroll
       for (int u = 0; u < 8; ++u) v += a[u];
     }
+    sq += (double)v * (double)v;
     if (row == col) { gdiag[(size_t)branch * Kpad + row] = v; v = 0.0f; }
     Gb[i] = f2bf(v);
     s_t[rr][cc] = v;
   }
-  if (ti == tj) return;
+  if (g2part) {
+    for (int d = 32; d > 0; d >>= 1) sq += __shfl_xor(sq, d, 64);
+    if ((tid & 63) == 0) s_sq[tid >> 6] = sq;
+  }
   __syncthreads();
+  if (g2part && tid == 0)                                        // tiles above the diagonal stand for their mirror image too
+    g2part[(size_t)branch * gridDim.x + blockIdx.x] = (ti == tj ? 1.0 : 2.0) * (((s_sq[0] + s_sq[1]) + s_sq[2]) + s_sq[3]);
+  if (ti == tj) return;
   for (int rr = tid >> 6; rr < 64; rr += 4)                      // row c0 + rr of the mirror image, columns r0 + cc
     Gb[(size_t)branch * plane + (size_t)(c0 + rr) * Kpad + r0 + cc] = f2bf(s_t[cc][rr]);
 }
@@ -1303,8 +1387,31 @@ __global__ __launch_bounds__(G2_THREADS, 2) void vicreg_grad256_kernel(
   }
 }
 
+// G = Xc Xc^T for both branches: partial Grams per D-slice [nsplit][2][Kpad][Kpad] (every word written), folded in slice
+// order to bf16 (diagonal apart, fp32); `squares`: the fold also leaves the partial sums of G_ab^2 at w.g2part.
+static void vicreg_launch_batch_gram(const VicregWs& w, char* ws, int D, hipStream_t stream, bool squares) {
+  float* G = (float*)(ws + w.bgram);
+  const int bt = w.Kpad / GT, npair = bt * (bt + 1) / 2;
+  const size_t lds256 = 2 * (size_t)G2_BUF_BYTES;
+  const int bt2 = (w.Kpad + G2_T - 1) / G2_T;
+  unsigned short* Gb = (unsigned short*)(ws + w.bgram16);
+  float* gdiag = (float*)(ws + w.gdiag);
+  double* g2part = squares ? (double*)(ws + w.g2part) : nullptr;
+  if (w.b256) {
+    (void)hipFuncSetAttribute((const void*)vicreg_bgram256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+    hipLaunchKernelGGL(vicreg_bgram256_kernel, dim3(bt2 * (bt2 + 1) / 2, w.nsplit, 2), dim3(G2_THREADS), lds256, stream,
+                       (const unsigned short*)(ws + w.xc_x), (const unsigned short*)(ws + w.xc_y), G, D, w.Kpad, bt2, w.ksplit);
+    hipLaunchKernelGGL(vicreg_gconv256_kernel, dim3(16 * (bt2 * (bt2 + 1) / 2), 2), dim3(256), 0, stream, G, Gb, gdiag, w.Kpad,
+                       w.nsplit, bt2, g2part);
+  } else {
+    hipLaunchKernelGGL(vicreg_bgram_kernel, dim3(npair, w.nsplit, 2), dim3(256), 0, stream, (const unsigned short*)(ws + w.xc_x),
+                       (const unsigned short*)(ws + w.xc_y), G, D, w.Kpad, bt, w.ksplit);
+    hipLaunchKernelGGL(vicreg_gconv_kernel, dim3(w.ng2 / 2), dim3(256), 0, stream, G, Gb, gdiag, w.Kpad, w.nsplit, g2part);
+  }
+}
+
 // Backward of ias_vicreg_loss on the SAME workspace (it must still hold the forward's column statistics and centred
-// bf16 copies): gcoef [4] device floats = the cotangents of (loss, repr_loss, std_loss, cov_loss) -> gx, gy [B,D] fp32.
+// bf16 copies -- and, after a batch-side forward, G): gcoef [4] device floats = the cotangents of (loss, repr_loss, std_loss, cov_loss) -> gx, gy [B,D] fp32.
 static int vicreg_backward_ld(const float* x, const float* y, long long ld, const float* gcoef, float* gx, float* gy,
                               long long ldg, void* workspace, long long workspace_bytes, int B, int D, int cfg_batch,
                               float sim_coeff, float std_coeff, float cov_coeff, void* stream_) {
@@ -1316,30 +1423,14 @@ static int vicreg_backward_ld(const float* x, const float* y, long long ld, cons
   const VicregWs w = vicreg_ws(B, D);
   if ((size_t)workspace_bytes < w.total) return IAS_ERR_WORKSPACE;
   char* ws = (char*)workspace;
-  float* G = (float*)(ws + w.bgram);                // [nsplit][2][Kpad][Kpad] partial Grams, every word written
   const int bt = w.Kpad / GT;
   if (w.Kpad % GT) return IAS_ERR_UNSUPPORTED;
-  const int npair = bt * (bt + 1) / 2;
-  const bool b256 = w.t256 && D % 64 == 0;
+  const bool b256 = w.b256;
   const size_t lds256 = 2 * (size_t)G2_BUF_BYTES;
   const int bt2 = (w.Kpad + G2_T - 1) / G2_T;
-  if (b256) {
-    (void)hipFuncSetAttribute((const void*)vicreg_bgram256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-    hipLaunchKernelGGL(vicreg_bgram256_kernel, dim3(bt2 * (bt2 + 1) / 2, w.nsplit, 2), dim3(G2_THREADS), lds256, stream,
-                       (const unsigned short*)(ws + w.xc_x), (const unsigned short*)(ws + w.xc_y), G, D, w.Kpad, bt2, w.ksplit);
-  } else {
-    hipLaunchKernelGGL(vicreg_bgram_kernel, dim3(npair, w.nsplit, 2), dim3(256), 0, stream, (const unsigned short*)(ws + w.xc_x),
-                       (const unsigned short*)(ws + w.xc_y), G, D, w.Kpad, bt, w.ksplit);
-  }
+  if (!w.dual) vicreg_launch_batch_gram(w, ws, D, stream, false);   // (batch-side forward: G and its diagonal are in place)
   unsigned short* Gb = (unsigned short*)(ws + w.bgram16);
   float* gdiag = (float*)(ws + w.gdiag);
-  int cgrid = (int)((2 * (size_t)w.Kpad * w.Kpad + 255) / 256);
-  if (cgrid > 2048) cgrid = 2048;
-  if (b256)
-    hipLaunchKernelGGL(vicreg_gconv256_kernel, dim3(16 * (bt2 * (bt2 + 1) / 2), 2), dim3(256), 0, stream, G, Gb, gdiag, w.Kpad,
-                       w.nsplit, bt2);
-  else
-    hipLaunchKernelGGL(vicreg_gconv_kernel, dim3(cgrid), dim3(256), 0, stream, G, Gb, gdiag, w.Kpad, w.nsplit);
   if (b256) {
     (void)hipFuncSetAttribute((const void*)vicreg_grad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
     hipLaunchKernelGGL(vicreg_grad256_kernel, dim3((D + G2_T - 1) / G2_T, bt2, 2), dim3(G2_THREADS), lds256, stream, x, y,

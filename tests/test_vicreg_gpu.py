@@ -140,3 +140,50 @@ def test_backward_is_bit_reproducible(lib, dev, B, D):
         grads.append(torch.autograd.grad(out[0], (x, y)))
     for g in grads[1:]:
         assert torch.equal(g[0], grads[0][0]) and torch.equal(g[1], grads[0][1])
+
+
+@pytest.fixture
+def both_forms(lib):
+    """ias_vicreg_set_form is process-wide: put the default back whatever the test does."""
+    yield lib.ias_vicreg_set_form
+    lib.ias_vicreg_set_form(-1)
+
+
+def _whitened(B, D, seed):
+    """Columns as decorrelated as a rank-(B-1) matrix allows: orthonormal rows scaled to unit column variance (the case
+    in which the D x D matrix's diagonal is as large a share of ||C||_F^2 as it can be)."""
+    g = torch.Generator().manual_seed(seed)
+    q, _ = torch.linalg.qr(torch.randn(D, B, generator=g, dtype=torch.float64))
+    x = q.t().contiguous()
+    x = x - x.mean(0, keepdim=True)
+    return (x / x.std(0, keepdim=True).clamp_min(1e-6)).float()
+
+
+@pytest.mark.parametrize("B,D,cfgB,kind", [(128, 8192, 128, "randn"), (1024, 8192, 1024, "randn"), (128, 128, 128, "randn"),
+                                           (120, 128, 120, "white"), (128, 8192, 128, "white"), (17, 136, 17, "randn"),
+                                           (200, 512, 64, "randn"), (256, 256, 256, "white"), (300, 1032, 300, "randn")])
+def test_batch_side_and_feature_side_forms_agree(lib, dev, both_forms, B, D, cfgB, kind):
+    """The covariance term contracted over the batch (B x B matrix, the default where the padded batch <= D) and over
+    the features (D x D, the reference's literal order, vicreg.py:47-51): same loss and same gradient, and both against
+    the oracle.  Also checks that the backward after a batch-side forward (which reuses the forward's matrix) equals the
+    backward after a feature-side forward (which builds it)."""
+    from inverse_audio_synthesis_amd.vicreg import vicreg_loss
+    if kind == "white":
+        x0, y0 = _whitened(B, D, 3), _whitened(B, D, 4) * 0.9
+    else:
+        x0, y0 = randn((B, D), 11) * 0.9 + 0.1, randn((B, D), 12) * 1.2
+    big = D > 2048                                                  # (fp64 D x D on the host only where it is cheap)
+    ref = [float(o) for o in (vo.loss(x0, y0, cfgB, D) if big else vo.loss(x0.double(), y0.double(), cfgB, D))]
+    res = {}
+    for form in (0, 1):
+        assert both_forms(form) == 0
+        xd, yd = x0.to(dev).requires_grad_(), y0.to(dev).requires_grad_()
+        out = vicreg_loss(xd, yd, cfgB)
+        out[0].backward()
+        res[form] = ([float(o.detach()) for o in out], xd.grad.cpu(), yd.grad.cpu())
+        _check(res[form][0], ref)
+    for k in range(4):
+        assert abs(res[0][0][k] - res[1][0][k]) <= 1e-4 * abs(ref[k]) + 1e-12, (k, res[0][0], res[1][0])
+    for a, b in ((res[0][1], res[1][1]), (res[0][2], res[1][2])):
+        assert torch.equal(a, b)                 # the same B x B matrix either way: the gradient is bit-equal
+    print(f"cov_loss: oracle {ref[3]:.6e}  D x D {res[0][0][3]:.6e}  B x B {res[1][0][3]:.6e}")
