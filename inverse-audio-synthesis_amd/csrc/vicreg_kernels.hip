@@ -1208,6 +1208,116 @@ __global__ __launch_bounds__(256, 2) void vicreg_grad_kernel(
   }
 }
 
+// ---- batch <= 128 (BASELINE configs[2]): both branches of a 128 (batch) x 64 (features) tile in one workgroup ---------
+// The whole contraction (K = 128) fits in LDS at once: G_x, G_y (2 x 32 KB bf16) and the two 64 x 128 slabs of Xt are
+// loaded with 16-byte accesses, one barrier, 16 MFMAs per wave (8 waves: 4 row blocks x 2 column blocks, both branches),
+// then the two accumulator tiles go through LDS so that the elementwise epilogue reads x and y ONCE for both branches
+// and moves 16 bytes per access (256-byte row segments).  vicreg_grad_kernel (one branch per workgroup, 4-byte accesses
+// to x, y read twice) took 27 us at B = 128, D = 8192; it stays as the fallback for unaligned views.
+#define G1_COLS 64
+#define G1_LDK 136        // bf16 row stride of the staged operands (272 B)
+#define G1_LDC 72         // fp32 row stride of the staged result (4 rows apart = 32 banks apart: the two lane halves)
+#define G1_LDS_BYTES ((2 * 128 + 2 * G1_COLS) * G1_LDK * 2)
+static_assert(2 * 128 * G1_LDC * 4 <= G1_LDS_BYTES, "the result tiles overlay the operands");
+__global__ __launch_bounds__(512) void vicreg_grad128_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const unsigned short* __restrict__ Xt_x,
+    const unsigned short* __restrict__ Xt_y, const unsigned short* __restrict__ Gb, const float* __restrict__ gdiag,
+    const float* __restrict__ colstats, const float* __restrict__ gcoef, float* __restrict__ gx, float* __restrict__ gy,
+    int B, int D, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff, size_t ld, size_t ldg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_g1[];
+  unsigned short (*s_a)[128][G1_LDK] = reinterpret_cast<unsigned short (*)[128][G1_LDK]>(s_g1);
+  unsigned short (*s_b)[G1_COLS][G1_LDK] =
+      reinterpret_cast<unsigned short (*)[G1_COLS][G1_LDK]>(s_g1 + 2 * 128 * G1_LDK * 2);
+  float (*s_c)[128][G1_LDC] = reinterpret_cast<float (*)[128][G1_LDC]>(s_g1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j0 = blockIdx.x * G1_COLS;
+  // ---- operands -> LDS (rows of 128 bf16 = 16 chunks of 16 bytes)
+  {
+    const int ch = tid & 15, r0 = tid >> 4;                      // 32 rows per pass
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = r0 + 32 * i;
+        *reinterpret_cast<uint4*>(&s_a[br][row][ch * 8]) =
+            *reinterpret_cast<const uint4*>(Gb + ((size_t)br * 128 + row) * 128 + ch * 8);
+      }
+      const unsigned short* Xt = br ? Xt_y : Xt_x;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = r0 + 32 * i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (j0 + row < D) v = *reinterpret_cast<const uint4*>(Xt + (size_t)(j0 + row) * 128 + ch * 8);
+        *reinterpret_cast<uint4*>(&s_b[br][row][ch * 8]) = v;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- (G - diag) vc, both branches: wave -> rows 32 (wave & 3), columns 32 (wave >> 2)
+  const int wr = wave & 3, wc = wave >> 2, r = lane & 31, h = lane >> 5;
+  f32x16 acc[2];
+#pragma unroll
+  for (int br = 0; br < 2; ++br)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[br][e] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+      const bf16x8 fa = *reinterpret_cast<const bf16x8*>(&s_a[br][wr * 32 + r][ks * 16 + h * 8]);
+      const bf16x8 fb = *reinterpret_cast<const bf16x8*>(&s_b[br][wc * 32 + r][ks * 16 + h * 8]);
+      acc[br] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[br], 0, 0, 0);
+    }
+  __syncthreads();                                               // every wave is done with the operands
+#pragma unroll
+  for (int br = 0; br < 2; ++br)
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      s_c[br][wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h][wc * 32 + r] = acc[br][e];
+  __syncthreads();
+  // ---- elementwise terms: thread -> 4 fixed columns, rows tid / 16 + 32 i
+  const float gl = gcoef[0];
+  const float ca = gl * sim_coeff + gcoef[1], cb = gl * std_coeff + gcoef[2], cc = gl * cov_coeff + gcoef[3];
+  const float kappa = 4.0f / ((float)(cfg_batch - 1) * (float)(cfg_batch - 1) * (float)D);
+  const float inv_bm1 = 1.0f / (float)(B - 1);
+  const float repr_k = ca * 2.0f / ((float)B * (float)D), cck = cc * kappa;
+  const int c4 = tid & 15, jc = j0 + 4 * c4;
+  if (jc >= D) return;                                           // D % 4 == 0: the four columns are in or out together
+  float mu[2][4], av[2][4];
+#pragma unroll
+  for (int br = 0; br < 2; ++br) {
+    const vc_f32x4 m = *reinterpret_cast<const vc_f32x4*>(colstats + (size_t)br * D + jc);
+    const vc_f32x4 m2 = *reinterpret_cast<const vc_f32x4*>(colstats + (size_t)(2 + br) * D + jc);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      mu[br][c] = m[c];
+      const float sd = sqrtf(m2[c] * inv_bm1 + 0.0001f);
+      // coefficient of vc: variance hinge (active where s < 1) and the diagonal part of the covariance term
+      av[br][c] = (sd < 1.0f ? -cb / (2.0f * (float)D * (float)(B - 1) * sd) : 0.0f) - cck * m2[c];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = (tid >> 4) + 32 * i;
+    if (b >= B) continue;
+    const vc_f32x4 xv = *reinterpret_cast<const vc_f32x4*>(x + (size_t)b * ld + jc);
+    const vc_f32x4 yv = *reinterpret_cast<const vc_f32x4*>(y + (size_t)b * ld + jc);
+    const vc_f32x4 cx = *reinterpret_cast<const vc_f32x4*>(&s_c[0][b][4 * c4]);
+    const vc_f32x4 cy = *reinterpret_cast<const vc_f32x4*>(&s_c[1][b][4 * c4]);
+    const float gdx = gdiag[b], gdy = gdiag[128 + b];
+    vc_f32x4 ox, oy;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d = repr_k * (xv[c] - yv[c]);
+      const float vx = xv[c] - mu[0][c], vy = yv[c] - mu[1][c];
+      ox[c] = d + av[0][c] * vx + cck * (cx[c] + gdx * vx);
+      oy[c] = -d + av[1][c] * vy + cck * (cy[c] + gdy * vy);
+    }
+    *reinterpret_cast<vc_f32x4*>(gx + (size_t)b * ldg + jc) = ox;
+    *reinterpret_cast<vc_f32x4*>(gy + (size_t)b * ldg + jc) = oy;
+  }
+}
+
 // ---- the same two products for batch > 128 on the 256 x 256 LDS-DMA tile product (g2_product) -------------------------
 // One upper-triangular 256 x 256 tile of one D-slice of G per workgroup (grid: tiles x slices x branches), written once
 // to the slice's own Gram (fixed-order sum over the slices in vicreg_gconv256_kernel: deterministic).
@@ -1436,6 +1546,12 @@ static int vicreg_backward_ld(const float* x, const float* y, long long ld, cons
     hipLaunchKernelGGL(vicreg_grad256_kernel, dim3((D + G2_T - 1) / G2_T, bt2, 2), dim3(G2_THREADS), lds256, stream, x, y,
                        (const unsigned short*)(ws + w.xt_x), (const unsigned short*)(ws + w.xt_y), Gb, gdiag,
                        (const float*)(ws + w.colstats), gcoef, gx, gy, B, D, w.Kpad, cfg_batch, sim_coeff, std_coeff, cov_coeff,
+                       (size_t)ld, (size_t)ldg);
+  } else if (w.Kpad == 128 && !((((size_t)x | (size_t)y | (size_t)gx | (size_t)gy) & 15) || ((ld | ldg) & 3))) {
+    (void)hipFuncSetAttribute((const void*)vicreg_grad128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G1_LDS_BYTES);
+    hipLaunchKernelGGL(vicreg_grad128_kernel, dim3((D + G1_COLS - 1) / G1_COLS), dim3(512), G1_LDS_BYTES, stream, x, y,
+                       (const unsigned short*)(ws + w.xt_x), (const unsigned short*)(ws + w.xt_y), Gb, gdiag,
+                       (const float*)(ws + w.colstats), gcoef, gx, gy, B, D, cfg_batch, sim_coeff, std_coeff, cov_coeff,
                        (size_t)ld, (size_t)ldg);
   } else {
     hipLaunchKernelGGL(vicreg_grad_kernel, dim3((D + GT - 1) / GT, bt, 2), dim3(256), 0, stream, x, y,

@@ -187,3 +187,24 @@ def test_batch_side_and_feature_side_forms_agree(lib, dev, both_forms, B, D, cfg
     for a, b in ((res[0][1], res[1][1]), (res[0][2], res[1][2])):
         assert torch.equal(a, b)                 # the same B x B matrix either way: the gradient is bit-equal
     print(f"cov_loss: oracle {ref[3]:.6e}  D x D {res[0][0][3]:.6e}  B x B {res[1][0][3]:.6e}")
+
+
+@pytest.mark.parametrize("B,D", [(128, 1024), (100, 136)])
+def test_backward_on_views_that_are_not_16_byte_aligned(lib, dev, B, D):
+    """Batch <= 128 takes vicreg_grad128_kernel (16-byte accesses) when x, y and the gradients are 16-byte aligned and
+    the 4-byte kernel otherwise: a contiguous view that starts one float into its storage gives the same gradient."""
+    from inverse_audio_synthesis_amd.vicreg import vicreg_loss
+    x0, y0 = randn((B, D), 21) * 0.8 + 0.2, randn((B, D), 22) * 1.1
+    res = []
+    for off in (0, 1):
+        fx, fy = torch.zeros(B * D + 4, device=dev), torch.zeros(B * D + 4, device=dev)
+        xd, yd = fx[off:off + B * D].view(B, D), fy[off:off + B * D].view(B, D)
+        xd.copy_(x0); yd.copy_(y0)
+        assert xd.data_ptr() % 16 == 4 * off
+        xd.requires_grad_(); yd.requires_grad_()
+        out = vicreg_loss(xd, yd, B)
+        gx, gy = torch.autograd.grad(out[0], (xd, yd))
+        res.append((gx.cpu(), gy.cpu()))
+    scale = float(res[0][0].abs().max())
+    for a, b in zip(res[0], res[1]):
+        assert float((a - b).abs().max()) <= 1e-5 * scale
