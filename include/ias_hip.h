@@ -330,6 +330,13 @@ int ias_vicreg_backward_ld(const float* x, const float* y, long long ld, const f
                            long long ldg, void* workspace, long long workspace_bytes, int B, int D, int cfg_batch,
                            float sim_coeff, float std_coeff, float cov_coeff, void* stream);
 
+/* ias_vicreg_backward_ld with the four cotangents as separate device floats, any of them NULL (= zero): autograd hands the
+ * outputs that were not differentiated over as None, and packing four scalars into gcoef costs a kernel per step. */
+int ias_vicreg_backward4_ld(const float* x, const float* y, long long ld, const float* g_loss, const float* g_repr,
+                            const float* g_std, const float* g_cov, float* gx, float* gy, long long ldg, void* workspace,
+                            long long workspace_bytes, int B, int D, int cfg_batch, float sim_coeff, float std_coeff,
+                            float cov_coeff, void* stream);
+
 /* One stage of ias_vicreg_loss on the same workspace: 0 column pass, 1 the Gram kernel(s) on the matrix cores,
  * 2 the final reduction (stage < 0: all of them = ias_vicreg_loss).  Lets a caller time the Gram alone. */
 int ias_vicreg_stage(int stage, const float* x, const float* y, float* out, void* workspace, long long workspace_bytes,

@@ -90,6 +90,7 @@ SYMBOLS = {
     "ias_vicreg_backward": (_I, [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
     "ias_vicreg_loss_ld": (_I, [_P, _P, _LL, _P, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
     "ias_vicreg_backward_ld": (_I, [_P, _P, _LL, _P, _P, _P, _LL, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
+    "ias_vicreg_backward4_ld": (_I, [_P, _P, _LL, _P, _P, _P, _P, _P, _P, _LL, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
     "ias_vicreg_stage": (_I, [_I, _P, _P, _P, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
     "ias_vicreg_set_form": (_I, [_I]),
     "ias_conv_out_size": (_I, [_I, _I, _I]),

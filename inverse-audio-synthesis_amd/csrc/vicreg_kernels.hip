@@ -40,6 +40,9 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 // x, y: [B, D] fp32.  Xt_*: [D][Kpad] bf16 (zero padded in k).  colstats: [4][D] = mean_x, mean_y, m2_x, m2_y
 // msepart: [gridDim.x] fp64.
 // A wave covers the workgroup's 32 columns (128-byte row segments) of TWO rows at a time: lane = (row half, column).
+// NR > 0: batch <= 32 NR, every thread keeps its NR rows of x and y in registers between the two passes (x and y are
+// read ONCE); NR = 0: any batch, the second pass reads them again.
+template <int NR>
 __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
     const float* __restrict__ x, const float* __restrict__ y, unsigned short* __restrict__ Xt_x,
     unsigned short* __restrict__ Xt_y, float* __restrict__ colstats, double* __restrict__ msepart,
@@ -58,12 +61,28 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
 
   // pass 1: column sums (wave w takes rows 2 w + rsub, + 32, ...), sum (x-y)^2
   float sx = 0.f, sy = 0.f, se = 0.f;
-  for (int b = 2 * wave + rsub; b < B; b += RPI) {
-    if (jok) {
-      const float xv = x[(size_t)b * ld + j], yv = y[(size_t)b * ld + j];
-      sx += xv; sy += yv;
-      const float d = xv - yv;
+  float keepx[NR > 0 ? NR : 1], keepy[NR > 0 ? NR : 1];
+  if (NR > 0) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int b = 2 * wave + rsub + RPI * i;
+      keepx[i] = 0.f; keepy[i] = 0.f;
+      if (jok && b < B) { keepx[i] = x[(size_t)b * ld + j]; keepy[i] = y[(size_t)b * ld + j]; }
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {                               // (rows beyond B hold zeros: they add nothing)
+      sx += keepx[i]; sy += keepy[i];
+      const float d = keepx[i] - keepy[i];
       se = fmaf(d, d, se);
+    }
+  } else {
+    for (int b = 2 * wave + rsub; b < B; b += RPI) {
+      if (jok) {
+        const float xv = x[(size_t)b * ld + j], yv = y[(size_t)b * ld + j];
+        sx += xv; sy += yv;
+        const float d = xv - yv;
+        se = fmaf(d, d, se);
+      }
     }
   }
   s_red[0][wave][lane] = sx; s_red[1][wave][lane] = sy;
@@ -90,13 +109,21 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
 
   // pass 2: centred sum of squares + bf16 transpose, 64 rows at a time
   float qx = 0.f, qy = 0.f, rx = 0.f, ry = 0.f;                 // (r*: the same sums over the bf16-ROUNDED values)
-  for (int b0 = 0; b0 < Kpad; b0 += 64) {
-    for (int r = 2 * wave + rsub; r < 64; r += RPI) {
+  auto chunk = [&](const int c64) {
+    const int b0 = 64 * c64;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                                // rows r = 2 wave + rsub (+ 32) of this 64-row chunk
+      const int r = 2 * wave + rsub + RPI * u;
       const int b = b0 + r;
       float cx = 0.f, cy = 0.f;
       if (jok && b < B) {
-        cx = x[(size_t)b * ld + j] - mx;
-        cy = y[(size_t)b * ld + j] - my;
+        if (NR > 0) {
+          cx = keepx[(2 * c64 + u) < NR ? 2 * c64 + u : 0] - mx;
+          cy = keepy[(2 * c64 + u) < NR ? 2 * c64 + u : 0] - my;
+        } else {
+          cx = x[(size_t)b * ld + j] - mx;
+          cy = y[(size_t)b * ld + j] - my;
+        }
         qx = fmaf(cx, cx, qx);
         qy = fmaf(cy, cy, qy);
       }
@@ -128,6 +155,15 @@ __global__ __launch_bounds__(VC_THREADS) void vicreg_colstats_kernel(
       }
     }
     __syncthreads();
+  };
+  if constexpr (NR > 0) {
+#pragma unroll
+    for (int c64 = 0; c64 < (NR + 1) / 2; ++c64) {
+      if (64 * c64 >= Kpad) break;
+      chunk(c64);
+    }
+  } else {
+    for (int c64 = 0; 64 * c64 < Kpad; ++c64) chunk(c64);
   }
   s_red[2][wave][lane] = qx; s_red[3][wave][lane] = qy;
   s_red[4][wave][lane] = rx; s_red[5][wave][lane] = ry;
@@ -795,21 +831,24 @@ __global__ __launch_bounds__(G2_THREADS, 2) void vicreg_gram256_kernel(const uns
   }
 }
 
-// out[0..3] = loss, repr_loss, std_loss, cov_loss (fp32)
-__global__ __launch_bounds__(256) void vicreg_finish_kernel(const double* __restrict__ hingepart,
-                                                            const double* __restrict__ msepart, int nmse,
-                                                            const double* __restrict__ gram_x,
-                                                            const double* __restrict__ gram_y, int ngram,
-                                                            const double* __restrict__ diagpart /* batch-side form: [nmse], else null */,
-                                                            int B, int D, int cfg_batch, float sim_coeff, float std_coeff,
-                                                            float cov_coeff, float* __restrict__ out) {
+// out[0..3] = loss, repr_loss, std_loss, cov_loss (fp32): fixed-order reduction of every partial, by 256 threads.
+// gram_x (+ gram_y): partial sums of squares; diagpart (batch-side form, else null): [nmse], taken off.
+struct VcFinish {
+  const double *hingepart, *msepart, *gram_x, *gram_y, *diagpart;
+  int nmse, ngram, B, D, cfg_batch;
+  float sim_coeff, std_coeff, cov_coeff;
+  float* out;
+};
+// (A variant in which the fold's last-arriving workgroup did this reduction -- ticket counter, device-scope loads -- cost
+// more than the launch it saved: +0 us at B = 128, +6 us at B = 1024, HISTORY.md round 4.)
+__global__ __launch_bounds__(256) void vicreg_finish_kernel(const VcFinish f) {
   __shared__ double s[256][4];
   double mse = 0.0, hinge = 0.0, gx = 0.0, gy = 0.0;
-  for (int i = threadIdx.x; i < nmse; i += 256) mse += msepart[i];
-  for (int i = threadIdx.x; i < ngram; i += 256) { gx += gram_x[i]; if (gram_y) gy += gram_y[i]; }
-  if (diagpart)                                                  // gram_x holds sum G_ab^2 = sum over ALL of C: take C's diagonal off
-    for (int i = threadIdx.x; i < nmse; i += 256) gy -= diagpart[i];
-  for (int i = threadIdx.x; i < nmse; i += 256) hinge += hingepart[i];
+  for (int i = threadIdx.x; i < f.nmse; i += 256) mse += f.msepart[i];
+  for (int i = threadIdx.x; i < f.ngram; i += 256) { gx += f.gram_x[i]; if (f.gram_y) gy += f.gram_y[i]; }
+  if (f.diagpart)                                                // gram_x holds sum G_ab^2 = sum over ALL of C: take C's diagonal off
+    for (int i = threadIdx.x; i < f.nmse; i += 256) gy -= f.diagpart[i];
+  for (int i = threadIdx.x; i < f.nmse; i += 256) hinge += f.hingepart[i];
   s[threadIdx.x][0] = mse; s[threadIdx.x][1] = hinge; s[threadIdx.x][2] = gx; s[threadIdx.x][3] = gy;
   __syncthreads();
   for (int d = 128; d > 0; d >>= 1) {
@@ -818,17 +857,16 @@ __global__ __launch_bounds__(256) void vicreg_finish_kernel(const double* __rest
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const double repr = s[0][0] / ((double)B * (double)D);
-    const double stdl = s[0][1] / (2.0 * (double)D);
-    const double den = (double)(cfg_batch - 1);
-    const double cov = (s[0][2] + s[0][3]) / (den * den) / (double)D;
-    out[0] = (float)((double)sim_coeff * repr + (double)std_coeff * stdl + (double)cov_coeff * cov);
-    out[1] = (float)repr;
-    out[2] = (float)stdl;
-    out[3] = (float)cov;
+    const double repr = s[0][0] / ((double)f.B * (double)f.D);
+    const double stdl = s[0][1] / (2.0 * (double)f.D);
+    const double den = (double)(f.cfg_batch - 1);
+    const double cov = (s[0][2] + s[0][3]) / (den * den) / (double)f.D;
+    f.out[0] = (float)((double)f.sim_coeff * repr + (double)f.std_coeff * stdl + (double)f.cov_coeff * cov);
+    f.out[1] = (float)repr;
+    f.out[2] = (float)stdl;
+    f.out[3] = (float)cov;
   }
 }
-
 // ------------------------------------------------------------------------ C ABI
 static inline size_t vc_align(size_t x) { return (x + 255) / 256 * 256; }
 struct VicregWs { size_t xt_x, xt_y, colstats, mse, hinge, diag, gram_x, gram_y, xc_x, xc_y, bgram, bgram16, gdiag, g2part, total; int Kpad, ntile, ngram, nmse, nsplit, ksplit, ng2; bool t256, b256, dual; };
@@ -931,17 +969,31 @@ static int vicreg_stage_ld(int stage, const float* x, const float* y, long long 
   double* gram_x = (double*)(ws + w.gram_x);
   double* gram_y = (double*)(ws + w.gram_y);
   if (stage < 0 || stage == 0)
-    hipLaunchKernelGGL(vicreg_colstats_kernel, dim3(w.nmse), dim3(VC_THREADS), 0, stream, x, y, xt_x, xt_y, colstats,
-                       mse, hinge, (double*)(ws + w.diag), (unsigned short*)(ws + w.xc_x), (unsigned short*)(ws + w.xc_y), B, D,
-                       w.Kpad, (size_t)ld);
+  {
+    auto launch = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(w.nmse), dim3(VC_THREADS), 0, stream, x, y, xt_x, xt_y, colstats, mse, hinge,
+                         (double*)(ws + w.diag), (unsigned short*)(ws + w.xc_x), (unsigned short*)(ws + w.xc_y), B, D, w.Kpad,
+                         (size_t)ld);
+    };
+    static const bool reread = getenv("IAS_VICREG_COLSTATS_REREAD") != nullptr;   // (diagnostics: the two-read form at any batch)
+    if (reread || w.Kpad > 1024) launch(vicreg_colstats_kernel<0>);
+    else if (w.Kpad <= 128) launch(vicreg_colstats_kernel<4>);
+    else if (w.Kpad <= 256) launch(vicreg_colstats_kernel<8>);
+    else if (w.Kpad <= 512) launch(vicreg_colstats_kernel<16>);
+    else launch(vicreg_colstats_kernel<32>);
+  }
+  VcFinish fin;
+  fin.hingepart = hinge; fin.msepart = mse; fin.nmse = w.nmse;
+  fin.B = B; fin.D = D; fin.cfg_batch = cfg_batch;
+  fin.sim_coeff = sim_coeff; fin.std_coeff = std_coeff; fin.cov_coeff = cov_coeff;
+  fin.out = out;
   if (w.dual) {
     // batch side: G = Xc Xc^T in D-slices, folded (and squared, summed) in slice order; the backward finds G in place
     if (w.Kpad % GT) return IAS_ERR_UNSUPPORTED;
+    fin.gram_x = (const double*)(ws + w.g2part); fin.gram_y = nullptr; fin.ngram = w.ng2;
+    fin.diagpart = (const double*)(ws + w.diag);
     if (stage < 0 || stage == 1) vicreg_launch_batch_gram(w, ws, D, stream, true);
-    if (stage < 0 || stage == 2)
-      hipLaunchKernelGGL(vicreg_finish_kernel, dim3(1), dim3(256), 0, stream, hinge, mse, w.nmse, (const double*)(ws + w.g2part),
-                         (const double*)nullptr, w.ng2, (const double*)(ws + w.diag), B, D, cfg_batch, sim_coeff, std_coeff,
-                         cov_coeff, out);
+    if (stage < 0 || stage == 2) hipLaunchKernelGGL(vicreg_finish_kernel, dim3(1), dim3(256), 0, stream, fin);
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   }
   int ngram = w.ngram;
@@ -972,9 +1024,10 @@ static int vicreg_stage_ld(int stage, const float* x, const float* y, long long 
                          w.ntile);
     }
   }
-  if (stage < 0 || stage == 2)
-    hipLaunchKernelGGL(vicreg_finish_kernel, dim3(1), dim3(256), 0, stream, hinge, mse, w.nmse, gram_x, gram_y,
-                       ngram, (const double*)nullptr, B, D, cfg_batch, sim_coeff, std_coeff, cov_coeff, out);
+  if (stage < 0 || stage == 2) {
+    fin.gram_x = gram_x; fin.gram_y = gram_y; fin.ngram = ngram; fin.diagpart = nullptr;
+    hipLaunchKernelGGL(vicreg_finish_kernel, dim3(1), dim3(256), 0, stream, fin);
+  }
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
@@ -1012,6 +1065,17 @@ extern "C" int ias_vicreg_loss_ld(const float* x, const float* y, long long ld, 
 //                               each write their own partial Gram (summed in slice order: deterministic);
 //          vicreg_grad_kernel   G vc as a second bf16 MFMA product (A = G cast to bf16, B = Xt) for x and y at once,
 //                               epilogue adds the elementwise terms from x, y and the column statistics, writes gx, gy.
+
+// The cotangents of (loss, repr_loss, std_loss, cov_loss): one device float each, null = zero (autograd hands the unused
+// outputs over as None; packing them into one buffer cost a concatenation kernel per backward).
+struct VcCot { const float* g[4]; };
+__device__ __forceinline__ void vc_cot_coefs(const VcCot& k, float sim_coeff, float std_coeff, float cov_coeff, float& ca,
+                                             float& cb, float& cc) {
+  const float gl = k.g[0] ? *k.g[0] : 0.0f;
+  ca = gl * sim_coeff + (k.g[1] ? *k.g[1] : 0.0f);
+  cb = gl * std_coeff + (k.g[2] ? *k.g[2] : 0.0f);
+  cc = gl * cov_coeff + (k.g[3] ? *k.g[3] : 0.0f);
+}
 
 // acc += A[row0 .. row0+127][k] B[col0 .. col0+127][k]^T over k in [kbeg, kend) (kbeg a multiple of GK, kend of 8), A / B bf16 row-major
 // with row strides lda / ldb; rows >= arows / brows and k >= kend read as zero.  The k loop is double-buffered as in vicreg_gram_kernel:
@@ -1159,7 +1223,7 @@ __global__ __launch_bounds__(256, 2) void vicreg_grad_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const unsigned short* __restrict__ Xt_x,
     const unsigned short* __restrict__ Xt_y, const unsigned short* __restrict__ Gb, const float* __restrict__ gdiag,
     const float* __restrict__ colstats,
-    const float* __restrict__ gcoef /* g_loss, g_repr, g_std, g_cov */, float* __restrict__ gx, float* __restrict__ gy,
+    const VcCot gcoef /* g_loss, g_repr, g_std, g_cov */, float* __restrict__ gx, float* __restrict__ gy,
     int B, int D, int Kpad, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff, size_t ld, size_t ldg) {
   __shared__ __attribute__((aligned(16))) unsigned short s_a[2][GT][GLD];   // G rows (bf16)
   __shared__ __attribute__((aligned(16))) unsigned short s_b[2][GT][GLD];   // Xt rows (features)
@@ -1167,8 +1231,8 @@ __global__ __launch_bounds__(256, 2) void vicreg_grad_kernel(
   const int wr = wave >> 1, wc = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int col0 = blockIdx.x * GT, row0 = blockIdx.y * GT, branch = blockIdx.z;   // one branch per workgroup (grid.z = 2)
-  const float gl = gcoef[0];
-  const float ca = gl * sim_coeff + gcoef[1], cb = gl * std_coeff + gcoef[2], cc = gl * cov_coeff + gcoef[3];
+  float ca, cb, cc;
+  vc_cot_coefs(gcoef, sim_coeff, std_coeff, cov_coeff, ca, cb, cc);
   const float kappa = 4.0f / ((float)(cfg_batch - 1) * (float)(cfg_batch - 1) * (float)D);
 
   f32x16 acc[2][2];   // [m][n]
@@ -1222,7 +1286,7 @@ static_assert(2 * 128 * G1_LDC * 4 <= G1_LDS_BYTES, "the result tiles overlay th
 __global__ __launch_bounds__(512) void vicreg_grad128_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const unsigned short* __restrict__ Xt_x,
     const unsigned short* __restrict__ Xt_y, const unsigned short* __restrict__ Gb, const float* __restrict__ gdiag,
-    const float* __restrict__ colstats, const float* __restrict__ gcoef, float* __restrict__ gx, float* __restrict__ gy,
+    const float* __restrict__ colstats, const VcCot gcoef, float* __restrict__ gx, float* __restrict__ gy,
     int B, int D, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff, size_t ld, size_t ldg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_g1[];
   unsigned short (*s_a)[128][G1_LDK] = reinterpret_cast<unsigned short (*)[128][G1_LDK]>(s_g1);
@@ -1276,8 +1340,8 @@ __global__ __launch_bounds__(512) void vicreg_grad128_kernel(
       s_c[br][wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h][wc * 32 + r] = acc[br][e];
   __syncthreads();
   // ---- elementwise terms: thread -> 4 fixed columns, rows tid / 16 + 32 i
-  const float gl = gcoef[0];
-  const float ca = gl * sim_coeff + gcoef[1], cb = gl * std_coeff + gcoef[2], cc = gl * cov_coeff + gcoef[3];
+  float ca, cb, cc;
+  vc_cot_coefs(gcoef, sim_coeff, std_coeff, cov_coeff, ca, cb, cc);
   const float kappa = 4.0f / ((float)(cfg_batch - 1) * (float)(cfg_batch - 1) * (float)D);
   const float inv_bm1 = 1.0f / (float)(B - 1);
   const float repr_k = ca * 2.0f / ((float)B * (float)D), cck = cc * kappa;
@@ -1378,29 +1442,27 @@ __global__ __launch_bounds__(256) void vicreg_gconv256_kernel(const float* __res
   g2_tri_item(blockIdx.x >> 4, nt, ti, tj);
   const int sub = blockIdx.x & 15, branch = blockIdx.y;
   const int r0 = ti * G2_T + (sub >> 2) * 64, c0 = tj * G2_T + (sub & 3) * 64;
-  if (r0 >= Kpad || c0 >= Kpad) {                                // Kpad % 64 == 0: a block is inside or outside
-    if (g2part && threadIdx.x == 0) g2part[(size_t)branch * gridDim.x + blockIdx.x] = 0.0;
-    return;
-  }
+  const bool inside = r0 < Kpad && c0 < Kpad;                    // Kpad % 64 == 0: a block is inside or outside
   const size_t plane = (size_t)Kpad * Kpad, n2 = 2 * plane;
   const int tid = threadIdx.x, cc = tid & 63;
   double sq = 0.0;                                               // sum of G_ab^2 over the block (the diagonal included)
-  for (int rr = tid >> 6; rr < 64; rr += 4) {
-    const int row = r0 + rr, col = c0 + cc;
-    const size_t i = (size_t)branch * plane + (size_t)row * Kpad + col;
-    float v = 0.0f;
-    for (int s0 = 0; s0 < nsplit; s0 += 8) {                     // eight slices in flight, added in slice order
-      float a[8];
+  if (inside)
+    for (int rr = tid >> 6; rr < 64; rr += 4) {
+      const int row = r0 + rr, col = c0 + cc;
+      const size_t i = (size_t)branch * plane + (size_t)row * Kpad + col;
+      float v = 0.0f;
+      for (int s0 = 0; s0 < nsplit; s0 += 8) {                   // eight slices in flight, added in slice order
+        float a[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] = s0 + u < nsplit ? Gp[(size_t)(s0 + u) * n2 + i] : 0.0f;
+        for (int u = 0; u < 8; ++u) a[u] = s0 + u < nsplit ? Gp[(size_t)(s0 + u) * n2 + i] : 0.0f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v += a[u];
+        for (int u = 0; u < 8; ++u) v += a[u];
+      }
+      sq += (double)v * (double)v;
+      if (row == col) { gdiag[(size_t)branch * Kpad + row] = v; v = 0.0f; }
+      Gb[i] = f2bf(v);
+      s_t[rr][cc] = v;
     }
-    sq += (double)v * (double)v;
-    if (row == col) { gdiag[(size_t)branch * Kpad + row] = v; v = 0.0f; }
-    Gb[i] = f2bf(v);
-    s_t[rr][cc] = v;
-  }
   if (g2part) {
     for (int d = 32; d > 0; d >>= 1) sq += __shfl_xor(sq, d, 64);
     if ((tid & 63) == 0) s_sq[tid >> 6] = sq;
@@ -1408,9 +1470,9 @@ __global__ __launch_bounds__(256) void vicreg_gconv256_kernel(const float* __res
   __syncthreads();
   if (g2part && tid == 0)                                        // tiles above the diagonal stand for their mirror image too
     g2part[(size_t)branch * gridDim.x + blockIdx.x] = (ti == tj ? 1.0 : 2.0) * (((s_sq[0] + s_sq[1]) + s_sq[2]) + s_sq[3]);
-  if (ti == tj) return;
-  for (int rr = tid >> 6; rr < 64; rr += 4)                      // row c0 + rr of the mirror image, columns r0 + cc
-    Gb[(size_t)branch * plane + (size_t)(c0 + rr) * Kpad + r0 + cc] = f2bf(s_t[cc][rr]);
+  if (inside && ti != tj)
+    for (int rr = tid >> 6; rr < 64; rr += 4)                    // row c0 + rr of the mirror image, columns r0 + cc
+      Gb[(size_t)branch * plane + (size_t)(c0 + rr) * Kpad + r0 + cc] = f2bf(s_t[cc][rr]);
 }
 
 // One 256 (batch rows) x 256 (features) tile of gx (branch 0) or gy (branch 1) per workgroup: (G - diag) vc on the
@@ -1418,14 +1480,14 @@ __global__ __launch_bounds__(256) void vicreg_gconv256_kernel(const float* __res
 __global__ __launch_bounds__(G2_THREADS, 2) void vicreg_grad256_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const unsigned short* __restrict__ Xt_x,
     const unsigned short* __restrict__ Xt_y, const unsigned short* __restrict__ Gb, const float* __restrict__ gdiag,
-    const float* __restrict__ colstats, const float* __restrict__ gcoef, float* __restrict__ gx, float* __restrict__ gy,
+    const float* __restrict__ colstats, const VcCot gcoef, float* __restrict__ gx, float* __restrict__ gy,
     int B, int D, int Kpad, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff, size_t ld, size_t ldg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_g2[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3, r = lane & 15, q = lane >> 4;
   const int col0 = blockIdx.x * G2_T, row0 = blockIdx.y * G2_T, branch = blockIdx.z;
-  const float gl = gcoef[0];
-  const float ca = gl * sim_coeff + gcoef[1], cb = gl * std_coeff + gcoef[2], cc = gl * cov_coeff + gcoef[3];
+  float ca, cb, cc;
+  vc_cot_coefs(gcoef, sim_coeff, std_coeff, cov_coeff, ca, cb, cc);
   const float kappa = 4.0f / ((float)(cfg_batch - 1) * (float)(cfg_batch - 1) * (float)D);
   vc_f32x4 acc[8][4];
 #pragma unroll
@@ -1498,7 +1560,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void vicreg_grad256_kernel(
 }
 
 // G = Xc Xc^T for both branches: partial Grams per D-slice [nsplit][2][Kpad][Kpad] (every word written), folded in slice
-// order to bf16 (diagonal apart, fp32); `squares`: the fold also leaves the partial sums of G_ab^2 at w.g2part.
+// order to bf16 (diagonal apart, fp32); `squares` (forward): the fold also leaves the partial sums of G_ab^2 at w.g2part.
 static void vicreg_launch_batch_gram(const VicregWs& w, char* ws, int D, hipStream_t stream, bool squares) {
   float* G = (float*)(ws + w.bgram);
   const int bt = w.Kpad / GT, npair = bt * (bt + 1) / 2;
@@ -1522,11 +1584,11 @@ static void vicreg_launch_batch_gram(const VicregWs& w, char* ws, int D, hipStre
 
 // Backward of ias_vicreg_loss on the SAME workspace (it must still hold the forward's column statistics and centred
 // bf16 copies -- and, after a batch-side forward, G): gcoef [4] device floats = the cotangents of (loss, repr_loss, std_loss, cov_loss) -> gx, gy [B,D] fp32.
-static int vicreg_backward_ld(const float* x, const float* y, long long ld, const float* gcoef, float* gx, float* gy,
+static int vicreg_backward_ld(const float* x, const float* y, long long ld, const VcCot gcoef, float* gx, float* gy,
                               long long ldg, void* workspace, long long workspace_bytes, int B, int D, int cfg_batch,
                               float sim_coeff, float std_coeff, float cov_coeff, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!x || !y || !gcoef || !gx || !gy || !workspace || B < 2 || D < 8 || (D & 7) || cfg_batch < 2 || ld < D || ldg < D)
+  if (!x || !y || !gx || !gy || !workspace || B < 2 || D < 8 || (D & 7) || cfg_batch < 2 || ld < D || ldg < D)
     return IAS_ERR_ARG;
   // the 256-tile epilogue moves 16 bytes per access: strided views must keep that alignment
   if ((ld != D || ldg != D) && ((((size_t)x | (size_t)y | (size_t)gx | (size_t)gy) & 15) || ((ld | ldg) & 3))) return IAS_ERR_ARG;
@@ -1565,7 +1627,8 @@ static int vicreg_backward_ld(const float* x, const float* y, long long ld, cons
 extern "C" int ias_vicreg_backward(const float* x, const float* y, const float* gcoef, float* gx, float* gy, void* workspace,
                                    long long workspace_bytes, int B, int D, int cfg_batch, float sim_coeff, float std_coeff,
                                    float cov_coeff, void* stream_) {
-  return vicreg_backward_ld(x, y, D, gcoef, gx, gy, D, workspace, workspace_bytes, B, D, cfg_batch, sim_coeff, std_coeff,
+  if (!gcoef) return IAS_ERR_ARG;
+  return vicreg_backward_ld(x, y, D, VcCot{{gcoef, gcoef + 1, gcoef + 2, gcoef + 3}}, gx, gy, D, workspace, workspace_bytes, B, D, cfg_batch, sim_coeff, std_coeff,
                             cov_coeff, stream_);
 }
 
@@ -1574,8 +1637,19 @@ extern "C" int ias_vicreg_backward(const float* x, const float* y, const float* 
 extern "C" int ias_vicreg_backward_ld(const float* x, const float* y, long long ld, const float* gcoef, float* gx, float* gy,
                                       long long ldg, void* workspace, long long workspace_bytes, int B, int D, int cfg_batch,
                                       float sim_coeff, float std_coeff, float cov_coeff, void* stream_) {
-  return vicreg_backward_ld(x, y, ld, gcoef, gx, gy, ldg, workspace, workspace_bytes, B, D, cfg_batch, sim_coeff, std_coeff,
+  if (!gcoef) return IAS_ERR_ARG;
+  return vicreg_backward_ld(x, y, ld, VcCot{{gcoef, gcoef + 1, gcoef + 2, gcoef + 3}}, gx, gy, ldg, workspace, workspace_bytes, B, D, cfg_batch, sim_coeff, std_coeff,
                             cov_coeff, stream_);
+}
+
+// The same backward with the four cotangents as separate device floats, any of them null (= zero): what autograd hands
+// over when only some of the four outputs were differentiated -- no packing kernel in front.
+extern "C" int ias_vicreg_backward4_ld(const float* x, const float* y, long long ld, const float* g_loss, const float* g_repr,
+                                       const float* g_std, const float* g_cov, float* gx, float* gy, long long ldg,
+                                       void* workspace, long long workspace_bytes, int B, int D, int cfg_batch,
+                                       float sim_coeff, float std_coeff, float cov_coeff, void* stream_) {
+  return vicreg_backward_ld(x, y, ld, VcCot{{g_loss, g_repr, g_std, g_cov}}, gx, gy, ldg, workspace, workspace_bytes, B, D,
+                            cfg_batch, sim_coeff, std_coeff, cov_coeff, stream_);
 }
 
 extern "C" long long ias_vicreg_colstats_offset(int B, int D) {

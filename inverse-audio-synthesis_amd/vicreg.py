@@ -30,6 +30,13 @@ def _zero_scalar(device):
     return z
 
 
+def _cotangent_ptrs(grads):
+    """-> ([four device pointers, None where autograd passed None], the fp32 tensors they point into -- keep them alive
+    until the launch has been issued)."""
+    keep = [None if g is None else g.detach().to(torch.float32).contiguous() for g in grads]
+    return [None if k is None else k.data_ptr() for k in keep], keep
+
+
 class _VICRegLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, cfg_batch, sim_coeff, std_coeff, cov_coeff):
@@ -61,14 +68,15 @@ class _VICRegLossFn(torch.autograd.Function):
         grads = (g_loss, g_repr, g_std, g_cov)
         if all(g is None for g in grads):
             return None, None, None, None, None, None
-        zero = _zero_scalar(x.device)
-        gcoef = torch.cat([zero if g is None else g.to(torch.float32).reshape(1) for g in grads])
         if D % 8 != 0:
+            zero = _zero_scalar(x.device)
+            gcoef = torch.cat([zero if g is None else g.to(torch.float32).reshape(1) for g in grads])
             return _vicreg_backward_torch(x, y, gcoef, cfg_batch, sim, std, cov) + (None, None, None, None)
         gx, gy = torch.empty_like(x), torch.empty_like(y)
-        st = lib.ias_vicreg_backward(_lib.ptr(x), _lib.ptr(y), _lib.ptr(gcoef), _lib.ptr(gx), _lib.ptr(gy), _lib.ptr(ws),
-                                     ws.numel(), B, D, cfg_batch, sim, std, cov, _lib.stream())
-        _lib.check(st, "ias_vicreg_backward")
+        cot = _cotangent_ptrs(grads)
+        st = lib.ias_vicreg_backward4_ld(_lib.ptr(x), _lib.ptr(y), D, *cot[0], _lib.ptr(gx), _lib.ptr(gy), D, _lib.ptr(ws),
+                                         ws.numel(), B, D, cfg_batch, sim, std, cov, _lib.stream())
+        _lib.check(st, "ias_vicreg_backward4_ld")
         return gx, gy, None, None, None, None
 
 
@@ -127,13 +135,12 @@ class _VICRegPairLossFn(torch.autograd.Function):
         grads = (g_loss, g_repr, g_std, g_cov)
         if all(g is None for g in grads):
             return None, None, None, None, None
-        zero = _zero_scalar(xy.device)
-        gcoef = torch.cat([zero if g is None else g.to(torch.float32).reshape(1) for g in grads])
         g = torch.empty_like(xy)
         base, gbase = xy.data_ptr(), g.data_ptr()
-        st = _lib.load().ias_vicreg_backward_ld(base, base + 4 * D, 2 * D, _lib.ptr(gcoef), gbase, gbase + 4 * D, 2 * D,
-                                                _lib.ptr(ws), ws.numel(), B, D, cfg_batch, sim, std, cov, _lib.stream())
-        _lib.check(st, "ias_vicreg_backward_ld")
+        cot = _cotangent_ptrs(grads)
+        st = _lib.load().ias_vicreg_backward4_ld(base, base + 4 * D, 2 * D, *cot[0], gbase, gbase + 4 * D, 2 * D,
+                                                 _lib.ptr(ws), ws.numel(), B, D, cfg_batch, sim, std, cov, _lib.stream())
+        _lib.check(st, "ias_vicreg_backward4_ld")
         return g, None, None, None, None
 
 
