@@ -124,28 +124,88 @@ __device__ __forceinline__ float sem_dot(const float* __restrict__ row, const fl
   return (a0 + a1) + (a2 + a3);
 }
 
-__global__ __launch_bounds__(SEM_THREADS) void se_mlp_forward_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+// Sum over the 16 lanes of a DPP row, the same value in every lane of the row (two quad permutes, two row rotations).
+__device__ __forceinline__ float sem_row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124 /* row_ror:4 */, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xf, 0xf, true));
+  return v;
+}
+
+// Forward of the two layers for SEF_SB samples per workgroup (round 4; the round-2 kernel above gave every THREAD a
+// weight row: 64 different cache lines per load instruction, 17.6 us per call).  Here 16 LANES take a weight row: they
+// read it with consecutive 16-byte loads (256 bytes per row and round, the row once for both samples), multiply against
+// the samples' input vectors in LDS, and the 16 partial sums are folded by four DPP adds -- no LDS, no readlane (a first
+// version with a whole wave per row spent its time in the 64-lane folds: 28.8 us).  A wave works on 4 rows at a time,
+// the 8 waves on 32.  Every workgroup still reads both weight matrices, but 64 workgroups do instead of 128.
+#define SEF_SB 2
+#define SEF_THREADS 512
+// out[s][o] = sum_k w[o][k] v[s][k] (+ bias[o]); v [SEF_SB][K] in LDS
+template <typename Epilogue>
+__device__ __forceinline__ void sef_layer(const float* __restrict__ w, const float* __restrict__ bias, const float* s_v, int K,
+                                          int O, bool vec, Epilogue&& done) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & 15, rsel = lane >> 4;
+  constexpr int RPW = 4, RPG = RPW * (SEF_THREADS / 64);         // rows per wave and round / per workgroup and round
+  for (int o0 = 0; o0 < O; o0 += RPG) {                          // (uniform trip count: the DPP folds need whole rows of lanes)
+    const int o = o0 + wave * RPW + rsel;
+    const bool ok = o < O;
+    const float* row = w + (size_t)(ok ? o : 0) * K;
+    float a0 = 0.f, a1 = 0.f;
+    if (vec) {
+      for (int k = 4 * sub; k < K; k += 64) {
+        const f4 wv = *reinterpret_cast<const f4*>(row + k);
+        const f4 v0 = *reinterpret_cast<const f4*>(s_v + k), v1 = *reinterpret_cast<const f4*>(s_v + K + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a0 = fmaf(wv[e], v0[e], a0); a1 = fmaf(wv[e], v1[e], a1); }
+      }
+    } else {
+      for (int k = sub; k < K; k += 16) {
+        const float wv = row[k];
+        a0 = fmaf(wv, s_v[k], a0); a1 = fmaf(wv, s_v[K + k], a1);
+      }
+    }
+    a0 = sem_row16_sum(a0);
+    a1 = sem_row16_sum(a1);
+    if (ok && sub == 0) {
+      const float b0 = bias ? bias[o] : 0.0f;
+      done(o, a0 + b0, a1 + b0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(SEF_THREADS) void se_mlp_forward_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
                                                                      const float* __restrict__ b1, const float* __restrict__ w2,
                                                                      const float* __restrict__ b2, float* __restrict__ h,
-                                                                     float* __restrict__ z, float* __restrict__ s, int C, int Cs,
-                                                                     int vec1, int vec2) {
+                                                                     float* __restrict__ z, float* __restrict__ s, int B, int C,
+                                                                     int Cs, int vec1, int vec2) {
   extern __shared__ __attribute__((aligned(16))) float sem_lds[];
-  float* s_p = sem_lds;            // [C]
-  float* s_h = sem_lds + C;        // [Cs]
-  const int b = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < C; i += SEM_THREADS) s_p[i] = pooled[(size_t)b * C + i];
-  __syncthreads();
-  for (int o = tid; o < Cs; o += SEM_THREADS) {
-    const float v = fmaxf(sem_dot(w1 + (size_t)o * C, s_p, C, b1 ? b1[o] : 0.0f, vec1 != 0), 0.0f);
-    s_h[o] = v;
-    h[(size_t)b * Cs + o] = v;
+  float* s_p = sem_lds;                    // [SEF_SB][C]
+  float* s_h = sem_lds + SEF_SB * C;       // [SEF_SB][Cs]   (C % 4 == 0 whenever vec2 is set: see the launcher)
+  const int bs = blockIdx.x * SEF_SB, tid = threadIdx.x;
+  const bool has1 = bs + 1 < B;            // (odd batch: the last workgroup's second sample repeats the first, not stored)
+  for (int i = tid; i < SEF_SB * C; i += SEF_THREADS) {
+    const int sm = i / C, c = i - sm * C;
+    s_p[i] = pooled[(size_t)(bs + (sm && has1 ? 1 : 0)) * C + c];
   }
   __syncthreads();
-  for (int o = tid; o < C; o += SEM_THREADS) {
-    const float v = sem_dot(w2 + (size_t)o * Cs, s_h, Cs, b2 ? b2[o] : 0.0f, vec2 != 0);
-    z[(size_t)b * C + o] = v;
-    s[(size_t)b * C + o] = fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f;
-  }
+  sef_layer(w1, b1, s_p, C, Cs, vec1 != 0, [&](int o, float v0, float v1) {
+    v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f);
+    s_h[o] = v0; s_h[Cs + o] = v1;
+    h[(size_t)bs * Cs + o] = v0;
+    if (has1) h[(size_t)(bs + 1) * Cs + o] = v1;
+  });
+  __syncthreads();
+  sef_layer(w2, b2, s_h, Cs, C, vec2 != 0, [&](int o, float v0, float v1) {
+    z[(size_t)bs * C + o] = v0;
+    s[(size_t)bs * C + o] = fminf(fmaxf(v0 + 3.0f, 0.0f), 6.0f) / 6.0f;
+    if (has1) {
+      z[(size_t)(bs + 1) * C + o] = v1;
+      s[(size_t)(bs + 1) * C + o] = fminf(fmaxf(v1 + 3.0f, 0.0f), 6.0f) / 6.0f;
+    }
+  });
 }
 
 // per sample: gz = gs * hardsigmoid'(z); gh = relu'(h) * W2^T gz; gp = W1^T gh   (lanes along the output index: the
@@ -191,25 +251,122 @@ __global__ __launch_bounds__(SEM_THREADS) void se_mlp_backward_sample_kernel(con
   }
 }
 
+// The same three products for SEF_SB samples per workgroup with the REDUCTION split over the 8 waves (round 4).  The
+// kernel above walks all C (or Cs) weight rows on one thread per output: 144-576 dependent rounds of four loads, 25.6 us
+// per call, latency all the way.  Here wave w takes rows w, w + 8, ... (four rows = up to 12 loads in flight), its lanes own
+// 4 consecutive outputs each (16-byte loads of the weight row, used for both samples), the 8 partial vectors meet in
+// LDS and are added in wave order.  max(C, Cs) <= SEB_MAXW outputs (LDS), C % 4 == Cs % 4 == 0, 16-byte aligned weights.
+#define SEB_MAXW 1024
+// part[wave][s][col] = sum over this wave's rows r of g[s][r] w[r][col]   (w [R][W] row-major, g [SEF_SB][R] in LDS)
+__device__ __forceinline__ void seb_matvec_t(const float* __restrict__ w, int R, int W, const float* s_g, float* s_part) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NWAVE = SEF_THREADS / 64;
+  for (int c0 = 4 * lane; c0 < W; c0 += 256) {
+    f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    int r = wave;
+    for (; r + 3 * NWAVE < R; r += 4 * NWAVE) {
+      f4 wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wv[u] = *reinterpret_cast<const f4*>(w + (size_t)(r + u * NWAVE) * W + c0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float g0 = s_g[r + u * NWAVE], g1 = s_g[R + r + u * NWAVE];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a0[e] = fmaf(g0, wv[u][e], a0[e]); a1[e] = fmaf(g1, wv[u][e], a1[e]); }
+      }
+    }
+    for (; r < R; r += NWAVE) {
+      const f4 wv = *reinterpret_cast<const f4*>(w + (size_t)r * W + c0);
+      const float g0 = s_g[r], g1 = s_g[R + r];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a0[e] = fmaf(g0, wv[e], a0[e]); a1[e] = fmaf(g1, wv[e], a1[e]); }
+    }
+    *reinterpret_cast<f4*>(s_part + ((size_t)wave * SEF_SB + 0) * W + c0) = a0;
+    *reinterpret_cast<f4*>(s_part + ((size_t)wave * SEF_SB + 1) * W + c0) = a1;
+  }
+}
+__global__ __launch_bounds__(SEF_THREADS) void se_mlp_backward_pair_kernel(const float* __restrict__ gs, const float* __restrict__ z,
+                                                                           const float* __restrict__ h, const float* __restrict__ w1,
+                                                                           const float* __restrict__ w2, float* __restrict__ gz,
+                                                                           float* __restrict__ gh, float* __restrict__ gp, int B,
+                                                                           int C, int Cs) {
+  extern __shared__ __attribute__((aligned(16))) float sem_lds[];
+  constexpr int NWAVE = SEF_THREADS / 64;
+  float* s_gz = sem_lds;                         // [SEF_SB][C]
+  float* s_gh = s_gz + SEF_SB * C;               // [SEF_SB][Cs]
+  float* s_part = s_gh + SEF_SB * Cs;            // [NWAVE][SEF_SB][max(C, Cs)]
+  const int bs = blockIdx.x * SEF_SB, tid = threadIdx.x;
+  const bool has1 = bs + 1 < B;
+  for (int i = tid; i < SEF_SB * C; i += SEF_THREADS) {
+    const int sm = i / C, c = i - sm * C;
+    float g = 0.0f;
+    if (sm == 0 || has1) {
+      const size_t at = (size_t)(bs + sm) * C + c;
+      const float zz = z[at];
+      g = (zz > -3.0f && zz < 3.0f) ? gs[at] * (1.0f / 6.0f) : 0.0f;
+      gz[at] = g;
+    }
+    s_gz[i] = g;
+  }
+  __syncthreads();
+  seb_matvec_t(w2, C, Cs, s_gz, s_part);         // W2^T gz
+  __syncthreads();
+  for (int i = tid; i < SEF_SB * Cs; i += SEF_THREADS) {
+    const int sm = i / Cs, j = i - sm * Cs;
+    float acc = 0.0f;
+#pragma unroll
+    for (int wv = 0; wv < NWAVE; ++wv) acc += s_part[((size_t)wv * SEF_SB + sm) * Cs + j];
+    float g = 0.0f;
+    if (sm == 0 || has1) {
+      const size_t at = (size_t)(bs + sm) * Cs + j;
+      g = h[at] > 0.0f ? acc : 0.0f;
+      gh[at] = g;
+    }
+    s_gh[i] = g;
+  }
+  __syncthreads();
+  seb_matvec_t(w1, Cs, C, s_gh, s_part);         // W1^T gh
+  __syncthreads();
+  for (int i = tid; i < SEF_SB * C; i += SEF_THREADS) {
+    const int sm = i / C, c = i - sm * C;
+    if (sm && !has1) continue;
+    float acc = 0.0f;
+#pragma unroll
+    for (int wv = 0; wv < NWAVE; ++wv) acc += s_part[((size_t)wv * SEF_SB + sm) * C + c];
+    gp[(size_t)(bs + sm) * C + c] = acc;
+  }
+}
+
 // out[r][q] = sum_b a[b][r] m[b][q] (a [B,R], m [B,Q]), colsum[r] = sum_b a[b][r]: 32 x 32 output tiles, the batch in
-// LDS slices of 32, a thread owns a 2 x 2 block
+// LDS slices of SEO_SLICE = 128 rows (the whole batch of BASELINE configs[2] in ONE load phase: all 32 loads of a thread
+// are in flight together, one barrier pair -- slices of 32 made it four dependent load -> barrier -> compute rounds,
+// 14.5 us for a 21 MFLOP product), a thread owns a 2 x 2 block; sums in batch order.
+#define SEO_SLICE 128
 __global__ __launch_bounds__(SEM_THREADS) void se_outer_sum_kernel(const float* __restrict__ a, const float* __restrict__ m,
                                                                    float* __restrict__ out, float* __restrict__ colsum, int B,
                                                                    int R, int Q) {
-  __shared__ float s_a[32][33], s_m[32][33];
+  __shared__ float s_a[SEO_SLICE][33], s_m[SEO_SLICE][33];
   const int r0 = blockIdx.x * 32, q0 = blockIdx.y * 32, tid = threadIdx.x;
   const int tr = tid >> 4, tq = tid & 15;
+  const int x = tid & 31, brow = tid >> 5;                       // loader: column x of rows brow + 8 i
+  const bool aok = r0 + x < R, mok = q0 + x < Q;
   float acc[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, cs[2] = {0.0f, 0.0f};
-  for (int b0 = 0; b0 < B; b0 += 32) {
-    __syncthreads();
-    for (int i = tid; i < 1024; i += SEM_THREADS) {
-      const int bb = i >> 5, x = i & 31;
-      s_a[bb][x] = (b0 + bb < B && r0 + x < R) ? a[(size_t)(b0 + bb) * R + r0 + x] : 0.0f;
-      s_m[bb][x] = (b0 + bb < B && q0 + x < Q) ? m[(size_t)(b0 + bb) * Q + q0 + x] : 0.0f;
+  for (int b0 = 0; b0 < B; b0 += SEO_SLICE) {
+    float va[SEO_SLICE / 8], vm[SEO_SLICE / 8];
+#pragma unroll
+    for (int i = 0; i < SEO_SLICE / 8; ++i) {
+      const int bb = b0 + brow + 8 * i;
+      va[i] = (bb < B && aok) ? a[(size_t)bb * R + r0 + x] : 0.0f;
+      vm[i] = (bb < B && mok) ? m[(size_t)bb * Q + q0 + x] : 0.0f;
     }
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SEO_SLICE / 8; ++i) { s_a[brow + 8 * i][x] = va[i]; s_m[brow + 8 * i][x] = vm[i]; }
+    __syncthreads();
+    const int nb = min(SEO_SLICE, B - b0);
 #pragma unroll 8
-    for (int bb = 0; bb < 32; ++bb) {
+    for (int bb = 0; bb < nb; ++bb) {
       const float a0 = s_a[bb][2 * tr], a1 = s_a[bb][2 * tr + 1], m0 = s_m[bb][2 * tq], m1 = s_m[bb][2 * tq + 1];
       acc[0][0] = fmaf(a0, m0, acc[0][0]); acc[0][1] = fmaf(a0, m1, acc[0][1]);
       acc[1][0] = fmaf(a1, m0, acc[1][0]); acc[1][1] = fmaf(a1, m1, acc[1][1]);
@@ -233,9 +390,13 @@ __global__ __launch_bounds__(SEM_THREADS) void se_outer_sum_kernel(const float* 
 extern "C" int ias_se_mlp_forward(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
                                   float* h, float* z, float* s, int B, int C, int Cs, void* stream_) {
   if (!pooled || !w1 || !w2 || !h || !z || !s || B <= 0 || C <= 0 || Cs <= 0 || C + Cs > 12288) return IAS_ERR_ARG;
-  const int vec1 = ((C & 3) == 0 && se_aligned16(w1)) ? 1 : 0, vec2 = ((Cs & 3) == 0 && se_aligned16(w2)) ? 1 : 0;
-  hipLaunchKernelGGL(se_mlp_forward_kernel, dim3(B), dim3(SEM_THREADS), sizeof(float) * (size_t)(C + Cs), (hipStream_t)stream_,
-                     pooled, w1, b1, w2, b2, h, z, s, C, Cs, vec1, vec2);
+  // 16-byte accesses: rows of w1 (C floats) / w2 (Cs floats) and the LDS vectors [SEF_SB][C], [SEF_SB][Cs] behind them
+  const int vec1 = ((C & 3) == 0 && se_aligned16(w1)) ? 1 : 0, vec2 = ((Cs & 3) == 0 && (C & 3) == 0 && se_aligned16(w2)) ? 1 : 0;
+  (void)hipFuncSetAttribute((const void*)se_mlp_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)(sizeof(float) * (size_t)SEF_SB * (C + Cs)));
+  hipLaunchKernelGGL(se_mlp_forward_kernel, dim3((B + SEF_SB - 1) / SEF_SB), dim3(SEF_THREADS),
+                     sizeof(float) * (size_t)SEF_SB * (C + Cs), (hipStream_t)stream_, pooled, w1, b1, w2, b2, h, z, s, B, C, Cs, vec1,
+                     vec2);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
@@ -248,8 +409,16 @@ extern "C" int ias_se_mlp_backward(const float* gs, const float* z, const float*
       C + Cs > 12288)
     return IAS_ERR_ARG;
   hipStream_t st = (hipStream_t)stream_;
-  hipLaunchKernelGGL(se_mlp_backward_sample_kernel, dim3(B), dim3(SEM_THREADS), sizeof(float) * (size_t)(C + Cs), st, gs, z, h,
-                     w1, w2, gz, gh, gp, C, Cs);
+  if ((C & 3) == 0 && (Cs & 3) == 0 && C <= SEB_MAXW && Cs <= SEB_MAXW && se_aligned16(w1) && se_aligned16(w2)) {
+    const int wmax = C > Cs ? C : Cs;
+    const size_t lds = sizeof(float) * ((size_t)SEF_SB * (C + Cs) + (size_t)(SEF_THREADS / 64) * SEF_SB * wmax);
+    (void)hipFuncSetAttribute((const void*)se_mlp_backward_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(se_mlp_backward_pair_kernel, dim3((B + SEF_SB - 1) / SEF_SB), dim3(SEF_THREADS), lds, st, gs, z, h, w1, w2,
+                       gz, gh, gp, B, C, Cs);
+  } else {
+    hipLaunchKernelGGL(se_mlp_backward_sample_kernel, dim3(B), dim3(SEM_THREADS), sizeof(float) * (size_t)(C + Cs), st, gs, z, h,
+                       w1, w2, gz, gh, gp, C, Cs);
+  }
   hipLaunchKernelGGL(se_outer_sum_kernel, dim3((C + 31) / 32, (Cs + 31) / 32), dim3(SEM_THREADS), 0, st, gz, h, gw2, gb2, B, C, Cs);
   hipLaunchKernelGGL(se_outer_sum_kernel, dim3((Cs + 31) / 32, (C + 31) / 32), dim3(SEM_THREADS), 0, st, gh, pooled, gw1, gb1, B, Cs, C);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;

@@ -159,7 +159,8 @@ def test_head_conv2x2_matches_torch(lib, dev, B, H, W, C, Cout):
 
 
 @pytest.mark.parametrize("B,C,Cs,H,W", [(4, 16, 8, 60, 62), (3, 96, 24, 15, 16), (2, 576, 144, 8, 8), (2, 8, 8, 3, 3),
-                                        (5, 12, 4, 7, 10)])
+                                        (5, 12, 4, 7, 10), (128, 240, 64, 15, 16), (130, 120, 32, 4, 4), (3, 10, 6, 5, 5),
+                                        (2, 1028, 260, 2, 2), (1, 288, 72, 8, 8)])
 def test_squeeze_excitation_matches_torch(lib, dev, B, C, Cs, H, W):
     """SqueezeExcitation on the device (csrc/se_kernels.hip + GEMMs) against the same block written with torch ops in
     fp64: output, input gradient and the four parameter gradients."""
