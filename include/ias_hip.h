@@ -357,7 +357,8 @@ int ias_conv_out_size(int n, int K, int S);
 int ias_dwconv_forward(const float* x, const float* w, float* out, int B, int C, int H, int W, int K, int S, void* stream);
 int ias_dwconv_backward_data(const float* g, const float* w, float* gx, int B, int C, int H, int W, int K, int S,
                              void* stream);
-long long ias_dwconv_weight_scratch(int B, int C, int K);     /* floats */
+long long ias_dwconv_weight_scratch(int B, int C, int K);     /* floats: upper bound for any plane size */
+long long ias_dwconv_weight_scratch_hw(int B, int C, int H, int W, int K, int S);   /* floats, for this plane size */
 int ias_dwconv_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int C, int H, int W,
                                int K, int S, void* stream);
 /* Conv2d(3, 16, 3, stride 2, padding 1, bias=False): x [B,3,H,W], w [16,3,3,3] -> out [B,16,Ho,Wo]; weight gradient. */

@@ -97,6 +97,7 @@ SYMBOLS = {
     "ias_dwconv_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ias_dwconv_backward_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ias_dwconv_weight_scratch": (_LL, [_I, _I, _I]),
+    "ias_dwconv_weight_scratch_hw": (_LL, [_I, _I, _I, _I, _I, _I]),
     "ias_dwconv_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ias_pwconv_supported": (_I, [_I, _I]),
     "ias_pwconv_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

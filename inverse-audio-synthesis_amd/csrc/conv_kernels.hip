@@ -81,7 +81,8 @@ __global__ __launch_bounds__(CV_THREADS) void dw_tile_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < (MODE == 1 ? KK : 1); ++i) aw[i] = 0.0f;
 
-  for (int r0 = 0; r0 < Ho; r0 += rows_out) {
+  // row tiles of a large plane: one per blockIdx.y (gridDim.y = number of tiles; 1: the loop walks them)
+  for (int r0 = blockIdx.y * rows_out; r0 < Ho; r0 += gridDim.y * rows_out) {
     const int nr = min(rows_out, Ho - r0);
     // MODE 1: the cotangents of this thread's first two items, requested BEFORE the tile so that they arrive with it
     float gpre[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
@@ -178,8 +179,204 @@ __global__ __launch_bounds__(CV_THREADS) void dw_tile_kernel(const float* __rest
       const int pl = i / KK, t = i - pl * KK;
       float v = 0.0f;
       for (int j = 0; j < tpp; ++j) v += s_w[(pl * tpp + j) * KK + t];
-      out[(size_t)(p0 + pl) * KK + t] = v;
+      out[((size_t)blockIdx.y * planes + p0 + pl) * KK + t] = v;     // [tile][b][c][K K]
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small planes (round 4): ONE WAVE owns whole planes and streams through them.  dw_tile_kernel gives four 15 x 16 planes
+// to a workgroup that loads, waits, computes, stores and retires: 7680 short-lived workgroups at four per CU (100 VGPRs at
+// k = 5), every one of them exposed to a full memory latency -- 31 us for 59 MB.  Here a workgroup IS one wave (the barrier
+// is free), it walks groups of PW = 64 / tpp consecutive planes with a stride of the grid, and the loads of its next group
+// (at most DWW_NL per lane, contiguous: PW planes are one run of PW H W floats) are issued before it computes the current
+// one; the halo is zeroed once (the geometry never changes), every index decode happens once per lane, before the loop.
+// MODE 0: out = conv(x, w) (flip: taps reversed = the stride-1 input gradient).
+// MODE 1: weight gradient.  A group is then PW consecutive CHANNELS of one sample and a wave walks `bch` samples of
+//         its channels before it folds its lanes' K K sums (DPP row sums + four readlanes per tap) and writes one partial
+//         per channel: partial[batch chunk][c][K K], added in chunk order by conv_reduce_partials_kernel.
+#define DWW_NL 16        // staged elements per lane and group: PW H W <= 1024
+#define DWW_NI 4         // items (four outputs of a row) per lane: Ho quads <= 4 tpp
+__device__ __forceinline__ float dww_row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124 /* row_ror:4 */, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xf, 0xf, true));
+  return v;
+}
+struct DwWave { int PW, tpp, Wp, rows_in, nl, ni, bch; unsigned mHW, mW, mQ; size_t lds; bool ok; };
+__device__ __forceinline__ int dww_div(int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; }   // (m = 0: divisor 1)
+// NL / NI: compile-time bounds of geo.nl / geo.ni (register arrays): (4, 1) the 15 x 16 and 8 x 8 planes, (16, 1), (16, 4)
+template <int K, int S, int MODE, int NL, int NI>
+__global__ __launch_bounds__(64) void dw_wave_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ g, float* __restrict__ out, int B, int C, int H,
+                                                     int W, int Ho, int Wo, int flip, const DwWave geo, int nwork) {
+  constexpr int P = (K - 1) / 2, KK = K * K, NSEG4 = (3 * S + K + 3) / 4;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float s_dw[];
+  const int PW = geo.PW, tpp = geo.tpp, Wp = geo.Wp, rows_in = geo.rows_in, HW = H * W;
+  float* s_x = s_dw;                                   // [PW][rows_in][Wp]
+  float* s_w = s_dw + PW * rows_in * Wp;               // [PW][KK] (MODE 0)
+  const int lane = threadIdx.x, slot = lane / tpp, tl = lane - slot * tpp;
+  const int quads = (Wo + 3) >> 2, nitems = Ho * quads, planes = B * C;
+  for (int i = lane; i < PW * rows_in * Wp; i += 64) s_x[i] = 0.0f;          // the halo stays zero
+  // once per lane: where its staged elements go, which items it computes
+  int soff[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int idx = lane + 64 * i;
+    soff[i] = -1;
+    if (i < geo.nl && idx < PW * HW) {
+      const int pl = dww_div(idx, geo.mHW), rem = idx - pl * HW;
+      const int hi = dww_div(rem, geo.mW), wi = rem - hi * W;
+      soff[i] = (pl * rows_in + hi + P) * Wp + wi + P;
+    }
+  }
+  int irow[NI], iq[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int item = tl + j * tpp;
+    irow[j] = -1; iq[j] = 0;
+    if (j < geo.ni && item < nitems) { irow[j] = dww_div(item, geo.mQ); iq[j] = item - irow[j] * quads; }
+  }
+  // work decomposition
+  const int cgroups = (C + PW - 1) / PW;                // MODE 1: channel groups per sample
+  const int bch = geo.bch;
+  float v[NL], wreg[2] = {0.0f, 0.0f}, gv[MODE == 1 ? NI : 1][4];
+  float aw[MODE == 1 ? KK : 1];
+  // first plane and number of valid planes of (work item, step)
+  auto group_of = [&](int work, int step, int& p_start, int& nvalid) {
+    if (MODE == 0) {
+      p_start = work * PW;
+      nvalid = min(PW, planes - p_start);
+    } else {
+      const int bc = work / cgroups, cg = work - bc * cgroups, b = bc * bch + step;
+      p_start = b * C + cg * PW;
+      nvalid = b < B ? min(PW, C - cg * PW) : 0;
+    }
+  };
+  auto issue = [&](int work, int step) {
+    int p_start, nvalid;
+    group_of(work, step, p_start, nvalid);
+    const float* src = x + (size_t)p_start * HW;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int idx = lane + 64 * i;
+      v[i] = (soff[i] >= 0 && idx < nvalid * HW) ? src[idx] : 0.0f;
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = lane + 64 * u;
+        if (i < PW * KK) {
+          const int pl = i / KK, t = i - pl * KK;
+          wreg[u] = pl < nvalid ? w[((p_start + pl) % C) * KK + (flip ? KK - 1 - t : t)] : 0.0f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          gv[j][e] = 0.0f;
+          if (irow[j] >= 0 && slot < nvalid && iq[j] * 4 + e < Wo)
+            gv[j][e] = g[(size_t)(p_start + slot) * Ho * Wo + irow[j] * Wo + iq[j] * 4 + e];
+        }
+    }
+  };
+  const int nsteps = MODE == 1 ? bch : 1;
+  int work = blockIdx.x, step = 0;
+  if (work < nwork) issue(work, 0);
+  __syncthreads();
+  while (work < nwork) {
+    if (MODE == 1 && step == 0) {
+#pragma unroll
+      for (int i = 0; i < KK; ++i) aw[i] = 0.0f;
+    }
+    int p_start, nvalid;
+    group_of(work, step, p_start, nvalid);
+    // registers -> LDS (interior only), then the next group's loads go out before the arithmetic
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (soff[i] >= 0) s_x[soff[i]] = v[i];
+    float gcur[MODE == 1 ? NI : 1][4];
+    if (MODE == 0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (lane + 64 * u < PW * KK) s_w[lane + 64 * u] = wreg[u];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gcur[j][e] = gv[j][e];
+    }
+    int nwork_i = work, nstep = step + 1;
+    if (nstep >= nsteps) { nstep = 0; nwork_i = work + gridDim.x; }
+    if (nwork_i < nwork) issue(nwork_i, nstep);
+    __syncthreads();
+    if (slot < nvalid) {
+      const size_t obase = (size_t)(p_start + slot) * Ho * Wo;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if (irow[j] < 0) continue;
+        const int r = irow[j], q = iq[j];
+        const float* row0 = s_x + (slot * rows_in + r * S) * Wp + q * 4 * S;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+          float seg[4 * NSEG4];
+#pragma unroll
+          for (int u = 0; u < NSEG4; ++u) {
+            const f4 t = *reinterpret_cast<const f4*>(row0 + kh * Wp + 4 * u);
+            seg[4 * u] = t[0]; seg[4 * u + 1] = t[1]; seg[4 * u + 2] = t[2]; seg[4 * u + 3] = t[3];
+          }
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            if (MODE == 0) {
+              const float wt = s_w[slot * KK + kh * K + kw];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[e] = fmaf(wt, seg[e * S + kw], acc[e]);
+            } else {
+              float t = aw[kh * K + kw];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) t = fmaf(gcur[j][e], seg[e * S + kw], t);
+              aw[kh * K + kw] = t;
+            }
+          }
+        }
+        if (MODE == 0) {
+          float* dst = out + obase + r * Wo + q * 4;
+          if ((Wo & 3) == 0) {
+            *reinterpret_cast<f4*>(dst) = (f4){acc[0], acc[1], acc[2], acc[3]};   // (plane sizes Ho Wo with Wo % 4 == 0: 16-byte aligned)
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (q * 4 + e < Wo) dst[e] = acc[e];
+          }
+        }
+      }
+    }
+    if (MODE == 1 && nstep == 0) {
+      // fold the lanes of each plane slot: 16-lane row sums on the DPP path, rows met through readlane (fixed order)
+      const int bc = work / cgroups, cg = work - bc * cgroups;
+      const int rows_per_slot = tpp >> 4;                // tpp in {16, 32, 64}
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const float rs = dww_row16_sum(aw[t]);
+        const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 0));
+        const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 16));
+        const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 32));
+        const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 48));
+        float tot;
+        if (rows_per_slot == 4) tot = (r0 + r1) + (r2 + r3);
+        else if (rows_per_slot == 2) tot = lane == 0 ? r0 + r1 : r2 + r3;
+        else tot = lane == 0 ? r0 : lane == 1 ? r1 : lane == 2 ? r2 : r3;
+        const int c = cg * PW + lane;                    // lane s < PW writes slot s
+        if (lane < PW && c < C) out[((size_t)bc * C + c) * KK + t] = tot;
+      }
+    }
+    __syncthreads();                                     // the tile has been read: the next one may be written
+    work = nwork_i; step = nstep;
   }
 }
 
@@ -190,7 +387,7 @@ __global__ __launch_bounds__(CV_THREADS) void dw_tile_kernel(const float* __rest
 template <int K>
 __global__ __launch_bounds__(CV_THREADS) void dw_tile_bwd_s2_kernel(const float* __restrict__ g, const float* __restrict__ w,
                                                                     float* __restrict__ gx, int C, int H, int W, int Ho,
-                                                                    int Wo, int planes, int pp) {
+                                                                    int Wo, int planes, int pp, unsigned mWp, unsigned mRows) {
   constexpr int P = (K - 1) / 2, KK = K * K;
   extern __shared__ __attribute__((aligned(16))) float s_dw[];
   const int Wp = Wo + 2, rows = Ho + 2;
@@ -201,12 +398,21 @@ __global__ __launch_bounds__(CV_THREADS) void dw_tile_bwd_s2_kernel(const float*
   const int tpp = CV_THREADS / pp, slot = tid / tpp, tl = tid - slot * tpp;
   for (int i = tid; i < npl * KK; i += CV_THREADS) s_w[i] = w[((p0 + i / KK) % C) * KK + i % KK];
   const int stage_n = npl * rows * Wp;
-#pragma unroll 4
-  for (int idx = tid; idx < stage_n; idx += CV_THREADS) {
-    const int pr = idx / Wp, col = idx - pr * Wp;
-    const int pl = pr / rows, ho = pr - pl * rows - 1;
-    const bool ok = ho >= 0 && ho < Ho && col >= 1 && col <= Wo;
-    s_g[idx] = ok ? g[((size_t)(p0 + pl) * Ho + ho) * Wo + col - 1] : 0.0f;
+  for (int base = tid; base < stage_n; base += DW_NB * CV_THREADS) {     // DW_NB loads in flight per thread (see dw_tile_kernel)
+    float v[DW_NB];
+#pragma unroll
+    for (int u = 0; u < DW_NB; ++u) {
+      const int idx = base + u * CV_THREADS;
+      const int pr = (int)__umulhi((unsigned)idx, mWp), col = idx - pr * Wp;
+      const int pl = (int)__umulhi((unsigned)pr, mRows), ho = pr - pl * rows - 1;
+      const bool ok = idx < stage_n && ho >= 0 && ho < Ho && col >= 1 && col <= Wo;
+      v[u] = ok ? g[((size_t)(p0 + pl) * Ho + ho) * Wo + col - 1] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < DW_NB; ++u) {
+      const int idx = base + u * CV_THREADS;
+      if (idx < stage_n) s_g[idx] = v[u];
+    }
   }
   __syncthreads();
   if (slot >= npl) return;
@@ -242,9 +448,10 @@ __global__ __launch_bounds__(CV_THREADS) void dw_tile_bwd_s2_kernel(const float*
   }
 }
 
-struct DwTile { int pp, rows_out, Wp; size_t lds; unsigned mWp, mRows; };
+struct DwTile { int pp, rows_out, Wp, ntiles; size_t lds; unsigned mWp, mRows; };
+#define DW_MAX_TILES 8
 // floor(n / d) = umulhi(n, dw_magic(d)) for n < 2^20, d < 2^11 (the staged tile's index space)
-static unsigned dw_magic(int d) { return d <= 1 ? 0xffffffffu : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+static unsigned dw_magic(int d) { return d <= 1 ? 0u /* callers never divide by 1 this way */ : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 static DwTile dw_tile_geometry(int H, int W, int Ho, int Wo, int K, int S, int mode) {
   (void)H;
   const int P = (K - 1) / 2, quads = (Wo + 3) / 4, nseg4 = (3 * S + K + 3) / 4;
@@ -261,12 +468,18 @@ static DwTile dw_tile_geometry(int H, int W, int Ho, int Wo, int K, int S, int m
     while (pp * 2 <= 64 && pp * 2 * rows_full * Wp <= budget && pp * 2 * Ho * quads <= CV_THREADS) pp *= 2;
     t.pp = pp;
   } else {
-    int rin = budget / Wp;
+    // a plane too large for one workgroup: row tiles of half the budget (16 KB: ten workgroups per CU), one workgroup each
+    // (the first layer's 2048 planes as 2048 workgroups walking two 32 KB tiles each ran 1.6 resident rounds at 60 us)
+    int rin = budget / 2 / Wp;
     int ro = (rin - K) / S + 1;
     if (ro < 1) ro = 1;
+    if ((Ho + ro - 1) / ro > DW_MAX_TILES) ro = (Ho + DW_MAX_TILES - 1) / DW_MAX_TILES;
+    if (((ro - 1) * S + K) * Wp > budget) ro = ((budget / Wp) - K) / S + 1 < 1 ? 1 : ((budget / Wp) - K) / S + 1;   // (very wide rows)
     t.rows_out = ro;
     t.pp = 1;
   }
+  t.ntiles = (Ho + t.rows_out - 1) / t.rows_out;
+  if (t.ntiles > DW_MAX_TILES) t.ntiles = 1;            // (the kernel then walks the tiles itself)
   t.Wp = Wp;
   const int rows_in = (t.rows_out - 1) * S + K;
   t.lds = sizeof(float) * ((size_t)t.pp * rows_in * Wp + (mode == 1 ? (size_t)CV_THREADS * K * K : (size_t)t.pp * K * K));
@@ -502,6 +715,55 @@ static int cv_check(const void* a, const void* b, const void* c, int B, int C, i
 
 extern "C" int ias_conv_out_size(int n, int K, int S) { return (n + 2 * ((K - 1) / 2) - K) / S + 1; }
 
+// geometry of dw_wave_kernel for x [B,C,H,W] -> [.,.,Ho,Wo]; ok = false: the plane is too large for a wave (dw_tile_kernel)
+static DwWave dw_wave_geometry(int B, int H, int W, int Ho, int Wo, int K, int S) {
+  DwWave g;
+  g.ok = false;
+  static const bool off = getenv("IAS_DW_NO_WAVE") != nullptr;
+  const int P = (K - 1) / 2, quads = (Wo + 3) / 4, nseg4 = (3 * S + K + 3) / 4, nitems = Ho * quads, HW = H * W;
+  if (off || HW > 64 * DWW_NL || nitems > 64 * DWW_NI) return g;
+  int tpp = nitems <= 16 ? 16 : nitems <= 32 ? 32 : 64;
+  while (tpp < 64 && (64 / tpp) * HW > 64 * DWW_NL) tpp *= 2;
+  g.tpp = tpp;
+  g.PW = 64 / tpp;
+  int Wp = W + 2 * P;
+  const int need = (quads - 1) * 4 * S + 4 * nseg4;
+  if (Wp < need) Wp = need;
+  g.Wp = (Wp + 3) & ~3;
+  g.rows_in = (Ho - 1) * S + K;
+  g.nl = (g.PW * HW + 63) / 64;
+  g.ni = (nitems + tpp - 1) / tpp;
+  g.bch = B < 8 ? B : 8;
+  g.mHW = HW > 1 ? dw_magic(HW) : 0;
+  g.mW = W > 1 ? dw_magic(W) : 0;
+  g.mQ = quads > 1 ? dw_magic(quads) : 0;
+  g.lds = sizeof(float) * ((size_t)g.PW * g.rows_in * g.Wp + (size_t)g.PW * K * K);
+  g.ok = g.nl <= DWW_NL && g.ni <= DWW_NI && g.lds <= 10240 && (size_t)g.PW * g.rows_in * g.Wp < (1u << 20);
+  return g;
+}
+#define DW_WAVE_DISPATCH_KS(MODE, NL, NI, ...)                                                              \
+  do {                                                                                                   \
+    if (K == 3 && S == 1) hipLaunchKernelGGL((dw_wave_kernel<3, 1, MODE, NL, NI>), __VA_ARGS__);         \
+    else if (K == 3 && S == 2) hipLaunchKernelGGL((dw_wave_kernel<3, 2, MODE, NL, NI>), __VA_ARGS__);    \
+    else if (K == 5 && S == 1) hipLaunchKernelGGL((dw_wave_kernel<5, 1, MODE, NL, NI>), __VA_ARGS__);    \
+    else if (K == 5 && S == 2) hipLaunchKernelGGL((dw_wave_kernel<5, 2, MODE, NL, NI>), __VA_ARGS__);    \
+    else return IAS_ERR_UNSUPPORTED;                                                                     \
+  } while (0)
+#define DW_WAVE_DISPATCH(MODE, WG, ...)                                                                    \
+  do {                                                                                                   \
+    if ((WG).nl <= 4 && (WG).ni <= 1) DW_WAVE_DISPATCH_KS(MODE, 4, 1, __VA_ARGS__);                       \
+    else if ((WG).ni <= 1) DW_WAVE_DISPATCH_KS(MODE, 16, 1, __VA_ARGS__);                                 \
+    else DW_WAVE_DISPATCH_KS(MODE, 16, 4, __VA_ARGS__);                                                   \
+  } while (0)
+// waves in the grid: every CU full at this LDS footprint (at most 32 waves), never more than there is work
+static int dw_wave_grid(const DwWave& g, int nwork) {
+  int per_cu = (int)((size_t)160 * 1024 / (g.lds ? g.lds : 1));
+  if (per_cu > 32) per_cu = 32;
+  if (per_cu < 1) per_cu = 1;
+  const long long full = 256LL * per_cu;
+  return (int)(nwork < full ? nwork : full);
+}
+
 // Depthwise Conv2d(C, C, K, stride S, padding (K-1)/2, groups=C, bias=False) forward: x [B,C,H,W], w [C,1,K,K] -> out
 #define DW_TILE_DISPATCH(MODE, ...)                                                                       \
   do {                                                                                                   \
@@ -517,9 +779,16 @@ extern "C" int ias_dwconv_forward(const float* x, const float* w, float* out, in
   int rc = cv_check(x, w, out, B, C, H, W, K, S);
   if (rc) return rc;
   const int Ho = ias_conv_out_size(H, K, S), Wo = ias_conv_out_size(W, K, S);
-  const DwTile t = dw_tile_geometry(H, W, Ho, Wo, K, S, 0);
   const int planes = B * C;
-  DW_TILE_DISPATCH(0, dim3((planes + t.pp - 1) / t.pp), dim3(CV_THREADS), t.lds, (hipStream_t)stream_, x, w,
+  const DwWave wg = dw_wave_geometry(B, H, W, Ho, Wo, K, S);
+  if (wg.ok) {
+    const int nwork = (planes + wg.PW - 1) / wg.PW;
+    DW_WAVE_DISPATCH(0, wg, dim3(dw_wave_grid(wg, nwork)), dim3(64), wg.lds, (hipStream_t)stream_, x, w, (const float*)nullptr, out, B, C,
+                     H, W, Ho, Wo, 0, wg, nwork);
+    return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+  }
+  const DwTile t = dw_tile_geometry(H, W, Ho, Wo, K, S, 0);
+  DW_TILE_DISPATCH(0, dim3((planes + t.pp - 1) / t.pp, t.ntiles), dim3(CV_THREADS), t.lds, (hipStream_t)stream_, x, w,
                    (const float*)nullptr, out, C, H, W, Ho, Wo, planes, t.pp, t.rows_out, t.Wp, 0, t.mWp, t.mRows);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
@@ -531,9 +800,16 @@ extern "C" int ias_dwconv_backward_data(const float* g, const float* w, float* g
   if (rc) return rc;
   const int Ho = ias_conv_out_size(H, K, S), Wo = ias_conv_out_size(W, K, S);
   if (S == 1) {   // Ho = H, Wo = W: the same convolution of g with the taps reversed
-    const DwTile t = dw_tile_geometry(Ho, Wo, H, W, K, 1, 0);
     const int planes = B * C;
-    DW_TILE_DISPATCH(0, dim3((planes + t.pp - 1) / t.pp), dim3(CV_THREADS), t.lds, (hipStream_t)stream_, g, w,
+    const DwWave wg = dw_wave_geometry(B, Ho, Wo, H, W, K, 1);
+    if (wg.ok) {
+      const int nwork = (planes + wg.PW - 1) / wg.PW;
+      DW_WAVE_DISPATCH(0, wg, dim3(dw_wave_grid(wg, nwork)), dim3(64), wg.lds, (hipStream_t)stream_, g, w, (const float*)nullptr, gx, B,
+                       C, Ho, Wo, H, W, 1, wg, nwork);
+      return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+    }
+    const DwTile t = dw_tile_geometry(Ho, Wo, H, W, K, 1, 0);
+    DW_TILE_DISPATCH(0, dim3((planes + t.pp - 1) / t.pp, t.ntiles), dim3(CV_THREADS), t.lds, (hipStream_t)stream_, g, w,
                      (const float*)nullptr, gx, C, Ho, Wo, H, W, planes, t.pp, t.rows_out, t.Wp, 1, t.mWp, t.mRows);
   } else if ((size_t)(Ho + 2) * (Wo + 2) <= 12288 && !getenv("IAS_DW_S2_DIRECT")) {
     const int planes = B * C, plane_lds = (Ho + 2) * (Wo + 2);
@@ -541,8 +817,8 @@ extern "C" int ias_dwconv_backward_data(const float* g, const float* w, float* g
     while (pp * 2 <= 64 && pp * 2 * plane_lds <= 8192 && pp * 2 * Ho * Wo <= CV_THREADS) pp *= 2;
     const size_t lds = sizeof(float) * ((size_t)pp * plane_lds + (size_t)pp * K * K);
     const dim3 grid((planes + pp - 1) / pp), block(CV_THREADS);
-    if (K == 3) hipLaunchKernelGGL((dw_tile_bwd_s2_kernel<3>), grid, block, lds, (hipStream_t)stream_, g, w, gx, C, H, W, Ho, Wo, planes, pp);
-    else hipLaunchKernelGGL((dw_tile_bwd_s2_kernel<5>), grid, block, lds, (hipStream_t)stream_, g, w, gx, C, H, W, Ho, Wo, planes, pp);
+    if (K == 3) hipLaunchKernelGGL((dw_tile_bwd_s2_kernel<3>), grid, block, lds, (hipStream_t)stream_, g, w, gx, C, H, W, Ho, Wo, planes, pp, dw_magic(Wo + 2), dw_magic(Ho + 2));
+    else hipLaunchKernelGGL((dw_tile_bwd_s2_kernel<5>), grid, block, lds, (hipStream_t)stream_, g, w, gx, C, H, W, Ho, Wo, planes, pp, dw_magic(Wo + 2), dw_magic(Ho + 2));
   } else {      // a plane too large for LDS: taps from global memory
     const dim3 grid(B * C, cv_grid_x(H * W)), block(CV_THREADS);
     CV_DISPATCH(dwconv_bwd_data_kernel, grid, block, 0, (hipStream_t)stream_, g, w, gx, C, H, W, Ho, Wo);
@@ -550,10 +826,16 @@ extern "C" int ias_dwconv_backward_data(const float* g, const float* w, float* g
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
-// floats of scratch for ias_dwconv_backward_weight: one K x K partial per (b, c) plane
+// floats of scratch for ias_dwconv_backward_weight: one K x K partial per (b, c) plane and row tile (large planes are cut
+// into up to DW_MAX_TILES row tiles, one workgroup each); without the plane's size: the upper bound
 extern "C" long long ias_dwconv_weight_scratch(int B, int C, int K) {
   if (B <= 0 || C <= 0 || K <= 0) return IAS_ERR_ARG;
-  return (long long)B * C * K * K;
+  return (long long)B * C * K * K * DW_MAX_TILES;
+}
+extern "C" long long ias_dwconv_weight_scratch_hw(int B, int C, int H, int W, int K, int S) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !((K == 3 || K == 5) && (S == 1 || S == 2))) return IAS_ERR_ARG;
+  const int Ho = ias_conv_out_size(H, K, S), Wo = ias_conv_out_size(W, K, S);
+  return (long long)B * C * K * K * dw_tile_geometry(H, W, Ho, Wo, K, S, 1).ntiles;
 }
 
 // its gradient w.r.t. the weights: x [B,C,H,W], g [B,C,Ho,Wo] -> gw [C,1,K,K]; scratch: ias_dwconv_weight_scratch floats
@@ -563,13 +845,24 @@ extern "C" int ias_dwconv_backward_weight(const float* x, const float* g, float*
   if (rc) return rc;
   if (!scratch) return IAS_ERR_ARG;
   const int Ho = ias_conv_out_size(H, K, S), Wo = ias_conv_out_size(W, K, S);
-  const DwTile t = dw_tile_geometry(H, W, Ho, Wo, K, S, 1);
   const int planes = B * C;
-  DW_TILE_DISPATCH(1, dim3((planes + t.pp - 1) / t.pp), dim3(CV_THREADS), t.lds, (hipStream_t)stream_, x,
+  const DwWave wg = dw_wave_geometry(B, H, W, Ho, Wo, K, S);
+  if (wg.ok) {
+    // partial[batch chunk][c][K K]: ceil(B / bch) chunks <= B, inside the scratch of any sizing call
+    const int cgroups = (C + wg.PW - 1) / wg.PW, nchunk = (B + wg.bch - 1) / wg.bch, nwork = cgroups * nchunk;
+    DW_WAVE_DISPATCH(1, wg, dim3(dw_wave_grid(wg, nwork)), dim3(64), wg.lds, (hipStream_t)stream_, x, (const float*)nullptr, g, scratch, B,
+                     C, H, W, Ho, Wo, 0, wg, nwork);
+    const int n = C * K * K;
+    hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((n + 3) / 4), dim3(CV_THREADS), 0, (hipStream_t)stream_, scratch, gw, n,
+                       nchunk);
+    return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+  }
+  const DwTile t = dw_tile_geometry(H, W, Ho, Wo, K, S, 1);
+  DW_TILE_DISPATCH(1, dim3((planes + t.pp - 1) / t.pp, t.ntiles), dim3(CV_THREADS), t.lds, (hipStream_t)stream_, x,
                    (const float*)nullptr, g, scratch, C, H, W, Ho, Wo, planes, t.pp, t.rows_out, t.Wp, 0, t.mWp, t.mRows);
-  const int n = C * K * K;   // scratch is [b][c][K K]: the planes of a channel are n floats apart
+  const int n = C * K * K;   // scratch is [tile][b][c][K K]: the partials of a channel are n floats apart
   hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((n + 3) / 4), dim3(CV_THREADS), 0, (hipStream_t)stream_, scratch, gw,
-                     n, B);
+                     n, B * t.ntiles);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 

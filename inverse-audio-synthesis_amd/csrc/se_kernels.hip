@@ -141,37 +141,74 @@ __device__ __forceinline__ float sem_row16_sum(float v) {
 // the 8 waves on 32.  Every workgroup still reads both weight matrices, but 64 workgroups do instead of 128.
 #define SEF_SB 2
 #define SEF_THREADS 512
-// out[s][o] = sum_k w[o][k] v[s][k] (+ bias[o]); v [SEF_SB][K] in LDS
+// out[s][o] = sum_k w[o][k] v[s][k] (+ bias[o]); v [SEF_SB][K] in LDS.  A 16-lane group works on SEF_RU rows at once
+// (rows g, g + 32, ... of a round of 32 SEF_RU) and takes two 64-float steps of k per iteration: 2 SEF_RU 16-byte loads in
+// flight per lane (with one, the C = 576 block waited out 80 L2 latencies: 53 us).
+#define SEF_RU 4
 template <typename Epilogue>
 __device__ __forceinline__ void sef_layer(const float* __restrict__ w, const float* __restrict__ bias, const float* s_v, int K,
                                           int O, bool vec, Epilogue&& done) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane & 15, rsel = lane >> 4;
-  constexpr int RPW = 4, RPG = RPW * (SEF_THREADS / 64);         // rows per wave and round / per workgroup and round
+  const int sub = lane & 15, grp = wave * 4 + (lane >> 4);       // 32 groups of 16 lanes
+  constexpr int NGRP = SEF_THREADS / 16, RPG = NGRP * SEF_RU;    // rows per workgroup and round
   for (int o0 = 0; o0 < O; o0 += RPG) {                          // (uniform trip count: the DPP folds need whole rows of lanes)
-    const int o = o0 + wave * RPW + rsel;
-    const bool ok = o < O;
-    const float* row = w + (size_t)(ok ? o : 0) * K;
-    float a0 = 0.f, a1 = 0.f;
-    if (vec) {
-      for (int k = 4 * sub; k < K; k += 64) {
-        const f4 wv = *reinterpret_cast<const f4*>(row + k);
-        const f4 v0 = *reinterpret_cast<const f4*>(s_v + k), v1 = *reinterpret_cast<const f4*>(s_v + K + k);
+    const float* row[SEF_RU];
+    float a0[SEF_RU], a1[SEF_RU];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { a0 = fmaf(wv[e], v0[e], a0); a1 = fmaf(wv[e], v1[e], a1); }
+    for (int u = 0; u < SEF_RU; ++u) {
+      const int o = o0 + grp + NGRP * u;
+      row[u] = w + (size_t)(o < O ? o : 0) * K;
+      a0[u] = 0.f; a1[u] = 0.f;
+    }
+    if (vec) {
+      int k = 4 * sub;
+      for (; k + 64 < K; k += 128) {
+        f4 wa[SEF_RU], wb[SEF_RU];
+#pragma unroll
+        for (int u = 0; u < SEF_RU; ++u) { wa[u] = *reinterpret_cast<const f4*>(row[u] + k); wb[u] = *reinterpret_cast<const f4*>(row[u] + k + 64); }
+        const f4 va0 = *reinterpret_cast<const f4*>(s_v + k), va1 = *reinterpret_cast<const f4*>(s_v + K + k);
+        const f4 vb0 = *reinterpret_cast<const f4*>(s_v + k + 64), vb1 = *reinterpret_cast<const f4*>(s_v + K + k + 64);
+#pragma unroll
+        for (int u = 0; u < SEF_RU; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a0[u] = fmaf(wa[u][e], va0[e], a0[u]); a1[u] = fmaf(wa[u][e], va1[e], a1[u]);
+            a0[u] = fmaf(wb[u][e], vb0[e], a0[u]); a1[u] = fmaf(wb[u][e], vb1[e], a1[u]);
+          }
+      }
+      for (; k < K; k += 64) {
+        f4 wa[SEF_RU];
+#pragma unroll
+        for (int u = 0; u < SEF_RU; ++u) wa[u] = *reinterpret_cast<const f4*>(row[u] + k);
+        const f4 va0 = *reinterpret_cast<const f4*>(s_v + k), va1 = *reinterpret_cast<const f4*>(s_v + K + k);
+#pragma unroll
+        for (int u = 0; u < SEF_RU; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a0[u] = fmaf(wa[u][e], va0[e], a0[u]); a1[u] = fmaf(wa[u][e], va1[e], a1[u]); }
       }
     } else {
       for (int k = sub; k < K; k += 16) {
-        const float wv = row[k];
-        a0 = fmaf(wv, s_v[k], a0); a1 = fmaf(wv, s_v[K + k], a1);
+        const float v0 = s_v[k], v1 = s_v[K + k];
+#pragma unroll
+        for (int u = 0; u < SEF_RU; ++u) {
+          const float wv = row[u][k];
+          a0[u] = fmaf(wv, v0, a0[u]); a1[u] = fmaf(wv, v1, a1[u]);
+        }
       }
     }
-    a0 = sem_row16_sum(a0);
-    a1 = sem_row16_sum(a1);
-    if (ok && sub == 0) {
-      const float b0 = bias ? bias[o] : 0.0f;
-      done(o, a0 + b0, a1 + b0);
+#pragma unroll
+    for (int u = 0; u < SEF_RU; ++u) {
+      a0[u] = sem_row16_sum(a0[u]);
+      a1[u] = sem_row16_sum(a1[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < SEF_RU; ++u) {                           // lane u of the group stores row u
+      const int o = o0 + grp + NGRP * u;
+      if (o < O && sub == u) {
+        const float b0 = bias ? bias[o] : 0.0f;
+        done(o, a0[u] + b0, a1[u] + b0);
+      }
     }
   }
 }
@@ -254,9 +291,10 @@ __global__ __launch_bounds__(SEM_THREADS) void se_mlp_backward_sample_kernel(con
 // The same three products for SEF_SB samples per workgroup with the REDUCTION split over the 8 waves (round 4).  The
 // kernel above walks all C (or Cs) weight rows on one thread per output: 144-576 dependent rounds of four loads, 25.6 us
 // per call, latency all the way.  Here wave w takes rows w, w + 8, ... (four rows = up to 12 loads in flight), its lanes own
-// 4 consecutive outputs each (16-byte loads of the weight row, used for both samples), the 8 partial vectors meet in
+// 4 consecutive outputs each (16-byte loads of the weight row, used for both samples; SEB_RU rows in flight), the 8 partial vectors meet in
 // LDS and are added in wave order.  max(C, Cs) <= SEB_MAXW outputs (LDS), C % 4 == Cs % 4 == 0, 16-byte aligned weights.
 #define SEB_MAXW 1024
+#define SEB_RU 8          // weight rows (16-byte loads) in flight per lane
 // part[wave][s][col] = sum over this wave's rows r of g[s][r] w[r][col]   (w [R][W] row-major, g [SEF_SB][R] in LDS)
 __device__ __forceinline__ void seb_matvec_t(const float* __restrict__ w, int R, int W, const float* s_g, float* s_part) {
   typedef float f4 __attribute__((ext_vector_type(4)));
@@ -265,12 +303,12 @@ __device__ __forceinline__ void seb_matvec_t(const float* __restrict__ w, int R,
   for (int c0 = 4 * lane; c0 < W; c0 += 256) {
     f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
     int r = wave;
-    for (; r + 3 * NWAVE < R; r += 4 * NWAVE) {
-      f4 wv[4];
+    for (; r + (SEB_RU - 1) * NWAVE < R; r += SEB_RU * NWAVE) {
+      f4 wv[SEB_RU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) wv[u] = *reinterpret_cast<const f4*>(w + (size_t)(r + u * NWAVE) * W + c0);
+      for (int u = 0; u < SEB_RU; ++u) wv[u] = *reinterpret_cast<const f4*>(w + (size_t)(r + u * NWAVE) * W + c0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SEB_RU; ++u) {
         const float g0 = s_g[r + u * NWAVE], g1 = s_g[R + r + u * NWAVE];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { a0[e] = fmaf(g0, wv[u][e], a0[e]); a1[e] = fmaf(g1, wv[u][e], a1[e]); }

@@ -134,7 +134,7 @@ class _DepthwiseFn(torch.autograd.Function):
                        "ias_dwconv_backward_data")
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
-            scratch = torch.empty(int(lib.ias_dwconv_weight_scratch(B, C, K)), dtype=torch.float32, device=x.device)
+            scratch = torch.empty(int(lib.ias_dwconv_weight_scratch_hw(B, C, H, W, K, S)), dtype=torch.float32, device=x.device)
             _lib.check(lib.ias_dwconv_backward_weight(_lib.ptr(x), _lib.ptr(g), _lib.ptr(gw), _lib.ptr(scratch), B, C, H, W, K,
                                                       S, _lib.stream()), "ias_dwconv_backward_weight")
         return gx, gw, None, None
