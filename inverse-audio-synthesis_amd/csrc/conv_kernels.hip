@@ -204,7 +204,7 @@ __device__ __forceinline__ float dww_row16_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xf, 0xf, true));
   return v;
 }
-struct DwWave { int PW, tpp, Wp, rows_in, nl, ni, bch; unsigned mHW, mW, mQ; size_t lds; bool ok; };
+struct DwWave { int PW, tpp, Wp, rows_in, nl, ni, bch, ntiles, rt; unsigned mHW, mW, mQ; size_t lds; bool ok; };
 __device__ __forceinline__ int dww_div(int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; }   // (m = 0: divisor 1)
 // NL / NI: compile-time bounds of geo.nl / geo.ni (register arrays): (4, 1) the 15 x 16 and 8 x 8 planes, (16, 1), (16, 4)
 template <int K, int S, int MODE, int NL, int NI>
@@ -218,18 +218,35 @@ __global__ __launch_bounds__(64) void dw_wave_kernel(const float* __restrict__ x
   float* s_x = s_dw;                                   // [PW][rows_in][Wp]
   float* s_w = s_dw + PW * rows_in * Wp;               // [PW][KK] (MODE 0)
   const int lane = threadIdx.x, slot = lane / tpp, tl = lane - slot * tpp;
-  const int quads = (Wo + 3) >> 2, nitems = Ho * quads, planes = B * C;
+  // geo.ntiles > 1: a group is ONE ROW TILE of one plane (PW = 1): geo.rt output rows, all rows_in = (rt - 1) S + K input
+  // rows staged, the run of rows_in W floats starting (r0 S - P) W floats into the plane is still contiguous.
+  const bool tiled = geo.ntiles > 1;
+  const int ntiles = geo.ntiles, rt = geo.rt;
+  const int quads = (Wo + 3) >> 2, nitems = (tiled ? rt : Ho) * quads, planes = B * C;
   for (int i = lane; i < PW * rows_in * Wp; i += 64) s_x[i] = 0.0f;          // the halo stays zero
-  // once per lane: where its staged elements go, which items it computes
+  // Once per lane: where its staged elements come from and go to, which items it computes.  The loop below has ONE form of
+  // load -- base pointer of the group (uniform) + this lane's fixed offsets -- and no predicates: lanes past the end of
+  // the run re-read its last element and park it in a spare word behind the tile; a group that would hang over the end of
+  // the tensor / of a sample's channels, or a tile that would hang over the plane, is moved back inside (whole planes /
+  // whole rows: results of the overlap are recomputed, bit-identical), see group_of.
+  const int run = tiled ? rows_in * W : PW * HW;       // staged floats per group, contiguous in memory
+  const int dummy = PW * rows_in * Wp + PW * KK;
   int soff[NL];
+  unsigned lofs[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const int idx = lane + 64 * i;
-    soff[i] = -1;
-    if (i < geo.nl && idx < PW * HW) {
-      const int pl = dww_div(idx, geo.mHW), rem = idx - pl * HW;
-      const int hi = dww_div(rem, geo.mW), wi = rem - hi * W;
-      soff[i] = (pl * rows_in + hi + P) * Wp + wi + P;
+    soff[i] = dummy;
+    lofs[i] = 4u * (unsigned)min(idx, run - 1);    // bytes
+    if (idx < run) {
+      if (tiled) {
+        const int r = dww_div(idx, geo.mW), wi = idx - r * W;
+        soff[i] = r * Wp + wi + P;
+      } else {
+        const int pl = dww_div(idx, geo.mHW), rem = idx - pl * HW;
+        const int hi = dww_div(rem, geo.mW), wi = rem - hi * W;
+        soff[i] = (pl * rows_in + hi + P) * Wp + wi + P;
+      }
     }
   }
   int irow[NI], iq[NI];
@@ -239,52 +256,93 @@ __global__ __launch_bounds__(64) void dw_wave_kernel(const float* __restrict__ x
     irow[j] = -1; iq[j] = 0;
     if (j < geo.ni && item < nitems) { irow[j] = dww_div(item, geo.mQ); iq[j] = item - irow[j] * quads; }
   }
-  // work decomposition
   const int cgroups = (C + PW - 1) / PW;                // MODE 1: channel groups per sample
   const int bch = geo.bch;
   float v[NL], wreg[2] = {0.0f, 0.0f}, gv[MODE == 1 ? NI : 1][4];
   float aw[MODE == 1 ? KK : 1];
-  // first plane and number of valid planes of (work item, step)
-  auto group_of = [&](int work, int step, int& p_start, int& nvalid) {
+  // (work item, step) -> first plane of the group (moved back so that PW planes / channels exist: the host guarantees
+  // planes >= PW, C >= PW), whether there is anything to do (MODE 1: samples past the batch), first output row, and the
+  // number of rows the staged window was moved DOWN (+) or UP (-) to stay inside the plane
+  auto group_of = [&](int work, int step, int& p_start, bool& live, int& r0, int& drows) {
+    r0 = 0; drows = 0; live = true;
     if (MODE == 0) {
-      p_start = work * PW;
-      nvalid = min(PW, planes - p_start);
+      if (tiled) {
+        p_start = work / ntiles;
+        r0 = (work - p_start * ntiles) * rt;
+      } else {
+        p_start = min(work * PW, planes - PW);
+      }
     } else {
-      const int bc = work / cgroups, cg = work - bc * cgroups, b = bc * bch + step;
-      p_start = b * C + cg * PW;
-      nvalid = b < B ? min(PW, C - cg * PW) : 0;
+      const int bc = work / cgroups, cg = work - bc * cgroups;
+      int bs = step;
+      if (tiled) { bs = step / ntiles; r0 = (step - bs * ntiles) * rt; }
+      const int b = bc * bch + bs;
+      live = b < B;
+      p_start = b * C + min(cg * PW, C - PW);
+    }
+    if (tiled) {
+      const int hi0 = r0 * S - P;                      // first input row of the tile
+      const int hi1 = min(max(hi0, 0), H - rows_in);   // ... of the window that is loaded
+      drows = hi1 - hi0;
     }
   };
   auto issue = [&](int work, int step) {
-    int p_start, nvalid;
-    group_of(work, step, p_start, nvalid);
-    const float* src = x + (size_t)p_start * HW;
+    int p_start, r0, drows;
+    bool live;
+    group_of(work, step, p_start, live, r0, drows);
+    if (!live) return;
+    // (the group's base as a scalar pair + the lane's byte offsets: one load instruction per element)
+    const size_t goff = (size_t)p_start * HW + (size_t)(tiled ? (r0 * S - P + drows) * W : 0);
+    const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)goff), ghi = __builtin_amdgcn_readfirstlane((unsigned)(goff >> 32));
+    const char* src = reinterpret_cast<const char*>(x + (((size_t)ghi << 32) | glo));
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int idx = lane + 64 * i;
-      v[i] = (soff[i] >= 0 && idx < nvalid * HW) ? src[idx] : 0.0f;
-    }
+    for (int i = 0; i < NL; ++i) v[i] = *reinterpret_cast<const float*>(src + lofs[i]);
     if (MODE == 0) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int i = lane + 64 * u;
         if (i < PW * KK) {
           const int pl = i / KK, t = i - pl * KK;
-          wreg[u] = pl < nvalid ? w[((p_start + pl) % C) * KK + (flip ? KK - 1 - t : t)] : 0.0f;
+          wreg[u] = w[((p_start + pl) % C) * KK + (flip ? KK - 1 - t : t)];
         }
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
+      for (int j = 0; j < NI; ++j) {
+        const bool rowok = irow[j] >= 0 && r0 + irow[j] < Ho;
+        const float* gp = g + (size_t)(p_start + slot) * Ho * Wo + (r0 + irow[j]) * Wo + iq[j] * 4;
+        if ((Wo & 3) == 0) {                               // (then every plane and row starts on 16 bytes)
+          const f4 t = rowok ? *reinterpret_cast<const f4*>(gp) : (f4){0.0f, 0.0f, 0.0f, 0.0f};
+          gv[j][0] = t[0]; gv[j][1] = t[1]; gv[j][2] = t[2]; gv[j][3] = t[3];
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          gv[j][e] = 0.0f;
-          if (irow[j] >= 0 && slot < nvalid && iq[j] * 4 + e < Wo)
-            gv[j][e] = g[(size_t)(p_start + slot) * Ho * Wo + irow[j] * Wo + iq[j] * 4 + e];
+          for (int e = 0; e < 4; ++e) gv[j][e] = (rowok && iq[j] * 4 + e < Wo) ? gp[e] : 0.0f;
         }
+      }
     }
   };
-  const int nsteps = MODE == 1 ? bch : 1;
+  // MODE 0: a group's results are stored one iteration LATE, right before the loads of the group after next go out.
+  // vmcnt counts loads and stores alike and retires them in order: stores issued after the prefetch would sit between
+  // the loop top's wait and the data it waits for; stores issued BEFORE the prefetch have the arithmetic phase to drain.
+  float res[MODE == 0 ? NI : 1][4];
+  int pplane = -1, pr0 = 0;
+  auto flush = [&]() {
+    if (MODE == 0 && pplane >= 0) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if (irow[j] < 0 || pr0 + irow[j] >= Ho) continue;
+        float* dst = out + (size_t)pplane * Ho * Wo + (pr0 + irow[j]) * Wo + iq[j] * 4;
+        if ((Wo & 3) == 0) {
+          *reinterpret_cast<f4*>(dst) = (f4){res[j][0], res[j][1], res[j][2], res[j][3]};   // (Wo % 4 == 0: 16-byte aligned)
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (iq[j] * 4 + e < Wo) dst[e] = res[j][e];
+        }
+      }
+    }
+  };
+  const int nsteps = MODE == 1 ? bch * ntiles : 1;
   int work = blockIdx.x, step = 0;
   if (work < nwork) issue(work, 0);
   __syncthreads();
@@ -293,12 +351,28 @@ __global__ __launch_bounds__(64) void dw_wave_kernel(const float* __restrict__ x
 #pragma unroll
       for (int i = 0; i < KK; ++i) aw[i] = 0.0f;
     }
-    int p_start, nvalid;
-    group_of(work, step, p_start, nvalid);
-    // registers -> LDS (interior only), then the next group's loads go out before the arithmetic
+    int p_start, r0, drows;
+    bool live;
+    group_of(work, step, p_start, live, r0, drows);
+    // registers -> LDS, then the next group's loads go out before the arithmetic
+    if (live) {
+      if (drows == 0) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
-      if (soff[i] >= 0) s_x[soff[i]] = v[i];
+        for (int i = 0; i < NL; ++i) s_x[soff[i]] = v[i];
+      } else {
+        // a boundary tile: the window was loaded drows rows further down (up) the plane, so everything lands drows rows
+        // later (earlier) in the tile, what falls off goes to the spare word, and the rows nothing lands on -- the rows
+        // outside the plane -- are zeroed
+        const int lim = rows_in * Wp, sh = drows * Wp;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          const int so = soff[i] + sh;
+          s_x[(soff[i] != dummy && (unsigned)so < (unsigned)lim) ? so : dummy] = v[i];
+        }
+        const int z0 = drows > 0 ? 0 : lim + sh, zn = drows > 0 ? sh : -sh;
+        for (int i = lane; i < zn; i += 64) s_x[z0 + i] = 0.0f;
+      }
+    }
     float gcur[MODE == 1 ? NI : 1][4];
     if (MODE == 0) {
 #pragma unroll
@@ -310,15 +384,17 @@ __global__ __launch_bounds__(64) void dw_wave_kernel(const float* __restrict__ x
 #pragma unroll
         for (int e = 0; e < 4; ++e) gcur[j][e] = gv[j][e];
     }
+    flush();                                             // the previous group's outputs, ahead of the prefetch
+    pplane = live ? p_start + slot : -1;
+    pr0 = r0;
     int nwork_i = work, nstep = step + 1;
     if (nstep >= nsteps) { nstep = 0; nwork_i = work + gridDim.x; }
     if (nwork_i < nwork) issue(nwork_i, nstep);
     __syncthreads();
-    if (slot < nvalid) {
-      const size_t obase = (size_t)(p_start + slot) * Ho * Wo;
+    if (live) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        if (irow[j] < 0) continue;
+        if (irow[j] < 0 || r0 + irow[j] >= Ho) continue;
         const int r = irow[j], q = iq[j];
         const float* row0 = s_x + (slot * rows_in + r * S) * Wp + q * 4 * S;
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -345,14 +421,8 @@ __global__ __launch_bounds__(64) void dw_wave_kernel(const float* __restrict__ x
           }
         }
         if (MODE == 0) {
-          float* dst = out + obase + r * Wo + q * 4;
-          if ((Wo & 3) == 0) {
-            *reinterpret_cast<f4*>(dst) = (f4){acc[0], acc[1], acc[2], acc[3]};   // (plane sizes Ho Wo with Wo % 4 == 0: 16-byte aligned)
-          } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (q * 4 + e < Wo) dst[e] = acc[e];
-          }
+          for (int e = 0; e < 4; ++e) res[j][e] = acc[e];
         }
       }
     }
@@ -363,21 +433,22 @@ __global__ __launch_bounds__(64) void dw_wave_kernel(const float* __restrict__ x
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
         const float rs = dww_row16_sum(aw[t]);
-        const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 0));
-        const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 16));
-        const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 32));
-        const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 48));
+        const float q0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 0));
+        const float q1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 16));
+        const float q2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 32));
+        const float q3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 48));
         float tot;
-        if (rows_per_slot == 4) tot = (r0 + r1) + (r2 + r3);
-        else if (rows_per_slot == 2) tot = lane == 0 ? r0 + r1 : r2 + r3;
-        else tot = lane == 0 ? r0 : lane == 1 ? r1 : lane == 2 ? r2 : r3;
-        const int c = cg * PW + lane;                    // lane s < PW writes slot s
-        if (lane < PW && c < C) out[((size_t)bc * C + c) * KK + t] = tot;
+        if (rows_per_slot == 4) tot = (q0 + q1) + (q2 + q3);
+        else if (rows_per_slot == 2) tot = lane == 0 ? q0 + q1 : q2 + q3;
+        else tot = lane == 0 ? q0 : lane == 1 ? q1 : lane == 2 ? q2 : q3;
+        const int c = min(cg * PW, C - PW) + lane;       // lane s < PW writes slot s (a moved-back group rewrites the same sums)
+        if (lane < PW) out[((size_t)bc * C + c) * KK + t] = tot;
       }
     }
     __syncthreads();                                     // the tile has been read: the next one may be written
     work = nwork_i; step = nstep;
   }
+  flush();
 }
 
 // Stride-2 input gradient, LDS-tiled: a workgroup stages pp cotangent planes [Ho][Wo] with a one-element zero halo; a
@@ -720,25 +791,47 @@ static DwWave dw_wave_geometry(int B, int H, int W, int Ho, int Wo, int K, int S
   DwWave g;
   g.ok = false;
   static const bool off = getenv("IAS_DW_NO_WAVE") != nullptr;
-  const int P = (K - 1) / 2, quads = (Wo + 3) / 4, nseg4 = (3 * S + K + 3) / 4, nitems = Ho * quads, HW = H * W;
-  if (off || HW > 64 * DWW_NL || nitems > 64 * DWW_NI) return g;
-  int tpp = nitems <= 16 ? 16 : nitems <= 32 ? 32 : 64;
-  while (tpp < 64 && (64 / tpp) * HW > 64 * DWW_NL) tpp *= 2;
-  g.tpp = tpp;
-  g.PW = 64 / tpp;
+  static const bool notile = getenv("IAS_DW_NO_WAVE_TILES") != nullptr;
+  const int P = (K - 1) / 2, quads = (Wo + 3) / 4, nseg4 = (3 * S + K + 3) / 4, HW = H * W;
+  if (off) return g;
   int Wp = W + 2 * P;
   const int need = (quads - 1) * 4 * S + 4 * nseg4;
   if (Wp < need) Wp = need;
   g.Wp = (Wp + 3) & ~3;
-  g.rows_in = (Ho - 1) * S + K;
-  g.nl = (g.PW * HW + 63) / 64;
-  g.ni = (nitems + tpp - 1) / tpp;
   g.bch = B < 8 ? B : 8;
   g.mHW = HW > 1 ? dw_magic(HW) : 0;
   g.mW = W > 1 ? dw_magic(W) : 0;
   g.mQ = quads > 1 ? dw_magic(quads) : 0;
-  g.lds = sizeof(float) * ((size_t)g.PW * g.rows_in * g.Wp + (size_t)g.PW * K * K);
-  g.ok = g.nl <= DWW_NL && g.ni <= DWW_NI && g.lds <= 10240 && (size_t)g.PW * g.rows_in * g.Wp < (1u << 20);
+  g.ntiles = 1;
+  g.rt = Ho;
+  int nitems = Ho * quads;
+  if (HW <= 64 * DWW_NL && nitems <= 64 * DWW_NI) {
+    // whole planes: PW of them per wave
+    int tpp = nitems <= 16 ? 16 : nitems <= 32 ? 32 : 64;
+    while (tpp < 64 && (64 / tpp) * HW > 64 * DWW_NL) tpp *= 2;
+    g.tpp = tpp;
+    g.PW = 64 / tpp;
+    g.rows_in = (Ho - 1) * S + K;
+    g.nl = (g.PW * HW + 63) / 64;
+  } else {
+    // row tiles: the most output rows whose input rows fit the lanes' registers and whose items fit one pass of the wave
+    if (notile || quads > 64) return g;
+    int rt = 64 / quads;
+    while (rt > 1 && ((rt - 1) * S + K) * W > 64 * DWW_NL) --rt;
+    if (((rt - 1) * S + K) * W > 64 * DWW_NL) return g;
+    g.rt = rt;
+    g.ntiles = (Ho + rt - 1) / rt;
+    if (g.ntiles < 2) return g;
+    g.tpp = 64;
+    g.PW = 1;
+    g.rows_in = (rt - 1) * S + K;
+    if (g.rows_in > H) return g;                           // (the loaded window is kept inside the plane)
+    g.nl = (g.rows_in * W + 63) / 64;
+    nitems = rt * quads;
+  }
+  g.ni = (nitems + g.tpp - 1) / g.tpp;
+  g.lds = sizeof(float) * ((size_t)g.PW * g.rows_in * g.Wp + (size_t)g.PW * K * K + 4);     // (+ the spare word)
+  g.ok = g.nl <= DWW_NL && g.ni <= DWW_NI && g.lds <= 10240;
   return g;
 }
 #define DW_WAVE_DISPATCH_KS(MODE, NL, NI, ...)                                                              \
@@ -781,8 +874,8 @@ extern "C" int ias_dwconv_forward(const float* x, const float* w, float* out, in
   const int Ho = ias_conv_out_size(H, K, S), Wo = ias_conv_out_size(W, K, S);
   const int planes = B * C;
   const DwWave wg = dw_wave_geometry(B, H, W, Ho, Wo, K, S);
-  if (wg.ok) {
-    const int nwork = (planes + wg.PW - 1) / wg.PW;
+  if (wg.ok && planes >= wg.PW) {
+    const int nwork = wg.ntiles > 1 ? planes * wg.ntiles : (planes + wg.PW - 1) / wg.PW;
     DW_WAVE_DISPATCH(0, wg, dim3(dw_wave_grid(wg, nwork)), dim3(64), wg.lds, (hipStream_t)stream_, x, w, (const float*)nullptr, out, B, C,
                      H, W, Ho, Wo, 0, wg, nwork);
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
@@ -802,8 +895,8 @@ extern "C" int ias_dwconv_backward_data(const float* g, const float* w, float* g
   if (S == 1) {   // Ho = H, Wo = W: the same convolution of g with the taps reversed
     const int planes = B * C;
     const DwWave wg = dw_wave_geometry(B, Ho, Wo, H, W, K, 1);
-    if (wg.ok) {
-      const int nwork = (planes + wg.PW - 1) / wg.PW;
+    if (wg.ok && planes >= wg.PW) {
+      const int nwork = wg.ntiles > 1 ? planes * wg.ntiles : (planes + wg.PW - 1) / wg.PW;
       DW_WAVE_DISPATCH(0, wg, dim3(dw_wave_grid(wg, nwork)), dim3(64), wg.lds, (hipStream_t)stream_, g, w, (const float*)nullptr, gx, B,
                        C, Ho, Wo, H, W, 1, wg, nwork);
       return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
@@ -846,10 +939,15 @@ extern "C" int ias_dwconv_backward_weight(const float* x, const float* g, float*
   if (!scratch) return IAS_ERR_ARG;
   const int Ho = ias_conv_out_size(H, K, S), Wo = ias_conv_out_size(W, K, S);
   const int planes = B * C;
-  const DwWave wg = dw_wave_geometry(B, H, W, Ho, Wo, K, S);
-  if (wg.ok) {
-    // partial[batch chunk][c][K K]: ceil(B / bch) chunks <= B, inside the scratch of any sizing call
-    const int cgroups = (C + wg.PW - 1) / wg.PW, nchunk = (B + wg.bch - 1) / wg.bch, nwork = cgroups * nchunk;
+  const DwWave wg0 = dw_wave_geometry(B, H, W, Ho, Wo, K, S);
+  if (wg0.ok && C >= wg0.PW) {
+    // partial[batch chunk][c][K K]: ceil(B / bch) chunks <= B, inside the scratch of any sizing call.  Samples per work
+    // item: 8 (one fold of the lanes per 8 planes), halved until there are 2048 work items (16 channels x 16 chunks of the
+    // first layer were 256 waves on 256 CUs: 320 us)
+    DwWave wg = wg0;
+    const int cgroups = (C + wg.PW - 1) / wg.PW;
+    while (wg.bch > 1 && cgroups * ((B + wg.bch - 1) / wg.bch) < 2048) wg.bch >>= 1;
+    const int nchunk = (B + wg.bch - 1) / wg.bch, nwork = cgroups * nchunk;
     DW_WAVE_DISPATCH(1, wg, dim3(dw_wave_grid(wg, nwork)), dim3(64), wg.lds, (hipStream_t)stream_, x, (const float*)nullptr, g, scratch, B,
                      C, H, W, Ho, Wo, 0, wg, nwork);
     const int n = C * K * K;
