@@ -39,6 +39,37 @@ def test_depthwise_conv_matches_torch(lib, dev, C, K, S, H, W):
         assert torch.equal(gx, gx_direct)
 
 
+def _random_dw_shapes(n, seed=7):
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(n):
+        K, S = rnd.choice([3, 5]), rnd.choice([1, 2])
+        H, W = rnd.randint(1, 70), rnd.randint(1, 70)
+        if rnd.random() < 0.25:
+            H, W = rnd.randint(60, 140), rnd.randint(40, 130)       # row-tiled waves / workgroup tiles
+        out.append((rnd.randint(1, 9), rnd.randint(1, 7), K, S, H, W))
+    return out
+
+
+@pytest.mark.parametrize("B,C,K,S,H,W", _random_dw_shapes(48))
+def test_depthwise_conv_random_shapes(lib, dev, B, C, K, S, H, W):
+    """Random plane sizes through every depthwise path (wave-owned planes with 1 / 2 / 4 planes per wave, groups moved back
+    at the end of the tensor / of the channels, row-tiled waves with boundary tiles, workgroup tiles, the direct kernels):
+    forward, input gradient and weight gradient against torch's conv2d on the same device."""
+    from inverse_audio_synthesis_amd.vision import DepthwiseConv2d
+    m = DepthwiseConv2d(C, C, K, S, (K - 1) // 2, groups=C, bias=False).to(dev)
+    x = randn((B, C, H, W), 31).to(dev).requires_grad_(True)
+    y = m(x)
+    ref = F.conv2d(x, m.weight, None, S, (K - 1) // 2, 1, C)
+    assert y.shape == ref.shape and (y - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    g = randn(tuple(ref.shape), 32).to(dev)
+    gx, gw = torch.autograd.grad(y, (x, m.weight), g)
+    rx, rw = torch.autograd.grad(ref, (x, m.weight), g)
+    assert (gx - rx).abs().max().item() <= 1e-5 * max(1.0, rx.abs().max().item())
+    assert (gw - rw).abs().max().item() <= 2e-4 * max(1.0, rw.abs().max().item())
+
+
 def test_stem_conv_matches_torch(lib, dev):
     from inverse_audio_synthesis_amd.vision import StemConv2d
     m = StemConv2d(3, 16, 3, 2, 1, bias=False).to(dev)
