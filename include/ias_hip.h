@@ -129,6 +129,11 @@ int ias_voice_backward_norm(const float* ctrl, const void* vconst, const float* 
 int ias_voice_backward_sums(const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
                             const float* rownorm, float* planes, double* tile_sums, double* partials, float* g_ctrl,
                             double* g_scal, int B, int T, int Tc, int sample_rate, void* stream);
+/* In two stages on the same buffers: stage 0 = the phase increments and their tile sums from the control signals (no
+ * cotangent: g_mixed, rownorm, noise, partials, g_ctrl, g_scal may be NULL), stage 1 = everything else. */
+int ias_voice_backward_sums_stage(int stage, const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
+                                  const float* rownorm, float* planes, double* tile_sums, double* partials, float* g_ctrl,
+                                  double* g_scal, int B, int T, int Tc, int sample_rate, void* stream);
 
 /* Control-rate half of the same backward: params01 [B,78], g_ctrl [B,5,Tc] fp32 and g_scal [B,12] fp64 (g_ctrl of
  * ias_voice_backward and the sum over tiles of its partials) -> g_params01 [B,78] fp32.  One launch instead of the
@@ -142,6 +147,12 @@ long long ias_voice_control_backward_ws_bytes(int B, int Tc);
 int ias_voice_control_backward_ws(const float* params01, const float* g_ctrl, const double* g_scal, float* g_params01,
                                   void* workspace, long long workspace_bytes, int B, int Tc, int control_rate,
                                   void* stream);
+/* The same in two stages on the same workspace: stage 0 = the part that does not see the cotangent (the envelope values,
+ * parameters only; g_ctrl, g_scal, g_params01 may be NULL) -- a caller that knows at render time that a backward will
+ * follow can run it beside the loss computation on another stream; stage 1 = the rest. */
+int ias_voice_control_backward_ws_stage(int stage, const float* params01, const float* g_ctrl, const double* g_scal,
+                                        float* g_params01, void* workspace, long long workspace_bytes, int B, int Tc,
+                                        int control_rate, void* stream);
 
 /* Transposed, zero-padded tap table: ias_pqmf_packed_taps_len(N, K) floats -- the fast kernel's layout for N = 3, 4
  * with K = 63, the wide kernel's [K][8|16|32|64] layout for other N <= 64 with K <= 255, 0 otherwise (generic

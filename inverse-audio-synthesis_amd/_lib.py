@@ -46,11 +46,13 @@ SYMBOLS = {
     "ias_voice_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_voice_backward_norm": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_voice_backward_sums": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_voice_backward_sums_stage": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_voice_norm_scratch_len": (_LL, [_I]),
     "ias_voice_norm_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "ias_voice_control_backward": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ias_voice_control_backward_ws_bytes": (_LL, [_I, _I]),
     "ias_voice_control_backward_ws": (_I, [_P, _P, _P, _P, _P, _LL, _I, _I, _I, _P]),
+    "ias_voice_control_backward_ws_stage": (_I, [_I, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _P]),
     "ias_pqmf_out_len": (_I, [_I, _I, _I]),
     "ias_pqmf_packed_taps_len": (_I, [_I, _I]),
     "ias_pqmf_pack_taps": (_I, [_P, _P, _I, _I, _P]),

@@ -501,12 +501,30 @@ extern "C" long long ias_voice_control_backward_ws_bytes(int B, int Tc) {
   if (B <= 0 || Tc <= 1) return IAS_ERR_ARG;
   return (long long)sizeof(float) * B * 6 * Tc + (long long)sizeof(double) * B * (2 * 78 + 40 + 6 * (long long)Tc) + 64;
 }
+static int voice_control_backward_stage(int stage, const float* params01, const float* g_ctrl, const double* g_scal,
+                                        float* g_params01, void* workspace, long long workspace_bytes, int B, int Tc,
+                                        int control_rate, void* stream_);
 extern "C" int ias_voice_control_backward_ws(const float* params01, const float* g_ctrl, const double* g_scal,
                                              float* g_params01, void* workspace, long long workspace_bytes, int B, int Tc,
                                              int control_rate, void* stream_) {
+  return voice_control_backward_stage(-1, params01, g_ctrl, g_scal, g_params01, workspace, workspace_bytes, B, Tc, control_rate,
+                                      stream_);
+}
+// In two stages on the same workspace: stage 0 = the envelope VALUES (voice_env_value_kernel: parameters only, no
+// cotangent; g_ctrl, g_scal, g_params01 may be NULL), stage 1 = the rest.
+extern "C" int ias_voice_control_backward_ws_stage(int stage, const float* params01, const float* g_ctrl, const double* g_scal,
+                                                   float* g_params01, void* workspace, long long workspace_bytes, int B,
+                                                   int Tc, int control_rate, void* stream_) {
+  if (stage != 0 && stage != 1) return IAS_ERR_ARG;
+  return voice_control_backward_stage(stage, params01, g_ctrl, g_scal, g_params01, workspace, workspace_bytes, B, Tc,
+                                      control_rate, stream_);
+}
+static int voice_control_backward_stage(int stage, const float* params01, const float* g_ctrl, const double* g_scal,
+                                        float* g_params01, void* workspace, long long workspace_bytes, int B, int Tc,
+                                        int control_rate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!params01 || !g_ctrl || !g_scal || !g_params01 || !workspace || B <= 0 || B > 65535 || Tc <= 1 || control_rate <= 0)
-    return IAS_ERR_ARG;
+  if (!params01 || !workspace || B <= 0 || B > 65535 || Tc <= 1 || control_rate <= 0) return IAS_ERR_ARG;
+  if (stage != 0 && (!g_ctrl || !g_scal || !g_params01)) return IAS_ERR_ARG;
   if (control_rate != IAS_CONTROL_RATE) return IAS_ERR_UNSUPPORTED;
   if (workspace_bytes < ias_voice_control_backward_ws_bytes(B, Tc) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return IAS_ERR_WORKSPACE;
   const size_t lds = sizeof(double) * 4 * (size_t)Tc + sizeof(float) * 6 * (size_t)Tc;
@@ -520,8 +538,10 @@ extern "C" int ias_voice_control_backward_ws(const float* params01, const float*
     (void)hipFuncSetAttribute((const void*)voice_ctrl_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int ppt = (Tc + CG_THREADS - 1) / CG_THREADS;
   const int eppt = (Tc + EG_THREADS - 1) / EG_THREADS;
-  hipLaunchKernelGGL(voice_env_value_kernel, dim3(6, B), dim3(EG_THREADS), 0, stream, params01, ws_env, Tc, eppt,
-                     (double)control_rate);
+  if (stage <= 0)
+    hipLaunchKernelGGL(voice_env_value_kernel, dim3(6, B), dim3(EG_THREADS), 0, stream, params01, ws_env, Tc, eppt,
+                       (double)control_rate);
+  if (stage == 0) return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   hipLaunchKernelGGL(voice_ctrl_grad_kernel<true>, dim3(B), dim3(CG_THREADS), lds, stream, params01, g_ctrl, g_scal,
                      g_params01, Tc, ppt, (double)control_rate, ws_genv, ws_vdv, ws_part, (const double*)ws_env);
   hipLaunchKernelGGL(voice_env_grad_kernel, dim3(6, B), dim3(EG_THREADS), 0, stream, ws_genv, ws_vdv, ws_part, Tc, eppt,

@@ -998,11 +998,33 @@ extern "C" int ias_voice_backward_norm(const float* ctrl, const void* vconst, co
 }
 // ... and g_scal [B, ias_voice_grad_nscalars()] fp64 (NULL: not wanted) = partials summed over the tiles, in tile order, by the
 // last launch
+static int voice_backward_stage(int stage, const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
+                                const float* rownorm, float* planes, double* tile_sums, double* partials, float* g_ctrl,
+                                double* g_scal, int B, int T, int Tc, int sample_rate, void* stream_);
 extern "C" int ias_voice_backward_sums(const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
                                        const float* rownorm, float* planes, double* tile_sums, double* partials,
                                        float* g_ctrl, double* g_scal, int B, int T, int Tc, int sample_rate, void* stream_) {
+  return voice_backward_stage(-1, ctrl, vconst, noise, g_mixed, rownorm, planes, tile_sums, partials, g_ctrl, g_scal, B, T, Tc,
+                              sample_rate, stream_);
+}
+// The same in two stages on the same buffers.  Stage 0 is the part that does not see the cotangent (the phase increments
+// and their tile sums from the control signals: voice_grad_inc_kernel) -- a caller that knows at render time that a
+// backward will follow can run it beside the loss computation, on another stream; stage 1 is everything else.
+// g_mixed, rownorm, partials, g_ctrl, g_scal may be NULL in stage 0.
+extern "C" int ias_voice_backward_sums_stage(int stage, const float* ctrl, const void* vconst, const float* noise,
+                                             const float* g_mixed, const float* rownorm, float* planes, double* tile_sums,
+                                             double* partials, float* g_ctrl, double* g_scal, int B, int T, int Tc,
+                                             int sample_rate, void* stream_) {
+  if (stage != 0 && stage != 1) return IAS_ERR_ARG;
+  return voice_backward_stage(stage, ctrl, vconst, noise, g_mixed, rownorm, planes, tile_sums, partials, g_ctrl, g_scal, B, T, Tc,
+                              sample_rate, stream_);
+}
+static int voice_backward_stage(int stage, const float* ctrl, const void* vconst, const float* noise, const float* g_mixed,
+                                const float* rownorm, float* planes, double* tile_sums, double* partials, float* g_ctrl,
+                                double* g_scal, int B, int T, int Tc, int sample_rate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!ctrl || !vconst || !noise || !g_mixed || !planes || !tile_sums || !partials || !g_ctrl) return IAS_ERR_ARG;
+  if (!ctrl || !vconst || !planes || !tile_sums) return IAS_ERR_ARG;
+  if (stage != 0 && (!noise || !g_mixed || !partials || !g_ctrl)) return IAS_ERR_ARG;
   if (B <= 0 || B > 65535 || T <= 1 || Tc <= 1 || sample_rate <= 0) return IAS_ERR_ARG;
   const int ntiles = (T + GRAD_TILE - 1) / GRAD_TILE;
   if (ntiles > 65535) return IAS_ERR_UNSUPPORTED;
@@ -1018,8 +1040,10 @@ extern "C" int ias_voice_backward_sums(const float* ctrl, const void* vconst, co
     return IAS_ERR_UNSUPPORTED;
   const IasVoiceConst* vc = (const IasVoiceConst*)vconst;
   const dim3 grid(ntiles, B), block(GRAD_THREADS);
-  hipLaunchKernelGGL(voice_grad_inc_kernel, grid, block, 0, stream, ctrl, vc, planes, tile_sums, T, Tc, ntiles,
-                     1.0 / (double)sample_rate, scale);
+  if (stage <= 0)
+    hipLaunchKernelGGL(voice_grad_inc_kernel, grid, block, 0, stream, ctrl, vc, planes, tile_sums, T, Tc, ntiles,
+                       1.0 / (double)sample_rate, scale);
+  if (stage == 0) return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   if (fold) {
     static const bool lds_ok = [] {      // 64 KB of staging blocks + the static part: above the default dynamic limit
       const bool a = hipFuncSetAttribute((const void*)voice_grad_sample16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

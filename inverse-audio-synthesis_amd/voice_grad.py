@@ -163,10 +163,56 @@ def normalisation_rows(g_audio, audio, peaks):
     return rownorm
 
 
-def audio_rate_backward(voice, params01, g_mixed, rownorm=None, control=None):
+class BackwardPrelude:
+    """The parts of the two backward calls that do not see a cotangent -- the phase increments + tile sums of the
+    audio-rate adjoint (``ias_voice_backward_sums_stage(0)``) and the envelope values of the control-rate adjoint
+    (``ias_voice_control_backward_ws_stage(0)``) -- launched at RENDER time on a stream of their own, beside whatever the
+    caller computes between the render and its backward (the losses).  ``join()`` makes the current stream wait for them.
+    ``IAS_VOICE_PRELUDE=0``: everything in the backward, as before."""
+
+    _streams = {}
+
+    def __init__(self, voice, p, ctrl, vconst):
+        c = voice.synthconfig
+        lib = _lib.load()
+        B, T, Tc = c.batch_size, c.buffer_size, c.control_buffer_size
+        dev = p.device
+        self.planes = torch.empty((B, lib.ias_voice_grad_nplanes(), T), dtype=torch.float32, device=dev)
+        self.tile_sums = torch.empty((B, lib.ias_voice_grad_tiles(T), 2), dtype=torch.float64, device=dev)
+        nws = int(lib.ias_voice_control_backward_ws_bytes(B, Tc))
+        self.cws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
+        cur = torch.cuda.current_stream(dev)
+        side = self._streams.get(dev)
+        if side is None:
+            side = self._streams[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        self.ctrl_ok = True
+        with torch.cuda.stream(side):
+            st = lib.ias_voice_backward_sums_stage(0, _lib.ptr(ctrl), _lib.ptr(vconst), None, None, None, _lib.ptr(self.planes),
+                                                   _lib.ptr(self.tile_sums), None, None, None, B, T, Tc, c.sample_rate,
+                                                   _lib.stream())
+            _lib.check(st, "ias_voice_backward_sums_stage")
+            st = lib.ias_voice_control_backward_ws_stage(0, _lib.ptr(p), None, None, None, _lib.ptr(self.cws), self.cws.numel(),
+                                                         B, Tc, c.control_rate, _lib.stream())
+            if st == -2:                                  # control buffer too long for the HIP form: the torch graph does it all
+                self.ctrl_ok = False
+            else:
+                _lib.check(st, "ias_voice_control_backward_ws_stage")
+        self.side = side
+
+    def join(self):
+        torch.cuda.current_stream(self.planes.device).wait_stream(self.side)
+
+
+def prelude_enabled():
+    import os
+    return os.environ.get("IAS_VOICE_PRELUDE", "1") not in ("0", "")
+
+
+def audio_rate_backward(voice, params01, g_mixed, rownorm=None, control=None, prelude=None):
     """HIP adjoint of the audio-rate render: g_mixed [B,T] -> (g_ctrl [B,5,Tc] fp32, g_constants [B,12] fp64).
     ``rownorm``: ``normalisation_rows`` of a normalised render; ``g_mixed`` is then the cotangent of the normalised
-    audio."""
+    audio.  ``prelude``: a joined ``BackwardPrelude`` of the same render (its stage 0 has run)."""
     c = voice.synthconfig
     lib = _lib.load()
     B, T, Tc = c.batch_size, c.buffer_size, c.control_buffer_size
@@ -176,15 +222,20 @@ def audio_rate_backward(voice, params01, g_mixed, rownorm=None, control=None):
     ctrl, vconst = control if control is not None else voice.control_signals(params01)
     dev = g_mixed.device
     ntiles = lib.ias_voice_grad_tiles(T)
-    planes = torch.empty((B, lib.ias_voice_grad_nplanes(), T), dtype=torch.float32, device=dev)
-    tile_sums = torch.empty((B, ntiles, 2), dtype=torch.float64, device=dev)
+    if prelude is not None:
+        planes, tile_sums = prelude.planes, prelude.tile_sums
+    else:
+        planes = torch.empty((B, lib.ias_voice_grad_nplanes(), T), dtype=torch.float32, device=dev)
+        tile_sums = torch.empty((B, ntiles, 2), dtype=torch.float64, device=dev)
     partials = torch.empty((B, ntiles, lib.ias_voice_grad_nscalars()), dtype=torch.float64, device=dev)
     g_ctrl = torch.empty((B, 5, Tc), dtype=torch.float32, device=dev)
     g_scal = torch.empty((B, lib.ias_voice_grad_nscalars()), dtype=torch.float64, device=dev)
-    st = lib.ias_voice_backward_sums(_lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(voice.noise), _lib.ptr(g_mixed),
-                                     _lib.ptr(rownorm), _lib.ptr(planes), _lib.ptr(tile_sums), _lib.ptr(partials),
-                                     _lib.ptr(g_ctrl), _lib.ptr(g_scal), B, T, Tc, c.sample_rate, _lib.stream())
-    _lib.check(st, "ias_voice_backward_sums")
+    args = (_lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(voice.noise), _lib.ptr(g_mixed), _lib.ptr(rownorm), _lib.ptr(planes),
+            _lib.ptr(tile_sums), _lib.ptr(partials), _lib.ptr(g_ctrl), _lib.ptr(g_scal), B, T, Tc, c.sample_rate, _lib.stream())
+    if prelude is not None:
+        _lib.check(lib.ias_voice_backward_sums_stage(1, *args), "ias_voice_backward_sums_stage")
+    else:
+        _lib.check(lib.ias_voice_backward_sums(*args), "ias_voice_backward_sums")
     return g_ctrl, g_scal
 
 
@@ -227,12 +278,19 @@ class _ControlBackwardGraph:
 _GRAPHS = {}
 
 
-def _control_backward_hip(cfg, p, g_ctrl, g_scal):
+def _control_backward_hip(cfg, p, g_ctrl, g_scal, prelude=None):
     """The same adjoint as one HIP launch (csrc/voice_ctrl_grad_kernels.hip); None if the shape is unsupported."""
     lib = _lib.load()
     g_ctrl = g_ctrl.to(torch.float32).contiguous()
     g_scal = g_scal.to(torch.float64).contiguous()
     out = torch.empty((p.shape[0], S.NPARAMS), dtype=torch.float32, device=p.device)
+    if prelude is not None and prelude.ctrl_ok:
+        ws = prelude.cws                                  # stage 0 (the envelope values) ran beside the losses
+        st = lib.ias_voice_control_backward_ws_stage(1, _lib.ptr(p), _lib.ptr(g_ctrl), _lib.ptr(g_scal), _lib.ptr(out),
+                                                     _lib.ptr(ws), ws.numel(), p.shape[0], cfg.control_buffer_size,
+                                                     cfg.control_rate, _lib.stream())
+        _lib.check(st, "ias_voice_control_backward_ws_stage")
+        return out
     nws = lib.ias_voice_control_backward_ws_bytes(p.shape[0], cfg.control_buffer_size)
     ws = torch.empty(max(int(nws), 16), dtype=torch.uint8, device=p.device)
     st = lib.ias_voice_control_backward_ws(_lib.ptr(p), _lib.ptr(g_ctrl), _lib.ptr(g_scal), _lib.ptr(out), _lib.ptr(ws),
@@ -243,10 +301,10 @@ def _control_backward_hip(cfg, p, g_ctrl, g_scal):
     return out
 
 
-def _control_backward(cfg, p, g_ctrl, g_scal, use_hip=True):
+def _control_backward(cfg, p, g_ctrl, g_scal, use_hip=True, prelude=None):
     """d loss / d params01 [B,78] from the gradients of the control signals and per-voice constants."""
     if use_hip:
-        out = _control_backward_hip(cfg, p, g_ctrl, g_scal)
+        out = _control_backward_hip(cfg, p, g_ctrl, g_scal, prelude)
         if out is not None:
             return out
     if torch.cuda.is_current_stream_capturing():
@@ -272,6 +330,9 @@ class _RenderFn(torch.autograd.Function):
         ctrl, vconst, peaks = voice.saved_for_backward(with_peaks=normalize)
         ctx.voice, ctx.normalize = voice, normalize
         ctx.save_for_backward(p, audio, peaks, ctrl, vconst)
+        # a backward will follow (this is only reached when params01 requires grad): its cotangent-free part starts now
+        ctx.prelude = BackwardPrelude(voice, p, ctrl, vconst) if ctx.needs_input_grad[0] and prelude_enabled() and p.is_cuda \
+            else None
         return audio
 
     @staticmethod
@@ -282,8 +343,11 @@ class _RenderFn(torch.autograd.Function):
         # audio = mixed / peak on rows with peak > 1 (peak = max |mixed|, attained at t*):
         #   g_mixed = g / peak, and the peak itself takes -sign(mixed[t*]) * sum_t g[t] audio[t] / peak at t*
         rownorm = normalisation_rows(g, audio, peaks) if ctx.normalize else None
-        g_ctrl, g_scal = audio_rate_backward(voice, p, g, rownorm, (ctrl, vconst))
-        g_p = _control_backward(voice.synthconfig, p, g_ctrl, g_scal)
+        prelude, ctx.prelude = ctx.prelude, None          # (a second backward through a retained graph runs the whole thing)
+        if prelude is not None:
+            prelude.join()
+        g_ctrl, g_scal = audio_rate_backward(voice, p, g, rownorm, (ctrl, vconst), prelude)
+        g_p = _control_backward(voice.synthconfig, p, g_ctrl, g_scal, prelude=prelude)
         return g_p.to(torch.float32), None, None
 
 

@@ -243,3 +243,43 @@ def test_control_backward_in_four_launches_equals_the_single_kernel(lib, dev):
     small = torch.empty(16, dtype=torch.uint8, device=dev)
     assert lib.ias_voice_control_backward_ws(_lib.ptr(p), _lib.ptr(g_ctrl), _lib.ptr(g_scal), _lib.ptr(four), _lib.ptr(small),
                                              small.numel(), B, Tc, 441, _lib.stream()) == -4      # IAS_ERR_WORKSPACE
+
+
+@pytest.mark.parametrize("B,sr,sec", [(4, 16000, 1.0), (3, 44100, 0.5)])
+def test_backward_prelude_on_a_side_stream_gives_the_same_bits(lib, dev, monkeypatch, B, sr, sec):
+    """The cotangent-free parts of the backward (phase increments, envelope values) start at render time on a stream of
+    their own (voice_grad.BackwardPrelude); IAS_VOICE_PRELUDE=0 keeps them in the backward.  Same gradient, bit for bit,
+    also through a retained graph differentiated twice and inside a captured hipGraph."""
+    v = _voice(dev, B, sr, sec)
+    p0 = so.sample_params01(so.VoiceConfig(B, sr, sec), 9).to(dev)
+    w = torch.randn(B, v.synthconfig.buffer_size, generator=torch.Generator().manual_seed(3)).to(dev)
+
+    def grad(twice=False):
+        p = p0.clone().requires_grad_(True)
+        loss = (v.render(p) * w).sum()
+        if twice:
+            g1 = torch.autograd.grad(loss, p, retain_graph=True)[0]
+            g2 = torch.autograd.grad(loss, p)[0]
+            assert torch.equal(g1, g2)
+            return g1
+        return torch.autograd.grad(loss, p)[0]
+
+    monkeypatch.setenv("IAS_VOICE_PRELUDE", "0")
+    ref = grad()
+    monkeypatch.setenv("IAS_VOICE_PRELUDE", "1")
+    assert torch.equal(grad(), ref)
+    assert torch.equal(grad(twice=True), ref)
+    torch.cuda.synchronize()
+    out = torch.zeros_like(ref)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            grad()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out.copy_(grad())
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
