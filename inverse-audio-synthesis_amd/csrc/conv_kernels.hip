@@ -101,7 +101,7 @@ __global__ __launch_bounds__(CV_THREADS) void dw_tile_kernel(const float* __rest
     __syncthreads();                                   // the previous tile has been consumed
     // staging: the tile as one flat index space, DW_NB loads in flight per thread: all of a batch's addresses first, then
     // its loads back to back, then the LDS writes (a row walk with one load per thread and pass left a 61 x 132 tile of the
-    // first layer waiting out forty memory latencies: 84 us for 38 MB).  Index -> (plane, row, column) by multiply-high
+    // first layer waiting out forty memory latencies: 84 us for 151 MB).  Index -> (plane, row, column) by multiply-high
     // with host-made reciprocals (exact for idx < 2^20).
     {
       const int stage_n = npl * rows_in * Wp;
