@@ -183,6 +183,30 @@ def vicreg_cpu_baseline(B, D):
             "sample": f"{reps} passes of VICReg.loss forward + backward on x, y [{B}, {D}] (oracle, torch CPU ops, {el:.1f} s)"}
 
 
+def vicreg_roofline(batch_side, kernel, achieved, gram_ms, executed, nominal, kpad, step_bytes, step_s, dxd):
+    """The vicreg workload's roofline object.  Batch-side form (the product path where the padded batch <= D): the step is
+    six small launches moving x, y in and gx, gy out -- bound "hbm" on those bytes (a small problem: the fraction says how
+    far from streaming it is), with the B x B contraction's matrix-core numbers under "contraction" and the D x D kernel of
+    rounds 1-3, timed in the same run, under "dxd".  Feature-side form: the D x D Gram kernel against the bf16 MFMA peak,
+    as in rounds 1-3."""
+    contraction = {"kernel": kernel, "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "avg_launch_ms": round(gram_ms, 4), "flops_executed": executed,
+                   "flops_nominal_2BD2_per_branch_x2": nominal,
+                   "measured": "HIP events around K back-to-back launches of stage 1 (the covariance contraction) on the "
+                               "global batch, fastest of 15 replays"}
+    if not batch_side:
+        contraction["form"] = "feature side (D x D)"
+        contraction["frac_nominal"] = round(nominal / (gram_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
+        contraction["traffic"] = pmc_traffic_of("vicreg_gram_pair_kernel" if kpad == 128 else "vicreg_gram256_kernel")
+        return contraction
+    gbps = step_bytes / step_s / 1e9
+    return {"kernel": "VICReg.loss forward + backward, batch-side form: colstats, B x B product, fold, finish | gradient product",
+            "form": "batch side (B x B)", "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbps / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_step": step_bytes,
+            "what": "x, y read, gx, gy written (fp32), per rank, over the step's time (driver-timed)",
+            "contraction": contraction, "dxd": dxd}
+
+
 def run_vicreg(args, rank, world, dev):
     """BASELINE configs[2] / [3]: the projector loss on [B, 8192] embeddings, forward + backward, through
     ``vicreg.global_batch_loss`` -- the function ``VICReg.loss`` calls.  N = 1: the local loss.  N > 1: cat(x, y) all-gathered
@@ -329,18 +353,7 @@ def run_vicreg(args, rank, world, dev):
                    "collective": "all_gather_into_tensor fwd + reduce_scatter_tensor bwd (RCCL)" if gather else None,
                    "rccl_world_size": dist.get_world_size() if gather else 1,
                    "loss": out[0], "repr_loss": out[1], "std_loss": out[2], "cov_loss": out[3]},
-        "roofline": {"kernel": kernel, "form": "batch side (B x B)" if batch_side else "feature side (D x D)",
-                     "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                     "traffic": None if batch_side else pmc_traffic_of("vicreg_gram_pair_kernel" if kpad == 128 else "vicreg_gram256_kernel"),
-                     "avg_launch_ms": round(gram_ms, 4), "flops_executed": executed, "flops_nominal_2BD2_per_branch_x2": nominal,
-                     "frac_nominal": None if batch_side else round(nominal / (gram_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                     "step_hbm": {"algorithmic_bytes_per_step": step_bytes, "what": "x, y read, gx, gy written (fp32), per rank",
-                                  "achieved_GBps": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
-                                  "frac": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
-                     "dxd": dxd,
-                     "measured": "HIP events around K back-to-back launches of stage 1 (the covariance contraction) on the "
-                                 "global batch, fastest of 15 replays"},
+        "roofline": vicreg_roofline(batch_side, kernel, achieved, gram_ms, executed, nominal, kpad, step_bytes, elapsed / args.steps, dxd),
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = vicreg_cpu_baseline(B, D)
@@ -364,7 +377,7 @@ def secondary_legs(args, dev):
                    "workload": r["config"]["workload"], "launch": r["config"]["launch"]}
             rf = r["roofline"]
             leg["roofline"] = {k: rf[k] for k in ("kernel", "form", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
-                                                  "frac_nominal", "flops_executed", "algorithmic_bytes_per_step", "step_hbm",
+                                                  "frac_nominal", "flops_executed", "algorithmic_bytes_per_step", "contraction",
                                                   "dxd") if k in rf}
         except Exception as e:  # noqa: BLE001 -- a failing leg must not take the headline line down
             leg = {"error": f"{type(e).__name__}: {e}"}
