@@ -20,6 +20,29 @@
 
 typedef float pw_v4f __attribute__((ext_vector_type(4)));
 
+// In-kernel stamps (diagnostic build -DIAS_PW_STAMPS only, scripts/diag/pw_stamps.py; the product build compiles none of
+// this): s_memrealtime (100 MHz) at the phase boundaries of pw_apply_kernel, per wave: [wave][8].
+#ifdef IAS_PW_STAMPS
+static __device__ unsigned long long* g_pw_stamps = nullptr;
+extern "C" int ias_pw_set_stamps(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_pw_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define PW_STAMP(id)                                                                                                    \
+  do {                                                                                                                  \
+    if (g_pw_stamps != nullptr && (threadIdx.x & 63) == 0)                                                              \
+      g_pw_stamps[((size_t)blockIdx.x * (PW_THREADS / 64) + (threadIdx.x >> 6)) * 8 + (id)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define PW_STAMP(id) do {} while (0)
+#endif
+
+// Row stride of the staged weight image [T KS][PW_WROW]: 64 operand floats + 1.  With rows of exactly 64 floats the
+// staging scatter -- consecutive lanes hold consecutive 16-byte groups of a weight row, i.e. consecutive k-steps of the
+// same output row -- put all 64 lanes of a store on ONE bank: 6.8 us of a 23 us wave on the 240 -> 40 layer
+// (scripts/diag/pw_stamps.py).  One float of padding moves consecutive k-steps to consecutive banks; the operand reads
+// (64 consecutive floats of a row) are conflict-free either way.
+#define PW_WROW 65
+
 // positions of a 64-position block as (N-tile j, column n): VEC 4: 4 n + j; VEC 2: 32 (j >> 1) + 2 n + (j & 1);
 // VEC 1: 16 j + n -- so that a lane's VEC tiles are consecutive positions (one load / store).
 template <int VEC>
@@ -77,14 +100,15 @@ template <int VEC>
 __global__ __launch_bounds__(PW_THREADS) void pw_apply_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               float* __restrict__ y, int B, int M, int K, int HW,
                                                               int transpose, int blocks, int ngroups, int cg, long long items) {
-  extern __shared__ __attribute__((aligned(16))) float s_w[];          // [T][KS][64]: the A operand of (tile, k-step)
+  extern __shared__ __attribute__((aligned(16))) float s_w[];          // [T][KS][PW_WROW]: the A operand of (tile, k-step)
   const int T = (M + 15) >> 4, KS = K >> 2, tid = threadIdx.x;
+  PW_STAMP(0);
   // the weight, read linearly in 16-byte groups and scattered into operand order: element (m, k) goes to
   // [(m >> 4) KS + (k >> 2)][16 (k & 3) + (m & 15)]; the rows past M of the last tile are zero
   if (M & 15) {
     const int t = T - 1, pad0 = M & 15;
     for (int i = tid; i < KS * 64; i += PW_THREADS)
-      if ((i & 15) >= pad0) s_w[t * KS * 64 + i] = 0.0f;
+      if ((i & 15) >= pad0) s_w[(t * KS + (i >> 6)) * PW_WROW + (i & 63)] = 0.0f;
   }
   const pw_v4f* w4 = reinterpret_cast<const pw_v4f*>(w);
 #pragma unroll 4
@@ -92,15 +116,16 @@ __global__ __launch_bounds__(PW_THREADS) void pw_apply_kernel(const float* __res
     const pw_v4f v = w4[i];
     if (transpose) {                       // w[k][m .. m+3]: four neighbours in operand order
       const int k = (4 * i) / M, m = 4 * i - k * M;
-      float* d = s_w + ((m >> 4) * KS + (k >> 2)) * 64 + 16 * (k & 3) + (m & 15);
+      float* d = s_w + ((m >> 4) * KS + (k >> 2)) * PW_WROW + 16 * (k & 3) + (m & 15);
       d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
     } else {                               // w[m][k .. k+3]: the four k-slots of one k-step
       const int m = (4 * i) / K, k = 4 * i - m * K;
-      float* d = s_w + ((m >> 4) * KS + (k >> 2)) * 64 + (m & 15);
+      float* d = s_w + ((m >> 4) * KS + (k >> 2)) * PW_WROW + (m & 15);
       d[0] = v[0]; d[16] = v[1]; d[32] = v[2]; d[48] = v[3];
     }
   }
   __syncthreads();
+  PW_STAMP(1);
   const int lane = tid & 63, n = lane & 15, q = lane >> 4;
   for (long long id = (long long)blockIdx.x * (PW_THREADS / 64) + (tid >> 6); id < items;
        id += (long long)gridDim.x * (PW_THREADS / 64)) {
@@ -115,7 +140,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_apply_kernel(const float* __res
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = pw_v4f{0.0f, 0.0f, 0.0f, 0.0f};
     const float* xb = x + ((size_t)b * K + q) * HW;                     // row 4 ks + q: advance by 4 HW per k-step
-    const float* sa = s_w + (size_t)t0 * KS * 64 + lane;
+    const float* sa = s_w + (size_t)t0 * KS * PW_WROW + lane;
     float cur[PW_PF][4], nxt[PW_PF][4];
 #pragma unroll
     for (int d = 0; d < PW_PF; ++d) {
@@ -123,6 +148,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_apply_kernel(const float* __res
       for (int j = 0; j < 4; ++j) cur[d][j] = nxt[d][j] = 0.0f;
       if (d < KS) pw_load_row64<VEC>(xb + (size_t)d * 4 * HW, p0, n, HW, cur[d]);
     }
+    PW_STAMP(2);
     for (int ks0 = 0; ks0 < KS; ks0 += PW_PF) {
 #pragma unroll
       for (int d = 0; d < PW_PF; ++d)
@@ -133,7 +159,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_apply_kernel(const float* __res
 #pragma unroll
           for (int i = 0; i < PW_CG; ++i) {
             if (i < tiles) {
-              const float a = sa[(i * KS + ks0 + d) * 64];
+              const float a = sa[(i * KS + ks0 + d) * PW_WROW];
 #pragma unroll
               for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, cur[d][j], acc[i][j], 0, 0, 0);
             }
@@ -145,6 +171,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_apply_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 4; ++j) cur[d][j] = nxt[d][j];
     }
+    PW_STAMP(3);
 #pragma unroll
     for (int i = 0; i < PW_CG; ++i) {
       if (i < tiles) {
@@ -158,6 +185,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_apply_kernel(const float* __res
         }
       }
     }
+    PW_STAMP(4);
   }
 }
 
@@ -318,7 +346,12 @@ static int pw_apply(const float* x, const float* w, float* y, int B, int M, int 
   const long long items = (long long)B * blocks * ngroups;
   long long grid = (items + PW_THREADS / 64 - 1) / (PW_THREADS / 64);
   if (grid > 1024) grid = 1024;                     // the weight is staged once per workgroup
-  const size_t lds = sizeof(float) * (size_t)T * 16 * K;
+  const size_t lds = sizeof(float) * (size_t)T * (K / 4) * PW_WROW;
+  if (lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)pw_apply_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)pw_apply_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)pw_apply_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   switch (pw_vec(x, y, HW)) {
     case 4: hipLaunchKernelGGL((pw_apply_kernel<4>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, x, w, y, B, M, K, HW, transpose, blocks, ngroups, cg, items); break;
     case 2: hipLaunchKernelGGL((pw_apply_kernel<2>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, x, w, y, B, M, K, HW, transpose, blocks, ngroups, cg, items); break;
