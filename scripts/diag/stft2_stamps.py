@@ -1,6 +1,8 @@
 """Where a wave of stft2_kernel spends its cycles: s_memtime stamps at the phase boundaries (diagnostic build
 -DIAS_S2_STAMPS of csrc/spectral_kernels.hip, linked into scripts/diag/_bin/libias_s2stamps.so; the product library has
-none).  usage (GPU box): python scripts/diag/stft2_stamps.py [loss|mel|raw|mr1024|mr2048]"""
+none).  usage (GPU box): python scripts/diag/stft2_stamps.py [loss|mel|raw|mr1024|mr2048]
+Caveat (round 4): the stamped build of the MR-STFT variants SPILLS (scratch reloads + s_waitcnt vmcnt(0) between stamps 7 and 8,
+which then absorb the latency of the next frame's prefetch): phase 8 reads 3-4 x too long there; the product build has no scratch."""
 import ctypes, os, subprocess, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "inverse-audio-synthesis_amd", "csrc")
