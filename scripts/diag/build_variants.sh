@@ -7,8 +7,9 @@ B=$R/scripts/diag/_bin
 mkdir -p $B
 stem=$1; shift
 objs=$(ls $C/*_kernels.o | grep -v $stem.o)
-extra=""; [ $stem = pqmf_kernels ] && extra="-fno-slp-vectorize"
+extra="-fno-slp-vectorize"       # the product flags (csrc/Makefile)
 [ $stem = voice_kernels ] && extra="-ffp-contract=off -fno-slp-vectorize"
+[ $stem = voice_grad_kernels ] && extra="-ffp-contract=off -fno-slp-vectorize"
 for spec in "$@"; do
   set -- $spec; name=$1; shift
   /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-value $extra "$@" -c $C/$stem.hip -o $B/${stem}_$name.o || exit 1
