@@ -6,7 +6,7 @@ B=$R/scripts/diag/_bin/all_$name; mkdir -p $B
 for f in $C/*_kernels.hip; do
   s=$(basename $f .hip); extra=""
   case $s in voice_kernels|voice_grad_kernels) extra="-ffp-contract=off";; esac
-  /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-value -fno-slp-vectorize $extra "$@" -c $f -o $B/$s.o &
+  /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-value -mllvm -amdgpu-kernarg-preload-count=16 -fno-slp-vectorize $extra "$@" -c $f -o $B/$s.o &
   while [ $(jobs -r | wc -l) -ge 4 ]; do sleep 1; done
 done
 wait

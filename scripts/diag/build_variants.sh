@@ -12,7 +12,7 @@ extra="-fno-slp-vectorize"       # the product flags (csrc/Makefile)
 [ $stem = voice_grad_kernels ] && extra="-ffp-contract=off -fno-slp-vectorize"
 for spec in "$@"; do
   set -- $spec; name=$1; shift
-  /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-value $extra "$@" -c $C/$stem.hip -o $B/${stem}_$name.o || exit 1
+  /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-value -mllvm -amdgpu-kernarg-preload-count=16 $extra "$@" -c $C/$stem.hip -o $B/${stem}_$name.o || exit 1
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $B/${stem}_$name.o $objs -o $B/libias_$name.so
   echo built $name
 done

@@ -9,7 +9,7 @@ os.makedirs(BIN, exist_ok=True)
 so = os.path.join(BIN, "libias_pwstamps.so")
 objs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith("_kernels.o") and not f.startswith("pointwise_kernels")]
 obj = os.path.join(BIN, "pointwise_pwstamps.o")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", "-fno-slp-vectorize",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16",
                        "-DIAS_PW_STAMPS", "-c", os.path.join(CSRC, "pointwise_kernels.hip"), "-o", obj])
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", obj] + objs + ["-o", so])
 if "--build-only" in sys.argv:

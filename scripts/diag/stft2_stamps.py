@@ -13,7 +13,7 @@ objs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith("_kernels.
 if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(CSRC, "spectral_kernels.hip")):
     obj = os.path.join(BIN, "spectral_s2stamps.o")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value",
-                           "-fno-slp-vectorize", "-DIAS_S2_STAMPS", "-c", os.path.join(CSRC, "spectral_kernels.hip"), "-o", obj])
+                           "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-DIAS_S2_STAMPS", "-c", os.path.join(CSRC, "spectral_kernels.hip"), "-o", obj])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", obj] + objs + ["-o", so])
 if "--build-only" in sys.argv:
     sys.exit(0)

@@ -10,7 +10,7 @@ so = os.path.join(BIN, "libias_smstamps.so")
 objs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith("_kernels.o") and not f.startswith("stft_mfma")]
 if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(CSRC, "stft_mfma_kernels.hip")):
     obj = os.path.join(BIN, "stft_mfma_stamps.o")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", "-fno-slp-vectorize",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=16",
                            "-Wno-pass-failed", "-DIAS_SM_STAMPS", "-c", os.path.join(CSRC, "stft_mfma_kernels.hip"), "-o", obj])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", obj] + objs + ["-o", so])
 if "--build-only" in sys.argv:

@@ -17,7 +17,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "inverse-audio-synthesis_amd", "csrc")
-BASE = ["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", "-S", "--cuda-device-only"]
+BASE = ["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-S", "--cuda-device-only"]
 KERNELS = [  # (json key = the name bench.py / rocprofv3 use, source, extra flags as in csrc/Makefile, mangled-name substring)
     ("voice_audio_kernel", "voice_kernels.hip", ["-ffp-contract=off", "-fno-slp-vectorize"], "voice_audio_kernelILi0ELb1E"),
     ("stft2_kernel<8, true, 1, 1>", "spectral_kernels.hip", ["-fno-slp-vectorize"], "stft2_kernelILi8ELb1ELi1ELi1E"),
