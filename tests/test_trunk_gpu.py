@@ -52,7 +52,12 @@ def _random_dw_shapes(n, seed=7):
     return out
 
 
-@pytest.mark.parametrize("B,C,K,S,H,W", _random_dw_shapes(48))
+# rows too wide for a wave (more than 64 four-output items per row): the workgroup-tiled kernels (dw_tile_kernel with its row
+# tiles as grid.y, per-tile weight-gradient partials, dw_tile_bwd_s2_kernel / the direct stride-2 kernel)
+_WIDE_DW_SHAPES = [(2, 3, 3, 1, 5, 1100), (2, 2, 5, 2, 40, 600), (2, 2, 3, 1, 200, 300), (3, 2, 5, 1, 70, 520), (2, 1, 3, 2, 130, 700)]
+
+
+@pytest.mark.parametrize("B,C,K,S,H,W", _random_dw_shapes(48) + _WIDE_DW_SHAPES)
 def test_depthwise_conv_random_shapes(lib, dev, B, C, K, S, H, W):
     """Random plane sizes through every depthwise path (wave-owned planes with 1 / 2 / 4 planes per wave, groups moved back
     at the end of the tensor / of the channels, row-tiled waves with boundary tiles, workgroup tiles, the direct kernels):
