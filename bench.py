@@ -261,8 +261,8 @@ def run_vicreg(args, rank, world, dev):
 
     # ---- the covariance contraction alone (stage 1 of ias_vicreg_stage on a filled workspace), HIP events around K launches.
     # The product path contracts over the batch where the padded batch <= D (B x B matrix, 2 B^2 D flops: SURVEY 8(d)'s
-    # identity); the feature-side D x D kernels of rounds 1-3 (2 B D^2 flops) are timed next to it under
-    # ias_vicreg_set_form(0), and the whole forward + backward once more in that form: `roofline.dxd`.
+    # identity); the feature-side D x D kernels of rounds 1-3 (2 B D^2 flops) are timed next to it through the diagnostic
+    # library under ias_vicreg_set_form(0), and the whole forward + backward once more in that form: `roofline.dxd`.
     Bg = B * world
     xg = torch.randn(Bg, D, generator=torch.Generator().manual_seed(100)).to(dev)
     yg = torch.randn(Bg, D, generator=torch.Generator().manual_seed(101)).to(dev)
@@ -294,7 +294,7 @@ def run_vicreg(args, rank, world, dev):
 
     kpad = (Bg + 127) // 128 * 128
     ntile = (D + 127) // 128
-    batch_side = kpad <= D and os.environ.get("IAS_VICREG_DXD", "0") in ("", "0")
+    batch_side = kpad <= D and D % 8 == 0
     stage(-1)
     gram_ms = time_graph(lambda: stage(1))
     loss_default = o4.tolist()
@@ -302,35 +302,40 @@ def run_vicreg(args, rank, world, dev):
     # feature side: both branches, the upper triangle at 128 x 128 granularity (the 256 x 256 kernel executes 1.5 % more)
     executed_dxd = 2.0 * (ntile * (ntile + 1) // 2) * 2.0 * 128 * 128 * kpad
     dxd_name = ("vicreg_gram_pair_kernel" if kpad == 128 else
-                ("vicreg_gram_kernel (128 x 128 tiles; both branches, one launch)"
-                 if os.environ.get("IAS_VICREG_GRAM128", "0") not in ("", "0") or D < 256 else
+                ("vicreg_gram_kernel (128 x 128 tiles; both branches, one launch)" if D < 256 else
                  "vicreg_gram256_kernel (256 x 256 tiles, LDS-DMA; both branches, one launch)"))
     dxd = None
     if batch_side:
-        t256 = kpad > 128 and os.environ.get("IAS_VICREG_GRAM128", "0") in ("", "0")
+        t256 = kpad > 128
         bt = (kpad + 255) // 256 if t256 else kpad // 128
         tile = 256 if t256 else 128
         executed = 2.0 * (bt * (bt + 1) // 2) * 2.0 * tile * tile * D         # upper-triangular tiles of Xc Xc^T, both branches
         kernel = ("vicreg_bgram256_kernel + vicreg_gconv256_kernel" if t256 else "vicreg_bgram_kernel + vicreg_gconv_kernel") + \
                  " (Xc Xc^T, B x B, in D-slices + the fixed-order fold that also sums its squares)"
-        # the D x D kernels on the same inputs, and the whole step in that form
-        _lib.check(lib.ias_vicreg_set_form(0), "ias_vicreg_set_form")
+        # the D x D kernels on the same inputs, and the whole step in that form: through the DIAGNOSTIC library (the product
+        # library has no switch -- the side follows from the shape; include/ias_hip_diag.h), a separate library instance
+        diag = _lib.load_diag()
+        _lib.check(diag.ias_vicreg_set_form(0), "ias_vicreg_set_form")
         try:
-            need0 = int(lib.ias_vicreg_workspace_bytes(Bg, D))
-            if need0 > need:
-                ws = torch.empty(need0, dtype=torch.uint8, device=dev)
-                need = need0
-            stage(-1)
-            dxd_ms = time_graph(lambda: stage(1))
-            loss_dxd = o4.tolist()
-            step_dxd_ms = None
-            if not gather:
-                step_dxd_ms = time_graph(step, reps=7)
+            with _lib.use_library(diag):
+                need0 = int(diag.ias_vicreg_workspace_bytes(Bg, D))
+                ws0 = torch.empty(need0, dtype=torch.uint8, device=dev)
+
+                def stage0(k):
+                    _lib.check(diag.ias_vicreg_stage(k, _lib.ptr(xg), _lib.ptr(yg), _lib.ptr(o4), _lib.ptr(ws0), need0, Bg, D, Bg,
+                                                     25.0, 25.0, 1.0, _lib.stream()), "ias_vicreg_stage (diagnostic library)")
+                stage0(-1)
+                dxd_ms = time_graph(lambda: stage0(1))
+                loss_dxd = o4.tolist()
+                step_dxd_ms = None
+                if not gather:
+                    step_dxd_ms = time_graph(step, reps=7)
         finally:
-            _lib.check(lib.ias_vicreg_set_form(-1), "ias_vicreg_set_form")
+            _lib.check(diag.ias_vicreg_set_form(-1), "ias_vicreg_set_form")
         a_dxd = executed_dxd / (dxd_ms * 1e-3) / 1e12
-        dxd = {"kernel": dxd_name, "note": "the feature-side contraction of rounds 1-3 (ias_vicreg_set_form(0)): NOT on the "
-                                           "product path at this shape, timed here for continuity",
+        dxd = {"kernel": dxd_name, "note": "the feature-side contraction of rounds 1-3: NOT in the product path at this shape (the "
+                                           "product library picks the side from the shape); timed through libias_hip_diag.so "
+                                           "(ias_vicreg_set_form(0)) for continuity",
                "avg_launch_ms": round(dxd_ms, 4), "flops_executed": executed_dxd, "achieved": round(a_dxd, 1),
                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(a_dxd / MFMA_BF16_PEAK_TFLOPS, 4),
                "traffic": pmc_traffic_of("vicreg_gram_pair_kernel" if kpad == 128 else "vicreg_gram256_kernel"),
@@ -664,6 +669,8 @@ def main():
     preclear = os.environ.get("IAS_BENCH_PRECLEAR", "0") == "1" and not args.no_pipeline
     reduce_aside = (not args.no_pipeline) and os.environ.get("IAS_BENCH_REDUCE_INLINE") != "1"   # (diag knob)
 
+    warmed = {}
+
     def run_steps(k, pipelined=True):
         main = torch.cuda.current_stream()
         consumed = [None] * nbuf
@@ -721,6 +728,14 @@ def main():
         # (two steps of lead, legal with three workspaces, measured slower: 0.232 vs 0.211 ms -- the capture order of the
         # extra successor changes the executor's queue assignment again)
         depth = 1
+        # IAS_BENCH_NOCTRL=1 (diagnostics, scripts/diag/run_noctrl_ab.sh): the control pass only for the first `nbuf` steps
+        # (the bench's parameters do not change, so every workspace keeps valid control signals) -- what the step would
+        # cost if the control pass were free
+        noctrl = os.environ.get("IAS_BENCH_NOCTRL", "0") == "1"
+        real_issue_control = issue_control
+        if noctrl:
+            def issue_control(i):  # noqa: F811
+                return real_issue_control(i) if not warmed.get("done") else side_c.record_event()
         ctrl_events = {j: issue_control(j) for j in range(min(depth, k))}
         for i in range(k):
             buf = i % nbuf
@@ -760,6 +775,7 @@ def main():
         main.wait_stream(side_b)
         main.wait_stream(side_c)
         main.wait_stream(side_d)
+        warmed["done"] = k >= nbuf
 
     def sync_all():
         torch.cuda.synchronize()
@@ -942,8 +958,8 @@ def main():
     }
     bps = {"render": RENDER_BYTES_PER_SAMPLE, "pqmf": 8.0, "stft": 4.0 + 4.0 * plan.n_out / plan.hop_length}
     knames = {"render": "voice_audio_kernel",
-              "pqmf": "pqmf_analysis_pipe_kernel" if os.environ.get("IAS_PQMF_NOMOD") else "pqmf_analysis_mod_kernel",
-              "stft": "stft2_kernel<8, true, 1, 1>" if plan.n_fft == 1024 and os.environ.get("IAS_STFT_V1") != "1" else "stft_kernel"}
+              "pqmf": "pqmf_analysis_mod_kernel",
+              "stft": "stft2_kernel<8, true, 1, 1>" if plan.n_fft == 1024 else "stft_kernel"}
     table = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):

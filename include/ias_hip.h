@@ -76,6 +76,13 @@ int ias_voice_stage(int stage, int math_mode, const float* noise, float* audio, 
  * its predecessors expired (that tile's audio is then NaN: an expired wait never continues with partial sums). */
 int ias_voice_read_status(const void* workspace, unsigned* status, int B, int T, int Tc, void* stream);
 
+/* The same flag, STICKY: status[0] (device) != 0 if ANY render into this workspace lost a tile since the word was last
+ * cleared (clear != 0 re-zeroes it behind the read, in stream order).  ias_voice_read_status only sees the last render --
+ * every render re-arms its own word --; a training loop that looks every N steps reads this one (the reference runs its
+ * Trainer with detect_anomaly=True, pretrain.py:96: a NaN loss must come with its reason).  Lives in the workspace in
+ * front of the words a render re-zeroes; the caller zeroes the workspace ONCE after allocating it. */
+int ias_voice_read_status_sticky(void* workspace, unsigned* status, int B, int T, int Tc, int clear, void* stream);
+
 /* Byte offset inside the workspace of the B row peaks (fp32, max |x| of the un-normalised mix) of the last render.
  * ias_pqmf_analysis / ias_stft take that address as `rowpeak` to fold normalize_if_clipping into their own pass
  * (render with normalize = 0): the normalised audio is then never written or re-read. */
@@ -353,13 +360,12 @@ int ias_vicreg_backward4_ld(const float* x, const float* y, long long ld, const 
 int ias_vicreg_stage(int stage, const float* x, const float* y, float* out, void* workspace, long long workspace_bytes,
                      int B, int D, int cfg_batch, float sim_coeff, float std_coeff, float cov_coeff, void* stream);
 
-/* Which side the covariance term (vicreg.py:47-51) is contracted on.  sum_{i != j} cov_ij^2 over the D x D matrix
- * cov = Xc^T Xc / (n - 1) equals (||Xc Xc^T||_F^2 - sum_j (Xc^T Xc)_jj^2) / (n - 1)^2: the B x B matrix Xc Xc^T costs
- * 2 B^2 D flops instead of 2 B D^2 (64x fewer at the reference's B = 128, D = 8192) and is the matrix the backward
- * needs anyway.  form 1: batch side wherever the padded batch (multiple of 128) <= D and D % 8 == 0; 0: always the
- * D x D kernels; -1 (default): 1 unless the environment has IAS_VICREG_DXD=1.  Process-wide; forward and backward of one
- * loss must run under the same setting (the batch-side forward leaves the B x B matrix in the workspace for the backward). */
-int ias_vicreg_set_form(int form);
+/* Which side the covariance term (vicreg.py:47-51) is contracted on is a pure function of the shape.
+ * sum_{i != j} cov_ij^2 over the D x D matrix cov = Xc^T Xc / (n - 1) equals
+ * (||Xc Xc^T||_F^2 - sum_j (Xc^T Xc)_jj^2) / (n - 1)^2: the B x B matrix Xc Xc^T costs 2 B^2 D flops instead of 2 B D^2
+ * (64x fewer at the reference's B = 128, D = 8192) and is the matrix the backward needs anyway.  Batch side wherever the
+ * padded batch (multiple of 128) <= D and D % 8 == 0; the D x D kernels otherwise.  (The diagnostic library can force a
+ * side: include/ias_hip_diag.h.) */
 
 /* ---- AudioEmbedding trunk: the depthwise convolutions and the stem of torchvision's mobilenet_v3_small.features
  * (reference vicreg_audio_params.py:52-54, audioembed.py:61), NCHW fp32, padding (K-1)/2, no bias.

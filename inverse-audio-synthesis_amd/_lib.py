@@ -35,6 +35,7 @@ SYMBOLS = {
     "ias_voice_render": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ias_voice_stage": (_I, [_I, _I, _P, _P, _P, _LL, _I, _I, _I, _I, _P]),
     "ias_voice_read_status": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ias_voice_read_status_sticky": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ias_voice_peaks_offset": (_LL, [_I, _I, _I]),
     "ias_voice_ctrl_offset": (_LL, [_I, _I, _I]),
     "ias_voice_vconst_offset": (_LL, [_I, _I, _I]),
@@ -94,7 +95,6 @@ SYMBOLS = {
     "ias_vicreg_backward_ld": (_I, [_P, _P, _LL, _P, _P, _P, _LL, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
     "ias_vicreg_backward4_ld": (_I, [_P, _P, _LL, _P, _P, _P, _P, _P, _P, _LL, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
     "ias_vicreg_stage": (_I, [_I, _P, _P, _P, _P, _LL, _I, _I, _I, _F, _F, _F, _P]),
-    "ias_vicreg_set_form": (_I, [_I]),
     "ias_conv_out_size": (_I, [_I, _I, _I]),
     "ias_dwconv_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ias_dwconv_backward_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -122,7 +122,14 @@ SYMBOLS = {
     "ias_lars_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
 }
 
+# Symbols only the diagnostic library exports (include/ias_hip_diag.h).
+DIAG_SYMBOLS = {
+    "ias_vicreg_set_form": (_I, [_I]),
+}
+DIAG_LIB_PATH = os.path.join(_HERE, "csrc", "libias_hip_diag.so")
+
 _lib = None
+_diag = None
 
 
 class HipLibraryMissing(RuntimeError):
@@ -139,13 +146,46 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C inverse-audio-synthesis_amd/csrc`.  There is no CPU fallback."
         )
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SYMBOLS.items():
+    _lib = _bind(ctypes.CDLL(LIB_PATH), SYMBOLS)
+    return _lib
+
+
+def _bind(lib, table):
+    for name, (res, args) in table.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
+
+
+def load_diag():
+    """The diagnostic build of the same sources (csrc/libias_hip_diag.so, -DIAS_DIAG: environment switches live,
+    superseded kernels and ``ias_vicreg_set_form`` compiled in; include/ias_hip_diag.h).  A SEPARATE library instance:
+    nothing the package does goes through it unless a test or a diagnostic script asks for it (``use_library``)."""
+    global _diag
+    if _diag is None:
+        if not os.path.exists(DIAG_LIB_PATH):
+            raise HipLibraryMissing(f"{DIAG_LIB_PATH} not found: `make -C inverse-audio-synthesis_amd/csrc`")
+        _diag = _bind(_bind(ctypes.CDLL(DIAG_LIB_PATH), SYMBOLS), DIAG_SYMBOLS)
+    return _diag
+
+
+class use_library:
+    """``with use_library(load_diag()): ...`` -- route every call of the package through another build of the C ABI for the
+    duration of the block (tests and diagnostics that compare kernel variants; never used by the package itself)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def __enter__(self):
+        global _lib
+        load()
+        self.saved, _lib = _lib, self.lib
+        return self.lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
 
 
 def check(status, what):

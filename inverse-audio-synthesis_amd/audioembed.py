@@ -103,7 +103,7 @@ class AudioEmbedding(nn.Module):
         def plain2x2(c):
             return (c.kernel_size == (2, 2) and c.stride == (1, 1) and c.padding == (0, 0) and c.dilation == (1, 1)
                     and c.groups == 1 and c.padding_mode == "zeros")
-        # IAS_TRUNK_TORCH=1: the nn.Conv2d head (A/B debugging; the trunk layers honour the same switch in vision.py)
+        # vision.FORCE_TORCH_LAYERS (diagnostics): the nn.Conv2d head; the trunk layers honour the same attribute
         if t.is_cuda and t.dtype == torch.float32 and not trunk_torch() and \
                 all(plain2x2(getattr(self, f"conv{i}")) for i in range(1, 8)):
             t = t.permute(0, 2, 3, 1)                 # channels-last once; the head stays channels-last

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(BNF_THREADS) void bn_fused_backward_kernel(
 }
 // vectors per thread the one-workgroup form needs for this layer, or 0 if it does not apply (IAS_BN_UNFUSED=1: never)
 static int bn_fused_nv(const void* p0, const void* p1, const void* p2, int B, int C, int HW) {
-  static const bool off = getenv("IAS_BN_UNFUSED") && atoi(getenv("IAS_BN_UNFUSED")) != 0;
+  static const bool off = ias_diag_env("IAS_BN_UNFUSED") && atoi(ias_diag_env("IAS_BN_UNFUSED")) != 0;
   if (off || (HW & 3) || ((((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15) != 0) || C < 32) return 0;
   const long long nvec = (long long)B * (HW >> 2);
   if (nvec <= 2 * BNF_THREADS) return 2;
@@ -296,7 +296,7 @@ static int bn_fused_nv(const void* p0, const void* p1, const void* p2, int B, in
 
 // ------------------------------------------------------------------------ C ABI
 static int bn_split(int B, int C) {
-  static const int target = getenv("IAS_BN_WGS") ? atoi(getenv("IAS_BN_WGS")) : 2048;   // (diagnostics knob)
+  static const int target = ias_diag_env("IAS_BN_WGS") ? atoi(ias_diag_env("IAS_BN_WGS")) : 2048;   // (diagnostics knob)
   int s = (target + C - 1) / C;
   if (s < 1) s = 1;
   if (s > B) s = B;

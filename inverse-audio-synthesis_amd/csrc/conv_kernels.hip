@@ -605,6 +605,7 @@ __global__ __launch_bounds__(CV_THREADS) void stem_fwd_kernel(const float* __res
   }
 }
 
+#ifdef IAS_DIAG   // the VALU / LDS form of the stem weight gradient: superseded by stem_bwd_weight_mfma_kernel, diagnostics only
 // partial[chunk][co][ci*9+kh*3+kw]: a workgroup stages 256 positions (27 inputs + COUT cotangents each) in LDS, then
 // thread t < COUT*27 sums its weight element over them; grid (position chunks, B).
 template <int CIN, int COUT>
@@ -650,6 +651,7 @@ __global__ __launch_bounds__(CV_THREADS) void stem_bwd_weight_kernel(const float
   if (t1 < NW) pp[t1] = acc1;
 }
 
+#endif
 // The same weight gradient on the matrix cores: gw[co][tap] = sum over positions of g[co][pos] * xcol[tap][pos] is a
 // 16 x 27 x (B Ho Wo) GEMM.  One wave per (sample, chunk of output rows); per 64 output positions of a row it issues
 // 16 k-steps of v_mfma_f32_16x16x4_f32 for each of the two tap tiles (taps 0..15, 16..26): lane (m, q) supplies
@@ -790,8 +792,8 @@ extern "C" int ias_conv_out_size(int n, int K, int S) { return (n + 2 * ((K - 1)
 static DwWave dw_wave_geometry(int B, int H, int W, int Ho, int Wo, int K, int S) {
   DwWave g;
   g.ok = false;
-  static const bool off = getenv("IAS_DW_NO_WAVE") != nullptr;
-  static const bool notile = getenv("IAS_DW_NO_WAVE_TILES") != nullptr;
+  static const bool off = ias_diag_env("IAS_DW_NO_WAVE") != nullptr;
+  static const bool notile = ias_diag_env("IAS_DW_NO_WAVE_TILES") != nullptr;
   const int P = (K - 1) / 2, quads = (Wo + 3) / 4, nseg4 = (3 * S + K + 3) / 4, HW = H * W;
   if (off) return g;
   int Wp = W + 2 * P;
@@ -904,7 +906,7 @@ extern "C" int ias_dwconv_backward_data(const float* g, const float* w, float* g
     const DwTile t = dw_tile_geometry(Ho, Wo, H, W, K, 1, 0);
     DW_TILE_DISPATCH(0, dim3((planes + t.pp - 1) / t.pp, t.ntiles), dim3(CV_THREADS), t.lds, (hipStream_t)stream_, g, w,
                      (const float*)nullptr, gx, C, Ho, Wo, H, W, planes, t.pp, t.rows_out, t.Wp, 1, t.mWp, t.mRows);
-  } else if ((size_t)(Ho + 2) * (Wo + 2) <= 12288 && !getenv("IAS_DW_S2_DIRECT")) {
+  } else if ((size_t)(Ho + 2) * (Wo + 2) <= 12288 && !ias_diag_env("IAS_DW_S2_DIRECT")) {
     const int planes = B * C, plane_lds = (Ho + 2) * (Wo + 2);
     int pp = 1;
     while (pp * 2 <= 64 && pp * 2 * plane_lds <= 8192 && pp * 2 * Ho * Wo <= CV_THREADS) pp *= 2;
@@ -968,7 +970,7 @@ extern "C" int ias_dwconv_backward_weight(const float* x, const float* g, float*
 extern "C" int ias_stem_forward(const float* x, const float* w, float* out, int B, int H, int W, void* stream_) {
   if (!x || !w || !out || B <= 0 || B > 65535 || H <= 0 || W <= 0) return IAS_ERR_ARG;
   const int Ho = ias_conv_out_size(H, 3, 2), Wo = ias_conv_out_size(W, 3, 2);
-  if (getenv("IAS_STEM_VALU") || (long long)3 * H * W > 0x7fffffffLL) {
+  if (ias_diag_env("IAS_STEM_VALU") || (long long)3 * H * W > 0x7fffffffLL) {
     hipLaunchKernelGGL((stem_fwd_kernel<3, 16>), dim3(cv_grid_x(Ho * Wo), B), dim3(CV_THREADS), 0, (hipStream_t)stream_, x, w,
                        out, H, W, Ho, Wo);
   } else {
@@ -987,10 +989,13 @@ extern "C" int ias_stem_backward_weight(const float* x, const float* g, float* g
                                         void* stream_) {
   if (!x || !g || !gw || !scratch || B <= 0 || B > 65535 || H <= 0 || W <= 0) return IAS_ERR_ARG;
   const int Ho = ias_conv_out_size(H, 3, 2), Wo = ias_conv_out_size(W, 3, 2);
-  if (getenv("IAS_STEM_GW_LDS")) {   // the VALU / LDS form (diagnostics)
+#ifdef IAS_DIAG
+  if (ias_diag_env("IAS_STEM_GW_LDS")) {   // the VALU / LDS form (diagnostics)
     hipLaunchKernelGGL((stem_bwd_weight_kernel<3, 16>), dim3(STEM_CHUNKS_X, B), dim3(CV_THREADS), 0, (hipStream_t)stream_, x,
                        g, scratch, H, W, Ho, Wo, STEM_CHUNKS_X);
-  } else {
+  } else
+#endif
+  {
     const int waves = B * STEM_CHUNKS_X, rows_per_chunk = (Ho + STEM_CHUNKS_X - 1) / STEM_CHUNKS_X;
     hipLaunchKernelGGL((stem_bwd_weight_mfma_kernel<3, 16>), dim3((waves + CV_THREADS / 64 - 1) / (CV_THREADS / 64)),
                        dim3(CV_THREADS), 0, (hipStream_t)stream_, x, g, scratch, B, H, W, Ho, Wo, STEM_CHUNKS_X,

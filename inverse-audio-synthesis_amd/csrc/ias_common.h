@@ -12,6 +12,19 @@
 #define IAS_HD inline
 #endif
 
+// Diagnostic switches.  The product library (libias_hip.so) has one kernel per operation and shape and reads NOTHING from
+// the environment: there ias_diag_env() is the constant NULL, so every alternative behind it -- and the kernels only such
+// an alternative reaches, which are additionally fenced by #ifdef IAS_DIAG -- is compiled out, and the library keeps no
+// mutable global state.  `make diag` builds libias_hip_diag.so from the same sources with -DIAS_DIAG, where
+// the switches are live: scripts/diag, bench.py's `dxd` comparison figure, and the tests that compare a superseded kernel
+// with its replacement load THAT library (inverse-audio-synthesis_amd/_lib.py: load_diag / use_library).
+#ifdef IAS_DIAG
+#include <stdlib.h>
+static inline const char* ias_diag_env(const char* name) { return getenv(name); }
+#else
+#define ias_diag_env(name) ((const char*)0)
+#endif
+
 // Error codes returned by every C-ABI entry point.
 #define IAS_OK 0
 #define IAS_ERR_ARG (-1)        // bad pointer / dimension

@@ -1121,8 +1121,8 @@ extern "C" int ias_pqmf_analysis(const float* x, const float* H, const float* pa
   const int L = ias_pqmf_out_len(T, N, K);
   if (L <= 0) return IAS_ERR_ARG;
   if (packed && ((uintptr_t)packed & 7)) return IAS_ERR_ARG;
-  static const bool force_valu = getenv("IAS_PQMF_VALU") != nullptr;   // diagnostics: the pre-MFMA kernels
-  static const bool no_mod = getenv("IAS_PQMF_NOMOD") != nullptr;      // diagnostics: never the modulated form
+  static const bool force_valu = ias_diag_env("IAS_PQMF_VALU") != nullptr;   // diagnostics: the pre-MFMA kernels
+  static const bool no_mod = ias_diag_env("IAS_PQMF_NOMOD") != nullptr;      // diagnostics: never the modulated form
   if (modtab && !no_mod && !force_valu && N == 3 && K == 63 && (long long)B * N * L < 0x7fffff00LL) {
     // the cosine-modulated form: any alignment, any T
     const int zvec = ((uintptr_t)z & 15) == 0 && (L & 3) == 0;
@@ -1157,8 +1157,8 @@ extern "C" int ias_pqmf_analysis(const float* x, const float* H, const float* pa
       hipLaunchKernelGGL(kern, dim3(grid), dim3(PQ_THREADS), C::LDS_BYTES, stream, x, H, z, mean, stdv, rowpeak, T, \
                          L, pad, tiles_x, (int)ntiles, zvec);                                                     \
     } while (0)
-    static const int percu = getenv("IAS_PQM_PERCU") ? atoi(getenv("IAS_PQM_PERCU")) : 0;
-    static const bool tiled = getenv("IAS_PQM_TILED") != nullptr;   // diagnostics: workgroup-tiled kernel for N = 3, 4 too
+    static const int percu = ias_diag_env("IAS_PQM_PERCU") ? atoi(ias_diag_env("IAS_PQM_PERCU")) : 0;
+    static const bool tiled = ias_diag_env("IAS_PQM_TILED") != nullptr;   // diagnostics: workgroup-tiled kernel for N = 3, 4 too
 #define IAS_PQP_LAUNCH(NN, SS, PSHH, NORMM, PERCU)                                                                \
     do {                                                                                                          \
       using C = PqmfPipe<NN, 63, SS, PSHH>;                                                                       \

@@ -419,10 +419,10 @@ extern "C" int ias_stft_loss_backward(const float* audio, const float* window, c
   if (n_out <= 0 || n_out > n_fft / 2 + 1) return IAS_ERR_ARG;
   const int F = 1 + T / hop;
   if (F > 2147483647 / n_fft) return IAS_ERR_UNSUPPORTED;
-  if (tables != nullptr && getenv("IAS_STFT_GRAD_V1") == nullptr) {
+  if (tables != nullptr && ias_diag_env("IAS_STFT_GRAD_V1") == nullptr) {
     // the frame part on the forward's wave-per-frame FFT core; overlap-add inside the kernel where the shape allows it
     // (IAS_STFT_GRAD_NOSPAN=1: the [B,F,n_fft] tensor + stft_grad_ola_kernel of round 2)
-    static const bool nospan = getenv("IAS_STFT_GRAD_NOSPAN") != nullptr && atoi(getenv("IAS_STFT_GRAD_NOSPAN")) != 0;
+    static const bool nospan = ias_diag_env("IAS_STFT_GRAD_NOSPAN") != nullptr && atoi(ias_diag_env("IAS_STFT_GRAD_NOSPAN")) != 0;
     if (!nospan && (reinterpret_cast<uintptr_t>(frame_grad) & 15) == 0) {
       int plan[3] = {0, 0, 0};
       const int rs = ias_stft_grad_spans(audio, tables, mel_start, mel_count, mel_woff, mel_w, mel ? mel_nnz : 0, n_out,

@@ -24,7 +24,7 @@
 // for a kernel bound by LDS round-trip latency); one 12-wave workgroup per CU gives 3 (the 164 VGPRs allow no more).
 #define SP_WAVES_MAX 12
 static int stft_waves(int n_fft) {
-  static const int env = getenv("IAS_STFT_WAVES") ? atoi(getenv("IAS_STFT_WAVES")) : 0;   // diagnostics: 4, 8, 10 or 12
+  static const int env = ias_diag_env("IAS_STFT_WAVES") ? atoi(ias_diag_env("IAS_STFT_WAVES")) : 0;   // diagnostics: 4, 8, 10 or 12
   if (n_fft == 1024) return (env == 8 || env == 10) ? env : 4;
   if (n_fft == 2048) return env == 4 ? 4 : 12;
   return 4;
@@ -1838,7 +1838,7 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
   a.mel_start = mel_start; a.mel_count = mel_count; a.mel_woff = mel_woff; a.mel_w = mel_w;
   a.n_out = n_out; a.mel_nnz = mel ? mel_nnz : 0;
   a.G = a.cper = a.L = a.nchunks = 0;
-  static const int wgs_env = getenv("IAS_STFT_GRAD_WGS") ? atoi(getenv("IAS_STFT_GRAD_WGS")) : 0;   // diagnostics
+  static const int wgs_env = ias_diag_env("IAS_STFT_GRAD_WGS") ? atoi(ias_diag_env("IAS_STFT_GRAD_WGS")) : 0;   // diagnostics
   int per_row = (wgs_env > 0 ? wgs_env : 1024) / B;   // one resident round (measured: 2.36 -> 2.29 ms for the MR-STFT loss)
   if (per_row < 1) per_row = 1;
   int g = (F + per_row - 1) / per_row;
@@ -1863,7 +1863,7 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
     plan[0] = G; plan[1] = cper; plan[2] = (int)L;
     return true;
   };
-  static const int v1_2k = getenv("IAS_STFT_V1") ? atoi(getenv("IAS_STFT_V1")) : 0;   // diagnostics: round-2 kernels
+  static const int v1_2k = ias_diag_env("IAS_STFT_V1") ? atoi(ias_diag_env("IAS_STFT_V1")) : 0;   // diagnostics: round-2 kernels
   if (n_fft == 2048 && !mel && !v1_2k && (long long)B * F < 2000000000LL && (reinterpret_cast<uintptr_t>(frame_grad) & 15) == 0 &&
       (!span || (hop & 3) == 0)) {
     constexpr int W2 = 8;
@@ -1884,7 +1884,7 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
     }
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   }
-  static const int v1_512 = getenv("IAS_STFT_V1") ? atoi(getenv("IAS_STFT_V1")) : 0;
+  static const int v1_512 = ias_diag_env("IAS_STFT_V1") ? atoi(ias_diag_env("IAS_STFT_V1")) : 0;
   if (n_fft == 512 && span && !mel && !v1_512) {
     constexpr int W5 = 8;
     const size_t lds5 = sizeof(cpx) * (W5 * 64 * IAS_S2_ROW) + sizeof(float) * W5 * 512;
@@ -2008,7 +2008,7 @@ static size_t stft_lds_bytes(int n_fft, int mel_nnz, int n_out) {
 // alone (85.1 -> 78.9 us) and in the pipelined step (0.2085 -> 0.1983 ms, scripts/diag/run_bench_stftwgs.sh).
 static int stft_groups(int B, int F, int n_fft) {
   const int waves = stft_waves(n_fft);
-  static const int wgs_env = getenv("IAS_STFT_WGS") ? atoi(getenv("IAS_STFT_WGS")) : 0;   // diagnostics
+  static const int wgs_env = ias_diag_env("IAS_STFT_WGS") ? atoi(ias_diag_env("IAS_STFT_WGS")) : 0;   // diagnostics
   int per_row = (wgs_env > 0 ? wgs_env : (waves == 12 ? 256 : (waves >= 8 ? 512 : 1024))) / B;
   if (per_row < 1) per_row = 1;
   int g = (F + per_row - 1) / per_row;
@@ -2034,15 +2034,15 @@ int ias_sm_launch(const float* audio, const float* mtab, bool mel, float* out, c
 // record per 16-frame group and wave, the VALU kernel one per workgroup)
 // the round-3 radix-8 kernel (stft2_kernel): n_fft 1024; mel plans need their segment-major tables
 static int stft2_waves() {
-  static const int env = getenv("IAS_STFT2_WAVES") ? atoi(getenv("IAS_STFT2_WAVES")) : 0;   // diagnostics: 4, 5, 8 or 10
+  static const int env = ias_diag_env("IAS_STFT2_WAVES") ? atoi(ias_diag_env("IAS_STFT2_WAVES")) : 0;   // diagnostics: 4, 5, 8 or 10
   return (env == 4 || env == 5 || env == 8 || env == 10) ? env : 8;
 }
 static bool stft2_enabled(int n_fft, bool mel, bool have_segtab) {
-  static const int v1 = getenv("IAS_STFT_V1") ? atoi(getenv("IAS_STFT_V1")) : 0;   // diagnostics: round-2 kernel
+  static const int v1 = ias_diag_env("IAS_STFT_V1") ? atoi(ias_diag_env("IAS_STFT_V1")) : 0;   // diagnostics: round-2 kernel
   return !v1 && ((n_fft == 1024 && (!mel || have_segtab)) || ((n_fft == 2048 || n_fft == 512) && !mel));
 }
 static int stft2_grid(long long nframes, int n_fft) {
-  static const int env = getenv("IAS_STFT2_WGS") ? atoi(getenv("IAS_STFT2_WGS")) : 0;   // diagnostics
+  static const int env = ias_diag_env("IAS_STFT2_WGS") ? atoi(ias_diag_env("IAS_STFT2_WGS")) : 0;   // diagnostics
   static int ncu = 0;
   if (ncu == 0) {
     int dev = 0, v = 0;

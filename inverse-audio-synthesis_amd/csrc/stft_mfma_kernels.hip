@@ -236,6 +236,8 @@ struct SmArgs {
 #endif
 };
 
+#ifdef IAS_DIAG   // the device code and its launcher exist in the diagnostic library only (ias_common.h): the product library's
+                  // STFT is the radix-8 kernel family of spectral_kernels.hip / stft2_kernels.hip, whatever the environment says
 // In-kernel stamps (diagnostic build -DIAS_SM_STAMPS only; the product build compiles none of this): where a wave's
 // cycles go, phase by phase.  scripts/diag/stft_stamps.py builds and reads them.
 #ifdef IAS_SM_STAMPS
@@ -730,7 +732,7 @@ static int sm_num_cus() {
 }
 // workgroups of the persistent grid: three per CU (LDS, <= 168 VGPRs), never more than there are 16-frame groups
 int ias_sm_grid(long long nframes) {
-  static const int env = getenv("IAS_STFT_MFMA_WGS") ? atoi(getenv("IAS_STFT_MFMA_WGS")) : 0;   // diagnostics
+  static const int env = ias_diag_env("IAS_STFT_MFMA_WGS") ? atoi(ias_diag_env("IAS_STFT_MFMA_WGS")) : 0;   // diagnostics
   const long long ngroups = (nframes + 15) / 16;
   const long long cap = env > 0 ? env : 3LL * sm_num_cus();
   return (int)std::min(ngroups, cap);
@@ -743,7 +745,7 @@ long long ias_sm_partials(long long nframes) { return ((nframes + 15) / 16) * IA
 // DFT-as-GEMM is paid in full on the vector ALU and this kernel (85-90 us at the headline size) loses to the radix-8
 // FFT kernel (csrc/spectral_kernels.hip).  Kept as the measured record of that experiment and for its tests.
 bool ias_sm_enabled(int n_fft, bool have_mtables) {
-  static const int on = getenv("IAS_STFT_MFMA") ? atoi(getenv("IAS_STFT_MFMA")) : 0;
+  static const int on = ias_diag_env("IAS_STFT_MFMA") ? atoi(ias_diag_env("IAS_STFT_MFMA")) : 0;
   return on && have_mtables && n_fft == 1024;
 }
 
@@ -761,7 +763,7 @@ int ias_sm_launch(const float* audio, const float* mtab, bool mel, float* out, c
   SmArgs a;
   a.audio = audio; a.mtab = mtab; a.out = out; a.target = target; a.partials = partials; a.rowpeak = rowpeak;
   a.T = T; a.F = F; a.hop = hop; a.n_out = n_out; a.nframes = B * F; a.ngroups = (a.nframes + 15) / 16;
-  static const int noticket = getenv("IAS_STFT_NOTICKET") ? atoi(getenv("IAS_STFT_NOTICKET")) : 0;   // diagnostics
+  static const int noticket = ias_diag_env("IAS_STFT_NOTICKET") ? atoi(ias_diag_env("IAS_STFT_NOTICKET")) : 0;   // diagnostics
   a.ticket = noticket ? nullptr : ticket;
   a.magicF = (F == 1 ? 0xFFFFFFFFu /* 2^32 / 1 does not fit: q0 = fi - 1, which row_of's one-step correction fixes */ : (unsigned)(0x100000000ULL / (unsigned long long)F));
   a.value_mode = value_mode; a.loss_mode = loss_mode; a.eps = eps;
@@ -796,3 +798,12 @@ int ias_sm_launch(const float* audio, const float* mtab, bool mel, float* out, c
 #undef IAS_SM_LAUNCH
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
+#else   // product library: the matrix-core STFT is not built
+bool ias_sm_enabled(int, bool) { return false; }
+long long ias_sm_partials(long long nframes) { return ((nframes + 15) / 16) * IAS_SM_WAVES; }
+int ias_sm_launch(const float*, const float*, bool, float*, const float*, double*, const float*, int*, int, int, int, int, int, int,
+                  int, int, float, hipStream_t) {
+  return IAS_ERR_UNSUPPORTED;
+}
+#endif
+

@@ -872,7 +872,7 @@ static inline size_t vc_align(size_t x) { return (x + 255) / 256 * 256; }
 struct VicregWs { size_t xt_x, xt_y, colstats, mse, hinge, diag, gram_x, gram_y, xc_x, xc_y, bgram, bgram16, gdiag, g2part, total; int Kpad, ntile, ngram, nmse, nsplit, ksplit, ng2; bool t256, b256, dual; };
 // IAS_VICREG_GRAM128=1 (diagnostics): the 128 x 128 register-staged kernels of round 2 for batch > 128 as well
 static bool vicreg_force128() {
-  static const bool v = getenv("IAS_VICREG_GRAM128") != nullptr && atoi(getenv("IAS_VICREG_GRAM128")) != 0;
+  static const bool v = ias_diag_env("IAS_VICREG_GRAM128") != nullptr && atoi(ias_diag_env("IAS_VICREG_GRAM128")) != 0;
   return v;
 }
 // The covariance term from the batch side.  sum_{i != j} C_ij^2 with C = Xc^T Xc (D x D) equals ||G||_F^2 - sum_j C_jj^2
@@ -880,7 +880,10 @@ static bool vicreg_force128() {
 // anyway (G vc).  Taken whenever the padded batch is no larger than the embedding (B = 128 / 1024 against D = 8192: 64x /
 // 8x fewer flops); the feature-side kernels stay for batch > D.  No cancellation on this side of the switch: C has rank
 // < B, so ||C||_F^2 >= (tr C)^2 / (B - 1) >= D / (B - 1) times its diagonal's share.
-// ias_vicreg_set_form(0 / 1 / -1): feature side always / batch side where it applies / default (env IAS_VICREG_DXD=1 -> 0).
+// Which side is taken is a pure function of the shape: the library keeps no state.  (Diagnostic library only:
+// ias_vicreg_set_form(0 / 1 / -1) = feature side always / batch side where it applies / default, and the environment
+// switch IAS_VICREG_DXD=1 -> 0: bench.py times the D x D kernels of rounds 1-3 through THAT library for `roofline.dxd`.)
+#ifdef IAS_DIAG
 static int g_vicreg_form = -1;
 extern "C" int ias_vicreg_set_form(int form) {
   if (form < -1 || form > 1) return IAS_ERR_ARG;
@@ -888,10 +891,13 @@ extern "C" int ias_vicreg_set_form(int form) {
   return IAS_OK;
 }
 static bool vicreg_batch_side(int Kpad, int D) {
-  static const bool env_dxd = getenv("IAS_VICREG_DXD") != nullptr && atoi(getenv("IAS_VICREG_DXD")) != 0;
+  static const bool env_dxd = ias_diag_env("IAS_VICREG_DXD") != nullptr && atoi(ias_diag_env("IAS_VICREG_DXD")) != 0;
   const bool want = g_vicreg_form < 0 ? !env_dxd : g_vicreg_form == 1;
   return want && D >= 8 && (D & 7) == 0 && Kpad <= D;
 }
+#else
+static bool vicreg_batch_side(int Kpad, int D) { return D >= 8 && (D & 7) == 0 && Kpad <= D; }
+#endif
 
 static VicregWs vicreg_ws(int B, int D) {
   VicregWs w;
@@ -975,7 +981,7 @@ static int vicreg_stage_ld(int stage, const float* x, const float* y, long long 
                          (double*)(ws + w.diag), (unsigned short*)(ws + w.xc_x), (unsigned short*)(ws + w.xc_y), B, D, w.Kpad,
                          (size_t)ld);
     };
-    static const bool reread = getenv("IAS_VICREG_COLSTATS_REREAD") != nullptr;   // (diagnostics: the two-read form at any batch)
+    static const bool reread = ias_diag_env("IAS_VICREG_COLSTATS_REREAD") != nullptr;   // (diagnostics: the two-read form at any batch)
     if (reread || w.Kpad > 1024) launch(vicreg_colstats_kernel<0>);
     else if (w.Kpad <= 128) launch(vicreg_colstats_kernel<4>);
     else if (w.Kpad <= 256) launch(vicreg_colstats_kernel<8>);

@@ -943,7 +943,7 @@ __global__ void voice_grad_scalars_kernel(const double* __restrict__ partials, d
 // IAS_VOICE_GRAD_V1=1: the chunk-scan kernels + separate transposed upsample for every shape (A/B and the test that compares
 // the two forms; read at every call)
 static bool voice_grad_force_v1() {
-  const char* e = getenv("IAS_VOICE_GRAD_V1");
+  const char* e = ias_diag_env("IAS_VOICE_GRAD_V1");
   return e && e[0] && e[0] != '0';
 }
 extern "C" int ias_voice_grad_tiles(int T) { return T > 0 ? (T + GRAD_TILE - 1) / GRAD_TILE : IAS_ERR_ARG; }

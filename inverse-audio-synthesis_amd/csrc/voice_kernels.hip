@@ -614,6 +614,7 @@ __global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) void voice_audio_ke
         if (timeout) {
           a1 = a2 = __longlong_as_double(0x7ff8000000000000ll);
           __hip_atomic_store((gu32*)ticket_status + VOICE_NCOUNTERS * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store((gu32*)ticket_status - 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky (VoiceWs::off_sticky)
         }
         s_carry[0] = a1; s_carry[1] = a2;
       }
@@ -700,7 +701,7 @@ __global__ __launch_bounds__(256) void voice_normalize_kernel(float* __restrict_
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct VoiceWs {
-  size_t off_ctrl, off_vconst, off_env, off_sync, sync_bytes, off_agg, off_peak, total;
+  size_t off_ctrl, off_vconst, off_env, off_sticky, off_sync, sync_bytes, off_agg, off_peak, total;
   int ntiles;
 };
 static VoiceWs voice_ws_layout(int B, int T, int Tc) {
@@ -710,6 +711,11 @@ static VoiceWs voice_ws_layout(int B, int T, int Tc) {
   w.off_ctrl = o;    o = align_up(o + sizeof(float) * (size_t)B * IAS_NCTRL * Tc, 256);
   w.off_vconst = o;  o = align_up(o + sizeof(IasVoiceConst) * (size_t)B, 256);
   w.off_env = o;     o = align_up(o + sizeof(float) * (size_t)B * 8 * Tc, 256);
+  // the STICKY status word: one 128-byte line directly in front of the zeroed block, set together with the per-launch
+  // status word and never cleared by a render (ias_voice_read_status_sticky clears it on request): a training loop that
+  // only looks every N steps still learns that SOME render since its last look lost a tile.  The caller zeroes the
+  // workspace once after allocating it.
+  w.off_sticky = o;  o += 128;
   // words zeroed before every launch, in one block of their own (multiple of 16 bytes):
   // [ticket counters: one 128-byte line each][status word line][agg: B*ntiles*2 u64][row peaks: B u32]
   w.off_sync = o;
@@ -794,13 +800,13 @@ static int voice_audio_grid(size_t lds, int total_tiles) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, voice_audio_kernel<MATH, FMA_DIV>, AUDIO_THREADS, lds) != hipSuccess ||
         per_cu < 1)
       per_cu = 2;
-    if (const char* e = getenv("IAS_VOICE_PERCU")) {   // diagnostics: fewer resident workgroups (room for neighbours)
+    if (const char* e = ias_diag_env("IAS_VOICE_PERCU")) {   // diagnostics: fewer resident workgroups (room for neighbours)
       const int v = atoi(e);
       if (v >= 1 && v < per_cu) per_cu = v;
     }
     cached_grid = per_cu * ncu;
     cached_lds = (int)lds;
-    if (getenv("IAS_DEBUG")) fprintf(stderr, "[ias] voice_audio_kernel: %d workgroups/CU x %d CUs, %zu B LDS\n", per_cu, ncu, lds);
+    if (ias_diag_env("IAS_DEBUG")) fprintf(stderr, "[ias] voice_audio_kernel: %d workgroups/CU x %d CUs, %zu B LDS\n", per_cu, ncu, lds);
   }
   return cached_grid < total_tiles ? cached_grid : total_tiles;
 }
@@ -889,6 +895,20 @@ extern "C" int ias_voice_read_status(const void* workspace, unsigned* status_dev
   if (hipMemcpyAsync(status_dev, (const char*)workspace + w.off_sync + VOICE_NCOUNTERS * 128, sizeof(unsigned), hipMemcpyDeviceToDevice,
                      (hipStream_t)stream_) != hipSuccess)
     return IAS_ERR_LAUNCH;
+  return IAS_OK;
+}
+
+// The sticky status word -> status_dev: non-zero if ANY render into this workspace since the word was last cleared lost a
+// tile (see VoiceWs::off_sticky); clear != 0 re-zeroes it behind the read, in stream order.  The workspace must have been
+// zeroed once after allocation.
+extern "C" int ias_voice_read_status_sticky(void* workspace, unsigned* status_dev, int B, int T, int Tc, int clear,
+                                            void* stream_) {
+  if (!workspace || !status_dev) return IAS_ERR_ARG;
+  const VoiceWs w = voice_ws_layout(B, T, Tc);
+  char* word = (char*)workspace + w.off_sticky;
+  if (hipMemcpyAsync(status_dev, word, sizeof(unsigned), hipMemcpyDeviceToDevice, (hipStream_t)stream_) != hipSuccess)
+    return IAS_ERR_LAUNCH;
+  if (clear && hipMemsetAsync(word, 0, sizeof(unsigned), (hipStream_t)stream_) != hipSuccess) return IAS_ERR_LAUNCH;
   return IAS_OK;
 }
 

@@ -64,13 +64,33 @@ class LARS(torch.optim.Optimizer):
 
 
     # ------------------------------------------------------------------ fused HIP path (momentum 0)
+    HYPER_RING = 8   # pinned staging slots of the device hyper-parameters (see _sync_group_hyper)
+
     @staticmethod
     def _sync_group_hyper(group, ent):
+        """Push (lr, weight decay, trust coefficient, eps) to the device scalars the fused step reads, when they changed.
+        The copy is asynchronous and the host may run many steps ahead of the GPU (a replaying loop never synchronises),
+        so the staging buffer a copy reads must not be rewritten before that copy has executed: the values go through a
+        ring of pinned slots, each guarded by an event recorded behind its last copy (the host only waits when it is a
+        whole ring ahead).  Never inside a hipGraph capture: a captured copy would re-read its slot at every replay and
+        put a stale learning rate back; the replaying loop pushes the values itself (``sync_hyper``) before each replay."""
         vals = (float(group["lr"]), float(group["weight_decay"]), float(group["trust_coefficient"]), float(group["eps"]))
-        if ent["hyper_vals"] != vals:
-            ent["hyper_host"].copy_(torch.tensor(vals, dtype=torch.float32))
-            ent["hyper"].copy_(ent["hyper_host"], non_blocking=True)
-            ent["hyper_vals"] = vals
+        if ent["hyper_vals"] == vals:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            ent["hyper_vals"] = None
+            return
+        i = ent["ring_pos"]
+        ent["ring_pos"] = (i + 1) % len(ent["ring"])
+        if ent["ring_events"][i] is not None:
+            ent["ring_events"][i].synchronize()
+        host = ent["ring"][i]
+        host[0], host[1], host[2], host[3] = vals
+        ent["hyper"].copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ent["ring_events"][i] = ev
+        ent["hyper_vals"] = vals
 
     def sync_hyper(self):
         """Push lr / weight decay / trust coefficient / eps of every group to the device scalars the fused step reads.
@@ -114,7 +134,8 @@ class LARS(torch.optim.Optimizer):
                        tensors=t_dev, chunks=c_dev, first=f_dev,
                        partials=torch.empty(2 * len(chunks), dtype=torch.float64, device=dev),
                        coef=torch.empty(2 * len(key), dtype=torch.float32, device=dev),
-                       hyper_host=torch.empty(4, dtype=torch.float32).pin_memory(),
+                       ring=[torch.empty(4, dtype=torch.float32).pin_memory() for _ in range(self.HYPER_RING)],
+                       ring_events=[None] * self.HYPER_RING, ring_pos=0,
                        hyper=torch.empty(4, dtype=torch.float32, device=dev), hyper_vals=None)
             cache[gi] = ent
         self._sync_group_hyper(group, ent)

@@ -65,13 +65,24 @@ def setup_gemm_tuning(mode):
         import torch.cuda.tunable as tunable
         tunable.enable(True)
         tunable.tuning_enable(mode == "online")
-        # whatever TunableOp writes goes to a scratch file (online: ./tunableop_online.csv), never into the shipped table
+        # whatever TunableOp writes goes to a scratch file of this rank's own (online: ./tunableop_online_rank<r>.csv), never
+        # into the shipped table; in "file" mode nothing is recorded, so nothing is written at exit either
         import tempfile
-        tunable.set_filename(os.path.join(os.getcwd(), "tunableop_online.csv") if mode == "online" else
-                             os.path.join(tempfile.gettempdir(), f"ias_tunableop_{os.getpid()}.csv"), False)
-        if os.path.exists(TUNING_FILE):
-            tunable.read_file(TUNING_FILE)
-        return "online" if mode == "online" else "file"
+        rank = int(os.environ.get("RANK", "0"))
+        if mode == "online":
+            tunable.set_filename(os.path.join(os.getcwd(), f"tunableop_online_rank{rank}.csv"), False)
+        else:
+            tunable.set_filename(os.path.join(tempfile.gettempdir(), f"ias_tunableop_{os.getpid()}.csv"), False)
+            tunable.write_file_on_exit(False)
+        loaded = os.path.exists(TUNING_FILE) and bool(tunable.read_file(TUNING_FILE))
+        if mode == "online":
+            return "online"
+        if not loaded:
+            # no table, or one recorded with other library versions (TunableOp's validators reject it): the libraries'
+            # default solutions -- say so instead of reporting a table that is not in use
+            tunable.enable(False)
+            return "unavailable"
+        return "file"
     except Exception as ex:  # noqa: BLE001 -- a torch build without TunableOp: the libraries' defaults
         import warnings
         warnings.warn(f"trainer.gemm_tuning: TunableOp not available ({type(ex).__name__}: {ex})")
@@ -108,6 +119,17 @@ class Trainer:
         if self.rank == 0:
             print(json.dumps(rec), flush=True)
 
+    def _check_render(self):
+        """At the logging cadence (which synchronises anyway): did ANY render since the last look lose a tile?  The render
+        turns such a tile into NaN audio, the loss follows, and without this the run would log NaNs without a reason (the
+        reference runs with detect_anomaly=True, pretrain.py:96).  Reads the STICKY status word, so it also covers the
+        steps nobody looked at, and steps replayed from the captured graph."""
+        voice = getattr(self.module, "voice", None)
+        if voice is not None and hasattr(voice, "chain_status_sticky") and self.device.type == "cuda" and \
+                voice.chain_status_sticky() != 0:
+            raise RuntimeError("voice render: a tile's bounded wait for its predecessors expired in a training step since the "
+                               "last check (ias_voice_read_status_sticky != 0): that step's audio, loss and update are NaN")
+
     def save_checkpoint(self, name):
         if self.rank != 0:
             return None
@@ -131,9 +153,16 @@ class Trainer:
 
     # ---- whole-step hipGraph (trainer.cuda_graph) --------------------------------------------------------------
     def _use_graph(self):
-        return bool(self.cfg.trainer.get("cuda_graph")) and self.world == 1 and self.stage == "vicreg" and \
-            self.device.type == "cuda" and hasattr(self.module, "voice") and not getattr(self, "_graph_failed", False) \
-            and not os.environ.get("IAS_CHECK_STATUS")
+        """The whole step replays from one captured hipGraph when asked to (trainer.cuda_graph) -- on several ranks too: the
+        bucketed gradient all-reduces (and the embedding gather of trainer.gather_embeddings) are RCCL collectives, which
+        capture like any other stream work; only a gloo group (tests / rehearsals on CPU transport) has to stay eager."""
+        import torch.distributed as dist
+        if not (bool(self.cfg.trainer.get("cuda_graph")) and self.stage == "vicreg" and self.device.type == "cuda" and
+                hasattr(self.module, "voice") and not getattr(self, "_graph_failed", False)):
+            return False
+        if self.bucketer.collective or self.world > 1:
+            return dist.is_initialized() and dist.get_backend() == "nccl"
+        return True
 
     def _graph_step(self, batch, step, warmup=3):
         """One training step as a replay of ONE captured hipGraph: render + PQMF + trunk + projector + loss + backward +
@@ -144,35 +173,40 @@ class Trainer:
         is captured (and executed by its first replay)."""
         m, opt = self.module, self.optimizer
         m.voice.randomize(int(batch))
-        if hasattr(opt, "sync_hyper"):
-            opt.sync_hyper()
+
+        def one_step():
+            self.bucketer.begin_step()            # drop / zero the gradients (a captured step's own live in the graph's pool)
+            m.training_step(None, step).backward()
+            self.bucketer.finish()                # several ranks: the bucket all-reduces, issued during backward, joined here
+            opt.step()
+
         g = getattr(self, "_graph", None)
         if g is None:
             n = getattr(self, "_graph_warm", 0)
             if n < warmup:
                 self._graph_warm = n + 1
-                self.bucketer.begin_step()
-                m.training_step(None, step).backward()
-                opt.step()
+                one_step()
                 return
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g):
-                    self.bucketer.begin_step()        # drop the gradients: the step's own live in the graph's pool
-                    m.training_step(None, step).backward()
-                    opt.step()
+                # with collectives in the step the capture must not trip over RCCL's watchdog thread polling its events
+                mode = "thread_local" if self.bucketer.collective or self.world > 1 else "global"
+                with torch.cuda.graph(g, capture_error_mode=mode):
+                    one_step()
             except Exception as ex:                   # something in the step cannot be captured: stay eager
                 import warnings
                 warnings.warn(f"trainer.cuda_graph: capture failed ({type(ex).__name__}: {ex}); running eagerly")
                 self._graph_failed = True
                 torch.cuda.synchronize(self.device)
-                self.bucketer.begin_step()
-                m.training_step(None, step).backward()
-                opt.step()
+                one_step()
                 return
             self._graph = g
             self._graph_logged = m.logged         # the metric tensors of the captured step (graph pool memory)
+        # the learning rate of THIS step -> the device scalars the captured LARS launches read (a capture never contains
+        # that copy: optim.LARS._sync_group_hyper), in stream order ahead of the replay
+        if hasattr(opt, "sync_hyper"):
+            opt.sync_hyper()
         g.replay()
         # evaluate() rebinds module.logged to its own eager tensors; a replay re-runs no Python, so point it back at
         # the tensors the replayed kernels write
@@ -209,6 +243,7 @@ class Trainer:
                 self.scheduler.step()
             self._step = step + 1
             if step % int(cfg.trainer.log_every) == 0 or step == steps - 1:
+                self._check_render()
                 self._log(step, {"elapsed_s": round(time.perf_counter() - t0, 3)})
             every = st.get("checkpoint_every_nbatches")
             if every and (step + 1) % int(every) == 0:

@@ -7,7 +7,7 @@ the architecture (Howard et al. 2019, "small" table) is defined here with torchv
 random-initialised; ``pretrained=True`` only warns.  On a ROCm device in fp32 the depthwise, stem and thin 1x1
 convolutions, BatchNorm + activation and the squeeze-excitation blocks run on this repo's HIP kernels
 (csrc/conv_kernels.hip, pointwise_kernels.hip, bn_kernels.hip, se_kernels.hip), the wide 1x1 convolutions as
-rocBLAS / hipBLASLt GEMMs; everything else (CPU tensors, other dtypes, IAS_TRUNK_TORCH=1) takes the torch.nn layers
+rocBLAS / hipBLASLt GEMMs; everything else (CPU tensors, other dtypes) takes the torch.nn layers these modules subclass
 (the trunk is a caller of the hot path, not part of it).
 """
 import os
@@ -17,20 +17,23 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+# Diagnostics only (scripts/diag set these attributes; nothing in the package or the environment does): every layer of the
+# trunk AND the conv head of audioembed.py on their torch.nn parents (MIOpen / rocBLAS) / the thin 1x1 convolutions as
+# batched GEMMs -- for A/B timing against the HIP kernels.
+FORCE_TORCH_LAYERS = False
+FORCE_PW_BMM = False
+
+
 def trunk_torch():
-    """IAS_TRUNK_TORCH=1: every layer of the trunk AND the conv head of audioembed.py take their torch.nn fallback
-    (MIOpen / rocBLAS): one switch for A/B debugging, read at every forward in this one place."""
-    return os.environ.get("IAS_TRUNK_TORCH") == "1"
+    return FORCE_TORCH_LAYERS
 
 
 _PW_SUPPORTED = {}
 
 
 def _pw_mfma(cin, cout):
-    """Whether csrc/pointwise_kernels.hip takes this 1x1 convolution (ias_pwconv_supported); IAS_PW_BMM=1 keeps the
-    batched-GEMM form everywhere (diagnostics)."""
-    import os
-    if os.environ.get("IAS_PW_BMM"):
+    """Whether csrc/pointwise_kernels.hip takes this 1x1 convolution (ias_pwconv_supported)."""
+    if FORCE_PW_BMM:
         return False
     key = (cin, cout)
     if key not in _PW_SUPPORTED:

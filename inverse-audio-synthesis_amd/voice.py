@@ -173,7 +173,7 @@ class Voice(nn.Module):
         if need < 0:
             _lib.check(int(need), "ias_voice_workspace_bytes")
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != p.device:
-            self._workspace = torch.empty(int(need), dtype=torch.uint8, device=p.device)
+            self._workspace = torch.zeros(int(need), dtype=torch.uint8, device=p.device)   # (zeroed once: sticky status word)
         audio = torch.empty((c.batch_size, c.buffer_size), dtype=torch.float32, device=p.device)
         st = lib.ias_voice_render(_lib.ptr(p), _lib.ptr(self.noise), _lib.ptr(audio), _lib.ptr(self._workspace),
                                   self._workspace.numel(), c.batch_size, c.buffer_size, c.control_buffer_size,
@@ -186,7 +186,7 @@ class Voice(nn.Module):
         """A private workspace for double-buffered pipelines (see ``render_control`` / ``render_audio``)."""
         c = self.synthconfig
         need = int(_lib.load().ias_voice_workspace_bytes(c.batch_size, c.buffer_size, c.control_buffer_size))
-        return torch.empty(need, dtype=torch.uint8, device=device or self.params01.device)
+        return torch.zeros(need, dtype=torch.uint8, device=device or self.params01.device)   # (zeroed once: sticky status word)
 
     def render_control(self, workspace, params01=None):
         """Control-rate pass only (78 params -> control signals + per-voice constants) into ``workspace``."""
@@ -265,6 +265,20 @@ class Voice(nn.Module):
         _lib.check(_lib.load().ias_voice_read_status(_lib.ptr(ws), _lib.ptr(st), c.batch_size,
                                                      c.buffer_size, c.control_buffer_size, _lib.stream()),
                    "ias_voice_read_status")
+        return int(st.item())
+
+    def chain_status_sticky(self, workspace=None, clear=True):
+        """Non-zero if ANY render into ``workspace`` (default: the module's own) since the last cleared look lost a tile
+        (``ias_voice_read_status_sticky``): what a loop that checks every N steps reads -- also behind a replayed hipGraph,
+        where no Python runs per step.  Synchronises (reads one word back)."""
+        c = self.synthconfig
+        ws = self._workspace if workspace is None else workspace
+        if ws is None:
+            return 0
+        st = torch.zeros(1, dtype=torch.int32, device=ws.device)
+        _lib.check(_lib.load().ias_voice_read_status_sticky(_lib.ptr(ws), _lib.ptr(st), c.batch_size, c.buffer_size,
+                                                            c.control_buffer_size, 1 if clear else 0, _lib.stream()),
+                   "ias_voice_read_status_sticky")
         return int(st.item())
 
     def _check_chain(self, workspace):

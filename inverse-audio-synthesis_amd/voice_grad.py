@@ -187,6 +187,13 @@ class BackwardPrelude:
             side = self._streams[dev] = torch.cuda.Stream(device=dev)
         side.wait_stream(cur)
         self.ctrl_ok = True
+        self._joined = False
+        # Everything the side stream touches was allocated on (or belongs to) the CURRENT stream: tell the caching allocator
+        # (as spectral.py does for its side streams), or a render whose autograd node is dropped without a backward -- a
+        # grad-enabled render used only for metrics, an exception, `del loss` -- would hand these blocks to current-stream
+        # work while the side-stream kernels are still writing / reading them.
+        for t in (self.planes, self.tile_sums, self.cws, p, ctrl, vconst):
+            t.record_stream(side)
         with torch.cuda.stream(side):
             st = lib.ias_voice_backward_sums_stage(0, _lib.ptr(ctrl), _lib.ptr(vconst), None, None, None, _lib.ptr(self.planes),
                                                    _lib.ptr(self.tile_sums), None, None, None, B, T, Tc, c.sample_rate,
@@ -202,6 +209,16 @@ class BackwardPrelude:
 
     def join(self):
         torch.cuda.current_stream(self.planes.device).wait_stream(self.side)
+        self._joined = True
+
+    def __del__(self):
+        # a prelude that never saw its backward still has to be joined: inside a hipGraph capture an unjoined fork fails
+        # the capture, outside one it would let later current-stream work overtake the side stream's kernels
+        try:
+            if not getattr(self, "_joined", True):
+                self.join()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 def prelude_enabled():

@@ -39,3 +39,36 @@ def test_voice_spec_tables_agree():
     from inverse_audio_synthesis_amd import voice_spec as b
     assert a.PARAMS == b.PARAMS and a.NPARAMS == b.NPARAMS == 78
     assert (a.CONTROL_RATE, a.EPS, a.NOISE_SEED, a.LFO_EXPONENT) == (b.CONTROL_RATE, b.EPS, b.NOISE_SEED, b.LFO_EXPONENT)
+
+
+def _declared_in(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ias_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_product_library_reads_no_environment_and_keeps_no_switch(lib):
+    """"reentrant; no global state except read-only tap tables".  The product library does not import
+    getenv, contains none of the IAS_* switch names, and does not export the process-wide ias_vicreg_set_form; the
+    sources reach the environment only through ias_diag_env(), which is a constant outside -DIAS_DIAG builds."""
+    import subprocess
+    from inverse_audio_synthesis_amd import _lib
+    syms = subprocess.run(["nm", "-D", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert "getenv" not in syms
+    assert "ias_vicreg_set_form" not in syms
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"IAS_STFT_MFMA", b"IAS_VICREG_DXD", b"IAS_VOICE_PERCU", b"IAS_PQMF_VALU", b"IAS_STFT_V1", b"IAS_BN_UNFUSED"):
+        assert name not in blob, name
+    csrc = os.path.join(ROOT, "inverse-audio-synthesis_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(".hip"):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+
+
+def test_diagnostic_library_exports_the_product_abi_plus_its_own(lib):
+    from inverse_audio_synthesis_amd import _lib
+    diag = _lib.load_diag()            # binds every product symbol and every diagnostic-only symbol, or raises
+    extra = _declared_in("ias_hip_diag.h")
+    assert extra == sorted(_lib.DIAG_SYMBOLS) == ["ias_vicreg_set_form"]
+    assert diag.ias_version() == lib.ias_version()
+    assert diag.ias_vicreg_set_form(7) < 0 and diag.ias_vicreg_set_form(-1) == 0

@@ -153,3 +153,43 @@ def test_two_rank_training_with_gathered_embeddings(lib, dev, tmp_path):
         for k in s0["local"]:
             assert abs(s0["local"][k] - s1["local"][k]) <= 1e-5 * max(1.0, abs(s0["local"][k])), (k, s0["local"], s1["local"])
     assert recs[0]["steps"][0]["digest"] != recs[0]["steps"][2]["digest"]
+
+
+def test_captured_ddp_step_equals_the_eager_loop_on_a_one_rank_rccl_group(lib, dev, tmp_path, nccl_group):
+    """trainer.cuda_graph with the gradient all-reduce INSIDE the captured graph (round 5; reference: Lightning strategy
+    "ddp" around the training step, pretrain.py:91-118, conf/config.yaml:6-8): on a one-rank RCCL group with
+    GradBucketer(always_reduce=True) the bucket all-reduces are real RCCL launches in the step.  Six steps (three eager
+    warm-up steps, the capture, replays) of the same small run, captured against eager: the logged losses, the learning
+    rates and the final parameters agree bit for bit, and the captured run did go through the collective path."""
+    import os
+    from conftest import ROOT
+    from inverse_audio_synthesis_amd import dist as ias_dist
+    from inverse_audio_synthesis_amd.config import load_config
+    from inverse_audio_synthesis_amd.harness import VicregAudioParams
+    from inverse_audio_synthesis_amd.trainer import Trainer
+    small = ["vicreg=fast", "vicreg.batch_size=4", "dim=64", "embeddim=256",
+             "vicreg.mlp=128-128-%d", "trainer.log_every=1", "vicreg.checkpoint_every_nbatches=null", "param_embed.dropout=0.0",
+             "trainer.bucket_mb=1"]
+    results = {}
+    for mode in ("false", "true"):
+        cfg = load_config(os.path.join(ROOT, "conf"), "config", small + [f"trainer.cuda_graph={mode}",
+                                                                       f"trainer.out_dir={tmp_path / mode}"])
+        torch.manual_seed(42)
+        m = VicregAudioParams(cfg)
+        tr = Trainer(cfg, m, stage="vicreg", device=dev)
+        tr.bucketer = ias_dist.GradBucketer(m, bucket_bytes=1 << 20, always_reduce=True)
+        assert tr.bucketer.collective and len(tr.bucketer.buckets) > 1
+        assert tr._use_graph() == (mode == "true")
+        hist = tr.fit(max_steps=6)
+        if mode == "true":
+            assert getattr(tr, "_graph", None) is not None and not getattr(tr, "_graph_failed", False)
+        results[mode] = (hist, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    he, hg = results["false"][0], results["true"][0]
+    assert len(he) == len(hg) == 6
+    for a, b in zip(he, hg):
+        assert a["lr"] == b["lr"]
+        for k in ("vicreg/train/loss", "vicreg/train/repr_loss", "vicreg/train/std_loss", "vicreg/train/cov_loss"):
+            assert a[k] == b[k], (k, a, b)
+    assert he[0]["vicreg/train/loss"] != he[-1]["vicreg/train/loss"]
+    for k, v in results["false"][1].items():
+        assert torch.equal(v, results["true"][1][k]), k

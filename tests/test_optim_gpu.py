@@ -54,3 +54,44 @@ def test_fused_lars_is_deterministic_and_handles_unaligned_views(lib, dev):
         outs.append(buf.clone())
         assert buf[0] == base[0] and torch.equal(buf[70002:70004], base[70002:70004])   # nothing written outside
     assert torch.equal(outs[0], outs[1])
+
+
+def test_replayed_lars_reads_each_steps_learning_rate_without_a_sync(lib, dev):
+    """A captured LARS step replayed in a loop whose host side runs ahead of the GPU (no synchronisation between steps,
+    a new learning rate every step, as Trainer._graph_step does under the warm-up schedule) against the eager loop, bit for
+    bit.  The learning rate reaches the captured launches through device scalars fed by an asynchronous copy from pinned
+    memory: with ONE staging buffer (round 4) step k's copy could read step k+1's value; the ring of guarded slots
+    (optim.LARS._sync_group_hyper) cannot.  The parameters are large enough (64 MB) that every replay takes far longer than
+    the host needs to queue the next one, and there are more steps than ring slots."""
+    n, steps = 16 << 20, 3 * LARS.HYPER_RING + 2
+    g = torch.Generator().manual_seed(5)
+    init = torch.randn(n, generator=g)
+    grad = (torch.randn(n, generator=g) * 0.1).to(dev)
+    lrs = [0.3 / (1 + k) for k in range(steps)]
+
+    def run(replayed):
+        p = torch.nn.Parameter(init.clone().to(dev))
+        opt = LARS([p], lr=lrs[0], weight_decay=1e-3)
+        p.grad = grad.clone()
+        graph = None
+        if replayed:
+            opt.step()                                    # (tables built eagerly once; undone below)
+            with torch.no_grad():
+                p.copy_(init.to(dev))
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                opt.step()
+        for k in range(steps):
+            opt.param_groups[0]["lr"] = lrs[k]
+            if graph is None:
+                opt.step()
+            else:
+                opt.sync_hyper()
+                graph.replay()                            # no synchronisation: the host is many steps ahead of the GPU
+        torch.cuda.synchronize()
+        return p.detach().clone()
+
+    eager, replay = run(False), run(True)
+    assert torch.isfinite(eager).all() and not torch.equal(eager.cpu(), init)
+    assert torch.equal(eager, replay)

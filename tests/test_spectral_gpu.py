@@ -112,9 +112,11 @@ def test_mrstft_cached_targets_equal_recomputed(lib, dev):
 
 @pytest.mark.parametrize("env", [{"IAS_STFT_MFMA": "1"}, {"IAS_STFT_V1": "1"}])
 def test_alternative_stft_kernels_in_a_child_process(lib, dev, env):
-    """The kernel choice is read once per process from the environment: the opt-in matrix-core kernel (IAS_STFT_MFMA=1,
-    DESIGN.md section 0) and the round-2 kernel (IAS_STFT_V1=1) are checked in a child process (a fresh interpreter, not a
-    re-exec of this one) against the same oracle and tolerances as the default kernel: mel spectrogram, raw power
+    """The DIAGNOSTIC library (csrc/libias_hip_diag.so; the product library reads nothing from the environment and does
+    not contain the matrix-core kernel) reads the kernel choice once per process from the environment: the opt-in
+    matrix-core kernel (IAS_STFT_MFMA=1) and the round-2 kernel (IAS_STFT_V1=1) are checked in a
+    child process (a fresh interpreter, not a re-exec of this one; IAS_HIP_LIB points the package at the diagnostic
+    library) against the same oracle and tolerances as the default kernel: mel spectrogram, raw power
     spectrogram with a hop that is not a multiple of four samples, and the fused mel-L1 loss."""
     import os
     import subprocess
@@ -140,8 +142,9 @@ ref = spo.mel_l1(a, b, sample_rate=16000).item()
 assert abs(got - ref) <= 1e-3 * abs(ref), (got, ref)
 print("child ok")
 '''.replace("ROOT", repr(ROOT))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    from inverse_audio_synthesis_amd import _lib
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, IAS_HIP_LIB=_lib.DIAG_LIB_PATH, **env),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:]
 
 

@@ -29,11 +29,13 @@ def test_depthwise_conv_matches_torch(lib, dev, C, K, S, H, W):
     assert (gw - rw).abs().max().item() <= 2e-4 * max(1.0, rw.abs().max().item())
     gw2 = torch.autograd.grad(m(x), m.weight, g)[0]
     assert torch.equal(gw, gw2), "the weight gradient is reduced in a fixed order"
-    if S == 2:      # the LDS-tiled input gradient adds its taps in the order of the direct kernel
-        import os
+    if S == 2:      # the LDS-tiled input gradient adds its taps in the order of the direct kernel (which only the
+        import os   # diagnostic library can be told to take at this shape: the product library reads no environment)
+        from inverse_audio_synthesis_amd import _lib
         os.environ["IAS_DW_S2_DIRECT"] = "1"
         try:
-            gx_direct = torch.autograd.grad(m(x), x, g)[0]
+            with _lib.use_library(_lib.load_diag()):
+                gx_direct = torch.autograd.grad(m(x), x, g)[0]
         finally:
             del os.environ["IAS_DW_S2_DIRECT"]
         assert torch.equal(gx, gx_direct)

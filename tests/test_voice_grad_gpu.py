@@ -100,6 +100,7 @@ def test_lane_consecutive_backward_agrees_with_the_chunk_scan_kernels(lib, dev, 
     row length that is not a multiple of 4 (guarded scalar accesses), with and without the normalisation adjoint.  The two
     differ in the sin / cos range reduction (fp32 split vs fp64), in fp32 vs fp64 partial sums inside a thread and in the
     order of the interval sums: agreement to 1e-5 of each output's largest element; the default form is bit-reproducible."""
+    from inverse_audio_synthesis_amd import _lib
     from inverse_audio_synthesis_amd.voice import SynthConfig, Voice
     from inverse_audio_synthesis_amd.voice_grad import audio_rate_backward, normalisation_rows
     for B, sr, sec in ((3, 44100, 0.5), (2, 16000, 0.500125), (2, 44100, 4.0)):
@@ -112,8 +113,9 @@ def test_lane_consecutive_backward_agrees_with_the_chunk_scan_kernels(lib, dev, 
             monkeypatch.delenv("IAS_VOICE_GRAD_V1", raising=False)
             c_new, s_new = audio_rate_backward(v, v.params01, g, rn, ctl)
             c_again, s_again = audio_rate_backward(v, v.params01, g, rn, ctl)
-            monkeypatch.setenv("IAS_VOICE_GRAD_V1", "1")
-            c_old, s_old = audio_rate_backward(v, v.params01, g, rn, ctl)
+            monkeypatch.setenv("IAS_VOICE_GRAD_V1", "1")     # honoured by the diagnostic library only
+            with _lib.use_library(_lib.load_diag()):
+                c_old, s_old = audio_rate_backward(v, v.params01, g, rn, ctl)
             monkeypatch.delenv("IAS_VOICE_GRAD_V1", raising=False)
             assert torch.equal(c_new, c_again) and torch.equal(s_new, s_again)
             assert torch.isfinite(c_new).all() and torch.isfinite(s_new).all()
