@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the short vicreg / gradstep legs behind the headline")
     ap.add_argument("--cpu-batch", type=int, default=32, help="voices in the CPU baseline sample")
+    ap.add_argument("--leg-child", action="store_true",
+                    help="(internal) one rank of the N > 1 legs: started by the ranks of a `--gpus N` run after their headline "
+                         "regions, on a process group of its own; rank 0 prints the legs' JSON")
     ap.add_argument("--replays", type=int, default=0,
                     help="timed regions of K steps each (0: as many as give >= 0.25 s of timed work, at least 20)")
     return ap.parse_args()
@@ -233,11 +236,13 @@ def run_vicreg(args, rank, world, dev):
         step()
     torch.cuda.synchronize()
     launch, graph = "eager", None
-    if not gather and not args.no_graph:
+    # the K steps replay from one hipGraph -- with the gather too when the collectives are RCCL's (they capture like any
+    # other stream work; a gloo rehearsal stays eager)
+    if not args.no_graph and (not gather or dist.get_backend() == "nccl"):
         try:
             state.clear()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if gather else "global"):
                 for _ in range(args.steps):
                     step()
             graph.replay()
@@ -247,6 +252,8 @@ def run_vicreg(args, rank, world, dev):
             sys.stderr.write(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly\n")
             graph = None
             torch.cuda.synchronize()
+            if not state:
+                step()
 
     def region():
         if graph is not None:
@@ -390,13 +397,16 @@ def secondary_legs(args, dev):
         legs[name] = leg
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
-    t0 = time.perf_counter()
-    try:
-        leg = pretrain_leg(dev)
-    except Exception as e:  # noqa: BLE001
-        leg = {"error": f"{type(e).__name__}: {e}"}
-    leg["wall_s"] = round(time.perf_counter() - t0, 2)
-    legs["pretrain"] = leg
+    for name, fn in (("pretrain", lambda: pretrain_leg(dev)), ("config0", lambda: config0_leg(dev, cpu=not args.no_cpu_baseline))):
+        t0 = time.perf_counter()
+        try:
+            leg = fn()
+        except Exception as e:  # noqa: BLE001
+            leg = {"error": f"{type(e).__name__}: {e}"}
+        leg["wall_s"] = round(time.perf_counter() - t0, 2)
+        legs[name] = leg
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     return legs
@@ -443,6 +453,254 @@ def pretrain_leg(dev, B=128, steps=5, reps=5):
                         "PQMF(3) + MobileNetV3-small trunk + projector 8192 + VICReg loss, backward, LARS; fp32 (bf16 only "
                         "inside the VICReg Gram), random init, synthetic parameters",
             "launch": "hipgraph (Trainer._graph_step)", "loss": loss, "gemm_tuning": gemm_tuning}
+
+
+def config0_leg(dev, cpu=True):
+    """BASELINE configs[0] -- the reference's own CPU-runnable case: one Voice, batch 4, 1 s @ 16 kHz, STFT-L1 loss (no
+    gradient: audio_to_params.py's test path) -- timed on the HIP path (K steps in a hipGraph) and, same inputs, on the
+    oracle's torch-op restatement on the host: legs.config0."""
+    from inverse_audio_synthesis_amd.spectral import STFTL1
+    from inverse_audio_synthesis_amd.voice import SynthConfig, Voice
+    B, sr, sec, K = 4, 16000, 1.0, 50
+    cfg = SynthConfig(batch_size=B, sample_rate=sr, buffer_size_seconds=sec, reproducible=False)
+    voice = Voice(cfg).to(dev)
+    loss_mod = STFTL1().to(dev)
+    p = torch.rand(B, 78, generator=torch.Generator().manual_seed(1000))
+    pt = torch.rand(B, 78, generator=torch.Generator().manual_seed(2000))
+    tgt = voice.render(pt.to(dev)).clone()
+    pd = p.to(dev)
+    out = {}
+
+    def step():
+        out["loss"] = loss_mod(voice.render(pd), tgt)
+
+    step(); step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(K):
+            step()
+    g.replay()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(9):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) / K)
+    times.sort()
+    leg = {"workload": f"BASELINE configs[0]: Voice render + STFT-L1 (n_fft 1024, hop 512), batch {B} x {sec:g} s @ {sr} Hz",
+           "ms_per_step": round(times[len(times) // 2], 5), "ms_per_step_min": round(times[0], 5), "steps": K,
+           "launch": "hipgraph", "value": round(B * sec / (times[len(times) // 2] * 1e-3), 1), "unit": "audio-s/s",
+           "loss": float(out["loss"])}
+    if cpu:
+        from oracle import spectral_oracle as spo
+        from oracle import synth_oracle as so
+        ocfg = so.VoiceConfig(batch_size=B, sample_rate=sr, buffer_size_seconds=sec)
+        noise = so.make_noise(ocfg)
+        tgt_c = so.render_from_params01(ocfg, pt, noise, "torch")
+        threads = min(os.cpu_count() or 1, 16)
+        torch.set_num_threads(threads)
+
+        def cpu_step():
+            return spo.stft_l1(so.render_from_params01(ocfg, p, noise, "torch"), tgt_c)
+        cpu_step()
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            ref = cpu_step()
+            reps += 1
+            el = time.perf_counter() - t0
+            if (el > 2.0 and reps >= 5) or el > 10.0:
+                break
+        cpu_ms = el / reps * 1e3
+        leg["cpu_baseline"] = {"value": round(B * sec / (cpu_ms * 1e-3), 1), "unit": "audio-s/s", "ms_per_step": round(cpu_ms, 3),
+                               "cores": threads, "kind": "port",
+                               "sample": f"{reps} passes of the same step (oracle, torch CPU ops) in {el:.1f} s", "loss": float(ref)}
+        leg["loss_rel_diff_vs_oracle"] = abs(leg["loss"] - float(ref)) / max(abs(float(ref)), 1e-30)
+    return leg
+
+
+# ---------------------------------------------------------------------------------------------- N > 1 legs (round 5)
+LEG_PG_TIMEOUT_S, LEG_WALL_TIMEOUT_S = 150, 420
+
+
+def vicreg_gather_leg(args, rank, world, dev):
+    """legs.vicreg_gather: configs[3]'s loss per rank -- global_batch_loss on B_l = 128 rows per rank, ONE all-gather of
+    cat(x, y) forward and ONE reduce-scatter backward over RCCL (reference: vicreg.py:38-39,79-95)."""
+    import copy
+    a2 = copy.copy(args)
+    a2.workload, a2.batch, a2.steps, a2.warmup, a2.replays, a2.no_cpu_baseline = "vicreg", 128, 10, 2, 10, True
+    r = run_vicreg(a2, rank, world, dev)
+    leg = {k: r[k] for k in ("ms_per_step", "ms_per_step_min", "steps", "timed_regions", "value", "unit")}
+    leg.update(workload=r["config"]["workload"], launch=r["config"]["launch"], collective=r["config"]["collective"],
+               rccl_world_size=r["config"]["rccl_world_size"], backend=dist.get_backend(), loss=r["config"]["loss"],
+               cov_loss=r["config"]["cov_loss"],
+               gathered_bytes_per_rank=int(2 * 8192 * 4 * 128 * world), roofline={k: r["roofline"][k] for k in
+                                                                                   ("bound", "achieved", "peak", "unit", "frac") if k in r["roofline"]})
+    return leg
+
+
+def pretrain_ddp_leg(dev, rank, world, B=128, steps=5, reps=3):
+    """legs.pretrain_ddp: the configs[2] pretraining step on every rank with the bucketed gradient all-reduce
+    (dist.GradBucketer; reference: Lightning strategy "ddp", conf/config.yaml:6-8, pretrain.py:97-99) -- eager, as one
+    captured hipGraph with the collectives inside (RCCL only), and the same step WITHOUT the collectives: the difference is
+    the all-reduce time the step does not hide."""
+    import warnings
+    from inverse_audio_synthesis_amd import dist as ias_dist
+    from inverse_audio_synthesis_amd.config import load_config
+    from inverse_audio_synthesis_amd.harness import VicregAudioParams
+    from inverse_audio_synthesis_amd.trainer import Trainer
+    gloo = dist.get_backend() != "nccl"
+    if gloo:
+        steps, reps = 2, 1          # (rehearsal: the 570 MB of gradients cross the host)
+
+    def build(local_only, graph):
+        torch.manual_seed(42)
+        cfg = load_config(os.path.join(ROOT, "conf"), "config", [f"vicreg.batch_size={B}", f"trainer.cuda_graph={'true' if graph else 'false'}"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = VicregAudioParams(cfg)
+        tr = Trainer(cfg, model, stage="vicreg", device=dev)
+        if local_only:
+            tr.bucketer = ias_dist.GradBucketer(model, bucket_bytes=int(cfg.trainer.bucket_mb) << 20, local_only=True)
+        model.train()
+        return tr, model
+
+    def timed(fn):
+        """median ms per step over `reps` regions of `steps` steps, max over ranks"""
+        ts = []
+        k = 100
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn(k * world + rank, k)
+                k += 1
+            torch.cuda.synchronize()
+            el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=COLL_DEV)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            ts.append(el.item() / steps * 1e3)
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    leg = {"workload": f"VICReg pretraining step (configs[2] shape, batch {B} per rank) x {world} ranks, gradients averaged by "
+                       "dist.GradBucketer (bucketed all-reduce overlapped with backward)", "steps": steps, "timed_regions": reps,
+           "rccl_world_size": dist.get_world_size(), "backend": dist.get_backend()}
+    tr, model = build(False, False)
+    nbytes = sum(f.numel() * f.element_size() for f, _ in tr.bucketer.buckets)
+    leg.update(gradient_bytes=int(nbytes), buckets=len(tr.bucketer.buckets), collective=tr.bucketer.collective)
+    for i in range(3):
+        tr._eager_step(i * world + rank, i)
+    leg["ms_per_step_eager"] = round(timed(tr._eager_step), 3)
+    leg["loss"] = float(model.logged["vicreg/train/loss"])
+    del tr, model
+    torch.cuda.empty_cache()
+    if not gloo:
+        tr, model = build(False, True)
+        if tr._use_graph():
+            for i in range(5):
+                tr._graph_step(i * world + rank, i)
+            if getattr(tr, "_graph", None) is not None:
+                leg["ms_per_step_graph"] = round(timed(tr._graph_step), 3)
+            else:
+                leg["graph_error"] = "capture failed: see stderr"
+        del tr, model
+        torch.cuda.empty_cache()
+    # the same step without the collectives (every rank for itself)
+    tr, model = build(True, not gloo)
+    if not gloo and tr._use_graph():
+        for i in range(5):
+            tr._graph_step(i * world + rank, i)
+        leg["ms_per_step_no_allreduce"] = round(timed(tr._graph_step), 3)
+        ref = leg.get("ms_per_step_graph")
+    else:
+        for i in range(3):
+            tr._eager_step(i * world + rank, i)
+        leg["ms_per_step_no_allreduce"] = round(timed(tr._eager_step), 3)
+        ref = leg["ms_per_step_eager"]
+    if ref is not None:
+        leg["allreduce_exposed_ms"] = round(ref - leg["ms_per_step_no_allreduce"], 3)
+        leg["allreduce_exposed_note"] = "step with the bucketed all-reduce minus the same step without it (same launch mode)"
+    best = leg.get("ms_per_step_graph") or leg["ms_per_step_eager"]
+    leg.update(ms_per_step=best, value=round(world * B * SECONDS / (best * 1e-3), 1), unit="audio-s/s trained (whole job)")
+    del tr, model
+    torch.cuda.empty_cache()
+    return leg
+
+
+def run_leg_child(args):
+    """One rank of the N > 1 legs (started by `multi_gpu_legs`): a process group of its own with a bounded timeout, so that
+    a wedged collective ends THIS process and becomes the leg's `error` -- the headline line of the parent is already
+    computed.  Rank 0 prints {"vicreg_gather": ..., "pretrain_ddp": ...} as one JSON line."""
+    import datetime
+    world, rank, local_rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("IAS_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
+    kw = {"device_id": dev} if backend == "nccl" else {}
+    dist.init_process_group(backend, timeout=datetime.timedelta(seconds=LEG_PG_TIMEOUT_S), **kw)
+    global COLL_DEV
+    COLL_DEV = dev if backend == "nccl" else torch.device("cpu")
+    from inverse_audio_synthesis_amd import _lib
+    _lib.load()
+    legs = {}
+    for name, fn in (("vicreg_gather", lambda: vicreg_gather_leg(args, rank, world, dev)),
+                     ("pretrain_ddp", lambda: pretrain_ddp_leg(dev, rank, world))):
+        t0 = time.perf_counter()
+        try:
+            leg = fn()
+        except Exception as e:  # noqa: BLE001
+            leg = {"error": f"{type(e).__name__}: {e}"[:500]}
+        leg["wall_s"] = round(time.perf_counter() - t0, 2)
+        legs[name] = leg
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    if rank == 0:
+        print(json.dumps(legs), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def multi_gpu_legs(args, rank, world, local_rank):
+    """After the headline's timed regions, at N > 1: every rank starts ONE child process (a fresh interpreter; this process
+    has initialised the GPU, so it never execs) that joins a second process group on a port rank 0 picks, runs the legs
+    that have a real exchange step -- legs.vicreg_gather (RCCL all-gather + reduce-scatter, configs[3]) and
+    legs.pretrain_ddp (bucketed gradient all-reduce, eager and captured) -- and exits.  A child that dies or outlives its
+    time limit becomes {"error": ...}; the headline line is not at risk."""
+    import socket
+    import subprocess
+    port = torch.zeros(1, dtype=torch.int64, device=COLL_DEV)
+    if rank == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port[0] = sk.getsockname()[1]
+    dist.broadcast(port, 0)
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(int(port.item())))
+    torch.cuda.empty_cache()
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg-child", "--gpus", str(world)]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=LEG_WALL_TIMEOUT_S)
+        rc, out, err = r.returncode, r.stdout, r.stderr
+    except subprocess.TimeoutExpired:
+        rc, out, err = -9, "", f"no result within {LEG_WALL_TIMEOUT_S} s"
+    legs = None
+    if rank == 0:
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        if rc == 0 and lines:
+            legs = json.loads(lines[-1])
+        else:
+            msg = f"legs child of rank 0 ended with code {rc}: {(err or '')[-400:]}"
+            legs = {"vicreg_gather": {"error": msg}, "pretrain_ddp": {"error": msg}}
+        legs["wall_s"] = round(time.perf_counter() - t0, 2)
+    ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int64, device=COLL_DEV)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if rank == 0 and int(ok.item()) == 0 and rc == 0:
+        legs["note"] = "a child of another rank failed"
+    return legs
 
 
 def pmc_traffic_of(kname):
@@ -550,6 +808,8 @@ def run_gradstep(args, rank, world, dev):
 
 def main():
     args = parse()
+    if args.leg_child:
+        return run_leg_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -956,6 +1216,7 @@ def main():
         "pqmf": isolated_ms(lambda: gram.analysis(audio_bufs[0].unsqueeze(1), rowpeak=peaks0)),
         "stft": isolated_ms(lambda: plan._call(audio_bufs[0], None, target_mel, parts, VALUE_POWER, LOSS_L1, 0.0, peaks0)),
     }
+    ctrl_iso_ms = isolated_ms(lambda: voice.render_control(workspaces[0]))
     bps = {"render": RENDER_BYTES_PER_SAMPLE, "pqmf": 8.0, "stft": 4.0 + 4.0 * plan.n_out / plan.hop_length}
     knames = {"render": "voice_audio_kernel",
               "pqmf": "pqmf_analysis_mod_kernel",
@@ -981,7 +1242,8 @@ def main():
         except Exception:  # noqa: BLE001
             return {}
     counters, isa_costs = load_json("counters.json"), load_json("isa_costs.json")
-    N_CU, N_SIMD, CLOCK_MHZ = 256, 1024, 2100.0     # shader clock under these kernels: 2.10-2.15 GHz (s_memtime / s_memrealtime)
+    N_CU = torch.cuda.get_device_properties(dev).multi_processor_count      # 256 on MI355X
+    N_SIMD, CLOCK_MHZ = 4 * N_CU, 2100.0     # shader clock under these kernels: 2.10-2.15 GHz (s_memtime / s_memrealtime)
     # SQ_INSTS_VALU counts wave instructions: the unit is what ONE WAVE INSTRUCTION STREAM covers
     units = {"render": ("sample per lane (a wave: 64 samples)", B * T / 64.0),
              "pqmf": ("4 frames per lane (a wave: 256 frames)", B * (T // 3) / 256.0),
@@ -1017,6 +1279,19 @@ def main():
         # what the counters say binds the kernel: the largest of its HBM, vector-pipe and LDS-pipe fractions
         k["bound"] = max(fracs, key=fracs.get)
         kernels[name] = k
+    # What the step's pipes are busy for (verdict r04 item 1a): per pipe, the sum over the three kernels of (busy fraction x
+    # isolated time).  The kernels are work-conserving neighbours (the step equals the sum of their isolated times), so the
+    # busiest pipe's sum is the floor this set of kernels can reach if nothing ever waited: the attainable step, and the
+    # chain's HBM fraction at it, next to the 0.70 the north_star asks for.
+    pipe_busy_us = {"valu": 0.0, "lds": 0.0, "hbm": 0.0}
+    for k_ in kernels.values():
+        iso_us = k_["isolated_avg_us"]
+        pipe_busy_us["valu"] += k_.get("frac_valu", 0.0) * iso_us
+        pipe_busy_us["lds"] += k_.get("lds_busy_frac", 0.0) * iso_us
+        pipe_busy_us["hbm"] += k_["frac"] * iso_us
+    have_counters = all("frac_valu" in k_ for k_ in kernels.values())
+    floor_pipe = max(pipe_busy_us, key=pipe_busy_us.get)
+    pipe_floor_ms = pipe_busy_us[floor_pipe] * 1e-3 if have_counters else None
     # the dominant kernel of the TIMED schedule = the one with the largest in-step duration per step
     dom = max(kernels, key=lambda n: kernels[n]["in_step_avg_us"] or 0.0)
     chain_bytes = sum(bps.values()) * B * T          # 21 B here; SURVEY.md rounds the chain to 22 B/sample (497 MB)
@@ -1047,7 +1322,7 @@ def main():
         "config": {
             "workload": "BASELINE configs[1]: torchsynth-style Voice render + PQMF(3) analysis + mel-L1 loss, "
                         f"batch {B} x {SECONDS:g} s @ {SAMPLE_RATE} Hz per GPU",
-            "batch_per_gpu": B, "samples_per_voice": T, "launch": launch, "streams": 4, "pipelined": pipelined, "loss": loss_value,
+            "batch_per_gpu": B, "samples_per_voice": T, "launch": launch, "streams": 5, "pipelined": pipelined, "loss": loss_value,
         },
         "roofline": {
             "kernel": kdesc[dom],
@@ -1070,6 +1345,15 @@ def main():
             "kernels": kernels,
             "chain_bytes_per_step": int(22.0 * B * T), "chain_bytes_listed_kernels": int(chain_bytes),
             "chain_frac": round(chain_frac, 4),
+            "pipe_busy_us_per_step": {k_: round(v_, 1) for k_, v_ in pipe_busy_us.items()},
+            "pipe_floor_ms": None if pipe_floor_ms is None else round(pipe_floor_ms, 4),
+            "pipe_floor_pipe": floor_pipe if have_counters else None,
+            "chain_frac_at_floor": None if pipe_floor_ms is None else round(22.0 * B * T / (pipe_floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "step_over_floor": None if pipe_floor_ms is None else round(ms_per_step / pipe_floor_ms, 3),
+            "pipe_floor_note": "per pipe: sum over render / PQMF / STFT of (busy fraction x isolated time) -- frac_valu, lds_busy_frac, "
+                               "HBM frac; the largest sum is the step these kernels could reach with perfect overlap and no waiting "
+                               "(the control pass and launch gaps excluded); chain_frac_at_floor = the chain's 22 B/sample over it",
+            "control_pass_isolated_us": round(ctrl_iso_ms * 1e3, 1),
             "chain_frac_note": "22 B/sample (SURVEY.md 8d: render 8 + PQMF 8 + mel-L1 5, rounded up) x B x T / ms_per_step "
                                "/ 8 TB/s: the whole step against the HBM roofline (north_star target 0.70)",
         },
@@ -1078,6 +1362,11 @@ def main():
     # Gram of configs[2] / [3]'s loss and the configs[4] gradient step, a few hundred ms each
     if rank == 0 and world == 1 and not args.no_legs:
         result["legs"] = secondary_legs(args, dev)
+    if world > 1 and not args.no_legs:
+        # the legs with a real exchange step, on every rank (children on a process group of their own: multi_gpu_legs)
+        legs = multi_gpu_legs(args, rank, world, local_rank)
+        if rank == 0:
+            result["legs"] = legs
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only (bench contract)
             result["cpu_baseline"] = cpu_baseline(args.cpu_batch)

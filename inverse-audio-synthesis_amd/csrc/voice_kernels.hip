@@ -172,6 +172,157 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_modmix_kernel(
   }
 }
 
+// ---- the whole control pass of a voice in ONE workgroup (round 5) -------------------------------------------------
+// voice_env_kernel -> voice_lfo_kernel -> voice_modmix_kernel are three dependent launches whose intermediate rows go through
+// HBM, and their pow / cos / fmodf were the device math library's (pow: ~300 fp64-rate instructions): 33 us alone, and
+// 15 us of every headline step (0.175 -> 0.159 ms without it, same box, scripts/diag/run_noctrl_ab.sh).  Here one
+// workgroup of 1024 threads owns a voice: mapped parameters -> the six envelopes -> both LFOs -> mod matrix, the rows in
+// LDS between the phases, the transcendentals by voice_ctrl_math.h (table in LDS; same fp32 values, checked against libm
+// on the host and against the oracle bit for bit).  Global outputs are the same as the three kernels': sig [B][8][Tc],
+// ctrl [B][5][Tc], vconst [B], and the optional dbg rows.
+#define CTLF_THREADS 1024
+#define CTLF_WAVES (CTLF_THREADS / 64)
+#define CTLF_LFO_WAVES (CTLF_WAVES / 2)      // waves per LFO in the scan phase
+
+__device__ const double g_ctl_tab[IAS_CTL_TAB_DOUBLES] = IAS_CTL_TAB_INIT;
+
+__global__ __launch_bounds__(CTLF_THREADS) void voice_control_fused_kernel(
+    const float* __restrict__ params01, float* __restrict__ sig, float* __restrict__ ctrl,
+    IasVoiceConst* __restrict__ vconst, float* __restrict__ dbg, int Tc, float control_rate) {
+  // dynamic LDS: ctl table | rows [8][Tc] floats (envelopes 0-5, LFO outputs 6-7) | scan sums [2][Tc] doubles
+  extern __shared__ __attribute__((aligned(16))) double ctlf_smem[];
+  double* s_tab = ctlf_smem;
+  double* s_sum = s_tab + IAS_CTL_TAB_DOUBLES;               // [2][Tc]
+  float* s_row = reinterpret_cast<float*>(s_sum + 2 * (size_t)Tc);
+  __shared__ float s_p[IAS_NPARAMS + 2];
+  __shared__ float s_head[12];
+  __shared__ float s_mode[2][8];
+  __shared__ double s_wtot[2][CTLF_LFO_WAVES];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float eps = (float)IAS_EPS;
+
+  for (int i = tid; i < IAS_CTL_TAB_DOUBLES; i += CTLF_THREADS) s_tab[i] = g_ctl_tab[i];
+  if (tid < IAS_NPARAMS) s_p[tid] = mapped_param(params01, b, tid);
+  __syncthreads();
+  const float note_on = s_p[IAS_P_KEYBOARD_DURATION];
+  // per-voice scalars, each on a wave of its own beside the envelope work: flat ramp heads (12 lanes), LFO shape weights
+  // (2 x 5 lanes), the audio-rate constants (one lane)
+  if (wave == CTLF_WAVES - 1) {
+    if (lane < 12) {
+      const int a = lane >> 1;
+      const float* q = s_p + adsr_base(a);
+      IasAdsr e; e.attack = q[0]; e.decay = q[1]; e.sustain = q[2]; e.release = q[3]; e.alpha = q[4];
+      const IasAdsrHeads h = ias_adsr_heads(e, note_on, control_rate, eps, s_tab);
+      s_head[lane] = (lane & 1) ? h.release_head : h.decay_head;
+    }
+  } else if (wave == CTLF_WAVES - 2) {
+    if (lane < 16 && (lane & 7) < 5) {
+      const int l = lane >> 3, k = lane & 7;
+      const int qbase = (l == 0) ? IAS_P_LFO_1_FREQUENCY : IAS_P_LFO_2_FREQUENCY;
+      s_mode[l][k] = ias_pow_ctl(s_p[qbase + 3 + k], IAS_LFO_EXPONENT_F, s_tab);    // ias_lfo_mode's five powers
+    }
+  } else if (wave == CTLF_WAVES - 3) {
+    if (lane == 0) {
+      const float* p = s_p;
+      const float midi_f0 = p[IAS_P_KEYBOARD_MIDI_F0];
+      IasVoiceConst vc;
+      vc.f0_1 = ias_add(midi_f0, p[IAS_P_VCO_1_TUNING]);
+      vc.depth_1 = p[IAS_P_VCO_1_MOD_DEPTH];
+      vc.phi_1 = p[IAS_P_VCO_1_INITIAL_PHASE];
+      vc.f0_2 = ias_add(midi_f0, p[IAS_P_VCO_2_TUNING]);
+      vc.depth_2 = p[IAS_P_VCO_2_MOD_DEPTH];
+      vc.phi_2 = p[IAS_P_VCO_2_INITIAL_PHASE];
+      vc.kpart = ias_partials_k(midi_f0, vc.depth_2);
+      vc.shape = p[IAS_P_VCO_2_SHAPE];
+      vc.shape_gain = ias_sub(1.0f, ias_div(vc.shape, 2.0f));
+      vc.lvl0 = p[IAS_P_MIXER_VCO_1];
+      vc.lvl1 = p[IAS_P_MIXER_VCO_2];
+      vc.lvl2 = p[IAS_P_MIXER_NOISE];
+      vc.pad[0] = vc.pad[1] = vc.pad[2] = vc.pad[3] = 0.0f;
+      vconst[b] = vc;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 1: the six envelopes -> s_row[a][t] (and sig rows 0-5).  The rows the LFOs read (2-5) first.
+  float* gsig = sig + (size_t)b * 8 * Tc;
+  for (int idx = tid; idx < 6 * Tc; idx += CTLF_THREADS) {
+    const int slot = idx / Tc, t = idx - slot * Tc;
+    const int a = slot < 4 ? slot + 2 : slot - 4;             // order 2, 3, 4, 5, 0, 1
+    const float* q = s_p + adsr_base(a);
+    IasAdsr e; e.attack = q[0]; e.decay = q[1]; e.sustain = q[2]; e.release = q[3]; e.alpha = q[4];
+    IasAdsrHeads heads; heads.decay_head = s_head[2 * a]; heads.release_head = s_head[2 * a + 1];
+    const float v = ias_adsr_headed(t, e, note_on, control_rate, eps, heads, s_tab);
+    s_row[a * Tc + t] = v;
+    gsig[a * Tc + t] = v;
+  }
+  // LFO shape weights: m / sum (ias_lfo_mode's normalisation)
+  if (tid < 2) {
+    float* m = s_mode[tid];
+    const float sm = (float)((double)m[0] + (double)m[1] + (double)m[2] + (double)m[3] + (double)m[4]);
+    for (int k = 0; k < 5; ++k) m[k] = ias_div(m[k], sm);
+  }
+  __syncthreads();
+
+  // ---- phase 2: the LFOs.  Waves 0-7: LFO 1, waves 8-15: LFO 2; each wave scans a contiguous stretch in chunks of 64
+  // (fp64; the order differs from a sequential loop only below 1e-16 relative, which the rounding to fp32 absorbs).
+  {
+    const int l = wave / CTLF_LFO_WAVES, w = wave - l * CTLF_LFO_WAVES;
+    const int qbase = (l == 0) ? IAS_P_LFO_1_FREQUENCY : IAS_P_LFO_2_FREQUENCY;
+    const float freq = s_p[qbase], depth = s_p[qbase + 1], phi = s_p[qbase + 2];
+    const float* rate_env = s_row + (4 + l) * Tc;
+    const float* amp_env = s_row + (2 + l) * Tc;
+    double* sums = s_sum + (size_t)l * Tc;
+    const int per_wave = ((Tc + CTLF_LFO_WAVES - 1) / CTLF_LFO_WAVES + 63) / 64 * 64;
+    const int t_begin = min(w * per_wave, Tc), t_end = min(t_begin + per_wave, Tc);
+    double carry = 0.0;
+    for (int t0 = t_begin; t0 < t_end; t0 += 64) {
+      const int t = t0 + lane;
+      double inc = 0.0;
+      if (t < t_end) inc = (double)ias_lfo_inc(freq, depth, rate_env[t], control_rate);
+      const double sc = wave_incl_scan(inc, lane) + carry;
+      carry = __shfl(sc, 63, 64);
+      if (t < t_end) sums[t] = sc;
+    }
+    if (lane == 0) s_wtot[l][w] = carry;
+    __syncthreads();
+    double base = 0.0;
+    for (int k = 0; k < w; ++k) base += s_wtot[l][k];
+    float mode[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) mode[k] = s_mode[l][k];
+    for (int t = t_begin + lane; t < t_end; t += 64) {
+      const double ph = base + sums[t];
+      const float arg = ias_add((float)ph, phi);
+      const float o = ias_mul(ias_lfo_shape_mix(arg, mode, s_tab), amp_env[t]);
+      s_row[(6 + l) * Tc + t] = o;
+      gsig[(6 + l) * Tc + t] = o;
+      if (dbg != nullptr) {
+        dbg[((size_t)b * 10 + 6 + l) * Tc + t] = arg;
+        dbg[((size_t)b * 10 + 8 + l) * Tc + t] = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: the 4 x 5 mod matrix -> ctrl[b][j][t]
+  float* out = ctrl + (size_t)b * IAS_NCTRL * Tc;
+  const float* wm = s_p + IAS_P_MOD_MATRIX_ADSR_1_TO_VCO_1_PITCH;
+  for (int t = tid; t < Tc; t += CTLF_THREADS) {
+    const float e0 = s_row[t], e1 = s_row[Tc + t], l0 = s_row[6 * Tc + t], l1 = s_row[7 * Tc + t];
+#pragma unroll
+    for (int j = 0; j < IAS_NCTRL; ++j)
+      out[j * Tc + t] = ias_dot4_cr(wm[j], wm[5 + j], wm[10 + j], wm[15 + j], e0, e1, l0, l1);
+    if (dbg != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) dbg[((size_t)b * 10 + r) * Tc + t] = s_row[r * Tc + t];
+    }
+  }
+}
+static size_t voice_control_fused_lds(int Tc) {
+  return sizeof(double) * (IAS_CTL_TAB_DOUBLES + 2 * (size_t)Tc) + sizeof(float) * 8 * (size_t)Tc;
+}
+
 // -------------------------------------------------------------------- audio rate
 #define VOICE_MAXCTRL 320  // control points staged per tile (covers sample rates down to ~6 kHz)
 #define VOICE_SPIN_LIMIT (1u << 24)
@@ -749,6 +900,21 @@ static int voice_control_launch(const float* params01, float* ctrl, void* vconst
                                 int Tc, int control_rate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!params01 || !ctrl || !vconst || !sig || B <= 0 || B > 65535 || Tc <= 1 || control_rate <= 0) return IAS_ERR_ARG;
+  // one workgroup per voice while its rows fit the LDS of a CU (48 bytes per control sample + the 4 KB table: Tc <= ~3200);
+  // longer control buffers take the three-kernel form (rows through HBM)
+  const size_t flds = voice_control_fused_lds(Tc);
+  // (diagnostic library: IAS_VOICE_CTRL_UNFUSED=1 takes the three kernels, with the library's pow / cos / fmodf, at any Tc)
+  if (flds <= 156 * 1024 && !ias_diag_env("IAS_VOICE_CTRL_UNFUSED")) {
+    static bool attr_set = false;                          // (idempotent: a race sets it twice)
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)voice_control_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+        return IAS_ERR_LAUNCH;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(voice_control_fused_kernel, dim3(B), dim3(CTLF_THREADS), flds, stream, params01, sig, ctrl,
+                       (IasVoiceConst*)vconst, dbg, Tc, (float)control_rate);
+    return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+  }
   const size_t lds = sizeof(double) * (VOICE_WAVES + (size_t)Tc);
   if (lds > 160 * 1024) return IAS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(voice_env_kernel, dim3(6, B), dim3(VOICE_THREADS), 0, stream, params01, sig, Tc,

@@ -13,6 +13,7 @@
 #pragma once
 #include "ias_common.h"
 #include "voice_exp2_table.h"
+#include "voice_ctrl_math.h"
 #if !defined(__HIPCC__)
 #include <algorithm>
 using std::min;
@@ -43,6 +44,18 @@ IAS_HD float ias_log2_cr(float x) { return (float)log2((double)x); }
 IAS_HD float ias_log10_cr(float x) { return (float)log10((double)x); }
 IAS_HD float ias_cos_cr(float x) { return (float)cos((double)x); }
 IAS_HD float ias_exp2_slow_cr(float x) { return (float)exp2((double)x); }
+// The same values from the written-out fp64 kernels of voice_ctrl_math.h (ctl: the IAS_CTL_TAB_INIT table, or NULL for
+// the library calls above): ~40 fp64-rate instructions instead of ~300 for pow, ~30 instead of ~120 for cos, inside
+// their domains -- which hold every argument the control pass produces for parameters in range; anything else takes
+// the library function.  Same accuracy class as the library calls (voice_ctrl_math.h), so the same fp32 values.
+IAS_HD float ias_pow_ctl(float x, float a, const double* ctl) {
+  if (ctl != nullptr && ias_ctl_pow_in_domain(x, a)) return (float)ias_ctl_pow(x, a, ctl);
+  return ias_pow_cr(x, a);
+}
+IAS_HD float ias_cos_ctl(float x, const double* ctl) {
+  if (ctl != nullptr && ias_ctl_cos_in_domain(x)) return (float)ias_ctl_cos(x);
+  return ias_cos_cr(x);
+}
 
 // 2^t for the audio-rate pitch path.  n = rint(t), f = t - n is exact in fp32;
 // 2^f by a degree-13 Taylor polynomial in fp64 (|f| <= 0.5: truncation < 2e-17
@@ -154,7 +167,7 @@ IAS_HD float ias_map_param(float u, float lo, float span, float curve, int symme
 // ---- ADSR (control rate) ----
 // ramp(t) of torchsynth ADSR.ramp: t = control-sample index, durations in seconds.
 IAS_HD float ias_ramp(int t, float duration, float start, int has_start, int inverse,
-                      float alpha, float control_rate, float eps) {
+                      float alpha, float control_rate, float eps, const double* ctl = nullptr) {
   const float dur = ias_mul(duration, control_rate);
   float r = (float)t;
   if (has_start) r = ias_sub(r, ias_mul(start, control_rate));
@@ -164,7 +177,7 @@ IAS_HD float ias_ramp(int t, float duration, float start, int has_start, int inv
   if (inverse && dur > 0.0f) r = ias_sub(1.0f, r);
   // saturated ramps: pow(1, a) = 1 and pow(0, a) = 0 exactly (alpha is in [0.1, 6])
   if (r == 1.0f || (r == 0.0f && alpha > 0.0f)) return r;
-  return ias_pow_cr(r, alpha);
+  return ias_pow_ctl(r, alpha, ctl);
 }
 
 struct IasAdsr { float attack, decay, sustain, release, alpha; };
@@ -174,38 +187,39 @@ struct IasAdsr { float attack, decay, sustain, release, alpha; };
 // t = 0.  Bit-identical to ias_ramp; at most one of an ADSR's three ramps is outside its head /
 // saturated region at any t, which cuts the fp64 pow() count by ~3x.
 IAS_HD float ias_ramp_headed(int t, float duration, float start, int inverse, float alpha, float control_rate,
-                             float eps, float head) {
+                             float eps, float head, const double* ctl = nullptr) {
   if (ias_sub((float)t, ias_mul(start, control_rate)) <= 0.0f) return head;
-  return ias_ramp(t, duration, start, 1, inverse, alpha, control_rate, eps);
+  return ias_ramp(t, duration, start, 1, inverse, alpha, control_rate, eps, ctl);
 }
 
 struct IasAdsrHeads { float decay_head, release_head; };
-IAS_HD IasAdsrHeads ias_adsr_heads(const IasAdsr& e, float note_on, float control_rate, float eps) {
+IAS_HD IasAdsrHeads ias_adsr_heads(const IasAdsr& e, float note_on, float control_rate, float eps,
+                                   const double* ctl = nullptr) {
   const float new_attack = fminf(e.attack, note_on);
   const float new_decay = fminf(fmaxf(ias_sub(note_on, e.attack), 0.0f), e.decay);
   IasAdsrHeads h;
-  h.decay_head = ias_ramp(0, new_decay, new_attack, 1, 1, e.alpha, control_rate, eps);
-  h.release_head = ias_ramp(0, e.release, note_on, 1, 1, e.alpha, control_rate, eps);
+  h.decay_head = ias_ramp(0, new_decay, new_attack, 1, 1, e.alpha, control_rate, eps, ctl);
+  h.release_head = ias_ramp(0, e.release, note_on, 1, 1, e.alpha, control_rate, eps, ctl);
   return h;
 }
 IAS_HD float ias_adsr_headed(int t, const IasAdsr& e, float note_on, float control_rate, float eps,
-                             const IasAdsrHeads& h) {
+                             const IasAdsrHeads& h, const double* ctl = nullptr) {
   const float new_attack = fminf(e.attack, note_on);
   const float new_decay = fminf(fmaxf(ias_sub(note_on, e.attack), 0.0f), e.decay);
-  const float a = ias_ramp(t, new_attack, 0.0f, 0, 0, e.alpha, control_rate, eps);
-  const float dr = ias_ramp_headed(t, new_decay, new_attack, 1, e.alpha, control_rate, eps, h.decay_head);
+  const float a = ias_ramp(t, new_attack, 0.0f, 0, 0, e.alpha, control_rate, eps, ctl);
+  const float dr = ias_ramp_headed(t, new_decay, new_attack, 1, e.alpha, control_rate, eps, h.decay_head, ctl);
   const float d = ias_add(ias_mul(ias_sub(1.0f, e.sustain), dr), e.sustain);
-  const float r = ias_ramp_headed(t, e.release, note_on, 1, e.alpha, control_rate, eps, h.release_head);
+  const float r = ias_ramp_headed(t, e.release, note_on, 1, e.alpha, control_rate, eps, h.release_head, ctl);
   return ias_mul(ias_mul(a, d), r);
 }
 
-IAS_HD float ias_adsr(int t, const IasAdsr& e, float note_on, float control_rate, float eps) {
+IAS_HD float ias_adsr(int t, const IasAdsr& e, float note_on, float control_rate, float eps, const double* ctl = nullptr) {
   const float new_attack = fminf(e.attack, note_on);
   const float new_decay = fminf(fmaxf(ias_sub(note_on, e.attack), 0.0f), e.decay);
-  const float a = ias_ramp(t, new_attack, 0.0f, 0, 0, e.alpha, control_rate, eps);
-  const float dr = ias_ramp(t, new_decay, new_attack, 1, 1, e.alpha, control_rate, eps);
+  const float a = ias_ramp(t, new_attack, 0.0f, 0, 0, e.alpha, control_rate, eps, ctl);
+  const float dr = ias_ramp(t, new_decay, new_attack, 1, 1, e.alpha, control_rate, eps, ctl);
   const float d = ias_add(ias_mul(ias_sub(1.0f, e.sustain), dr), e.sustain);
-  const float r = ias_ramp(t, e.release, note_on, 1, 1, e.alpha, control_rate, eps);
+  const float r = ias_ramp(t, e.release, note_on, 1, 1, e.alpha, control_rate, eps, ctl);
   return ias_mul(ias_mul(a, d), r);
 }
 
@@ -222,14 +236,24 @@ IAS_HD float ias_remainder(float a, float b) {
   return m;
 }
 
+// the same by voice_ctrl_math.h's exact fp64 remainder (b = fl32(2 pi) only; other arguments: fmodf)
+IAS_HD float ias_remainder_2pi_ctl(float a, const double* ctl) {
+  const float b = (float)IAS_TWO_PI_D;
+  float m;
+  if (ctl != nullptr && ias_ctl_fmod_in_domain(a, b)) m = ias_ctl_fmod(a, b, 1.0 / (double)(float)IAS_TWO_PI_D);
+  else m = fmodf(a, b);
+  if (m != 0.0f && m < 0.0f) m = ias_add(m, b);
+  return m;
+}
+
 // arg = fl(fl32(cumsum_double(inc)) + phi0); mode[5] already normalised.
-IAS_HD float ias_lfo_shape_mix(float arg, const float* mode) {
+IAS_HD float ias_lfo_shape_mix(float arg, const float* mode, const double* ctl = nullptr) {
   const float two_pi = (float)IAS_TWO_PI_D;
-  float c = ias_cos_cr(ias_add(arg, (float)IAS_PI_D));
+  float c = ias_cos_ctl(ias_add(arg, (float)IAS_PI_D), ctl);
   float sq = (c > 0.0f) ? 1.0f : ((c < 0.0f) ? -1.0f : 0.0f);
   c = ias_div(ias_add(c, 1.0f), 2.0f);
   sq = ias_div(ias_add(sq, 1.0f), 2.0f);
-  const float saw = ias_div(ias_remainder(arg, two_pi), two_pi);
+  const float saw = ias_div(ias_remainder_2pi_ctl(arg, ctl), two_pi);
   const float rsaw = ias_sub(1.0f, saw);
   float tri = ias_mul(2.0f, saw);
   if (tri > 1.0f) tri = ias_sub(2.0f, tri);

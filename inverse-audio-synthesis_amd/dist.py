@@ -57,11 +57,13 @@ class GradBucketer:
     """Bucketed, backward-overlapped gradient averaging for ``module`` (replicas only: no SyncBN,
     matching the reference's plain DDP)."""
 
-    def __init__(self, module, bucket_bytes=128 << 20, always_reduce=False):
+    def __init__(self, module, bucket_bytes=128 << 20, always_reduce=False, local_only=False):
         """``always_reduce``: issue the collectives on a one-rank group as well (exercises the RCCL path on a
-        single GPU; tests)."""
+        single GPU; tests).  ``local_only``: no collectives even on several ranks (bench.py's measurement of what the
+        all-reduce adds to a step: the same step with and without it)."""
         self.world = world_size()
-        self.collective = dist.is_available() and dist.is_initialized() and (self.world > 1 or always_reduce)
+        self.collective = dist.is_available() and dist.is_initialized() and (self.world > 1 or always_reduce) and \
+            not local_only
         if self.collective:
             # replicas start from rank 0's parameters AND buffers (BatchNorm running statistics), as torch DDP /
             # Lightning's strategy "ddp" do at construction (/root/reference/conf/config.yaml:8 -> pretrain.py:97-99)

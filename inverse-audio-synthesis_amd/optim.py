@@ -66,8 +66,34 @@ class LARS(torch.optim.Optimizer):
     # ------------------------------------------------------------------ fused HIP path (momentum 0)
     HYPER_RING = 8   # pinned staging slots of the device hyper-parameters (see _sync_group_hyper)
 
+    def _group_hyper(self, gi, dev):
+        """The device scalars (lr, weight decay, trust coefficient, eps) of group ``gi`` and their staging ring: ONE
+        allocation per group for the optimizer's lifetime, made OUTSIDE any hipGraph capture.  A tensor allocated during a
+        capture lives in the graph's private pool, where a replay's earlier kernels may reuse its bytes (the pool recycles
+        what the captured step freed before the allocation): values written into it from outside the graph -- the
+        scheduler's learning rate before each replay -- would be overwritten by the replay itself."""
+        table = self.__dict__.setdefault("_hip_hyper", {})
+        h = table.get(gi)
+        if h is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("LARS: the first fused step of a parameter group cannot run inside a hipGraph capture "
+                                   "(its device hyper-parameters must be allocated outside the graph's pool): run one "
+                                   "eager step, or call optimizer.prepare_capture(), first")
+            h = table[gi] = dict(dev=torch.empty(4, dtype=torch.float32, device=dev),
+                                 ring=[torch.empty(4, dtype=torch.float32).pin_memory() for _ in range(self.HYPER_RING)],
+                                 events=[None] * self.HYPER_RING, pos=0, vals=None)
+        return h
+
+    def prepare_capture(self):
+        """Allocate what must not live in a graph's pool (see ``_group_hyper``) for every group whose parameters are on a
+        ROCm device; for loops that capture their very first step."""
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.is_cuda]
+            if ps:
+                self._sync_group_hyper(group, self._group_hyper(gi, ps[0].device))
+
     @staticmethod
-    def _sync_group_hyper(group, ent):
+    def _sync_group_hyper(group, h):
         """Push (lr, weight decay, trust coefficient, eps) to the device scalars the fused step reads, when they changed.
         The copy is asynchronous and the host may run many steps ahead of the GPU (a replaying loop never synchronises),
         so the staging buffer a copy reads must not be rewritten before that copy has executed: the values go through a
@@ -75,31 +101,28 @@ class LARS(torch.optim.Optimizer):
         whole ring ahead).  Never inside a hipGraph capture: a captured copy would re-read its slot at every replay and
         put a stale learning rate back; the replaying loop pushes the values itself (``sync_hyper``) before each replay."""
         vals = (float(group["lr"]), float(group["weight_decay"]), float(group["trust_coefficient"]), float(group["eps"]))
-        if ent["hyper_vals"] == vals:
+        if h["vals"] == vals or torch.cuda.is_current_stream_capturing():
             return
-        if torch.cuda.is_current_stream_capturing():
-            ent["hyper_vals"] = None
-            return
-        i = ent["ring_pos"]
-        ent["ring_pos"] = (i + 1) % len(ent["ring"])
-        if ent["ring_events"][i] is not None:
-            ent["ring_events"][i].synchronize()
-        host = ent["ring"][i]
+        i = h["pos"]
+        h["pos"] = (i + 1) % len(h["ring"])
+        if h["events"][i] is not None:
+            h["events"][i].synchronize()
+        host = h["ring"][i]
         host[0], host[1], host[2], host[3] = vals
-        ent["hyper"].copy_(host, non_blocking=True)
+        h["dev"].copy_(host, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        ent["ring_events"][i] = ev
-        ent["hyper_vals"] = vals
+        h["events"][i] = ev
+        h["vals"] = vals
 
     def sync_hyper(self):
         """Push lr / weight decay / trust coefficient / eps of every group to the device scalars the fused step reads.
         ``step()`` does this itself; a step replayed from a captured hipGraph cannot (the Python around the launches
         does not run again), so the replaying loop calls this after the scheduler has moved the learning rate."""
         for gi, group in enumerate(self.param_groups):
-            ent = self.__dict__.get("_hip_tables", {}).get(gi)
-            if ent is not None:
-                self._sync_group_hyper(group, ent)
+            h = self.__dict__.get("_hip_hyper", {}).get(gi)
+            if h is not None:
+                self._sync_group_hyper(group, h)
 
     @staticmethod
     def _hip_ok(ps, gs):
@@ -134,11 +157,9 @@ class LARS(torch.optim.Optimizer):
                        tensors=t_dev, chunks=c_dev, first=f_dev,
                        partials=torch.empty(2 * len(chunks), dtype=torch.float64, device=dev),
                        coef=torch.empty(2 * len(key), dtype=torch.float32, device=dev),
-                       ring=[torch.empty(4, dtype=torch.float32).pin_memory() for _ in range(self.HYPER_RING)],
-                       ring_events=[None] * self.HYPER_RING, ring_pos=0,
-                       hyper=torch.empty(4, dtype=torch.float32, device=dev), hyper_vals=None)
+                       hyper=self._group_hyper(gi, dev)["dev"])
             cache[gi] = ent
-        self._sync_group_hyper(group, ent)
+        self._sync_group_hyper(group, self._group_hyper(gi, dev))
         skip = group["weight_decay"] == 0
         if skip:
             c2 = ent["coef"].view(-1, 2)

@@ -73,7 +73,8 @@ def setup_gemm_tuning(mode):
             tunable.set_filename(os.path.join(os.getcwd(), f"tunableop_online_rank{rank}.csv"), False)
         else:
             tunable.set_filename(os.path.join(tempfile.gettempdir(), f"ias_tunableop_{os.getpid()}.csv"), False)
-            tunable.write_file_on_exit(False)
+            if hasattr(tunable, "write_file_on_exit"):
+                tunable.write_file_on_exit(False)
         loaded = os.path.exists(TUNING_FILE) and bool(tunable.read_file(TUNING_FILE))
         if mode == "online":
             return "online"
@@ -212,6 +213,16 @@ class Trainer:
         # the tensors the replayed kernels write
         m.logged = self._graph_logged
 
+    def _eager_step(self, batch, step):
+        """One training step launched from Python: the bucket all-reduces go out during backward (GradBucketer's hooks),
+        ``finish`` joins them and averages."""
+        self.bucketer.begin_step()
+        loss = self.module.training_step(batch, step)
+        loss.backward()
+        self.bucketer.finish()
+        self.optimizer.step()
+        return loss
+
     def fit(self, max_steps=None):
         cfg, st = self.cfg, self.cfg[self.stage]
         lo, hi = split_sizes(cfg.num_batches, cfg.ntest_batches)["train"]
@@ -234,11 +245,7 @@ class Trainer:
             if self._use_graph():
                 self._graph_step(batch, step)
             else:
-                self.bucketer.begin_step()
-                loss = self.module.training_step(batch, step)
-                loss.backward()
-                self.bucketer.finish()
-                self.optimizer.step()
+                self._eager_step(batch, step)
             if self.scheduler is not None:
                 self.scheduler.step()
             self._step = step + 1

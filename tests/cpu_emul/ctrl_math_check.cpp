@@ -1,0 +1,70 @@
+// Test infrastructure (never part of the product path): csrc/voice_ctrl_math.h compiled for the host and compared with
+// libm -- the functions the oracle's "cr" arithmetic is defined by (evaluate in fp64, round once to fp32).
+//   ctrl_math_check(kind, n, seed, out[4]) -> out = {evaluations, fp32 mismatches, max |fast - libm| / |libm| in units of
+//   2^-53, evaluations outside the fast domain}
+#include <cstdint>
+#include <cmath>
+#include "voice_ctrl_math.h"
+
+static const double g_tab[IAS_CTL_TAB_DOUBLES] = IAS_CTL_TAB_INIT;
+
+static inline uint64_t splitmix(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static inline float u01(uint64_t& s) { return (float)(splitmix(s) >> 40) * (1.0f / 16777216.0f); }
+
+extern "C" int ctrl_math_check(int kind, long long n, unsigned long long seed, double* out) {
+  uint64_t s = seed;
+  long long bad = 0, outside = 0;
+  double worst = 0.0;
+  for (long long it = 0; it < n; ++it) {
+    double fast, ref;
+    if (kind == 0) {            // pow: ramp positions as the ADSR produces them (uniform, near 0, near 1), alpha in [0.1, 6]
+      float x = u01(s);
+      const unsigned mode = (unsigned)(splitmix(s) & 3);
+      if (mode == 1) x = ldexpf(x, -(int)(splitmix(s) % 20));           // small ramps
+      if (mode == 2) x = 1.0f - ldexpf(x, -(int)(splitmix(s) % 24));    // 1 - small
+      const float a = 0.1f + 5.9f * u01(s);
+      if (!ias_ctl_pow_in_domain(x, a)) { ++outside; continue; }
+      fast = ias_ctl_pow(x, a, g_tab);
+      ref = pow((double)x, (double)a);
+    } else if (kind == 1) {     // pow over the whole guarded domain: any normal x < 1, a in [2^-6, 64]
+      union { float f; uint32_t u; } b;
+      b.u = (uint32_t)(splitmix(s) % (0x3f800000u - 0x00800000u)) + 0x00800000u;
+      const float x = b.f;
+      const float a = ldexpf(1.0f + u01(s), (int)(splitmix(s) % 12) - 6);
+      if (!ias_ctl_pow_in_domain(x, a)) { ++outside; continue; }
+      fast = ias_ctl_pow(x, a, g_tab);
+      ref = pow((double)x, (double)a);
+    } else if (kind == 2) {     // cos: LFO arguments (phase + pi), up to ~2^15
+      const unsigned mode = (unsigned)(splitmix(s) & 3);
+      float x = u01(s) * (mode == 0 ? 8.0f : (mode == 1 ? 1100.0f : 32000.0f));
+      if (mode == 3) x = (float)((double)(splitmix(s) % 20000) * 1.5707963267948966);   // next to the zeros / extrema
+      if (splitmix(s) & 1) x = -x;
+      if (!ias_ctl_cos_in_domain(x)) { ++outside; continue; }
+      fast = ias_ctl_cos(x);
+      ref = cos((double)x);
+    } else {                    // fmod by fl32(2 pi)
+      const float b = 6.2831854820251465f;
+      const unsigned mode = (unsigned)(splitmix(s) & 3);
+      float a = u01(s) * (mode == 0 ? 7.0f : (mode == 1 ? 1100.0f : 1.0e6f));
+      if (mode == 3) a = (float)((double)(splitmix(s) % 4000) * (double)b);             // next to the multiples
+      if ((splitmix(s) & 7) == 0) a = -a;
+      if (!ias_ctl_fmod_in_domain(a, b)) { ++outside; continue; }
+      fast = (double)ias_ctl_fmod(a, b, 1.0 / (double)b);
+      ref = (double)fmodf(a, b);
+      if (fast != ref) ++bad;
+      continue;
+    }
+    if ((float)fast != (float)ref) ++bad;
+    if (fabs(ref) > 1.0e-290) {                  // (relative error is meaningless next to fp64 underflow: fp32 result 0 either way)
+      const double rel = fabs(fast - ref) / fabs(ref) * 9007199254740992.0;
+      if (rel > worst) worst = rel;
+    }
+  }
+  out[0] = (double)n; out[1] = (double)bad; out[2] = worst; out[3] = (double)outside;
+  return 0;
+}

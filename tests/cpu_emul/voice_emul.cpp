@@ -8,6 +8,12 @@
 #include "voice_math.h"
 #include "voice_table.h"
 
+// emul_set_ctl(1): the control-rate pow / cos / fmod by csrc/voice_ctrl_math.h (what the HIP control kernel runs);
+// 0 (default): the libm calls that DEFINE the "cr" arithmetic.  Both must give the oracle's bits.
+static const double g_ctl_tab[IAS_CTL_TAB_DOUBLES] = IAS_CTL_TAB_INIT;
+static const double* g_ctl = nullptr;
+extern "C" void emul_set_ctl(int on) { g_ctl = on ? g_ctl_tab : nullptr; }
+
 static void adsr_from(const float* p, int base, IasAdsr& e) {
   e.attack = p[base + 0]; e.decay = p[base + 1]; e.sustain = p[base + 2];
   e.release = p[base + 3]; e.alpha = p[base + 4];
@@ -32,7 +38,7 @@ extern "C" int emul_voice_render(const float* params01, const float* noise, floa
                           IAS_P_LFO_2_AMP_ADSR_ATTACK, IAS_P_LFO_1_RATE_ADSR_ATTACK, IAS_P_LFO_2_RATE_ADSR_ATTACK};
     for (int a = 0; a < 6; ++a) {
       IasAdsr e; adsr_from(p, bases[a], e);
-      for (int t = 0; t < Tc; ++t) env[a * Tc + t] = ias_adsr(t, e, note_on, cr, eps);
+      for (int t = 0; t < Tc; ++t) env[a * Tc + t] = ias_adsr(t, e, note_on, cr, eps, g_ctl);
     }
     const int lbase[2] = {IAS_P_LFO_1_FREQUENCY, IAS_P_LFO_2_FREQUENCY};
     for (int l = 0; l < 2; ++l) {
@@ -42,7 +48,7 @@ extern "C" int emul_voice_render(const float* params01, const float* noise, floa
       for (int t = 0; t < Tc; ++t) {
         acc += (double)ias_lfo_inc(q[0], q[1], env[(4 + l) * Tc + t], cr);
         const float arg = ias_add((float)acc, q[2]);
-        lfo[l * Tc + t] = ias_mul(ias_lfo_shape_mix(arg, mode), env[(2 + l) * Tc + t]);
+        lfo[l * Tc + t] = ias_mul(ias_lfo_shape_mix(arg, mode, g_ctl), env[(2 + l) * Tc + t]);
       }
     }
     const float* w = p + IAS_P_MOD_MATRIX_ADSR_1_TO_VCO_1_PITCH;  // [input k][output j]

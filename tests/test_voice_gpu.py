@@ -255,3 +255,47 @@ def test_saved_for_backward_with_a_two_point_control_buffer(lib, dev):
     c2, v2 = v.rendered_control()
     assert torch.equal(ctrl, c2) and torch.equal(peaks, v.read_peaks())
     assert torch.equal(vconst.view(torch.int32), v2.view(torch.int32))          # every word copied (bit compare: NaN-safe)
+
+
+@pytest.mark.parametrize("B,sr,sec,seed", [(128, 44100, 4.0, 5), (5, 16000, 1.0, 6), (3, 44100, 0.37, 7)])
+def test_fused_control_pass_equals_the_three_kernel_form(lib, dev, monkeypatch, B, sr, sec, seed):
+    """Round 5: one workgroup per voice runs mapped parameters -> envelopes -> LFOs -> mod matrix with the fp64 pow / cos /
+    fmod written out (csrc/voice_ctrl_math.h).  The three-kernel form with the device math library's functions is still
+    in the sources (long control buffers) and can be forced in the DIAGNOSTIC library (IAS_VOICE_CTRL_UNFUSED=1): every
+    output -- the 5 control signals, the 16 per-voice constants, the 8 intermediate rows, the 10 debug rows -- must be the
+    same bits, at the headline size (1.35 M envelope samples) and on small / ragged shapes."""
+    from inverse_audio_synthesis_amd import _lib
+    v = _voice(dev, B, sr, sec)
+    v.randomize(seed)
+    c = v.synthconfig
+
+    def run(l):
+        ctrl = torch.empty((B, 5, c.control_buffer_size), device=dev)
+        vconst = torch.empty((B, 16), device=dev)
+        env = torch.empty((B, 8, c.control_buffer_size), device=dev)
+        dbg = torch.empty((B, 10, c.control_buffer_size), device=dev)
+        _lib.check(l.ias_voice_control_debug(_lib.ptr(v.params01), _lib.ptr(ctrl), _lib.ptr(vconst), _lib.ptr(env), _lib.ptr(dbg), B,
+                                             c.control_buffer_size, c.control_rate, _lib.stream()), "ias_voice_control_debug")
+        torch.cuda.synchronize()
+        return ctrl.cpu(), vconst.cpu(), env.cpu(), dbg.cpu()
+
+    fused = run(lib)
+    monkeypatch.setenv("IAS_VOICE_CTRL_UNFUSED", "1")
+    unfused = run(_lib.load_diag())
+    monkeypatch.delenv("IAS_VOICE_CTRL_UNFUSED")
+    for name, a, b in zip(("ctrl", "vconst", "rows", "debug rows"), fused, unfused):
+        assert torch.equal(a, b), (name, (a != b).sum().item())
+    assert torch.isfinite(fused[0]).all()
+
+
+def test_long_control_buffer_takes_the_three_kernel_form(lib, dev):
+    """A control buffer whose rows do not fit one CU's LDS (Tc > ~3200: here 10 s at the default control rate) runs the
+    three-kernel control pass in the product library; control signals bit-exact against the oracle as everywhere."""
+    B, sr, sec = 2, 16000, 10.0
+    v = _voice(dev, B, sr, sec)
+    v.randomize(3)
+    assert v.synthconfig.control_buffer_size > 3300
+    cfg = so.VoiceConfig(batch_size=B, sample_rate=sr, buffer_size_seconds=sec)
+    _, parts = so.render_from_params01(cfg, v.params01.cpu(), so.make_noise(cfg), "cr", True)
+    ctrl, _ = v.control_signals()
+    assert torch.equal(ctrl.cpu(), parts["ctrl"])

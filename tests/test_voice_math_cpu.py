@@ -36,13 +36,20 @@ def _run(emul, cfg, p01, noise):
     return audio, ctrl, mixed
 
 
+@pytest.mark.parametrize("ctl", [0, 1])
 @pytest.mark.parametrize("B,sr,sec,seed", [(4, 16000, 1.0, 0), (6, 44100, 4.0, 3)])
-def test_device_math_matches_cr_oracle(emul, B, sr, sec, seed):
+def test_device_math_matches_cr_oracle(emul, B, sr, sec, seed, ctl):
+    """ctl = 0: the libm calls that define the "cr" arithmetic; ctl = 1: the written-out fp64 pow / cos / fmod of
+    csrc/voice_ctrl_math.h that the HIP control kernel runs (round 5).  The same bits either way."""
     cfg = so.VoiceConfig(batch_size=B, sample_rate=sr, buffer_size_seconds=sec)
     noise = so.make_noise(cfg)
     p01 = so.sample_params01(cfg, seed)
     ref, parts = so.render_from_params01(cfg, p01, noise, "cr", True)
-    audio, ctrl, mixed = _run(emul, cfg, p01, noise)
+    emul.emul_set_ctl(ctl)
+    try:
+        audio, ctrl, mixed = _run(emul, cfg, p01, noise)
+    finally:
+        emul.emul_set_ctl(0)
     assert torch.equal(ctrl, parts["ctrl"]), "control-rate signals must be bit-exact"
     assert (audio - ref).abs().max().item() <= 2e-6
     assert not torch.isnan(audio).any()
@@ -146,3 +153,32 @@ def test_headed_adsr_is_bit_identical(emul):
     p = p.contiguous()
     bad = emul.emul_check_adsr_headed(C.c_void_p(p.data_ptr()), C.c_longlong(n), C.c_int(1764), C.c_int(441))
     assert bad == 0
+
+
+@pytest.fixture(scope="module")
+def ctl_check(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("ctl") / "libctrl_math_check.so")
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import gen_ctrl_tables
+    gen_ctrl_tables.main()
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-march=native", "-shared", "-fPIC", "-I",
+                           os.path.join(ROOT, "inverse-audio-synthesis_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cpu_emul", "ctrl_math_check.cpp"), "-o", out])
+    lib = ctypes.CDLL(out)
+    lib.ctrl_math_check.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_ulonglong, ctypes.POINTER(ctypes.c_double)]
+    return lib
+
+
+@pytest.mark.parametrize("kind,name,max_ulp64", [(0, "pow on ADSR-like ramps", 4.0), (1, "pow over its whole guarded domain", 4.0),
+                                                 (2, "cos", 4.0), (3, "fmod by fl32(2 pi)", 0.0)])
+def test_written_out_control_math_equals_libm_after_the_rounding_to_fp32(ctl_check, kind, name, max_ulp64):
+    """csrc/voice_ctrl_math.h (the fp64 pow / cos / fmod the HIP control pass evaluates instead of calling the device math
+    library) against libm, the functions the "cr" contract is defined by, on 10^7 random arguments each: the value rounded
+    to fp32 is IDENTICAL everywhere, the fp64 values agree to a few ulp (fmod: exactly)."""
+    out = (ctypes.c_double * 4)()
+    assert ctl_check.ctrl_math_check(kind, 10_000_000, 2024 + kind, out) == 0
+    n, bad, worst, outside = list(out)
+    assert bad == 0, (name, bad)
+    assert worst <= max_ulp64, (name, worst)
+    assert outside <= 0.02 * n, (name, outside)
