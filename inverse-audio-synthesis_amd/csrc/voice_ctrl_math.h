@@ -9,7 +9,7 @@
 // themselves (the value rounded to fp32 then equals the rounding of the exact result unless the exact result lies within
 // ~2^-52 of an fp32 rounding boundary: probability ~2^-28 per evaluation, for these functions as for the library's).
 //
-//   ias_ctl_pow(x, a)   0 < x < 1 (normal fp32), 2^-6 <= a <= 64:  x^a in ~40 fp64-rate instructions
+//   ias_ctl_pow(x, a)   x > 0 finite fp32, a finite fp32:  x^a in ~40 fp64-rate instructions
 //       log2 x = e + thi_i + (tlo_i + log2(1 + r)),  r = m c_i - 1 EXACT (c_i: 29 bits), |r| < 2^-8, degree-7 polynomial;
 //       e + thi_i has <= 29 bits, so y_hi = a (e + thi_i) is EXACT; y_lo = a (tlo_i + P) carries an error < 2^-57;
 //       2^y = 2^n E_j (1 + q(g)), y_hi + y_lo = n + j/128 + g by a two-sum (no bits of y_lo lost), degree-6 polynomial.
@@ -34,11 +34,14 @@ IAS_HD bool ias_ctl_pow_in_domain(float x, float a) {
   return x >= 1.17549435e-38f && x < 1.0f && a >= 0.015625f && a <= 64.0f;
 }
 
-// x^a for (x, a) in the domain above; tab = the IAS_CTL_TAB_INIT table (LDS on the device)
-IAS_HD double ias_ctl_pow(float x, float a, const double* tab) {
+// log2 x = hi + lo for a positive finite fp32 x (denormals included): hi = e + thi_i EXACT (<= 29 bits, a multiple of
+// 2^-22), lo = tlo_i + log2(1 + r) with an absolute error < 2^-60.  tab = the IAS_CTL_TAB_INIT table (LDS or global).
+IAS_HD void ias_ctl_log2(float x, const double* tab, double& hi, double& lo) {
   union { float f; uint32_t u; } b;
   b.f = x;
-  const int e = (int)(b.u >> 23) - 127;
+  int e = -127;
+  if (b.u < 0x00800000u) { b.f = x * 18446744073709551616.0f; e = -127 - 64; }   // denormal: x 2^64 is exact
+  e += (int)(b.u >> 23);
   const int i = (int)((b.u >> 16) & 127u);
   b.u = (b.u & 0x007fffffu) | 0x3f800000u;
   const double m = (double)b.f;
@@ -51,13 +54,16 @@ IAS_HD double ias_ctl_pow(float x, float a, const double* tab) {
   p = fma(p, r, IAS_CTL_L3);
   p = fma(p, r, IAS_CTL_L2);
   p = fma(p, r, IAS_CTL_L1);
-  const double s_lo = fma(p, r, row[2]);                       // tlo + log2(1 + r)
-  const double s_hi = (double)e + row[1];                      // exact (<= 29 bits)
-  const double ad = (double)a;
-  const double y_hi = ad * s_hi;                               // exact (24 + 29 bits)
-  const double y_lo = ad * s_lo;
+  lo = fma(p, r, row[2]);                                      // tlo + log2(1 + r)
+  hi = (double)e + row[1];                                     // exact
+}
+
+// 2^(y_hi + y_lo), |y_lo| <= 2^-3 |y_hi| or so (a two-sum sorts it out); saturates to 0 / inf far outside fp32's range
+IAS_HD double ias_ctl_exp2(double y_hi, double y_lo, const double* tab) {
   const double yh = y_hi + y_lo;                               // two-sum: yh + yl == y_hi + y_lo
   const double yl = y_lo - (yh - y_hi);
+  if (!(yh > -2000.0)) return yh != yh ? yh : 0.0;
+  if (yh > 2000.0) return INFINITY;
   const double kd = rint(yh * 128.0);
   const double g = fma(kd, -0.0078125, yh) + yl;               // (first term exact) |g| <= 2^-8
   const int k = (int)kd;
@@ -72,6 +78,42 @@ IAS_HD double ias_ctl_pow(float x, float a, const double* tab) {
   return ldexp(fma(ej, q, ej), k >> 7);
 }
 
+// x^a for a positive finite fp32 x and any finite fp32 a (a (e + thi) is exact for every 24-bit a)
+IAS_HD double ias_ctl_pow(float x, float a, const double* tab) {
+  double hi, lo;
+  ias_ctl_log2(x, tab, hi, lo);
+  const double ad = (double)a;
+  return ias_ctl_exp2(ad * hi, ad * lo, tab);                  // ad * hi exact (24 + 29 bits)
+}
+
+// log2 x as ONE double with a RELATIVE error ~2^-52 for every positive finite fp32 x: next to x = 1, where hi + lo would
+// cancel, the series in d = x - 1 (exact) instead.  x == 1 gives exactly 0.
+IAS_HD double ias_ctl_log2_value(float x, const double* tab) {
+  const float d = x - 1.0f;                                    // exact for x in [0.5, 2]
+  if (fabsf(d) < 0.0078125f) {
+    const double dd = (double)d;
+    double p = IAS_CTL_L9;
+    p = fma(p, dd, IAS_CTL_L8);
+    p = fma(p, dd, IAS_CTL_L7);
+    p = fma(p, dd, IAS_CTL_L6);
+    p = fma(p, dd, IAS_CTL_L5);
+    p = fma(p, dd, IAS_CTL_L4);
+    p = fma(p, dd, IAS_CTL_L3);
+    p = fma(p, dd, IAS_CTL_L2);
+    p = fma(p, dd, IAS_CTL_L1);
+    return p * dd;
+  }
+  double hi, lo;
+  ias_ctl_log2(x, tab, hi, lo);
+  return hi + lo;
+}
+// log10 x = log2 x * log10(2), same accuracy class (x not next to 1: the render's only use is a frequency in Hz)
+IAS_HD double ias_ctl_log10_value(float x, const double* tab) {
+  double hi, lo;
+  ias_ctl_log2(x, tab, hi, lo);
+  return fma(hi, IAS_CTL_LOG10_2_HI, fma(lo, IAS_CTL_LOG10_2_HI, hi * IAS_CTL_LOG10_2_LO));
+}
+
 IAS_HD bool ias_ctl_cos_in_domain(float x) { return fabsf(x) < 32768.0f; }
 
 // cos(x), |x| < 2^15
@@ -83,24 +125,18 @@ IAS_HD double ias_ctl_cos(float x) {
   r = fma(-kd, IAS_CTL_PIO2_3, r);
   const int k = (int)kd;
   const double z = r * r;
-  double s = IAS_CTL_S7;
-  s = fma(s, z, IAS_CTL_S6);
-  s = fma(s, z, IAS_CTL_S5);
-  s = fma(s, z, IAS_CTL_S4);
-  s = fma(s, z, IAS_CTL_S3);
-  s = fma(s, z, IAS_CTL_S2);
-  s = fma(s, z, IAS_CTL_S1);
-  s = fma(s * z, r, r);                                        // sin r = r + r^3 S(r^2)
-  double c = IAS_CTL_C8;
-  c = fma(c, z, IAS_CTL_C7);
-  c = fma(c, z, IAS_CTL_C6);
-  c = fma(c, z, IAS_CTL_C5);
-  c = fma(c, z, IAS_CTL_C4);
-  c = fma(c, z, IAS_CTL_C3);
-  c = fma(c, z, IAS_CTL_C2);
-  c = fma(c * z, z, fma(z, -0.5, 1.0));                        // cos r = 1 - r^2/2 + r^4 C(r^2)
-  // cos(r + k pi/2): k mod 4 = 0: cos r, 1: -sin r, 2: -cos r, 3: sin r
-  const double v = (k & 1) ? s : c;
+  // cos(r + k pi/2): k mod 4 = 0: cos r, 1: -sin r, 2: -cos r, 3: sin r.  ONE Horner chain with the coefficient set picked
+  // per lane (sin r = r + (r z) S(z), cos r = (1 - z/2) + (z z) C(z)): half the live registers of evaluating both.
+  const bool odd = (k & 1) != 0;
+  double p = odd ? IAS_CTL_S7 : IAS_CTL_C8;
+  p = fma(p, z, odd ? IAS_CTL_S6 : IAS_CTL_C7);
+  p = fma(p, z, odd ? IAS_CTL_S5 : IAS_CTL_C6);
+  p = fma(p, z, odd ? IAS_CTL_S4 : IAS_CTL_C5);
+  p = fma(p, z, odd ? IAS_CTL_S3 : IAS_CTL_C4);
+  p = fma(p, z, odd ? IAS_CTL_S2 : IAS_CTL_C3);
+  p = fma(p, z, odd ? IAS_CTL_S1 : IAS_CTL_C2);
+  const double lead = odd ? r : fma(z, -0.5, 1.0);
+  const double v = fma(p * z, odd ? r : z, lead);
   return (((k + 1) >> 1) & 1) ? -v : v;
 }
 

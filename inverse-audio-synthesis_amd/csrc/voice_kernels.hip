@@ -896,15 +896,24 @@ static int voice_check_dims(int B, int T, int Tc) {
   return IAS_OK;
 }
 
+// csrc/voice_ctrl_kernels.hip: the control pass as kernels that fit beside the render's waves (<= 56 VGPRs, no library math)
+bool ias_voice_control_slim_ok(int Tc, int control_rate);
+int ias_voice_control_slim_launch(const float* params01, float* ctrl, void* vconst, float* sig, float* dbg, int B, int Tc,
+                                  int control_rate, hipStream_t stream);
+
 static int voice_control_launch(const float* params01, float* ctrl, void* vconst, float* sig, float* dbg, int B,
                                 int Tc, int control_rate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!params01 || !ctrl || !vconst || !sig || B <= 0 || B > 65535 || Tc <= 1 || control_rate <= 0) return IAS_ERR_ARG;
+  // (diagnostic library: IAS_VOICE_CTRL=fused / libm pick the one-workgroup-per-voice kernel / the round-1 kernels with the
+  // device math library's pow / cos / fmodf at any size)
+  const char* form = ias_diag_env("IAS_VOICE_CTRL");
+  if (form == nullptr && ias_voice_control_slim_ok(Tc, control_rate))
+    return ias_voice_control_slim_launch(params01, ctrl, vconst, sig, dbg, B, Tc, control_rate, stream);
   // one workgroup per voice while its rows fit the LDS of a CU (48 bytes per control sample + the 4 KB table: Tc <= ~3200);
   // longer control buffers take the three-kernel form (rows through HBM)
   const size_t flds = voice_control_fused_lds(Tc);
-  // (diagnostic library: IAS_VOICE_CTRL_UNFUSED=1 takes the three kernels, with the library's pow / cos / fmodf, at any Tc)
-  if (flds <= 156 * 1024 && !ias_diag_env("IAS_VOICE_CTRL_UNFUSED")) {
+  if (flds <= 156 * 1024 && form != nullptr && form[0] == 'f') {
     static bool attr_set = false;                          // (idempotent: a race sets it twice)
     if (!attr_set) {
       if (hipFuncSetAttribute((const void*)voice_control_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)

@@ -45,16 +45,38 @@ IAS_HD float ias_log10_cr(float x) { return (float)log10((double)x); }
 IAS_HD float ias_cos_cr(float x) { return (float)cos((double)x); }
 IAS_HD float ias_exp2_slow_cr(float x) { return (float)exp2((double)x); }
 // The same values from the written-out fp64 kernels of voice_ctrl_math.h (ctl: the IAS_CTL_TAB_INIT table, or NULL for
-// the library calls above): ~40 fp64-rate instructions instead of ~300 for pow, ~30 instead of ~120 for cos, inside
-// their domains -- which hold every argument the control pass produces for parameters in range; anything else takes
-// the library function.  Same accuracy class as the library calls (voice_ctrl_math.h), so the same fp32 values.
+// the library calls above): ~40 fp64-rate instructions instead of ~300 for pow, ~30 instead of ~120 for cos.  Same
+// accuracy class as the library calls (voice_ctrl_math.h), so the same fp32 values.
+// A translation unit compiled with IAS_CTL_NO_LIBM (csrc/voice_ctrl_kernels.hip: the control pass that has to fit beside
+// the render's waves, <= 56 VGPRs) never reaches the library: ctl must be given, pow / log2 / exp2 are total on their own
+// (x <= 0 as IEEE pow / log2 define it), and the launcher only takes those kernels where every LFO phase is far below the
+// 2^20 rad up to which cos / fmod reduce exactly.
+#ifdef IAS_CTL_NO_LIBM
+#define IAS_CTL_LIBM_IF(cond) if (false)
+#else
+#define IAS_CTL_LIBM_IF(cond) if (cond)
+#endif
 IAS_HD float ias_pow_ctl(float x, float a, const double* ctl) {
-  if (ctl != nullptr && ias_ctl_pow_in_domain(x, a)) return (float)ias_ctl_pow(x, a, ctl);
-  return ias_pow_cr(x, a);
+  IAS_CTL_LIBM_IF(ctl == nullptr || !ias_ctl_pow_in_domain(x, a)) return ias_pow_cr(x, a);
+  if (!(x > 0.0f)) return x == 0.0f ? (a > 0.0f ? 0.0f : (a == 0.0f ? 1.0f : INFINITY)) : NAN;
+  return (float)ias_ctl_pow(x, a, ctl);
 }
 IAS_HD float ias_cos_ctl(float x, const double* ctl) {
-  if (ctl != nullptr && ias_ctl_cos_in_domain(x)) return (float)ias_ctl_cos(x);
-  return ias_cos_cr(x);
+  IAS_CTL_LIBM_IF(ctl == nullptr || !ias_ctl_cos_in_domain(x)) return ias_cos_cr(x);
+  return (float)ias_ctl_cos(x);
+}
+IAS_HD float ias_log2_ctl(float x, const double* ctl) {
+  IAS_CTL_LIBM_IF(ctl == nullptr || !(x > 0.0f) || !(x < INFINITY)) return ias_log2_cr(x);
+  if (!(x > 0.0f)) return x == 0.0f ? -INFINITY : NAN;
+  return (float)ias_ctl_log2_value(x, ctl);
+}
+IAS_HD float ias_log10_ctl(float x, const double* ctl) {
+  IAS_CTL_LIBM_IF(ctl == nullptr || !(x > 0.0f) || !(x < INFINITY) || fabsf(x - 1.0f) < 0.25f) return ias_log10_cr(x);
+  return (float)ias_ctl_log10_value(x, ctl);
+}
+IAS_HD float ias_exp2_ctl(float v, const double* ctl) {
+  IAS_CTL_LIBM_IF(ctl == nullptr) return ias_exp2_slow_cr(v);
+  return (float)ias_ctl_exp2((double)v, 0.0, ctl);
 }
 
 // 2^t for the audio-rate pitch path.  n = rint(t), f = t - n is exact in fp32;
@@ -150,15 +172,15 @@ IAS_HD int ias_div_fma_rate_ok(int sample_rate) {
 // ---- parameter range mapping (torchsynth ModuleParameterRange.from_0to1) ----
 // lo = fl32(minimum); span = fl32(maximum - minimum) (non-symmetric) or
 // fl32((maximum - minimum) / 2) (symmetric), both rounded from the double table.
-IAS_HD float ias_map_param(float u, float lo, float span, float curve, int symmetric) {
+IAS_HD float ias_map_param(float u, float lo, float span, float curve, int symmetric, const double* ctl = nullptr) {
   if (!symmetric) {
-    if (curve != 1.0f) u = ias_exp2_slow_cr(ias_div(ias_log2_cr(u), curve));
+    if (curve != 1.0f) u = ias_exp2_ctl(ias_div(ias_log2_ctl(u, ctl), curve), ctl);
     return ias_add(lo, ias_mul(span, u));
   }
   const float dist = ias_sub(ias_mul(2.0f, u), 1.0f);
   float v = dist;
   if (curve != 1.0f && dist != 0.0f) {
-    const float mag = ias_exp2_slow_cr(ias_div(ias_log2_cr(fabsf(dist)), curve));
+    const float mag = ias_exp2_ctl(ias_div(ias_log2_ctl(fabsf(dist), ctl), curve), ctl);
     v = dist < 0.0f ? -mag : mag;
   }
   return ias_add(lo, ias_mul(span, ias_add(v, 1.0f)));
@@ -240,8 +262,8 @@ IAS_HD float ias_remainder(float a, float b) {
 IAS_HD float ias_remainder_2pi_ctl(float a, const double* ctl) {
   const float b = (float)IAS_TWO_PI_D;
   float m;
-  if (ctl != nullptr && ias_ctl_fmod_in_domain(a, b)) m = ias_ctl_fmod(a, b, 1.0 / (double)(float)IAS_TWO_PI_D);
-  else m = fmodf(a, b);
+  m = ias_ctl_fmod(a, b, 1.0 / (double)(float)IAS_TWO_PI_D);
+  IAS_CTL_LIBM_IF(ctl == nullptr || !ias_ctl_fmod_in_domain(a, b)) m = fmodf(a, b);
   if (m != 0.0f && m < 0.0f) m = ias_add(m, b);
   return m;
 }
@@ -275,9 +297,9 @@ IAS_HD float ias_dot4_cr(float w0, float w1, float w2, float w3, float s0, float
 }
 
 // torchsynth LFO: mode = pow(p, exponent) / sum with the LFO.__init__ default exponent (IAS_LFO_EXPONENT_F)
-IAS_HD void ias_lfo_mode(const float* p5, float* mode) {
+IAS_HD void ias_lfo_mode(const float* p5, float* mode, const double* ctl = nullptr) {
   float m[5];
-  for (int k = 0; k < 5; ++k) m[k] = ias_pow_cr(p5[k], IAS_LFO_EXPONENT_F);
+  for (int k = 0; k < 5; ++k) m[k] = ias_pow_ctl(p5[k], IAS_LFO_EXPONENT_F, ctl);
   const float s = (float)((double)m[0] + (double)m[1] + (double)m[2] + (double)m[3] + (double)m[4]);
   for (int k = 0; k < 5; ++k) mode[k] = ias_div(m[k], s);
 }
@@ -330,10 +352,10 @@ IAS_HD float ias_vco_inc_fast(float f0, float depth, float pitch_mod, double inv
   return ias_div_by_recip(ias_mul((float)IAS_TWO_PI_D, hz), inv_sample_rate);
 }
 
-IAS_HD float ias_partials_k(float midi_f0, float depth_2) {
+IAS_HD float ias_partials_k(float midi_f0, float depth_2, const double* ctl = nullptr) {
   const float max_pitch = ias_add(midi_f0, fmaxf(depth_2, 0.0f));
   const float max_f0 = ias_midi_to_hz(max_pitch);
-  const float partials = ias_div(12000.0f, ias_mul(max_f0, ias_log10_cr(max_f0)));
+  const float partials = ias_div(12000.0f, ias_mul(max_f0, ias_log10_ctl(max_f0, ctl)));
   return ias_mul((float)IAS_PI_D, partials);
 }
 

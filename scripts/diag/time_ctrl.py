@@ -1,4 +1,4 @@
-"""The control pass alone: K launches in a hipGraph (developer tool; IAS_HIP_LIB / IAS_VOICE_CTRL_UNFUSED select builds)."""
+"""The control pass alone: K launches in a hipGraph (developer tool; IAS_HIP_LIB=...libias_hip_diag.so + IAS_VOICE_CTRL=libm|fused select the other forms)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -19,4 +19,4 @@ for _ in range(9):
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1) / K * 1e3)
 ts.sort()
-print(f"control pass B={B}: median {ts[4]:.1f} us  min {ts[0]:.1f} us  lib={os.environ.get('IAS_HIP_LIB', 'product')} unfused={os.environ.get('IAS_VOICE_CTRL_UNFUSED')}")
+print(f"control pass B={B}: median {ts[4]:.1f} us  min {ts[0]:.1f} us  lib={os.environ.get('IAS_HIP_LIB', 'product')} form={os.environ.get('IAS_VOICE_CTRL', 'slim')}")

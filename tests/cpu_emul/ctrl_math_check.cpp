@@ -47,6 +47,32 @@ extern "C" int ctrl_math_check(int kind, long long n, unsigned long long seed, d
       if (!ias_ctl_cos_in_domain(x)) { ++outside; continue; }
       fast = ias_ctl_cos(x);
       ref = cos((double)x);
+    } else if (kind == 4) {     // log2 as one value: uniform, next to 1 (both sides), tiny
+      const unsigned mode = (unsigned)(splitmix(s) & 3);
+      float x = u01(s);
+      if (mode == 1) x = 1.0f - ldexpf(x, -(int)(splitmix(s) % 24));
+      if (mode == 2) x = 1.0f + ldexpf(x, -(int)(splitmix(s) % 23));
+      if (mode == 3) x = ldexpf(x + 0.5f, (int)(splitmix(s) % 250) - 140);
+      if (!(x > 0.0f)) { ++outside; continue; }
+      fast = ias_ctl_log2_value(x, g_tab);
+      ref = log2((double)x);
+      if (x == 1.0f) { if (fast != 0.0) ++bad; continue; }
+    } else if (kind == 5) {     // log10 of a frequency in Hz
+      const float x = 8.0f + 26000.0f * u01(s);
+      fast = ias_ctl_log10_value(x, g_tab);
+      ref = log10((double)x);
+    } else if (kind == 6) {     // 2^v for an fp32 v (parameter curves: v = log2(u) / curve <= 0; some positive too)
+      const float v = (u01(s) - 0.9f) * ldexpf(1.0f, (int)(splitmix(s) % 10) - 2);
+      fast = ias_ctl_exp2((double)v, 0.0, g_tab);
+      ref = exp2((double)v);
+    } else if (kind == 7) {     // pow outside (0, 1): denormal x, x > 1, tiny and large exponents
+      union { float f; uint32_t u; } b;
+      b.u = (uint32_t)(splitmix(s) % 0x7f000000u) + 1u;
+      const float x = b.f;
+      const float a = ldexpf(1.0f + u01(s), (int)(splitmix(s) % 16) - 9) * ((splitmix(s) & 1) ? 1.0f : -1.0f);
+      fast = ias_ctl_pow(x, a, g_tab);
+      ref = pow((double)x, (double)a);
+      if (!(fabs(ref) < 1.0e290) || fabs(ref) < 1.0e-290) { if ((float)fast != (float)ref) ++bad; continue; }
     } else {                    // fmod by fl32(2 pi)
       const float b = 6.2831854820251465f;
       const unsigned mode = (unsigned)(splitmix(s) & 3);

@@ -30,7 +30,7 @@ extern "C" int emul_voice_render(const float* params01, const float* noise, floa
     float p[IAS_NPARAMS];
     for (int i = 0; i < IAS_NPARAMS; ++i) {
       const IasParamRange& r = IAS_PARAM_TABLE[i];
-      p[i] = ias_map_param(params01[b * IAS_NPARAMS + i], (float)r.lo, (float)r.span, (float)r.curve, r.symmetric);
+      p[i] = ias_map_param(params01[b * IAS_NPARAMS + i], (float)r.lo, (float)r.span, (float)r.curve, r.symmetric, g_ctl);
     }
     const float midi_f0 = p[IAS_P_KEYBOARD_MIDI_F0], note_on = p[IAS_P_KEYBOARD_DURATION];
     // env order: adsr_1, adsr_2, lfo_1_amp, lfo_2_amp, lfo_1_rate, lfo_2_rate
@@ -43,7 +43,7 @@ extern "C" int emul_voice_render(const float* params01, const float* noise, floa
     const int lbase[2] = {IAS_P_LFO_1_FREQUENCY, IAS_P_LFO_2_FREQUENCY};
     for (int l = 0; l < 2; ++l) {
       const float* q = p + lbase[l];
-      float mode[5]; ias_lfo_mode(q + 3, mode);
+      float mode[5]; ias_lfo_mode(q + 3, mode, g_ctl);
       double acc = 0.0;
       for (int t = 0; t < Tc; ++t) {
         acc += (double)ias_lfo_inc(q[0], q[1], env[(4 + l) * Tc + t], cr);
@@ -63,7 +63,7 @@ extern "C" int emul_voice_render(const float* params01, const float* noise, floa
     IasVoiceConst vc;
     vc.f0_1 = ias_add(midi_f0, p[IAS_P_VCO_1_TUNING]); vc.depth_1 = p[IAS_P_VCO_1_MOD_DEPTH]; vc.phi_1 = p[IAS_P_VCO_1_INITIAL_PHASE];
     vc.f0_2 = ias_add(midi_f0, p[IAS_P_VCO_2_TUNING]); vc.depth_2 = p[IAS_P_VCO_2_MOD_DEPTH]; vc.phi_2 = p[IAS_P_VCO_2_INITIAL_PHASE];
-    vc.kpart = ias_partials_k(midi_f0, vc.depth_2);
+    vc.kpart = ias_partials_k(midi_f0, vc.depth_2, g_ctl);
     vc.shape = p[IAS_P_VCO_2_SHAPE];
     vc.shape_gain = ias_sub(1.0f, ias_div(vc.shape, 2.0f));
     vc.lvl0 = p[IAS_P_MIXER_VCO_1]; vc.lvl1 = p[IAS_P_MIXER_VCO_2]; vc.lvl2 = p[IAS_P_MIXER_NOISE];

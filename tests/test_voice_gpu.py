@@ -258,12 +258,13 @@ def test_saved_for_backward_with_a_two_point_control_buffer(lib, dev):
 
 
 @pytest.mark.parametrize("B,sr,sec,seed", [(128, 44100, 4.0, 5), (5, 16000, 1.0, 6), (3, 44100, 0.37, 7)])
-def test_fused_control_pass_equals_the_three_kernel_form(lib, dev, monkeypatch, B, sr, sec, seed):
-    """Round 5: one workgroup per voice runs mapped parameters -> envelopes -> LFOs -> mod matrix with the fp64 pow / cos /
-    fmod written out (csrc/voice_ctrl_math.h).  The three-kernel form with the device math library's functions is still
-    in the sources (long control buffers) and can be forced in the DIAGNOSTIC library (IAS_VOICE_CTRL_UNFUSED=1): every
-    output -- the 5 control signals, the 16 per-voice constants, the 8 intermediate rows, the 10 debug rows -- must be the
-    same bits, at the headline size (1.35 M envelope samples) and on small / ragged shapes."""
+def test_control_pass_without_library_math_equals_the_library_forms(lib, dev, monkeypatch, B, sr, sec, seed):
+    """Round 5: the control pass runs as three kernels of <= 56 VGPRs whose fp64 pow / cos / fmod / log2 / exp2 are written
+    out (csrc/voice_ctrl_kernels.hip, voice_ctrl_math.h), so that their waves fit beside the render's.  The round-1 kernels
+    with the device math library's functions are still in the sources (long control buffers), and a one-workgroup-per-voice
+    kernel with both; the DIAGNOSTIC library can be told to take them (IAS_VOICE_CTRL=libm / fused).  Every output -- the
+    5 control signals, the 16 per-voice constants, the 8 intermediate rows, the 10 debug rows -- must be the same bits in
+    all three, at the headline size (1.35 M envelope samples) and on small / ragged shapes."""
     from inverse_audio_synthesis_amd import _lib
     v = _voice(dev, B, sr, sec)
     v.randomize(seed)
@@ -279,22 +280,23 @@ def test_fused_control_pass_equals_the_three_kernel_form(lib, dev, monkeypatch, 
         torch.cuda.synchronize()
         return ctrl.cpu(), vconst.cpu(), env.cpu(), dbg.cpu()
 
-    fused = run(lib)
-    monkeypatch.setenv("IAS_VOICE_CTRL_UNFUSED", "1")
-    unfused = run(_lib.load_diag())
-    monkeypatch.delenv("IAS_VOICE_CTRL_UNFUSED")
-    for name, a, b in zip(("ctrl", "vconst", "rows", "debug rows"), fused, unfused):
-        assert torch.equal(a, b), (name, (a != b).sum().item())
-    assert torch.isfinite(fused[0]).all()
+    slim = run(lib)
+    assert torch.isfinite(slim[0]).all()
+    for form in ("libm", "fused"):
+        monkeypatch.setenv("IAS_VOICE_CTRL", form)
+        other = run(_lib.load_diag())
+        monkeypatch.delenv("IAS_VOICE_CTRL")
+        for name, a, b in zip(("ctrl", "vconst", "rows", "debug rows"), slim, other):
+            assert torch.equal(a, b), (form, name, (a != b).sum().item())
 
 
 def test_long_control_buffer_takes_the_three_kernel_form(lib, dev):
-    """A control buffer whose rows do not fit one CU's LDS (Tc > ~3200: here 10 s at the default control rate) runs the
-    three-kernel control pass in the product library; control signals bit-exact against the oracle as everywhere."""
+    """A control buffer longer than the library-free kernels take (Tc > 4096: here 10 s at the default control rate) runs
+    the round-1 control kernels in the product library; control signals bit-exact against the oracle as everywhere."""
     B, sr, sec = 2, 16000, 10.0
     v = _voice(dev, B, sr, sec)
     v.randomize(3)
-    assert v.synthconfig.control_buffer_size > 3300
+    assert v.synthconfig.control_buffer_size > 4096
     cfg = so.VoiceConfig(batch_size=B, sample_rate=sr, buffer_size_seconds=sec)
     _, parts = so.render_from_params01(cfg, v.params01.cpu(), so.make_noise(cfg), "cr", True)
     ctrl, _ = v.control_signals()

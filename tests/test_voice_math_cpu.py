@@ -74,12 +74,23 @@ def test_cr_upsample_is_the_torch_op_bit_for_bit():
     fl(w0 a + fl(w1 b)) -- x0 * w0 + x1 * w1 contracted into one fma -- and the oracle's statement of it (fma32, an
     exactly rounded emulation) gives the same bits on every element, at the headline and at a ragged length.  (The
     three-rounding form of rounds 1-3 differed from the op in 24 % of the elements.)"""
+    # "cr" DEFINES the upsample as fl(w0 a + fl(w1 b)).  That this is also what the local torch op computes is a property of
+    # the compiler and ISA torch was built with (which product of `x0 * w0 + x1 * w1` gets fused, if any), not of the op:
+    # probe the local op's rounding form first, assert bit-equality where it is the fused form (this image), and a
+    # one-ulp bound on any other build.
+    pcfg = so.VoiceConfig(batch_size=1, sample_rate=44100, buffer_size_seconds=4096 / so.VoiceConfig().control_rate)
+    probe = torch.randn(1, 1, pcfg.control_buffer_size, generator=torch.Generator().manual_seed(99)) * 3.0
+    local_is_fused_form = torch.equal(so._Math("torch").upsample(probe, pcfg), so._Math("cr").upsample(probe, pcfg))
     for B, sr, sec in ((3, 44100, 4.0), (2, 16000, 0.37)):
         cfg = so.VoiceConfig(batch_size=B, sample_rate=sr, buffer_size_seconds=sec)
         ctrl = torch.randn(B, 5, cfg.control_buffer_size, generator=torch.Generator().manual_seed(B)) * 3.0
         want = so._Math("torch").upsample(ctrl, cfg)
         got = so._Math("cr").upsample(ctrl, cfg)
-        assert torch.equal(got, want)
+        if local_is_fused_form:
+            assert torch.equal(got, want)
+        else:
+            ulp = torch.maximum(want.abs(), got.abs()) * 2.0 ** -23 + 1e-45
+            assert ((got - want).abs() <= ulp).all()
     # fma32 is a single rounding: against exact rational arithmetic, including cancellation and far-apart exponents
     from fractions import Fraction
     g = torch.Generator().manual_seed(5)
@@ -170,8 +181,11 @@ def ctl_check(tmp_path_factory):
     return lib
 
 
-@pytest.mark.parametrize("kind,name,max_ulp64", [(0, "pow on ADSR-like ramps", 4.0), (1, "pow over its whole guarded domain", 4.0),
-                                                 (2, "cos", 4.0), (3, "fmod by fl32(2 pi)", 0.0)])
+@pytest.mark.parametrize("kind,name,max_ulp64", [(0, "pow on ADSR-like ramps", 4.0), (1, "pow: any normal x < 1, a in [2^-6, 64]", 4.0),
+                                                 (2, "cos", 4.0), (3, "fmod by fl32(2 pi)", 0.0),
+                                                 (4, "log2 as one value, also next to 1", 4.0), (5, "log10 of a frequency", 4.0),
+                                                 (6, "exp2 of an fp32", 4.0),
+                                                 (7, "pow outside the render's domain: denormal x, x > 1, |a| up to 256", 1000.0)])
 def test_written_out_control_math_equals_libm_after_the_rounding_to_fp32(ctl_check, kind, name, max_ulp64):
     """csrc/voice_ctrl_math.h (the fp64 pow / cos / fmod the HIP control pass evaluates instead of calling the device math
     library) against libm, the functions the "cr" contract is defined by, on 10^7 random arguments each: the value rounded
