@@ -859,12 +859,12 @@ def main():
     voice.set_parameters01(params)
 
     ev = {"begin": [], "end": []}
-    cev = {"pqmf": [], "stft": []}      # (begin, end) HIP events on the consumers' own streams (in-step durations)
+    cev = {"pqmf": [], "stft": [], "control": []}      # (begin, end) HIP events on the stages' own streams (in-step durations)
     # instrument["on"]: False, "events" (HIP events around the stages: eager passes only) or "stamps" (ias_stamp launches
     # around the stages: device timestamps that can be captured INTO a graph, so the in-step durations of the line belong
     # to a replayed graph like the one the timed regions replay -- HIP events cannot be read back from a replay)
     instrument = {"on": False}
-    STAGES = ("render", "pqmf", "stft")
+    STAGES = ("render", "pqmf", "stft", "control")
     stamp_buf = torch.zeros((len(STAGES), max(args.steps, args.warmup, 2), 2), dtype=torch.int64, device=dev)
     stamp_n = {n: 0 for n in STAGES}
 
@@ -945,7 +945,8 @@ def main():
             with torch.cuda.stream(side_c):
                 if ws_free[buf] is not None:
                     side_c.wait_event(ws_free[buf])
-                voice.render_control(workspaces[buf])
+                with bracket("control"):
+                    voice.render_control(workspaces[buf])
                 if preclear:
                     # the re-zeroing of the render's polled words leaves the render queue too (it was a memset node
                     # between every two renders): here it has to wait for the readers of the row peaks as well
@@ -1104,7 +1105,7 @@ def main():
     # The bracket holds the kernel and the 90 KB memset of its ticket / aggregate words.
     def timed_pass(pipe):
         ev["begin"].clear(); ev["end"].clear()
-        cev["pqmf"].clear(); cev["stft"].clear()
+        cev["pqmf"].clear(); cev["stft"].clear(); cev["control"].clear()
         instrument["on"] = "events"
         torch.cuda.synchronize()
         run_steps(args.steps, pipe)
@@ -1136,8 +1137,14 @@ def main():
         e0.record(); gi.replay(); e1.record()
         torch.cuda.synchronize()
         t = stamp_buf.cpu().double()[:, :args.steps]
+        if os.environ.get("IAS_BENCH_DUMP_STAMPS"):            # diagnostics: the raw timeline of the instrumented replay [us]
+            t0_ = t[t > 0].min()
+            with open(os.environ["IAS_BENCH_DUMP_STAMPS"], "w") as f:
+                for i_ in range(args.steps):
+                    f.write("step %2d  " % i_ + "  ".join("%s %8.1f -> %8.1f" % (n, (t[k_, i_, 0] - t0_) * 1e-2, (t[k_, i_, 1] - t0_) * 1e-2)
+                                                          for k_, n in enumerate(STAGES)) + "\n")
         dur = (t[:, :, 1] - t[:, :, 0]) * 1e-5                # 100 MHz ticks -> ms
-        return {n: float(dur[i].mean()) for i, n in enumerate(STAGES)}, e0.elapsed_time(e1) / args.steps
+        return {n: float(dur[i][dur[i] > 0].mean()) if (dur[i] > 0).any() else None for i, n in enumerate(STAGES)}, e0.elapsed_time(e1) / args.steps
 
     instep_source, stamped_step_ms = "HIP events around the stages in an eager pass of the schedule", None
     instep_ms = None
@@ -1354,6 +1361,7 @@ def main():
                                "HBM frac; the largest sum is the step these kernels could reach with perfect overlap and no waiting "
                                "(the control pass and launch gaps excluded); chain_frac_at_floor = the chain's 22 B/sample over it",
             "control_pass_isolated_us": round(ctrl_iso_ms * 1e3, 1),
+            "control_pass_in_step_us": None if not instep_ms.get("control") else round(instep_ms["control"] * 1e3, 1),
             "chain_frac_note": "22 B/sample (SURVEY.md 8d: render 8 + PQMF 8 + mel-L1 5, rounded up) x B x T / ms_per_step "
                                "/ 8 TB/s: the whole step against the HBM roofline (north_star target 0.70)",
         },

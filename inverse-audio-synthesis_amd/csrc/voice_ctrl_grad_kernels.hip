@@ -21,6 +21,21 @@
 // 245 -> 115 us at B = 64, bit-identical output.
 #include "ias_common.h"
 #include "voice_table.h"
+#include "voice_ctrl_math.h"
+
+// Round 5: the fp64 pow / log / sin / cos / mod of this file by csrc/voice_ctrl_math.h's written-out forms (relative error
+// ~2^-50 against the device math library's < 1 ulp: the gradients are checked to 1e-5) -- pow alone was ~300 fp64-rate
+// instructions per call, three of them per envelope point.  Arguments outside the forms' domains (x not a positive normal
+// double) take the library function.
+__device__ const double g_cg_tab[IAS_CTL_TAB_DOUBLES] = IAS_CTL_TAB_INIT;
+__device__ __forceinline__ double cg_pow(double x, double a) {
+  if (x >= 2.3e-308 && x < 1.0e300) return ias_ctl_pow_d(x, a, g_cg_tab);
+  return pow(x, a);
+}
+__device__ __forceinline__ double cg_log(double x) {
+  if (x >= 2.3e-308 && x < 1.0e300) return ias_ctl_log_d(x, g_cg_tab);
+  return log(x);
+}
 
 #ifndef CG_THREADS
 #define CG_THREADS 512    // 8 waves per voice (2 per SIMD; 16 would cap the kernel at 128 VGPRs and spill: 467 us instead of 240)
@@ -80,7 +95,7 @@ __device__ __forceinline__ double cg_ramp(int i, double duration, double alpha, 
   *y_out = y; *q_out = q; *t_out = t; *t_live = live;
   if (y == 1.0) return 1.0;                      // saturated attack ramps, zero-length segments: no pow()
   if (has_start && !live && head >= 0.0) return head;   // flat head before the segment starts: same value for all i
-  return pow(y >= 1e-300 ? y : 1e-300, alpha);
+  return cg_pow(y >= 1e-300 ? y : 1e-300, alpha);
 }
 // accumulate d/d(duration, start, alpha) of g * ramp
 __device__ __forceinline__ void cg_ramp_back(double g, double val, double y, double q, double t, bool t_live,
@@ -88,7 +103,7 @@ __device__ __forceinline__ void cg_ramp_back(double g, double val, double y, dou
                                              CgRampGrad& acc) {
   if (g == 0.0) return;
   const double yc = y >= 1e-300 ? y : 1e-300;
-  acc.alpha += g * val * log(yc);
+  acc.alpha += g * val * cg_log(yc);
   if (y < 1e-300) return;                       // clamp_min: no gradient below the floor (0^alpha ramps)
   const double dur = duration * cr;
   if (!(dur > 0.0) || q > 1.0) return;          // constant ramp / saturated at 1
@@ -122,10 +137,12 @@ __device__ __forceinline__ double cg_adsr(int i, const CgAdsr& e, double note_on
 // the five LFO shapes at phase arg and their derivatives d shape / d arg
 __device__ __forceinline__ void cg_lfo_shapes(double arg, double* sh, double* dsh) {
   const double two_pi = 6.283185307179586, pi = 3.141592653589793;
-  const double c = cos(arg + pi);
-  sh[0] = (c + 1.0) * 0.5;                       dsh[0] = -sin(arg + pi) * 0.5;
-  double m = fmod(arg, two_pi);
-  if (m < 0.0) m += two_pi;
+  double c, sn;
+  if (fabs(arg) < 1.0e6) ias_ctl_sincos_d(arg + pi, sn, c); else { c = cos(arg + pi); sn = sin(arg + pi); }
+  sh[0] = (c + 1.0) * 0.5;                       dsh[0] = -sn * 0.5;
+  double m;
+  if (fabs(arg) < 1.0e6) m = ias_ctl_mod_d(arg, two_pi, 0.15915494309189535);
+  else { m = fmod(arg, two_pi); if (m < 0.0) m += two_pi; }
   const double saw = m / two_pi;
   const double tri2 = 2.0 * saw;
   sh[1] = tri2 > 1.0 ? 2.0 - tri2 : tri2;        dsh[1] = tri2 > 1.0 ? -1.0 / pi : 1.0 / pi;
@@ -141,14 +158,14 @@ __device__ __forceinline__ void cg_param_value(int idx, double u, double* v_out,
   double v, dv;
   if (!r.symmetric) {
     const double uc = u >= 1e-300 ? u : 1e-300;
-    v = r.lo + r.span * pow(uc, ic);
-    dv = u >= 1e-300 ? r.span * ic * pow(uc, ic - 1.0) : 0.0;
+    v = r.lo + r.span * cg_pow(uc, ic);
+    dv = u >= 1e-300 ? r.span * ic * cg_pow(uc, ic - 1.0) : 0.0;
   } else {
     const double dist = 2.0 * u - 1.0, ad = fabs(dist);
     const double ac = ad >= 1e-300 ? ad : 1e-300;
     const double sg = dist > 0.0 ? 1.0 : (dist < 0.0 ? -1.0 : 0.0);
-    v = r.lo + r.span * (sg * pow(ac, ic) + 1.0);
-    dv = ad >= 1e-300 ? r.span * ic * pow(ac, ic - 1.0) * 2.0 : 0.0;   // sign(d)^2 = 1
+    v = r.lo + r.span * (sg * cg_pow(ac, ic) + 1.0);
+    dv = ad >= 1e-300 ? r.span * ic * cg_pow(ac, ic - 1.0) * 2.0 : 0.0;   // sign(d)^2 = 1
   }
   *v_out = v; *dv_out = dv;
 }
@@ -219,7 +236,7 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
   double mode[2][5], msum[2];
   for (int m = 0; m < 2; ++m) {
     msum[m] = 0.0;
-    for (int s = 0; s < 5; ++s) { mode[m][s] = pow(s_v[lfo_base[m] + 3 + s], (double)IAS_LFO_EXPONENT_F); msum[m] += mode[m][s]; }
+    for (int s = 0; s < 5; ++s) { mode[m][s] = cg_pow(s_v[lfo_base[m] + 3 + s], (double)IAS_LFO_EXPONENT_F); msum[m] += mode[m][s]; }
     for (int s = 0; s < 5; ++s) mode[m][s] /= msum[m];
   }
   double w[5][4];
@@ -267,7 +284,7 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
     if (tid == 0)
       for (int s = 0; s < 5; ++s) {   // mode = p^e / sum p^e;  d p^e / dp = e p^(e-1)
         const double p = s_v[lfo_base[m] + 3 + s], ex = (double)IAS_LFO_EXPONENT_F;
-        s_gv[lfo_base[m] + 3 + s] += (gm[s] - dot) / msum[m] * ex * pow(p, ex - 1.0);
+        s_gv[lfo_base[m] + 3 + s] += (gm[s] - dot) / msum[m] * ex * cg_pow(p, ex - 1.0);
       }
   }
 

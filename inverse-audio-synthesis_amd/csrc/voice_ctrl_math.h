@@ -152,3 +152,77 @@ IAS_HD float ias_ctl_fmod(float a, float b, double binv) {
   const float m = (float)rem;                                  // exact: a remainder of two floats is a float
   return a < 0.0f ? -m : m;
 }
+
+// ---- the same kernels for fp64 ARGUMENTS (the control-rate backward, csrc/voice_ctrl_grad_kernels.hip, is fp64 throughout:
+// gradients are checked to 1e-5, not bit for bit).  r = m c_i - 1 and a (e + thi) are rounded here, not exact: relative
+// error ~2^-50 instead of ~2^-52.
+// log2 x = hi + lo for a positive NORMAL double
+IAS_HD void ias_ctl_log2_d(double x, const double* tab, double& hi, double& lo) {
+  union { double f; uint64_t u; } b;
+  b.f = x;
+  const int e = (int)(b.u >> 52) - 1023;
+  const int i = (int)((b.u >> 45) & 127u);
+  b.u = (b.u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+  const double* row = tab + 4 * i;
+  const double r = fma(b.f, row[0], -1.0);
+  double p = IAS_CTL_L7;
+  p = fma(p, r, IAS_CTL_L6);
+  p = fma(p, r, IAS_CTL_L5);
+  p = fma(p, r, IAS_CTL_L4);
+  p = fma(p, r, IAS_CTL_L3);
+  p = fma(p, r, IAS_CTL_L2);
+  p = fma(p, r, IAS_CTL_L1);
+  lo = fma(p, r, row[2]);
+  hi = (double)e + row[1];
+}
+// x^a, x a positive normal double, a finite; ln_x (optional) receives ln x from the same logarithm
+IAS_HD double ias_ctl_pow_d(double x, double a, const double* tab, double* ln_x = nullptr) {
+  double hi, lo;
+  ias_ctl_log2_d(x, tab, hi, lo);
+  if (ln_x != nullptr) *ln_x = (hi + lo) * 0.6931471805599453;
+  const double y_hi = a * hi;
+  const double y_lo = fma(a, hi, -y_hi) + a * lo;
+  return ias_ctl_exp2(y_hi, y_lo, tab);
+}
+IAS_HD double ias_ctl_log_d(double x, const double* tab) {
+  double hi, lo;
+  ias_ctl_log2_d(x, tab, hi, lo);
+  return (hi + lo) * 0.6931471805599453;
+}
+// sin x and cos x for |x| < 2^20 (absolute error ~2^-52 max(1, |x| 2^-20))
+IAS_HD void ias_ctl_sincos_d(double x, double& sn, double& cs) {
+  const double kd = rint(x * IAS_CTL_2OPI);
+  double r = fma(-kd, IAS_CTL_PIO2_1, x);
+  r = fma(-kd, IAS_CTL_PIO2_2, r);
+  r = fma(-kd, IAS_CTL_PIO2_3, r);
+  const int k = (int)kd;
+  const double z = r * r;
+  double s = IAS_CTL_S7;
+  s = fma(s, z, IAS_CTL_S6);
+  s = fma(s, z, IAS_CTL_S5);
+  s = fma(s, z, IAS_CTL_S4);
+  s = fma(s, z, IAS_CTL_S3);
+  s = fma(s, z, IAS_CTL_S2);
+  s = fma(s, z, IAS_CTL_S1);
+  s = fma(s * z, r, r);
+  double c = IAS_CTL_C8;
+  c = fma(c, z, IAS_CTL_C7);
+  c = fma(c, z, IAS_CTL_C6);
+  c = fma(c, z, IAS_CTL_C5);
+  c = fma(c, z, IAS_CTL_C4);
+  c = fma(c, z, IAS_CTL_C3);
+  c = fma(c, z, IAS_CTL_C2);
+  c = fma(c * z, z, fma(z, -0.5, 1.0));
+  // (sin, cos)(r + k pi/2)
+  const double s0 = (k & 1) ? c : s, c0 = (k & 1) ? s : c;
+  sn = (k & 2) ? -s0 : s0;
+  cs = ((k + 1) & 2) ? -c0 : c0;
+}
+// x mod b in [0, b) for b > 0, |x| < 2^30 b (not exact: one rounding of x - q b, as fmod's result would be after the += b)
+IAS_HD double ias_ctl_mod_d(double x, double b, double binv) {
+  const double q = floor(x * binv);
+  double m = fma(-q, b, x);
+  if (m < 0.0) m += b;
+  else if (m >= b) m -= b;
+  return m;
+}

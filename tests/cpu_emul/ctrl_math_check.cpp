@@ -94,3 +94,45 @@ extern "C" int ctrl_math_check(int kind, long long n, unsigned long long seed, d
   out[0] = (double)n; out[1] = (double)bad; out[2] = worst; out[3] = (double)outside;
   return 0;
 }
+
+// the fp64-argument forms (control-rate backward): max relative error against libm in units of 2^-53; out[1] counts
+// results that are off by more than 2^-44 relative (sincos: absolute)
+extern "C" int ctrl_math_check_d(int kind, long long n, unsigned long long seed, double* out) {
+  uint64_t s = seed;
+  long long bad = 0;
+  double worst = 0.0;
+  for (long long it = 0; it < n; ++it) {
+    const double u = (double)(splitmix(s) >> 11) * (1.0 / 9007199254740992.0);
+    double err;
+    if (kind == 0) {            // pow (and ln) on (0, 1] x [0.1, 6]
+      const unsigned mode = (unsigned)(splitmix(s) & 3);
+      double x = u;
+      if (mode == 1) x = ldexp(u, -(int)(splitmix(s) % 60));
+      if (mode == 2) x = 1.0 - ldexp(u, -(int)(splitmix(s) % 50));
+      if (!(x >= 1e-300)) x = 1e-300;
+      const double a = 0.1 + 5.9 * (double)u01(s);
+      double ln_x;
+      const double fast = ias_ctl_pow_d(x, a, g_tab, &ln_x), ref = pow(x, a);
+      err = ref > 1e-290 ? fabs(fast - ref) / ref : 0.0;
+      const double lref = log(x);
+      if (x != 1.0) err = fmax(err, fmin(fabs(ln_x - lref) / fabs(lref), fabs(ln_x - lref) * 1e3));
+    } else if (kind == 1) {     // sin / cos up to 2^20
+      const double x = (u - 0.5) * ldexp(1.0, (int)(splitmix(s) % 21));
+      double sn, cs;
+      ias_ctl_sincos_d(x, sn, cs);
+      err = fmax(fabs(sn - sin(x)), fabs(cs - cos(x)));
+    } else {                    // mod 2 pi
+      const double b = 6.283185307179586, x = (u - 0.3) * ldexp(1.0, (int)(splitmix(s) % 21));
+      double ref = fmod(x, b);
+      if (ref < 0.0) ref += b;
+      const double m = ias_ctl_mod_d(x, b, 1.0 / b);
+      err = fmin(fabs(m - ref), b - fabs(m - ref)) / b;
+      if (!(m >= 0.0 && m < b)) err = 1.0;
+    }
+    const double rel = err * 9007199254740992.0;
+    if (rel > worst) worst = rel;
+    if (rel > 512.0) ++bad;
+  }
+  out[0] = (double)n; out[1] = (double)bad; out[2] = worst; out[3] = 0.0;
+  return 0;
+}
