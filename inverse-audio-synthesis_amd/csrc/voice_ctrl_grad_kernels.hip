@@ -59,6 +59,26 @@ __device__ __forceinline__ double cg_block_sum(double v, double* s_red, int tid)
   for (int w = 0; w < CG_THREADS / 64; ++w) t += s_red[w];
   return t;
 }
+// N workgroup sums at once, each in the order of cg_block_sum (butterfly inside a wave, wave order across): two barriers
+// for all of them instead of two per value -- the 45 sums of voice_ctrl_grad_kernel were 90 barriers and 45 dependent
+// shuffle chains, 40 of the kernel's 60 us at configs[4]'s share (round 5).  s_buf: [N][CG_THREADS / 64] doubles.
+template <int N>
+__device__ __forceinline__ void cg_block_sum_n(double (&v)[N], double (*s_buf)[CG_THREADS / 64], int tid) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = cg_wave_sum(v[k]);
+  __syncthreads();
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) s_buf[k][tid >> 6] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double t = 0.0;
+    for (int w = 0; w < CG_THREADS / 64; ++w) t += s_buf[k][w];
+    v[k] = t;
+  }
+}
 // exclusive prefix of one value per thread (thread order); REVERSE: suffix instead.  s_scan: CG_THREADS/64 doubles
 template <bool REVERSE>
 __device__ __forceinline__ double cg_block_excl_scan(double v, double* s_scan, int tid) {
@@ -188,6 +208,7 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
   float* s_genv = reinterpret_cast<float*>(s_garg + 2 * Tc);   // [6][Tc] d loss / d envelope
   __shared__ double s_v[78], s_dv[78], s_gv[78];
   __shared__ double s_red[CG_THREADS / 64], s_scan[CG_THREADS / 64];
+  __shared__ double s_many[36][CG_THREADS / 64];
 
   const int tid = threadIdx.x, b = blockIdx.x;
   const int i_lo = min(tid * ppt, Tc), i_hi = min(i_lo + ppt, Tc);
@@ -273,14 +294,30 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
       s_garg[m * Tc + i] = gmix * ga;
     }
   }
-  for (int o = 0; o < 5; ++o)
-    for (int k = 0; k < 4; ++k) {
-      const double t = cg_block_sum(gw[o][k], s_red, tid);
-      if (tid == 0) s_gv[IAS_P_MOD_MATRIX_ADSR_1_TO_VCO_1_PITCH + k * 5 + o] += t;
-    }
+  {
+    double all[30];
+#pragma unroll
+    for (int o = 0; o < 5; ++o)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) all[o * 4 + k] = gw[o][k];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int s = 0; s < 5; ++s) all[20 + m * 5 + s] = gmode[m][s];
+    cg_block_sum_n<30>(all, s_many, tid);
+#pragma unroll
+    for (int o = 0; o < 5; ++o)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (tid == 0) s_gv[IAS_P_MOD_MATRIX_ADSR_1_TO_VCO_1_PITCH + k * 5 + o] += all[o * 4 + k];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int s = 0; s < 5; ++s) gmode[m][s] = all[20 + m * 5 + s];
+  }
   for (int m = 0; m < 2; ++m) {
     double gm[5], dot = 0.0;
-    for (int s = 0; s < 5; ++s) { gm[s] = cg_block_sum(gmode[m][s], s_red, tid); dot += gm[s] * mode[m][s]; }
+    for (int s = 0; s < 5; ++s) { gm[s] = gmode[m][s]; dot += gm[s] * mode[m][s]; }
     if (tid == 0)
       for (int s = 0; s < 5; ++s) {   // mode = p^e / sum p^e;  d p^e / dp = e p^(e-1)
         const double p = s_v[lfo_base[m] + 3 + s], ex = (double)IAS_LFO_EXPONENT_F;
@@ -302,10 +339,9 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
       gf += gfr; gdep += gfr * renv;
       s_genv[(4 + m) * Tc + i] = (float)(gfr * dep);
     }
-    gphi = cg_block_sum(gphi, s_red, tid);
-    gf = cg_block_sum(gf, s_red, tid);
-    gdep = cg_block_sum(gdep, s_red, tid);
-    if (tid == 0) { s_gv[lfo_base[m]] += gf; s_gv[lfo_base[m] + 1] += gdep; s_gv[lfo_base[m] + 2] += gphi; }
+    double three[3] = {gphi, gf, gdep};
+    cg_block_sum_n<3>(three, s_many, tid);
+    if (tid == 0) { s_gv[lfo_base[m]] += three[1]; s_gv[lfo_base[m] + 1] += three[2]; s_gv[lfo_base[m] + 2] += three[0]; }
   }
   __syncthreads();
 
@@ -340,12 +376,9 @@ __global__ __launch_bounds__(CG_THREADS) void voice_ctrl_grad_kernel(
     //   new_attack = min(attack, note_on)           (ramp A duration, ramp D start)
     //   new_decay  = min(max(note_on - attack, 0), decay)   (ramp D duration)
     //   release                                      (ramp R duration), note_on (ramp R start)
-    const double g_na = cg_block_sum(ga.duration + gd.start, s_red, tid);
-    const double g_nd = cg_block_sum(gd.duration, s_red, tid);
-    const double g_rel = cg_block_sum(gr.duration, s_red, tid);
-    const double g_no_r = cg_block_sum(gr.start, s_red, tid);
-    const double g_alpha = cg_block_sum(ga.alpha + gd.alpha + gr.alpha, s_red, tid);
-    const double g_sus = cg_block_sum(gsus, s_red, tid);
+    double six[6] = {ga.duration + gd.start, gd.duration, gr.duration, gr.start, ga.alpha + gd.alpha + gr.alpha, gsus};
+    cg_block_sum_n<6>(six, s_many, tid);
+    const double g_na = six[0], g_nd = six[1], g_rel = six[2], g_no_r = six[3], g_alpha = six[4], g_sus = six[5];
     if (tid == 0) {
       double g_att = 0.0, g_dec = 0.0, g_no = g_no_r;
       // torch.minimum: the smaller argument takes the gradient, a tie splits it
