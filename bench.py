@@ -1249,6 +1249,14 @@ def main():
         except Exception:  # noqa: BLE001
             return {}
     counters, isa_costs = load_json("counters.json"), load_json("isa_costs.json")
+    # the counters belong to the build they were profiled on: scripts/make_counters.py stores a hash of the three kernels'
+    # sources and flags; when the sources have moved on, the per-pipe fractions are marked stale and no limiter is named
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        from make_counters import kernel_sources_sha16
+        counters_stale = counters.get("_source_sha16") != kernel_sources_sha16(ROOT)
+    except Exception:  # noqa: BLE001
+        counters_stale = True
     N_CU = torch.cuda.get_device_properties(dev).multi_processor_count      # 256 on MI355X
     N_SIMD, CLOCK_MHZ = 4 * N_CU, 2100.0     # shader clock under these kernels: 2.10-2.15 GHz (s_memtime / s_memrealtime)
     # SQ_INSTS_VALU counts wave instructions: the unit is what ONE WAVE INSTRUCTION STREAM covers
@@ -1283,8 +1291,9 @@ def main():
                 if c["SQ_LDS_IDX_ACTIVE"] > 0 and "SQ_LDS_BANK_CONFLICT" in c:
                     k["lds_conflict_frac"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 4)
             k["counters_round"] = counters.get("_round")
+            k["counters_stale"] = counters_stale
         # what the counters say binds the kernel: the largest of its HBM, vector-pipe and LDS-pipe fractions
-        k["bound"] = max(fracs, key=fracs.get)
+        k["bound"] = max(fracs, key=fracs.get) if not counters_stale else "hbm (counters stale: profiled on other sources)"
         kernels[name] = k
     # What the step's pipes are busy for (verdict r04 item 1a): per pipe, the sum over the three kernels of (busy fraction x
     # isolated time).  The kernels are work-conserving neighbours (the step equals the sum of their isolated times), so the

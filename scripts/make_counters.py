@@ -15,6 +15,21 @@ PICK = {"pmc_voice.txt": ("voice_audio_kernel", "voice_audio_kernel"),
         "pmc_pqmf.txt": ("pqmf_analysis_mod_kernel", "pqmf_analysis_mod_kernel")}
 
 
+HASHED = ("voice_kernels.hip", "voice_math.h", "voice_trig.h", "wave_ops.h", "voice_exp2_table.h", "stft2_kernels.hip",
+          "spectral_kernels.hip", "pqmf_kernels.hip", "ias_common.h", "Makefile")
+
+
+def kernel_sources_sha16(root):
+    """sha256 (first 16 hex digits) over the sources and build flags of the three profiled kernels: bench.py recomputes it
+    and marks the imported counters stale when the kernels have changed since they were profiled."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in HASHED:
+        with open(os.path.join(root, "inverse-audio-synthesis_amd", "csrc", f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read() + b"\0")
+    return h.hexdigest()[:16]
+
+
 def parse(path):
     out, cur = {}, None
     for line in open(path):
@@ -33,7 +48,8 @@ def main():
     dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(src, "counters.json")
     res = {"_method": "rocprofv3 --pmc passes of scripts/diag/pmc_voice.sh / pmc_stft.sh / pmc_pqmf.sh (each counter set in a run of its "
                       "own, --kernel-trace only), averages per launch at B = 128 x 176400; SQ_* are sums over all CUs, "
-                      "GRBM_GUI_ACTIVE over the 8 XCDs", "_round": tag}
+                      "GRBM_GUI_ACTIVE over the 8 XCDs", "_round": tag,
+           "_source_sha16": kernel_sources_sha16(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))}
     for fname, (needle, key) in PICK.items():
         p = os.path.join(src, fname)
         if not os.path.exists(p):

@@ -158,8 +158,65 @@ def main():
         xin = randn((6, 40), 12)
         ar[f"{tag}_in"], ar[f"{tag}_out"] = xin.numpy(), m(xin).detach().numpy()
     np.savez_compressed(os.path.join(OUT, "audio_repr_to_params.npz"), **ar)
+    third_party_goldens()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+def third_party_goldens():
+    """The arithmetic of the render and of the spectral losses lives in packages the reference only NAMES
+    (requirements.txt: torchsynth, torchaudio; audio_to_params.py:233: auraloss) and this image does not have: those
+    stages are "parity unpinned" (DESIGN.md section 2).  The moment one of them imports in the build container, this
+    writes the vectors that pin it -- inputs and outputs only, small -- and tests/test_oracle_golden.py /
+    tests/test_third_party_golden_gpu.py start using them; nothing but the .npz travels to the GPU box.
+      voice_torchsynth.npz   Voice(SynthConfig(...))(batch_idx): params, audio (B = 4 x 1 s @ 16 kHz in full; B = 8 x 4 s @
+                             44.1 kHz as a strided subsample + checksums), is_train
+      mel_torchaudio.npz     torchaudio.transforms.MelSpectrogram with conf/config.yaml:52-61's settings on seeded noise
+      mrstft_auraloss.npz    auraloss.freq.MultiResolutionSTFTLoss() on two seeded signals"""
+    made = []
+    try:
+        from torchsynth.config import SynthConfig
+        from torchsynth.synth import Voice
+        vg = {}
+        for tag, B, sr, sec, idx in (("small", 4, 16000, 1.0, 0), ("head", 8, 44100, 4.0, 3)):
+            # batch sizes below torchsynth's reproducibility unit need reproducible=False, as the reference passes it
+            # (vicreg_audio_params.py:86-91 reads cfg.torchsynth.reproducible = False)
+            voice = Voice(synthconfig=SynthConfig(batch_size=B, reproducible=False, sample_rate=sr, buffer_size_seconds=sec))
+            audio, params, is_train = voice(idx)
+            vg[f"{tag}_cfg"] = np.array([B, sr, sec, idx], dtype=np.float64)
+            vg[f"{tag}_params"] = params.detach().cpu().numpy()
+            vg[f"{tag}_is_train"] = is_train.detach().cpu().numpy()
+            a = audio.detach().cpu()
+            if a.numel() <= 1 << 17:
+                vg[f"{tag}_audio"] = a.numpy()
+            else:
+                vg[f"{tag}_audio_sub"] = a.flatten()[::97].numpy()
+                vg[f"{tag}_audio_checks"] = checks(a)
+            vg[f"{tag}_param_names"] = np.array([f"{m}.{n}" for (m, n), _ in voice.get_parameters().items()])
+        np.savez_compressed(os.path.join(OUT, "voice_torchsynth.npz"), **vg)
+        made.append("voice_torchsynth.npz")
+    except ImportError as e:
+        print(f"[make_golden] torchsynth not importable ({e}): the Voice stays parity-unpinned")
+    try:
+        import torchaudio
+        x = randn((3, 20000), 301) * 0.5
+        mel = torchaudio.transforms.MelSpectrogram(sample_rate=44100, n_fft=1024, win_length=None, hop_length=512, center=True,
+                                                   pad_mode="reflect", power=2.0, norm="slaney", n_mels=128, mel_scale="htk")
+        np.savez_compressed(os.path.join(OUT, "mel_torchaudio.npz"), seed=np.array(301), scale=np.array(0.5),
+                            shape=np.array(x.shape), mel=mel(x).numpy(), fb=mel.mel_scale.fb.numpy())
+        made.append("mel_torchaudio.npz")
+    except ImportError as e:
+        print(f"[make_golden] torchaudio not importable ({e}): the mel spectrogram stays parity-unpinned")
+    try:
+        import auraloss
+        a, b = randn((2, 1, 20000), 302) * 0.1, randn((2, 1, 20000), 303) * 0.1
+        loss = auraloss.freq.MultiResolutionSTFTLoss()(a, b)
+        np.savez_compressed(os.path.join(OUT, "mrstft_auraloss.npz"), seeds=np.array([302, 303]), scale=np.array(0.1),
+                            shape=np.array(a.shape), loss=np.array(float(loss)))
+        made.append("mrstft_auraloss.npz")
+    except ImportError as e:
+        print(f"[make_golden] auraloss not importable ({e}): the MR-STFT loss stays parity-unpinned")
+    return made
 
 
 if __name__ == "__main__":
