@@ -390,7 +390,7 @@ def secondary_legs(args, dev):
             rf = r["roofline"]
             leg["roofline"] = {k: rf[k] for k in ("kernel", "form", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
                                                   "frac_nominal", "flops_executed", "algorithmic_bytes_per_step", "contraction",
-                                                  "dxd") if k in rf}
+                                                  "dxd", "pipes") if k in rf}
         except Exception as e:  # noqa: BLE001 -- a failing leg must not take the headline line down
             leg = {"error": f"{type(e).__name__}: {e}"}
         leg["wall_s"] = round(time.perf_counter() - t0, 2)
@@ -714,6 +714,50 @@ def pmc_traffic_of(kname):
     return hits[0].get("hbm_bytes_per_launch") if hits else None
 
 
+def gradstep_pipes(step_ms, B):
+    """What the gradient step's pipes are busy for, from profiles/counters_gradstep.json (scripts/diag/pmc_gradstep.sh: SQ
+    counters per kernel and launch at B = 64) and profiles/isa_costs.json (static clocks per VALU instruction): per kernel
+    the vector-pipe and LDS-pipe time it needs on the whole chip, and their sums as fractions of THIS run's step -- the
+    evidence behind "the step is bound by the transforms' vector work, not by HBM" (verdict r04 item 6).  None when the
+    counters are absent, were taken at another batch, or on other sources."""
+    try:
+        c = json.load(open(os.path.join(ROOT, "profiles", "counters_gradstep.json")))
+        costs = json.load(open(os.path.join(ROOT, "profiles", "isa_costs.json")))
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from make_counters import kernel_sources_sha16
+        stale = c.get("_source_sha16") != kernel_sources_sha16(ROOT)
+    except Exception:  # noqa: BLE001
+        return None
+    if B != 64:
+        return None
+    n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    clk_hz = 2.1e9
+    rows, valu_us, lds_us = {}, 0.0, 0.0
+    for k, v in c.items():
+        if not isinstance(v, dict) or "SQ_INSTS_VALU" not in v:
+            continue
+        cost = next((x["valu_clk_per_inst"] for kk, x in costs.items() if isinstance(x, dict) and kk.split("<")[0] == k.split("<")[0]
+                     and (kk == k or "<" not in kk)), None)
+        cost = cost if cost is not None else next((x["valu_clk_per_inst"] for kk, x in costs.items()
+                                                   if isinstance(x, dict) and kk.split("<")[0] == k.split("<")[0]), 3.5)
+        v_us = v["SQ_INSTS_VALU"] * cost / (4 * n_cu) / clk_hz * 1e6
+        l_us = v.get("SQ_LDS_IDX_ACTIVE", 0.0) / n_cu / clk_hz * 1e6
+        valu_us += v_us
+        lds_us += l_us
+        if v_us + l_us >= 5.0:
+            rows[k] = {"valu_us": round(v_us, 1), "lds_us": round(l_us, 1), "in_step_avg_us": round(v.get("avg_us", 0.0), 1),
+                       "valu_insts": int(v["SQ_INSTS_VALU"]), "valu_clk_per_inst": cost,
+                       "lds_conflict_frac": round(v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"], 3)
+                       if v.get("SQ_LDS_IDX_ACTIVE") and "SQ_LDS_BANK_CONFLICT" in v else None}
+    return {"valu_busy_us_per_step": round(valu_us, 1), "lds_busy_us_per_step": round(lds_us, 1),
+            "valu_busy_frac_of_step": round(valu_us / (step_ms * 1e3), 4), "lds_busy_frac_of_step": round(lds_us / (step_ms * 1e3), 4),
+            "counters_round": c.get("_round"), "counters_stale": stale,
+            "note": "per kernel and launch: SQ_INSTS_VALU x static clocks per instruction / (4 SIMDs x CUs) and SQ_LDS_IDX_ACTIVE / CUs, "
+                    "at 2.1 GHz = the time the kernel needs of the whole chip's vector / LDS pipes; sums over one step against this "
+                    "run's step time.  Kernels below 5 us of pipe time are in the sums but not listed",
+            "kernels": rows}
+
+
 def run_gradstep(args, rank, world, dev):
     """BASELINE configs[4], one GPU's share (global batch 512 / 8): params -> Voice render -> {3-resolution MR-STFT loss,
     64-band PQMF sub-band L1} -> gradient w.r.t. the 78 normalised parameters, all HIP (render and its backward,
@@ -786,6 +830,7 @@ def run_gradstep(args, rank, world, dev):
     bytes_per_sample = 8 + 8 + 3 * 4 + 4 * bins + 32 + 8
     algo = bytes_per_sample * B * T
     ms = elapsed / args.steps * 1e3
+    pipes = gradstep_pipes(ms, B)
     return {
         "metric": "audio-seconds rendered+lossed+differentiated/sec, BASELINE configs[4] per-GPU share: 64-band PQMF + "
                   "3-resolution STFT loss, forward + backward to the 78 parameters",
@@ -801,7 +846,7 @@ def run_gradstep(args, rank, world, dev):
                                       "backward": round(phases[2], 4)}},
         "roofline": {"kernel": "whole gradient step (no single dominant kernel: ~20 launches)", "bound": "hbm",
                      "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "pipes": pipes,
                      "algorithmic_bytes_per_step": int(algo), "bytes_per_sample": round(bytes_per_sample, 1)},
     }
 
