@@ -733,19 +733,26 @@ def gradstep_pipes(step_ms, B):
     n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
     clk_hz = 2.1e9
     rows, valu_us, lds_us = {}, 0.0, 0.0
+    # launches per step: the profiled run also computed the loss targets once (their transforms are not part of a step)
+    render_calls = next((v.get("calls", 0) for k, v in c.items() if isinstance(v, dict) and k.startswith("voice_audio_kernel")), 0)
+    n_steps = max(render_calls - 1, 1)
     for k, v in c.items():
         if not isinstance(v, dict) or "SQ_INSTS_VALU" not in v:
+            continue
+        per_step = round(v.get("calls", 0) / n_steps)
+        if per_step < 1:
             continue
         cost = next((x["valu_clk_per_inst"] for kk, x in costs.items() if isinstance(x, dict) and kk.split("<")[0] == k.split("<")[0]
                      and (kk == k or "<" not in kk)), None)
         cost = cost if cost is not None else next((x["valu_clk_per_inst"] for kk, x in costs.items()
                                                    if isinstance(x, dict) and kk.split("<")[0] == k.split("<")[0]), 3.5)
-        v_us = v["SQ_INSTS_VALU"] * cost / (4 * n_cu) / clk_hz * 1e6
-        l_us = v.get("SQ_LDS_IDX_ACTIVE", 0.0) / n_cu / clk_hz * 1e6
+        v_us = per_step * v["SQ_INSTS_VALU"] * cost / (4 * n_cu) / clk_hz * 1e6
+        l_us = per_step * v.get("SQ_LDS_IDX_ACTIVE", 0.0) / n_cu / clk_hz * 1e6
         valu_us += v_us
         lds_us += l_us
         if v_us + l_us >= 5.0:
-            rows[k] = {"valu_us": round(v_us, 1), "lds_us": round(l_us, 1), "in_step_avg_us": round(v.get("avg_us", 0.0), 1),
+            rows[k] = {"launches_per_step": per_step, "valu_us": round(v_us, 1), "lds_us": round(l_us, 1),
+                       "in_step_avg_us": round(v.get("avg_us", 0.0), 1),
                        "valu_insts": int(v["SQ_INSTS_VALU"]), "valu_clk_per_inst": cost,
                        "lds_conflict_frac": round(v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"], 3)
                        if v.get("SQ_LDS_IDX_ACTIVE") and "SQ_LDS_BANK_CONFLICT" in v else None}
