@@ -473,14 +473,16 @@ class ParallelLossSum(nn.Module):
         super().__init__()
         self.losses = nn.ModuleList(losses)
         self.parallel = True
+        self.share_from = 0       # which of the first term's side streams the extra terms borrow (-1: streams of their own)
 
     def _streams(self, device):
         # A first term with side streams of its own (MultiResolutionSTFTLoss: one per resolution) lends them: the extra
         # terms then queue behind its SHORTER resolutions, forward and backward, instead of opening more branches than the
         # device has hardware queues (a fifth branch of the captured step was run behind the longest one).
         first = self.losses[0]
-        if hasattr(first, "_streams") and getattr(first, "parallel", False):
+        if self.share_from >= 0 and hasattr(first, "_streams") and getattr(first, "parallel", False):
             own = list(first._streams(device))
+            own = own[self.share_from:] + own[:self.share_from]
             if len(own) >= len(self.losses) - 1:
                 return own[:len(self.losses) - 1]
         pool = self.__dict__.setdefault("_side_streams", {})
