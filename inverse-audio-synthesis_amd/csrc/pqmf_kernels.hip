@@ -966,7 +966,7 @@ static int pqmf_resident_blocks() {
 // output scale (not bit for bit; the reference's conv1d has no defined summation order either).
 // A lane owns 4 consecutive frames: its 72-sample window comes out of the wave's LDS staging as 18 aligned 16-byte
 // reads at a 48-byte lane stride (conflict-free), the 52 signed prototype taps sit in scalar registers.
-#define PQD_FPL 4                       // frames per lane
+#define PQD_FPL 4                       // frames per lane (the asm operand list of the stream form is written for 4)
 #define PQD_WF (64 * PQD_FPL)           // frames per wave tile
 #define PQD_STAGE (3 * PQD_WF + 64)     // staged samples per wave tile (3 per frame + 60 of halo, rounded up)
 #define PQD_NLOAD ((PQD_STAGE + 63) / 64)
@@ -998,30 +998,49 @@ extern "C" int ias_pqmf_build_modtab(const float* H_host, int N, int K, float* o
   return IAS_OK;
 }
 
-template <bool NORM>
-#ifndef IAS_PQMF_MOD_MINW
-#define IAS_PQMF_MOD_MINW 4   // waves per SIMD the kernel is compiled for (register budget 512 / MINW)
-#endif
-__global__ __launch_bounds__(PQ_THREADS, IAS_PQMF_MOD_MINW) void pqmf_analysis_mod_kernel(
-    const float* __restrict__ x, const float* __restrict__ modtab, float* __restrict__ z, const float* __restrict__ mean,
-    const float* __restrict__ stdv, const float* __restrict__ rowpeak, int T, int L, int tiles_x, int ntiles, int zvec) {
-  __shared__ __attribute__((aligned(16))) float s_stage[PQ_THREADS / 64][PQD_STAGE];
+// Two register budgets of ONE body (same arithmetic, same order of every sum: the same bits).
+//   WINDOW (rounds 3-4): the lane's 72-sample window is read into registers first, then the 20 sums run over it: 96 VGPRs.
+//   STREAM (round 5): the 18 quads are consumed as they arrive -- each sample goes straight into the sums of the (up to four)
+//   frames it belongs to -- so only the 20 accumulators, a few quads and the next tile's 13 prefetched values are live:
+//   <= 56 VGPRs, which is what a SIMD has left beside three waves of the persistent render (csrc/voice_ctrl_kernels.hip has
+//   the same story).  The step's PQMF is HBM-bound on its own (0.74 of 8 TB/s) while the render is vector-bound and uses a
+//   quarter of the bandwidth: a PQMF wave that fits beside the render's runs in its gaps instead of after it.
+template <bool NORM, bool STREAM>
+__device__ __forceinline__ void pqmf_mod_body(const float* __restrict__ x, const float* __restrict__ modtab, float* __restrict__ z,
+                                              const float* __restrict__ mean, const float* __restrict__ stdv,
+                                              const float* __restrict__ rowpeak, int T, int L, int tiles_x, int ntiles, int zvec,
+                                              float (*s_stage)[PQD_STAGE]) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* st = s_stage[wave];
   const int nwaves = gridDim.x * (PQ_THREADS / 64);
   int tile = blockIdx.x * (PQ_THREADS / 64) + wave;
 
-  // the staged samples of wave tile `t`: x[b][3 f0 - 31 + q], q = lane + 64 i, zero outside the row
+  // the staged samples of wave tile `t`: x[b][3 f0 - 31 + q], q = lane + 64 i, zero outside the row.
+  // STREAM: through a buffer descriptor of the ROW (num_records = 4 T bytes): an index beyond T - 1 is out of the buffer's
+  // range and reads as 0 in hardware -- no per-load index, predicate and select (13 x 3 registers that the window form
+  // keeps alive across the tile's arithmetic), one byte offset and immediate strides.  A row's first tile (indices below
+  // 0) takes the predicated loads.
   float nx[PQD_NLOAD];
   auto fetch = [&](int t) {
     const int b = t / tiles_x, ft = t - b * tiles_x;
     const float* xrow = x + (size_t)b * T;
     const int base = 3 * PQD_WF * ft - 31;
+    if (STREAM && ft > 0) {
+      // (every tile but a row's first: base >= 0, so the byte offset is non-negative; the hardware compares
+      // vgpr offset + immediate offset with num_records, which is why the stride 256 i goes into the offset and not
+      // into the scalar offset operand, which the range check ignores)
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xrow), 0, 4 * T, 0x00020000);
+      const int voff = 4 * (base + lane);
 #pragma unroll
-    for (int i = 0; i < PQD_NLOAD; ++i) {
-      const int idx = base + lane + 64 * i;
-      nx[i] = (idx >= 0 && idx < T) ? xrow[idx] : 0.0f;
+      for (int i = 0; i < PQD_NLOAD; ++i)
+        nx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 256 * i, 0, 0));
+    } else {
+#pragma unroll
+      for (int i = 0; i < PQD_NLOAD; ++i) {
+        const int idx = base + lane + 64 * i;
+        nx[i] = (idx >= 0 && idx < T) ? xrow[idx] : 0.0f;
+      }
     }
   };
   if (tile < ntiles) fetch(tile);
@@ -1034,33 +1053,67 @@ __global__ __launch_bounds__(PQ_THREADS, IAS_PQMF_MOD_MINW) void pqmf_analysis_m
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // the lane's window: samples 12 lane .. 12 lane + 71 of the stage
-    float w[72];
+    // v[i][r5] = sum_t a[r5][t] w[3 i + r + 6 t], w = samples 12 lane .. 12 lane + 71 of the stage
+    float v[PQD_FPL][5];
+    constexpr int rs[5] = {0, 1, 3, 4, 5};
+    if (!STREAM) {
+      float w[72];
 #pragma unroll
-    for (int i = 0; i < 18; ++i) {
-      const pq_f32x4 q = *reinterpret_cast<const pq_f32x4*>(st + 12 * lane + 4 * i);
-      w[4 * i] = q[0]; w[4 * i + 1] = q[1]; w[4 * i + 2] = q[2]; w[4 * i + 3] = q[3];
+      for (int i = 0; i < 18; ++i) {
+        const pq_f32x4 q = *reinterpret_cast<const pq_f32x4*>(st + 12 * lane + 4 * i);
+        w[4 * i] = q[0]; w[4 * i + 1] = q[1]; w[4 * i + 2] = q[2]; w[4 * i + 3] = q[3];
+      }
+#pragma unroll
+      for (int i = 0; i < PQD_FPL; ++i)
+#pragma unroll
+        for (int r5 = 0; r5 < 5; ++r5) {
+          float acc = 0.0f;
+#pragma unroll
+          for (int t = 0; rs[r5] + 6 * t < 63; ++t) acc = fmaf(modtab[r5 * 11 + t], w[3 * i + rs[r5] + 6 * t], acc);
+          v[i][r5] = acc;
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PQD_FPL; ++i)
+#pragma unroll
+        for (int r5 = 0; r5 < 5; ++r5) v[i][r5] = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 18; ++c) {
+        const pq_f32x4 q = *reinterpret_cast<const pq_f32x4*>(st + 12 * lane + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < PQD_FPL; ++i) {
+            const int j = 4 * c + e - 3 * i;                 // tap of frame i that meets window sample 4 c + e
+            if (j >= 0 && j < 63 && j % 6 != 2) {
+              const int r = j % 6, r5 = r < 2 ? r : r - 1, t = j / 6;
+              v[i][r5] = fmaf(modtab[r5 * 11 + t], q[e], v[i][r5]);   // t ascends with c for every (i, r5): the order above
+            }
+          }
+        // at most a few quads in flight -- the point is the register count.  A sched_barrier alone orders the LDS reads but
+        // lets the instruction selector sink every multiply-add below the last of them (all 72 samples live again): the
+        // empty asm takes the 20 sums as in / out operands, so what feeds them is complete before it and what follows
+        // starts behind it.
+        if ((c & 1) == 1) {
+          asm volatile("" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]), "+v"(v[0][4]),
+                            "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]), "+v"(v[1][3]), "+v"(v[1][4]),
+                            "+v"(v[2][0]), "+v"(v[2][1]), "+v"(v[2][2]), "+v"(v[2][3]), "+v"(v[2][4]),
+                            "+v"(v[3][0]), "+v"(v[3][1]), "+v"(v[3][2]), "+v"(v[3][3]), "+v"(v[3][4]) :: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                     // every read precedes the next tile's staging stores
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const float rsc = pqmf_row_scale(rowpeak, b);
     float o[3][PQD_FPL];
-    constexpr int rs[5] = {0, 1, 3, 4, 5};
 #pragma unroll
     for (int i = 0; i < PQD_FPL; ++i) {
-      float v[5];
-#pragma unroll
-      for (int r5 = 0; r5 < 5; ++r5) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int t = 0; rs[r5] + 6 * t < 63; ++t) acc = fmaf(modtab[r5 * 11 + t], w[3 * i + rs[r5] + 6 * t], acc);
-        v[r5] = acc;
-      }
-      const float d31 = v[2] - v[1];                      // v_3 - v_1
-      const float A = 0.86602540378443865f * (v[3] - v[0]);
-      const float C = fmaf(0.5f, d31, v[4]);
-      const float z0 = A + C, z1 = d31 - v[4], z2 = A - C;
+      const float d31 = v[i][2] - v[i][1];                // v_3 - v_1
+      const float A = 0.86602540378443865f * (v[i][3] - v[i][0]);
+      const float C = fmaf(0.5f, d31, v[i][4]);
+      const float z0 = A + C, z1 = d31 - v[i][4], z2 = A - C;
       o[0][i] = pqmf_finish(z0, rsc, NORM, NORM ? mean[0] : 0.0f, NORM ? stdv[0] : 1.0f);
       o[1][i] = pqmf_finish(z1, rsc, NORM, NORM ? mean[1] : 0.0f, NORM ? stdv[1] : 1.0f);
       o[2][i] = pqmf_finish(z2, rsc, NORM, NORM ? mean[2] : 0.0f, NORM ? stdv[2] : 1.0f);
@@ -1076,6 +1129,25 @@ __global__ __launch_bounds__(PQ_THREADS, IAS_PQMF_MOD_MINW) void pqmf_analysis_m
       }
     }
   }
+}
+
+#ifndef IAS_PQMF_MOD_MINW
+#define IAS_PQMF_MOD_MINW 4   // waves per SIMD the window form is compiled for (register budget 512 / MINW)
+#endif
+template <bool NORM>
+__global__ __launch_bounds__(PQ_THREADS, IAS_PQMF_MOD_MINW) void pqmf_analysis_mod_kernel(
+    const float* __restrict__ x, const float* __restrict__ modtab, float* __restrict__ z, const float* __restrict__ mean,
+    const float* __restrict__ stdv, const float* __restrict__ rowpeak, int T, int L, int tiles_x, int ntiles, int zvec) {
+  __shared__ __attribute__((aligned(16))) float s_stage[PQ_THREADS / 64][PQD_STAGE];
+  pqmf_mod_body<NORM, false>(x, modtab, z, mean, stdv, rowpeak, T, L, tiles_x, ntiles, zvec, s_stage);
+}
+// (amdgpu_num_vgpr(28): on gfx90a+ the backend doubles the value for the unified register file -> a budget of 56)
+template <bool NORM>
+__global__ __launch_bounds__(PQ_THREADS) __attribute__((amdgpu_num_vgpr(28))) void pqmf_analysis_mods_kernel(
+    const float* __restrict__ x, const float* __restrict__ modtab, float* __restrict__ z, const float* __restrict__ mean,
+    const float* __restrict__ stdv, const float* __restrict__ rowpeak, int T, int L, int tiles_x, int ntiles, int zvec) {
+  __shared__ __attribute__((aligned(16))) float s_stage[PQ_THREADS / 64][PQD_STAGE];
+  pqmf_mod_body<NORM, true>(x, modtab, z, mean, stdv, rowpeak, T, L, tiles_x, ntiles, zvec, s_stage);
 }
 
 // Floats of the transposed tap table (whole polyphase steps, whole pairs); 0 when (N, K) has no fast path.
@@ -1132,9 +1204,18 @@ extern "C" int ias_pqmf_analysis(const float* x, const float* H, const float* pa
     const long long wgs = (ntiles + PQ_THREADS / 64 - 1) / (PQ_THREADS / 64);
     const long long res = pqmf_resident_blocks();
     const int grid = (int)(wgs < res ? wgs : res);
-    if (mean) hipLaunchKernelGGL(pqmf_analysis_mod_kernel<true>, dim3(grid), dim3(PQ_THREADS), 0, stream, x, modtab, z, mean,
-                                 stdv, rowpeak, T, L, tiles_x, (int)ntiles, zvec);
-    else hipLaunchKernelGGL(pqmf_analysis_mod_kernel<false>, dim3(grid), dim3(PQ_THREADS), 0, stream, x, modtab, z, mean,
+    // (diagnostic library: IAS_PQMF_MOD_WINDOW=1 takes the 96-register window form of rounds 3-4; same bits)
+    const bool window = ias_diag_env("IAS_PQMF_MOD_WINDOW") != nullptr;
+    if (window) {
+#ifdef IAS_DIAG
+      if (mean) hipLaunchKernelGGL(pqmf_analysis_mod_kernel<true>, dim3(grid), dim3(PQ_THREADS), 0, stream, x, modtab, z, mean,
+                                   stdv, rowpeak, T, L, tiles_x, (int)ntiles, zvec);
+      else hipLaunchKernelGGL(pqmf_analysis_mod_kernel<false>, dim3(grid), dim3(PQ_THREADS), 0, stream, x, modtab, z, mean,
+                              stdv, rowpeak, T, L, tiles_x, (int)ntiles, zvec);
+#endif
+    } else if (mean) hipLaunchKernelGGL(pqmf_analysis_mods_kernel<true>, dim3(grid), dim3(PQ_THREADS), 0, stream, x, modtab, z, mean,
+                                        stdv, rowpeak, T, L, tiles_x, (int)ntiles, zvec);
+    else hipLaunchKernelGGL(pqmf_analysis_mods_kernel<false>, dim3(grid), dim3(PQ_THREADS), 0, stream, x, modtab, z, mean,
                             stdv, rowpeak, T, L, tiles_x, (int)ntiles, zvec);
   } else if (!force_valu && K == 63 && (N == 3 || N == 64) && T >= 4 && (T & 3) == 0 && ((uintptr_t)x & 15) == 0 &&
       (long long)L * N + 4 * K < 0x7fffffffLL) {
