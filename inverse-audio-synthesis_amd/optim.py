@@ -74,6 +74,8 @@ class LARS(torch.optim.Optimizer):
         scheduler's learning rate before each replay -- would be overwritten by the replay itself."""
         table = self.__dict__.setdefault("_hip_hyper", {})
         h = table.get(gi)
+        if h is not None and h["dev"].device != dev:      # the module moved to another device after its first step
+            h = None
         if h is None:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("LARS: the first fused step of a parameter group cannot run inside a hipGraph capture "
