@@ -1280,7 +1280,7 @@ def main():
     ctrl_iso_ms = isolated_ms(lambda: voice.render_control(workspaces[0]))
     bps = {"render": RENDER_BYTES_PER_SAMPLE, "pqmf": 8.0, "stft": 4.0 + 4.0 * plan.n_out / plan.hop_length}
     knames = {"render": "voice_audio_kernel",
-              "pqmf": "pqmf_analysis_mod_kernel",
+              "pqmf": "pqmf_analysis_mods_kernel",
               "stft": "stft2_kernel<8, true, 1, 1>" if plan.n_fft == 1024 else "stft_kernel"}
     table = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")

@@ -21,7 +21,7 @@ BASE = ["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx
 KERNELS = [  # (json key = the name bench.py / rocprofv3 use, source, extra flags as in csrc/Makefile, mangled-name substring)
     ("voice_audio_kernel", "voice_kernels.hip", ["-ffp-contract=off", "-fno-slp-vectorize"], "voice_audio_kernelILi0ELb1E"),
     ("stft2_kernel<8, true, 1, 1>", "spectral_kernels.hip", ["-fno-slp-vectorize"], "stft2_kernelILi8ELb1ELi1ELi1E"),
-    ("pqmf_analysis_mod_kernel", "pqmf_kernels.hip", ["-fno-slp-vectorize"], "pqmf_analysis_mod_kernelILb0E"),
+    ("pqmf_analysis_mods_kernel", "pqmf_kernels.hip", ["-fno-slp-vectorize"], "pqmf_analysis_mods_kernelILb0E"),
     # the configs[4] gradient step's transform kernels and the Voice backward (legs.gradstep.roofline.pipes)
     ("stft2_kernel<8, false, 2, 1>", "spectral_kernels.hip", ["-fno-slp-vectorize"], "stft2_kernelILi8ELb0ELi2ELi1E"),
     ("stft2_kernel<8, false, 2, 2>", "spectral_kernels.hip", ["-fno-slp-vectorize"], "stft2_kernelILi8ELb0ELi2ELi2E"),

@@ -12,7 +12,7 @@ WANT = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "
         "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")
 PICK = {"pmc_voice.txt": ("voice_audio_kernel", "voice_audio_kernel"),
         "pmc_stft.txt": ("stft2_kernel<8, true, 1, 1>", "stft2_kernel<8, true, 1, 1>"),
-        "pmc_pqmf.txt": ("pqmf_analysis_mod_kernel", "pqmf_analysis_mod_kernel")}
+        "pmc_pqmf.txt": ("pqmf_analysis_mods_kernel", "pqmf_analysis_mods_kernel")}
 
 
 HASHED = ("voice_kernels.hip", "voice_math.h", "voice_trig.h", "wave_ops.h", "voice_exp2_table.h", "stft2_kernels.hip",
