@@ -632,7 +632,7 @@ def pretrain_ddp_leg(dev, rank, world, B=128, steps=5, reps=3):
 def run_leg_child(args):
     """One rank of the N > 1 legs (started by `multi_gpu_legs`): a process group of its own with a bounded timeout, so that
     a wedged collective ends THIS process and becomes the leg's `error` -- the headline line of the parent is already
-    computed.  Rank 0 prints {"vicreg_gather": ..., "pretrain_ddp": ...} as one JSON line."""
+    computed.  Rank 0 prints one JSON line per leg, {"leg": name, "result": {...}}, as soon as the leg is done."""
     import datetime
     world, rank, local_rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("IAS_BENCH_BACKEND", "nccl")
@@ -645,7 +645,6 @@ def run_leg_child(args):
     COLL_DEV = dev if backend == "nccl" else torch.device("cpu")
     from inverse_audio_synthesis_amd import _lib
     _lib.load()
-    legs = {}
     for name, fn in (("vicreg_gather", lambda: vicreg_gather_leg(args, rank, world, dev)),
                      ("pretrain_ddp", lambda: pretrain_ddp_leg(dev, rank, world))):
         t0 = time.perf_counter()
@@ -654,11 +653,12 @@ def run_leg_child(args):
         except Exception as e:  # noqa: BLE001
             leg = {"error": f"{type(e).__name__}: {e}"[:500]}
         leg["wall_s"] = round(time.perf_counter() - t0, 2)
-        legs[name] = leg
+        if rank == 0:
+            # one line per leg, as soon as it is done: a later leg that takes the process down (a collective that expires
+            # ends the process, it does not raise) does not take the finished ones with it
+            print(json.dumps({"leg": name, "result": leg}), flush=True)
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
-    if rank == 0:
-        print(json.dumps(legs), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -685,16 +685,22 @@ def multi_gpu_legs(args, rank, world, local_rank):
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=LEG_WALL_TIMEOUT_S)
         rc, out, err = r.returncode, r.stdout, r.stderr
-    except subprocess.TimeoutExpired:
-        rc, out, err = -9, "", f"no result within {LEG_WALL_TIMEOUT_S} s"
+    except subprocess.TimeoutExpired as e:
+        so = e.stdout or ""
+        rc, out, err = -9, so.decode(errors="replace") if isinstance(so, bytes) else so, f"no result within {LEG_WALL_TIMEOUT_S} s"
     legs = None
     if rank == 0:
-        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
-        if rc == 0 and lines:
-            legs = json.loads(lines[-1])
-        else:
-            msg = f"legs child of rank 0 ended with code {rc}: {(err or '')[-400:]}"
-            legs = {"vicreg_gather": {"error": msg}, "pretrain_ddp": {"error": msg}}
+        legs = {}
+        for ln in out.splitlines():
+            if ln.startswith('{"leg"'):
+                try:
+                    rec = json.loads(ln)
+                    legs[rec["leg"]] = rec["result"]
+                except ValueError:
+                    pass
+        for name in ("vicreg_gather", "pretrain_ddp"):
+            if name not in legs:
+                legs[name] = {"error": f"legs child of rank 0 ended with code {rc} before this leg reported: {(err or '')[-400:]}"}
         legs["wall_s"] = round(time.perf_counter() - t0, 2)
     ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int64, device=COLL_DEV)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
