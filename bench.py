@@ -988,6 +988,9 @@ def main():
     # worse -- so it is off; kept as a knob)
     preclear = os.environ.get("IAS_BENCH_PRECLEAR", "0") == "1" and not args.no_pipeline
     reduce_aside = (not args.no_pipeline) and os.environ.get("IAS_BENCH_REDUCE_INLINE") != "1"   # (diag knob)
+    # IAS_BENCH_EXTRA_FILL=n (diagnostics): n more 90 KB memset nodes in front of every render, like the one it starts with
+    extra_fill = int(os.environ.get("IAS_BENCH_EXTRA_FILL", "0"))
+    dummy_fill = torch.zeros(90 * 1024, dtype=torch.uint8, device=dev)
 
     warmed = {}
 
@@ -1068,6 +1071,8 @@ def main():
             if early_ctrl and i + depth < k:
                 ctrl_events[i + depth] = issue_control(i + depth)
             # normalize_if_clipping is folded into the two consumers (row peaks read in place from the workspace)
+            for _ in range(extra_fill):            # (diagnostics: is the render queue the step's critical chain?)
+                dummy_fill.zero_()
             audio = voice.render_audio(workspaces[buf], out=audio_bufs[buf], on_stage=hook, normalize=False,
                                        precleared=preclear)
             peaks = voice.peaks_view(workspaces[buf])
