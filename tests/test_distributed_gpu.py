@@ -193,3 +193,33 @@ def test_captured_ddp_step_equals_the_eager_loop_on_a_one_rank_rccl_group(lib, d
     assert he[0]["vicreg/train/loss"] != he[-1]["vicreg/train/loss"]
     for k, v in results["false"][1].items():
         assert torch.equal(v, results["true"][1][k]), k
+
+
+def test_gathered_loss_step_captures_with_its_rccl_collectives(lib, dev, nccl_group):
+    """What `bench.py --gpus N`'s legs.vicreg_gather replays at N > 1: global_batch_loss forward + backward -- the RCCL
+    all_gather_into_tensor and reduce_scatter_tensor included -- captured into one hipGraph (capture mode thread_local, as the
+    Trainer and bench.py use it) on the one-rank RCCL group with gather="always", K steps per graph, against the eager
+    steps: same four numbers, same gradients, bit for bit."""
+    from inverse_audio_synthesis_amd.vicreg import global_batch_loss
+    B, D, K = 128, 1024, 3
+    x = torch.randn(B, D, generator=torch.Generator().manual_seed(5)).to(dev).requires_grad_()
+    y = torch.randn(B, D, generator=torch.Generator().manual_seed(6)).to(dev).requires_grad_()
+    state = {}
+
+    def step():
+        out = global_batch_loss(x, y, B, 25.0, 25.0, 1.0, gather="always")
+        gx, gy = torch.autograd.grad(out[0], (x, y))
+        state["out"], state["g"] = [o.detach() for o in out], (gx, gy)
+
+    step(); step()
+    torch.cuda.synchronize()
+    eager = ([float(o) for o in state["out"]], state["g"][0].clone(), state["g"][1].clone())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        for _ in range(K):
+            step()
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert [float(o) for o in state["out"]] == eager[0]
+    assert torch.equal(state["g"][0], eager[1]) and torch.equal(state["g"][1], eager[2])
