@@ -677,7 +677,10 @@ def multi_gpu_legs(args, rank, world, local_rank):
             sk.bind(("127.0.0.1", 0))
             port[0] = sk.getsockname()[1]
     dist.broadcast(port, 0)
-    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+    # (under torch.distributed.run the environment says TORCHELASTIC_USE_AGENT_STORE=True: every rank, rank 0 included, would
+    # look for the launcher's store on the new port instead of rank 0 hosting one -- the children get a plain env:// set-up)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(int(port.item())))
     torch.cuda.empty_cache()
     cmd = [sys.executable, os.path.abspath(__file__), "--leg-child", "--gpus", str(world)]

@@ -14,12 +14,20 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run_bench(extra, timeout=900, legs=False):
+def _run_bench(extra, timeout=900, legs=False, torchrun=False):
     env = dict(os.environ, IAS_BENCH_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-                        "--no-cpu-baseline", "--replays", "5"] + ([] if legs else ["--no-legs"]) + extra, env=env,
+    head = [sys.executable, os.path.join(ROOT, "bench.py")]
+    if torchrun:        # the driver's launch: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), os.path.join(ROOT, "bench.py")]
+    r = subprocess.run(head + ["--gpus", "2", "--steps", "5", "--warmup", "2",
+                               "--no-cpu-baseline", "--replays", "5"] + ([] if legs else ["--no-legs"]) + extra, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
