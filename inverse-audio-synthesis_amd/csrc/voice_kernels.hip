@@ -172,6 +172,7 @@ __global__ __launch_bounds__(VOICE_THREADS) void voice_modmix_kernel(
   }
 }
 
+#ifdef IAS_DIAG   // measured slower in the step than the three slim kernels: diagnostic library only
 // ---- the whole control pass of a voice in ONE workgroup (round 5) -------------------------------------------------
 // voice_env_kernel -> voice_lfo_kernel -> voice_modmix_kernel are three dependent launches whose intermediate rows go through
 // HBM, and their pow / cos / fmodf were the device math library's (pow: ~300 fp64-rate instructions): 33 us alone, and
@@ -322,6 +323,8 @@ __global__ __launch_bounds__(CTLF_THREADS) void voice_control_fused_kernel(
 static size_t voice_control_fused_lds(int Tc) {
   return sizeof(double) * (IAS_CTL_TAB_DOUBLES + 2 * (size_t)Tc) + sizeof(float) * 8 * (size_t)Tc;
 }
+
+#endif
 
 // -------------------------------------------------------------------- audio rate
 #define VOICE_MAXCTRL 320  // control points staged per tile (covers sample rates down to ~6 kHz)
@@ -910,8 +913,8 @@ static int voice_control_launch(const float* params01, float* ctrl, void* vconst
   const char* form = ias_diag_env("IAS_VOICE_CTRL");
   if (form == nullptr && ias_voice_control_slim_ok(Tc, control_rate))
     return ias_voice_control_slim_launch(params01, ctrl, vconst, sig, dbg, B, Tc, control_rate, stream);
-  // one workgroup per voice while its rows fit the LDS of a CU (48 bytes per control sample + the 4 KB table: Tc <= ~3200);
-  // longer control buffers take the three-kernel form (rows through HBM)
+#ifdef IAS_DIAG
+  // (one workgroup per voice while its rows fit the LDS of a CU: 48 bytes per control sample + the 4 KB table, Tc <= ~3200)
   const size_t flds = voice_control_fused_lds(Tc);
   if (flds <= 156 * 1024 && form != nullptr && form[0] == 'f') {
     static bool attr_set = false;                          // (idempotent: a race sets it twice)
@@ -924,6 +927,8 @@ static int voice_control_launch(const float* params01, float* ctrl, void* vconst
                        (IasVoiceConst*)vconst, dbg, Tc, (float)control_rate);
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   }
+#endif
+  // control buffers longer than the slim kernels take: the round-1 kernels (device math library, rows through HBM)
   const size_t lds = sizeof(double) * (VOICE_WAVES + (size_t)Tc);
   if (lds > 160 * 1024) return IAS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(voice_env_kernel, dim3(6, B), dim3(VOICE_THREADS), 0, stream, params01, sig, Tc,
