@@ -790,6 +790,8 @@ def run_gradstep(args, rank, world, dev):
     sub = SubbandL1(gram)
     both = ParallelLossSum(mr, sub)          # the two loss branches on streams of their own, forward and backward
     both.parallel = os.environ.get("IAS_BENCH_SERIAL_LOSSES", "0") in ("", "0")
+    if os.environ.get("IAS_BENCH_MR_SERIAL"):      # (diagnostics: the three STFT resolutions one after the other on one stream)
+        mr.parallel = False
     if os.environ.get("IAS_BENCH_PLS_SHARE"):      # (diagnostics: which STFT resolution's stream the sub-band branch borrows)
         both.share_from = int(os.environ["IAS_BENCH_PLS_SHARE"])
     params = torch.rand(B, 78, generator=torch.Generator().manual_seed(1000 + rank)).to(dev).requires_grad_(True)

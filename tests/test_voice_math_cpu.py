@@ -196,3 +196,15 @@ def test_written_out_control_math_equals_libm_after_the_rounding_to_fp32(ctl_che
     assert bad == 0, (name, bad)
     assert worst <= max_ulp64, (name, worst)
     assert outside <= 0.02 * n, (name, outside)
+
+
+@pytest.mark.parametrize("kind,name,max_ulp64", [(0, "pow and ln of a double in (0, 1]", 16.0), (1, "sin / cos up to 2^20 rad", 8.0),
+                                                 (2, "x mod 2 pi", 8.0)])
+def test_written_out_fp64_argument_forms_against_libm(ctl_check, kind, name, max_ulp64):
+    """The fp64-ARGUMENT forms of csrc/voice_ctrl_math.h (ias_ctl_pow_d / log_d / sincos_d / mod_d: the control-rate
+    backward, whose gradients are checked to 1e-5) against libm on 5 * 10^6 arguments each: within a few ulp of fp64."""
+    ctl_check.ctrl_math_check_d.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_ulonglong, ctypes.POINTER(ctypes.c_double)]
+    out = (ctypes.c_double * 4)()
+    assert ctl_check.ctrl_math_check_d(kind, 5_000_000, 4242 + kind, out) == 0
+    n, bad, worst, _ = list(out)
+    assert bad == 0 and worst <= max_ulp64, (name, bad, worst)
