@@ -440,6 +440,13 @@ int ias_bn_act_backward(const float* x, const float* dy, const float* weight, co
 int ias_lars_chunk_elems(void);
 int ias_lars_step(const long long* tensors, const int* chunks, const int* first_chunk, double* partials, float* coef,
                   const float* hyper, int ntensors, int nchunks, int skip_norms, void* stream);
+/* The same step (weight decay on) with the parameters' norms carried from update to update: carry = 1 computes both norms
+ * as ias_lars_step does and lets the update pass leave sum p_new^2 per chunk in partials[2 c] (summed in the norm pass'
+ * own order); carry = 2 reads only the gradient in the norm pass and takes the parameters' sums the previous call left in
+ * `partials` -- valid while the same tensors are stepped, the buffer is kept and nothing else wrote the parameters.  Same
+ * bits as ias_lars_step; one read of the parameters less per step. */
+int ias_lars_step_carry(const long long* tensors, const int* chunks, const int* first_chunk, double* partials, float* coef,
+                        const float* hyper, int ntensors, int nchunks, int carry, void* stream);
 
 #ifdef __cplusplus
 }

@@ -120,6 +120,7 @@ SYMBOLS = {
     "ias_bn_act_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_lars_chunk_elems": (_I, []),
     "ias_lars_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ias_lars_step_carry": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
 }
 
 # Symbols only the diagnostic library exports (include/ias_hip_diag.h).

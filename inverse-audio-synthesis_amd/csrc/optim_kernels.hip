@@ -17,6 +17,9 @@
 #define IAS_LARS_CHUNK 65536
 #define LARS_THREADS 256
 
+// GRAD_ONLY (round 5): the parameters' partial sums are carried over from the previous step's update pass (lars_update_kernel
+// writes sum p_new^2 per chunk, in THIS kernel's order of additions, into partials[2 c]); only the gradient is read here.
+template <bool GRAD_ONLY>
 __global__ __launch_bounds__(LARS_THREADS) void lars_norm_partials_kernel(const long long* __restrict__ tensors,
                                                                            const int* __restrict__ chunks,
                                                                            double* __restrict__ partials) {
@@ -39,21 +42,21 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_norm_partials_kernel(const 
     for (; i + 3 * LARS_THREADS < n4; i += 4 * LARS_THREADS) {
       float4 a[4], b[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { a[u] = p4[i + u * LARS_THREADS]; b[u] = g4[i + u * LARS_THREADS]; }
+      for (int u = 0; u < 4; ++u) { if (!GRAD_ONLY) a[u] = p4[i + u * LARS_THREADS]; b[u] = g4[i + u * LARS_THREADS]; }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        sp = fmaf(a[u].x, a[u].x, sp); sp = fmaf(a[u].y, a[u].y, sp); sp = fmaf(a[u].z, a[u].z, sp); sp = fmaf(a[u].w, a[u].w, sp);
+        if (!GRAD_ONLY) { sp = fmaf(a[u].x, a[u].x, sp); sp = fmaf(a[u].y, a[u].y, sp); sp = fmaf(a[u].z, a[u].z, sp); sp = fmaf(a[u].w, a[u].w, sp); }
         sg = fmaf(b[u].x, b[u].x, sg); sg = fmaf(b[u].y, b[u].y, sg); sg = fmaf(b[u].z, b[u].z, sg); sg = fmaf(b[u].w, b[u].w, sg);
       }
     }
     for (; i < n4; i += LARS_THREADS) {
-      const float4 a = p4[i], b = g4[i];
-      sp = fmaf(a.x, a.x, sp); sp = fmaf(a.y, a.y, sp); sp = fmaf(a.z, a.z, sp); sp = fmaf(a.w, a.w, sp);
+      const float4 b = g4[i];
+      if (!GRAD_ONLY) { const float4 a = p4[i]; sp = fmaf(a.x, a.x, sp); sp = fmaf(a.y, a.y, sp); sp = fmaf(a.z, a.z, sp); sp = fmaf(a.w, a.w, sp); }
       sg = fmaf(b.x, b.x, sg); sg = fmaf(b.y, b.y, sg); sg = fmaf(b.z, b.z, sg); sg = fmaf(b.w, b.w, sg);
     }
-    for (int i = (n4 << 2) + tid; i < len; i += LARS_THREADS) { sp = fmaf(p[i], p[i], sp); sg = fmaf(g[i], g[i], sg); }
+    for (int i = (n4 << 2) + tid; i < len; i += LARS_THREADS) { if (!GRAD_ONLY) sp = fmaf(p[i], p[i], sp); sg = fmaf(g[i], g[i], sg); }
   } else {
-    for (int i = tid; i < len; i += LARS_THREADS) { sp = fmaf(p[i], p[i], sp); sg = fmaf(g[i], g[i], sg); }
+    for (int i = tid; i < len; i += LARS_THREADS) { if (!GRAD_ONLY) sp = fmaf(p[i], p[i], sp); sg = fmaf(g[i], g[i], sg); }
   }
   __shared__ double s_p[LARS_THREADS], s_g[LARS_THREADS];
   s_p[tid] = (double)sp; s_g[tid] = (double)sg;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_norm_partials_kernel(const 
     if (tid < d) { s_p[tid] += s_p[tid + d]; s_g[tid] += s_g[tid + d]; }
     __syncthreads();
   }
-  if (tid == 0) { partials[2 * c] = s_p[0]; partials[2 * c + 1] = s_g[0]; }
+  if (tid == 0) { if (!GRAD_ONLY) partials[2 * c] = s_p[0]; partials[2 * c + 1] = s_g[0]; }
 }
 
 // coef[t] = (ratio, ratio * wd) where both norms are non-zero, (1, 0) elsewhere   (hyper = lr, wd, trust, eps)
@@ -88,10 +91,15 @@ __global__ __launch_bounds__(64) void lars_coef_kernel(const int* __restrict__ f
   coef[2 * t] = ratio; coef[2 * t + 1] = decay;
 }
 
+// CARRY (round 5): the pass also sums the squares of the values it writes -- element by element in the order in which
+// lars_norm_partials_kernel adds them, through the same workgroup reduction -- into partials[2 c]: the next step's norm pass
+// then reads the gradient only (570 MB less per step of the 142 M-parameter model), and gets the bits it would have computed.
+template <bool CARRY>
 __global__ __launch_bounds__(LARS_THREADS) void lars_update_kernel(const long long* __restrict__ tensors,
                                                                     const int* __restrict__ chunks,
                                                                     const float* __restrict__ coef,
-                                                                    const float* __restrict__ hyper) {
+                                                                    const float* __restrict__ hyper,
+                                                                    double* __restrict__ partials) {
   const int c = blockIdx.x, t = chunks[2 * c], ci = chunks[2 * c + 1];
   float* p = reinterpret_cast<float*>(tensors[3 * t]);
   const float* g = reinterpret_cast<const float*>(tensors[3 * t + 1]);
@@ -101,6 +109,7 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_update_kernel(const long lo
   p += off; g += off;
   const float ratio = coef[2 * t], decay = coef[2 * t + 1], nlr = -hyper[0];
   const int tid = threadIdx.x;
+  float sp = 0.0f;
   // update = ratio * g + decay * p ;  p += (-lr) * update     (the order of torch's foreach formulation)
   if ((((uintptr_t)p | (uintptr_t)g) & 15) == 0) {
     float4* p4 = reinterpret_cast<float4*>(p);
@@ -119,12 +128,39 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_update_kernel(const long lo
 #pragma unroll
       for (int u = 0; u < 4; ++u) { a[u] = p4[i + u * LARS_THREADS]; b[u] = g4[i + u * LARS_THREADS]; }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) p4[i + u * LARS_THREADS] = upd(a[u], b[u]);
+      for (int u = 0; u < 4; ++u) {
+        const float4 n = upd(a[u], b[u]);
+        p4[i + u * LARS_THREADS] = n;
+        if (CARRY) { sp = fmaf(n.x, n.x, sp); sp = fmaf(n.y, n.y, sp); sp = fmaf(n.z, n.z, sp); sp = fmaf(n.w, n.w, sp); }
+      }
     }
-    for (; i < n4; i += LARS_THREADS) p4[i] = upd(p4[i], g4[i]);
-    for (int i = (n4 << 2) + tid; i < len; i += LARS_THREADS) p[i] = fmaf(nlr, fmaf(decay, p[i], ratio * g[i]), p[i]);
+    for (; i < n4; i += LARS_THREADS) {
+      const float4 n = upd(p4[i], g4[i]);
+      p4[i] = n;
+      if (CARRY) { sp = fmaf(n.x, n.x, sp); sp = fmaf(n.y, n.y, sp); sp = fmaf(n.z, n.z, sp); sp = fmaf(n.w, n.w, sp); }
+    }
+    for (int i = (n4 << 2) + tid; i < len; i += LARS_THREADS) {
+      const float n = fmaf(nlr, fmaf(decay, p[i], ratio * g[i]), p[i]);
+      p[i] = n;
+      if (CARRY) sp = fmaf(n, n, sp);
+    }
   } else {
-    for (int i = tid; i < len; i += LARS_THREADS) p[i] = fmaf(nlr, fmaf(decay, p[i], ratio * g[i]), p[i]);
+    for (int i = tid; i < len; i += LARS_THREADS) {
+      const float n = fmaf(nlr, fmaf(decay, p[i], ratio * g[i]), p[i]);
+      p[i] = n;
+      if (CARRY) sp = fmaf(n, n, sp);
+    }
+  }
+  if (CARRY) {
+    __shared__ double s_p[LARS_THREADS];
+    s_p[tid] = (double)sp;
+    __syncthreads();
+#pragma unroll
+    for (int d = LARS_THREADS / 2; d > 0; d >>= 1) {
+      if (tid < d) s_p[tid] += s_p[tid + d];
+      __syncthreads();
+    }
+    if (tid == 0) partials[2 * c] = s_p[0];
   }
 }
 
@@ -135,18 +171,40 @@ extern "C" int ias_lars_chunk_elems(void) { return IAS_LARS_CHUNK; }
 // trust_coefficient, eps -- on the device so that a captured graph picks up the scheduler's learning rate.
 // partials [nchunks][2] doubles and coef [ntensors][2] floats are caller-owned scratch.  weight_decay 0 is the caller's
 // business (plain p -= lr g: set coef to (1, 0) and pass skip_norms != 0).
-extern "C" int ias_lars_step(const long long* tensors, const int* chunks, const int* first_chunk, double* partials,
-                             float* coef, const float* hyper, int ntensors, int nchunks, int skip_norms,
-                             void* stream_) {
+static int lars_step_impl(const long long* tensors, const int* chunks, const int* first_chunk, double* partials,
+                          float* coef, const float* hyper, int ntensors, int nchunks, int skip_norms, int carry,
+                          void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!tensors || !chunks || !first_chunk || !partials || !coef || !hyper || ntensors <= 0 || nchunks <= 0)
+  if (!tensors || !chunks || !first_chunk || !partials || !coef || !hyper || ntensors <= 0 || nchunks <= 0 || carry < 0 || carry > 2)
     return IAS_ERR_ARG;
   if (!skip_norms) {
-    hipLaunchKernelGGL(lars_norm_partials_kernel, dim3(nchunks), dim3(LARS_THREADS), 0, stream, tensors, chunks,
-                       partials);
+    if (carry == 2)
+      hipLaunchKernelGGL(lars_norm_partials_kernel<true>, dim3(nchunks), dim3(LARS_THREADS), 0, stream, tensors, chunks, partials);
+    else
+      hipLaunchKernelGGL(lars_norm_partials_kernel<false>, dim3(nchunks), dim3(LARS_THREADS), 0, stream, tensors, chunks, partials);
     hipLaunchKernelGGL(lars_coef_kernel, dim3(ntensors), dim3(64), 0, stream, first_chunk, partials,
                        hyper, coef, ntensors);
   }
-  hipLaunchKernelGGL(lars_update_kernel, dim3(nchunks), dim3(LARS_THREADS), 0, stream, tensors, chunks, coef, hyper);
+  if (carry != 0 && !skip_norms)
+    hipLaunchKernelGGL(lars_update_kernel<true>, dim3(nchunks), dim3(LARS_THREADS), 0, stream, tensors, chunks, coef, hyper, partials);
+  else
+    hipLaunchKernelGGL(lars_update_kernel<false>, dim3(nchunks), dim3(LARS_THREADS), 0, stream, tensors, chunks, coef, hyper, partials);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+extern "C" int ias_lars_step(const long long* tensors, const int* chunks, const int* first_chunk, double* partials,
+                             float* coef, const float* hyper, int ntensors, int nchunks, int skip_norms,
+                             void* stream_) {
+  return lars_step_impl(tensors, chunks, first_chunk, partials, coef, hyper, ntensors, nchunks, skip_norms, 0, stream_);
+}
+
+// The same step with the parameters' norms carried from update to update.  carry = 1: norms of p and g as in ias_lars_step,
+// and the update pass leaves sum p_new^2 per chunk in partials[2 c]; carry = 2: the norm pass reads the gradient only and
+// takes the parameters' sums that the previous call (carry 1 or 2, same tensors, same partials buffer, parameters not
+// modified in between) left there.  Bit-identical coefficients and parameters to ias_lars_step.  The caller keeps
+// `partials` alive and unmodified between the calls (inside a captured step: outside the graph's memory pool).
+extern "C" int ias_lars_step_carry(const long long* tensors, const int* chunks, const int* first_chunk, double* partials,
+                                   float* coef, const float* hyper, int ntensors, int nchunks, int carry, void* stream_) {
+  if (carry != 1 && carry != 2) return IAS_ERR_ARG;
+  return lars_step_impl(tensors, chunks, first_chunk, partials, coef, hyper, ntensors, nchunks, 0, carry, stream_);
 }

@@ -86,6 +86,25 @@ class LARS(torch.optim.Optimizer):
                                  events=[None] * self.HYPER_RING, pos=0, vals=None)
         return h
 
+    def _group_carry(self, gi, dev, pkey, nchunks):
+        """The per-chunk sums of squares of group ``gi``'s parameters, carried from one update to the next
+        (``ias_lars_step_carry``): the update pass writes them, the next step's norm pass then reads only the gradient.
+        Persistent and OUTSIDE any graph pool for the same reason as ``_group_hyper``; -> None when it cannot be set up
+        here (first use inside a capture, or another parameter set inside a capture)."""
+        table = self.__dict__.setdefault("_hip_carry", {})
+        st = table.get(gi)
+        if st is None or st["pkey"] != pkey or st["partials"].device != dev:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            st = table[gi] = dict(pkey=pkey, partials=torch.zeros(2 * nchunks, dtype=torch.float64, device=dev),
+                                  valid=False, versions=None)
+        return st
+
+    def invalidate_carried_norms(self):
+        """Forget the carried parameter norms (after anything wrote the parameters behind torch's version counters)."""
+        for st in self.__dict__.get("_hip_carry", {}).values():
+            st["valid"] = False
+
     def prepare_capture(self):
         """Allocate what must not live in a graph's pool (see ``_group_hyper``) for every group whose parameters are on a
         ROCm device; for loops that capture their very first step."""
@@ -167,9 +186,22 @@ class LARS(torch.optim.Optimizer):
             c2 = ent["coef"].view(-1, 2)
             c2[:, 0].fill_(1.0)
             c2[:, 1].fill_(0.0)
-        _lib.check(lib.ias_lars_step(_lib.ptr(ent["tensors"]), _lib.ptr(ent["chunks"]), _lib.ptr(ent["first"]),
-                                     _lib.ptr(ent["partials"]), _lib.ptr(ent["coef"]), _lib.ptr(ent["hyper"]),
-                                     ent["n"], ent["nchunks"], int(skip), _lib.stream()), "ias_lars_step")
+        # the parameters' norms travel from update to update: the update pass sums the squares of what it writes (in the
+        # norm pass' own order: the same bits), so the norm pass of the next step reads the gradient only.  Valid while
+        # nobody else wrote the parameters -- torch's version counters say so (this optimizer's kernels do not bump them)
+        st = None if skip else self._group_carry(gi, dev, tuple((p.data_ptr(), p.numel()) for p in ps), ent["nchunks"])
+        if st is None:
+            self.invalidate_carried_norms()
+            _lib.check(lib.ias_lars_step(_lib.ptr(ent["tensors"]), _lib.ptr(ent["chunks"]), _lib.ptr(ent["first"]),
+                                         _lib.ptr(ent["partials"]), _lib.ptr(ent["coef"]), _lib.ptr(ent["hyper"]),
+                                         ent["n"], ent["nchunks"], int(skip), _lib.stream()), "ias_lars_step")
+            return
+        versions = tuple(p._version for p in ps)
+        carry = 2 if (st["valid"] and st["versions"] == versions) else 1
+        _lib.check(lib.ias_lars_step_carry(_lib.ptr(ent["tensors"]), _lib.ptr(ent["chunks"]), _lib.ptr(ent["first"]),
+                                           _lib.ptr(st["partials"]), _lib.ptr(ent["coef"]), _lib.ptr(ent["hyper"]),
+                                           ent["n"], ent["nchunks"], carry, _lib.stream()), "ias_lars_step_carry")
+        st["valid"], st["versions"] = True, tuple(p._version for p in ps)
 
 
 class LinearWarmupCosineAnnealingLR:

@@ -150,6 +150,11 @@ class Trainer:
         if self.scheduler is not None and ck.get("scheduler") is not None:
             self.scheduler.load_state_dict(ck["scheduler"])
         self.start_step = int(ck.get("step", 0))
+        # the parameters changed under a captured step (its LARS launches carry the parameters' norms from update to update)
+        # and under the eager warm-up state: capture again
+        self._graph, self._graph_warm = None, 0
+        if hasattr(self.optimizer, "invalidate_carried_norms"):
+            self.optimizer.invalidate_carried_norms()
         return ck
 
     # ---- whole-step hipGraph (trainer.cuda_graph) --------------------------------------------------------------

@@ -95,3 +95,39 @@ def test_replayed_lars_reads_each_steps_learning_rate_without_a_sync(lib, dev):
     eager, replay = run(False), run(True)
     assert torch.isfinite(eager).all() and not torch.equal(eager.cpu(), init)
     assert torch.equal(eager, replay)
+
+
+def test_carried_parameter_norms_give_the_same_bits_and_notice_outside_writes(lib, dev):
+    """Round 5: the update pass of the fused LARS step leaves sum p_new^2 per chunk (summed in the norm pass' own order) for
+    the next step, whose norm pass then reads only the gradient (ias_lars_step_carry).  Ten steps with carried norms against
+    ten steps of the plain three-pass form (carry switched off by invalidating before every step): the same parameters, bit
+    for bit; and a write to a parameter through torch between two steps (version counter) makes the next step recompute."""
+    def run(carry, poke_at=None):
+        ps = _params(dev, 7)
+        opt = LARS(ps, lr=0.2, weight_decay=1e-2)
+        modes = []
+        for step in range(10):
+            for i, p in enumerate(ps):
+                p.grad = (torch.randn(p.shape, generator=torch.Generator().manual_seed(1000 * step + i)) * 0.3).to(dev)
+            if not carry:
+                opt.invalidate_carried_norms()
+            if step == poke_at:
+                with torch.no_grad():
+                    ps[0].mul_(1.5)                      # somebody else writes a parameter
+            st = opt.__dict__.get("_hip_carry", {}).get(0)
+            modes.append(bool(st and st["valid"] and st["versions"] == tuple(p._version for p in ps)))
+            opt.step()
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in ps], modes
+
+    plain, m0 = run(False)
+    carried, m1 = run(True)
+    assert m0 == [False] * 10 and m1 == [False] + [True] * 9          # (what the step was about to do: recompute / carry)
+    for a, b in zip(plain, carried):
+        assert torch.equal(a, b)
+    poked_plain, _ = run(False, poke_at=4)
+    poked_carried, m2 = run(True, poke_at=4)
+    assert m2[4] is False and m2[5] is True
+    for a, b in zip(poked_plain, poked_carried):
+        assert torch.equal(a, b)
+    assert not torch.equal(poked_plain[0], plain[0])
