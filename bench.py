@@ -629,6 +629,20 @@ def pretrain_ddp_leg(dev, rank, world, B=128, steps=5, reps=3):
     return leg
 
 
+def gradstep_all_ranks_leg(args, rank, world, dev):
+    """legs.gradstep_all_ranks: BASELINE configs[4] as it is stated -- global batch 64 x N (512 at N = 8), 64-band PQMF +
+    3-resolution STFT loss, gradient step -- every rank its share at the same time, batch-split, no data-path collective;
+    value = the whole job's audio-seconds over the slowest rank's time."""
+    import copy
+    a2 = copy.copy(args)
+    a2.workload, a2.batch, a2.steps, a2.warmup, a2.replays, a2.no_cpu_baseline = "gradstep", 64, 5, 2, 10, True
+    r = run_gradstep(a2, rank, world, dev)
+    return {"ms_per_step": r["ms_per_step"], "ms_per_step_min": r["ms_per_step_min"], "steps": r["steps"],
+            "timed_regions": r["timed_regions"], "value": r["value"], "unit": r["unit"], "n_gpus": world,
+            "global_batch": 64 * world, "workload": r["config"]["workload"], "launch": r["config"]["launch"],
+            "loss": r["config"]["loss"], "scaling": "weak"}
+
+
 def run_leg_child(args):
     """One rank of the N > 1 legs (started by `multi_gpu_legs`): a process group of its own with a bounded timeout, so that
     a wedged collective ends THIS process and becomes the leg's `error` -- the headline line of the parent is already
@@ -646,7 +660,8 @@ def run_leg_child(args):
     from inverse_audio_synthesis_amd import _lib
     _lib.load()
     for name, fn in (("vicreg_gather", lambda: vicreg_gather_leg(args, rank, world, dev)),
-                     ("pretrain_ddp", lambda: pretrain_ddp_leg(dev, rank, world))):
+                     ("pretrain_ddp", lambda: pretrain_ddp_leg(dev, rank, world)),
+                     ("gradstep_all_ranks", lambda: gradstep_all_ranks_leg(args, rank, world, dev))):
         t0 = time.perf_counter()
         try:
             leg = fn()
@@ -701,7 +716,7 @@ def multi_gpu_legs(args, rank, world, local_rank):
                     legs[rec["leg"]] = rec["result"]
                 except ValueError:
                     pass
-        for name in ("vicreg_gather", "pretrain_ddp"):
+        for name in ("vicreg_gather", "pretrain_ddp", "gradstep_all_ranks"):
             if name not in legs:
                 legs[name] = {"error": f"legs child of rank 0 ended with code {rc} before this leg reported: {(err or '')[-400:]}"}
         legs["wall_s"] = round(time.perf_counter() - t0, 2)

@@ -88,3 +88,7 @@ def test_bench_two_ranks_run_the_collective_legs(lib, dev):
     assert d["allreduce_exposed_ms"] == pytest.approx(d["ms_per_step_eager"] - d["ms_per_step_no_allreduce"], abs=2e-3)
     import math
     assert math.isfinite(d["loss"])
+    gs = legs["gradstep_all_ranks"]            # configs[4] batch-split over the ranks, no collective
+    assert "error" not in gs, gs
+    assert gs["global_batch"] == 128 and gs["n_gpus"] == 2 and gs["ms_per_step"] > 0
+    assert abs(gs["value"] - 2 * 64 * 4.0 / (gs["ms_per_step"] * 1e-3)) <= 1e-3 * gs["value"]
