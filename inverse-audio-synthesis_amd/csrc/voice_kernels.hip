@@ -560,24 +560,24 @@ __device__ __forceinline__ void voice_phase_b(const char* s_ctrl, float* s_stage
       }
     }
     const float real = scale * (jf0 + (float)e);
-    const float w1 = __builtin_amdgcn_fractf(real), w0 = 1.0f - w1;
+    const float w1 = __builtin_amdgcn_fractf(real);
     voice_lds_cchar* cp = voice_ctrl_row(real, ctrl_biased);
+    // the amplitude rows hold (level x c[i], level x (c[i + 1] - c[i])): one multiply-add each (voice_ctrl_put)
     const voice_f2 qa = *(voice_lds_cfloat2*)(cp + 8), qb = *(voice_lds_cfloat2*)(cp + 24), qn = *(voice_lds_cfloat2*)(cp + 32);
-    const float amp1 = voice_lerp(w0, w1, qa), amp2 = voice_lerp(w0, w1, qb), ampn = voice_lerp(w0, w1, qn);
+    const float amp1 = fmaf(w1, qa.y, qa.x), amp2 = fmaf(w1, qb.y, qb.x), ampn = fmaf(w1, qn.y, qn.x);
     run1 += (double)inc1[e]; run2 += (double)inc2[e];
     const float arg1 = (float)run1 + vc.phi_1, arg2 = (float)run2 + vc.phi_2;
     float s2, c2;
     bool flip;
     voice_sincos(arg2, s2, c2, flip);    // sin = (flip ? -s2 : s2), cos = (flip ? -c2 : c2)
-    const float v1 = voice_cos(arg1) * amp1;
-    // square = tanh(k sin / 2) is odd in sin: magnitude from |s2|, sign = sign(s2) ^ flip (signs commute with the
-    // correctly rounded multiplications that follow)
+    // square = tanh(k sin / 2) is odd in sin: magnitude from |s2|, sign = sign(s2) ^ flip
     const float sqm = __builtin_copysignf(voice_tanh_abs_half(vc.kpart * s2), s2);
-    const float sc = vc.shape * c2;
-    const float v2 = ((vc.shape_gain * (flip ? -sqm : sqm)) * (1.0f + (flip ? -sc : sc))) * amp2;
-    float om = vc.lvl0 * v1;
-    om = om + vc.lvl1 * v2;
-    om = om + vc.lvl2 * (nz[e & 3] * ampn);
+    // vco_2 = gain x square x (1 + shape cos) x amplitude (gain and mixer level are inside amp2), vco_1 = cos x amplitude,
+    // mix = vco_1 + vco_2 + noise x amplitude: fused multiply-adds (the amplitude path is held to 1e-4, not to the bit)
+    const float v2 = (flip ? -sqm : sqm) * fmaf(flip ? -vc.shape : vc.shape, c2, 1.0f);
+    float om = voice_cos(arg1) * amp1;
+    om = fmaf(v2, amp2, om);
+    om = fmaf(nz[e & 3], ampn, om);
     if (FAST || j0 + e < T) pk = fmaxf(pk, fabsf(om));
     o[e & 3] = om;
     if ((e & 3) == 3) {
@@ -606,8 +606,20 @@ __device__ __forceinline__ float2 voice_ctrl_elem(const float* __restrict__ ctrl
   const float* crow = ctrl + ((size_t)t.b * IAS_NCTRL + k) * Tc;
   return make_float2(crow[t.c_lo + c], crow[min(t.c_lo + c + 1, Tc - 1)]);
 }
-__device__ __forceinline__ void voice_ctrl_put(char* dst, const VoiceTile& t, int i, float2 v) {
+// Pitch signals (k = 0, 2) are staged as the pair (c[i], c[i + 1]): phase A evaluates torch's upsample form on them, bit for
+// bit.  The three AMPLITUDE signals (k = 1 vco_1, 3 vco_2, 4 noise) do not feed a phase -- an error there is not amplified,
+// and the audio is held to 1e-4, not to the bit -- so what is staged for them is what phase B can use in ONE multiply-add
+// per sample: (g c[i], g c[i + 1] - g c[i]) with the voice's mixer level g folded in (vco_2: level x the shape gain).
+// amplitude(t) = fma(w1, difference, value) then already carries the level: five multiplies and three adds per sample less
+// than the left-to-right chain of the "cr" statement, a few ulp away from it (tests: audio within 1e-4 of the oracle;
+// measured max |delta| in DESIGN.md).
+__device__ __forceinline__ void voice_ctrl_put(char* dst, const VoiceTile& t, int i, float2 v, const IasVoiceConst& vc) {
   const int k = i / t.ncp, c = i - k * t.ncp;
+  if (k == 1 || k == 3 || k == 4) {
+    const float g = k == 1 ? vc.lvl0 : (k == 3 ? vc.lvl1 * vc.shape_gain : vc.lvl2);
+    const float a = g * v.x;
+    v = make_float2(a, g * v.y - a);
+  }
   reinterpret_cast<float2*>(dst)[c * IAS_NCTRL + k] = v;
 }
 
@@ -632,7 +644,7 @@ __device__ __forceinline__ void voice_ctrl_put(char* dst, const VoiceTile& t, in
 #define VOICE_WAVE_LOOKBACK (AUDIO_WAVES - 1)
 #define VOICE_WAVE_PUBLISH (AUDIO_WAVES - 2)
 template <int MATH, bool FMA_DIV>
-__global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) void voice_audio_kernel(
+__global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) __attribute__((amdgpu_num_vgpr(76))) void voice_audio_kernel(
     const float* __restrict__ ctrl, const IasVoiceConst* __restrict__ vconst,
     const float* __restrict__ noise, float* __restrict__ audio, unsigned long long* agg /* [B][ntiles][2] */,
     unsigned int* ticket_status /* VOICE_NCOUNTERS ticket counters (32 words apart), then the spin-timeout flag */,
@@ -679,9 +691,10 @@ __global__ __launch_bounds__(AUDIO_THREADS, VOICE_MIN_WAVES) void voice_audio_ke
     if (have_next) {
       // the next tile's control points (fetched during the previous phase B) -> LDS
       char* dst = s_ctrl0 + (slot ^ 1) * ctrl_bytes;
-      if (tid < IAS_NCTRL * next.ncp) voice_ctrl_put(dst, next, tid, pre);
+      const IasVoiceConst vcp = vconst[next.b];
+      if (tid < IAS_NCTRL * next.ncp) voice_ctrl_put(dst, next, tid, pre, vcp);
       for (int i = tid + AUDIO_THREADS; i < IAS_NCTRL * next.ncp; i += AUDIO_THREADS)   // windows wider than 51 points
-        voice_ctrl_put(dst, next, i, voice_ctrl_elem(ctrl, next, Tc, i));
+        voice_ctrl_put(dst, next, i, voice_ctrl_elem(ctrl, next, Tc, i), vcp);
     }
     unsigned long long early1 = VOICE_READY_BIT, early2 = VOICE_READY_BIT;
     if (have_cur) {
