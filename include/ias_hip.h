@@ -413,6 +413,10 @@ int ias_se_mlp_backward(const float* gs, const float* z, const float* h, const f
  * GEMM's other operand) from x [B,H,W,C], and the adjoint gp -> gx [B,H,W,C].  patches 16-byte aligned. */
 int ias_conv2x2_patches(const float* x, float* patches, int B, int H, int W, int C, void* stream);
 int ias_conv2x2_patches_backward(const float* gp, float* gx, int B, int H, int W, int C, void* stream);
+/* the same patches from / gradient into an NCHW map x, gx [B,C,H,W] (the trunk's output in front of the first head layer:
+ * no permuted copy); IAS_ERR_UNSUPPORTED when H W > 255 */
+int ias_conv2x2_patches_nchw(const float* x, float* patches, int B, int H, int W, int C, void* stream);
+int ias_conv2x2_patches_backward_nchw(const float* gp, float* gx, int B, int H, int W, int C, void* stream);
 int ias_stem_forward(const float* x, const float* w, float* out, int B, int H, int W, void* stream);
 long long ias_stem_weight_scratch(int B);                     /* floats */
 int ias_stem_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int H, int W, void* stream);
@@ -429,6 +433,20 @@ int ias_bn_act_forward(const float* x, const float* weight, const float* bias, f
 int ias_bn_act_backward(const float* x, const float* dy, const float* weight, const float* bias, const float* save_mean,
                         const float* save_invstd, float* dx, float* gw, float* gb, double* scratch, float* sums, int B,
                         int C, int HW, int act, void* stream);
+
+/* ---- Training-mode BatchNorm1d (+ ReLU) on row groups: the Linear -> BatchNorm1d -> ReLU layers of the shared projector
+ * (/root/reference/vicreg.py:27-30, 60-70: one projector applied to the audio branch, then to the parameter branch) with
+ * both branches stacked.  z, y, dy, dx [G n, F] fp32 row-major; each group of n rows gets its own batch statistics, the
+ * running statistics are updated group after group (G calls of nn.BatchNorm1d in that order), *num_batches_tracked += G.
+ * lin_bias (or NULL): the bias of the Linear in front, added on the fly (z is the GEMM output without it); g_lin_bias: its
+ * gradient.  save_mean / save_invstd [G, F]; weight / bias / running_* [F] or NULL; n >= 2. */
+int ias_bn1d_groups_forward(const float* z, const float* lin_bias, const float* weight, const float* bias,
+                            float* running_mean, float* running_var, long long* num_batches_tracked, float* y,
+                            float* save_mean, float* save_invstd, int G, int n, int F, float eps, float momentum, int relu,
+                            void* stream);
+int ias_bn1d_groups_backward(const float* z, const float* lin_bias, const float* dy, const float* weight, const float* bias,
+                             const float* save_mean, const float* save_invstd, float* dx, float* gw, float* gb,
+                             float* g_lin_bias, int G, int n, int F, int relu, void* stream);
 
 /* ---- LARS optimizer step (momentum 0) as three multi-tensor launches: replaces flash.core.optimizers.LARS.step as
  * configured at vicreg_audio_params.py:134-151.

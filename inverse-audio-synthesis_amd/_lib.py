@@ -112,12 +112,16 @@ SYMBOLS = {
     "ias_se_mlp_backward": (_I, [_P] * 13 + [_I, _I, _I, _P]),
     "ias_conv2x2_patches": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ias_conv2x2_patches_backward": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ias_conv2x2_patches_backward_nchw": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ias_conv2x2_patches_nchw": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ias_stem_forward": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ias_stem_weight_scratch": (_LL, [_I]),
     "ias_stem_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "ias_bn_scratch_doubles": (_LL, [_I, _I]),
     "ias_bn_act_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P]),
     "ias_bn_act_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_bn1d_groups_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P]),
+    "ias_bn1d_groups_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_lars_chunk_elems": (_I, []),
     "ias_lars_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ias_lars_step_carry": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -33,19 +33,27 @@ class _Conv2x2Fn(torch.autograd.Function):
     gradient directly in the weight's layout."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, nchw=False):
         from . import _lib
         lib = _lib.load()
         x, weight = x.contiguous(), weight.contiguous()
         _lib.require_f32(x, weight)
-        B, H, W, C = x.shape
+        if nchw:
+            B, C, H, W = x.shape
+        else:
+            B, H, W, C = x.shape
         Cout = weight.shape[0]
         patches = torch.empty((B * (H - 1) * (W - 1), 4 * C), dtype=torch.float32, device=x.device)
-        _lib.check(lib.ias_conv2x2_patches(_lib.ptr(x), _lib.ptr(patches), B, H, W, C, _lib.stream()), "ias_conv2x2_patches")
+        if nchw:
+            _lib.check(lib.ias_conv2x2_patches_nchw(_lib.ptr(x), _lib.ptr(patches), B, H, W, C, _lib.stream()),
+                       "ias_conv2x2_patches_nchw")
+        else:
+            _lib.check(lib.ias_conv2x2_patches(_lib.ptr(x), _lib.ptr(patches), B, H, W, C, _lib.stream()), "ias_conv2x2_patches")
         w2 = weight.view(Cout, 4 * C)
         out = torch.addmm(bias, patches, w2.t()) if bias is not None else torch.mm(patches, w2.t())
         ctx.save_for_backward(patches, weight)
         ctx.shape = (B, H, W, C)
+        ctx.nchw = bool(nchw)
         ctx.has_bias = bias is not None
         return out.view(B, H - 1, W - 1, Cout)
 
@@ -60,14 +68,19 @@ class _Conv2x2Fn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gp = torch.mm(g2, weight.view(Cout, 4 * C))
-            gx = torch.empty((B, H, W, C), dtype=torch.float32, device=g.device)
-            _lib.check(lib.ias_conv2x2_patches_backward(_lib.ptr(gp), _lib.ptr(gx), B, H, W, C, _lib.stream()),
-                       "ias_conv2x2_patches_backward")
+            if ctx.nchw:
+                gx = torch.empty((B, C, H, W), dtype=torch.float32, device=g.device)
+                _lib.check(lib.ias_conv2x2_patches_backward_nchw(_lib.ptr(gp), _lib.ptr(gx), B, H, W, C, _lib.stream()),
+                           "ias_conv2x2_patches_backward_nchw")
+            else:
+                gx = torch.empty((B, H, W, C), dtype=torch.float32, device=g.device)
+                _lib.check(lib.ias_conv2x2_patches_backward(_lib.ptr(gp), _lib.ptr(gx), B, H, W, C, _lib.stream()),
+                           "ias_conv2x2_patches_backward")
         if ctx.needs_input_grad[1]:
             gw = torch.mm(g2.t(), patches).view_as(weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g2.sum(0)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 def conv2x2_nhwc(x, weight, bias):
@@ -79,6 +92,13 @@ def conv2x2_nhwc(x, weight, bias):
     hipBLASLt calls.  fp32 throughout.  The patch columns are ordered (c, di, dj) -- the weight's own memory order -- so
     neither the weight nor its gradient is ever permuted."""
     return _Conv2x2Fn.apply(x, weight, bias)
+
+
+def conv2x2_from_nchw(x, weight, bias):
+    """The same layer on an NCHW activation x [B,Cin,H,W] (H W <= 255) -> channels-last [B,H-1,W-1,Cout]: the patches are
+    gathered straight from the planes (``ias_conv2x2_patches_nchw``), the input gradient comes back NCHW -- the first
+    head layer needs no permuted copy of the trunk's output in either direction."""
+    return _Conv2x2Fn.apply(x, weight, bias, True)
 
 
 class AudioEmbedding(nn.Module):
@@ -106,10 +126,14 @@ class AudioEmbedding(nn.Module):
         # vision.FORCE_TORCH_LAYERS (diagnostics): the nn.Conv2d head; the trunk layers honour the same attribute
         if t.is_cuda and t.dtype == torch.float32 and not trunk_torch() and \
                 all(plain2x2(getattr(self, f"conv{i}")) for i in range(1, 8)):
-            t = t.permute(0, 2, 3, 1)                 # channels-last once; the head stays channels-last
-            for i in range(7, 0, -1):
+            for i in range(7, 0, -1):                 # the head is channels-last from its first output on
                 c = getattr(self, f"conv{i}")
-                t = conv2x2_nhwc(t, c.weight, c.bias)
+                if i != 7:
+                    t = conv2x2_nhwc(t, c.weight, c.bias)
+                elif t.shape[2] * t.shape[3] <= 255:  # the trunk's output is NCHW
+                    t = conv2x2_from_nchw(t, c.weight, c.bias)
+                else:
+                    t = conv2x2_nhwc(t.permute(0, 2, 3, 1), c.weight, c.bias)
             return t.reshape(-1, self.dim)            # [B,1,1,dim]
         for i in range(7, 0, -1):
             t = getattr(self, f"conv{i}")(t)

@@ -382,3 +382,208 @@ extern "C" int ias_bn_act_backward(const float* x, const float* dy, const float*
   bn_launch_apply<1>(stream, x, dy, save_mean, save_invstd, weight, bias, sums, dx, B, C, HW, act);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Training-mode BatchNorm1d (+ ReLU) on ROW GROUPS of a [G n, F] matrix: each group of n consecutive rows is normalised
+// with its own batch statistics, the groups update the running statistics one after the other (group 0 first) -- what
+// the reference's shared projector does when it is applied to the audio branch and then to the parameter branch
+// (/root/reference/vicreg.py:27-30: `self.projector(...)` twice; Linear -> BatchNorm1d -> ReLU per layer, vicreg.py:60-70).
+// With both branches stacked (vicreg.project_pair) torch needed per layer and step: 2 x (counter add, statistics,
+// finalize, transform) + cat + ReLU forward and ReLU', 2 x (zero fill, copy, reduce, elementwise), 3 adds backward --
+// ~24 launches of 5-8 us each on an 8 MB activation.  Here: ONE launch per direction.  The preceding Linear's bias is an
+// argument (`lin_bias`, added on the fly; its gradient, the column sums of dx, comes out of the backward launch), so the
+// GEMM in front runs without a bias pass and without a column-sum launch behind it.
+//
+// A workgroup owns BN1_FT features and walks the groups; a thread owns one feature and every BN1_RG-th row, the rows of a
+// group in registers (n <= BN1_RG * RPT; RPT = 0: re-read from memory -- the tile is 32 KB, it stays in L1 / L2).
+// All sums in a fixed order: deterministic.
+#define BN1_FT 32
+#define BN1_RG 8
+#define BN1_THREADS (BN1_FT * BN1_RG)
+
+// sum over the BN1_RG row groups of a feature, fixed order; every thread of the feature gets the result
+__device__ __forceinline__ float bn1_reduce(float v, float (*red)[BN1_FT], int tx, int ty) {
+  __syncthreads();              // the previous use of `red` is over
+  red[ty][tx] = v;
+  __syncthreads();
+  float s = red[0][tx];
+#pragma unroll
+  for (int k = 1; k < BN1_RG; ++k) s += red[k][tx];
+  return s;
+}
+
+template <int RPT>
+__global__ __launch_bounds__(BN1_THREADS) void bn1d_groups_forward_kernel(
+    const float* __restrict__ z, const float* __restrict__ lin_bias, const float* __restrict__ weight,
+    const float* __restrict__ bias, float* __restrict__ running_mean, float* __restrict__ running_var,
+    long long* __restrict__ num_batches_tracked, float* __restrict__ y, float* __restrict__ save_mean,
+    float* __restrict__ save_invstd, int G, int n, int F, float eps, float momentum, int relu) {
+  __shared__ float red[BN1_RG][BN1_FT];
+  const int tx = threadIdx.x % BN1_FT, ty = threadIdx.x / BN1_FT;
+  const int f = blockIdx.x * BN1_FT + tx;
+  const bool live = f < F;
+  const int fc = live ? f : F - 1;                       // dead lanes read a valid column and write nothing
+  const float lb = lin_bias ? lin_bias[fc] : 0.0f, w = weight ? weight[fc] : 1.0f, b = bias ? bias[fc] : 0.0f;
+  float rm = running_mean ? running_mean[fc] : 0.0f, rv = running_var ? running_var[fc] : 0.0f;
+  const float inv_n = 1.0f / (float)n, unbias = (float)n / (float)(n - 1);
+  for (int g = 0; g < G; ++g) {
+    const float* zg = z + (size_t)g * n * F + fc;
+    float* yg = y + (size_t)g * n * F + fc;
+    float xv[RPT > 0 ? RPT : 1];
+    float s = 0.0f;
+    if (RPT > 0) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int r = ty + i * BN1_RG;
+        xv[i] = r < n ? zg[(size_t)r * F] + lb : 0.0f;
+        s += xv[i];
+      }
+    } else {
+      for (int r = ty; r < n; r += BN1_RG) s += zg[(size_t)r * F] + lb;
+    }
+    const float mean = bn1_reduce(s, red, tx, ty) * inv_n;
+    float q = 0.0f;
+    if (RPT > 0) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const float d = xv[i] - mean;
+        q += (ty + i * BN1_RG < n) ? d * d : 0.0f;
+      }
+    } else {
+      for (int r = ty; r < n; r += BN1_RG) { const float d = (zg[(size_t)r * F] + lb) - mean; q += d * d; }
+    }
+    const float var = bn1_reduce(q, red, tx, ty) * inv_n;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float a = invstd * w;
+    if (RPT > 0) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int r = ty + i * BN1_RG;
+        const float v = (xv[i] - mean) * a + b;
+        if (live && r < n) yg[(size_t)r * F] = relu ? fmaxf(v, 0.0f) : v;
+      }
+    } else {
+      for (int r = ty; r < n; r += BN1_RG) {
+        const float v = ((zg[(size_t)r * F] + lb) - mean) * a + b;
+        if (live) yg[(size_t)r * F] = relu ? fmaxf(v, 0.0f) : v;
+      }
+    }
+    if (live && ty == 0) {
+      save_mean[(size_t)g * F + f] = mean;
+      save_invstd[(size_t)g * F + f] = invstd;
+    }
+    rm = (1.0f - momentum) * rm + momentum * mean;       // as torch: one update per call, in call order
+    rv = (1.0f - momentum) * rv + momentum * (var * unbias);
+  }
+  if (live && ty == 0) {
+    if (running_mean) running_mean[f] = rm;
+    if (running_var) running_var[f] = rv;
+  }
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += G;
+}
+
+// dy [G n, F] -> dx [G n, F] (the gradient of the Linear output in front), gw / gb [F] (BatchNorm weight and bias,
+// summed over the groups in group order), g_lin_bias [F] (column sums of dx).
+template <int RPT>
+__global__ __launch_bounds__(BN1_THREADS) void bn1d_groups_backward_kernel(
+    const float* __restrict__ z, const float* __restrict__ lin_bias, const float* __restrict__ dy,
+    const float* __restrict__ weight, const float* __restrict__ bias, const float* __restrict__ save_mean,
+    const float* __restrict__ save_invstd, float* __restrict__ dx, float* __restrict__ gw, float* __restrict__ gb,
+    float* __restrict__ g_lin_bias, int G, int n, int F, int relu) {
+  __shared__ float red[BN1_RG][BN1_FT];
+  const int tx = threadIdx.x % BN1_FT, ty = threadIdx.x / BN1_FT;
+  const int f = blockIdx.x * BN1_FT + tx;
+  const bool live = f < F;
+  const int fc = live ? f : F - 1;
+  const float lb = lin_bias ? lin_bias[fc] : 0.0f, w = weight ? weight[fc] : 1.0f, b = bias ? bias[fc] : 0.0f;
+  const float inv_n = 1.0f / (float)n;
+  float gw_acc = 0.0f, gb_acc = 0.0f, glb_acc = 0.0f;
+  for (int g = 0; g < G; ++g) {
+    const size_t base = (size_t)g * n * F + fc;
+    const float mean = save_mean[(size_t)g * F + fc], invstd = save_invstd[(size_t)g * F + fc];
+    const float a = invstd * w;
+    float xh[RPT > 0 ? RPT : 1], dz[RPT > 0 ? RPT : 1];
+    float s1 = 0.0f, s2 = 0.0f;
+    // the forward's own expression for the pre-activation value: the ReLU mask is the forward's mask
+    auto one = [&](int r, float& xhat, float& d) {
+      const float c = (z[base + (size_t)r * F] + lb) - mean;
+      const float v = c * a + b;
+      xhat = c * invstd;
+      d = dy[base + (size_t)r * F];
+      if (relu && !(v > 0.0f)) d = 0.0f;
+    };
+    if (RPT > 0) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int r = ty + i * BN1_RG;
+        xh[i] = 0.0f; dz[i] = 0.0f;
+        if (r < n) one(r, xh[i], dz[i]);
+        s1 += dz[i]; s2 += dz[i] * xh[i];
+      }
+    } else {
+      for (int r = ty; r < n; r += BN1_RG) { float xhat, d; one(r, xhat, d); s1 += d; s2 += d * xhat; }
+    }
+    s1 = bn1_reduce(s1, red, tx, ty);
+    s2 = bn1_reduce(s2, red, tx, ty);
+    const float m1 = s1 * inv_n, m2 = s2 * inv_n;
+    float sb = 0.0f;
+    if (RPT > 0) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int r = ty + i * BN1_RG;
+        const float v = a * (dz[i] - m1 - xh[i] * m2);
+        if (r < n) { sb += v; if (live) dx[base + (size_t)r * F] = v; }
+      }
+    } else {
+      for (int r = ty; r < n; r += BN1_RG) {
+        float xhat, d; one(r, xhat, d);
+        const float v = a * (d - m1 - xhat * m2);
+        sb += v;
+        if (live) dx[base + (size_t)r * F] = v;
+      }
+    }
+    sb = bn1_reduce(sb, red, tx, ty);
+    gw_acc += s2; gb_acc += s1; glb_acc += sb;
+  }
+  if (live && ty == 0) {
+    if (gw) gw[f] = gw_acc;
+    if (gb) gb[f] = gb_acc;
+    if (g_lin_bias) g_lin_bias[f] = glb_acc;
+  }
+}
+
+static int bn1_rpt(int n) { return n <= BN1_RG * 16 ? 16 : (n <= BN1_RG * 32 ? 32 : 0); }
+
+// z [G n, F] fp32 row-major (the Linear output WITHOUT its bias when lin_bias is given), y the same shape; lin_bias, weight,
+// bias, running_mean, running_var [F] or NULL; num_batches_tracked: one int64 or NULL (+= G); save_mean / save_invstd [G, F].
+extern "C" int ias_bn1d_groups_forward(const float* z, const float* lin_bias, const float* weight, const float* bias,
+                                       float* running_mean, float* running_var, long long* num_batches_tracked, float* y,
+                                       float* save_mean, float* save_invstd, int G, int n, int F, float eps, float momentum,
+                                       int relu, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!z || !y || !save_mean || !save_invstd || G <= 0 || n < 2 || F <= 0 ||
+      !(eps >= 0.0f))
+    return IAS_ERR_ARG;
+  const dim3 grid((F + BN1_FT - 1) / BN1_FT), block(BN1_THREADS);
+  switch (bn1_rpt(n)) {
+    case 16: hipLaunchKernelGGL((bn1d_groups_forward_kernel<16>), grid, block, 0, stream, z, lin_bias, weight, bias, running_mean, running_var, num_batches_tracked, y, save_mean, save_invstd, G, n, F, eps, momentum, relu); break;
+    case 32: hipLaunchKernelGGL((bn1d_groups_forward_kernel<32>), grid, block, 0, stream, z, lin_bias, weight, bias, running_mean, running_var, num_batches_tracked, y, save_mean, save_invstd, G, n, F, eps, momentum, relu); break;
+    default: hipLaunchKernelGGL((bn1d_groups_forward_kernel<0>), grid, block, 0, stream, z, lin_bias, weight, bias, running_mean, running_var, num_batches_tracked, y, save_mean, save_invstd, G, n, F, eps, momentum, relu); break;
+  }
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+
+extern "C" int ias_bn1d_groups_backward(const float* z, const float* lin_bias, const float* dy, const float* weight,
+                                        const float* bias, const float* save_mean, const float* save_invstd, float* dx,
+                                        float* gw, float* gb, float* g_lin_bias, int G, int n, int F, int relu,
+                                        void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!z || !dy || !dx || !save_mean || !save_invstd || G <= 0 || n < 2 || F <= 0) return IAS_ERR_ARG;
+  const dim3 grid((F + BN1_FT - 1) / BN1_FT), block(BN1_THREADS);
+  switch (bn1_rpt(n)) {
+    case 16: hipLaunchKernelGGL((bn1d_groups_backward_kernel<16>), grid, block, 0, stream, z, lin_bias, dy, weight, bias, save_mean, save_invstd, dx, gw, gb, g_lin_bias, G, n, F, relu); break;
+    case 32: hipLaunchKernelGGL((bn1d_groups_backward_kernel<32>), grid, block, 0, stream, z, lin_bias, dy, weight, bias, save_mean, save_invstd, dx, gw, gb, g_lin_bias, G, n, F, relu); break;
+    default: hipLaunchKernelGGL((bn1d_groups_backward_kernel<0>), grid, block, 0, stream, z, lin_bias, dy, weight, bias, save_mean, save_invstd, dx, gw, gb, g_lin_bias, G, n, F, relu); break;
+  }
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}

@@ -217,22 +217,100 @@ def Projector(cfg, reprdim):
     return nn.Sequential(*layers)
 
 
+class _BN1dGroupsFn(torch.autograd.Function):
+    """relu?(BatchNorm1d_train(z + lin_bias)) on G stacked row groups, each with its own batch statistics, the running
+    statistics updated group after group (csrc/bn_kernels.hip: ias_bn1d_groups_forward / _backward, one launch each)."""
+
+    @staticmethod
+    def forward(ctx, z, lin_bias, weight, bias, running_mean, running_var, num_batches_tracked, eps, momentum, groups, relu):
+        lib = _lib.load()
+        z = z.contiguous()
+        _lib.require_f32(z, weight, bias)
+        R, Fdim = z.shape
+        n = R // groups
+        y = torch.empty_like(z)
+        mean = torch.empty((groups, Fdim), dtype=torch.float32, device=z.device)
+        invstd = torch.empty_like(mean)
+        _lib.check(lib.ias_bn1d_groups_forward(_lib.ptr(z), _lib.ptr(lin_bias), _lib.ptr(weight), _lib.ptr(bias),
+                                               _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(num_batches_tracked),
+                                               _lib.ptr(y), _lib.ptr(mean), _lib.ptr(invstd), groups, n, Fdim, float(eps),
+                                               float(momentum), int(relu), _lib.stream()), "ias_bn1d_groups_forward")
+        ctx.save_for_backward(z, lin_bias, weight, bias, mean, invstd)
+        ctx.groups, ctx.relu = groups, int(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        z, lin_bias, weight, bias, mean, invstd = ctx.saved_tensors
+        g = g.contiguous()
+        R, Fdim = z.shape
+        dx = torch.empty_like(z)
+        gw = torch.empty_like(weight) if weight is not None else None
+        gb = torch.empty_like(bias) if bias is not None else None
+        glb = torch.empty_like(lin_bias) if lin_bias is not None else None
+        _lib.check(lib.ias_bn1d_groups_backward(_lib.ptr(z), _lib.ptr(lin_bias), _lib.ptr(g), _lib.ptr(weight),
+                                                _lib.ptr(bias), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(dx), _lib.ptr(gw),
+                                                _lib.ptr(gb), _lib.ptr(glb), ctx.groups, R // ctx.groups, Fdim, ctx.relu,
+                                                _lib.stream()), "ias_bn1d_groups_backward")
+        return dx, glb, gw, gb, None, None, None, None, None, None, None
+
+
+def _bn1d_hip_ok(m, t, n):
+    return (isinstance(m, nn.BatchNorm1d) and m.training and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and
+            n >= 2 and m.affine and m.track_running_stats and m.momentum is not None and m.num_batches_tracked is not None
+            and not PROJECT_PAIR_TORCH)
+
+
+class _SplitRowsFn(torch.autograd.Function):
+    """t -> (t[:n], t[n:]); the backward is ONE concatenation (two slice nodes cost two zero fills, two copies and an add)."""
+
+    @staticmethod
+    def forward(ctx, t, n):
+        return t[:n], t[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        return torch.cat([ga, gb], 0), None
+
+
+PROJECT_PAIR_TORCH = False    # tests / diagnostics: every BatchNorm1d of project_pair through nn.BatchNorm1d
+
+
 def project_pair(projector, a, b):
     """``projector(a), projector(b)`` (reference vicreg.py:27-30: the shared projector applied to both branches) with
     every Linear run ONCE on the concatenated rows and every BatchNorm1d on each branch alone, in the order a, b -- the
     same statistics, running-stat updates and outputs as two calls.  At embeddim 8192 the two calls cost two weight
-    gradients per layer (each a 268 MB write) plus the add that accumulates them; the pair form costs one."""
+    gradients per layer (each a 268 MB write) plus the add that accumulates them; the pair form costs one.
+    Training on the GPU: Linear -> BatchNorm1d -> ReLU runs as one GEMM without bias + ONE launch for the Linear's bias,
+    both branches' normalisation, the running statistics, their counter and the ReLU (``_BN1dGroupsFn``)."""
     mods = list(projector) if isinstance(projector, nn.Sequential) else None
     if mods is None or a.shape != b.shape or a.dim() != 2 or not all(
             isinstance(m, (nn.Linear, nn.modules.batchnorm._BatchNorm, nn.ReLU)) for m in mods):
         return projector(a), projector(b)
     n = a.shape[0]
     t = torch.cat([a, b], 0)
-    for m in mods:
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        if isinstance(m, nn.Linear) and nxt is not None and _bn1d_hip_ok(nxt, t, n):
+            relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+            t = _BN1dGroupsFn.apply(F.linear(t, m.weight), m.bias, nxt.weight, nxt.bias, nxt.running_mean, nxt.running_var,
+                                    nxt.num_batches_tracked, nxt.eps, nxt.momentum, 2, relu)
+            i += 3 if relu else 2
+            continue
         if isinstance(m, nn.modules.batchnorm._BatchNorm):
-            t = torch.cat([m(t[:n]), m(t[n:])], 0)
+            if _bn1d_hip_ok(m, t, n):
+                t = _BN1dGroupsFn.apply(t, None, m.weight, m.bias, m.running_mean, m.running_var, m.num_batches_tracked,
+                                        m.eps, m.momentum, 2, False)
+            else:
+                t = torch.cat([m(t[:n]), m(t[n:])], 0)
         else:
             t = m(t)
+        i += 1
+    if t.is_cuda and not PROJECT_PAIR_TORCH:
+        return _SplitRowsFn.apply(t, n)
     return t[:n], t[n:]
 
 

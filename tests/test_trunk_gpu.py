@@ -196,6 +196,28 @@ def test_head_conv2x2_matches_torch(lib, dev, B, H, W, C, Cout):
         assert (a - r).abs().max().item() <= 1e-4 * max(1.0, r.abs().max().item()), name
 
 
+@pytest.mark.parametrize("B,H,W,C,Cout", [(3, 8, 8, 64, 32), (2, 2, 2, 8, 8), (5, 3, 6, 12, 20), (128, 8, 8, 576, 16),
+                                          (2, 15, 17, 70, 8), (1, 4, 5, 130, 12)])
+def test_head_conv2x2_from_nchw_matches_torch(lib, dev, B, H, W, C, Cout):
+    """conv2x2_from_nchw (ias_conv2x2_patches_nchw + GEMM: the first head layer on the trunk's NCHW output, no permuted
+    copy) against F.conv2d: output, NCHW input gradient, weight and bias gradients.  Channel counts that are not a
+    multiple of the 64-channel tile, the largest map the LDS tile takes (15 x 17)."""
+    from inverse_audio_synthesis_amd.audioembed import conv2x2_from_nchw
+    x = randn((B, C, H, W), 11).to(dev).requires_grad_(True)
+    w = (randn((Cout, C, 2, 2), 12) * 0.1).to(dev).requires_grad_(True)
+    b = randn((Cout,), 13).to(dev).requires_grad_(True)
+    y = conv2x2_from_nchw(x, w, b)
+    ref = F.conv2d(x, w, b).permute(0, 2, 3, 1)
+    assert y.shape == ref.shape and (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    g = randn(tuple(ref.shape), 14).to(dev)
+    got = torch.autograd.grad(y, (x, w, b), g)
+    want = torch.autograd.grad(ref, (x, w, b), g)
+    for a, r, name in zip(got, want, ("gx", "gw", "gb")):
+        assert a.shape == r.shape and (a - r).abs().max().item() <= 1e-4 * max(1.0, r.abs().max().item()), name
+    with pytest.raises(RuntimeError):     # maps beyond the LDS tile are refused by the C ABI (the module permutes instead)
+        conv2x2_from_nchw(randn((1, 4, 16, 16), 15).to(dev), w[:, :4].contiguous(), b)
+
+
 @pytest.mark.parametrize("B,C,Cs,H,W", [(4, 16, 8, 60, 62), (3, 96, 24, 15, 16), (2, 576, 144, 8, 8), (2, 8, 8, 3, 3),
                                         (5, 12, 4, 7, 10), (128, 240, 64, 15, 16), (130, 120, 32, 4, 4), (3, 10, 6, 5, 5),
                                         (2, 1028, 260, 2, 2), (1, 288, 72, 8, 8)])

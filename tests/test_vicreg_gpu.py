@@ -225,3 +225,56 @@ def test_backward_on_views_that_are_not_16_byte_aligned(lib, dev, B, D):
     scale = float(res[0][0].abs().max())
     for a, b in zip(res[0], res[1]):
         assert float((a - b).abs().max()) <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("n,widths", [(128, (96, 256, 256, 64)), (20, (40, 200, 72, 24)), (200, (32, 64, 64, 32)),
+                                       (300, (16, 40, 32, 8))])
+def test_project_pair_fused_batchnorm_matches_two_projector_calls(lib, dev, n, widths):
+    """vicreg.project_pair on the GPU (one GEMM without bias + ONE launch per Linear -> BatchNorm1d -> ReLU layer for both
+    branches: ias_bn1d_groups_forward / _backward) against projector(a), projector(b) as the reference calls it
+    (vicreg.py:27-30) on torch's own kernels: outputs, running statistics, counters, input and parameter gradients.
+    Row counts per branch on each of the kernel's three forms (16 / 32 rows per thread in registers, re-read), feature
+    counts that are not a multiple of the 32-feature tile."""
+    import copy
+    from inverse_audio_synthesis_amd import vicreg
+    torch.manual_seed(11)
+    d0, d1, d2, d3 = widths
+    proj = torch.nn.Sequential(torch.nn.Linear(d0, d1), torch.nn.BatchNorm1d(d1), torch.nn.ReLU(True),
+                               torch.nn.Linear(d1, d2), torch.nn.BatchNorm1d(d2), torch.nn.ReLU(True),
+                               torch.nn.Linear(d2, d3, bias=False)).to(dev)
+    with torch.no_grad():
+        for m in proj:
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.copy_(1.0 + 0.3 * randn((m.num_features,), 3).to(dev))
+                m.bias.copy_(0.2 * randn((m.num_features,), 4).to(dev))
+                m.running_mean.copy_(0.1 * randn((m.num_features,), 5).to(dev))
+    ref = copy.deepcopy(proj)
+    a = (randn((n, d0), 41) * 2 + 0.5).to(dev).requires_grad_(True)
+    b = (randn((n, d0), 42) - 0.25).to(dev).requires_grad_(True)
+    wa, wb = randn((n, d3), 43).to(dev), randn((n, d3), 44).to(dev)
+    for _ in range(2):                      # two steps: the running statistics chain through both
+        xa, xb = vicreg.project_pair(proj, a, b)
+        ra, rb = ref(a), ref(b)
+    tol = 2e-5
+    scale = max(1.0, ra.abs().max().item())
+    assert (xa - ra).abs().max().item() <= tol * scale and (xb - rb).abs().max().item() <= tol * scale
+    got = torch.autograd.grad((xa * wa).sum() + (xb * wb).sum(), [a, b] + list(proj.parameters()))
+    want = torch.autograd.grad((ra * wa).sum() + (rb * wb).sum(), [a, b] + list(ref.parameters()))
+    names = ["a", "b"] + [k for k, _ in proj.named_parameters()]
+    for k, g, w in zip(names, got, want):
+        # the Linear biases in front of a BatchNorm have a gradient that is zero in exact arithmetic: absolute bound
+        bound = 2e-4 * max(1.0, w.abs().max().item())
+        assert (g - w).abs().max().item() <= bound, (k, (g - w).abs().max().item(), w.abs().max().item())
+    for m, r in zip(proj, ref):
+        if isinstance(m, torch.nn.BatchNorm1d):
+            assert torch.allclose(m.running_mean, r.running_mean, atol=1e-6, rtol=1e-5)
+            assert torch.allclose(m.running_var, r.running_var, atol=1e-6, rtol=1e-5)
+            assert int(m.num_batches_tracked) == int(r.num_batches_tracked) == 4
+    # the same call with the switch that keeps nn.BatchNorm1d: the torch form of the pair is still there and agrees
+    vicreg.PROJECT_PAIR_TORCH = True
+    try:
+        ta, tb = vicreg.project_pair(copy.deepcopy(ref), a, b)
+    finally:
+        vicreg.PROJECT_PAIR_TORCH = False
+    ra2, rb2 = copy.deepcopy(ref)(a), None
+    assert (ta - ra2).abs().max().item() <= tol * scale
