@@ -417,6 +417,10 @@ int ias_conv2x2_patches_backward(const float* gp, float* gx, int B, int H, int W
  * no permuted copy); IAS_ERR_UNSUPPORTED when H W > 255 */
 int ias_conv2x2_patches_nchw(const float* x, float* patches, int B, int H, int W, int C, void* stream);
 int ias_conv2x2_patches_backward_nchw(const float* gp, float* gx, int B, int H, int W, int C, void* stream);
+/* column sums of a row-major fp32 [rows, cols] matrix in a fixed order (the bias gradient g.sum(0) of the head
+ * convolutions run as GEMMs); scratch: ias_colsum_scratch_floats(rows, cols) floats */
+long long ias_colsum_scratch_floats(int rows, int cols);
+int ias_colsum(const float* a, float* out, float* scratch, int rows, int cols, void* stream);
 int ias_stem_forward(const float* x, const float* w, float* out, int B, int H, int W, void* stream);
 long long ias_stem_weight_scratch(int B);                     /* floats */
 int ias_stem_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int H, int W, void* stream);

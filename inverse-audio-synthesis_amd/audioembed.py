@@ -79,7 +79,11 @@ class _Conv2x2Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = torch.mm(g2.t(), patches).view_as(weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g2.sum(0)
+            g2c = g2.contiguous()
+            gb = torch.empty(Cout, dtype=torch.float32, device=g.device)
+            scratch = torch.empty(int(lib.ias_colsum_scratch_floats(g2c.shape[0], Cout)), dtype=torch.float32, device=g.device)
+            _lib.check(lib.ias_colsum(_lib.ptr(g2c), _lib.ptr(gb), _lib.ptr(scratch), g2c.shape[0], Cout, _lib.stream()),
+                       "ias_colsum")
         return gx, gw, gb, None
 
 

@@ -1141,3 +1141,57 @@ extern "C" int ias_conv2x2_patches_backward_nchw(const float* gp, float* gx, int
                      (hipStream_t)stream_, gp, gx, H, W, C);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
+
+// ---- column sums of a row-major [rows, cols] matrix: the bias gradient of the head's convolutions-as-GEMMs
+// (audioembed._Conv2x2Fn.backward: g2.sum(0), rows = B Ho Wo up to 6272, cols = dim).  torch's reduction zero-fills the
+// result and runs a split reduction (5 + 8..21 us); here: S row slices x 32-column tiles, 8 rows in flight per thread,
+// then a fixed-order sum of the S partial rows (deterministic; two short launches).
+#define CS_CT 32
+#define CS_RG 8
+__global__ __launch_bounds__(CS_CT * CS_RG) void colsum_partial_kernel(const float* __restrict__ a, float* __restrict__ partial,
+                                                                        int rows, int cols, int rows_per_slice) {
+  __shared__ float red[CS_RG][CS_CT];
+  const int tx = threadIdx.x % CS_CT, ty = threadIdx.x / CS_CT;
+  const int c = blockIdx.x * CS_CT + tx, cc = min(c, cols - 1);
+  const int r0 = blockIdx.y * rows_per_slice, r1 = min(rows, r0 + rows_per_slice);
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  int r = r0 + ty;
+  for (; r + 3 * CS_RG < r1; r += 4 * CS_RG)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += a[(size_t)(r + k * CS_RG) * cols + cc];
+  for (; r < r1; r += CS_RG) acc[0] += a[(size_t)r * cols + cc];
+  red[ty][tx] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    float s = red[0][tx];
+#pragma unroll
+    for (int k = 1; k < CS_RG; ++k) s += red[k][tx];
+    partial[(size_t)blockIdx.y * cols + c] = s;
+  }
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int S,
+                                                            int cols) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = partial[c];
+  for (int k = 1; k < S; ++k) s += partial[(size_t)k * cols + c];
+  out[c] = s;
+}
+static int colsum_slices(int rows) {
+  const int s = (rows + 63) / 64;               // >= 64 rows per slice (8 per thread)
+  return s < 1 ? 1 : (s > 64 ? 64 : s);
+}
+// scratch: ias_colsum_scratch_floats(rows, cols) floats
+extern "C" long long ias_colsum_scratch_floats(int rows, int cols) {
+  if (rows <= 0 || cols <= 0) return IAS_ERR_ARG;
+  return (long long)colsum_slices(rows) * cols;
+}
+extern "C" int ias_colsum(const float* a, float* out, float* scratch, int rows, int cols, void* stream_) {
+  if (!a || !out || !scratch || rows <= 0 || cols <= 0) return IAS_ERR_ARG;
+  const int S = colsum_slices(rows);
+  const int rps = (rows + S - 1) / S;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + CS_CT - 1) / CS_CT, S), dim3(CS_CT * CS_RG), 0, (hipStream_t)stream_, a,
+                     scratch, rows, cols, rps);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream_, scratch, out, S, cols);
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}

@@ -6,6 +6,7 @@ asserts, paramembed.py:13-18).  Submodule names (lin1, norm1, do1, lin2, norm2, 
 state_dicts interchange.  Tiny GEMMs: stays on torch.nn (rocBLAS), SURVEY.md section 8(b).
 """
 import torch.nn as nn
+import torch.nn.functional as F
 from torch import Tensor
 
 _NORMS = {"nn.BatchNorm1d": nn.BatchNorm1d, "nn.Identity": lambda _dim: nn.Identity()}
@@ -14,6 +15,18 @@ _NORMS = {"nn.BatchNorm1d": nn.BatchNorm1d, "nn.Identity": lambda _dim: nn.Ident
 def _hidden_norm(kind, dim):
     assert kind in _NORMS, f"hidden_norm must be one of {sorted(_NORMS)}"
     return _NORMS[kind](dim)
+
+
+def linear_norm(lin, norm, x):
+    """``norm(lin(x))``.  Training on the GPU with nn.BatchNorm1d: the GEMM without its bias + ONE launch that adds the bias,
+    takes the batch statistics, updates the running ones and their counter and normalises (vicreg._BN1dGroupsFn with one
+    row group; its backward is one launch that also returns the Linear bias' gradient) instead of torch's counter add,
+    statistics, finalize and transform launches and a column-sum launch for the bias gradient."""
+    from .vicreg import _BN1dGroupsFn, _bn1d_hip_ok
+    if x.dim() == 2 and _bn1d_hip_ok(norm, x, x.shape[0]):
+        return _BN1dGroupsFn.apply(F.linear(x, lin.weight), lin.bias, norm.weight, norm.bias, norm.running_mean,
+                                   norm.running_var, norm.num_batches_tracked, norm.eps, norm.momentum, 1, False)
+    return norm(lin(x))
 
 
 class ParamEmbed(nn.Module):
@@ -30,8 +43,8 @@ class ParamEmbed(nn.Module):
         self.lin3 = nn.Linear(dim, dim)
 
     def forward(self, x: Tensor) -> Tensor:
-        h = self.relu(self.do1(self.norm1(self.lin1(x))))
-        h = self.relu(self.do2(self.norm2(self.lin2(h))))
+        h = self.relu(self.do1(linear_norm(self.lin1, self.norm1, x)))
+        h = self.relu(self.do2(linear_norm(self.lin2, self.norm2, h)))
         return self.lin3(h)
 
 
@@ -52,6 +65,6 @@ class AudioRepresentationToParams(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, x: Tensor) -> Tensor:
-        h = self.relu(self.do1(self.norm1(self.lin1(x))))
-        h = self.relu(self.do2(self.norm2(self.lin2(h))))
+        h = self.relu(self.do1(linear_norm(self.lin1, self.norm1, x)))
+        h = self.relu(self.do2(linear_norm(self.lin2, self.norm2, h)))
         return self.sigmoid(self.lin3(h))

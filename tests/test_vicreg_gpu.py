@@ -278,3 +278,37 @@ def test_project_pair_fused_batchnorm_matches_two_projector_calls(lib, dev, n, w
         vicreg.PROJECT_PAIR_TORCH = False
     ra2, rb2 = copy.deepcopy(ref)(a), None
     assert (ta - ra2).abs().max().item() <= tol * scale
+
+
+@pytest.mark.parametrize("B,dim", [(128, 256), (7, 40)])
+def test_paramembed_fused_linear_batchnorm_matches_torch(lib, dev, B, dim):
+    """ParamEmbed / AudioRepresentationToParams in training mode on the GPU (Linear -> BatchNorm1d as a GEMM without bias +
+    ias_bn1d_groups_* with one row group) against the same modules on nn.BatchNorm1d (reference paramembed.py:20-40,
+    audio_to_params.py:16-53): outputs, parameter gradients, running statistics and counters; dropout 0 so that the two
+    runs see the same mask."""
+    import copy
+    from inverse_audio_synthesis_amd import vicreg
+    from inverse_audio_synthesis_amd.paramembed import AudioRepresentationToParams, ParamEmbed
+    torch.manual_seed(2)
+    for mod, x in ((ParamEmbed(78, dim, "nn.BatchNorm1d", 0.0), torch.rand(B, 78)),
+                   (AudioRepresentationToParams(78, dim, "nn.BatchNorm1d", 0.0), randn((B, dim), 9))):
+        mod = mod.to(dev).train()
+        ref = copy.deepcopy(mod)
+        x = x.to(dev)
+        y = mod(x)
+        vicreg.PROJECT_PAIR_TORCH = True
+        try:
+            r = ref(x)
+        finally:
+            vicreg.PROJECT_PAIR_TORCH = False
+        assert (y - r).abs().max().item() <= 2e-5 * max(1.0, r.abs().max().item())
+        w = randn(tuple(r.shape), 10).to(dev)
+        got = torch.autograd.grad((y * w).sum(), list(mod.parameters()))
+        want = torch.autograd.grad((r * w).sum(), list(ref.parameters()))
+        for (k, _), g, t in zip(mod.named_parameters(), got, want):
+            assert (g - t).abs().max().item() <= 2e-4 * max(1.0, t.abs().max().item()), k
+        for m, t in zip(mod.modules(), ref.modules()):
+            if isinstance(m, torch.nn.BatchNorm1d):
+                assert torch.allclose(m.running_mean, t.running_mean, atol=1e-6, rtol=1e-5)
+                assert torch.allclose(m.running_var, t.running_var, atol=1e-6, rtol=1e-5)
+                assert int(m.num_batches_tracked) == int(t.num_batches_tracked) == 1
