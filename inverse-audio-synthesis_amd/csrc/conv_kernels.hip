@@ -1154,13 +1154,13 @@ __global__ __launch_bounds__(CS_CT * CS_RG) void colsum_partial_kernel(const flo
   const int tx = threadIdx.x % CS_CT, ty = threadIdx.x / CS_CT;
   const int c = blockIdx.x * CS_CT + tx, cc = min(c, cols - 1);
   const int r0 = blockIdx.y * rows_per_slice, r1 = min(rows, r0 + rows_per_slice);
-  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   int r = r0 + ty;
-  for (; r + 3 * CS_RG < r1; r += 4 * CS_RG)
+  for (; r + 7 * CS_RG < r1; r += 8 * CS_RG)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] += a[(size_t)(r + k * CS_RG) * cols + cc];
+    for (int k = 0; k < 8; ++k) acc[k] += a[(size_t)(r + k * CS_RG) * cols + cc];
   for (; r < r1; r += CS_RG) acc[0] += a[(size_t)r * cols + cc];
-  red[ty][tx] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  red[ty][tx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
   if (ty == 0 && c < cols) {
     float s = red[0][tx];
@@ -1173,13 +1173,17 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
                                                             int cols) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= cols) return;
-  float s = partial[c];
-  for (int k = 1; k < S; ++k) s += partial[(size_t)k * cols + c];
+  float v[16];                                   // S <= 16 (colsum_slices): every load in flight before the first add
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = k < S ? partial[(size_t)k * cols + c] : 0.0f;
+  float s = v[0];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) s += v[k];
   out[c] = s;
 }
 static int colsum_slices(int rows) {
-  const int s = (rows + 63) / 64;               // >= 64 rows per slice (8 per thread)
-  return s < 1 ? 1 : (s > 64 ? 64 : s);
+  const int s = (rows + 63) / 64;               // >= 64 rows per slice (8 per thread), at most 16 slices
+  return s < 1 ? 1 : (s > 16 ? 16 : s);
 }
 // scratch: ias_colsum_scratch_floats(rows, cols) floats
 extern "C" long long ias_colsum_scratch_floats(int rows, int cols) {

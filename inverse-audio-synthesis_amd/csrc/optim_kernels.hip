@@ -100,7 +100,9 @@ __global__ __launch_bounds__(LARS_THREADS) void lars_update_kernel(const long lo
                                                                     const float* __restrict__ coef,
                                                                     const float* __restrict__ hyper,
                                                                     double* __restrict__ partials) {
-  const int c = blockIdx.x, t = chunks[2 * c], ci = chunks[2 * c + 1];
+  // chunks in DESCENDING order: the norm pass in front read the gradients in ascending order, so the last ~200 MB it
+  // touched are what the 256 MB memory-side cache still holds -- the update starts with those
+  const int c = gridDim.x - 1 - blockIdx.x, t = chunks[2 * c], ci = chunks[2 * c + 1];
   float* p = reinterpret_cast<float*>(tensors[3 * t]);
   const float* g = reinterpret_cast<const float*>(tensors[3 * t + 1]);
   const long long n = tensors[3 * t + 2];
