@@ -709,6 +709,107 @@ __global__ __launch_bounds__(CV_THREADS) void stem_bwd_weight_mfma_kernel(const 
   }
 }
 
+// The same GEMM with its operands staged through LDS (round 5).  The kernel above gathers 48 scalars per lane and 64 positions
+// straight from global memory, 16-32 cache lines per load instruction: 122 us inside the training step for 211 MB (35 us of
+// HBM time).  Here a wave copies what an output row needs -- the 9 input rows (3 channels x rows 2 ho - 1 .. 2 ho + 1, zero
+// padded left, right and outside the image) and the 16 rows of g -- with whole 256-byte loads into an LDS block of its own
+// (no workgroup barrier: LDS operations of one wave execute in order) and feeds the matrix cores from there.  Bank layout:
+// input rows at a stride = 3 (mod 32) floats put tap t of position p in bank t + 2 p, g rows at a stride = 1 (mod 32) put
+// channel m in bank m + p; with k-slot (q, s) <-> position w0 + 8 q + (s & 7) + 32 (s >> 3) the 64 lanes of either operand
+// read fall on all 32 banks twice -- the minimum.
+#define STEM_STAGE_THREADS 128
+// XI, GI: 64-float pieces per staged input row / g row (compile-time: every load of a row set is issued before the first
+// is waited for, and the NEXT output row's loads are in flight while the matrix cores work on the current one -- with the
+// trip counts at run time the compiler waited for each load before the LDS write behind it: 265 us instead of the 122 us
+// of the gather form).
+template <int CIN, int COUT, int XI, int GI>
+__global__ __launch_bounds__(STEM_STAGE_THREADS) void stem_bwd_weight_stage_kernel(
+    const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial, int B, int H, int W, int Ho, int Wo,
+    int chunks, int rows_per_chunk, int XS, int GS) {
+  static_assert(COUT == 16 && CIN * 9 <= 32, "one 16-row tile of output channels, two 16-column tiles of taps");
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  constexpr int NT = CIN * 9, NR = CIN * 3, GW = 64 * GI;
+  extern __shared__ float s_stem[];
+  const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (STEM_STAGE_THREADS / 64) + wib;
+  if (wave >= B * chunks) return;                        // (no workgroup barrier in this kernel)
+  float* xs = s_stem + (size_t)wib * (NR * XS + COUT * GS);
+  float* gs = xs + NR * XS;
+  const int b = wave / chunks, chunk = wave - b * chunks;
+  const int m = lane & 15, q = lane >> 4;
+  const int t1 = m + 16;
+  const bool t1ok = t1 < NT;
+  const int x0 = (m / 3) * XS + m % 3;                   // tap t: input row t / 3 (= 3 ci + kh), column offset kw = t % 3
+  const int x1 = t1ok ? (t1 / 3) * XS + t1 % 3 : 0;
+  const float* xb = x + (size_t)b * CIN * H * W;
+  const float* gb = g + (size_t)b * COUT * Ho * Wo;
+  v4f acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int ho_end = min(Ho, (chunk + 1) * rows_per_chunk);
+  float xr[NR][XI], gr[COUT][GI];
+  auto fetch = [&](int ho) {                             // xs[r][i] = x[ci][2 ho + kh - 1][i - 1] or 0 ; gs[co][i] = g[co][ho][i] or 0
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int hi = 2 * ho + r % 3 - 1;
+      const bool rv = hi >= 0 && hi < H;
+      const float* src = xb + ((size_t)(r / 3) * H + (rv ? hi : 0)) * W;
+#pragma unroll
+      for (int k = 0; k < XI; ++k) {
+        const int i = lane + 64 * k;
+        xr[r][k] = (rv && i >= 1 && i <= W) ? src[i - 1] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      const float* src = gb + ((size_t)co * Ho + ho) * Wo;
+#pragma unroll
+      for (int k = 0; k < GI; ++k) {
+        const int i = lane + 64 * k;
+        gr[co][k] = i < Wo ? src[i] : 0.0f;
+      }
+    }
+  };
+  int ho = chunk * rows_per_chunk;
+  if (ho < ho_end) fetch(ho);
+  for (; ho < ho_end; ++ho) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int k = 0; k < XI; ++k)
+        if (lane + 64 * k < XS) xs[r * XS + lane + 64 * k] = xr[r][k];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+#pragma unroll
+      for (int k = 0; k < GI; ++k) gs[co * GS + lane + 64 * k] = gr[co][k];
+    if (ho + 1 < ho_end) fetch(ho + 1);                  // in flight during the products below
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int w0 = 0; w0 < GW; w0 += 64) {
+      float a[16], b0[16], b1[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int pos = w0 + 8 * q + (s & 7) + 32 * (s >> 3);
+        a[s] = gs[m * GS + pos];
+        b0[s] = xs[x0 + 2 * pos];
+        b1[s] = t1ok ? xs[x1 + 2 * pos] : 0.0f;
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b0[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[s], acc1, 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  float* pp = partial + (size_t)wave * (COUT * NT);     // D[co = 4 q + reg][tap = m (+16)]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    pp[(4 * q + r) * NT + m] = acc0[r];
+    if (t1ok) pp[(4 * q + r) * NT + t1] = acc1[r];
+  }
+}
+
 // The stem forward on the matrix cores: out[co][pos] = sum_tap w[co][tap] xcol[tap][pos] with M = 16 output channels,
 // K = 27 taps (7 k-steps of 4, the last tap slot zero), N = 16 positions per tile.  One wave per output row (b, ho);
 // lane (n, q) keeps its 7 weights w[co = n][tap = 4 ks + q] in registers and reads the tap's input of position
@@ -997,6 +1098,23 @@ extern "C" int ias_stem_backward_weight(const float* x, const float* g, float* g
 #endif
   {
     const int waves = B * STEM_CHUNKS_X, rows_per_chunk = (Ho + STEM_CHUNKS_X - 1) / STEM_CHUNKS_X;
+    // LDS-staged form: strides = 3 and = 1 (mod 32) floats; the input rows reach past the last position a tile reads
+    const int GW = (Wo + 63) / 64 * 64;
+    int XS = 2 * GW + 2 > W + 2 ? 2 * GW + 2 : W + 2, GS = GW;
+    while (XS % 32 != 3) ++XS;
+    while (GS % 32 != 1) ++GS;
+    const size_t lds = (size_t)(STEM_STAGE_THREADS / 64) * (9 * XS + 16 * GS) * sizeof(float);
+    if (GW == 128 && XS <= 320 && lds <= 65536 && !ias_diag_env("IAS_STEM_GW_GATHER")) {
+      // half as many chunks as the gather form: 8 resident waves per CU (LDS) x 256 CUs hold B = 128 samples in one round,
+      // and only the first of a wave's 8 rows is fetched with nothing to hide behind
+      const int sc = STEM_CHUNKS_X / 2, swaves = B * sc, srows = (Ho + sc - 1) / sc;
+      hipLaunchKernelGGL((stem_bwd_weight_stage_kernel<3, 16, 5, 2>),
+                         dim3((swaves + STEM_STAGE_THREADS / 64 - 1) / (STEM_STAGE_THREADS / 64)), dim3(STEM_STAGE_THREADS), lds,
+                         (hipStream_t)stream_, x, g, scratch, B, H, W, Ho, Wo, sc, srows, XS, GS);
+      hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((432 + 3) / 4), dim3(CV_THREADS), 0, (hipStream_t)stream_, scratch, gw,
+                         432, swaves);
+      return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+    } else
     hipLaunchKernelGGL((stem_bwd_weight_mfma_kernel<3, 16>), dim3((waves + CV_THREADS / 64 - 1) / (CV_THREADS / 64)),
                        dim3(CV_THREADS), 0, (hipStream_t)stream_, x, g, scratch, B, H, W, Ho, Wo, STEM_CHUNKS_X,
                        rows_per_chunk);
