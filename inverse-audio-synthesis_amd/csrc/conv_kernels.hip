@@ -866,6 +866,85 @@ __global__ __launch_bounds__(CV_THREADS) void stem_fwd_mfma_kernel(const float* 
   }
 }
 
+// The stem forward with its input rows staged the same way (round 5): a wave owns a run of output rows of one sample,
+// copies the 9 input rows of an output row into its own LDS block with whole 256-byte loads -- the next row's loads in
+// flight while the matrix cores work on the current one -- and reads the taps from there (tap t of position p in bank
+// t + 2 p: lane (n, q) reads tap 4 ks + q of position wo0 + n, two lanes per bank).  The gather form above touches ~16 cache
+// lines per load instruction.
+template <int CIN, int COUT, int XI>
+__global__ __launch_bounds__(CV_THREADS) void stem_fwd_stage_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    float* __restrict__ out, int B, int H, int W, int Ho, int Wo,
+                                                                    int chunks, int rows_per_chunk, int XS) {
+  static_assert(COUT == 16 && CIN * 9 <= 28, "one 16-row tile of output channels, 7 k-steps of taps");
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  constexpr int NT = CIN * 9, KS = 7, NR = CIN * 3;
+  extern __shared__ float s_stem[];
+  const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (CV_THREADS / 64) + wib;
+  if (wave >= B * chunks) return;                        // (no workgroup barrier in this kernel)
+  float* xs = s_stem + (size_t)wib * (NR * XS);
+  const int b = wave / chunks, chunk = wave - b * chunks;
+  const int n = lane & 15, q = lane >> 4;
+  float aw[KS];
+  int xo[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int tap = 4 * ks + q;
+    const bool tv = tap < NT;
+    aw[ks] = tv ? w[n * NT + tap] : 0.0f;
+    xo[ks] = tv ? (tap / 3) * XS + tap % 3 : 0;          // (a tap beyond the 27 multiplies a zero weight)
+  }
+  const float* xb = x + (size_t)b * CIN * H * W;
+  float xr[NR][XI];
+  auto fetch = [&](int ho) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int hi = 2 * ho + r % 3 - 1;
+      const bool rv = hi >= 0 && hi < H;
+      const float* src = xb + ((size_t)(r / 3) * H + (rv ? hi : 0)) * W;
+#pragma unroll
+      for (int k = 0; k < XI; ++k) {
+        const int i = lane + 64 * k;
+        xr[r][k] = (rv && i >= 1 && i <= W) ? src[i - 1] : 0.0f;
+      }
+    }
+  };
+  const int ho_end = min(Ho, (chunk + 1) * rows_per_chunk);
+  int ho = chunk * rows_per_chunk;
+  if (ho < ho_end) fetch(ho);
+  for (; ho < ho_end; ++ho) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int k = 0; k < XI; ++k)
+        if (lane + 64 * k < XS) xs[r * XS + lane + 64 * k] = xr[r][k];
+    if (ho + 1 < ho_end) fetch(ho + 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* ob = out + ((size_t)b * COUT * Ho + ho) * Wo;
+    for (int wo0 = 0; wo0 < Wo; wo0 += 32) {
+      const int wa = wo0 + n, wb = wo0 + 16 + n;
+      v4f acc_a = {0.0f, 0.0f, 0.0f, 0.0f}, acc_b = {0.0f, 0.0f, 0.0f, 0.0f};
+      float va[KS], vb[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) { va[ks] = xs[xo[ks] + 2 * wa]; vb[ks] = xs[xo[ks] + 2 * wb]; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[ks], va[ks], acc_a, 0, 0, 0);
+        acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[ks], vb[ks], acc_b, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* oc = ob + (size_t)(4 * q + r) * Ho * Wo;
+        if (wa < Wo) oc[wa] = acc_a[r];
+        if (wb < Wo) oc[wb] = acc_b[r];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------------ C ABI
 static int cv_grid_x(int n) {
   int g = (n + CV_THREADS - 1) / CV_THREADS;
@@ -1076,6 +1155,19 @@ extern "C" int ias_stem_forward(const float* x, const float* w, float* out, int 
                        out, H, W, Ho, Wo);
   } else {
     const int rows = B * Ho;
+    // LDS-staged form: input rows at a stride = 3 (mod 32) floats that covers the last position a 32-wide tile reads
+    const int GW = (Wo + 31) / 32 * 32;
+    int XS = 2 * GW + 2 > W + 2 ? 2 * GW + 2 : W + 2;
+    while (XS % 32 != 3) ++XS;
+    if (XS <= 320 && !ias_diag_env("IAS_STEM_FWD_GATHER")) {
+      // two output rows per wave: in the step 15 / 30 / 60 / 120 chunks of the 120 rows measured 59 / 53 / 50 / 50 us
+      int chunks = Ho >= 60 ? 60 : 1;
+      if (const char* e = ias_diag_env("IAS_STEM_FWD_CHUNKS")) chunks = atoi(e);
+      const int rpc = (Ho + chunks - 1) / chunks, waves = B * chunks;
+      const size_t lds = (size_t)(CV_THREADS / 64) * 9 * XS * sizeof(float);
+      hipLaunchKernelGGL((stem_fwd_stage_kernel<3, 16, 5>), dim3((waves + CV_THREADS / 64 - 1) / (CV_THREADS / 64)),
+                         dim3(CV_THREADS), lds, (hipStream_t)stream_, x, w, out, B, H, W, Ho, Wo, chunks, rpc, XS);
+    } else
     hipLaunchKernelGGL((stem_fwd_mfma_kernel<3, 16>), dim3((rows + CV_THREADS / 64 - 1) / (CV_THREADS / 64)),
                        dim3(CV_THREADS), 0, (hipStream_t)stream_, x, w, out, rows, H, W, Ho, Wo);
   }
