@@ -292,19 +292,6 @@ int ias_stft_grad_spans(const float* audio, const float* tables, const int* mel_
  * reflect-folded chunk spans.  spans_host: HOST array of nres <= 8 device pointers; plans_host: HOST ints [nres][5] =
  * {n_fft, hop, plan[0], plan[1], plan[2]}. */
 int ias_stft_grad_span_plan(int B, int T, int n_fft, int hop, int mel_nnz, int n_out, int* plan_host);
-/* Round 5: the MR-STFT loss (audio_to_params.py:233, auraloss) without the backward's second transform.  ias_stft_spec is
- * ias_stft for linear bins (mel_* = mtables = segtab = NULL, n_out = n_fft/2+1) that also writes the complex spectrum
- * spec [B,F,n_fft/2+1][2] fp32 (X of audio / peak, natural bin order; 8-byte aligned; out may be NULL with loss_mode 0);
- * ias_stft_grad_spans_spec is ias_stft_grad_spans reading that spectrum instead of the audio (window, three forward
- * passes, two LDS exchanges and the unpack per frame are not executed: the gradient step is bound by its vector and LDS
- * pipes, not by HBM); its chunk plan comes from ias_stft_grad_span_plan_spec.  IAS_ERR_UNSUPPORTED: shape not served. */
-int ias_stft_spec(const float* audio, const float* tables, float* out, const float* target, double* partials,
-                  const float* rowpeak, float* spec, int B, int T, int n_fft, int hop, int value_mode, int loss_mode,
-                  float eps, void* stream);
-int ias_stft_grad_span_plan_spec(int B, int T, int n_fft, int hop, int* plan_host);
-int ias_stft_grad_spans_spec(const float* spec, const float* tables, const float* target, const double* coef,
-                             float* chunk_spans, int B, int T, int n_fft, int hop, int power, int loss_mode, float scale,
-                             float eps, int* plan_host, void* stream);
 int ias_stft_grad_combine(const float* const* spans_host, const int* plans_host, int nres, const float* g_loss,
                           float* g_audio, int B, int T, void* stream);
 

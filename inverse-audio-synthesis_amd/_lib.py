@@ -80,9 +80,6 @@ SYMBOLS = {
     "ias_stft_grad_spans": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, ctypes.c_float,
                                 ctypes.c_float, _P, _P]),
     "ias_stft_grad_span_plan": (_I, [_I, _I, _I, _I, _I, _I, _P]),
-    "ias_stft_spec": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
-    "ias_stft_grad_span_plan_spec": (_I, [_I, _I, _I, _I, _P]),
-    "ias_stft_grad_spans_spec": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
     "ias_stft_grad_combine": (_I, [_P, _P, _I, _P, _P, _I, _I, _P]),
     "ias_reduce_partials": (_I, [_P, _LL, _P, _c.c_double, _P, _P]),
     "ias_mrstft_total": (_I, [_P, _P, _I, _P, _P]),

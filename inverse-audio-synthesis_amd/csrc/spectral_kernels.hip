@@ -517,8 +517,6 @@ struct Spec2Args {
   const float* target;     // [B,F,n_out] or null
   double* partials;        // [gridDim.x][3] or null
   const float* rowpeak;    // [B] or null
-  cpx* spec;               // linear bins only: [B,F,n_fft/2+1] complex spectrum X (of audio / peak) or null (round 5: saved
-                           // for the backward of the MR-STFT loss, which otherwise transforms every frame a second time)
   int T, F, hop, n_out, nframes;
   unsigned magicF;         // floor(2^32 / F)
   int value_mode, loss_mode;
@@ -608,9 +606,7 @@ template <int NSUB> __device__ __forceinline__ void stft2_load_frame(const float
 #define S2X_UP(i) ((i) + S2X_PAD * ((i) >> 3))
 static_assert(64 * S2X_ROW <= 64 * IAS_S2_ROW && 256 + S2X_PAD * 32 <= 64 * IAS_S2_ROW, "stft2 scratch indexing fits the wave's scratch");
 template <int SP_WAVES, bool MEL, int LOSS, int NSUB>
-// (linear bins: 4 waves per SIMD -- the spectrum stores of the gradient step's forward need a few registers more, and that
-// kernel never runs beside the persistent render)
-__global__ __launch_bounds__(64 * SP_WAVES, NSUB == 2 ? 3 * SP_WAVES / 8 : (SP_WAVES >= 8 ? (SP_WAVES == 8 ? (MEL ? IAS_STFT2_MINW : 4) : SP_WAVES / 2) : (3 * SP_WAVES + 3) / 4))
+__global__ __launch_bounds__(64 * SP_WAVES, NSUB == 2 ? 3 * SP_WAVES / 8 : (SP_WAVES >= 8 ? (SP_WAVES == 8 ? IAS_STFT2_MINW : SP_WAVES / 2) : (3 * SP_WAVES + 3) / 4))
 void stft2_kernel(const Spec2Args a) {
   static_assert(NSUB == 1 || (NSUB == 2 && !MEL), "mel filterbanks: n_fft 1024 only");
   constexpr int SP_THREADS = 64 * SP_WAVES, N2 = 512 * NSUB, R = 8, SCR = 64 * IAS_S2_ROW, NPK = 4 * NSUB, HALF = N2 / 2;
@@ -695,8 +691,8 @@ void stft2_kernel(const Spec2Args a) {
       stft2_load_frame<NSUB>(a.audio + (size_t)bnext * a.T, a.T, a.hop, fnext, lane, xn);
       if (a.rowpeak != nullptr) pk_next = a.rowpeak[bnext];
     }
-    float pscale = 0.25f, xs = 0.5f;          // |.|^2 and amplitude scale of the packed transform's (2 X), times 1 / peak
-    if (pk_cur > 1.0f) { const float r = __builtin_amdgcn_rcpf(pk_cur); pscale = 0.25f * (r * r); xs = 0.5f * r; }
+    float pscale = 0.25f;
+    if (pk_cur > 1.0f) { const float r = __builtin_amdgcn_rcpf(pk_cur); pscale = 0.25f * (r * r); }
     const size_t row = (size_t)fi * a.n_out;
     // MEL: the frame's target row is requested now and consumed after the transform
     float tgt_m[3] = {0.f, 0.f, 0.f};
@@ -792,12 +788,7 @@ void stft2_kernel(const Spec2Args a) {
       const float xr = ea + tx, xi = eb + ty, yr = ea - tx, yi = eb - ty;
       pk[e] = fmaf(xi, xi, xr * xr) * pscale;
       pn[e] = fmaf(yi, yi, yr * yr) * pscale;
-      if (!MEL && a.spec != nullptr) {                       // X[k] = (xr + i xi) / 2, X[N2 - k] = (yr - i yi) / 2
-        a.spec[row + k] = cmk(xs * xr, xs * xi);
-        a.spec[row + N2 - k] = cmk(xs * yr, -xs * yi);
-      }
     }
-    if (!MEL && a.spec != nullptr && lane == 0) a.spec[row + HALF] = cmk(2.0f * xs * zhi[0].x, -2.0f * xs * zhi[0].y);   // conj Z[HALF]
     float pmid = fmaf(zhi[0].y, zhi[0].y, zhi[0].x * zhi[0].x) * (4.0f * pscale);    // lane 0: |Z[HALF]|^2
     if (a.value_mode == 1) {
 #pragma unroll
@@ -966,8 +957,8 @@ void stft2h_kernel(const Spec2Args a) {
     const bool own = fr == 0 || 2 * pi + 1 < a.nframes;                // this lane's frame exists
     const int fi = own ? 2 * pi + fr : 2 * pi;
     const size_t row = (size_t)fi * a.n_out;
-    float pscale = 0.25f, xs = 0.5f;
-    if (a.rowpeak != nullptr) { const float pkv = a.rowpeak[fr ? bB : bA]; if (pkv > 1.0f) { const float r = __builtin_amdgcn_rcpf(pkv); pscale = 0.25f * (r * r); xs = 0.5f * r; } }
+    float pscale = 0.25f;
+    if (a.rowpeak != nullptr) { const float pkv = a.rowpeak[fr ? bB : bA]; if (pkv > 1.0f) { const float r = __builtin_amdgcn_rcpf(pkv); pscale = 0.25f * (r * r); } }
     float tg_k[4], tg_n[4], tg_mid = 0.f;
     if (LOSS != 0) {
 #pragma unroll
@@ -1021,12 +1012,7 @@ void stft2h_kernel(const Spec2Args a) {
       const float xr = ea + tx, xi = eb + ty, yr = ea - tx, yi = eb - ty;
       pk[e] = fmaf(xi, xi, xr * xr) * pscale;
       pn[e] = fmaf(yi, yi, yr * yr) * pscale;
-      if (a.spec != nullptr && own) {                        // X[k] = (xr + i xi) / 2, X[N2 - k] = (yr - i yi) / 2
-        a.spec[row + k] = cmk(xs * xr, xs * xi);
-        a.spec[row + N2 - k] = cmk(xs * yr, -xs * yi);
-      }
     }
-    if (a.spec != nullptr && own && kl == 0) a.spec[row + HALF] = cmk(2.0f * xs * u[4].x, -2.0f * xs * u[4].y);   // conj Z[HALF]
     float pmid = fmaf(u[4].y, u[4].y, u[4].x * u[4].x) * (4.0f * pscale);    // lanes with kl = 0: |Z[128]|^2
     if (a.value_mode == 1) {
 #pragma unroll
@@ -1089,7 +1075,6 @@ struct SgwArgs {
   int T, F, hop, groups, power2, loss_mode, n_out, mel_nnz;
   float scale, eps;
   int G, cper, L, nchunks;   // SPAN kernels: frames per chunk, chunks per row, floats per chunk span, B * cper
-  const cpx* spec;           // FROMSPEC kernels: the forward's saved spectrum [B,F,n_fft/2+1] (ias_stft_spec), else unused
 };
 
 // MEL: the loss is taken on O = melW^T V (loss_mode 1 only).  V goes to LDS, a lane computes two outputs with the
@@ -1102,12 +1087,8 @@ struct SgwArgs {
 // touches leave the ring for the chunk's span  frame_grad[chunk][L], L = (G - 1) hop + n_fft.  The [B,F,n_fft] tensor
 // (8.5 - 10 floats per audio sample, written here and read again by stft_grad_ola_kernel) shrinks to ~1.2 - 1.5
 // floats per sample; stft_grad_combine_kernel adds the two chunks that meet at a sample, lower chunk first.
-// FROMSPEC (round 5, linear bins): X[k] comes from the spectrum the forward saved (ias_stft_spec) instead of a second
-// transform of the frame -- the window, the three forward passes, their two LDS exchanges and the unpack are not executed;
-// 8 bytes per bin are read instead (the gradient step is bound by its vector and LDS pipes, HBM is at a tenth of its rate).
-template <int LOG2N, bool MEL, bool SPAN, bool FROMSPEC = false>
+template <int LOG2N, bool MEL, bool SPAN>
 __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
-  static_assert(!(FROMSPEC && MEL), "saved spectra: linear bins");
   constexpr int SP_WAVES = 4, SP_THREADS = 256;
   constexpr int NFFT = 1 << LOG2N, N2 = NFFT / 2, R = N2 / 64, NPAIR = 8 * R, NP_IT = (NPAIR + 63) / 64;
   constexpr int SCR = NPAIR * IAS_S2_ROW, NUNP = (N2 / 2) / 64 + 1, NB = N2 + 1;
@@ -1232,8 +1213,7 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
   const float* arow = a.audio + (size_t)b * a.T;
   float* span = a.frame_grad + (size_t)c * a.L;
   for (int f = f_lo; f < f_hi; f += SPAN ? 1 : SP_WAVES) {
-    if (!FROMSPEC) load_frame<R, N2>(arow, a.T, a.hop, f, lane, xc);
-    const cpx* srow = FROMSPEC ? a.spec + ((size_t)b * a.F + f) * NB : nullptr;
+    load_frame<R, N2>(arow, a.T, a.hop, f, lane, xc);
     const float* trow = a.target + ((size_t)b * a.F + f) * (MEL ? a.n_out : NB);
     // linear bins: the lane's target values are requested with the frame and consumed after the forward transform
     float tk_[NUNP], tq_[NUNP];
@@ -1246,11 +1226,9 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
       }
     }
     cpx v[R];
-    if (!FROMSPEC) {
 #pragma unroll
-      for (int n1 = 0; n1 < R; ++n1) v[n1] = cmk(xc[2 * n1], xc[2 * n1 + 1]) * t_win[64 * n1];
-      fft(v);
-    }
+    for (int n1 = 0; n1 < R; ++n1) v[n1] = cmk(xc[2 * n1], xc[2 * n1 + 1]) * t_win[64 * n1];
+    fft(v);
     // unpack per bin pair (k, N2 - k), k = lane + 64 i <= N2 / 2: X and V of both bins in registers
     cpx xk_[NUNP], xq_[NUNP];
     float vk_[NUNP], vq_[NUNP], gk_[NUNP], gq_[NUNP];
@@ -1260,9 +1238,6 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
       xk_[i] = xq_[i] = cmk(0.0f, 0.0f);
       vk_[i] = vq_[i] = gk_[i] = gq_[i] = 0.0f;
       if (k <= N2 / 2) {
-        if (FROMSPEC) {
-          xk_[i] = srow[k]; xq_[i] = srow[N2 - k];
-        } else {
         const int kn = (N2 - k) & (N2 - 1);
         const cpx zk = sA[IAS_S2_UP(k)], zn = sA[IAS_S2_UP(kn)];
         const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
@@ -1270,7 +1245,6 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
         const cpx t = cmul(t_twu[64 * i], zo);            // W_N^k Zo[k]
         xk_[i] = cadd(ze, t);                             // X[k]
         xq_[i] = cmk(ze.x - t.x, -(ze.y - t.y));          // X[N2 - k]
-        }
         vk_[i] = bin_value(xk_[i].x * xk_[i].x + xk_[i].y * xk_[i].y);
         vq_[i] = bin_value(xq_[i].x * xq_[i].x + xq_[i].y * xq_[i].y);
         if (!MEL) { gk_[i] = value_grad(vk_[i], tk_[i]); gq_[i] = value_grad(vq_[i], tq_[i]); }
@@ -1419,7 +1393,7 @@ __global__ __launch_bounds__(256) void stft_grad_wave_kernel(const SgwArgs a) {
 // SPAN: as in stft_grad_wave_kernel (a wave walks a chunk of G consecutive frames, overlap-add in an LDS ring, hop % 4
 // == 0).  The ring is kept in 16-byte units q = sample / 4 at slot q ^ ((q >> 3) & 7): the lanes' units m = k1 + 8 d
 // (+ 64 e) are 8 apart for consecutive lanes, the swizzle spreads them over the banks.
-template <int SP_WAVES, bool SPAN, bool FROMSPEC = false>
+template <int SP_WAVES, bool SPAN>
 __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void stft_grad2k_kernel(const SgwArgs a, int nframes, unsigned magicF) {
   constexpr int SP_THREADS = 64 * SP_WAVES, N2 = 1024, HALF = 512, NFFT = 2048, SCR = 64 * IAS_S2_ROW, NB = N2 + 1;
   constexpr int NTAB = 16 + 8 + 8 + 8 + 8 + 16;   // stft2's 2048 section + the window at the lane's OUTPUT samples
@@ -1496,8 +1470,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
   for (int fr = f_lo; fr < f_hi; ++fr) {
     const int fi = b * a.F + fr;
     float xc[32];
-    if (!FROMSPEC) stft2_load_frame<2>(a.audio + (size_t)b * a.T, a.T, a.hop, fr, lane, xc);
-    const cpx* srow = FROMSPEC ? a.spec + (size_t)fi * NB : nullptr;
+    stft2_load_frame<2>(a.audio + (size_t)b * a.T, a.T, a.hop, fr, lane, xc);
     const float* trow = a.target + (size_t)fi * NB;
     // the lane's target values are requested with the frame and consumed after the forward transform
     float tk_[8], tq_[8], th_ = 0.0f;
@@ -1506,7 +1479,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
     if (lane == 0) th_ = trow[HALF];
     // ---- forward: Z[k], Z[k + 512] for k = kl + 64 e
     cpx zlo[8], zhi[8];
-    if (!FROMSPEC) {
+    {
       cpx ue[8], u[8], v[8];
 #pragma unroll
       for (int n1 = 0; n1 < 8; ++n1) v[n1] = cmk(xc[2 * n1], xc[2 * n1 + 1]) * t_win[64 * n1];
@@ -1516,29 +1489,24 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
       fft512(v, u);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const cpx t = cmul(u[e], t_cmb[64 * e]); zlo[e] = cadd(ue[e], t); zhi[e] = csub(ue[e], t); }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sA[pad(kl + 64 * e)] = zhi[e];
-      wave_lds_sync();
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sA[pad(kl + 64 * e)] = zhi[e];
+    wave_lds_sync();
     // ---- per bin pair (k, N2 - k): X, value, cotangent, the pair's two inverse inputs
     cpx zk_in[8], zn_in[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = kl + 64 * e;
+      cpx zn = sA[pad((HALF - k) & (HALF - 1))];
+      const cpx zk = zlo[e];
+      if (e == 0 && k == 0) zn = zk;
       const cpx w = t_twu[64 * e];                              // W_N^k = e^{-2 pi i k / N}
-      cpx xk, xq;
-      if (FROMSPEC) {
-        xk = srow[k]; xq = srow[N2 - k];
-      } else {
-        cpx zn = sA[pad((HALF - k) & (HALF - 1))];
-        const cpx zk = zlo[e];
-        if (e == 0 && k == 0) zn = zk;
-        const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-        const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-        const cpx t = cmul(w, zo);
-        xk = cadd(ze, t);                                       // X[k]
-        xq = cmk(ze.x - t.x, -(ze.y - t.y));                    // X[N2 - k]
-      }
+      const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+      const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+      const cpx t = cmul(w, zo);
+      const cpx xk = cadd(ze, t);                               // X[k]
+      const cpx xq = cmk(ze.x - t.x, -(ze.y - t.y));            // X[N2 - k]
       const float vk = bin_value(xk.x * xk.x + xk.y * xk.y), vq = bin_value(xq.x * xq.x + xq.y * xq.y);
       const float gk = value_grad(vk, tk_[e]), gq = value_grad(vq, tq_[e]);
       const cpx ck = xk * (2.0f * power_grad(gk, vk));          // G[k]
@@ -1558,7 +1526,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
     // bin HALF pairs with itself: X[HALF] = conj(Z[HALF]) (lane 0 holds Z[HALF] = zhi[0])
     cpx zh_in;
     {
-      const cpx xh = FROMSPEC ? srow[HALF] : cmk(zhi[0].x, -zhi[0].y);
+      const cpx xh = cmk(zhi[0].x, -zhi[0].y);
       const float vh = bin_value(xh.x * xh.x + xh.y * xh.y);
       const float gh = value_grad(vh, th_);
       const cpx ch = xh * (2.0f * power_grad(gh, vh));
@@ -1648,7 +1616,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SPAN ? 2 : 3 * SP_WAVES / 8) void st
 // B), the inverse inputs Zin of both frames through the scratch in natural order, ONE more run of the three passes on
 // their conjugates, then frame A's lanes add their windowed samples into the ring, after them frame B's (frame order:
 // deterministic), and the 2 hop samples no later frame reaches leave the ring.
-template <int SP_WAVES, bool FROMSPEC = false>
+template <int SP_WAVES>
 __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 2) void stft_grad512_kernel(const SgwArgs a) {
   constexpr int SP_THREADS = 64 * SP_WAVES, SCR = 64 * IAS_S2_ROW, NFFT = 512, N2 = 256, HALF = 128, NB = 257;
   constexpr int NTAB = 4 + 4 + 8 + 4 + 8;    // stft2h's tables + the window at the lane's OUTPUT samples
@@ -1721,13 +1689,12 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 2) void stft_grad512_kern
       const bool hasB = f + 1 < f_hi;                         // wave-uniform
       const bool own = fr == 0 || hasB;
       float xc[16];
-      if (!FROMSPEC) {
+      {
         float (&xa)[8] = reinterpret_cast<float (&)[8]>(xc[0]);
         float (&xb)[8] = reinterpret_cast<float (&)[8]>(xc[8]);
         load_frame<4, 256>(arow, a.T, a.hop, f, lane, xa);
         load_frame<4, 256>(arow, a.T, a.hop, hasB ? f + 1 : f, lane, xb);
       }
-      const cpx* srow = FROMSPEC ? a.spec + ((size_t)b * a.F + f + (own ? fr : 0)) * NB : nullptr;
       const float* trow = a.target + ((size_t)b * a.F + f + (own ? fr : 0)) * NB;
       float tk_[4], tq_[4], th_ = 0.0f;
 #pragma unroll
@@ -1735,7 +1702,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 2) void stft_grad512_kern
       if (kl == 0) th_ = trow[HALF];
       // ---- forward
       cpx u[8];
-      if (!FROMSPEC) {
+      {
         cpx v[8];
 #pragma unroll
         for (int n1 = 0; n1 < 4; ++n1) {
@@ -1743,29 +1710,24 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 2) void stft_grad512_kern
           v[4 + n1] = cmk(xc[8 + 2 * n1], xc[8 + 2 * n1 + 1]) * t_win[64 * n1];
         }
         fft2(v, u);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sA[fr * HALF + kl + 32 * e] = u[4 + e];
-        wave_lds_sync();
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sA[fr * HALF + kl + 32 * e] = u[4 + e];
+      wave_lds_sync();
       // ---- per bin pair (k, N2 - k): X, value, cotangent, the pair's two inverse inputs
       cpx zk_in[4], zn_in[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int k = kl + 32 * e;
+        cpx zn = sA[fr * HALF + ((HALF - k) & (HALF - 1))];
+        const cpx zk = u[e];
+        if (e == 0 && k == 0) zn = zk;
         const cpx w = t_twu[64 * e];                              // W_N^k = e^{-2 pi i k / N}
-        cpx xk, xq;
-        if (FROMSPEC) {
-          xk = srow[k]; xq = srow[N2 - k];
-        } else {
-          cpx zn = sA[fr * HALF + ((HALF - k) & (HALF - 1))];
-          const cpx zk = u[e];
-          if (e == 0 && k == 0) zn = zk;
-          const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-          const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-          const cpx t = cmul(w, zo);
-          xk = cadd(ze, t);                                       // X[k]
-          xq = cmk(ze.x - t.x, -(ze.y - t.y));                    // X[N2 - k]
-        }
+        const cpx ze = cmk(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        const cpx zo = cmk(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        const cpx t = cmul(w, zo);
+        const cpx xk = cadd(ze, t);                               // X[k]
+        const cpx xq = cmk(ze.x - t.x, -(ze.y - t.y));            // X[N2 - k]
         const float vk = bin_value(xk.x * xk.x + xk.y * xk.y), vq = bin_value(xq.x * xq.x + xq.y * xq.y);
         const float gk = value_grad(vk, tk_[e]), gq = value_grad(vq, tq_[e]);
         const cpx ck = xk * (2.0f * power_grad(gk, vk));          // G[k]
@@ -1785,7 +1747,7 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 2) void stft_grad512_kern
       // bin HALF pairs with itself: X[HALF] = conj(Z[HALF]) (the lanes with kl = 0 hold Z[HALF] = u[4])
       cpx zh_in;
       {
-        const cpx xh = FROMSPEC ? srow[HALF] : cmk(u[4].x, -u[4].y);
+        const cpx xh = cmk(u[4].x, -u[4].y);
         const float vh = bin_value(xh.x * xh.x + xh.y * xh.y);
         const float gh = value_grad(vh, th_);
         const cpx ch = xh * (2.0f * power_grad(gh, vh));
@@ -1859,10 +1821,8 @@ __global__ __launch_bounds__(64 * SP_WAVES, SP_WAVES / 2) void stft_grad512_kern
 static int grad_frames_launch(const float* audio, const float* tables, const int* mel_start, const int* mel_count,
                               const int* mel_woff, const float* mel_w, int mel_nnz, int n_out, const float* target,
                               const double* coef, float* frame_grad, int B, int T, int n_fft, int hop, int power,
-                              int loss_mode, float scale, float eps, int* plan, hipStream_t stream, bool dry = false,
-                              const cpx* spec = nullptr, bool from_spec = false) {
-  if (!dry && ((!audio && !from_spec) || (from_spec && !spec) || !tables || !target || !frame_grad)) return IAS_ERR_ARG;
-  if (from_spec && (plan == nullptr || mel_start != nullptr || mel_nnz > 0)) return IAS_ERR_UNSUPPORTED;   // SPAN kernels, linear bins
+                              int loss_mode, float scale, float eps, int* plan, hipStream_t stream, bool dry = false) {
+  if (!dry && (!audio || !tables || !target || !frame_grad)) return IAS_ERR_ARG;
   if (B <= 0 || B > 65535 || hop <= 0) return IAS_ERR_ARG;
   if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return IAS_ERR_UNSUPPORTED;
   if ((power != 1 && power != 2) || (loss_mode != 1 && loss_mode != 2) || (!dry && loss_mode == 2 && !coef)) return IAS_ERR_ARG;
@@ -1878,7 +1838,6 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
   a.mel_start = mel_start; a.mel_count = mel_count; a.mel_woff = mel_woff; a.mel_w = mel_w;
   a.n_out = n_out; a.mel_nnz = mel ? mel_nnz : 0;
   a.G = a.cper = a.L = a.nchunks = 0;
-  a.spec = spec;
   static const int wgs_env = ias_diag_env("IAS_STFT_GRAD_WGS") ? atoi(ias_diag_env("IAS_STFT_GRAD_WGS")) : 0;   // diagnostics
   int per_row = (wgs_env > 0 ? wgs_env : 1024) / B;   // one resident round (measured: 2.36 -> 2.29 ms for the MR-STFT loss)
   if (per_row < 1) per_row = 1;
@@ -1914,13 +1873,8 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
       if (dry) return IAS_OK;
       const long long need = ((long long)a.nchunks + W2 - 1) / W2;
       const int grid2 = (int)(need < (long long)ncu ? need : (long long)ncu);
-      if (from_spec) {
-        (void)hipFuncSetAttribute((const void*)stft_grad2k_kernel<W2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        hipLaunchKernelGGL((stft_grad2k_kernel<W2, true, true>), dim3(grid2), dim3(64 * W2), lds2, stream, a, B * F, 0u);
-      } else {
-        (void)hipFuncSetAttribute((const void*)stft_grad2k_kernel<W2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        hipLaunchKernelGGL((stft_grad2k_kernel<W2, true>), dim3(grid2), dim3(64 * W2), lds2, stream, a, B * F, 0u);
-      }
+      (void)hipFuncSetAttribute((const void*)stft_grad2k_kernel<W2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      hipLaunchKernelGGL((stft_grad2k_kernel<W2, true>), dim3(grid2), dim3(64 * W2), lds2, stream, a, B * F, 0u);
     } else {
       const long long need = ((long long)B * F + W2 - 1) / W2;
       const int grid2 = (int)(need < 2LL * ncu ? need : 2LL * ncu);
@@ -1934,18 +1888,14 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
   if (n_fft == 512 && span && !mel && !v1_512) {
     constexpr int W5 = 8;
     const size_t lds5 = sizeof(cpx) * (W5 * 64 * IAS_S2_ROW) + sizeof(float) * W5 * 512;
-    (void)hipFuncSetAttribute(from_spec ? (const void*)stft_grad512_kernel<W5, true> : (const void*)stft_grad512_kernel<W5>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
+    (void)hipFuncSetAttribute((const void*)stft_grad512_kernel<W5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
     int nb = 0;
-    if ((from_spec ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stft_grad512_kernel<W5, true>, 64 * W5, lds5)
-                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stft_grad512_kernel<W5>, 64 * W5, lds5)) != hipSuccess || nb < 1)
-      nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stft_grad512_kernel<W5>, 64 * W5, lds5) != hipSuccess || nb < 1) nb = 1;
     if (!make_plan((long long)ncu * nb * W5)) return IAS_ERR_UNSUPPORTED;
     if (dry) return IAS_OK;
     const long long need = ((long long)a.nchunks + W5 - 1) / W5;
     const int grid5 = (int)(need < (long long)ncu * nb ? need : (long long)ncu * nb);
-    if (from_spec) hipLaunchKernelGGL((stft_grad512_kernel<W5, true>), dim3(grid5), dim3(64 * W5), lds5, stream, a);
-    else hipLaunchKernelGGL((stft_grad512_kernel<W5>), dim3(grid5), dim3(64 * W5), lds5, stream, a);
+    hipLaunchKernelGGL((stft_grad512_kernel<W5>), dim3(grid5), dim3(64 * W5), lds5, stream, a);
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   }
   const int R = n_fft / 128, scr = 8 * R * IAS_S2_ROW, np_it = (8 * R + 63) / 64, nunp = (n_fft / 4) / 64 + 1;
@@ -1980,21 +1930,6 @@ static int grad_frames_launch(const float* audio, const float* tables, const int
     else if (n_fft == 1024) IAS_SGW_LAUNCH(10, MEL, SPAN);                                                         \
     else IAS_SGW_LAUNCH(11, MEL, SPAN);                                                                            \
   } while (0)
-  if (from_spec) {
-    if (n_fft != 1024) return IAS_ERR_UNSUPPORTED;          // (512 / 2048 took their own kernels above; round-2 switches: no)
-    if (lds + lds_static > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)stft_grad_wave_kernel<10, false, true, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stft_grad_wave_kernel<10, false, true, true>, 256, lds) != hipSuccess || nb < 1)
-      nb = 1;
-    if (!make_plan((long long)ncu * nb * 4)) return IAS_ERR_UNSUPPORTED;
-    if (dry) return IAS_OK;
-    const long long need = ((long long)a.nchunks + 3) / 4;
-    grid = dim3((unsigned)(need < (long long)ncu * nb ? need : (long long)ncu * nb));
-    hipLaunchKernelGGL((stft_grad_wave_kernel<10, false, true, true>), grid, block, lds, stream, a);
-    return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
-  }
   if (mel) { if (span) IAS_SGW_PICK(true, true); else IAS_SGW_PICK(true, false); }
   else { if (span) IAS_SGW_PICK(false, true); else IAS_SGW_PICK(false, false); }
 #undef IAS_SGW_PICK
@@ -2030,23 +1965,6 @@ extern "C" int ias_stft_grad_spans(const float* audio, const float* tables, cons
   if (!plan_host || (reinterpret_cast<uintptr_t>(chunk_spans) & 15) != 0) return IAS_ERR_ARG;
   return grad_frames_launch(audio, tables, mel_start, mel_count, mel_woff, mel_w, mel_nnz, n_out, target, coef, chunk_spans,
                             B, T, n_fft, hop, power, loss_mode, scale, eps, plan_host, (hipStream_t)stream_);
-}
-
-// The same two calls for the FROMSPEC kernels (round 5): spec = what ias_stft_spec left for this audio ([B,F,n_fft/2+1][2]
-// fp32); linear bins, n_fft in {512, 1024, 2048}; the audio itself is not read.
-extern "C" int ias_stft_grad_span_plan_spec(int B, int T, int n_fft, int hop, int* plan_host) {
-  if (!plan_host) return IAS_ERR_ARG;
-  return grad_frames_launch(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_fft / 2 + 1, nullptr, nullptr, nullptr,
-                            B, T, n_fft, hop, 1, 1, 1.0f, 0.0f, plan_host, nullptr, true, nullptr, true);
-}
-extern "C" int ias_stft_grad_spans_spec(const float* spec, const float* tables, const float* target, const double* coef,
-                                        float* chunk_spans, int B, int T, int n_fft, int hop, int power, int loss_mode,
-                                        float scale, float eps, int* plan_host, void* stream_) {
-  if (!spec || !plan_host || (reinterpret_cast<uintptr_t>(chunk_spans) & 15) != 0 || (reinterpret_cast<uintptr_t>(spec) & 7) != 0)
-    return IAS_ERR_ARG;
-  return grad_frames_launch(nullptr, tables, nullptr, nullptr, nullptr, nullptr, 0, n_fft / 2 + 1, target, coef, chunk_spans,
-                            B, T, n_fft, hop, power, loss_mode, scale, eps, plan_host, (hipStream_t)stream_, false,
-                            reinterpret_cast<const cpx*>(spec), true);
 }
 
 // sums[0..2] = sum over n partial triples (fixed order: deterministic); optionally
@@ -2248,44 +2166,22 @@ extern "C" int ias_stft_build_tables(int n_fft, const float* window_host, float*
 //   partials [ias_stft_partials_count][3] doubles, required when loss_mode != 0
 //   rowpeak  [B] or NULL : row peaks max |audio| (ias_voice_render's workspace): the spectrum of the row normalised as
 //                          torchsynth's normalize_if_clipping would, without the normalised audio ever being written
-static int stft_impl(const float* audio, const float* tables, const float* mtables, const float* segtab, const int* mel_start, const int* mel_count,
-                     const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
-                     double* partials, const float* rowpeak, int* ticket, int B, int T, int n_fft, int hop, int n_out,
-                     int value_mode, int loss_mode, float eps, cpx* spec, void* stream_);
 extern "C" int ias_stft(const float* audio, const float* tables, const float* mtables, const float* segtab, const int* mel_start, const int* mel_count,
                         const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
                         double* partials, const float* rowpeak, int* ticket, int B, int T, int n_fft, int hop, int n_out,
                         int value_mode, int loss_mode, float eps, void* stream_) {
-  return stft_impl(audio, tables, mtables, segtab, mel_start, mel_count, mel_woff, mel_w, mel_nnz, out, target, partials, rowpeak,
-                   ticket, B, T, n_fft, hop, n_out, value_mode, loss_mode, eps, nullptr, stream_);
-}
-// The linear-bin forward that also leaves the complex spectrum behind: spec [B,F,n_fft/2+1][2] fp32 (X of audio / peak,
-// natural bin order), for ias_stft_grad_spans_spec.  Otherwise as ias_stft with mel_* = mtables = segtab = NULL.
-// IAS_ERR_UNSUPPORTED where the wave-per-frame radix-8 kernels do not serve the shape (nothing launched).
-extern "C" int ias_stft_spec(const float* audio, const float* tables, float* out, const float* target, double* partials,
-                             const float* rowpeak, float* spec, int B, int T, int n_fft, int hop, int value_mode,
-                             int loss_mode, float eps, void* stream_) {
-  if (!spec || (((uintptr_t)spec) & 7) != 0) return IAS_ERR_ARG;
-  return stft_impl(audio, tables, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, out, target, partials, rowpeak,
-                   nullptr, B, T, n_fft, hop, n_fft / 2 + 1, value_mode, loss_mode, eps, reinterpret_cast<cpx*>(spec), stream_);
-}
-static int stft_impl(const float* audio, const float* tables, const float* mtables, const float* segtab, const int* mel_start, const int* mel_count,
-                     const int* mel_woff, const float* mel_w, int mel_nnz, float* out, const float* target,
-                     double* partials, const float* rowpeak, int* ticket, int B, int T, int n_fft, int hop, int n_out,
-                     int value_mode, int loss_mode, float eps, cpx* spec, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!audio || !tables || B <= 0 || B > 65535 || n_out <= 0) return IAS_ERR_ARG;
   if (value_mode < 1 || value_mode > 3 || loss_mode < 0 || loss_mode > 2) return IAS_ERR_ARG;
   if (loss_mode != 0 && (!target || !partials)) return IAS_ERR_ARG;
-  if (loss_mode == 0 && !out && !spec) return IAS_ERR_ARG;
+  if (loss_mode == 0 && !out) return IAS_ERR_ARG;
   const bool mel = mel_start != nullptr;
   if (mel && (!mel_count || !mel_woff || !mel_w || mel_nnz <= 0)) return IAS_ERR_ARG;
   if (!mel && n_out != n_fft / 2 + 1) return IAS_ERR_ARG;
   const int F = ias_stft_num_frames(T, n_fft, hop);
   if (F < 0) return IAS_ERR_ARG;
   if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return IAS_ERR_UNSUPPORTED;
-  if (spec != nullptr && (mel || !stft2_enabled(n_fft, false, false))) return IAS_ERR_UNSUPPORTED;
-  if (spec == nullptr && ias_sm_enabled(n_fft, mtables != nullptr))
+  if (ias_sm_enabled(n_fft, mtables != nullptr))
     return ias_sm_launch(audio, mtables, mel, out, target, partials, rowpeak, ticket, B, T, F, n_fft, hop, n_out,
                          value_mode, loss_mode, eps, stream);
 
@@ -2293,7 +2189,7 @@ static int stft_impl(const float* audio, const float* tables, const float* mtabl
     if ((long long)B * F > 2000000000LL) return IAS_ERR_UNSUPPORTED;
     Spec2Args a2;
     a2.audio = audio; a2.tables = tables; a2.segtab = mel ? segtab : nullptr; a2.out = out; a2.target = target;
-    a2.partials = partials; a2.rowpeak = rowpeak; a2.spec = spec; a2.T = T; a2.F = F; a2.hop = hop; a2.n_out = n_out; a2.nframes = B * F;
+    a2.partials = partials; a2.rowpeak = rowpeak; a2.T = T; a2.F = F; a2.hop = hop; a2.n_out = n_out; a2.nframes = B * F;
     a2.magicF = (F == 1 ? 0xFFFFFFFFu /* 2^32 / 1 does not fit: q0 = fi - 1, which row_of's one-step correction fixes */ : (unsigned)(0x100000000ULL / (unsigned long long)F));
     a2.value_mode = value_mode; a2.loss_mode = loss_mode; a2.eps = eps;
 #ifdef IAS_S2_STAMPS

@@ -132,17 +132,10 @@ class STFTPlan(nn.Module):
         _lib.check(min(F, 0), "ias_stft_num_frames (need T > n_fft/2 for reflect padding)")
         return F
 
-    def _call(self, audio, out, target, partials, value_mode, loss_mode, eps, rowpeak=None, spec=None):
+    def _call(self, audio, out, target, partials, value_mode, loss_mode, eps, rowpeak=None):
         lib = _lib.load()
         B, T = audio.shape
         mel = self.n_mels is not None
-        if spec is not None:
-            # linear bins, and the complex spectrum [B,F,n_fft/2+1,2] is left behind for the backward (ias_stft_spec)
-            assert not mel
-            _lib.check(lib.ias_stft_spec(_lib.ptr(audio), _lib.ptr(self.tables), _lib.ptr(out), _lib.ptr(target),
-                                         _lib.ptr(partials), _lib.ptr(rowpeak), _lib.ptr(spec), B, T, self.n_fft,
-                                         self.hop_length, value_mode, loss_mode, float(eps), _lib.stream()), "ias_stft_spec")
-            return
         st = lib.ias_stft(_lib.ptr(audio), _lib.ptr(self.tables), _lib.ptr(self.mtables), _lib.ptr(self.segtab),
                           _lib.ptr(self.mel_start) if mel else None, _lib.ptr(self.mel_count) if mel else None,
                           _lib.ptr(self.mel_woff) if mel else None, _lib.ptr(self.mel_w) if mel else None,
@@ -168,7 +161,7 @@ class STFTPlan(nn.Module):
         return out
 
     def loss_sums(self, audio, target_values, value_mode, loss_mode, eps=0.0, mean_scale=None, rowpeak=None,
-                  reduce_stream=None, spec=None):
+                  reduce_stream=None):
         """Fused STFT + comparison with cached target values -> 3 fp64 sums on the device
         (with ``mean_scale``: -> the fp32 scalar sums[0] * mean_scale, computed by the reduction launch).
         ``reduce_stream``: issue the small fixed-order reduction of the per-workgroup partials on that stream (it waits
@@ -182,7 +175,7 @@ class STFTPlan(nn.Module):
                                         (0 if self.mtables is None else 1) | (0 if self.n_mels is None else 2) |
                                         (0 if self.segtab is None else 4))
         partials = torch.empty((n, 3), dtype=torch.float64, device=a.device)
-        self._call(a, None, target_values, partials, value_mode, loss_mode, eps, rowpeak, spec)
+        self._call(a, None, target_values, partials, value_mode, loss_mode, eps, rowpeak)
         sums = torch.empty(3, dtype=torch.float64, device=a.device)
         mean = torch.empty((), dtype=torch.float32, device=a.device) if mean_scale is not None else None
 
@@ -312,9 +305,6 @@ class MultiResolutionSTFTLoss(nn.Module):
         self.eps = eps
         self.parallel = True      # the resolutions on side streams (False: one after the other on the caller's stream)
         self.fused_combine = True # backward: one combine launch for all resolutions (False: one per resolution + adds)
-        # training forward: leave each resolution's complex spectrum behind (8 bytes per bin) so that the backward does not
-        # transform every frame a second time -- the gradient step is bound by its vector / LDS pipes, not by HBM
-        self.save_spectra = True
         self.plans = nn.ModuleList([STFTPlan(n, w, h) for n, h, w in zip(fft_sizes, hop_sizes, win_lengths)])
 
     def target(self, y):
@@ -339,44 +329,24 @@ class MultiResolutionSTFTLoss(nn.Module):
             pool[device] = [torch.cuda.Stream(device) for _ in self.plans]
         return pool[device]
 
-    def _spec_plans(self, B, T):
-        """Chunk plans of the backward that reads saved spectra, one per resolution, or None when any resolution's shape is
-        not served (then nothing is saved and the backward transforms the frames itself)."""
-        lib = _lib.load()
-        plans = []
-        for plan in self.plans:
-            hp = (ctypes.c_int * 3)()
-            if plan.n_mels is not None or lib.ias_stft_grad_span_plan_spec(B, T, plan.n_fft, plan.hop_length, hp) != 0:
-                return None
-            plans.append((hp[0], hp[1], hp[2]))
-        return plans
-
-    def _forward(self, x, targets, save_spectra=False):
+    def _forward(self, x, targets):
         cur = torch.cuda.current_stream(x.device) if x.is_cuda else None
         streams = self._streams(x.device) if (x.is_cuda and self.parallel) else None
-        sums, specs = [], []
+        sums = []
         for k, (plan, tgt) in enumerate(zip(self.plans, targets)):
-            def one():
-                spec = None
-                if save_spectra:
-                    spec = torch.empty(tuple(tgt.shape) + (2,), dtype=torch.float32, device=x.device)
-                    if streams is not None:
-                        spec.record_stream(cur)
-                specs.append(spec)
-                return plan.loss_sums(x, tgt, VALUE_MAG_CLAMPED, LOSS_MRSTFT, self.eps, spec=spec)
             if streams is None:
-                sums.append(one())
+                sums.append(plan.loss_sums(x, tgt, VALUE_MAG_CLAMPED, LOSS_MRSTFT, self.eps))
             else:
                 streams[k].wait_stream(cur)
                 with torch.cuda.stream(streams[k]):
-                    s = one()
+                    s = plan.loss_sums(x, tgt, VALUE_MAG_CLAMPED, LOSS_MRSTFT, self.eps)
                     s.record_stream(cur)
                     sums.append(s)
         saved = []
         for k, (tgt, s) in enumerate(zip(targets, sums)):
             if streams is not None:
                 cur.wait_stream(streams[k])
-            saved.append((tgt, s) if not save_spectra else (tgt, s, specs[k]))
+            saved.append((tgt, s))
         # (sum_k sqrt(s_k[0]) / sqrt(s_k[1]) + s_k[2] / count_k) / nres in fp64 -> fp32, one launch
         n = len(sums)
         loss = torch.empty((), dtype=torch.float32, device=x.device)
@@ -392,9 +362,8 @@ class _MRSTFTFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, module, *targets):
         a = STFTPlan._audio2d(x)
-        spec_plans = module._spec_plans(*a.shape) if (module.save_spectra and module.fused_combine) else None
-        loss, saved = module._forward(a, targets, save_spectra=spec_plans is not None)
-        ctx.module, ctx.shape, ctx.spec_plans = module, x.shape, spec_plans
+        loss, saved = module._forward(a, targets)
+        ctx.module, ctx.shape = module, x.shape
         ctx.save_for_backward(a, *[t for pair in saved for t in pair])
         return loss
 
@@ -409,27 +378,6 @@ class _MRSTFTFn(torch.autograd.Function):
         cur = torch.cuda.current_stream(a.device)
         streams = module._streams(a.device) if module.parallel else None
         eps = float(module.eps)
-        if ctx.spec_plans is not None:
-            # the forward left the spectra behind: (target, sums, spectrum) per resolution; the backward kernels start at
-            # the cotangent (no second transform of the frames)
-            plans, spans = ctx.spec_plans, []
-            for i, plan in enumerate(module.plans):
-                tgt, s, spec = rest[3 * i], rest[3 * i + 1], rest[3 * i + 2]
-                if streams is not None:
-                    streams[i].wait_stream(cur)
-                with torch.cuda.stream(streams[i] if streams is not None else cur):
-                    spans.append(_mrstft_plan_spans(lib, plan, a, tgt, s, g32, nres, eps, plans[i], cur, spec=spec))
-            if streams is not None:
-                for st in streams[:nres]:
-                    cur.wait_stream(st)
-            g_total = torch.empty_like(a)
-            ptrs = (ctypes.c_void_p * nres)(*[sp.data_ptr() for sp in spans])
-            flat = []
-            for plan, (G, cper, L) in zip(module.plans, plans):
-                flat += [plan.n_fft, plan.hop_length, G, cper, L]
-            _lib.check(lib.ias_stft_grad_combine(ptrs, (ctypes.c_int * len(flat))(*flat), nres, None, _lib.ptr(g_total),
-                                                 B, T, _lib.stream()), "ias_stft_grad_combine")
-            return (g_total.reshape(ctx.shape), None) + (None,) * nres
         # chunk plans of the fused overlap-add (csrc/spectral_kernels.hip, SPAN kernels); any unsupported shape -> the
         # per-resolution path (frame tensor / spans + one combine each, summed with torch)
         plans = []
@@ -480,26 +428,15 @@ def _mrstft_coef(lib, s, g32, count, nres, device):
     return coef
 
 
-def _mrstft_plan_spans(lib, plan, a, tgt, s, g32, nres, eps, chunk_plan, consumer_stream, spec=None):
+def _mrstft_plan_spans(lib, plan, a, tgt, s, g32, nres, eps, chunk_plan, consumer_stream):
     """One resolution's chunk spans of d loss / d (windowed frames), overlap-added inside the kernel (on the current
-    stream; the result is handed to ``consumer_stream``, where ``ias_stft_grad_combine`` finishes all resolutions).
-    ``spec``: the spectrum the forward saved (``ias_stft_spec``) -- the kernel then reads X instead of transforming the
-    frames again."""
+    stream; the result is handed to ``consumer_stream``, where ``ias_stft_grad_combine`` finishes all resolutions)."""
     B, T = a.shape
     g32.record_stream(torch.cuda.current_stream(a.device))
     coef = _mrstft_coef(lib, s, g32, tgt.numel(), nres, a.device)
     G, cper, L = chunk_plan
     spans = torch.empty(B * cper * L, dtype=torch.float32, device=a.device)
     hp = (ctypes.c_int * 3)()
-    if spec is not None:
-        spec.record_stream(torch.cuda.current_stream(a.device))
-        st = lib.ias_stft_grad_spans_spec(_lib.ptr(spec), _lib.ptr(plan.tables), _lib.ptr(tgt), _lib.ptr(coef),
-                                          _lib.ptr(spans), B, T, plan.n_fft, plan.hop_length, 1, LOSS_MRSTFT, 0.0, eps, hp,
-                                          _lib.stream())
-        _lib.check(st, "ias_stft_grad_spans_spec")
-        assert (hp[0], hp[1], hp[2]) == chunk_plan
-        spans.record_stream(consumer_stream)
-        return spans
     st = lib.ias_stft_grad_spans(_lib.ptr(a), _lib.ptr(plan.tables), None, None, None, None, 0, plan.n_out, _lib.ptr(tgt),
                                  _lib.ptr(coef), _lib.ptr(spans), B, T, plan.n_fft, plan.hop_length, 1, LOSS_MRSTFT, 0.0,
                                  eps, hp, _lib.stream())
