@@ -223,12 +223,14 @@ def run_vicreg(args, rank, world, dev):
     y = torch.randn(B, D, generator=torch.Generator().manual_seed(2 * rank + 1)).to(dev).requires_grad_()
     gather = world > 1
     state = {}
+    one = torch.ones((), dtype=torch.float32, device=dev)
 
     def step():
         # the code VICReg.loss runs (inverse-audio-synthesis_amd/vicreg.py): N > 1 = ONE all-gather of cat(x, y, dim=1), the
         # loss on the gathered buffer in place with denominator B * world - 1, one reduce-scatter of its cotangent
         out = global_batch_loss(x, y, B, 25.0, 25.0, 1.0, gather=True)
-        gx, gy = torch.autograd.grad(out[0], (x, y))          # backward of the loss (and of the gather)
+        # `one`: the loss' cotangent as a trainer passes it (autograd otherwise fills a fresh 1 per step: a 5 us launch)
+        gx, gy = torch.autograd.grad(out[0], (x, y), one)     # backward of the loss (and of the gather)
         state["out"] = tuple(v.detach() for v in out)
         state["grads"] = (gx, gy)
 
@@ -813,6 +815,7 @@ def run_gradstep(args, rank, world, dev):
     tgt = voice.render(torch.rand(B, 78, generator=torch.Generator().manual_seed(2000 + rank)).to(dev)).clone()
     tb, tm = sub.target(tgt), mr.target(tgt)
     state = {}
+    one = torch.ones((), dtype=torch.float32, device=dev)     # the loss' cotangent, as a trainer passes it (no fill launch per step)
 
     def step(ev=None):
         if ev: ev[0].record()
@@ -820,7 +823,7 @@ def run_gradstep(args, rank, world, dev):
         if ev: ev[1].record()
         loss = both(a, [dict(targets=tm), dict(target_bands=tb)])
         if ev: ev[2].record()
-        (g,) = torch.autograd.grad(loss, params)
+        (g,) = torch.autograd.grad(loss, params, one)
         if ev: ev[3].record()
         state["loss"], state["g"] = loss.detach(), g
 

@@ -109,6 +109,14 @@ class Trainer:
         self.out_dir = t.out_dir
         self.history = []
 
+    def _seed(self):
+        """The loss' cotangent, a 1 that lives outside any graph pool (autograd otherwise creates it with a fill launch per
+        step)."""
+        one = getattr(self, "_one", None)
+        if one is None or one.device != self.device:
+            one = self._one = torch.ones((), dtype=torch.float32, device=self.device)
+        return one
+
     def _log(self, step, extra=None):
         rec = {"step": step}
         for k, v in self.module.logged.items():
@@ -182,7 +190,7 @@ class Trainer:
 
         def one_step():
             self.bucketer.begin_step()            # drop / zero the gradients (a captured step's own live in the graph's pool)
-            m.training_step(None, step).backward()
+            m.training_step(None, step).backward(self._seed())   # (a cached 1: `.backward()` alone launches a fill for it)
             self.bucketer.finish()                # several ranks: the bucket all-reduces, issued during backward, joined here
             opt.step()
 
@@ -223,7 +231,7 @@ class Trainer:
         ``finish`` joins them and averages."""
         self.bucketer.begin_step()
         loss = self.module.training_step(batch, step)
-        loss.backward()
+        loss.backward(self._seed())
         self.bucketer.finish()
         self.optimizer.step()
         return loss

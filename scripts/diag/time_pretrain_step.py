@@ -22,7 +22,7 @@ def step(i):
         tr._graph_step(i, i)
     else:
         tr.bucketer.begin_step()
-        model.training_step(i).backward()
+        model.training_step(i).backward(tr._seed())
         opt.step()
 for i in range(5): step(i)          # (graph mode: 3 eager warm-up steps, capture, first replays)
 torch.cuda.synchronize()
