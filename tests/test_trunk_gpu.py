@@ -80,7 +80,7 @@ def test_depthwise_conv_random_shapes(lib, dev, B, C, K, S, H, W):
 def test_stem_conv_matches_torch(lib, dev):
     from inverse_audio_synthesis_amd.vision import StemConv2d
     m = StemConv2d(3, 16, 3, 2, 1, bias=False).to(dev)
-    for shape in ((4, 3, 240, 245), (3, 3, 17, 10)):
+    for shape in ((4, 3, 240, 245), (3, 3, 17, 10), (128, 3, 240, 245), (2, 3, 121, 128), (1, 3, 5, 300)):   # third: configs[2]
         x = randn(shape, 3).to(dev)
         y = m(x)
         ref = F.conv2d(x, m.weight, None, 2, 1)

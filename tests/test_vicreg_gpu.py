@@ -228,7 +228,7 @@ def test_backward_on_views_that_are_not_16_byte_aligned(lib, dev, B, D):
 
 
 @pytest.mark.parametrize("n,widths", [(128, (96, 256, 256, 64)), (20, (40, 200, 72, 24)), (200, (32, 64, 64, 32)),
-                                       (300, (16, 40, 32, 8))])
+                                       (300, (16, 40, 32, 8)), (128, (1024, 8192, 8192, 8192))])   # last: configs[2]'s projector
 def test_project_pair_fused_batchnorm_matches_two_projector_calls(lib, dev, n, widths):
     """vicreg.project_pair on the GPU (one GEMM without bias + ONE launch per Linear -> BatchNorm1d -> ReLU layer for both
     branches: ias_bn1d_groups_forward / _backward) against projector(a), projector(b) as the reference calls it
@@ -264,7 +264,14 @@ def test_project_pair_fused_batchnorm_matches_two_projector_calls(lib, dev, n, w
     for k, g, w in zip(names, got, want):
         # the Linear biases in front of a BatchNorm have a gradient that is zero in exact arithmetic: absolute bound
         bound = 2e-4 * max(1.0, w.abs().max().item())
-        assert (g - w).abs().max().item() <= bound, (k, (g - w).abs().max().item(), w.abs().max().item())
+        d = (g - w).abs()
+        if d1 >= 8192:
+            # the full-size projector: of 2 x 2 M pre-activations a few hundred lie within rounding of zero and take the
+            # other side of the ReLU in one of the two runs -- isolated elements move, the gradient as a whole does not
+            rel = (d.double().pow(2).sum().sqrt() / w.double().pow(2).sum().sqrt()).item()
+            assert rel <= 5e-3 and (d > bound).double().mean().item() <= 2e-2, (k, rel, (d > bound).double().mean().item())
+        else:
+            assert d.max().item() <= bound, (k, d.max().item(), w.abs().max().item())
     for m, r in zip(proj, ref):
         if isinstance(m, torch.nn.BatchNorm1d):
             assert torch.allclose(m.running_mean, r.running_mean, atol=1e-6, rtol=1e-5)
