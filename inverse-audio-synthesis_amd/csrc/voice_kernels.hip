@@ -539,6 +539,7 @@ __device__ __forceinline__ void voice_phase_b(const char* s_ctrl, float* s_stage
   const int perm = (lane >> 2) & 3;
   const unsigned ctrl_biased = (unsigned)(uintptr_t)(voice_lds_cchar*)s_ctrl - (unsigned)(t.c_lo * VOICE_CTRL_ROW);
 
+  const float kexp = -1.4426950408889634f * vc.kpart;
   double run1 = s_carry[0] + ex1, run2 = s_carry[1] + ex2;   // all exact
   for (int w = 0; w < wave_u; ++w) { run1 += wsum[0][w]; run2 += wsum[1][w]; }
   float o[4], nz[4];
@@ -567,14 +568,15 @@ __device__ __forceinline__ void voice_phase_b(const char* s_ctrl, float* s_stage
     const float amp1 = fmaf(w1, qa.y, qa.x), amp2 = fmaf(w1, qb.y, qb.x), ampn = fmaf(w1, qn.y, qn.x);
     run1 += (double)inc1[e]; run2 += (double)inc2[e];
     const float arg1 = (float)run1 + vc.phi_1, arg2 = (float)run2 + vc.phi_2;
-    float s2, c2;
-    bool flip;
-    voice_sincos(arg2, s2, c2, flip);    // sin = (flip ? -s2 : s2), cos = (flip ? -c2 : c2)
-    // square = tanh(k sin / 2) is odd in sin: magnitude from |s2|, sign = sign(s2) ^ flip
-    const float sqm = __builtin_copysignf(voice_tanh_abs_half(vc.kpart * s2), s2);
-    // vco_2 = gain x square x (1 + shape cos) x amplitude (gain and mixer level are inside amp2), vco_1 = cos x amplitude,
-    // mix = vco_1 + vco_2 + noise x amplitude: fused multiply-adds (the amplitude path is held to 1e-4, not to the bit)
-    const float v2 = (flip ? -sqm : sqm) * fmaf(flip ? -vc.shape : vc.shape, c2, 1.0f);
+    float s2, c2, sgn;
+    voice_sincos_sgn(arg2, s2, c2, sgn);   // sin = sgn s2, cos = sgn c2, sgn = +-1
+    // square = tanh(k sin / 2) is odd in sin: sgn tanh(k s2 / 2), the tanh of the SIGNED argument (kexp = -k log2 e)
+    const float th = voice_tanh_half_of_exp2arg(kexp * s2);
+    // vco_2 = gain x square x (1 + shape cos) x amplitude (gain and mixer level are inside amp2):
+    // sgn th (1 + shape sgn c2) = th (sgn + shape c2) -- the sign costs nothing beyond its two multiply-adds;
+    // vco_1 = cos x amplitude, mix = vco_1 + vco_2 + noise x amplitude: fused multiply-adds (the amplitude path is held
+    // to 1e-4, not to the bit)
+    const float v2 = th * fmaf(vc.shape, c2, sgn);
     float om = voice_cos(arg1) * amp1;
     om = fmaf(v2, amp2, om);
     om = fmaf(nz[e & 3], ampn, om);

@@ -32,6 +32,25 @@ __device__ __forceinline__ void voice_sincos(float a, float& s, float& c, bool& 
   s = __builtin_amdgcn_sinf(r2);
   c = __builtin_amdgcn_cosf(r2);
 }
+// The render's form (round 5): the sign of both values as a FACTOR sgn = (-1)^q = 1 - 2 q (2 - q), q in {0, 1, 2} -- two
+// multiply-adds -- instead of a compare whose flag the caller turns into two selects (12 clocks of quarter-rate
+// instructions).  sin = sgn s, cos = sgn c.
+__device__ __forceinline__ void voice_sincos_sgn(float a, float& s, float& c, float& sgn) {
+  float fp, t;
+  voice_rev_split(a, fp, t);
+  const float r = fp + t;
+  const float q = __builtin_rintf(r + r);
+  const float r2 = fmaf(q, -0.5f, fp) + t;
+  sgn = fmaf(q, fmaf(q, 2.0f, -4.0f), 1.0f);
+  s = __builtin_amdgcn_sinf(r2);
+  c = __builtin_amdgcn_cosf(r2);
+}
+// tanh(z / 2) = 2 / (1 + e^{-z}) - 1 for SIGNED z, given x = -z log2(e): one multiply-add behind v_exp_f32 + v_rcp_f32, no
+// |z| / copysign pair around them (e^{-z} = inf gives 2 * 0 - 1 = -1, e^{-z} = 0 gives 1: no special cases).  Absolute
+// error 1.2e-7 (the form below keeps RELATIVE accuracy near 0, which the mix -- held to 1e-4 absolute -- does not need).
+__device__ __forceinline__ float voice_tanh_half_of_exp2arg(float x) {
+  return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x)), -1.0f);
+}
 // |tanh(z)| = (1 - e^{-2|z|}) / (1 + e^{-2|z|})   (v_exp_f32 + v_rcp_f32; max abs error 1.3e-7)
 __device__ __forceinline__ float voice_tanh_abs(float z) {
   const float t = __builtin_amdgcn_exp2f(-2.885390081777927f * fabsf(z));
