@@ -434,6 +434,12 @@ long long ias_bn_scratch_doubles(int B, int C);
 int ias_bn_act_forward(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
                        float* y, float* save_mean, float* save_invstd, double* scratch, int B, int C, int HW, float eps,
                        float momentum, int act, void* stream);
+/* the same with the block's residual connection taken in the same pass: y = act(BatchNorm_train(x)) + res (torchvision's
+ * InvertedResidual: `result += input` behind the block's last ConvNormActivation); res [B,C,HW]; the same bits as the
+ * separate addition */
+int ias_bn_act_forward_res(const float* x, const float* res, const float* weight, const float* bias, float* running_mean,
+                           float* running_var, float* y, float* save_mean, float* save_invstd, double* scratch, int B,
+                           int C, int HW, float eps, float momentum, int act, void* stream);
 int ias_bn_act_backward(const float* x, const float* dy, const float* weight, const float* bias, const float* save_mean,
                         const float* save_invstd, float* dx, float* gw, float* gb, double* scratch, float* sums, int B,
                         int C, int HW, int act, void* stream);

@@ -142,6 +142,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float* __res
     if (MODE == 0) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) o[e] = bn_act(fmaf(w, (xv[e] - m) * is, bb), act);
+      if (dy != nullptr) {                                   // forward: `dy` carries the residual (or null)
+        const vt rv = reinterpret_cast<const vt*>(dy)[i];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] += rv[e];
+      }
     } else {
       const vt gv = reinterpret_cast<const vt*>(dy)[i];
       const float a = sums[2 * c] * inv_n, b2 = sums[2 * c + 1] * inv_n, ws = w * is;
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_scalar_kernel(const float
     const int c = (int)((i / HW) % C);
     const float m = mean[c], is = invstd[c], w = weight ? weight[c] : 1.0f, bb = bias ? bias[c] : 0.0f;
     const float xh = (x[i] - m) * is;
-    if (MODE == 0) out[i] = bn_act(fmaf(w, xh, bb), act);
+    if (MODE == 0) out[i] = bn_act(fmaf(w, xh, bb), act) + (dy != nullptr ? dy[i] : 0.0f);
     else {
       const float dz = dy[i] * bn_act_grad(fmaf(w, xh, bb), act);
       out[i] = w * is * (dz - sums[2 * c] * inv_n - xh * sums[2 * c + 1] * inv_n);
@@ -204,7 +209,8 @@ template <int NV>
 __global__ __launch_bounds__(BNF_THREADS) void bn_fused_forward_kernel(
     const float4* __restrict__ x, const float* __restrict__ weight, const float* __restrict__ bias,
     float* __restrict__ running_mean, float* __restrict__ running_var, float4* __restrict__ y, float* __restrict__ save_mean,
-    float* __restrict__ save_invstd, int B, int C, int hwv, float eps, float momentum, int act) {
+    float* __restrict__ save_invstd, int B, int C, int hwv, float eps, float momentum, int act,
+    const float4* __restrict__ res /* or null: y = act(bn(x)) + res (the block's residual connection) */) {
   __shared__ double s_red[BNF_THREADS / 64][2];
   const int c = blockIdx.x, tid = threadIdx.x, nvec = B * hwv;
   const float k = reinterpret_cast<const float*>(x)[(size_t)c * hwv * 4];
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(BNF_THREADS) void bn_fused_forward_kernel(
       float4 o;
       o.x = bn_act(fmaf(w, (v[e].x - mean) * invstd, bb), act); o.y = bn_act(fmaf(w, (v[e].y - mean) * invstd, bb), act);
       o.z = bn_act(fmaf(w, (v[e].z - mean) * invstd, bb), act); o.w = bn_act(fmaf(w, (v[e].w - mean) * invstd, bb), act);
+      if (res != nullptr) { const float4 r = res[bnf_off(i, hwv, C, c)]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
       y[bnf_off(i, hwv, C, c)] = o;
     }
   }
@@ -333,19 +340,41 @@ static void bn_launch_apply(hipStream_t stream, const float* x, const float* dy,
 
 // y = act(BatchNorm_train(x)); x, y [B,C,HW] fp32 contiguous; weight / bias [C] or NULL; running_mean / running_var [C]
 // or NULL (updated in place with `momentum`); save_mean / save_invstd [C] out; act 0 none, 1 ReLU, 2 Hardswish.
+static int bn_act_forward_impl(const float* x, const float* res, const float* weight, const float* bias, float* running_mean,
+                               float* running_var, float* y, float* save_mean, float* save_invstd, double* scratch, int B, int C,
+                               int HW, float eps, float momentum, int act, void* stream_);
 extern "C" int ias_bn_act_forward(const float* x, const float* weight, const float* bias, float* running_mean,
                                   float* running_var, float* y, float* save_mean, float* save_invstd, double* scratch,
                                   int B, int C, int HW, float eps, float momentum, int act, void* stream_) {
+  return bn_act_forward_impl(x, nullptr, weight, bias, running_mean, running_var, y, save_mean, save_invstd, scratch, B, C, HW,
+                             eps, momentum, act, stream_);
+}
+// y = act(BatchNorm_train(x)) + res: the residual connection of an inverted-residual block (torchvision InvertedResidual:
+// `result += input` behind the block's last ConvNormActivation) taken in the same pass -- one elementwise launch and one
+// read + write of the map less per block; the same bits as the separate addition.  res [B,C,HW] like x, 16-byte aligned
+// where x is.
+extern "C" int ias_bn_act_forward_res(const float* x, const float* res, const float* weight, const float* bias,
+                                      float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd,
+                                      double* scratch, int B, int C, int HW, float eps, float momentum, int act, void* stream_) {
+  if (!res) return IAS_ERR_ARG;
+  return bn_act_forward_impl(x, res, weight, bias, running_mean, running_var, y, save_mean, save_invstd, scratch, B, C, HW, eps,
+                             momentum, act, stream_);
+}
+static int bn_act_forward_impl(const float* x, const float* res, const float* weight, const float* bias, float* running_mean,
+                               float* running_var, float* y, float* save_mean, float* save_invstd, double* scratch, int B, int C,
+                               int HW, float eps, float momentum, int act, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !y || !save_mean || !save_invstd || !scratch || B <= 0 || C <= 0 || C > 65535 || HW <= 0 || act < 0 || act > 2)
     return IAS_ERR_ARG;
-  if (const int nv = bn_fused_nv(x, y, nullptr, B, C, HW)) {
+  if (const int nv = bn_fused_nv(x, y, res, B, C, HW)) {
     if (nv == 2)
       hipLaunchKernelGGL((bn_fused_forward_kernel<2>), dim3(C), dim3(BNF_THREADS), 0, stream, (const float4*)x, weight, bias,
-                         running_mean, running_var, (float4*)y, save_mean, save_invstd, B, C, HW >> 2, eps, momentum, act);
+                         running_mean, running_var, (float4*)y, save_mean, save_invstd, B, C, HW >> 2, eps, momentum, act,
+                         (const float4*)res);
     else
       hipLaunchKernelGGL((bn_fused_forward_kernel<8>), dim3(C), dim3(BNF_THREADS), 0, stream, (const float4*)x, weight, bias,
-                         running_mean, running_var, (float4*)y, save_mean, save_invstd, B, C, HW >> 2, eps, momentum, act);
+                         running_mean, running_var, (float4*)y, save_mean, save_invstd, B, C, HW >> 2, eps, momentum, act,
+                         (const float4*)res);
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   }
   const int S = bn_split(B, C);
@@ -354,7 +383,7 @@ extern "C" int ias_bn_act_forward(const float* x, const float* weight, const flo
                      HW, act);
   hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, x, scratch, save_mean, save_invstd,
                      running_mean, running_var, C, S, HW, (double)B * HW, eps, momentum);
-  bn_launch_apply<0>(stream, x, nullptr, save_mean, save_invstd, weight, bias, nullptr, y, B, C, HW, act);
+  bn_launch_apply<0>(stream, x, res, save_mean, save_invstd, weight, bias, nullptr, y, B, C, HW, act);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
@@ -401,24 +430,32 @@ extern "C" int ias_bn_act_backward(const float* x, const float* dy, const float*
 #define BN1_RG 8
 #define BN1_THREADS (BN1_FT * BN1_RG)
 
-// sum over the BN1_RG row groups of a feature, fixed order; every thread of the feature gets the result
-__device__ __forceinline__ float bn1_reduce(float v, float (*red)[BN1_FT], int tx, int ty) {
+// sums over the BN1_RG row groups of a feature, fixed order, NV values at once (one pair of barriers); every thread of
+// the feature gets the results
+template <int NV>
+__device__ __forceinline__ void bn1_reduce(float (&v)[NV], float (*red)[BN1_RG][BN1_FT], int tx, int ty) {
   __syncthreads();              // the previous use of `red` is over
-  red[ty][tx] = v;
-  __syncthreads();
-  float s = red[0][tx];
 #pragma unroll
-  for (int k = 1; k < BN1_RG; ++k) s += red[k][tx];
-  return s;
+  for (int j = 0; j < NV; ++j) red[j][ty][tx] = v[j];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    float s = red[j][0][tx];
+#pragma unroll
+    for (int k = 1; k < BN1_RG; ++k) s += red[j][k][tx];
+    v[j] = s;
+  }
 }
 
-template <int RPT>
+// GB: row groups handled per pass (2: both branches of the projector at once -- every load of the pass in flight together,
+// half the barriers; the running statistics still chain in group order)
+template <int RPT, int GB>
 __global__ __launch_bounds__(BN1_THREADS) void bn1d_groups_forward_kernel(
     const float* __restrict__ z, const float* __restrict__ lin_bias, const float* __restrict__ weight,
     const float* __restrict__ bias, float* __restrict__ running_mean, float* __restrict__ running_var,
     long long* __restrict__ num_batches_tracked, float* __restrict__ y, float* __restrict__ save_mean,
     float* __restrict__ save_invstd, int G, int n, int F, float eps, float momentum, int relu) {
-  __shared__ float red[BN1_RG][BN1_FT];
+  __shared__ float red[2 * GB][BN1_RG][BN1_FT];
   const int tx = threadIdx.x % BN1_FT, ty = threadIdx.x / BN1_FT;
   const int f = blockIdx.x * BN1_FT + tx;
   const bool live = f < F;
@@ -426,54 +463,70 @@ __global__ __launch_bounds__(BN1_THREADS) void bn1d_groups_forward_kernel(
   const float lb = lin_bias ? lin_bias[fc] : 0.0f, w = weight ? weight[fc] : 1.0f, b = bias ? bias[fc] : 0.0f;
   float rm = running_mean ? running_mean[fc] : 0.0f, rv = running_var ? running_var[fc] : 0.0f;
   const float inv_n = 1.0f / (float)n, unbias = (float)n / (float)(n - 1);
-  for (int g = 0; g < G; ++g) {
-    const float* zg = z + (size_t)g * n * F + fc;
-    float* yg = y + (size_t)g * n * F + fc;
-    float xv[RPT > 0 ? RPT : 1];
-    float s = 0.0f;
-    if (RPT > 0) {
+  for (int g0 = 0; g0 < G; g0 += GB) {                   // (G % GB == 0: the launcher)
+    float xv[GB][RPT > 0 ? RPT : 1];
+    float s[GB], q[GB];
 #pragma unroll
-      for (int i = 0; i < RPT; ++i) {
-        const int r = ty + i * BN1_RG;
-        xv[i] = r < n ? zg[(size_t)r * F] + lb : 0.0f;
-        s += xv[i];
-      }
-    } else {
-      for (int r = ty; r < n; r += BN1_RG) s += zg[(size_t)r * F] + lb;
-    }
-    const float mean = bn1_reduce(s, red, tx, ty) * inv_n;
-    float q = 0.0f;
-    if (RPT > 0) {
+    for (int j = 0; j < GB; ++j) {
+      const float* zg = z + (size_t)(g0 + j) * n * F + fc;
+      s[j] = 0.0f;
+      if (RPT > 0) {
 #pragma unroll
-      for (int i = 0; i < RPT; ++i) {
-        const float d = xv[i] - mean;
-        q += (ty + i * BN1_RG < n) ? d * d : 0.0f;
+        for (int i = 0; i < RPT; ++i) {
+          const int r = ty + i * BN1_RG;
+          xv[j][i] = r < n ? zg[(size_t)r * F] + lb : 0.0f;
+          s[j] += xv[j][i];
+        }
+      } else {
+        for (int r = ty; r < n; r += BN1_RG) s[j] += zg[(size_t)r * F] + lb;
       }
-    } else {
-      for (int r = ty; r < n; r += BN1_RG) { const float d = (zg[(size_t)r * F] + lb) - mean; q += d * d; }
     }
-    const float var = bn1_reduce(q, red, tx, ty) * inv_n;
-    const float invstd = 1.0f / sqrtf(var + eps);
-    const float a = invstd * w;
-    if (RPT > 0) {
+    bn1_reduce<GB>(s, red, tx, ty);
+    float mean[GB];
 #pragma unroll
-      for (int i = 0; i < RPT; ++i) {
-        const int r = ty + i * BN1_RG;
-        const float v = (xv[i] - mean) * a + b;
-        if (live && r < n) yg[(size_t)r * F] = relu ? fmaxf(v, 0.0f) : v;
-      }
-    } else {
-      for (int r = ty; r < n; r += BN1_RG) {
-        const float v = ((zg[(size_t)r * F] + lb) - mean) * a + b;
-        if (live) yg[(size_t)r * F] = relu ? fmaxf(v, 0.0f) : v;
+    for (int j = 0; j < GB; ++j) {
+      const float* zg = z + (size_t)(g0 + j) * n * F + fc;
+      mean[j] = s[j] * inv_n;
+      q[j] = 0.0f;
+      if (RPT > 0) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+          const float d = xv[j][i] - mean[j];
+          q[j] += (ty + i * BN1_RG < n) ? d * d : 0.0f;
+        }
+      } else {
+        for (int r = ty; r < n; r += BN1_RG) { const float d = (zg[(size_t)r * F] + lb) - mean[j]; q[j] += d * d; }
       }
     }
-    if (live && ty == 0) {
-      save_mean[(size_t)g * F + f] = mean;
-      save_invstd[(size_t)g * F + f] = invstd;
+    bn1_reduce<GB>(q, red, tx, ty);
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+      const int g = g0 + j;
+      const float* zg = z + (size_t)g * n * F + fc;
+      float* yg = y + (size_t)g * n * F + fc;
+      const float var = q[j] * inv_n;
+      const float invstd = 1.0f / sqrtf(var + eps);
+      const float a = invstd * w;
+      if (RPT > 0) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+          const int r = ty + i * BN1_RG;
+          const float v = (xv[j][i] - mean[j]) * a + b;
+          if (live && r < n) yg[(size_t)r * F] = relu ? fmaxf(v, 0.0f) : v;
+        }
+      } else {
+        for (int r = ty; r < n; r += BN1_RG) {
+          const float v = ((zg[(size_t)r * F] + lb) - mean[j]) * a + b;
+          if (live) yg[(size_t)r * F] = relu ? fmaxf(v, 0.0f) : v;
+        }
+      }
+      if (live && ty == 0) {
+        save_mean[(size_t)g * F + f] = mean[j];
+        save_invstd[(size_t)g * F + f] = invstd;
+      }
+      rm = (1.0f - momentum) * rm + momentum * mean[j];    // as torch: one update per call, in call order
+      rv = (1.0f - momentum) * rv + momentum * (var * unbias);
     }
-    rm = (1.0f - momentum) * rm + momentum * mean;       // as torch: one update per call, in call order
-    rv = (1.0f - momentum) * rv + momentum * (var * unbias);
   }
   if (live && ty == 0) {
     if (running_mean) running_mean[f] = rm;
@@ -484,13 +537,13 @@ __global__ __launch_bounds__(BN1_THREADS) void bn1d_groups_forward_kernel(
 
 // dy [G n, F] -> dx [G n, F] (the gradient of the Linear output in front), gw / gb [F] (BatchNorm weight and bias,
 // summed over the groups in group order), g_lin_bias [F] (column sums of dx).
-template <int RPT>
+template <int RPT, int GB>
 __global__ __launch_bounds__(BN1_THREADS) void bn1d_groups_backward_kernel(
     const float* __restrict__ z, const float* __restrict__ lin_bias, const float* __restrict__ dy,
     const float* __restrict__ weight, const float* __restrict__ bias, const float* __restrict__ save_mean,
     const float* __restrict__ save_invstd, float* __restrict__ dx, float* __restrict__ gw, float* __restrict__ gb,
     float* __restrict__ g_lin_bias, int G, int n, int F, int relu) {
-  __shared__ float red[BN1_RG][BN1_FT];
+  __shared__ float red[2 * GB][BN1_RG][BN1_FT];
   const int tx = threadIdx.x % BN1_FT, ty = threadIdx.x / BN1_FT;
   const int f = blockIdx.x * BN1_FT + tx;
   const bool live = f < F;
@@ -498,52 +551,62 @@ __global__ __launch_bounds__(BN1_THREADS) void bn1d_groups_backward_kernel(
   const float lb = lin_bias ? lin_bias[fc] : 0.0f, w = weight ? weight[fc] : 1.0f, b = bias ? bias[fc] : 0.0f;
   const float inv_n = 1.0f / (float)n;
   float gw_acc = 0.0f, gb_acc = 0.0f, glb_acc = 0.0f;
-  for (int g = 0; g < G; ++g) {
-    const size_t base = (size_t)g * n * F + fc;
-    const float mean = save_mean[(size_t)g * F + fc], invstd = save_invstd[(size_t)g * F + fc];
-    const float a = invstd * w;
-    float xh[RPT > 0 ? RPT : 1], dz[RPT > 0 ? RPT : 1];
-    float s1 = 0.0f, s2 = 0.0f;
+  for (int g0 = 0; g0 < G; g0 += GB) {
+    float xh[GB][RPT > 0 ? RPT : 1], dz[GB][RPT > 0 ? RPT : 1];
+    float mean[GB], invstd[GB], a[GB], ss[2 * GB];
     // the forward's own expression for the pre-activation value: the ReLU mask is the forward's mask
-    auto one = [&](int r, float& xhat, float& d) {
-      const float c = (z[base + (size_t)r * F] + lb) - mean;
-      const float v = c * a + b;
-      xhat = c * invstd;
+    auto one = [&](int j, size_t base, int r, float& xhat, float& d) {
+      const float c = (z[base + (size_t)r * F] + lb) - mean[j];
+      const float v = c * a[j] + b;
+      xhat = c * invstd[j];
       d = dy[base + (size_t)r * F];
       if (relu && !(v > 0.0f)) d = 0.0f;
     };
-    if (RPT > 0) {
 #pragma unroll
-      for (int i = 0; i < RPT; ++i) {
-        const int r = ty + i * BN1_RG;
-        xh[i] = 0.0f; dz[i] = 0.0f;
-        if (r < n) one(r, xh[i], dz[i]);
-        s1 += dz[i]; s2 += dz[i] * xh[i];
-      }
-    } else {
-      for (int r = ty; r < n; r += BN1_RG) { float xhat, d; one(r, xhat, d); s1 += d; s2 += d * xhat; }
-    }
-    s1 = bn1_reduce(s1, red, tx, ty);
-    s2 = bn1_reduce(s2, red, tx, ty);
-    const float m1 = s1 * inv_n, m2 = s2 * inv_n;
-    float sb = 0.0f;
-    if (RPT > 0) {
+    for (int j = 0; j < GB; ++j) {
+      const size_t base = (size_t)(g0 + j) * n * F + fc;
+      mean[j] = save_mean[(size_t)(g0 + j) * F + fc]; invstd[j] = save_invstd[(size_t)(g0 + j) * F + fc];
+      a[j] = invstd[j] * w;
+      float s1 = 0.0f, s2 = 0.0f;
+      if (RPT > 0) {
 #pragma unroll
-      for (int i = 0; i < RPT; ++i) {
-        const int r = ty + i * BN1_RG;
-        const float v = a * (dz[i] - m1 - xh[i] * m2);
-        if (r < n) { sb += v; if (live) dx[base + (size_t)r * F] = v; }
+        for (int i = 0; i < RPT; ++i) {
+          const int r = ty + i * BN1_RG;
+          xh[j][i] = 0.0f; dz[j][i] = 0.0f;
+          if (r < n) one(j, base, r, xh[j][i], dz[j][i]);
+          s1 += dz[j][i]; s2 += dz[j][i] * xh[j][i];
+        }
+      } else {
+        for (int r = ty; r < n; r += BN1_RG) { float xhat, d; one(j, base, r, xhat, d); s1 += d; s2 += d * xhat; }
       }
-    } else {
-      for (int r = ty; r < n; r += BN1_RG) {
-        float xhat, d; one(r, xhat, d);
-        const float v = a * (d - m1 - xhat * m2);
-        sb += v;
-        if (live) dx[base + (size_t)r * F] = v;
+      ss[2 * j] = s1; ss[2 * j + 1] = s2;
+    }
+    bn1_reduce<2 * GB>(ss, red, tx, ty);
+    float sb[GB];
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+      const size_t base = (size_t)(g0 + j) * n * F + fc;
+      const float m1 = ss[2 * j] * inv_n, m2 = ss[2 * j + 1] * inv_n;
+      sb[j] = 0.0f;
+      if (RPT > 0) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+          const int r = ty + i * BN1_RG;
+          const float v = a[j] * (dz[j][i] - m1 - xh[j][i] * m2);
+          if (r < n) { sb[j] += v; if (live) dx[base + (size_t)r * F] = v; }
+        }
+      } else {
+        for (int r = ty; r < n; r += BN1_RG) {
+          float xhat, d; one(j, base, r, xhat, d);
+          const float v = a[j] * (d - m1 - xhat * m2);
+          sb[j] += v;
+          if (live) dx[base + (size_t)r * F] = v;
+        }
       }
     }
-    sb = bn1_reduce(sb, red, tx, ty);
-    gw_acc += s2; gb_acc += s1; glb_acc += sb;
+    bn1_reduce<GB>(sb, reinterpret_cast<float (*)[BN1_RG][BN1_FT]>(red), tx, ty);
+#pragma unroll
+    for (int j = 0; j < GB; ++j) { gw_acc += ss[2 * j + 1]; gb_acc += ss[2 * j]; glb_acc += sb[j]; }
   }
   if (live && ty == 0) {
     if (gw) gw[f] = gw_acc;
@@ -565,11 +628,13 @@ extern "C" int ias_bn1d_groups_forward(const float* z, const float* lin_bias, co
       !(eps >= 0.0f))
     return IAS_ERR_ARG;
   const dim3 grid((F + BN1_FT - 1) / BN1_FT), block(BN1_THREADS);
+#define BN1_FWD(RPT, GB) hipLaunchKernelGGL((bn1d_groups_forward_kernel<RPT, GB>), grid, block, 0, stream, z, lin_bias, weight, bias, running_mean, running_var, num_batches_tracked, y, save_mean, save_invstd, G, n, F, eps, momentum, relu)
   switch (bn1_rpt(n)) {
-    case 16: hipLaunchKernelGGL((bn1d_groups_forward_kernel<16>), grid, block, 0, stream, z, lin_bias, weight, bias, running_mean, running_var, num_batches_tracked, y, save_mean, save_invstd, G, n, F, eps, momentum, relu); break;
-    case 32: hipLaunchKernelGGL((bn1d_groups_forward_kernel<32>), grid, block, 0, stream, z, lin_bias, weight, bias, running_mean, running_var, num_batches_tracked, y, save_mean, save_invstd, G, n, F, eps, momentum, relu); break;
-    default: hipLaunchKernelGGL((bn1d_groups_forward_kernel<0>), grid, block, 0, stream, z, lin_bias, weight, bias, running_mean, running_var, num_batches_tracked, y, save_mean, save_invstd, G, n, F, eps, momentum, relu); break;
+    case 16: if (G % 2 == 0) BN1_FWD(16, 2); else BN1_FWD(16, 1); break;
+    case 32: BN1_FWD(32, 1); break;
+    default: BN1_FWD(0, 1); break;
   }
+#undef BN1_FWD
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
@@ -580,10 +645,12 @@ extern "C" int ias_bn1d_groups_backward(const float* z, const float* lin_bias, c
   hipStream_t stream = (hipStream_t)stream_;
   if (!z || !dy || !dx || !save_mean || !save_invstd || G <= 0 || n < 2 || F <= 0) return IAS_ERR_ARG;
   const dim3 grid((F + BN1_FT - 1) / BN1_FT), block(BN1_THREADS);
+#define BN1_BWD(RPT, GB) hipLaunchKernelGGL((bn1d_groups_backward_kernel<RPT, GB>), grid, block, 0, stream, z, lin_bias, dy, weight, bias, save_mean, save_invstd, dx, gw, gb, g_lin_bias, G, n, F, relu)
   switch (bn1_rpt(n)) {
-    case 16: hipLaunchKernelGGL((bn1d_groups_backward_kernel<16>), grid, block, 0, stream, z, lin_bias, dy, weight, bias, save_mean, save_invstd, dx, gw, gb, g_lin_bias, G, n, F, relu); break;
-    case 32: hipLaunchKernelGGL((bn1d_groups_backward_kernel<32>), grid, block, 0, stream, z, lin_bias, dy, weight, bias, save_mean, save_invstd, dx, gw, gb, g_lin_bias, G, n, F, relu); break;
-    default: hipLaunchKernelGGL((bn1d_groups_backward_kernel<0>), grid, block, 0, stream, z, lin_bias, dy, weight, bias, save_mean, save_invstd, dx, gw, gb, g_lin_bias, G, n, F, relu); break;
+    case 16: if (G % 2 == 0) BN1_BWD(16, 2); else BN1_BWD(16, 1); break;
+    case 32: BN1_BWD(32, 1); break;
+    default: BN1_BWD(0, 1); break;
   }
+#undef BN1_BWD
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }

@@ -206,7 +206,7 @@ class _BNActFn(torch.autograd.Function):
     """Training-mode batch norm + activation as the HIP kernels of csrc/bn_kernels.hip (ias_bn_act_forward / _backward)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act, res=None):
         from . import _lib
         lib = _lib.load()
         x = x.contiguous()
@@ -216,12 +216,22 @@ class _BNActFn(torch.autograd.Function):
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty_like(mean)
         scratch = torch.empty(int(lib.ias_bn_scratch_doubles(B, C)), dtype=torch.float64, device=x.device)
-        _lib.check(lib.ias_bn_act_forward(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(running_mean),
-                                          _lib.ptr(running_var), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(invstd),
-                                          _lib.ptr(scratch), B, C, HW, float(eps), float(momentum), int(act),
-                                          _lib.stream()), "ias_bn_act_forward")
+        if res is not None:
+            # the block's residual connection in the same pass: y = act(bn(x)) + res
+            res = res.contiguous()
+            assert res.shape == x.shape
+            _lib.check(lib.ias_bn_act_forward_res(_lib.ptr(x), _lib.ptr(res), _lib.ptr(weight), _lib.ptr(bias),
+                                                  _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(y), _lib.ptr(mean),
+                                                  _lib.ptr(invstd), _lib.ptr(scratch), B, C, HW, float(eps), float(momentum),
+                                                  int(act), _lib.stream()), "ias_bn_act_forward_res")
+        else:
+            _lib.check(lib.ias_bn_act_forward(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(running_mean),
+                                              _lib.ptr(running_var), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(invstd),
+                                              _lib.ptr(scratch), B, C, HW, float(eps), float(momentum), int(act),
+                                              _lib.stream()), "ias_bn_act_forward")
         ctx.save_for_backward(x, weight, bias, mean, invstd)
         ctx.act = int(act)
+        ctx.has_res = res is not None
         return y
 
     @staticmethod
@@ -240,7 +250,7 @@ class _BNActFn(torch.autograd.Function):
         _lib.check(lib.ias_bn_act_backward(_lib.ptr(x), _lib.ptr(g), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(mean),
                                            _lib.ptr(invstd), _lib.ptr(dx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(scratch),
                                            _lib.ptr(sums), B, C, HW, ctx.act, _lib.stream()), "ias_bn_act_backward")
-        return dx, gw, gb, None, None, None, None, None
+        return dx, gw, gb, None, None, None, None, None, (g if ctx.has_res else None)
 
 
 _ACT_CODE = {None: 0, nn.ReLU: 1, nn.Hardswish: 2}
@@ -256,13 +266,16 @@ class BatchNormAct2d(nn.BatchNorm2d):
         assert act in _ACT_CODE
         self.act_code = _ACT_CODE[act]
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """``residual`` (InvertedResidual's skip connection): returns act(bn(x)) + residual, on the HIP path in one pass."""
         if self.training and x.is_cuda and not trunk_torch() and x.dtype == torch.float32 and x.dim() == 4 and self.track_running_stats and \
                 self.momentum is not None and self.affine:
             if self.num_batches_tracked is not None and not getattr(self, "counter_deferred", False):
                 self.num_batches_tracked.add_(1)     # (deferred: one multi-tensor add for all layers, see defer_bn_counters)
             return _BNActFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
-                                  self.momentum, self.act_code)
+                                  self.momentum, self.act_code, residual)
+        if residual is not None:
+            return residual + self.forward(x)
         y = super().forward(x)
         if self.training and getattr(self, "counter_deferred", False) and self.num_batches_tracked is not None and \
                 self.track_running_stats:
@@ -395,8 +408,14 @@ class InvertedResidual(nn.Module):
         self.block = nn.Sequential(*layers)
 
     def forward(self, x):
-        y = self.block(x)
-        return x + y if self.use_res else y
+        if not self.use_res:
+            return self.block(x)
+        # the skip connection is added by the block's last normalisation (one pass: BatchNormAct2d.forward(residual=...))
+        h = x
+        for layer in list(self.block)[:-1]:
+            h = layer(h)
+        conv, norm = self.block[-1][0], self.block[-1][1]
+        return norm(conv(h), residual=x)
 
 
 # (in, kernel, expanded, out, squeeze-excite, hardswish, stride)

@@ -269,3 +269,29 @@ def test_pointwise_conv_matches_torch(lib, dev, B, Cin, Cout, H, W):
     gw2 = torch.autograd.grad(m(x), m.weight, g)[0]
     if lib.ias_pwconv_supported(Cin, Cout):
         assert torch.equal(gw, gw2)
+
+
+@pytest.mark.parametrize("shape", [(128, 40, 15, 16), (6, 24, 30, 31), (3, 96, 8, 8), (2, 33, 7, 9), (128, 24, 30, 31)])
+def test_batchnorm_with_the_residual_in_the_same_pass(lib, dev, shape):
+    """BatchNormAct2d.forward(x, residual=r) (ias_bn_act_forward_res: the skip connection of an inverted-residual block
+    added by the block's last normalisation) against the separate addition: the same bits forward, the same gradients for
+    x, the residual and the affine parameters -- on the one-workgroup-per-channel kernels (maps up to 15 x 16), the
+    three-launch form (30 x 31) and the scalar form (odd sizes)."""
+    from inverse_audio_synthesis_amd.vision import BatchNormAct2d
+    import copy
+    torch.manual_seed(4)
+    a = BatchNormAct2d(shape[1], eps=0.001, momentum=0.01, act=None).to(dev).train()
+    with torch.no_grad():
+        a.weight.copy_(1.0 + 0.2 * torch.randn(shape[1])); a.bias.copy_(0.1 * torch.randn(shape[1]))
+    b = copy.deepcopy(a)
+    x1 = randn(shape, 1).to(dev).requires_grad_(True); r1 = randn(shape, 2).to(dev).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True); r2 = r1.detach().clone().requires_grad_(True)
+    y1 = a(x1, residual=r1)
+    y2 = r2 + b(x2)
+    assert torch.equal(y1, y2)
+    g = randn(shape, 3).to(dev)
+    got = torch.autograd.grad(y1, [x1, r1, a.weight, a.bias], g)
+    want = torch.autograd.grad(y2, [x2, r2, b.weight, b.bias], g)
+    for u, v in zip(got, want):
+        assert torch.equal(u, v)
+    assert torch.equal(a.running_mean, b.running_mean) and torch.equal(a.running_var, b.running_var)

@@ -239,9 +239,17 @@ def test_project_pair_fused_batchnorm_matches_two_projector_calls(lib, dev, n, w
     from inverse_audio_synthesis_amd import vicreg
     torch.manual_seed(11)
     d0, d1, d2, d3 = widths
-    proj = torch.nn.Sequential(torch.nn.Linear(d0, d1), torch.nn.BatchNorm1d(d1), torch.nn.ReLU(True),
-                               torch.nn.Linear(d1, d2), torch.nn.BatchNorm1d(d2), torch.nn.ReLU(True),
-                               torch.nn.Linear(d2, d3, bias=False)).to(dev)
+    if d1 >= 8192:
+        # the full-size projector WITHOUT its ReLUs: of 2 x 2 M pre-activations a few hundred lie within rounding of zero and
+        # take the other side of the ReLU in one of the two runs (the GEMMs in front differ in their bias pass), which moves
+        # isolated gradient elements by percents; the mask is covered by the small cases, the sizes by this one
+        proj = torch.nn.Sequential(torch.nn.Linear(d0, d1), torch.nn.BatchNorm1d(d1),
+                                   torch.nn.Linear(d1, d2), torch.nn.BatchNorm1d(d2),
+                                   torch.nn.Linear(d2, d3, bias=False)).to(dev)
+    else:
+        proj = torch.nn.Sequential(torch.nn.Linear(d0, d1), torch.nn.BatchNorm1d(d1), torch.nn.ReLU(True),
+                                   torch.nn.Linear(d1, d2), torch.nn.BatchNorm1d(d2), torch.nn.ReLU(True),
+                                   torch.nn.Linear(d2, d3, bias=False)).to(dev)
     with torch.no_grad():
         for m in proj:
             if isinstance(m, torch.nn.BatchNorm1d):
@@ -265,13 +273,7 @@ def test_project_pair_fused_batchnorm_matches_two_projector_calls(lib, dev, n, w
         # the Linear biases in front of a BatchNorm have a gradient that is zero in exact arithmetic: absolute bound
         bound = 2e-4 * max(1.0, w.abs().max().item())
         d = (g - w).abs()
-        if d1 >= 8192 and d.max().item() > bound:
-            # the full-size projector: of 2 x 2 M pre-activations a few hundred lie within rounding of zero and take the
-            # other side of the ReLU in one of the two runs -- isolated elements move, the gradient as a whole does not
-            rel = (d.double().pow(2).sum().sqrt() / w.double().pow(2).sum().sqrt()).item()
-            assert rel <= 5e-3 and (d > bound).double().mean().item() <= 2e-2, (k, rel, (d > bound).double().mean().item())
-        else:
-            assert d.max().item() <= bound, (k, d.max().item(), w.abs().max().item())
+        assert d.max().item() <= bound, (k, d.max().item(), w.abs().max().item())
     for m, r in zip(proj, ref):
         if isinstance(m, torch.nn.BatchNorm1d):
             assert torch.allclose(m.running_mean, r.running_mean, atol=1e-6, rtol=1e-5)
