@@ -147,12 +147,12 @@ __device__ __forceinline__ float sem_row16_sum(float v) {
 #define SEF_RU 4
 template <typename Epilogue>
 __device__ __forceinline__ void sef_layer(const float* __restrict__ w, const float* __restrict__ bias, const float* s_v, int K,
-                                          int O, bool vec, Epilogue&& done) {
+                                          int O, bool vec, Epilogue&& done, int o_begin = 0) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & 15, grp = wave * 4 + (lane >> 4);       // 32 groups of 16 lanes
   constexpr int NGRP = SEF_THREADS / 16, RPG = NGRP * SEF_RU;    // rows per workgroup and round
-  for (int o0 = 0; o0 < O; o0 += RPG) {                          // (uniform trip count: the DPP folds need whole rows of lanes)
+  for (int o0 = o_begin; o0 < O; o0 += RPG) {                    // (uniform trip count: the DPP folds need whole rows of lanes)
     const float* row[SEF_RU];
     float a0[SEF_RU], a1[SEF_RU];
 #pragma unroll
@@ -231,18 +231,24 @@ __global__ __launch_bounds__(SEF_THREADS) void se_mlp_forward_kernel(const float
   sef_layer(w1, b1, s_p, C, Cs, vec1 != 0, [&](int o, float v0, float v1) {
     v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f);
     s_h[o] = v0; s_h[Cs + o] = v1;
-    h[(size_t)bs * Cs + o] = v0;
-    if (has1) h[(size_t)(bs + 1) * Cs + o] = v1;
+    if (blockIdx.y == 0) {
+      h[(size_t)bs * Cs + o] = v0;
+      if (has1) h[(size_t)(bs + 1) * Cs + o] = v1;
+    }
   });
   __syncthreads();
-  sef_layer(w2, b2, s_h, Cs, C, vec2 != 0, [&](int o, float v0, float v1) {
+  // gridDim.y workgroups per sample pair (wide blocks: a workgroup streams its weights at ~33 GB/s, and 64 workgroups
+  // leave three quarters of the chip idle): every one of them computes ALL of h (it needs it), then its own slice of the
+  // second layer's outputs -- C = 576 with five slices: 663 -> 398 KB of weights per workgroup
+  const int per = (C + (int)gridDim.y - 1) / (int)gridDim.y, c_lo = (int)blockIdx.y * per, c_hi = min(C, c_lo + per);
+  sef_layer(w2, b2, s_h, Cs, c_hi, vec2 != 0, [&](int o, float v0, float v1) {
     z[(size_t)bs * C + o] = v0;
     s[(size_t)bs * C + o] = fminf(fmaxf(v0 + 3.0f, 0.0f), 6.0f) / 6.0f;
     if (has1) {
       z[(size_t)(bs + 1) * C + o] = v1;
       s[(size_t)(bs + 1) * C + o] = fminf(fmaxf(v1 + 3.0f, 0.0f), 6.0f) / 6.0f;
     }
-  });
+  }, c_lo);
 }
 
 // per sample: gz = gs * hardsigmoid'(z); gh = relu'(h) * W2^T gz; gp = W1^T gh   (lanes along the output index: the
@@ -432,7 +438,8 @@ extern "C" int ias_se_mlp_forward(const float* pooled, const float* w1, const fl
   const int vec1 = ((C & 3) == 0 && se_aligned16(w1)) ? 1 : 0, vec2 = ((Cs & 3) == 0 && (C & 3) == 0 && se_aligned16(w2)) ? 1 : 0;
   (void)hipFuncSetAttribute((const void*)se_mlp_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)(sizeof(float) * (size_t)SEF_SB * (C + Cs)));
-  hipLaunchKernelGGL(se_mlp_forward_kernel, dim3((B + SEF_SB - 1) / SEF_SB), dim3(SEF_THREADS),
+  const int slices = C >= 192 ? (C + 127) / 128 : 1;   // one round of 32 x SEF_RU = 128 second-layer rows per workgroup (C = 576: 5 slices of 116)
+  hipLaunchKernelGGL(se_mlp_forward_kernel, dim3((B + SEF_SB - 1) / SEF_SB, slices), dim3(SEF_THREADS),
                      sizeof(float) * (size_t)SEF_SB * (C + Cs), (hipStream_t)stream_, pooled, w1, b1, w2, b2, h, z, s, B, C, Cs, vec1,
                      vec2);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
