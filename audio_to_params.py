@@ -29,7 +29,9 @@ def app(overrides=None):
     ckpt = os.path.join(ROOT, "vicreg.ckpt")
     if os.path.exists(ckpt):
         # a checkpoint of this build, or one shaped like the reference's Lightning file (extra classifier / voice keys)
-        sd = torch.load(ckpt, map_location="cpu", weights_only=False)["state_dict"]
+        # (tensors and plain containers only: nothing in the file is executed.  A Lightning checkpoint that carries pickled
+        # hyper-parameter objects is refused by this loader -- re-save its "state_dict" entry alone)
+        sd = torch.load(ckpt, map_location="cpu", weights_only=True)["state_dict"]
         missing, unexpected, dropped = load_reference_state_dict(vicreg, sd)
         if missing or unexpected:
             print({"vicreg.ckpt": {"missing": missing, "unexpected": unexpected, "dropped": len(dropped)}}, flush=True)

@@ -151,7 +151,7 @@ class Trainer:
 
     def load_checkpoint(self, path, strict=True):
         """Resume: module, optimizer and scheduler state (so a resumed LARS run does not restart its warm-up)."""
-        ck = torch.load(path, map_location=self.device, weights_only=False)
+        ck = torch.load(path, map_location=self.device, weights_only=True)   # tensors / plain containers only
         self.module.load_state_dict(ck["state_dict"], strict=strict)
         if ck.get("optimizer") is not None:
             self.optimizer.load_state_dict(ck["optimizer"])

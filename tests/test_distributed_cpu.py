@@ -76,20 +76,22 @@ def _body_gather_rows(rank, world):
 def _body_grad_bucketer(rank, world):
     from inverse_audio_synthesis_amd.dist import GradBucketer, all_reduce_mean
     torch.manual_seed(0)  # same init on every rank
-    model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4),
+    H = 2800              # 6 x 2800 weights: above GradBucketer.SMALL (own copy launch); the rest go in by the joint copy
+    model = torch.nn.Sequential(torch.nn.Linear(6, H), torch.nn.ReLU(), torch.nn.Linear(H, 4),
                                 torch.nn.Linear(4, 3))
-    for p in model[3].parameters():   # a branch that gets no gradient this step
-        pass
     bucketer = GradBucketer(model, bucket_bytes=300)  # tiny buckets: several collectives
     assert len(bucketer.buckets) >= 3
+    assert model[0].weight.numel() >= GradBucketer.SMALL > model[2].weight.numel()
     data = [torch.randn(5, 6, generator=torch.Generator().manual_seed(50 + r)) for r in range(world)]
     ok = True
-    for step in range(2):
+    for step in range(3):
         bucketer.begin_step()
+        ok = ok and all(p.grad is None for p in model.parameters())
+        nback = 1
         model[2](model[1](model[0](data[rank]))).pow(2).sum().backward()   # model[3] unused
         bucketer.finish()
         # reference: mean over ranks of the single-process gradients
-        ref_model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+        ref_model = torch.nn.Sequential(torch.nn.Linear(6, H), torch.nn.ReLU(), torch.nn.Linear(H, 4))
         ref_model.load_state_dict({k: v for k, v in model.state_dict().items() if not k.startswith("3.")})
         grads = None
         for r in range(world):
@@ -98,8 +100,21 @@ def _body_grad_bucketer(rank, world):
             g = [p.grad.clone() for p in ref_model.parameters()]
             grads = g if grads is None else [a + b for a, b in zip(grads, g)]
         for p, g in zip(list(model.parameters())[:4], grads):
-            ok = ok and torch.allclose(p.grad, g / world, atol=1e-6)
+            ok = ok and torch.allclose(p.grad, nback * g / world, rtol=1e-5, atol=1e-6)
+        # a parameter without a gradient takes part as zeros; every gradient lives in its bucket after the step
         ok = ok and all(float(p.grad.abs().sum()) == 0.0 for p in model[3].parameters())
+        for flat, plist in bucketer.buckets:
+            lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+            ok = ok and all(lo <= p.grad.data_ptr() < hi for p in plist)
+    # one backward per step: a bucket goes out as soon as its gradients of ONE backward are in
+    bucketer.begin_step()
+    model[2](model[1](model[0](data[rank]))).pow(2).sum().backward()
+    try:
+        model[2](model[1](model[0](data[rank]))).pow(2).sum().backward()
+        ok = False
+    except RuntimeError as ex:
+        ok = ok and "second backward" in str(ex)
+    bucketer.finish()
     m = all_reduce_mean(torch.tensor(float(rank + 1)))
     return bool(ok and abs(m.item() - (world + 1) / 2) < 1e-6)
 
