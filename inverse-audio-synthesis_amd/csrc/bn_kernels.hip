@@ -10,6 +10,7 @@
 //             dz and dz * xhat per channel, a finalize (dw, db), and ONE pass dx = w invstd (dz - mean(dz) - xhat mean(dz xhat)).
 // Nothing but mean / invstd is saved between forward and backward.  All sums in a fixed order (deterministic).
 #include "ias_common.h"
+#include "wave_ops.h"
 #include <cstdint>
 #include <cstdlib>
 
@@ -95,14 +96,25 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partials_kernel(const float* __
 
 // mean, biased variance -> save_mean, save_invstd, running statistics (momentum m: r = (1 - m) r + m stat, unbiased
 // variance in the running one, as torch.nn.BatchNorm2d)
-__global__ void bn_finalize_stats_kernel(const float* __restrict__ x, const double* __restrict__ partials,
-                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                         float* __restrict__ running_mean, float* __restrict__ running_var, int C, int S,
-                                         int HW, double n, float eps, float momentum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// The finalize launches sit between the partial-sum pass and the apply pass of every large-map layer, 20 per pretraining
+// step, and are pure latency.  Rounds 2-4: a thread per channel walking its S <= 64 partial pairs one dependent 16-byte
+// load after the other, ONE workgroup for the layer (5-10 us per launch).  Round 5: a WAVE per channel -- lane s loads
+// pair s (one request per lane, all in flight together) and the pairs meet in the DPP scan of wave_ops.h (fixed order:
+// deterministic, fp64 as before).
+#define BN_FIN_WAVES 4
+__global__ __launch_bounds__(64 * BN_FIN_WAVES) void bn_finalize_stats_kernel(
+    const float* __restrict__ x, const double* __restrict__ partials, float* __restrict__ save_mean,
+    float* __restrict__ save_invstd, float* __restrict__ running_mean, float* __restrict__ running_var, int C, int S, int HW,
+    double n, float eps, float momentum) {
+  const int lane = threadIdx.x & 63, c = blockIdx.x * BN_FIN_WAVES + (threadIdx.x >> 6);
+  if (c >= C) return;                                  // (whole waves leave: c is wave-uniform)
   double s1 = 0.0, s2 = 0.0;
-  for (int s = 0; s < S; ++s) { s1 += partials[((size_t)c * S + s) * 2]; s2 += partials[((size_t)c * S + s) * 2 + 1]; }
+  if (lane < S) {
+    const double2 v = reinterpret_cast<const double2*>(partials)[(size_t)c * S + lane];
+    s1 = v.x; s2 = v.y;
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane != 0) return;
   const double k = (double)x[(size_t)c * HW];
   const double dm = s1 / n;
   double var = s2 / n - dm * dm;
@@ -114,12 +126,18 @@ __global__ void bn_finalize_stats_kernel(const float* __restrict__ x, const doub
   if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * (n > 1.0 ? n / (n - 1.0) : 1.0));
 }
 
-__global__ void bn_finalize_grads_kernel(const double* __restrict__ partials, float* __restrict__ gw, float* __restrict__ gb,
-                                         float* __restrict__ sums, int C, int S) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64 * BN_FIN_WAVES) void bn_finalize_grads_kernel(const double* __restrict__ partials,
+                                                                              float* __restrict__ gw, float* __restrict__ gb,
+                                                                              float* __restrict__ sums, int C, int S) {
+  const int lane = threadIdx.x & 63, c = blockIdx.x * BN_FIN_WAVES + (threadIdx.x >> 6);
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int s = 0; s < S; ++s) { s1 += partials[((size_t)c * S + s) * 2]; s2 += partials[((size_t)c * S + s) * 2 + 1]; }
+  if (lane < S) {
+    const double2 v = reinterpret_cast<const double2*>(partials)[(size_t)c * S + lane];
+    s1 = v.x; s2 = v.y;
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane != 0) return;
   if (gb) gb[c] = (float)s1;
   if (gw) gw[c] = (float)s2;
   sums[2 * c] = (float)s1; sums[2 * c + 1] = (float)s2;
@@ -307,7 +325,7 @@ static int bn_split(int B, int C) {
   int s = (target + C - 1) / C;
   if (s < 1) s = 1;
   if (s > B) s = B;
-  if (s > 64) s = 64;
+  if (s > 64) s = 64;     // (bn_finalize_*: one partial pair per lane of a wave)
   return s;
 }
 // doubles of scratch the forward / backward need (partials [C][split][2])
@@ -381,7 +399,7 @@ static int bn_act_forward_impl(const float* x, const float* res, const float* we
   hipLaunchKernelGGL((bn_partials_kernel<0>), dim3(C, S), dim3(BN_THREADS), 0, stream, x, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, scratch, B, C,
                      HW, act);
-  hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, x, scratch, save_mean, save_invstd,
+  hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + BN_FIN_WAVES - 1) / BN_FIN_WAVES), dim3(64 * BN_FIN_WAVES), 0, stream, x, scratch, save_mean, save_invstd,
                      running_mean, running_var, C, S, HW, (double)B * HW, eps, momentum);
   bn_launch_apply<0>(stream, x, res, save_mean, save_invstd, weight, bias, nullptr, y, B, C, HW, act);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
@@ -407,7 +425,7 @@ extern "C" int ias_bn_act_backward(const float* x, const float* dy, const float*
   const int S = bn_split(B, C);
   hipLaunchKernelGGL((bn_partials_kernel<1>), dim3(C, S), dim3(BN_THREADS), 0, stream, x, dy, save_mean, save_invstd, weight,
                      bias, scratch, B, C, HW, act);
-  hipLaunchKernelGGL(bn_finalize_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch, gw, gb, sums, C, S);
+  hipLaunchKernelGGL(bn_finalize_grads_kernel, dim3((C + BN_FIN_WAVES - 1) / BN_FIN_WAVES), dim3(64 * BN_FIN_WAVES), 0, stream, scratch, gw, gb, sums, C, S);
   bn_launch_apply<1>(stream, x, dy, save_mean, save_invstd, weight, bias, sums, dx, B, C, HW, act);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
