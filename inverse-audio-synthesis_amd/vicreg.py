@@ -19,17 +19,6 @@ import torch.nn.functional as F
 from . import _lib
 
 
-_ZERO = {}
-
-
-def _zero_scalar(device):
-    """A cached fp32 zero [1] per device (never written)."""
-    z = _ZERO.get(device)
-    if z is None:
-        z = _ZERO[device] = torch.zeros(1, dtype=torch.float32, device=device)
-    return z
-
-
 def _cotangent_ptrs(grads):
     """-> ([four device pointers, None where autograd passed None], the fp32 tensors they point into -- keep them alive
     until the launch has been issued)."""
@@ -68,37 +57,33 @@ class _VICRegLossFn(torch.autograd.Function):
         grads = (g_loss, g_repr, g_std, g_cov)
         if all(g is None for g in grads):
             return None, None, None, None, None, None
-        if D % 8 != 0:
-            zero = _zero_scalar(x.device)
-            gcoef = torch.cat([zero if g is None else g.to(torch.float32).reshape(1) for g in grads])
-            return _vicreg_backward_torch(x, y, gcoef, cfg_batch, sim, std, cov) + (None, None, None, None)
-        gx, gy = torch.empty_like(x), torch.empty_like(y)
         cot = _cotangent_ptrs(grads)
+        if D % 8 != 0:
+            # The backward kernels move 16-byte groups of 8 bf16 columns.  An embedding width that is not a multiple of 8 (none
+            # of the reference's configurations; toy shapes) runs them on the inputs padded with zero COLUMNS: a zero column
+            # is its own mean, so it adds nothing to any covariance entry, its hinge term is a constant, and every term of
+            # the loss carries the same 1 / D -- the gradient of the real columns is the padded one times D8 / D, exactly.
+            D8 = (D + 7) // 8 * 8
+            xp, yp = x.new_zeros((B, D8)), y.new_zeros((B, D8))
+            xp[:, :D].copy_(x)
+            yp[:, :D].copy_(y)
+            need = lib.ias_vicreg_workspace_bytes(B, D8)
+            _lib.check(min(int(need), 0), "ias_vicreg_workspace_bytes")
+            wsp = torch.empty(int(need), dtype=torch.uint8, device=x.device)
+            outp = torch.empty(4, dtype=torch.float32, device=x.device)
+            _lib.check(lib.ias_vicreg_loss(_lib.ptr(xp), _lib.ptr(yp), _lib.ptr(outp), _lib.ptr(wsp), wsp.numel(), B, D8, cfg_batch,
+                                           sim, std, cov, _lib.stream()), "ias_vicreg_loss")
+            gxp, gyp = torch.empty_like(xp), torch.empty_like(yp)
+            _lib.check(lib.ias_vicreg_backward4_ld(_lib.ptr(xp), _lib.ptr(yp), D8, *cot[0], _lib.ptr(gxp), _lib.ptr(gyp), D8,
+                                                   _lib.ptr(wsp), wsp.numel(), B, D8, cfg_batch, sim, std, cov, _lib.stream()),
+                       "ias_vicreg_backward4_ld")
+            k = float(D8) / float(D)
+            return gxp[:, :D] * k, gyp[:, :D] * k, None, None, None, None
+        gx, gy = torch.empty_like(x), torch.empty_like(y)
         st = lib.ias_vicreg_backward4_ld(_lib.ptr(x), _lib.ptr(y), D, *cot[0], _lib.ptr(gx), _lib.ptr(gy), D, _lib.ptr(ws),
                                          ws.numel(), B, D, cfg_batch, sim, std, cov, _lib.stream())
         _lib.check(st, "ias_vicreg_backward4_ld")
         return gx, gy, None, None, None, None
-
-
-def _vicreg_backward_torch(x, y, gcoef, cfg_batch, sim, std, cov):
-    """The same closed form as plain fp32 device ops (embedding widths that are not a multiple of 8; also the
-    definition the HIP backward is tested against besides autograd through the oracle)."""
-    B, D = x.shape
-    a = gcoef[0] * sim + gcoef[1]
-    b = gcoef[0] * std + gcoef[2]
-    c = gcoef[0] * cov + gcoef[3]
-    d_repr = (x - y) * (2.0 / (B * D))
-
-    def branch(v):
-        vc = v - v.mean(dim=0)
-        m2 = (vc * vc).sum(dim=0)
-        s = torch.sqrt(m2 / (B - 1) + 0.0001)
-        d_std = -(s < 1).to(v.dtype) / (2.0 * D * (B - 1) * s) * vc
-        gram = vc @ vc.T
-        d_cov = (gram @ vc - vc * m2) * (4.0 / ((cfg_batch - 1) ** 2 * D))
-        return b * d_std + c * d_cov
-
-    return a * d_repr + branch(x), -a * d_repr + branch(y)
 
 
 class _VICRegPairLossFn(torch.autograd.Function):
