@@ -564,6 +564,7 @@ def pretrain_ddp_leg(dev, rank, world, B=128, steps=5, reps=3):
             model = VicregAudioParams(cfg)
         tr = Trainer(cfg, model, stage="vicreg", device=dev)
         if local_only:
+            tr.bucketer.close()        # (the Trainer's own: its hooks would go on filling and reducing its buckets)
             tr.bucketer = ias_dist.GradBucketer(model, bucket_bytes=int(cfg.trainer.bucket_mb) << 20, local_only=True)
         model.train()
         return tr, model

@@ -378,6 +378,10 @@ long long ias_dwconv_weight_scratch(int B, int C, int K);     /* floats: upper b
 long long ias_dwconv_weight_scratch_hw(int B, int C, int H, int W, int K, int S);   /* floats, for this plane size */
 int ias_dwconv_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int C, int H, int W,
                                int K, int S, void* stream);
+/* ... without its reduction launch: the partial rows stay in `scratch` -> their number (> 0; C K K floats each) for
+ * ias_reduce_partials_multi below, or a negative IAS_ERR_* */
+int ias_dwconv_backward_weight_partials(const float* x, const float* g, float* scratch, int B, int C, int H, int W, int K,
+                                        int S, void* stream);
 /* Conv2d(3, 16, 3, stride 2, padding 1, bias=False): x [B,3,H,W], w [16,3,3,3] -> out [B,16,Ho,Wo]; weight gradient. */
 /* 1x1 convolutions (nn.Conv2d(Cin, Cout, 1, bias=False)) of torchvision's mobilenet_v3_small.features as run at
  * /root/reference/audioembed.py:61, NCHW fp32, on fp32 MFMA: x [B,Cin,HW], w [Cout,Cin], y / g [B,Cout,HW].
@@ -390,6 +394,21 @@ int ias_pwconv_backward_data(const float* g, const float* w, float* gx, int B, i
 long long ias_pwconv_weight_scratch(int B, int Cin, int Cout, int HW);
 int ias_pwconv_backward_weight(const float* g, const float* x, float* gw, float* scratch, int B, int Cin, int Cout, int HW,
                                void* stream);
+/* ... without its reduction launch -> the number of partial rows (> 0; Cout Cin floats each), or a negative IAS_ERR_* */
+int ias_pwconv_backward_weight_partials(const float* g, const float* x, float* scratch, int B, int Cin, int Cout, int HW,
+                                        void* stream);
+
+/* The weight-gradient reductions of a whole backward pass of the trunk (torchvision mobilenet_v3_small.features, run at
+ * /root/reference/audioembed.py:61; autograd of /root/reference/vicreg_audio_params.py:96-122) in ONE launch:
+ * out[i] = sum_r partial[r n + i] (i < n, r < rows; fixed order) for every entry of a HOST array of `count` entries
+ * holding device pointers -- the table travels in the kernel arguments (nothing is copied to the device, nothing has to
+ * outlive the call; capturable).  The *_backward_weight_partials entry points leave such rows behind. */
+typedef struct IasReduceItem {
+  const float* partial;
+  float* out;
+  int n, rows;
+} IasReduceItem;
+int ias_reduce_partials_multi(const IasReduceItem* items, int count, void* stream);
 
 /* squeeze-and-excitation blocks of the trunk (torchvision SqueezeExcitation; /root/reference/vicreg_audio_params.py:52-54):
  * per-plane reductions and the per-plane scale over a [planes][hw] activation (planes = B C).
@@ -424,6 +443,8 @@ int ias_colsum(const float* a, float* out, float* scratch, int rows, int cols, v
 int ias_stem_forward(const float* x, const float* w, float* out, int B, int H, int W, void* stream);
 long long ias_stem_weight_scratch(int B);                     /* floats */
 int ias_stem_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int H, int W, void* stream);
+/* ... without its reduction launch -> the number of partial rows (> 0; 432 floats each), or a negative IAS_ERR_* */
+int ias_stem_backward_weight_partials(const float* x, const float* g, float* scratch, int B, int H, int W, void* stream);
 
 /* ---- Training-mode BatchNorm2d with the following activation fused (act 0 none, 1 ReLU, 2 Hardswish): replaces the
  * nn.BatchNorm2d + activation pairs of torchvision's mobilenet_v3_small.features (audioembed.py:61) and their autograd.

@@ -101,11 +101,14 @@ SYMBOLS = {
     "ias_dwconv_weight_scratch": (_LL, [_I, _I, _I]),
     "ias_dwconv_weight_scratch_hw": (_LL, [_I, _I, _I, _I, _I, _I]),
     "ias_dwconv_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ias_dwconv_backward_weight_partials": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ias_pwconv_supported": (_I, [_I, _I]),
     "ias_pwconv_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_pwconv_backward_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_pwconv_weight_scratch": (_LL, [_I, _I, _I, _I]),
     "ias_pwconv_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_pwconv_backward_weight_partials": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_reduce_partials_multi": (_I, [_P, _I, _P]),
     "ias_se_plane_reduce": (_I, [_P, _P, _P, _LL, _I, _F, _P]),
     "ias_se_scale": (_I, [_P, _P, _P, _P, _LL, _I, _F, _P]),
     "ias_se_mlp_forward": (_I, [_P] * 8 + [_I, _I, _I, _P]),
@@ -119,6 +122,7 @@ SYMBOLS = {
     "ias_stem_forward": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ias_stem_weight_scratch": (_LL, [_I]),
     "ias_stem_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "ias_stem_backward_weight_partials": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ias_bn_scratch_doubles": (_LL, [_I, _I]),
     "ias_bn_act_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P]),
     "ias_bn_act_forward_res": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P]),

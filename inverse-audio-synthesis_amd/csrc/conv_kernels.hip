@@ -1114,11 +1114,11 @@ extern "C" long long ias_dwconv_weight_scratch_hw(int B, int C, int H, int W, in
 }
 
 // its gradient w.r.t. the weights: x [B,C,H,W], g [B,C,Ho,Wo] -> gw [C,1,K,K]; scratch: ias_dwconv_weight_scratch floats
-extern "C" int ias_dwconv_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int C, int H,
-                                          int W, int K, int S, void* stream_) {
-  int rc = cv_check(x, g, gw, B, C, H, W, K, S);
+// gw == nullptr: the partial sums only -> *nrows rows of C K K floats in `scratch` (ias_dwconv_backward_weight_partials)
+static int dw_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int C, int H, int W, int K,
+                              int S, int* nrows, void* stream_) {
+  int rc = cv_check(x, g, scratch, B, C, H, W, K, S);
   if (rc) return rc;
-  if (!scratch) return IAS_ERR_ARG;
   const int Ho = ias_conv_out_size(H, K, S), Wo = ias_conv_out_size(W, K, S);
   const int planes = B * C;
   const DwWave wg0 = dw_wave_geometry(B, H, W, Ho, Wo, K, S);
@@ -1133,17 +1133,34 @@ extern "C" int ias_dwconv_backward_weight(const float* x, const float* g, float*
     DW_WAVE_DISPATCH(1, wg, dim3(dw_wave_grid(wg, nwork)), dim3(64), wg.lds, (hipStream_t)stream_, x, (const float*)nullptr, g, scratch, B,
                      C, H, W, Ho, Wo, 0, wg, nwork);
     const int n = C * K * K;
-    hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((n + 3) / 4), dim3(CV_THREADS), 0, (hipStream_t)stream_, scratch, gw, n,
-                       nchunk);
+    if (nrows) *nrows = nchunk;
+    if (gw)
+      hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((n + 3) / 4), dim3(CV_THREADS), 0, (hipStream_t)stream_, scratch, gw, n,
+                         nchunk);
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   }
   const DwTile t = dw_tile_geometry(H, W, Ho, Wo, K, S, 1);
   DW_TILE_DISPATCH(1, dim3((planes + t.pp - 1) / t.pp, t.ntiles), dim3(CV_THREADS), t.lds, (hipStream_t)stream_, x,
                    (const float*)nullptr, g, scratch, C, H, W, Ho, Wo, planes, t.pp, t.rows_out, t.Wp, 0, t.mWp, t.mRows);
   const int n = C * K * K;   // scratch is [tile][b][c][K K]: the partials of a channel are n floats apart
-  hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((n + 3) / 4), dim3(CV_THREADS), 0, (hipStream_t)stream_, scratch, gw,
-                     n, B * t.ntiles);
+  if (nrows) *nrows = B * t.ntiles;
+  if (gw)
+    hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((n + 3) / 4), dim3(CV_THREADS), 0, (hipStream_t)stream_, scratch, gw,
+                       n, B * t.ntiles);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+extern "C" int ias_dwconv_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int C, int H,
+                                          int W, int K, int S, void* stream_) {
+  if (!gw) return IAS_ERR_ARG;
+  return dw_backward_weight(x, g, gw, scratch, B, C, H, W, K, S, nullptr, stream_);
+}
+// The same without the reduction launch: -> the number of partial rows (> 0; C K K floats each) for
+// ias_reduce_partials_multi, or a negative status
+extern "C" int ias_dwconv_backward_weight_partials(const float* x, const float* g, float* scratch, int B, int C, int H, int W,
+                                                   int K, int S, void* stream_) {
+  int nrows = 0;
+  const int rc = dw_backward_weight(x, g, nullptr, scratch, B, C, H, W, K, S, &nrows, stream_);
+  return rc != IAS_OK ? rc : nrows;
 }
 
 // Stem Conv2d(3, 16, 3, stride 2, padding 1, bias=False): x [B,3,H,W], w [16,3,3,3] -> out [B,16,Ho,Wo]
@@ -1178,9 +1195,10 @@ extern "C" int ias_stem_forward(const float* x, const float* w, float* out, int 
 extern "C" long long ias_stem_weight_scratch(int B) { return B <= 0 ? IAS_ERR_ARG : (long long)B * STEM_CHUNKS_X * 432; }
 
 // its weight gradient: x [B,3,H,W], g [B,16,Ho,Wo] -> gw [16,3,3,3]; scratch: ias_stem_weight_scratch(B) floats
-extern "C" int ias_stem_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int H, int W,
-                                        void* stream_) {
-  if (!x || !g || !gw || !scratch || B <= 0 || B > 65535 || H <= 0 || W <= 0) return IAS_ERR_ARG;
+// gw == nullptr: the partial sums only -> *nrows rows of 432 floats in `scratch` (ias_stem_backward_weight_partials)
+static int stem_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int H, int W, int* nrows,
+                                void* stream_) {
+  if (!x || !g || !scratch || B <= 0 || B > 65535 || H <= 0 || W <= 0) return IAS_ERR_ARG;
   const int Ho = ias_conv_out_size(H, 3, 2), Wo = ias_conv_out_size(W, 3, 2);
 #ifdef IAS_DIAG
   if (ias_diag_env("IAS_STEM_GW_LDS")) {   // the VALU / LDS form (diagnostics)
@@ -1203,17 +1221,33 @@ extern "C" int ias_stem_backward_weight(const float* x, const float* g, float* g
       hipLaunchKernelGGL((stem_bwd_weight_stage_kernel<3, 16, 5, 2>),
                          dim3((swaves + STEM_STAGE_THREADS / 64 - 1) / (STEM_STAGE_THREADS / 64)), dim3(STEM_STAGE_THREADS), lds,
                          (hipStream_t)stream_, x, g, scratch, B, H, W, Ho, Wo, sc, srows, XS, GS);
-      hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((432 + 3) / 4), dim3(CV_THREADS), 0, (hipStream_t)stream_, scratch, gw,
-                         432, swaves);
+      if (nrows) *nrows = swaves;
+      if (gw)
+        hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((432 + 3) / 4), dim3(CV_THREADS), 0, (hipStream_t)stream_, scratch,
+                           gw, 432, swaves);
       return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
     } else
     hipLaunchKernelGGL((stem_bwd_weight_mfma_kernel<3, 16>), dim3((waves + CV_THREADS / 64 - 1) / (CV_THREADS / 64)),
                        dim3(CV_THREADS), 0, (hipStream_t)stream_, x, g, scratch, B, H, W, Ho, Wo, STEM_CHUNKS_X,
                        rows_per_chunk);
   }
-  hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((432 + 3) / 4), dim3(CV_THREADS), 0, (hipStream_t)stream_, scratch, gw,
-                     432, B * STEM_CHUNKS_X);
+  if (nrows) *nrows = B * STEM_CHUNKS_X;
+  if (gw)
+    hipLaunchKernelGGL(conv_reduce_partials_kernel, dim3((432 + 3) / 4), dim3(CV_THREADS), 0, (hipStream_t)stream_, scratch, gw,
+                       432, B * STEM_CHUNKS_X);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+extern "C" int ias_stem_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int H, int W,
+                                        void* stream_) {
+  if (!gw) return IAS_ERR_ARG;
+  return stem_backward_weight(x, g, gw, scratch, B, H, W, nullptr, stream_);
+}
+// The same without the reduction launch: -> the number of partial rows (> 0; 432 floats each), or a negative status
+extern "C" int ias_stem_backward_weight_partials(const float* x, const float* g, float* scratch, int B, int H, int W,
+                                                 void* stream_) {
+  int nrows = 0;
+  const int rc = stem_backward_weight(x, g, nullptr, scratch, B, H, W, &nrows, stream_);
+  return rc != IAS_OK ? rc : nrows;
 }
 
 // ---- head: Conv2d(C, Cout, kernel 2) on channels-last maps as one GEMM (audioembed.py: conv7 .. conv1) -------------

@@ -37,6 +37,13 @@ static inline const char* ias_diag_env(const char* name) { return getenv(name); 
 #define IAS_LFO_EXPONENT_F 2.7182817459106445f
 #define IAS_NCTRL 5             // mod-matrix outputs: vco1 pitch, vco1 amp, vco2 pitch, vco2 amp, noise amp
 
+// One entry of ias_reduce_partials_multi's table (include/ias_hip.h): out[i] = sum_r partial[r n + i], i < n.
+struct IasReduceItem {
+  const float* partial;
+  float* out;
+  int n, rows;
+};
+
 // Per-voice scalars produced by the control-rate kernel, consumed at audio rate.
 struct IasVoiceConst {
   float f0_1, depth_1, phi_1;   // vco_1: fl(midi_f0 + tuning), mod_depth, initial_phase

@@ -389,10 +389,11 @@ extern "C" long long ias_pwconv_weight_scratch(int B, int Cin, int Cout, int HW)
   return (long long)B * pw_wgrad_splits(B, Cout, HW) * Cin * Cout;
 }
 
-// its weight gradient: g [B,Cout,HW], x [B,Cin,HW] -> gw [Cout,Cin]; scratch: ias_pwconv_weight_scratch floats
-extern "C" int ias_pwconv_backward_weight(const float* g, const float* x, float* gw, float* scratch, int B, int Cin, int Cout,
-                                          int HW, void* stream_) {
-  if (!g || !x || !gw || !scratch || B <= 0 || HW <= 0) return IAS_ERR_ARG;
+// its weight gradient: g [B,Cout,HW], x [B,Cin,HW] -> gw [Cout,Cin]; scratch: ias_pwconv_weight_scratch floats.
+// gw == nullptr: the partial sums only -> *nchunk rows of Cout Cin floats in `scratch` (ias_pwconv_backward_weight_partials)
+static int pw_backward_weight(const float* g, const float* x, float* gw, float* scratch, int B, int Cin, int Cout, int HW,
+                              int* nchunk, void* stream_) {
+  if (!g || !x || !scratch || B <= 0 || HW <= 0) return IAS_ERR_ARG;
   if (!ias_pwconv_supported(Cin, Cout)) return IAS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream_;
   const int T = (Cout + 15) / 16, NTI = (Cin + 15) / 16, chunks = (HW + 63) / 64, splits = pw_wgrad_splits(B, Cout, HW);
@@ -406,7 +407,84 @@ extern "C" int ias_pwconv_backward_weight(const float* g, const float* x, float*
     case 2: hipLaunchKernelGGL((pw_wgrad_kernel<2>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, g, x, scratch, B, Cout, Cin, HW, splits, cps); break;
     default: hipLaunchKernelGGL((pw_wgrad_kernel<1>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, g, x, scratch, B, Cout, Cin, HW, splits, cps); break;
   }
-  const int n = Cout * Cin;
-  hipLaunchKernelGGL(pw_reduce_partials_kernel, dim3((n + 15) / 16), dim3(PW_THREADS), 0, st, scratch, gw, n, (int)ugroups);
+  if (nchunk) *nchunk = (int)ugroups;
+  if (gw) {
+    const int n = Cout * Cin;
+    hipLaunchKernelGGL(pw_reduce_partials_kernel, dim3((n + 15) / 16), dim3(PW_THREADS), 0, st, scratch, gw, n, (int)ugroups);
+  }
+  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+extern "C" int ias_pwconv_backward_weight(const float* g, const float* x, float* gw, float* scratch, int B, int Cin, int Cout,
+                                          int HW, void* stream_) {
+  if (!gw) return IAS_ERR_ARG;
+  return pw_backward_weight(g, x, gw, scratch, B, Cin, Cout, HW, nullptr, stream_);
+}
+// The same without the reduction launch: -> the number of partial rows (> 0; row r is scratch[r Cout Cin ...]) for
+// ias_reduce_partials_multi, or a negative status
+extern "C" int ias_pwconv_backward_weight_partials(const float* g, const float* x, float* scratch, int B, int Cin, int Cout,
+                                                   int HW, void* stream_) {
+  int nchunk = 0;
+  const int rc = pw_backward_weight(g, x, nullptr, scratch, B, Cin, Cout, HW, &nchunk, stream_);
+  return rc != IAS_OK ? rc : nchunk;
+}
+
+// ---- the weight-gradient reductions of a whole backward pass in ONE launch ------------------------------------------
+// Every weight gradient of the trunk (thin 1x1, depthwise, stem) ends in out[i] = sum_r partial[r n + i], a launch of
+// 5-6 us that is all latency, 27 of them on the backward's dependency chain per pretraining step.  The *_partials entry
+// points leave the partial rows behind; this kernel folds all of them: a workgroup per 16 outputs of one item, the
+// arithmetic of pw_reduce_partials_kernel (fixed order: deterministic).  The table travels BY VALUE in the kernel
+// arguments (2.7 KB of the 4 KB a launch may carry): no device table, no staging copy, nothing to keep alive for a
+// captured graph, and nothing allocated while a capture is open.
+#define IAS_REDUCE_MAX_ITEMS 96
+struct IasReduceTable {
+  IasReduceItem it[IAS_REDUCE_MAX_ITEMS];
+  int first[IAS_REDUCE_MAX_ITEMS + 1];       // running sums of ceil(n / 16)
+};
+__global__ __launch_bounds__(PW_THREADS) void reduce_partials_multi_kernel(const IasReduceTable tab, int count) {
+  __shared__ float s_v[16][16];
+  int j = 0;
+  while (j + 1 < count && (int)blockIdx.x >= tab.first[j + 1]) ++j;     // uniform: scalar loads from the argument segment
+  const float* __restrict__ partial = tab.it[j].partial;
+  float* __restrict__ out = tab.it[j].out;
+  const int n = tab.it[j].n, nchunk = tab.it[j].rows;
+  const int il = threadIdx.x & 15, kg = threadIdx.x >> 4, i = ((int)blockIdx.x - tab.first[j]) * 16 + il;
+  float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+  if (i < n) {
+    int k = kg;
+    for (; k + 48 < nchunk; k += 64) {
+      v0 += partial[(size_t)k * n + i];
+      v1 += partial[(size_t)(k + 16) * n + i];
+      v2 += partial[(size_t)(k + 32) * n + i];
+      v3 += partial[(size_t)(k + 48) * n + i];
+    }
+    for (; k < nchunk; k += 16) v0 += partial[(size_t)k * n + i];
+  }
+  s_v[kg][il] = (v0 + v1) + (v2 + v3);
+  __syncthreads();
+  if (threadIdx.x < 16 && i < n) {
+    float v = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += s_v[q][il];
+    out[i] = v;
+  }
+}
+// items: HOST array of `count` entries (device pointers inside); more than IAS_REDUCE_MAX_ITEMS entries: several launches
+extern "C" int ias_reduce_partials_multi(const IasReduceItem* items, int count, void* stream_) {
+  if (!items || count <= 0) return IAS_ERR_ARG;
+  for (int i = 0; i < count; ++i)
+    if (!items[i].partial || !items[i].out || items[i].n <= 0 || items[i].rows <= 0) return IAS_ERR_ARG;
+  for (int c0 = 0; c0 < count; c0 += IAS_REDUCE_MAX_ITEMS) {
+    IasReduceTable tab;
+    const int c = count - c0 < IAS_REDUCE_MAX_ITEMS ? count - c0 : IAS_REDUCE_MAX_ITEMS;
+    long long blocks = 0;
+    for (int i = 0; i < c; ++i) {
+      tab.it[i] = items[c0 + i];
+      tab.first[i] = (int)blocks;
+      blocks += (items[c0 + i].n + 15) / 16;
+    }
+    if (blocks > 0x7fffffffLL) return IAS_ERR_ARG;
+    tab.first[c] = (int)blocks;
+    hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, (hipStream_t)stream_, tab, c);
+  }
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }

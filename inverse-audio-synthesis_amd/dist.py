@@ -75,6 +75,7 @@ class GradBucketer:
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.buckets = []      # (flat buffer, [params])
         self._pending = {}     # bucket index -> grads still to arrive this step
+        self._handles = []     # the post-accumulate-grad hooks (close() removes them)
         self._small = {}       # bucket index -> (views, gradients) of the small tensors waiting for their joint copy
         self._work = []
         # RCCL averages inside the collective (no division pass over the buckets afterwards); gloo has no AVG.  On a one-rank
@@ -105,8 +106,16 @@ class GradBucketer:
                 self._bucket_of[p] = bi
                 self._offset_of[p] = off          # (looked up by identity: list.index would compare tensors by value)
                 off += p.numel()
-                p.register_post_accumulate_grad_hook(self._on_grad)
+                self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.begin_step()
+
+    def close(self):
+        """Take this bucketer's hooks off the parameters (before another one is installed on the same module: its hooks
+        would go on copying gradients into its buckets and counting them)."""
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+        self.collective = False
 
     def _seal(self, plist):
         flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)

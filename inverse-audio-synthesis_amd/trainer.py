@@ -109,6 +109,21 @@ class Trainer:
         self.out_dir = t.out_dir
         self.history = []
 
+    def _deferred_reductions(self):
+        """The trunk's weight-gradient reductions as ONE launch at the end of the backward pass (vision.defer_weight_reductions)
+        -- on exactly when nothing reads a gradient DURING the pass: GradBucketer's hooks do, on several ranks."""
+        import contextlib
+        from . import vision
+
+        @contextlib.contextmanager
+        def scope():
+            old = vision.defer_weight_reductions(not self.bucketer.collective)
+            try:
+                yield
+            finally:
+                vision.defer_weight_reductions(old)
+        return scope()
+
     def _seed(self):
         """The loss' cotangent, a 1 that lives outside any graph pool (autograd otherwise creates it with a fill launch per
         step)."""
@@ -189,8 +204,9 @@ class Trainer:
         m.voice.randomize(int(batch))
 
         def one_step():
-            self.bucketer.begin_step()            # drop / zero the gradients (a captured step's own live in the graph's pool)
-            m.training_step(None, step).backward(self._seed())   # (a cached 1: `.backward()` alone launches a fill for it)
+            self.bucketer.begin_step()            # drop the gradients (a captured step's own live in the graph's pool)
+            with self._deferred_reductions():
+                m.training_step(None, step).backward(self._seed())   # (a cached 1: `.backward()` alone launches a fill for it)
             self.bucketer.finish()                # several ranks: the bucket all-reduces, issued during backward, joined here
             opt.step()
 
@@ -230,8 +246,9 @@ class Trainer:
         """One training step launched from Python: the bucket all-reduces go out during backward (GradBucketer's hooks),
         ``finish`` joins them and averages."""
         self.bucketer.begin_step()
-        loss = self.module.training_step(batch, step)
-        loss.backward(self._seed())
+        with self._deferred_reductions():
+            loss = self.module.training_step(batch, step)
+            loss.backward(self._seed())
         self.bucketer.finish()
         self.optimizer.step()
         return loss

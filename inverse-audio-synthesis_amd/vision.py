@@ -11,6 +11,7 @@ rocBLAS / hipBLASLt GEMMs; everything else (CPU tensors, other dtypes) takes the
 (the trunk is a caller of the hot path, not part of it).
 """
 import os
+import ctypes
 import warnings
 
 import torch
@@ -26,6 +27,53 @@ FORCE_PW_BMM = False
 
 def trunk_torch():
     return FORCE_TORCH_LAYERS
+
+
+# ---- the weight-gradient reductions of a backward pass, deferred to ONE launch at its end ---------------------------------
+# Every weight gradient of the trunk (thin 1x1, depthwise, stem) ends in a reduction of per-workgroup partial rows: a launch
+# of 5-6 us, all latency, 27 of them on the dependency chain of a pretraining step's backward.  With
+# ``defer_weight_reductions(True)`` the backward functions below leave their partial rows behind
+# (``ias_*_backward_weight_partials``), hand autograd the still unwritten gradient tensor, and ONE
+# ``ias_reduce_partials_multi`` launch fills all of them from a callback the autograd engine runs when the backward pass is
+# over (``queue_callback``: before ``backward()`` / ``autograd.grad()`` returns, also inside a hipGraph capture).  Nothing
+# may READ a weight gradient during the backward pass, then: a post-accumulate-grad hook would (dist.GradBucketer on
+# several ranks copies gradients into its buckets from one) -- so this is a switch the owner of the training loop sets
+# (Trainer: on exactly when no such hooks are installed), off by default.
+_DEFER = {"on": False, "items": []}
+
+
+def defer_weight_reductions(on):
+    """-> the previous setting."""
+    old, _DEFER["on"] = _DEFER["on"], bool(on)
+    return old
+
+
+def _defer_reduction(scratch, gw, n, rows):
+    # (the gradient's STORAGE is kept alive, not the tensor: with another reference to the tensor around, autograd's
+    # AccumulateGrad would not adopt it as the parameter's .grad but clone it on the spot -- the still unwritten bytes)
+    _DEFER["items"].append((scratch, gw.untyped_storage(), gw.data_ptr(), gw.device, int(n), int(rows)))
+    # (one callback per item: the first one of a pass reduces everything queued so far, the others find nothing -- no flag
+    # that a failed backward pass could leave set)
+    torch.autograd.Variable._execution_engine.queue_callback(_flush_reductions)
+
+
+class _ReduceItem(ctypes.Structure):      # IasReduceItem (include/ias_hip.h)
+    _fields_ = [("partial", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n", ctypes.c_int), ("rows", ctypes.c_int)]
+
+
+def _flush_reductions():
+    items, _DEFER["items"] = _DEFER["items"], []
+    if not items:
+        return
+    from . import _lib
+    lib = _lib.load()
+    # a HOST table: the library passes it to the kernel by value (no device table, no staging copy: nothing is allocated
+    # here, which matters inside a hipGraph capture -- pinned memory must not be allocated while one is open)
+    table = (_ReduceItem * len(items))()
+    for t, (s, _st, gp, _dev, n, r) in zip(table, items):
+        t.partial, t.out, t.n, t.rows = s.data_ptr(), gp, n, r
+    _lib.check(lib.ias_reduce_partials_multi(ctypes.cast(table, ctypes.c_void_p), len(items), _lib.stream()),
+               "ias_reduce_partials_multi")
 
 
 _PW_SUPPORTED = {}
@@ -76,8 +124,14 @@ class _PointwiseFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
             scratch = torch.empty(int(lib.ias_pwconv_weight_scratch(B, C, Cout, H * W)), dtype=torch.float32, device=x.device)
-            _lib.check(lib.ias_pwconv_backward_weight(_lib.ptr(g), _lib.ptr(x), _lib.ptr(gw), _lib.ptr(scratch), B, C, Cout,
-                                                      H * W, _lib.stream()), "ias_pwconv_backward_weight")
+            if _DEFER["on"]:
+                rows = lib.ias_pwconv_backward_weight_partials(_lib.ptr(g), _lib.ptr(x), _lib.ptr(scratch), B, C, Cout, H * W,
+                                                               _lib.stream())
+                _lib.check(min(int(rows), 0), "ias_pwconv_backward_weight_partials")
+                _defer_reduction(scratch, gw, gw.numel(), rows)
+            else:
+                _lib.check(lib.ias_pwconv_backward_weight(_lib.ptr(g), _lib.ptr(x), _lib.ptr(gw), _lib.ptr(scratch), B, C, Cout,
+                                                          H * W, _lib.stream()), "ias_pwconv_backward_weight")
         return gx, gw
 
 
@@ -138,8 +192,14 @@ class _DepthwiseFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
             scratch = torch.empty(int(lib.ias_dwconv_weight_scratch_hw(B, C, H, W, K, S)), dtype=torch.float32, device=x.device)
-            _lib.check(lib.ias_dwconv_backward_weight(_lib.ptr(x), _lib.ptr(g), _lib.ptr(gw), _lib.ptr(scratch), B, C, H, W, K,
-                                                      S, _lib.stream()), "ias_dwconv_backward_weight")
+            if _DEFER["on"]:
+                rows = lib.ias_dwconv_backward_weight_partials(_lib.ptr(x), _lib.ptr(g), _lib.ptr(scratch), B, C, H, W, K, S,
+                                                               _lib.stream())
+                _lib.check(min(int(rows), 0), "ias_dwconv_backward_weight_partials")
+                _defer_reduction(scratch, gw, gw.numel(), rows)
+            else:
+                _lib.check(lib.ias_dwconv_backward_weight(_lib.ptr(x), _lib.ptr(g), _lib.ptr(gw), _lib.ptr(scratch), B, C, H, W,
+                                                          K, S, _lib.stream()), "ias_dwconv_backward_weight")
         return gx, gw, None, None
 
 
@@ -185,8 +245,13 @@ class _StemFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
             scratch = torch.empty(int(lib.ias_stem_weight_scratch(B)), dtype=torch.float32, device=x.device)
-            _lib.check(lib.ias_stem_backward_weight(_lib.ptr(x), _lib.ptr(g), _lib.ptr(gw), _lib.ptr(scratch), B, H, W,
-                                                    _lib.stream()), "ias_stem_backward_weight")
+            if _DEFER["on"]:
+                rows = lib.ias_stem_backward_weight_partials(_lib.ptr(x), _lib.ptr(g), _lib.ptr(scratch), B, H, W, _lib.stream())
+                _lib.check(min(int(rows), 0), "ias_stem_backward_weight_partials")
+                _defer_reduction(scratch, gw, gw.numel(), rows)
+            else:
+                _lib.check(lib.ias_stem_backward_weight(_lib.ptr(x), _lib.ptr(g), _lib.ptr(gw), _lib.ptr(scratch), B, H, W,
+                                                        _lib.stream()), "ias_stem_backward_weight")
         return gx, gw
 
 

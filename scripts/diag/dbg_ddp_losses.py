@@ -30,6 +30,7 @@ for form in ("kern",):
             model = VicregAudioParams(cfg)
         tr = Trainer(cfg, model, stage="vicreg", device=dev)
         mb = int(cfg.trainer.bucket_mb) << 20
+        tr.bucketer.close()
         tr.bucketer = ias_dist.GradBucketer(model, bucket_bytes=mb, local_only=(mode == "none"), always_reduce=(mode != "none"))
         if mode == "new_sum":             # RCCL's in-place one-rank SUM: nothing is enqueued between the fork and the join
             tr.bucketer._op = dist.ReduceOp.SUM

@@ -63,6 +63,7 @@ def main():
             model = VicregAudioParams(cfg)
         tr = Trainer(cfg, model, stage="vicreg", device=dev)
         mb = int(cfg.trainer.bucket_mb) << 20
+        tr.bucketer.close()
         if mode == "none":
             tr.bucketer = ias_dist.GradBucketer(model, bucket_bytes=mb, local_only=True)
         elif mode in ("new", "newsum", "newnodefer"):

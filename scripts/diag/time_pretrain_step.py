@@ -1,5 +1,5 @@
 """One VICReg pretraining step (BASELINE config #3: B=128, 4 s @ 44.1 kHz, dim 1024, embeddim 8192) -- wall time per step,
-eager (default) or as the Trainer's captured hipGraph (GRAPH=1)."""
+eager (default) or as the Trainer's captured hipGraph (GRAPH=1); DEFER=0: without the joint weight-gradient reduction."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -15,6 +15,9 @@ torch.manual_seed(42)
 cfg = load_config(os.path.join(ROOT, "conf"), "config", [f"vicreg.batch_size={B}", f"trainer.cuda_graph={'true' if graph else 'false'}"])
 model = VicregAudioParams(cfg)
 tr = Trainer(cfg, model, stage="vicreg", device=dev)
+if os.environ.get("DEFER") == "0":      # the trunk's weight-gradient reductions as a launch per layer (vision.defer_weight_reductions off)
+    import contextlib
+    tr._deferred_reductions = contextlib.nullcontext
 model.train()
 opt = tr.optimizer
 def step(i):

@@ -177,6 +177,7 @@ def test_captured_ddp_step_equals_the_eager_loop_on_a_one_rank_rccl_group(lib, d
         torch.manual_seed(42)
         m = VicregAudioParams(cfg)
         tr = Trainer(cfg, m, stage="vicreg", device=dev)
+        tr.bucketer.close()
         tr.bucketer = ias_dist.GradBucketer(m, bucket_bytes=1 << 20, always_reduce=True)
         assert tr.bucketer.collective and len(tr.bucketer.buckets) > 1
         assert tr._use_graph() == (mode == "true")

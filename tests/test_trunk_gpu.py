@@ -295,3 +295,47 @@ def test_batchnorm_with_the_residual_in_the_same_pass(lib, dev, shape):
     for u, v in zip(got, want):
         assert torch.equal(u, v)
     assert torch.equal(a.running_mean, b.running_mean) and torch.equal(a.running_var, b.running_var)
+
+
+def test_deferred_weight_gradient_reductions_equal_the_immediate_ones(lib, dev):
+    """vision.defer_weight_reductions(True): the thin 1x1 / depthwise / stem weight gradients leave their partial rows
+    behind and ONE ias_reduce_partials_multi launch at the end of the backward pass fills all of them (Trainer's setting on
+    one rank) -- against the same backward with a reduction launch per layer.  Train mode, B = 6, through autograd.grad
+    and through .backward(); the 1x1 layers add in the same order in both forms (bit-equal), the depthwise / stem layers
+    in another fixed order (1e-6 of the largest element)."""
+    from inverse_audio_synthesis_amd import vision
+    from inverse_audio_synthesis_amd.audioembed import AudioEmbedding, ChannelNormalize
+    from inverse_audio_synthesis_amd.pqmf import PQMF
+    torch.manual_seed(0)
+    net = AudioEmbedding(PQMF(N=3), vision.mobilenet_v3_small(), ChannelNormalize(), dim=32).to(dev).train()
+    audio = (randn((6, 1, 176400), 5) * 0.3).to(dev)
+    params = [p for p in net.parameters() if p.requires_grad]
+    names = [n for n, p in net.named_parameters() if p.requires_grad]
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    res = {}
+    for on in (False, True, True):
+        net.load_state_dict(state)                  # (the same BatchNorm running statistics going in)
+        old = vision.defer_weight_reductions(on)
+        try:
+            out = net(audio)
+            w = randn(tuple(out.shape), 6).to(dev)
+            if len(res) < 2:
+                g = torch.autograd.grad((out * w).sum(), params)
+            else:
+                for p in params:
+                    p.grad = None
+                (out * w).sum().backward()
+                g = [p.grad for p in params]
+        finally:
+            assert vision.defer_weight_reductions(old) == on
+        assert not vision._DEFER["items"]           # everything queued was reduced before the pass returned
+        res[len(res)] = [t.detach().clone() for t in g]
+    assert vision._DEFER["on"] is False
+    nthin = 0
+    for n, a, b, c in zip(names, res[0], res[1], res[2]):
+        assert torch.equal(b, c), n
+        scale = max(1e-6, a.abs().max().item())
+        assert (a - b).abs().max().item() <= 1e-6 * scale, (n, (a - b).abs().max().item(), scale)
+        if a.dim() == 4 and a.shape[2:] == (1, 1) and torch.equal(a, b):
+            nthin += 1
+    assert nthin >= 10
