@@ -339,3 +339,33 @@ def test_deferred_weight_gradient_reductions_equal_the_immediate_ones(lib, dev):
         if a.dim() == 4 and a.shape[2:] == (1, 1) and torch.equal(a, b):
             nthin += 1
     assert nthin >= 10
+
+
+def test_reduce_partials_multi_through_the_c_abi(lib, dev):
+    """ias_reduce_partials_multi: out_j[i] = sum_r partial_j[r n_j + i] for a host table of items -- ragged n (1, 15, 16, 17,
+    432, 9600), 1 .. 600 rows, and more items than one launch carries in its arguments (the library then launches twice);
+    bad entries are refused."""
+    import ctypes
+    from inverse_audio_synthesis_amd import _lib
+    from inverse_audio_synthesis_amd.vision import _ReduceItem
+    g = torch.Generator().manual_seed(7)
+    shapes = [(1, 1), (15, 3), (16, 64), (17, 65), (432, 128), (9600, 130), (33, 600)] + [(5 + k, 1 + (k % 7)) for k in range(120)]
+    parts = [torch.randn(r, n, generator=g).to(dev) for n, r in shapes]
+    outs = [torch.full((n,), float("nan"), device=dev) for n, r in shapes]
+    table = (_ReduceItem * len(shapes))()
+    for t, p, o, (n, r) in zip(table, parts, outs, shapes):
+        t.partial, t.out, t.n, t.rows = p.data_ptr(), o.data_ptr(), n, r
+    assert lib.ias_reduce_partials_multi(ctypes.cast(table, ctypes.c_void_p), len(shapes), _lib.stream()) == 0
+    torch.cuda.synchronize()
+    for p, o in zip(parts, outs):
+        ref = p.double().sum(0)
+        assert (o.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    again = [torch.empty_like(o) for o in outs]
+    for t, o in zip(table, again):
+        t.out = o.data_ptr()
+    assert lib.ias_reduce_partials_multi(ctypes.cast(table, ctypes.c_void_p), len(shapes), _lib.stream()) == 0
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(outs, again))          # fixed order: the same bits
+    table[3].rows = 0
+    assert lib.ias_reduce_partials_multi(ctypes.cast(table, ctypes.c_void_p), len(shapes), _lib.stream()) == -1
+    assert lib.ias_reduce_partials_multi(None, 3, _lib.stream()) == -1
