@@ -4,8 +4,8 @@
 // (/root/reference/audioembed.py:61 -> vision_model.features, /root/reference/vicreg_audio_params.py:52-54) and their
 // autograd.  On MIOpen the two large-map layers alone took 0.8 ms forward and 0.77 ms backward each at batch 128
 // ([128,16,120,123]); the activation and its backward were separate elementwise passes.  Here:
-//   forward : per-channel shifted sums (partials + fixed-order finalize, running statistics updated as torch does),
-//             then ONE pass y = act(w (x - mean) invstd + b);
+//   forward : per-channel shifted sums (partials), then ONE pass that finalizes them per workgroup (fixed order; running
+//             statistics updated as torch does) and writes y = act(w (x - mean) invstd + b);
 //   backward: ONE reduction pass over (x, dy) that recomputes the pre-activation value z, applies act'(z) and sums
 //             dz and dz * xhat per channel, a finalize (dw, db), and ONE pass dx = w invstd (dz - mean(dz) - xhat mean(dz xhat)).
 // Nothing but mean / invstd is saved between forward and backward.  All sums in a fixed order (deterministic).
@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #define BN_THREADS 256
+#define BN_UNROLL 4      // bn_partials_kernel: loads requested before the first is consumed
 #define BN_ACT_NONE 0
 #define BN_ACT_RELU 1
 #define BN_ACT_HARDSWISH 2
@@ -32,21 +33,29 @@ __device__ __forceinline__ float bn_act_grad(float z, int act) {
   return 1.0f;
 }
 
+// sum of a, b over the workgroup, fixed order: DPP scan inside each wave (wave_ops.h), the four wave totals through LDS --
+// one barrier instead of the eight of a shared-memory tree on doubles
 __device__ __forceinline__ void bn_block_reduce2(double& a, double& b) {
-  __shared__ double s_a[BN_THREADS], s_b[BN_THREADS];
-  const int tid = threadIdx.x;
-  s_a[tid] = a; s_b[tid] = b;
+  __shared__ double s_a[BN_THREADS / 64], s_b[BN_THREADS / 64];
+  a = wave_sum(a); b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
   __syncthreads();
+  a = 0.0; b = 0.0;
 #pragma unroll
-  for (int d = BN_THREADS / 2; d > 0; d >>= 1) {
-    if (tid < d) { s_a[tid] += s_a[tid + d]; s_b[tid] += s_b[tid + d]; }
-    __syncthreads();
-  }
-  a = s_a[0]; b = s_b[0];
+  for (int w = 0; w < BN_THREADS / 64; ++w) { a += s_a[w]; b += s_b[w]; }
 }
 
 // Workgroup (c, s) sums over the batches b = s, s + S, ... of channel c.  MODE 0: sum (x - K), sum (x - K)^2 with the
 // shift K = x[0, c, 0] (no cancellation for channels with a large mean).  MODE 1: sum dz, sum dz xhat.
+//
+// A plane is HW contiguous floats at an arbitrary 4-byte phase ([*, C, 30, 31] maps: 930 floats, every other plane starts
+// 8 bytes into a 16-byte group).  Rounds 2-5 read such planes with 4-byte loads, one dependent load per lane and plane:
+// 2.3-3.0 TB/s on the six 30 x 31 layers of the trunk (profiles/r05f_trace_pretrain_list.txt: 75 us forward, 128 us
+// backward per pretraining step).  Now every plane is `head` (< 4) scalars up to the next 16-byte boundary, `body4`
+// 16-byte vectors and a tail of < 4 scalars; a lane's work item is one vector or one scalar, the items of the workgroup's
+// planes form ONE sequence, and BN_UNROLL of them are requested before the first is consumed (the loads of several
+// planes -- or of several vectors of a large plane -- in flight per lane instead of one).  Sums in a fixed order.
+struct BnItem { float4 a, g; int n; };     // n: valid elements (4: a vector, 1: a scalar in .x, 0: nothing)
 template <int MODE>
 __global__ __launch_bounds__(BN_THREADS) void bn_partials_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                   const float* __restrict__ mean,
@@ -59,13 +68,6 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partials_kernel(const float* __
   float k = 0.0f, m = 0.0f, is = 1.0f, w = 1.0f, bb = 0.0f;
   if (MODE == 0) k = x[(size_t)c * HW];
   else { m = mean[c]; is = invstd[c]; w = weight ? weight[c] : 1.0f; bb = bias ? bias[c] : 0.0f; }
-  const bool vec = (HW & 3) == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0;
-  // small planes share the workgroup: lpp lanes per plane (a power of two >= the plane's vector count, at most the
-  // workgroup), BN_THREADS / lpp planes per pass -- a [*,576,8,8] layer has 16 vectors per plane
-  const int nv = vec ? (HW >> 2) : HW;
-  int lpp = BN_THREADS;
-  while (lpp > 16 && (lpp >> 1) >= nv) lpp >>= 1;
-  const int ppi = BN_THREADS / lpp, pl = tid / lpp, li = tid - pl * lpp;
   auto one = [&](float xv, float gv) {
     if (MODE == 0) { const float d = xv - k; p0 += d; p1 = fmaf(d, d, p1); }
     else {
@@ -74,19 +76,92 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partials_kernel(const float* __
       p0 += dz; p1 = fmaf(dz, xh, p1);
     }
   };
-  for (int b = s + pl * S; b < B; b += S * ppi) {
-    const size_t base = ((size_t)b * C + c) * HW;
-    if (vec) {
+  // x and dy share the phase of every plane when both arrays start on a 16-byte boundary (torch allocations do)
+  const bool a16 = (((uintptr_t)x | (uintptr_t)dy) & 15) == 0;
+  if (a16 && (HW & 3) == 0) {
+    // planes of whole, aligned vectors: a plain strided loop per plane (the compiler keeps several of its loads in flight;
+    // on the [*, 16, 120, 123] and [*, 72, 60, 62] maps the item sequence below measured 30 % SLOWER than this loop,
+    // gpurun_out/trace_ptl of the round's third session).  Small planes share the workgroup: lpp lanes per plane (a
+    // power of two >= the plane's vector count), BN_THREADS / lpp planes per pass
+    const int nv = HW >> 2;
+    int lpp = BN_THREADS;
+    while (lpp > 16 && (lpp >> 1) >= nv) lpp >>= 1;
+    const int ppi = BN_THREADS / lpp, pl = tid / lpp, li = tid - pl * lpp;
+    for (int b = s + pl * S; b < B; b += S * ppi) {
+      const size_t base = ((size_t)b * C + c) * HW;
       const float4* x4 = reinterpret_cast<const float4*>(x + base);
       const float4* g4 = MODE == 1 ? reinterpret_cast<const float4*>(dy + base) : nullptr;
-      for (int i = li; i < nv; i += lpp) {
+      int i = li;
+      // large planes, forward: BN_UNROLL vectors requested at once ([*, 16, 120, 123]: 26.8 -> 21.6 us; on planes of 930
+      // vectors most lanes fall through to the remainder loop -- 64.7 -> 69.9 us backward -- and (x, dy) pairs gain nothing)
+      if (MODE == 0 && nv >= 8 * lpp)
+      for (; i + (BN_UNROLL - 1) * lpp < nv; i += BN_UNROLL * lpp) {
+        float4 a[BN_UNROLL], g[BN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u) {
+          a[u] = x4[i + u * lpp];
+          g[u] = float4{0.f, 0.f, 0.f, 0.f};
+          if (MODE == 1) g[u] = g4[i + u * lpp];
+        }
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u) { one(a[u].x, g[u].x); one(a[u].y, g[u].y); one(a[u].z, g[u].z); one(a[u].w, g[u].w); }
+      }
+      for (; i < nv; i += lpp) {
         const float4 a = x4[i];
         float4 g = {0.f, 0.f, 0.f, 0.f};
         if (MODE == 1) g = g4[i];
         one(a.x, g.x); one(a.y, g.y); one(a.z, g.z); one(a.w, g.w);
       }
-    } else {
-      for (int i = li; i < HW; i += lpp) one(x[base + i], MODE == 1 ? dy[base + i] : 0.0f);
+    }
+  } else if (a16) {
+    // items per plane: its vectors and, behind them, up to 6 scalar slots; small planes share the workgroup: lpp lanes per
+    // plane (a power of two >= the item count, at most the workgroup), BN_THREADS / lpp planes side by side
+    const int nitems = (HW >> 2) + 6;
+    int lpp = BN_THREADS;
+    while (lpp > 16 && (lpp >> 1) >= nitems) lpp >>= 1;
+    const int ppi = BN_THREADS / lpp, pl = tid / lpp, li = tid - pl * lpp;
+    const int ipl = (nitems + lpp - 1) / lpp;                       // items per lane and plane
+    const int nplanes = (B - s + S - 1) / S;                        // planes of this workgroup: b = s + j S
+    const int jn = pl < nplanes ? (nplanes - pl + ppi - 1) / ppi : 0;   // ... of this lane group: j = pl + jj ppi
+    const int total = jn * ipl;
+    auto fetch = [&](int mi, BnItem& it) {
+      it.n = 0;
+      it.a = float4{0.f, 0.f, 0.f, 0.f}; it.g = float4{0.f, 0.f, 0.f, 0.f};
+      if (mi >= total) return;
+      const int jj = mi / ipl, i = li + (mi - jj * ipl) * lpp;
+      const int b = s + (pl + jj * ppi) * S;
+      const size_t base = ((size_t)b * C + c) * HW;
+      int head = (4 - (int)(base & 3)) & 3;
+      if (head > HW) head = HW;
+      const int body4 = (HW - head) >> 2;
+      if (i < body4) {
+        it.a = *reinterpret_cast<const float4*>(x + base + head + 4 * (size_t)i);
+        if (MODE == 1) it.g = *reinterpret_cast<const float4*>(dy + base + head + 4 * (size_t)i);
+        it.n = 4;
+      } else {
+        const int e = i - body4, nscal = HW - 4 * body4;             // head + tail scalars
+        if (e < nscal) {
+          const size_t idx = base + (e < head ? e : 4 * body4 + e);
+          it.a.x = x[idx];
+          if (MODE == 1) it.g.x = dy[idx];
+          it.n = 1;
+        }
+      }
+    };
+    for (int m0 = 0; m0 < total; m0 += BN_UNROLL) {
+      BnItem it[BN_UNROLL];
+#pragma unroll
+      for (int u = 0; u < BN_UNROLL; ++u) fetch(m0 + u, it[u]);
+#pragma unroll
+      for (int u = 0; u < BN_UNROLL; ++u) {
+        if (it[u].n > 0) one(it[u].a.x, it[u].g.x);
+        if (it[u].n == 4) { one(it[u].a.y, it[u].g.y); one(it[u].a.z, it[u].g.z); one(it[u].a.w, it[u].g.w); }
+      }
+    }
+  } else {
+    for (int b = s; b < B; b += S) {
+      const size_t base = ((size_t)b * C + c) * HW;
+      for (int i = tid; i < HW; i += BN_THREADS) one(x[base + i], MODE == 1 ? dy[base + i] : 0.0f);
     }
   }
   double d0 = (double)p0, d1 = (double)p1;
@@ -193,6 +268,102 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_scalar_kernel(const float
     else {
       const float dz = dy[i] * bn_act_grad(fmaf(w, xh, bb), act);
       out[i] = w * is * (dz - sums[2 * c] * inv_n - xh * sums[2 * c + 1] * inv_n);
+    }
+  }
+}
+
+// The pass behind the partial sums of a layer below BN_FINAPPLY_MAX_BYTES: finalize + apply in ONE launch.
+// The finalize launch above sits between the partial-sum pass and the elementwise pass (mean / invstd / running statistics
+// forward, dw / db / the two means backward): ~5 us of pure latency on the step's dependency chain, 20 of them per
+// pretraining step.  Here every workgroup of the elementwise pass belongs to ONE
+// channel (grid: channel x group of samples x segment of the plane) and its first wave finalizes that channel itself:
+// lane s loads partial pair s (S <= 64: one request per lane, L2 hits), the pairs meet in the DPP scan of wave_ops.h, lane 0
+// does the fp64 arithmetic the finalize kernels did -- the same operations in the same order, so every value is
+// bit-identical to the three-launch form -- and the workgroup of (sample group 0, segment 0) writes save_mean / save_invstd
+// / the running statistics (forward: momentum m: r = (1 - m) r + m stat, unbiased variance in the running one, as
+// torch.nn.BatchNorm2d) or dw / db (backward).  Nothing is atomic and nothing polls: the partial sums are complete when
+// this kernel starts.  Measured per layer against finalize + flat apply (profiles/r05g_trace_pretrain_list.txt and the
+// round's earlier lists): 4-6 us less on the 30 x 31 and [*, 16, 60, 62] maps in either direction; on the two 120+ MB maps
+// ([*, 16, 120, 123], [*, 72, 60, 62]) a workgroup's share is long, the launch is 1.1-2.3 rounds of resident workgroups
+// and its last round runs latency-bound (53 against 44 us forward, 76 against 68 backward): those keep the three launches.
+//   MODE 0: y = act(w xhat + b) (+ res: `dy` carries the residual or null);
+//   MODE 1: dx = w invstd (dz - mean(dz) - xhat mean(dz xhat)).
+template <int MODE, int VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_finapply_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const double* __restrict__ partials,
+    float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ running_mean,
+    float* __restrict__ running_var, const float* __restrict__ weight, const float* __restrict__ bias, float* __restrict__ gw,
+    float* __restrict__ gb, float* __restrict__ out, int B, int C, int HW, int S, int PB, int segv, double n, float eps,
+    float momentum, float inv_n, int act) {
+  typedef float vt __attribute__((ext_vector_type(VEC)));
+  __shared__ float s_stat[4];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const bool writer = blockIdx.y == 0 && blockIdx.z == 0;
+  if (tid < 64) {
+    double s1 = 0.0, s2 = 0.0;
+    if (tid < S) {
+      const double2 v = reinterpret_cast<const double2*>(partials)[(size_t)c * S + tid];
+      s1 = v.x; s2 = v.y;
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (tid == 0) {
+      if (MODE == 0) {
+        const double k = (double)x[(size_t)c * HW];
+        const double dm = s1 / n;
+        double var = s2 / n - dm * dm;
+        if (var < 0.0) var = 0.0;
+        const double mean = k + dm;
+        const float mf = (float)mean, isf = (float)(1.0 / sqrt(var + (double)eps));
+        s_stat[0] = mf; s_stat[1] = isf;
+        if (writer) {
+          save_mean[c] = mf;
+          save_invstd[c] = isf;
+          if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+          if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * (n > 1.0 ? n / (n - 1.0) : 1.0));
+        }
+      } else {
+        s_stat[0] = save_mean[c]; s_stat[1] = save_invstd[c];
+        s_stat[2] = (float)s1; s_stat[3] = (float)s2;
+        if (writer) {
+          if (gb) gb[c] = (float)s1;
+          if (gw) gw[c] = (float)s2;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const float m = s_stat[0], is = s_stat[1], w = weight ? weight[c] : 1.0f, bb = bias ? bias[c] : 0.0f;
+  const float a = MODE == 1 ? s_stat[2] * inv_n : 0.0f, b2 = MODE == 1 ? s_stat[3] * inv_n : 0.0f, ws = w * is;
+  const int hwv = HW / VEC;
+  const int v0 = blockIdx.z * segv, v1 = min(hwv, v0 + segv);
+  const int b_begin = blockIdx.y * PB, b_end = min(B, b_begin + PB);
+  for (int b = b_begin; b < b_end; ++b) {
+    const size_t base = ((size_t)b * C + c) * HW;
+    const vt* xp = reinterpret_cast<const vt*>(x + base);
+    const vt* gp = dy != nullptr ? reinterpret_cast<const vt*>(dy + base) : nullptr;
+    vt* op = reinterpret_cast<vt*>(out + base);
+#pragma unroll 4
+    for (int i = v0 + tid; i < v1; i += BN_THREADS) {
+      const vt xv = xp[i];
+      vt o;
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = bn_act(fmaf(w, (xv[e] - m) * is, bb), act);
+        if (gp != nullptr) {
+          const vt rv = gp[i];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] += rv[e];
+        }
+      } else {
+        const vt gv = gp[i];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float xh = (xv[e] - m) * is;
+          const float dz = gv[e] * bn_act_grad(fmaf(w, xh, bb), act);
+          o[e] = ws * (dz - a - xh * b2);
+        }
+      }
+      op[i] = o;
     }
   }
 }
@@ -325,7 +496,7 @@ static int bn_split(int B, int C) {
   int s = (target + C - 1) / C;
   if (s < 1) s = 1;
   if (s > B) s = B;
-  if (s > 64) s = 64;     // (bn_finalize_*: one partial pair per lane of a wave)
+  if (s > 64) s = 64;     // (bn_finalize_*, bn_finapply_kernel: one partial pair per lane of a wave)
   return s;
 }
 // doubles of scratch the forward / backward need (partials [C][split][2])
@@ -354,6 +525,41 @@ static void bn_launch_apply(hipStream_t stream, const float* x, const float* dy,
   else
     hipLaunchKernelGGL((bn_apply_scalar_kernel<MODE>), dim3((unsigned)blocks), dim3(BN_THREADS), 0, stream, x, dy, mean,
                        invstd, weight, bias, sums, out, C, HW, tv, inv_n, act);
+}
+
+// layers whose map is below 64 MB take the two-launch form (see bn_finapply_kernel)
+#define BN_FINAPPLY_MAX_BYTES (64ll << 20)
+static bool bn_finapply_takes(int B, int C, int HW) { return (long long)B * C * HW * 4 < BN_FINAPPLY_MAX_BYTES; }
+
+// finalize + apply (bn_finapply_kernel): grid (C, groups of PB samples, segments of segv vectors).  A workgroup should
+// see >= ~4 vectors per thread behind its finalize prologue, and the launch ~4096 workgroups.
+template <int MODE>
+static void bn_launch_finapply(hipStream_t stream, const float* x, const float* dy, const double* partials, float* save_mean,
+                               float* save_invstd, float* running_mean, float* running_var, const float* weight,
+                               const float* bias, float* gw, float* gb, float* out, int B, int C, int HW, int S, float eps,
+                               float momentum, int act) {
+  const float inv_n = 1.0f / (float)((long long)B * HW);
+  const double n = (double)B * HW;
+  const bool a16 = ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy) & 15) == 0);
+  const int vec = (a16 && (HW & 3) == 0) ? 4 : ((a16 && (HW & 1) == 0) ? 2 : 1);
+  const int hwv = HW / vec;
+  const int segv = hwv <= 8 * BN_THREADS ? hwv : 4 * BN_THREADS;
+  const int nseg = (hwv + segv - 1) / segv;
+  // samples per workgroup: doubled while the launch keeps >= 2048 workgroups (1024 while a workgroup has fewer than four
+  // vectors per thread) and a workgroup stays at <= 16 vectors per thread
+  const long long per_plane = segv < hwv ? segv : hwv;
+  int PB = 1;
+  while (PB < B && 2 * PB * per_plane <= 16 * BN_THREADS &&
+         (long long)C * ((B + 2 * PB - 1) / (2 * PB)) * nseg >= (PB * per_plane < 4 * BN_THREADS ? 1024 : 2048))
+    PB *= 2;
+  const dim3 grid(C, (B + PB - 1) / PB, nseg);
+#define BN_FINAPPLY(V)                                                                                                      \
+  hipLaunchKernelGGL((bn_finapply_kernel<MODE, V>), grid, dim3(BN_THREADS), 0, stream, x, dy, partials, save_mean, save_invstd, \
+                     running_mean, running_var, weight, bias, gw, gb, out, B, C, HW, S, PB, segv, n, eps, momentum, inv_n, act)
+  if (vec == 4) BN_FINAPPLY(4);
+  else if (vec == 2) BN_FINAPPLY(2);
+  else BN_FINAPPLY(1);
+#undef BN_FINAPPLY
 }
 
 // y = act(BatchNorm_train(x)); x, y [B,C,HW] fp32 contiguous; weight / bias [C] or NULL; running_mean / running_var [C]
@@ -399,6 +605,11 @@ static int bn_act_forward_impl(const float* x, const float* res, const float* we
   hipLaunchKernelGGL((bn_partials_kernel<0>), dim3(C, S), dim3(BN_THREADS), 0, stream, x, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, scratch, B, C,
                      HW, act);
+  if (bn_finapply_takes(B, C, HW)) {
+    bn_launch_finapply<0>(stream, x, res, scratch, save_mean, save_invstd, running_mean, running_var, weight, bias, nullptr,
+                          nullptr, y, B, C, HW, S, eps, momentum, act);
+    return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + BN_FIN_WAVES - 1) / BN_FIN_WAVES), dim3(64 * BN_FIN_WAVES), 0, stream, x, scratch, save_mean, save_invstd,
                      running_mean, running_var, C, S, HW, (double)B * HW, eps, momentum);
   bn_launch_apply<0>(stream, x, res, save_mean, save_invstd, weight, bias, nullptr, y, B, C, HW, act);
@@ -425,6 +636,11 @@ extern "C" int ias_bn_act_backward(const float* x, const float* dy, const float*
   const int S = bn_split(B, C);
   hipLaunchKernelGGL((bn_partials_kernel<1>), dim3(C, S), dim3(BN_THREADS), 0, stream, x, dy, save_mean, save_invstd, weight,
                      bias, scratch, B, C, HW, act);
+  if (bn_finapply_takes(B, C, HW)) {
+    bn_launch_finapply<1>(stream, x, dy, scratch, const_cast<float*>(save_mean), const_cast<float*>(save_invstd), nullptr, nullptr,
+                          weight, bias, gw, gb, dx, B, C, HW, S, 0.0f, 0.0f, act);
+    return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(bn_finalize_grads_kernel, dim3((C + BN_FIN_WAVES - 1) / BN_FIN_WAVES), dim3(64 * BN_FIN_WAVES), 0, stream, scratch, gw, gb, sums, C, S);
   bn_launch_apply<1>(stream, x, dy, save_mean, save_invstd, weight, bias, sums, dx, B, C, HW, act);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
