@@ -397,6 +397,18 @@ int ias_pwconv_backward_weight(const float* g, const float* x, float* gw, float*
 /* ... without its reduction launch -> the number of partial rows (> 0; Cout Cin floats each), or a negative IAS_ERR_* */
 int ias_pwconv_backward_weight_partials(const float* g, const float* x, float* scratch, int B, int Cin, int Cout, int HW,
                                         void* stream);
+/* The projection behind a squeeze-excitation block with the block's gate taken on load: y[b] = W (x[b] * scale[b]),
+ * scale [B,Cin] -- torchvision InvertedResidual's `SqueezeExcitation -> Conv2dNormActivation(cexp, cout, 1)` inside
+ * mobilenet_v3_small.features (run at /root/reference/audioembed.py:61) without the gate's own pass over the expanded map
+ * (`scale * input` of torchvision's SqueezeExcitation.forward); same bits as ias_se_scale followed by ias_pwconv_forward.
+ * The input gradient of the product x * scale is ias_pwconv_backward_data; the weight gradient is
+ * gw = sum_b g[b] (x[b] * scale[b])^T (scale applied once per sample and column where the sums leave the accumulators). */
+int ias_pwconv_forward_scaled(const float* x, const float* scale, const float* w, float* y, int B, int Cin, int Cout, int HW,
+                              void* stream);
+int ias_pwconv_backward_weight_scaled(const float* g, const float* x, const float* scale, float* gw, float* scratch, int B,
+                                      int Cin, int Cout, int HW, void* stream);
+int ias_pwconv_backward_weight_partials_scaled(const float* g, const float* x, const float* scale, float* scratch, int B,
+                                               int Cin, int Cout, int HW, void* stream);
 
 /* The weight-gradient reductions of a whole backward pass of the trunk (torchvision mobilenet_v3_small.features, run at
  * /root/reference/audioembed.py:61; autograd of /root/reference/vicreg_audio_params.py:96-122) in ONE launch:

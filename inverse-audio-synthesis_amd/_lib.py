@@ -108,6 +108,9 @@ SYMBOLS = {
     "ias_pwconv_weight_scratch": (_LL, [_I, _I, _I, _I]),
     "ias_pwconv_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_pwconv_backward_weight_partials": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_pwconv_forward_scaled": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_pwconv_backward_weight_scaled": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ias_pwconv_backward_weight_partials_scaled": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ias_reduce_partials_multi": (_I, [_P, _I, _P]),
     "ias_se_plane_reduce": (_I, [_P, _P, _P, _LL, _I, _F, _P]),
     "ias_se_scale": (_I, [_P, _P, _P, _P, _LL, _I, _F, _P]),

@@ -95,9 +95,13 @@ __device__ __forceinline__ void pw_store_row64(float* __restrict__ row, int p0, 
 // A wave takes items (sample, 64-position block, group of <= PW_CG row tiles) in a grid-stride loop; the workgroup's
 // four waves share the weight, staged once.  The input rows of PW_PF k-steps are requested ahead of the MFMAs that
 // use them (a k-step is only 4 x tiles MFMAs, ~0.2 us: a distance of one step left the wave waiting on every load).
+// SCALED: y[b] = A (x[b] * xs[b]) with a scale per (sample, input row) -- the squeeze-excitation gate of an
+// inverted-residual block taken on load by the projection behind it (one multiply per loaded value beside 4 x tiles
+// MFMAs per k-step) instead of a pass of its own over the expanded map; the scales travel with the rows' prefetch.
 #define PW_PF 8
-template <int VEC>
-__global__ __launch_bounds__(PW_THREADS) void pw_apply_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int VEC, bool SCALED>
+__global__ __launch_bounds__(PW_THREADS) void pw_apply_kernel(const float* __restrict__ x, const float* __restrict__ xs,
+                                                              const float* __restrict__ w,
                                                               float* __restrict__ y, int B, int M, int K, int HW,
                                                               int transpose, int blocks, int ngroups, int cg, long long items) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];          // [T][KS][PW_WROW]: the A operand of (tile, k-step)
@@ -141,21 +145,34 @@ __global__ __launch_bounds__(PW_THREADS) void pw_apply_kernel(const float* __res
       for (int j = 0; j < 4; ++j) acc[i][j] = pw_v4f{0.0f, 0.0f, 0.0f, 0.0f};
     const float* xb = x + ((size_t)b * K + q) * HW;                     // row 4 ks + q: advance by 4 HW per k-step
     const float* sa = s_w + (size_t)t0 * KS * PW_WROW + lane;
+    const float* sb = SCALED ? xs + (size_t)b * K + q : nullptr;        // scale of row 4 ks + q
     float cur[PW_PF][4], nxt[PW_PF][4];
+    float cur_s[PW_PF], nxt_s[PW_PF];
 #pragma unroll
     for (int d = 0; d < PW_PF; ++d) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) cur[d][j] = nxt[d][j] = 0.0f;
-      if (d < KS) pw_load_row64<VEC>(xb + (size_t)d * 4 * HW, p0, n, HW, cur[d]);
+      cur_s[d] = nxt_s[d] = 1.0f;
+      if (d < KS) {
+        pw_load_row64<VEC>(xb + (size_t)d * 4 * HW, p0, n, HW, cur[d]);
+        if (SCALED) cur_s[d] = sb[4 * d];
+      }
     }
     PW_STAMP(2);
     for (int ks0 = 0; ks0 < KS; ks0 += PW_PF) {
 #pragma unroll
       for (int d = 0; d < PW_PF; ++d)
-        if (ks0 + PW_PF + d < KS) pw_load_row64<VEC>(xb + (size_t)(ks0 + PW_PF + d) * 4 * HW, p0, n, HW, nxt[d]);
+        if (ks0 + PW_PF + d < KS) {
+          pw_load_row64<VEC>(xb + (size_t)(ks0 + PW_PF + d) * 4 * HW, p0, n, HW, nxt[d]);
+          if (SCALED) nxt_s[d] = sb[4 * (ks0 + PW_PF + d)];
+        }
 #pragma unroll
       for (int d = 0; d < PW_PF; ++d) {
         if (ks0 + d < KS) {
+          if (SCALED) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[d][j] *= cur_s[d];
+          }
 #pragma unroll
           for (int i = 0; i < PW_CG; ++i) {
             if (i < tiles) {
@@ -167,9 +184,11 @@ __global__ __launch_bounds__(PW_THREADS) void pw_apply_kernel(const float* __res
         }
       }
 #pragma unroll
-      for (int d = 0; d < PW_PF; ++d)
+      for (int d = 0; d < PW_PF; ++d) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) cur[d][j] = nxt[d][j];
+        if (SCALED) cur_s[d] = nxt_s[d];
+      }
     }
     PW_STAMP(3);
 #pragma unroll
@@ -222,11 +241,14 @@ __device__ __forceinline__ void pw_load_slots(const float* __restrict__ row, boo
 // partial[(b, split)][m][k] = sum over the split's positions of g[b][m][p] x[b][k][p]; one wave per (b, split, 16-row
 // tile of g), all <= PW_NTI input tiles accumulated at once.  The input rows of a (chunk, tile) step are requested two
 // steps (32 MFMAs) ahead, the g rows of the next chunk one chunk ahead.
-template <int VEC>
+// SCALED: the gradient of W in y[b] = W (x[b] * xs[b]): column k of a (sample, split) unit's sums times xs[b][k], applied
+// once where the unit's sums leave the accumulators.
+template <int VEC, bool SCALED>
 __global__ __launch_bounds__(PW_THREADS) void pw_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                              const float* __restrict__ xs,
                                                               float* __restrict__ partial, int B, int M, int K, int HW,
                                                               int splits, int chunks_per_split) {
-  extern __shared__ __attribute__((aligned(16))) float s_acc[];      // [4 waves][NTI][4][64]
+  extern __shared__ __attribute__((aligned(16))) float s_acc[];      // [4 waves][NTI][4][64] (SCALED: + [4 waves][256])
   const int T = (M + 15) >> 4, NTI = (K + 15) >> 4, wave = threadIdx.x >> 6;
   const int t = (int)(blockIdx.x % T);
   const long long unit = (long long)(blockIdx.x / T) * (PW_THREADS / 64) + wave;   // (b, split), four per workgroup
@@ -238,6 +260,12 @@ __global__ __launch_bounds__(PW_THREADS) void pw_wgrad_kernel(const float* __res
   pw_v4f acc[PW_NTI];
 #pragma unroll
   for (int u = 0; u < PW_NTI; ++u) acc[u] = pw_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+  // (SCALED) the unit's K column scales go to a wave-private LDS row here: fetched where the sums leave the accumulators
+  // they were up to 15 loads, one exposed latency after the other (the scaled launches measured 12 % over the plain
+  // ones), and 15 more registers would cost the kernel its third wave per SIMD (160 -> 176 VGPRs)
+  float* s_sc = s_acc + (size_t)(PW_THREADS / 64) * NTI * 256 + wave * 256;
+  if (SCALED)
+    for (int i = lane; i < 16 * NTI; i += 64) s_sc[i] = i < K ? xs[(size_t)b * K + i] : 0.0f;
   const int gm = 16 * t + n;
   const bool gok = gm < M;
   const float* grow = g + ((size_t)b * M + (gok ? gm : 0)) * HW;
@@ -279,9 +307,10 @@ __global__ __launch_bounds__(PW_THREADS) void pw_wgrad_kernel(const float* __res
   // the four waves of the workgroup (same row tile, four (sample, split) units) meet in LDS, added in wave order
 #pragma unroll
   for (int u = 0; u < PW_NTI; ++u)
-    if (u < NTI)
+    if (u < NTI) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s_acc[((wave * NTI + u) * 4 + r) * 64 + lane] = acc[u][r];
+      for (int r = 0; r < 4; ++r) s_acc[((wave * NTI + u) * 4 + r) * 64 + lane] = SCALED ? acc[u][r] * s_sc[16 * u + n] : acc[u][r];
+    }
   __syncthreads();
   float* pp = partial + (size_t)(blockIdx.x / T) * M * K;
   for (int e = threadIdx.x; e < NTI * 256; e += PW_THREADS) {          // e = (u, r, lane)
@@ -337,7 +366,22 @@ extern "C" int ias_pwconv_supported(int Cin, int Cout) {
   return Cin <= 16 * PW_NTI ? 1 : 0;
 }
 
-static int pw_apply(const float* x, const float* w, float* y, int B, int M, int K, int HW, int transpose, hipStream_t st) {
+template <bool SCALED>
+static void pw_apply_launch(int vec, long long grid, size_t lds, hipStream_t st, const float* x, const float* xs, const float* w,
+                            float* y, int B, int M, int K, int HW, int transpose, int blocks, int ngroups, int cg, long long items) {
+  if (lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)pw_apply_kernel<4, SCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)pw_apply_kernel<2, SCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)pw_apply_kernel<1, SCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  switch (vec) {
+    case 4: hipLaunchKernelGGL((pw_apply_kernel<4, SCALED>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, x, xs, w, y, B, M, K, HW, transpose, blocks, ngroups, cg, items); break;
+    case 2: hipLaunchKernelGGL((pw_apply_kernel<2, SCALED>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, x, xs, w, y, B, M, K, HW, transpose, blocks, ngroups, cg, items); break;
+    default: hipLaunchKernelGGL((pw_apply_kernel<1, SCALED>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, x, xs, w, y, B, M, K, HW, transpose, blocks, ngroups, cg, items); break;
+  }
+}
+// xs: NULL, or a scale per (sample, input row) [B][K] applied to x on load
+static int pw_apply(const float* x, const float* xs, const float* w, float* y, int B, int M, int K, int HW, int transpose, hipStream_t st) {
   if (((uintptr_t)w & 15) != 0) return IAS_ERR_ARG;
   const int T = (M + 15) / 16, blocks = (HW + 63) / 64;
   int cg = PW_CG;                                   // fewer tiles per wave (the input re-read from L2) when that is what
@@ -347,16 +391,8 @@ static int pw_apply(const float* x, const float* w, float* y, int B, int M, int 
   long long grid = (items + PW_THREADS / 64 - 1) / (PW_THREADS / 64);
   if (grid > 1024) grid = 1024;                     // the weight is staged once per workgroup
   const size_t lds = sizeof(float) * (size_t)T * (K / 4) * PW_WROW;
-  if (lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)pw_apply_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)pw_apply_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)pw_apply_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
-  switch (pw_vec(x, y, HW)) {
-    case 4: hipLaunchKernelGGL((pw_apply_kernel<4>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, x, w, y, B, M, K, HW, transpose, blocks, ngroups, cg, items); break;
-    case 2: hipLaunchKernelGGL((pw_apply_kernel<2>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, x, w, y, B, M, K, HW, transpose, blocks, ngroups, cg, items); break;
-    default: hipLaunchKernelGGL((pw_apply_kernel<1>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, x, w, y, B, M, K, HW, transpose, blocks, ngroups, cg, items); break;
-  }
+  if (xs) pw_apply_launch<true>(pw_vec(x, y, HW), grid, lds, st, x, xs, w, y, B, M, K, HW, transpose, blocks, ngroups, cg, items);
+  else pw_apply_launch<false>(pw_vec(x, y, HW), grid, lds, st, x, xs, w, y, B, M, K, HW, transpose, blocks, ngroups, cg, items);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
 
@@ -364,7 +400,16 @@ static int pw_apply(const float* x, const float* w, float* y, int B, int M, int 
 extern "C" int ias_pwconv_forward(const float* x, const float* w, float* y, int B, int Cin, int Cout, int HW, void* stream_) {
   if (!x || !w || !y || B <= 0 || HW <= 0) return IAS_ERR_ARG;
   if (!ias_pwconv_supported(Cin, Cout)) return IAS_ERR_UNSUPPORTED;
-  return pw_apply(x, w, y, B, Cout, Cin, HW, 0, (hipStream_t)stream_);
+  return pw_apply(x, nullptr, w, y, B, Cout, Cin, HW, 0, (hipStream_t)stream_);
+}
+// The same on a gated input: y[b] = W (x[b] * scale[b]), scale [B,Cin] -- the projection behind a squeeze-excitation block
+// (torchvision InvertedResidual: SqueezeExcitation -> Conv2dNormActivation(cexp, cout, 1); reference: the trunk of
+// /root/reference/audioembed.py:61) without the gate's own pass over the expanded map.
+extern "C" int ias_pwconv_forward_scaled(const float* x, const float* scale, const float* w, float* y, int B, int Cin, int Cout,
+                                         int HW, void* stream_) {
+  if (!x || !scale || !w || !y || B <= 0 || HW <= 0) return IAS_ERR_ARG;
+  if (!ias_pwconv_supported(Cin, Cout)) return IAS_ERR_UNSUPPORTED;
+  return pw_apply(x, scale, w, y, B, Cout, Cin, HW, 0, (hipStream_t)stream_);
 }
 
 // its input gradient: g [B,Cout,HW], w [Cout,Cin] -> gx [B,Cin,HW]
@@ -372,7 +417,7 @@ extern "C" int ias_pwconv_backward_data(const float* g, const float* w, float* g
                                         void* stream_) {
   if (!g || !w || !gx || B <= 0 || HW <= 0) return IAS_ERR_ARG;
   if (!ias_pwconv_supported(Cin, Cout)) return IAS_ERR_UNSUPPORTED;
-  return pw_apply(g, w, gx, B, Cin, Cout, HW, 1, (hipStream_t)stream_);
+  return pw_apply(g, nullptr, w, gx, B, Cin, Cout, HW, 1, (hipStream_t)stream_);
 }
 
 static int pw_wgrad_splits(int B, int Cout, int HW) {
@@ -391,7 +436,17 @@ extern "C" long long ias_pwconv_weight_scratch(int B, int Cin, int Cout, int HW)
 
 // its weight gradient: g [B,Cout,HW], x [B,Cin,HW] -> gw [Cout,Cin]; scratch: ias_pwconv_weight_scratch floats.
 // gw == nullptr: the partial sums only -> *nchunk rows of Cout Cin floats in `scratch` (ias_pwconv_backward_weight_partials)
-static int pw_backward_weight(const float* g, const float* x, float* gw, float* scratch, int B, int Cin, int Cout, int HW,
+template <bool SCALED>
+static void pw_wgrad_launch(int vec, long long grid, size_t lds, hipStream_t st, const float* g, const float* x, const float* xs,
+                            float* scratch, int B, int Cout, int Cin, int HW, int splits, int cps) {
+  switch (vec) {
+    case 4: hipLaunchKernelGGL((pw_wgrad_kernel<4, SCALED>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, g, x, xs, scratch, B, Cout, Cin, HW, splits, cps); break;
+    case 2: hipLaunchKernelGGL((pw_wgrad_kernel<2, SCALED>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, g, x, xs, scratch, B, Cout, Cin, HW, splits, cps); break;
+    default: hipLaunchKernelGGL((pw_wgrad_kernel<1, SCALED>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, g, x, xs, scratch, B, Cout, Cin, HW, splits, cps); break;
+  }
+}
+// xs: NULL, or the [B][Cin] scale of the forward's gated input (ias_pwconv_forward_scaled)
+static int pw_backward_weight(const float* g, const float* x, const float* xs, float* gw, float* scratch, int B, int Cin, int Cout, int HW,
                               int* nchunk, void* stream_) {
   if (!g || !x || !scratch || B <= 0 || HW <= 0) return IAS_ERR_ARG;
   if (!ias_pwconv_supported(Cin, Cout)) return IAS_ERR_UNSUPPORTED;
@@ -401,12 +456,9 @@ static int pw_backward_weight(const float* g, const float* x, float* gw, float* 
   const long long units = (long long)B * splits, ugroups = (units + PW_THREADS / 64 - 1) / (PW_THREADS / 64);
   const long long grid = ugroups * T;
   if (grid > 0x7fffffffLL) return IAS_ERR_ARG;
-  const size_t lds = sizeof(float) * (size_t)(PW_THREADS / 64) * NTI * 256;
-  switch (pw_vec(g, x, HW)) {
-    case 4: hipLaunchKernelGGL((pw_wgrad_kernel<4>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, g, x, scratch, B, Cout, Cin, HW, splits, cps); break;
-    case 2: hipLaunchKernelGGL((pw_wgrad_kernel<2>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, g, x, scratch, B, Cout, Cin, HW, splits, cps); break;
-    default: hipLaunchKernelGGL((pw_wgrad_kernel<1>), dim3((unsigned)grid), dim3(PW_THREADS), lds, st, g, x, scratch, B, Cout, Cin, HW, splits, cps); break;
-  }
+  const size_t lds = sizeof(float) * (size_t)(PW_THREADS / 64) * (NTI * 256 + (xs ? 256 : 0));   // (+ the waves' scale rows)
+  if (xs) pw_wgrad_launch<true>(pw_vec(g, x, HW), grid, lds, st, g, x, xs, scratch, B, Cout, Cin, HW, splits, cps);
+  else pw_wgrad_launch<false>(pw_vec(g, x, HW), grid, lds, st, g, x, xs, scratch, B, Cout, Cin, HW, splits, cps);
   if (nchunk) *nchunk = (int)ugroups;
   if (gw) {
     const int n = Cout * Cin;
@@ -417,14 +469,27 @@ static int pw_backward_weight(const float* g, const float* x, float* gw, float* 
 extern "C" int ias_pwconv_backward_weight(const float* g, const float* x, float* gw, float* scratch, int B, int Cin, int Cout,
                                           int HW, void* stream_) {
   if (!gw) return IAS_ERR_ARG;
-  return pw_backward_weight(g, x, gw, scratch, B, Cin, Cout, HW, nullptr, stream_);
+  return pw_backward_weight(g, x, nullptr, gw, scratch, B, Cin, Cout, HW, nullptr, stream_);
+}
+// the weight gradient of ias_pwconv_forward_scaled: gw = sum_b g[b] (x[b] * scale[b])^T
+extern "C" int ias_pwconv_backward_weight_scaled(const float* g, const float* x, const float* scale, float* gw, float* scratch,
+                                                 int B, int Cin, int Cout, int HW, void* stream_) {
+  if (!gw || !scale) return IAS_ERR_ARG;
+  return pw_backward_weight(g, x, scale, gw, scratch, B, Cin, Cout, HW, nullptr, stream_);
 }
 // The same without the reduction launch: -> the number of partial rows (> 0; row r is scratch[r Cout Cin ...]) for
 // ias_reduce_partials_multi, or a negative status
 extern "C" int ias_pwconv_backward_weight_partials(const float* g, const float* x, float* scratch, int B, int Cin, int Cout,
                                                    int HW, void* stream_) {
   int nchunk = 0;
-  const int rc = pw_backward_weight(g, x, nullptr, scratch, B, Cin, Cout, HW, &nchunk, stream_);
+  const int rc = pw_backward_weight(g, x, nullptr, nullptr, scratch, B, Cin, Cout, HW, &nchunk, stream_);
+  return rc != IAS_OK ? rc : nchunk;
+}
+extern "C" int ias_pwconv_backward_weight_partials_scaled(const float* g, const float* x, const float* scale, float* scratch,
+                                                          int B, int Cin, int Cout, int HW, void* stream_) {
+  if (!scale) return IAS_ERR_ARG;
+  int nchunk = 0;
+  const int rc = pw_backward_weight(g, x, scale, nullptr, scratch, B, Cin, Cout, HW, &nchunk, stream_);
   return rc != IAS_OK ? rc : nchunk;
 }
 

@@ -442,6 +442,93 @@ class _SEFn(torch.autograd.Function):
         return gx, gw1, gb1, gw2, gb2
 
 
+class _SEProjFn(torch.autograd.Function):
+    """y = W (x * s), s = hardsigmoid(fc2(relu(fc1(mean_hw x)))): a SqueezeExcitation block AND the bias-free 1x1 projection
+    behind it (torchvision InvertedResidual) as one node.  The gate is applied by the projection on load
+    (ias_pwconv_forward_scaled): the forward has no `scale * input` pass over the expanded map; the backward is _SEFn's
+    with the projection's input gradient as its cotangent, plus the weight gradient on the gated input
+    (ias_pwconv_backward_weight*_scaled).  Same values as SqueezeExcitation followed by PointwiseConv2d."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w):
+        from . import _lib
+        lib = _lib.load()
+        x, w = x.contiguous(), w.contiguous()
+        _lib.require_f32(x, w1, b1, w2, b2, w)
+        B, C, H, W = x.shape
+        hw = H * W
+        Cs, Cout = w1.shape[0], w.shape[0]
+        w1, w2 = w1.contiguous(), w2.contiguous()
+        pooled = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.ias_se_plane_reduce(_lib.ptr(x), None, _lib.ptr(pooled), B * C, hw, 1.0 / hw, _lib.stream()),
+                   "ias_se_plane_reduce")
+        h = torch.empty((B, Cs), dtype=torch.float32, device=x.device)
+        z, s = torch.empty_like(pooled), torch.empty_like(pooled)
+        _lib.check(lib.ias_se_mlp_forward(_lib.ptr(pooled), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(h),
+                                          _lib.ptr(z), _lib.ptr(s), B, C, Cs, _lib.stream()), "ias_se_mlp_forward")
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+        _lib.check(lib.ias_pwconv_forward_scaled(_lib.ptr(x), _lib.ptr(s), _lib.ptr(w), _lib.ptr(y), B, C, Cout, hw,
+                                                 _lib.stream()), "ias_pwconv_forward_scaled")
+        ctx.save_for_backward(x, pooled, h, z, s, w1, w2, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.load()
+        x, pooled, h, z, s, w1, w2, w = ctx.saved_tensors
+        g = g.contiguous()
+        B, C, H, W = x.shape
+        hw = H * W
+        Cs, Cout = w1.shape[0], w.shape[0]
+        # the cotangent of the gated map x * s (_SEFn's backward runs on it below)
+        gy = torch.empty_like(x)
+        _lib.check(lib.ias_pwconv_backward_data(_lib.ptr(g), _lib.ptr(w), _lib.ptr(gy), B, C, Cout, hw, _lib.stream()),
+                   "ias_pwconv_backward_data")
+        # ... and the projection's weight gradient on the gated input (behind the input gradient, as _PointwiseFn orders them)
+        gw = None
+        if ctx.needs_input_grad[5]:
+            gw = torch.empty_like(w)
+            scratch = torch.empty(int(lib.ias_pwconv_weight_scratch(B, C, Cout, hw)), dtype=torch.float32, device=x.device)
+            if _DEFER["on"]:
+                rows = lib.ias_pwconv_backward_weight_partials_scaled(_lib.ptr(g), _lib.ptr(x), _lib.ptr(s), _lib.ptr(scratch),
+                                                                      B, C, Cout, hw, _lib.stream())
+                _lib.check(min(int(rows), 0), "ias_pwconv_backward_weight_partials_scaled")
+                _defer_reduction(scratch, gw, gw.numel(), rows)
+            else:
+                _lib.check(lib.ias_pwconv_backward_weight_scaled(_lib.ptr(g), _lib.ptr(x), _lib.ptr(s), _lib.ptr(gw),
+                                                                 _lib.ptr(scratch), B, C, Cout, hw, _lib.stream()),
+                           "ias_pwconv_backward_weight_scaled")
+        gs = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.ias_se_plane_reduce(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(gs), B * C, hw, 1.0, _lib.stream()),
+                   "ias_se_plane_reduce")
+        gz, gp = torch.empty_like(gs), torch.empty_like(gs)
+        gh = torch.empty((B, Cs), dtype=torch.float32, device=x.device)
+        gw1, gw2 = torch.empty_like(w1), torch.empty_like(w2)
+        gb1 = torch.empty(Cs, dtype=torch.float32, device=x.device)
+        gb2 = torch.empty(C, dtype=torch.float32, device=x.device)
+        _lib.check(lib.ias_se_mlp_backward(_lib.ptr(gs), _lib.ptr(z), _lib.ptr(h), _lib.ptr(pooled), _lib.ptr(w1), _lib.ptr(w2),
+                                           _lib.ptr(gz), _lib.ptr(gh), _lib.ptr(gp), _lib.ptr(gw1), _lib.ptr(gb1), _lib.ptr(gw2),
+                                           _lib.ptr(gb2), B, C, Cs, _lib.stream()), "ias_se_mlp_backward")
+        gx = torch.empty_like(x)
+        _lib.check(lib.ias_se_scale(_lib.ptr(gy), _lib.ptr(s), _lib.ptr(gp), _lib.ptr(gx), B * C, hw, 1.0 / hw, _lib.stream()),
+                   "ias_se_scale")
+        return gx, gw1, gb1, gw2, gb2, gw
+
+
+FUSE_SE_PROJECTION = True      # (tests / scripts/diag A/B runs: False keeps SqueezeExcitation and its projection apart)
+
+
+def se_projection(se, conv, x):
+    """``conv(se(x))`` for a SqueezeExcitation ``se`` and the 1x1 projection ``conv`` behind it; one fused node
+    (_SEProjFn) where the projection is a shape of csrc/pointwise_kernels.hip, the two modules otherwise."""
+    if FUSE_SE_PROJECTION and x.is_cuda and not trunk_torch() and x.dtype == torch.float32 and x.dim() == 4 and isinstance(conv, PointwiseConv2d) and \
+            conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None and \
+            _pw_mfma(x.shape[1], conv.out_channels):
+        return _SEProjFn.apply(x, se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias, conv.weight)
+    return conv(se(x))
+
+
 class SqueezeExcitation(nn.Module):
     def __init__(self, channels, squeeze):
         super().__init__()
@@ -473,14 +560,20 @@ class InvertedResidual(nn.Module):
         self.block = nn.Sequential(*layers)
 
     def forward(self, x):
-        if not self.use_res:
-            return self.block(x)
-        # the skip connection is added by the block's last normalisation (one pass: BatchNormAct2d.forward(residual=...))
+        # the block's last ConvBNAct by hand: its 1x1 projection takes the squeeze-excitation gate on load (se_projection)
+        # and its normalisation adds the skip connection (one pass: BatchNormAct2d.forward(residual=...))
+        layers = list(self.block)
+        conv, norm = layers[-1][0], layers[-1][1]
         h = x
-        for layer in list(self.block)[:-1]:
+        for layer in layers[:-1]:
+            if isinstance(layer, SqueezeExcitation):
+                break
             h = layer(h)
-        conv, norm = self.block[-1][0], self.block[-1][1]
-        return norm(conv(h), residual=x)
+        if isinstance(layers[-2], SqueezeExcitation):
+            h = se_projection(layers[-2], conv, h)
+        else:
+            h = conv(h)
+        return norm(h, residual=x) if self.use_res else norm(h)
 
 
 # (in, kernel, expanded, out, squeeze-excite, hardswish, stride)

@@ -1,5 +1,6 @@
 """One VICReg pretraining step (BASELINE config #3: B=128, 4 s @ 44.1 kHz, dim 1024, embeddim 8192) -- wall time per step,
-eager (default) or as the Trainer's captured hipGraph (GRAPH=1); DEFER=0: without the joint weight-gradient reduction."""
+eager (default) or as the Trainer's captured hipGraph (GRAPH=1); DEFER=0: without the joint weight-gradient reduction;
+SEPROJ=0: without the squeeze-excitation gate taken by the projection on load."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -18,6 +19,9 @@ tr = Trainer(cfg, model, stage="vicreg", device=dev)
 if os.environ.get("DEFER") == "0":      # the trunk's weight-gradient reductions as a launch per layer (vision.defer_weight_reductions off)
     import contextlib
     tr._deferred_reductions = contextlib.nullcontext
+if os.environ.get("SEPROJ") == "0":     # SqueezeExcitation and its projection as two nodes (the gate's own pass over the map)
+    from inverse_audio_synthesis_amd import vision
+    vision.FUSE_SE_PROJECTION = False
 model.train()
 opt = tr.optimizer
 def step(i):

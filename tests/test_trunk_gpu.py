@@ -278,6 +278,49 @@ def test_pointwise_conv_matches_torch(lib, dev, B, Cin, Cout, H, W):
         assert torch.equal(gw, gw2)
 
 
+@pytest.mark.parametrize("B,C,Cs,Cout,H,W", [(3, 16, 8, 16, 60, 62), (4, 96, 24, 40, 15, 16), (5, 240, 64, 40, 15, 16),
+                                             (3, 120, 32, 48, 15, 16), (130, 144, 40, 48, 15, 16), (3, 24, 8, 8, 5, 7),
+                                             (2, 288, 72, 96, 8, 8)])      # the last: the projection's batched-GEMM form
+def test_squeeze_excitation_gate_taken_by_the_projection_on_load(lib, dev, B, C, Cs, Cout, H, W):
+    """vision.se_projection (_SEProjFn: ias_pwconv_forward_scaled / ias_pwconv_backward_weight_scaled, no `scale * input`
+    pass) against SqueezeExcitation followed by PointwiseConv2d: the same bits forward and for every gradient that does not
+    pass through the weight-gradient sums, the projection's weight gradient against fp64 (and, where the fused node runs,
+    the same bits twice and through the deferred joint reduction)."""
+    from inverse_audio_synthesis_amd import vision
+    torch.manual_seed(5)
+    se = vision.SqueezeExcitation(C, Cs).to(dev)
+    conv = vision.PointwiseConv2d(C, Cout, 1, bias=False).to(dev)
+    with torch.no_grad():
+        for p in se.parameters():
+            p.copy_(torch.randn(p.shape) * 0.5)
+    params = [se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias, conv.weight]
+    x1 = randn((B, C, H, W), 41).to(dev).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    g = randn((B, Cout, H, W), 42).to(dev)
+    y1 = vision.se_projection(se, conv, x1)
+    y2 = conv(se(x2))
+    assert torch.equal(y1, y2)
+    got = torch.autograd.grad(y1, [x1] + params, g)
+    want = torch.autograd.grad(y2, [x2] + params, g)
+    for a, r, name in zip(got[:5], want[:5], ("gx", "gw1", "gb1", "gw2", "gb2")):
+        assert torch.equal(a, r), name
+    xd = x1.detach().double().requires_grad_(True)
+    pd = [p.detach().double().requires_grad_(True) for p in params]
+    sd = F.hardsigmoid(F.conv2d(F.relu(F.conv2d(xd.mean((2, 3), keepdim=True), pd[0], pd[1])), pd[2], pd[3]))
+    rw = torch.autograd.grad(F.conv2d(sd * xd, pd[4]), pd[4], g.double())[0]
+    assert (got[5].double() - rw).abs().max().item() <= 1e-4 * max(1.0, rw.abs().max().item())
+    if lib.ias_pwconv_supported(C, Cout):
+        again = torch.autograd.grad(vision.se_projection(se, conv, x1), conv.weight, g)[0]
+        assert torch.equal(again, got[5])
+        vision.defer_weight_reductions(True)
+        try:
+            deferred = torch.autograd.grad(vision.se_projection(se, conv, x1), conv.weight, g)[0]
+            vision._flush_reductions()
+        finally:
+            vision.defer_weight_reductions(False)
+        assert torch.equal(deferred, got[5])
+
+
 @pytest.mark.parametrize("shape", [(128, 40, 15, 16), (6, 24, 30, 31), (3, 96, 8, 8), (2, 33, 7, 9), (128, 24, 30, 31)])
 def test_batchnorm_with_the_residual_in_the_same_pass(lib, dev, shape):
     """BatchNormAct2d.forward(x, residual=r) (ias_bn_act_forward_res: the skip connection of an inverted-residual block
