@@ -452,6 +452,10 @@ int ias_conv2x2_patches_backward_nchw(const float* gp, float* gx, int B, int H, 
  * convolutions run as GEMMs); scratch: ias_colsum_scratch_floats(rows, cols) floats */
 long long ias_colsum_scratch_floats(int rows, int cols);
 int ias_colsum(const float* a, float* out, float* scratch, int rows, int cols, void* stream);
+/* ... without its second launch: the slice sums stay in `scratch` -> their number (> 0, <= 16; `cols` floats each) for
+ * ias_reduce_partials_multi (same bits as ias_colsum), or a negative IAS_ERR_*.  Reference: the bias gradient of the
+ * head's nn.Conv2d(dim, dim, 2) layers, autograd of /root/reference/audioembed.py:62-68. */
+int ias_colsum_partials(const float* a, float* scratch, int rows, int cols, void* stream);
 int ias_stem_forward(const float* x, const float* w, float* out, int B, int H, int W, void* stream);
 long long ias_stem_weight_scratch(int B);                     /* floats */
 int ias_stem_backward_weight(const float* x, const float* g, float* gw, float* scratch, int B, int H, int W, void* stream);

@@ -122,6 +122,7 @@ SYMBOLS = {
     "ias_conv2x2_patches_nchw": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ias_colsum_scratch_floats": (_LL, [_I, _I]),
     "ias_colsum": (_I, [_P, _P, _P, _I, _I, _P]),
+    "ias_colsum_partials": (_I, [_P, _P, _I, _I, _P]),
     "ias_stem_forward": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ias_stem_weight_scratch": (_LL, [_I]),
     "ias_stem_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

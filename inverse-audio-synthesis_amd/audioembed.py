@@ -82,8 +82,15 @@ class _Conv2x2Fn(torch.autograd.Function):
             g2c = g2.contiguous()
             gb = torch.empty(Cout, dtype=torch.float32, device=g.device)
             scratch = torch.empty(int(lib.ias_colsum_scratch_floats(g2c.shape[0], Cout)), dtype=torch.float32, device=g.device)
-            _lib.check(lib.ias_colsum(_lib.ptr(g2c), _lib.ptr(gb), _lib.ptr(scratch), g2c.shape[0], Cout, _lib.stream()),
-                       "ias_colsum")
+            from . import vision
+            if vision._DEFER["on"]:
+                # the second launch joins the backward pass' ONE reduction launch (vision.defer_weight_reductions)
+                srows = lib.ias_colsum_partials(_lib.ptr(g2c), _lib.ptr(scratch), g2c.shape[0], Cout, _lib.stream())
+                _lib.check(min(int(srows), 0), "ias_colsum_partials")
+                vision._defer_reduction(scratch, gb, Cout, srows)
+            else:
+                _lib.check(lib.ias_colsum(_lib.ptr(g2c), _lib.ptr(gb), _lib.ptr(scratch), g2c.shape[0], Cout, _lib.stream()),
+                           "ias_colsum")
         return gx, gw, gb, None
 
 

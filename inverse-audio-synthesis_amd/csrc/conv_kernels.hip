@@ -1434,12 +1434,26 @@ extern "C" long long ias_colsum_scratch_floats(int rows, int cols) {
   if (rows <= 0 || cols <= 0) return IAS_ERR_ARG;
   return (long long)colsum_slices(rows) * cols;
 }
-extern "C" int ias_colsum(const float* a, float* out, float* scratch, int rows, int cols, void* stream_) {
-  if (!a || !out || !scratch || rows <= 0 || cols <= 0) return IAS_ERR_ARG;
+// out == nullptr: the slice sums only (S rows of `cols` floats in scratch)
+static int colsum_launch(const float* a, float* out, float* scratch, int rows, int cols, int* nrows, void* stream_) {
+  if (!a || !scratch || rows <= 0 || cols <= 0) return IAS_ERR_ARG;
   const int S = colsum_slices(rows);
   const int rps = (rows + S - 1) / S;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + CS_CT - 1) / CS_CT, S), dim3(CS_CT * CS_RG), 0, (hipStream_t)stream_, a,
                      scratch, rows, cols, rps);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream_, scratch, out, S, cols);
+  if (out) hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream_, scratch, out, S, cols);
+  if (nrows) *nrows = S;
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+}
+extern "C" int ias_colsum(const float* a, float* out, float* scratch, int rows, int cols, void* stream_) {
+  if (!out) return IAS_ERR_ARG;
+  return colsum_launch(a, out, scratch, rows, cols, nullptr, stream_);
+}
+// The same without its second launch -> the number of slice rows (> 0; `cols` floats each, in slice order) left in
+// `scratch` for ias_reduce_partials_multi (which adds <= 16 rows in row order, as the second launch does: the same bits),
+// or a negative IAS_ERR_*
+extern "C" int ias_colsum_partials(const float* a, float* scratch, int rows, int cols, void* stream_) {
+  int S = 0;
+  const int rc = colsum_launch(a, nullptr, scratch, rows, cols, &S, stream_);
+  return rc != IAS_OK ? rc : S;
 }

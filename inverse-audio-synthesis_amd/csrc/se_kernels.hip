@@ -387,11 +387,20 @@ __global__ __launch_bounds__(SEF_THREADS) void se_mlp_backward_pair_kernel(const
 // are in flight together, one barrier pair -- slices of 32 made it four dependent load -> barrier -> compute rounds,
 // 14.5 us for a 21 MFLOP product), a thread owns a 2 x 2 block; sums in batch order.
 #define SEO_SLICE 128
-__global__ __launch_bounds__(SEM_THREADS) void se_outer_sum_kernel(const float* __restrict__ a, const float* __restrict__ m,
-                                                                   float* __restrict__ out, float* __restrict__ colsum, int B,
-                                                                   int R, int Q) {
+// Both parameter gradients of a block's MLP in ONE launch (round 5: they were two launches of ~6 us, 18 per pretraining
+// step, all latency): workgroups [0, n1) take problem 1 (a1, m1 -> out1, colsum1; R1 x Q1 in tiles of 32 x 32, row tiles
+// fastest), the others problem 2; the arithmetic per output is unchanged.
+struct SeOuterProblem { const float* a; const float* m; float* out; float* colsum; int R, Q; };
+__global__ __launch_bounds__(SEM_THREADS) void se_outer_sum_kernel(const SeOuterProblem p1, const SeOuterProblem p2, int n1, int B) {
   __shared__ float s_a[SEO_SLICE][33], s_m[SEO_SLICE][33];
-  const int r0 = blockIdx.x * 32, q0 = blockIdx.y * 32, tid = threadIdx.x;
+  const bool second = (int)blockIdx.x >= n1;                       // (uniform)
+  const float* __restrict__ a = second ? p2.a : p1.a;
+  const float* __restrict__ m = second ? p2.m : p1.m;
+  float* __restrict__ out = second ? p2.out : p1.out;
+  float* __restrict__ colsum = second ? p2.colsum : p1.colsum;
+  const int R = second ? p2.R : p1.R, Q = second ? p2.Q : p1.Q;
+  const int tile = (int)blockIdx.x - (second ? n1 : 0), rt = (R + 31) / 32, tile_q = tile / rt;
+  const int r0 = (tile - tile_q * rt) * 32, q0 = tile_q * 32, tid = threadIdx.x;
   const int tr = tid >> 4, tq = tid & 15;
   const int x = tid & 31, brow = tid >> 5;                       // loader: column x of rows brow + 8 i
   const bool aok = r0 + x < R, mok = q0 + x < Q;
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(SEM_THREADS) void se_outer_sum_kernel(const float* 
       const int q = q0 + 2 * tq + j;
       if (q < Q) out[(size_t)r * Q + q] = acc[i][j];
     }
-    if (colsum && blockIdx.y == 0 && tq == 0) colsum[r] = cs[i];
+    if (colsum && tile_q == 0 && tq == 0) colsum[r] = cs[i];
   }
 }
 
@@ -464,7 +473,8 @@ extern "C" int ias_se_mlp_backward(const float* gs, const float* z, const float*
     hipLaunchKernelGGL(se_mlp_backward_sample_kernel, dim3(B), dim3(SEM_THREADS), sizeof(float) * (size_t)(C + Cs), st, gs, z, h,
                        w1, w2, gz, gh, gp, C, Cs);
   }
-  hipLaunchKernelGGL(se_outer_sum_kernel, dim3((C + 31) / 32, (Cs + 31) / 32), dim3(SEM_THREADS), 0, st, gz, h, gw2, gb2, B, C, Cs);
-  hipLaunchKernelGGL(se_outer_sum_kernel, dim3((Cs + 31) / 32, (C + 31) / 32), dim3(SEM_THREADS), 0, st, gh, pooled, gw1, gb1, B, Cs, C);
+  const int ntiles = ((C + 31) / 32) * ((Cs + 31) / 32);
+  const SeOuterProblem p2w = {gz, h, gw2, gb2, C, Cs}, p1w = {gh, pooled, gw1, gb1, Cs, C};
+  hipLaunchKernelGGL(se_outer_sum_kernel, dim3(2 * ntiles), dim3(SEM_THREADS), 0, st, p2w, p1w, ntiles, B);
   return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
 }
