@@ -477,6 +477,13 @@ int ias_bn_act_forward(const float* x, const float* weight, const float* bias, f
 int ias_bn_act_forward_res(const float* x, const float* res, const float* weight, const float* bias, float* running_mean,
                            float* running_var, float* y, float* save_mean, float* save_invstd, double* scratch, int B,
                            int C, int HW, float eps, float momentum, int act, void* stream);
+/* ias_bn_act_forward that also leaves pooled[b][c] = mean over the plane of y[b][c] behind ([B,C]): the average pool of the
+ * squeeze-excitation block that follows a depthwise convolution's normalisation in torchvision's InvertedResidual
+ * (SqueezeExcitation._scale: `self.avgpool(input)`; the trunk run at /root/reference/audioembed.py:61) -- in the
+ * normalisation's own launch on maps up to 15 x 16, as ias_se_plane_reduce behind it on larger ones */
+int ias_bn_act_forward_pool(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
+                            float* y, float* pooled, float* save_mean, float* save_invstd, double* scratch, int B, int C,
+                            int HW, float eps, float momentum, int act, void* stream);
 int ias_bn_act_backward(const float* x, const float* dy, const float* weight, const float* bias, const float* save_mean,
                         const float* save_invstd, float* dx, float* gw, float* gb, double* scratch, float* sums, int B,
                         int C, int HW, int act, void* stream);

@@ -394,13 +394,19 @@ __device__ __forceinline__ size_t bnf_off(int i, int hwv, int C, int c) {
   return ((size_t)b * C + c) * hwv + j;
 }
 
-template <int NV>
+// POOL: also pooled[b][c] = mean over the plane of y[b][c] -- the average pool of the squeeze-excitation block behind a
+// depthwise convolution's normalisation (torchvision SqueezeExcitation._scale: `self.avgpool(input)`), whose own launch
+// (ias_se_plane_reduce, ~5 us of latency, nine per pretraining step) re-read the map this workgroup holds in registers: a
+// thread leaves the sum of each of its vectors in LDS, thread b adds the hwv sums of plane b in order (fixed order).
+template <int NV, bool POOL>
 __global__ __launch_bounds__(BNF_THREADS) void bn_fused_forward_kernel(
     const float4* __restrict__ x, const float* __restrict__ weight, const float* __restrict__ bias,
     float* __restrict__ running_mean, float* __restrict__ running_var, float4* __restrict__ y, float* __restrict__ save_mean,
     float* __restrict__ save_invstd, int B, int C, int hwv, float eps, float momentum, int act,
-    const float4* __restrict__ res /* or null: y = act(bn(x)) + res (the block's residual connection) */) {
+    const float4* __restrict__ res /* or null: y = act(bn(x)) + res (the block's residual connection) */,
+    float* __restrict__ pooled /* POOL: [B][C] */) {
   __shared__ double s_red[BNF_THREADS / 64][2];
+  __shared__ float s_pool[POOL ? NV * BNF_THREADS : 1];
   const int c = blockIdx.x, tid = threadIdx.x, nvec = B * hwv;
   const float k = reinterpret_cast<const float*>(x)[(size_t)c * hwv * 4];
   float4 v[NV];
@@ -437,6 +443,16 @@ __global__ __launch_bounds__(BNF_THREADS) void bn_fused_forward_kernel(
       o.z = bn_act(fmaf(w, (v[e].z - mean) * invstd, bb), act); o.w = bn_act(fmaf(w, (v[e].w - mean) * invstd, bb), act);
       if (res != nullptr) { const float4 r = res[bnf_off(i, hwv, C, c)]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
       y[bnf_off(i, hwv, C, c)] = o;
+      if (POOL) s_pool[i] = (o.x + o.y) + (o.z + o.w);
+    }
+  }
+  if (POOL) {
+    __syncthreads();
+    const float inv_hw = 1.0f / (float)(4 * hwv);
+    for (int b = tid; b < B; b += BNF_THREADS) {
+      float t = 0.0f;
+      for (int j = 0; j < hwv; ++j) t += s_pool[b * hwv + j];
+      pooled[(size_t)b * C + c] = t * inv_hw;
     }
   }
 }
@@ -566,7 +582,7 @@ static void bn_launch_finapply(hipStream_t stream, const float* x, const float* 
 // or NULL (updated in place with `momentum`); save_mean / save_invstd [C] out; act 0 none, 1 ReLU, 2 Hardswish.
 static int bn_act_forward_impl(const float* x, const float* res, const float* weight, const float* bias, float* running_mean,
                                float* running_var, float* y, float* save_mean, float* save_invstd, double* scratch, int B, int C,
-                               int HW, float eps, float momentum, int act, void* stream_);
+                               int HW, float eps, float momentum, int act, void* stream_, float* pooled = nullptr);
 extern "C" int ias_bn_act_forward(const float* x, const float* weight, const float* bias, float* running_mean,
                                   float* running_var, float* y, float* save_mean, float* save_invstd, double* scratch,
                                   int B, int C, int HW, float eps, float momentum, int act, void* stream_) {
@@ -584,21 +600,21 @@ extern "C" int ias_bn_act_forward_res(const float* x, const float* res, const fl
   return bn_act_forward_impl(x, res, weight, bias, running_mean, running_var, y, save_mean, save_invstd, scratch, B, C, HW, eps,
                              momentum, act, stream_);
 }
+extern "C" int ias_se_plane_reduce(const float* x, const float* m, float* out, long long planes, int HW, float scale, void* stream_);   // se_kernels.hip
 static int bn_act_forward_impl(const float* x, const float* res, const float* weight, const float* bias, float* running_mean,
                                float* running_var, float* y, float* save_mean, float* save_invstd, double* scratch, int B, int C,
-                               int HW, float eps, float momentum, int act, void* stream_) {
+                               int HW, float eps, float momentum, int act, void* stream_, float* pooled) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !y || !save_mean || !save_invstd || !scratch || B <= 0 || C <= 0 || C > 65535 || HW <= 0 || act < 0 || act > 2)
     return IAS_ERR_ARG;
   if (const int nv = bn_fused_nv(x, y, res, B, C, HW)) {
-    if (nv == 2)
-      hipLaunchKernelGGL((bn_fused_forward_kernel<2>), dim3(C), dim3(BNF_THREADS), 0, stream, (const float4*)x, weight, bias,
-                         running_mean, running_var, (float4*)y, save_mean, save_invstd, B, C, HW >> 2, eps, momentum, act,
-                         (const float4*)res);
-    else
-      hipLaunchKernelGGL((bn_fused_forward_kernel<8>), dim3(C), dim3(BNF_THREADS), 0, stream, (const float4*)x, weight, bias,
-                         running_mean, running_var, (float4*)y, save_mean, save_invstd, B, C, HW >> 2, eps, momentum, act,
-                         (const float4*)res);
+#define BNF_FWD(NV, POOL)                                                                                                   \
+  hipLaunchKernelGGL((bn_fused_forward_kernel<NV, POOL>), dim3(C), dim3(BNF_THREADS), 0, stream, (const float4*)x, weight, bias, \
+                     running_mean, running_var, (float4*)y, save_mean, save_invstd, B, C, HW >> 2, eps, momentum, act,       \
+                     (const float4*)res, pooled)
+    if (nv == 2) { if (pooled) BNF_FWD(2, true); else BNF_FWD(2, false); }
+    else { if (pooled) BNF_FWD(8, true); else BNF_FWD(8, false); }
+#undef BNF_FWD
     return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
   }
   const int S = bn_split(B, C);
@@ -608,12 +624,24 @@ static int bn_act_forward_impl(const float* x, const float* res, const float* we
   if (bn_finapply_takes(B, C, HW)) {
     bn_launch_finapply<0>(stream, x, res, scratch, save_mean, save_invstd, running_mean, running_var, weight, bias, nullptr,
                           nullptr, y, B, C, HW, S, eps, momentum, act);
-    return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+  } else {
+    hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + BN_FIN_WAVES - 1) / BN_FIN_WAVES), dim3(64 * BN_FIN_WAVES), 0, stream, x, scratch, save_mean, save_invstd,
+                       running_mean, running_var, C, S, HW, (double)B * HW, eps, momentum);
+    bn_launch_apply<0>(stream, x, res, save_mean, save_invstd, weight, bias, nullptr, y, B, C, HW, act);
   }
-  hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3((C + BN_FIN_WAVES - 1) / BN_FIN_WAVES), dim3(64 * BN_FIN_WAVES), 0, stream, x, scratch, save_mean, save_invstd,
-                     running_mean, running_var, C, S, HW, (double)B * HW, eps, momentum);
-  bn_launch_apply<0>(stream, x, res, save_mean, save_invstd, weight, bias, nullptr, y, B, C, HW, act);
-  return hipGetLastError() == hipSuccess ? IAS_OK : IAS_ERR_LAUNCH;
+  if (hipGetLastError() != hipSuccess) return IAS_ERR_LAUNCH;
+  // (maps too large for the one-workgroup-per-channel kernel: the pool as its own pass)
+  if (pooled) return ias_se_plane_reduce(y, nullptr, pooled, (long long)B * C, HW, 1.0f / (float)HW, stream_);
+  return IAS_OK;
+}
+// ias_bn_act_forward that also leaves pooled[b][c] = mean_hw y[b][c] behind ([B,C]): the squeeze-excitation block's average
+// pool, taken by the normalisation's own launch on maps up to 15 x 16
+extern "C" int ias_bn_act_forward_pool(const float* x, const float* weight, const float* bias, float* running_mean,
+                                       float* running_var, float* y, float* pooled, float* save_mean, float* save_invstd,
+                                       double* scratch, int B, int C, int HW, float eps, float momentum, int act, void* stream_) {
+  if (!pooled) return IAS_ERR_ARG;
+  return bn_act_forward_impl(x, nullptr, weight, bias, running_mean, running_var, y, save_mean, save_invstd, scratch, B, C, HW,
+                             eps, momentum, act, stream_, pooled);
 }
 
 // Backward of ias_bn_act_forward: dy [B,C,HW] -> dx [B,C,HW], gw / gb [C] (either may be NULL); sums [C][2] floats scratch.

@@ -271,7 +271,7 @@ class _BNActFn(torch.autograd.Function):
     """Training-mode batch norm + activation as the HIP kernels of csrc/bn_kernels.hip (ias_bn_act_forward / _backward)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act, res=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, act, res=None, pool=False):
         from . import _lib
         lib = _lib.load()
         x = x.contiguous()
@@ -281,7 +281,17 @@ class _BNActFn(torch.autograd.Function):
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty_like(mean)
         scratch = torch.empty(int(lib.ias_bn_scratch_doubles(B, C)), dtype=torch.float64, device=x.device)
-        if res is not None:
+        pooled = None
+        if pool:
+            # (y, pooled): the following squeeze-excitation block's average pool from the same launch.  pooled is NOT a
+            # differentiable output: the block's backward (_SEFn / _SEProjFn) carries the pool's gradient itself
+            assert res is None
+            pooled = torch.empty((B, C), dtype=torch.float32, device=x.device)
+            _lib.check(lib.ias_bn_act_forward_pool(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(running_mean),
+                                                   _lib.ptr(running_var), _lib.ptr(y), _lib.ptr(pooled), _lib.ptr(mean),
+                                                   _lib.ptr(invstd), _lib.ptr(scratch), B, C, HW, float(eps), float(momentum),
+                                                   int(act), _lib.stream()), "ias_bn_act_forward_pool")
+        elif res is not None:
             # the block's residual connection in the same pass: y = act(bn(x)) + res
             res = res.contiguous()
             assert res.shape == x.shape
@@ -297,10 +307,17 @@ class _BNActFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight, bias, mean, invstd)
         ctx.act = int(act)
         ctx.has_res = res is not None
+        if pool:
+            # (no zero cotangent for the pool: autograd would fill one per backward pass, a launch per block)
+            ctx.mark_non_differentiable(pooled)
+            ctx.set_materialize_grads(False)
+            return y, pooled
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g_pooled=None):
+        if g is None:
+            return (None,) * 10
         from . import _lib
         lib = _lib.load()
         x, weight, bias, mean, invstd = ctx.saved_tensors
@@ -315,7 +332,7 @@ class _BNActFn(torch.autograd.Function):
         _lib.check(lib.ias_bn_act_backward(_lib.ptr(x), _lib.ptr(g), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(mean),
                                            _lib.ptr(invstd), _lib.ptr(dx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(scratch),
                                            _lib.ptr(sums), B, C, HW, ctx.act, _lib.stream()), "ias_bn_act_backward")
-        return dx, gw, gb, None, None, None, None, None, (g if ctx.has_res else None)
+        return dx, gw, gb, None, None, None, None, None, (g if ctx.has_res else None), None
 
 
 _ACT_CODE = {None: 0, nn.ReLU: 1, nn.Hardswish: 2}
@@ -331,14 +348,22 @@ class BatchNormAct2d(nn.BatchNorm2d):
         assert act in _ACT_CODE
         self.act_code = _ACT_CODE[act]
 
-    def forward(self, x, residual=None):
-        """``residual`` (InvertedResidual's skip connection): returns act(bn(x)) + residual, on the HIP path in one pass."""
+    def forward(self, x, residual=None, pool=False):
+        """``residual`` (InvertedResidual's skip connection): returns act(bn(x)) + residual, on the HIP path in one pass.
+        ``pool=True``: returns (y, pooled) with pooled = y.mean((2, 3)) [B,C], detached -- the average pool of the
+        squeeze-excitation block behind this layer, on the HIP path from the same launch (hand it to that block; its
+        backward carries the pool's gradient)."""
+        if pool:
+            assert residual is None
         if self.training and x.is_cuda and not trunk_torch() and x.dtype == torch.float32 and x.dim() == 4 and self.track_running_stats and \
                 self.momentum is not None and self.affine:
             if self.num_batches_tracked is not None and not getattr(self, "counter_deferred", False):
                 self.num_batches_tracked.add_(1)     # (deferred: one multi-tensor add for all layers, see defer_bn_counters)
             return _BNActFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
-                                  self.momentum, self.act_code, residual)
+                                  self.momentum, self.act_code, residual, pool)
+        if pool:
+            y = self.forward(x)
+            return y, y.detach().mean((2, 3))
         if residual is not None:
             return residual + self.forward(x)
         y = super().forward(x)
@@ -395,7 +420,7 @@ class _SEFn(torch.autograd.Function):
     [B, C] with their backward (one workgroup per sample; parameter gradients as small tiled products over the batch)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, pooled=None):
         from . import _lib
         lib = _lib.load()
         x = x.contiguous()
@@ -404,9 +429,10 @@ class _SEFn(torch.autograd.Function):
         hw = H * W
         Cs = w1.shape[0]
         w1, w2 = w1.contiguous(), w2.contiguous()
-        pooled = torch.empty((B, C), dtype=torch.float32, device=x.device)
-        _lib.check(lib.ias_se_plane_reduce(_lib.ptr(x), None, _lib.ptr(pooled), B * C, hw, 1.0 / hw, _lib.stream()),
-                   "ias_se_plane_reduce")
+        if pooled is None:          # (else: x.mean((2, 3)) as the layer in front left it behind, BatchNormAct2d.forward(pool=True))
+            pooled = torch.empty((B, C), dtype=torch.float32, device=x.device)
+            _lib.check(lib.ias_se_plane_reduce(_lib.ptr(x), None, _lib.ptr(pooled), B * C, hw, 1.0 / hw, _lib.stream()),
+                       "ias_se_plane_reduce")
         h = torch.empty((B, Cs), dtype=torch.float32, device=x.device)
         z, s = torch.empty_like(pooled), torch.empty_like(pooled)
         _lib.check(lib.ias_se_mlp_forward(_lib.ptr(pooled), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(h),
@@ -439,7 +465,7 @@ class _SEFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         _lib.check(lib.ias_se_scale(_lib.ptr(gy), _lib.ptr(s), _lib.ptr(gp), _lib.ptr(gx), B * C, hw, 1.0 / hw, _lib.stream()),
                    "ias_se_scale")
-        return gx, gw1, gb1, gw2, gb2
+        return gx, gw1, gb1, gw2, gb2, None
 
 
 class _SEProjFn(torch.autograd.Function):
@@ -450,7 +476,7 @@ class _SEProjFn(torch.autograd.Function):
     (ias_pwconv_backward_weight*_scaled).  Same values as SqueezeExcitation followed by PointwiseConv2d."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w):
+    def forward(ctx, x, w1, b1, w2, b2, w, pooled=None):
         from . import _lib
         lib = _lib.load()
         x, w = x.contiguous(), w.contiguous()
@@ -459,9 +485,10 @@ class _SEProjFn(torch.autograd.Function):
         hw = H * W
         Cs, Cout = w1.shape[0], w.shape[0]
         w1, w2 = w1.contiguous(), w2.contiguous()
-        pooled = torch.empty((B, C), dtype=torch.float32, device=x.device)
-        _lib.check(lib.ias_se_plane_reduce(_lib.ptr(x), None, _lib.ptr(pooled), B * C, hw, 1.0 / hw, _lib.stream()),
-                   "ias_se_plane_reduce")
+        if pooled is None:          # (else: as the layer in front left it behind, BatchNormAct2d.forward(pool=True))
+            pooled = torch.empty((B, C), dtype=torch.float32, device=x.device)
+            _lib.check(lib.ias_se_plane_reduce(_lib.ptr(x), None, _lib.ptr(pooled), B * C, hw, 1.0 / hw, _lib.stream()),
+                       "ias_se_plane_reduce")
         h = torch.empty((B, Cs), dtype=torch.float32, device=x.device)
         z, s = torch.empty_like(pooled), torch.empty_like(pooled)
         _lib.check(lib.ias_se_mlp_forward(_lib.ptr(pooled), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(h),
@@ -513,20 +540,22 @@ class _SEProjFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         _lib.check(lib.ias_se_scale(_lib.ptr(gy), _lib.ptr(s), _lib.ptr(gp), _lib.ptr(gx), B * C, hw, 1.0 / hw, _lib.stream()),
                    "ias_se_scale")
-        return gx, gw1, gb1, gw2, gb2, gw
+        return gx, gw1, gb1, gw2, gb2, gw, None
 
 
 FUSE_SE_PROJECTION = True      # (tests / scripts/diag A/B runs: False keeps SqueezeExcitation and its projection apart)
+SE_POOL_FROM_NORM = True       # (the same: False lets the gate pool its input itself)
 
 
-def se_projection(se, conv, x):
+def se_projection(se, conv, x, pooled=None):
     """``conv(se(x))`` for a SqueezeExcitation ``se`` and the 1x1 projection ``conv`` behind it; one fused node
-    (_SEProjFn) where the projection is a shape of csrc/pointwise_kernels.hip, the two modules otherwise."""
+    (_SEProjFn) where the projection is a shape of csrc/pointwise_kernels.hip, the two modules otherwise.  ``pooled``:
+    ``x.mean((2, 3))`` where the layer in front has left it behind (BatchNormAct2d.forward(pool=True)), or None."""
     if FUSE_SE_PROJECTION and x.is_cuda and not trunk_torch() and x.dtype == torch.float32 and x.dim() == 4 and isinstance(conv, PointwiseConv2d) and \
             conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None and \
             _pw_mfma(x.shape[1], conv.out_channels):
-        return _SEProjFn.apply(x, se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias, conv.weight)
-    return conv(se(x))
+        return _SEProjFn.apply(x, se.fc1.weight, se.fc1.bias, se.fc2.weight, se.fc2.bias, conv.weight, pooled)
+    return conv(se(x, pooled))
 
 
 class SqueezeExcitation(nn.Module):
@@ -538,9 +567,11 @@ class SqueezeExcitation(nn.Module):
         self.activation = nn.ReLU()
         self.scale_activation = nn.Hardsigmoid()
 
-    def forward(self, x):
+    def forward(self, x, pooled=None):
+        """``pooled``: ``x.mean((2, 3))`` [B,C] where the layer in front has left it behind (a hint for the HIP path: the
+        gradient of the pool is taken through ``x`` either way), or None."""
         if x.is_cuda and not trunk_torch() and x.dtype == torch.float32 and x.dim() == 4:
-            return _SEFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+            return _SEFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, pooled)
         s = self.scale_activation(self.fc2(self.activation(self.fc1(self.avgpool(x)))))
         return s * x
 
@@ -564,13 +595,18 @@ class InvertedResidual(nn.Module):
         # and its normalisation adds the skip connection (one pass: BatchNormAct2d.forward(residual=...))
         layers = list(self.block)
         conv, norm = layers[-1][0], layers[-1][1]
-        h = x
-        for layer in layers[:-1]:
-            if isinstance(layer, SqueezeExcitation):
-                break
-            h = layer(h)
-        if isinstance(layers[-2], SqueezeExcitation):
-            h = se_projection(layers[-2], conv, h)
+        has_se = isinstance(layers[-2], SqueezeExcitation)
+        body = layers[:-2] if has_se else layers[:-1]
+        h, pooled = x, None
+        for i, layer in enumerate(body):
+            if has_se and SE_POOL_FROM_NORM and i == len(body) - 1 and isinstance(layer, ConvBNAct) and isinstance(layer[1], BatchNormAct2d):
+                # the depthwise layer in front of the squeeze-excitation block: its normalisation leaves the block's
+                # average pool behind (same launch on the small maps)
+                h, pooled = layer[1](layer[0](h), pool=True)
+            else:
+                h = layer(h)
+        if has_se:
+            h = se_projection(layers[-2], conv, h, pooled)
         else:
             h = conv(h)
         return norm(h, residual=x) if self.use_res else norm(h)

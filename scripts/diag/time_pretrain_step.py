@@ -1,6 +1,7 @@
 """One VICReg pretraining step (BASELINE config #3: B=128, 4 s @ 44.1 kHz, dim 1024, embeddim 8192) -- wall time per step,
 eager (default) or as the Trainer's captured hipGraph (GRAPH=1); DEFER=0: without the joint weight-gradient reduction;
-SEPROJ=0: without the squeeze-excitation gate taken by the projection on load."""
+SEPROJ=0: without the squeeze-excitation gate taken by the projection on load; SEPOOL=0: without the gate's pool taken by the
+normalisation in front of it."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -22,6 +23,9 @@ if os.environ.get("DEFER") == "0":      # the trunk's weight-gradient reductions
 if os.environ.get("SEPROJ") == "0":     # SqueezeExcitation and its projection as two nodes (the gate's own pass over the map)
     from inverse_audio_synthesis_amd import vision
     vision.FUSE_SE_PROJECTION = False
+if os.environ.get("SEPOOL") == "0":     # the squeeze-excitation gate pools its input itself (no pool from the normalisation in front)
+    from inverse_audio_synthesis_amd import vision
+    vision.SE_POOL_FROM_NORM = False
 model.train()
 opt = tr.optimizer
 def step(i):

@@ -278,6 +278,61 @@ def test_pointwise_conv_matches_torch(lib, dev, B, Cin, Cout, H, W):
         assert torch.equal(gw, gw2)
 
 
+@pytest.mark.parametrize("shape", [(128, 240, 15, 16), (128, 96, 8, 8), (100, 40, 15, 16), (16, 576, 8, 8), (4, 16, 60, 62),
+                                   (3, 24, 30, 31)])
+@pytest.mark.parametrize("act", [None, torch.nn.Hardswish])
+def test_batchnorm_leaves_the_squeeze_excitation_pool_behind(lib, dev, shape, act):
+    """BatchNormAct2d.forward(x, pool=True) (ias_bn_act_forward_pool: the following squeeze-excitation block's average pool
+    from the normalisation's own launch on maps up to 15 x 16, ias_se_plane_reduce behind it on larger ones): the same y
+    and the same gradients as the plain forward, pooled = y.mean((2, 3)), not differentiable; and an inverted-residual
+    block that hands the pool on against the same block with the pool computed by the gate itself."""
+    from inverse_audio_synthesis_amd.vision import BatchNormAct2d
+    import copy
+    torch.manual_seed(6)
+    a = BatchNormAct2d(shape[1], eps=0.001, momentum=0.01, act=act).to(dev).train()
+    with torch.no_grad():
+        a.weight.copy_(1.0 + 0.2 * torch.randn(shape[1])); a.bias.copy_(0.1 * torch.randn(shape[1]))
+    b = copy.deepcopy(a)
+    x1 = randn(shape, 51).to(dev).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    y1, pooled = a(x1, pool=True)
+    y2 = b(x2)
+    assert torch.equal(y1, y2)
+    assert not pooled.requires_grad and pooled.shape == shape[:2]
+    ref = y2.detach().double().mean((2, 3))
+    assert (pooled.double() - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item())
+    g = randn(shape, 52).to(dev)
+    got = torch.autograd.grad(y1, [x1, a.weight, a.bias], g)
+    want = torch.autograd.grad(y2, [x2, b.weight, b.bias], g)
+    for u, v in zip(got, want):
+        assert torch.equal(u, v)
+    assert torch.equal(a.running_mean, b.running_mean) and torch.equal(a.running_var, b.running_var)
+
+
+def test_inverted_residual_hands_the_pool_to_its_gate(lib, dev):
+    """vision.InvertedResidual with a squeeze-excitation block: the depthwise normalisation's pool reaches the gate
+    (BatchNormAct2d.forward(pool=True) -> se_projection(..., pooled)) -- against the block's layers applied one by one
+    (the gate pooling its input itself): output and every gradient to 1e-5 of the largest element."""
+    from inverse_audio_synthesis_amd import vision
+    import copy
+    torch.manual_seed(7)
+    blk = vision.InvertedResidual(40, 5, 240, 40, True, True, 1).to(dev).train()
+    ref = copy.deepcopy(blk)
+    x1 = randn((9, 40, 15, 16), 61).to(dev).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    g = randn((9, 40, 15, 16), 62).to(dev)
+    y1 = blk(x1)
+    h = x2
+    for layer in ref.block:
+        h = layer(h)
+    y2 = h + x2
+    assert (y1 - y2).abs().max().item() <= 1e-5 * max(1.0, y2.abs().max().item())
+    got = torch.autograd.grad(y1, [x1] + list(blk.parameters()), g)
+    want = torch.autograd.grad(y2, [x2] + list(ref.parameters()), g)
+    for (n, _), u, v in zip([("x", None)] + list(blk.named_parameters()), got, want):
+        assert (u - v).abs().max().item() <= 1e-4 * max(1e-3, v.abs().max().item()), n
+
+
 @pytest.mark.parametrize("B,C,Cs,Cout,H,W", [(3, 16, 8, 16, 60, 62), (4, 96, 24, 40, 15, 16), (5, 240, 64, 40, 15, 16),
                                              (3, 120, 32, 48, 15, 16), (130, 144, 40, 48, 15, 16), (3, 24, 8, 8, 5, 7),
                                              (2, 288, 72, 96, 8, 8)])      # the last: the projection's batched-GEMM form
