@@ -47,15 +47,40 @@ def step_part(h):
 # one graph per part (STEPS steps of that part, captured exactly like bench.py's gradient step), the parts' graphs replayed
 # side by side on streams of their own: one graph over forked streams crashed hipStreamEndCapture (two tries, not pursued)
 graphs = []
-for h in range(H):
+if os.environ.get("MODE", "multi") == "one":
+    # ONE graph, the parts as branches forked from the capturing stream (crashes hipStreamEndCapture with the shipped
+    # BackwardPrelude; IAS_VOICE_PRELUDE=0 to try without its shared side stream)
+    dummy = torch.zeros(64, device=dev)
+
+    def step_all():
+        cur = torch.cuda.current_stream(dev)
+        dummy.zero_()
+        for h in range(H):
+            streams[h].wait_stream(cur)
+            with torch.cuda.stream(streams[h]):
+                step_part(h)
+        for h in range(H):
+            cur.wait_stream(streams[h])
+
     for _ in range(3):
-        step_part(h)
+        step_all()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for _ in range(STEPS):
-            step_part(h)
+            step_all()
     graphs.append(g)
+    streams = [torch.cuda.current_stream(dev)]
+else:
+    for h in range(H):
+        for _ in range(3):
+            step_part(h)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(STEPS):
+                step_part(h)
+        graphs.append(g)
 torch.cuda.synchronize()
 
 
